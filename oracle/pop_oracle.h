@@ -1,0 +1,94 @@
+/*
+ * pop_oracle.h -- CPU restatement of the POP2 per-timestep dynamics hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and there only as the checker / reported CPU baseline.
+ *
+ * It follows the reference (ESCOMP/POP2-CESM, read-only under /root/reference)
+ * statement for statement, in the reference's own (i,j,k,block) i-fastest
+ * layout and 1-based index conventions; every function cites the file:line it
+ * restates.  The reference itself cannot be compiled here, so
+ * this restatement is pinned by the reference's own fixtures only:
+ *   - MWJF known answer rho(S=35,theta=20,p=200bar)=1.033213242
+ *     (source/state_mod.F90:413-414)
+ *   - the constructive halo rule of test/unit/halo/POP.F90Dipole:134-147
+ *   - the serial-sum rule of test/unit/reduction/POP.F90
+ * For advection / hmix / vmix / solvers the reference holds no fixtures:
+ * parity for those is "unpinned by reference tests" (see DESIGN.md).
+ */
+#ifndef POP_ORACLE_H
+#define POP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same field order as include/pop_amd.h's pop_config so one ctypes
+ * Structure serves both libraries (declared separately on purpose). */
+typedef struct {
+  int nx_global, ny_global, km, nt;
+  int block_size_x, block_size_y;
+  int ew_boundary;            /* 0 closed, 1 cyclic */
+  int ns_boundary;            /* 0 closed, 1 cyclic */
+  int hmix_momentum;          /* 2 del2, 4 del4 */
+  int hmix_tracer;            /* 2 del2, 4 del4 */
+  int lvariable_hmix;         /* variable hmix coefficients */
+  int vmix_choice;            /* 1 const, 2 rich, 3 kpp */
+  int tadvect;                /* 1 centered, 2 upwind3 */
+  int solver_choice;          /* 1 pcg, 2 ChronGear */
+  int max_iterations;
+  int convergence_check_freq;
+  int tmix_opt;               /* 0 none, 1 avg, 2 avgfit */
+  int time_mix_freq;
+  int steps_per_day;
+  int lbouss_correct, lpressure_avg, impcor, reset_to_freezing;
+  int lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri; /* kpp */
+  int reserved_i[8];
+  double am, ah;              /* del2 or del4 coefficients */
+  double const_vvc, const_vdc;
+  double convect_diff, convect_visc, bottom_drag, aidif;
+  double rich_bckgrnd_vvc, rich_bckgrnd_vdc, rich_mix;
+  double bckgrnd_vdc1, bckgrnd_vdc2, bckgrnd_vdc_dpth, bckgrnd_vdc_linv;
+  double Prandtl, kpp_rich_mix;
+  double convergence_criterion;
+  double reserved_d[8];
+} orc_config;
+
+typedef struct orc_model orc_model;
+
+orc_model *orc_create(const orc_config *cfg);
+void       orc_destroy(orc_model *m);
+
+/* array access by the reference's variable name; tl = 0 old,1 cur,2 new
+ * (logical time level, resolved through the rotating indices); n = tracer.
+ * Returns pointer to the (nx_block,ny_block[,km],nblocks) array, or NULL. */
+double *orc_field(orc_model *m, const char *name, int tl, int n);
+int    *orc_ifield(orc_model *m, const char *name);
+double *orc_vfield(orc_model *m, const char *name);  /* vertical 1-D arrays */
+int     orc_dim(orc_model *m, const char *name);
+double  orc_scalar(orc_model *m, const char *name);
+
+/* the step_mod.F90 call sequence, one entry per reference routine */
+void orc_time_manager(orc_model *m);      /* set step flags for next step */
+void orc_dhdt(orc_model *m);
+int  orc_baroclinic_driver(orc_model *m);
+int  orc_barotropic_driver(orc_model *m);
+void orc_baroclinic_correct_adjust(orc_model *m);
+void orc_step_tail(orc_model *m);
+int  orc_step(orc_model *m);              /* all of the above */
+
+/* pieces exposed for unit parity */
+void   orc_state(orc_model *m, int k, int kk, const double *T, const double *S,
+                 double *rho, double *drhodt, double *drhods, int npts);
+double orc_state_point(double T, double S_msu, double p_bar);
+void   orc_halo_update(orc_model *m, double *a, int nz, int fieldloc_unused);
+void   orc_halo_update_int(orc_model *m, int *a);
+double orc_global_sum(orc_model *m, const double *a, const double *mask);
+int    orc_solver_iterations(orc_model *m);
+double orc_solver_rms(orc_model *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

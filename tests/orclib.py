@@ -1,0 +1,110 @@
+"""ctypes binding of oracle/libpop_oracle.so (TEST INFRASTRUCTURE: the checker)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+from popcfg import PopConfig
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "libpop_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
+
+
+def load():
+    if not os.path.exists(_SO):
+        build()
+    L = C.CDLL(_SO)
+    L.orc_create.restype = C.c_void_p
+    L.orc_create.argtypes = [C.POINTER(PopConfig)]
+    L.orc_destroy.argtypes = [C.c_void_p]
+    L.orc_field.restype = C.POINTER(C.c_double)
+    L.orc_field.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    L.orc_ifield.restype = C.POINTER(C.c_int)
+    L.orc_ifield.argtypes = [C.c_void_p, C.c_char_p]
+    L.orc_vfield.restype = C.POINTER(C.c_double)
+    L.orc_vfield.argtypes = [C.c_void_p, C.c_char_p]
+    L.orc_dim.argtypes = [C.c_void_p, C.c_char_p]
+    L.orc_scalar.restype = C.c_double
+    L.orc_scalar.argtypes = [C.c_void_p, C.c_char_p]
+    for f in ("orc_time_manager", "orc_dhdt", "orc_baroclinic_correct_adjust", "orc_step_tail"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = None
+    for f in ("orc_baroclinic_driver", "orc_barotropic_driver", "orc_step", "orc_solver_iterations"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = C.c_int
+    L.orc_solver_rms.argtypes = [C.c_void_p]
+    L.orc_solver_rms.restype = C.c_double
+    L.orc_state_point.restype = C.c_double
+    L.orc_state_point.argtypes = [C.c_double] * 3
+    L.orc_halo_update.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]
+    L.orc_halo_update_int.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.orc_global_sum.restype = C.c_double
+    L.orc_global_sum.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    return L
+
+
+class Oracle:
+    """Thin object wrapper; arrays come back as numpy views in Fortran index order
+    reversed, i.e. shape (nblocks, [km,] ny_block, nx_block)."""
+
+    def __init__(self, cfg):
+        self.L = load()
+        self.cfg = cfg
+        self.h = self.L.orc_create(C.byref(cfg))
+        if not self.h:
+            raise RuntimeError("orc_create failed")
+        d = lambda n: self.L.orc_dim(self.h, n.encode())
+        self.nxb, self.nyb, self.km, self.nt, self.nblocks = (d("nx_block"), d("ny_block"), d("km"),
+                                                              d("nt"), d("nblocks"))
+
+    def close(self):
+        if self.h:
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def dim(self, n):
+        return self.L.orc_dim(self.h, n.encode())
+
+    def scalar(self, n):
+        return self.L.orc_scalar(self.h, n.encode())
+
+    def f2(self, name, tl=1, n=0):
+        p = self.L.orc_field(self.h, name.encode(), tl, n)
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(self.nblocks, self.nyb, self.nxb))
+
+    def f3(self, name, tl=1, n=0):
+        p = self.L.orc_field(self.h, name.encode(), tl, n)
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(self.nblocks, self.km, self.nyb, self.nxb))
+
+    def vdc(self, n=0):
+        p = self.L.orc_field(self.h, b"VDC", 0, n)
+        return np.ctypeslib.as_array(p, shape=(self.nblocks, self.km + 2, self.nyb, self.nxb))
+
+    def i2(self, name):
+        p = self.L.orc_ifield(self.h, name.encode())
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(self.nblocks, self.nyb, self.nxb))
+
+    def ivec(self, name, n):
+        p = self.L.orc_ifield(self.h, name.encode())
+        return np.ctypeslib.as_array(p, shape=(n,))
+
+    def v1(self, name):
+        p = self.L.orc_vfield(self.h, name.encode())
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(self.km + 3,))
+
+    def step(self):
+        e = self.L.orc_step(self.h)
+        if e:
+            raise RuntimeError("oracle solver did not converge")
+        return self.L.orc_solver_iterations(self.h)

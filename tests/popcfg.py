@@ -1,0 +1,85 @@
+"""Shared ctypes mirror of pop_config / orc_config and the named BASELINE configs.
+
+Used by tests/, bench.py and __graft_entry__.py.  The struct layout is the
+one declared (separately) in include/pop_amd.h and oracle/pop_oracle.h.
+"""
+import ctypes as C
+
+
+class PopConfig(C.Structure):
+    _fields_ = [
+        ("nx_global", C.c_int), ("ny_global", C.c_int), ("km", C.c_int), ("nt", C.c_int),
+        ("block_size_x", C.c_int), ("block_size_y", C.c_int),
+        ("ew_boundary", C.c_int), ("ns_boundary", C.c_int),
+        ("hmix_momentum", C.c_int), ("hmix_tracer", C.c_int), ("lvariable_hmix", C.c_int),
+        ("vmix_choice", C.c_int), ("tadvect", C.c_int), ("solver_choice", C.c_int),
+        ("max_iterations", C.c_int), ("convergence_check_freq", C.c_int),
+        ("tmix_opt", C.c_int), ("time_mix_freq", C.c_int), ("steps_per_day", C.c_int),
+        ("lbouss_correct", C.c_int), ("lpressure_avg", C.c_int), ("impcor", C.c_int),
+        ("reset_to_freezing", C.c_int),
+        ("lrich", C.c_int), ("ldbl_diff", C.c_int), ("lshort_wave", C.c_int), ("lcheckekmo", C.c_int),
+        ("num_v_smooth_Ri", C.c_int),
+        ("reserved_i", C.c_int * 8),
+        ("am", C.c_double), ("ah", C.c_double),
+        ("const_vvc", C.c_double), ("const_vdc", C.c_double),
+        ("convect_diff", C.c_double), ("convect_visc", C.c_double), ("bottom_drag", C.c_double),
+        ("aidif", C.c_double),
+        ("rich_bckgrnd_vvc", C.c_double), ("rich_bckgrnd_vdc", C.c_double), ("rich_mix", C.c_double),
+        ("bckgrnd_vdc1", C.c_double), ("bckgrnd_vdc2", C.c_double), ("bckgrnd_vdc_dpth", C.c_double),
+        ("bckgrnd_vdc_linv", C.c_double), ("Prandtl", C.c_double), ("kpp_rich_mix", C.c_double),
+        ("convergence_criterion", C.c_double),
+        ("reserved_d", C.c_double * 8),
+    ]
+
+
+def base_config(**kw):
+    """Defaults = the reference's code defaults for the options this path supports
+    (vertical_mix.F90:233-240, POP_SolversMod.F90:578-662, pressure_grad.F90:118-119,
+    baroclinic.F90:208, vmix_rich.F90:108-110, vmix_const.F90:101-102)."""
+    c = PopConfig()
+    c.nt = 2
+    c.ew_boundary, c.ns_boundary = 1, 0
+    c.hmix_momentum = c.hmix_tracer = 2
+    c.lvariable_hmix = 0
+    c.vmix_choice, c.tadvect, c.solver_choice = 1, 1, 1
+    c.max_iterations, c.convergence_check_freq = 1000, 10
+    c.tmix_opt, c.time_mix_freq = 2, 17
+    c.lbouss_correct, c.lpressure_avg, c.impcor, c.reset_to_freezing = 0, 1, 1, 1
+    c.lrich, c.ldbl_diff, c.lshort_wave, c.lcheckekmo, c.num_v_smooth_Ri = 1, 0, 0, 0, 1
+    c.const_vvc = c.const_vdc = 0.25
+    c.convect_diff = c.convect_visc = 1000.0
+    c.bottom_drag, c.aidif = 1.0e-3, 1.0
+    c.rich_bckgrnd_vvc, c.rich_bckgrnd_vdc, c.rich_mix = 1.0, 0.1, 50.0
+    c.bckgrnd_vdc1, c.bckgrnd_vdc2, c.bckgrnd_vdc_dpth, c.bckgrnd_vdc_linv = 0.1, 0.0, 2500.0e2, 4.5e-5
+    c.Prandtl, c.kpp_rich_mix = 10.0, 50.0
+    c.convergence_criterion = 1.0e-12
+    c.reserved_d[0] = 1.0e-2          # init T perturbation amplitude
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def named_config(name, **kw):
+    """BASELINE.json configs."""
+    if name == "test":      # test_domain_size 192x128x20, 16x16 blocks, Richardson vmix
+        c = base_config(nx_global=192, ny_global=128, km=20, block_size_x=16, block_size_y=16,
+                        vmix_choice=2, steps_per_day=24, am=1.0e8, ah=1.0e7)
+    elif name == "tiny":    # small multi-block case for fast CPU parity
+        c = base_config(nx_global=48, ny_global=40, km=12, block_size_x=12, block_size_y=10,
+                        vmix_choice=1, steps_per_day=24, am=3.0e9, ah=1.0e7)
+    elif name == "gx3v7":
+        c = base_config(nx_global=100, ny_global=116, km=60, block_size_x=100, block_size_y=116,
+                        vmix_choice=1, steps_per_day=12, am=3.0e9, ah=1.0e7)
+    elif name == "gx1v7":
+        c = base_config(nx_global=320, ny_global=384, km=60, block_size_x=320, block_size_y=384,
+                        vmix_choice=3, steps_per_day=24, am=0.5e8, ah=0.6e7,
+                        convergence_criterion=1.0e-13)
+    elif name == "tx0.1v3":
+        c = base_config(nx_global=3600, ny_global=2400, km=62, block_size_x=3600, block_size_y=2400,
+                        vmix_choice=3, steps_per_day=300, hmix_momentum=4, hmix_tracer=4,
+                        lvariable_hmix=1, am=-27.0e17, ah=-3.0e17, convergence_criterion=1.0e-13)
+    else:
+        raise KeyError(name)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
