@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- POP2 dynamics hot path on N MI355X GPUs of one node (one process per GPU).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full model time step (step_mod.F90 `step`: dhdt -> baroclinic_driver ->
+barotropic_driver -> baroclinic_correct_adjust -> halo updates / time-level update) on synthetic
+bathymetry and forcing, all state resident in HBM before the timed region.  The headline value is
+simulated years per day (SYPD = 86400 / (t_step * steps_per_day * 365)); ms_per_step
+is the step wall time.  N > 1 shards the SAME global domain by blocks (strong scaling) with halo
+exchange and the solver's block-sum all-reduce on RCCL (torch.distributed backend "nccl").
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed in this process) and,
+at N = 1, `cpu_baseline` (the CPU oracle = restated reference algorithm, timed on this box's host).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+# algorithmic fp64 words per 3-D cell per launch of each phase kernel
+PHASE_WORDS = {
+    # phase: (const vmix, rich vmix, kpp)
+    "vmix": (4, 7, 9),
+    "tracer_rhs": (9, 9, 12),
+    "impvmixt": (7, 7, 8),
+    "state": (3, 3, 3),
+    "momentum_rhs": (10, 10, 10),
+    "impvmixu": (7, 7, 7),
+    "correct": (6, 6, 7),
+    "add_btrop": (4, 4, 4),
+}
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def workload_config(name, nranks):
+    from popcfg import named_config
+    cfg = named_config(name)
+    if nranks > 1:
+        # shard by j-bands: one block per rank
+        if cfg.ny_global % nranks:
+            raise SystemExit("ny_global=%d not divisible by %d ranks" % (cfg.ny_global, nranks))
+        cfg.block_size_y = cfg.ny_global // nranks
+    return cfg
+
+
+class TorchComm:
+    """RCCL transport for the library's halo messages and block-sum all-reduce.  The library packs
+    into / unpacks from torch-owned device buffers; everything runs on torch's current stream."""
+
+    def __init__(self, pkg, model, rank, nranks):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        n = int(model.L.pop_comm_buffer_doubles(model.h))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.send = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.recv = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.red = torch.zeros(max(4 * model.nblocks_tot, 8), dtype=torch.float64, device=dev)
+
+        def xchg(user, nmsg, peer, soff, scnt, roff, rcnt):
+            try:
+                ops = []
+                for i in range(nmsg):
+                    if rcnt[i]:
+                        ops.append(dist.P2POp(dist.irecv, self.recv[roff[i]:roff[i] + rcnt[i]], peer[i]))
+                    if scnt[i]:
+                        ops.append(dist.P2POp(dist.isend, self.send[soff[i]:soff[i] + scnt[i]], peer[i]))
+                if ops:
+                    for r in dist.batch_isend_irecv(ops):
+                        r.wait()
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("exchange failed:", e, file=sys.stderr)
+                return 1
+
+        def allred(user, off, cnt):
+            try:
+                dist.all_reduce(self.red[off:off + cnt])
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("allreduce failed:", e, file=sys.stderr)
+                return 1
+
+        self._x, self._a = pkg.XCHG_FN(xchg), pkg.ALLRED_FN(allred)
+        model._chk(model.L.pop_set_stream(model.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        model._chk(model.L.pop_set_comm(model.h, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr()),
+                                        C.c_void_p(self.red.data_ptr()), n, self._x, self._a, None))
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """Time the CPU oracle (single thread) on the same workload for a bounded number of steps."""
+    from orclib import Oracle
+    o = Oracle(cfg)
+    o.step()                      # forward-Euler first step excluded (BASELINE.md procedure)
+    t0 = time.time(); n = 0
+    while True:
+        o.step(); n += 1
+        if time.time() - t0 > budget_s or n >= 10:
+            break
+    dt = (time.time() - t0) / n
+    o.close()
+    return dt, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("POP_BENCH_WORKLOAD", "gx3v7"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libpop_amd has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    cfg = workload_config(args.workload, world)
+    model = pkg.PopModel(cfg, rank=rank, nranks=world)
+    comm = TorchComm(pkg, model, rank, world) if world > 1 else None  # noqa: F841
+
+    def barrier():
+        model.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    iters = []
+    for _ in range(args.warmup):
+        model.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.step()
+        iters.append(model.solver_diagnostics()[0])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_step = 1e3 * elapsed / args.steps
+    sypd = 86400.0 / ((elapsed / args.steps) * cfg.steps_per_day * 365.0)
+
+    # ---- roofline: every 3-D phase kernel timed with HIP events on its launch stream
+    vm = cfg.vmix_choice - 1
+    ncell_local = model.nxb * model.nyb * model.km * model.nblocks
+    ncell_phys = cfg.nx_global * cfg.ny_global * cfg.km // world
+    phases = {}
+    for ph, words in PHASE_WORDS.items():
+        if ph == "impvmixt" and not cfg.lpressure_avg:
+            continue
+        try:
+            ms = model.time_phase(ph, reps=10)
+        except pkg.PopError:
+            continue
+        gb = words[vm] * 8.0 * ncell_phys / 1e9
+        phases[ph] = {"ms": round(ms, 4), "alg_GB": round(gb, 4), "GBps": round(gb / (ms * 1e-3), 1)}
+    dom = max(phases, key=lambda k: phases[k]["ms"])
+    roof = {"bound": "hbm", "kernel": dom, "achieved": phases[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(phases[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+            "alg_bytes_per_launch": phases[dom]["alg_GB"] * 1e9, "avg_launch_ms": phases[dom]["ms"], "phases": phases}
+    step_words = sum(v[vm] for k, v in PHASE_WORDS.items() if k in phases)
+    roof["step_alg_GBps"] = round(step_words * 8.0 * ncell_phys * world / 1e9 / (elapsed / args.steps), 1)
+
+    out = {
+        "metric": "simulated_years_per_day", "value": round(sypd, 3), "unit": "SYPD",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "grid": [cfg.nx_global, cfg.ny_global, cfg.km], "nt": cfg.nt,
+                   "block_size": [cfg.block_size_x, cfg.block_size_y], "steps_per_day": cfg.steps_per_day,
+                   "hmix": "del%d" % cfg.hmix_momentum, "vmix": ["const", "rich", "kpp"][vm],
+                   "solver": ["pcg", "ChronGear"][cfg.solver_choice - 1], "pcg_iters_per_step": float(np.mean(iters)),
+                   "cells_local_with_ghosts": ncell_local},
+        "roofline": roof,
+    }
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        dt, n = cpu_baseline(cfg)
+        out["cpu_baseline"] = {"value": round(86400.0 / (dt * cfg.steps_per_day * 365.0), 4), "unit": "SYPD",
+                               "ms_per_step": round(dt * 1e3, 2), "cores": 1, "kind": "port",
+                               "sample": "%d leapfrog steps of the full %s workload, single-thread C oracle "
+                                         "(restated reference algorithm, not the upstream binary)" % (n, args.workload)}
+    if rank == 0:
+        print(json.dumps(out))
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+/*
+ * pop_amd.h -- C ABI of the MI355X-native POP2 dynamics core (libpop_amd.so).
+ *
+ * This is the drop-in boundary for the reference's per-timestep hot path.
+ * The reference (ESCOMP/POP2-CESM) has no FFI: its seam is the Fortran
+ * module-procedure surface that source/step_mod.F90 calls.  Each entry point
+ * below names the reference routine it replaces (file:line under
+ * /root/reference/); pop2-cesm_amd/fortran/ holds ISO_C_BINDING modules with
+ * the reference's names and argument lists that forward here, and
+ * INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; no torch / HIP types in signatures;
+ *   - every function returns int: 0 = POP_Success, nonzero = error, message
+ *     via pop_last_error() (mirrors POP_ErrorSet/return, POP_ErrorMod.F90:82);
+ *   - one host thread per GPU/rank; all entry points are collective across
+ *     ranks (same order on every rank), like the reference's MPI tasks;
+ *   - host arrays are Fortran order (nx_block, ny_block[, km], nblocks_local),
+ *     i fastest, exactly source/prognostic.F90:47-66 per time level;
+ *   - the three time levels are rotated by index, never copied
+ *     (step_mod.F90:827-830): tl = 0 old, 1 cur, 2 new (logical).
+ */
+#ifndef POP_AMD_H
+#define POP_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Run-time configuration: the namelist subset this path reads
+ * (domain_nml, grid_nml, time_manager_nml, hmix_*_nml, vertical_mix_nml,
+ *  vmix_*_nml, advect_nml, pressure_grad_nml, baroclinic_nml, &solvers). */
+typedef struct pop_config {
+  int nx_global, ny_global, km, nt;   /* domain_size.F90 */
+  int block_size_x, block_size_y;     /* domain_size.F90 */
+  int ew_boundary;            /* 0 closed, 1 cyclic   (domain.F90 ew_boundary_type) */
+  int ns_boundary;            /* 0 closed, 1 cyclic   (tripole: not in this round) */
+  int hmix_momentum;          /* 2 del2, 4 del4       (horizontal_mix.F90:427-472) */
+  int hmix_tracer;            /* 2 del2, 4 del4 */
+  int lvariable_hmix;         /* hmix_del2.F90:223, hmix_del4.F90:200 */
+  int vmix_choice;            /* 1 const, 2 rich, 3 kpp (vertical_mix.F90:280-296) */
+  int tadvect;                /* 1 centered, 2 upwind3  (advection.F90:1667-1729) */
+  int solver_choice;          /* 1 pcg, 2 ChronGear     (POP_SolversMod.F90:442-472) */
+  int max_iterations;
+  int convergence_check_freq;
+  int tmix_opt;               /* 0 none, 1 avg, 2 avgfit (time_management.F90:2170-2213) */
+  int time_mix_freq;
+  int steps_per_day;          /* dt_option='steps_per_day', dt_count */
+  int lbouss_correct, lpressure_avg, impcor, reset_to_freezing;
+  int lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri; /* vmix_kpp_nml */
+  int reserved_i[8];
+  double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
+  double const_vvc, const_vdc;
+  double convect_diff, convect_visc, bottom_drag, aidif;
+  double rich_bckgrnd_vvc, rich_bckgrnd_vdc, rich_mix;
+  double bckgrnd_vdc1, bckgrnd_vdc2, bckgrnd_vdc_dpth, bckgrnd_vdc_linv;
+  double Prandtl, kpp_rich_mix;
+  double convergence_criterion;
+  double reserved_d[8];       /* [0] = amplitude of the synthetic initial T perturbation */
+} pop_config;
+
+typedef struct pop_ctx pop_ctx;
+
+/* flags for pop_create */
+#define POP_CREATE_HOST_ONLY 1   /* build blocks/grid/plans on the host, touch no GPU */
+
+/* ---- lifecycle (no reference counterpart: the reference's state is module
+ *      global, initial.F90:133-699 builds it) -------------------------------- */
+int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx **out);
+int pop_destroy(pop_ctx *ctx);
+const char *pop_last_error(const pop_ctx *ctx);
+
+/* ---- blocks.F90:43-63 / get_block (blocks.F90:282-320) ---------------------- */
+int pop_get_dim(const pop_ctx *ctx, const char *name);         /* nx_block, ny_block, km, nt,
+                                                                  nblocks (local), nblocks_tot,
+                                                                  nblocks_x, nblocks_y, ... */
+double pop_get_scalar(const pop_ctx *ctx, const char *name);   /* dtt, dtu, dtp, residualNorm ... */
+/* block_id is the global 1-based id; out[8] = {block_id, local_id, ib, ie, jb, je, iblock, jblock};
+ * i_glob (nx_block) / j_glob (ny_block) may be NULL */
+int pop_get_block(const pop_ctx *ctx, int block_id, int *out8, int *i_glob, int *j_glob);
+int pop_local_block_ids(const pop_ctx *ctx, int *ids /* nblocks local */);
+
+/* ---- state transfer: host arrays in the reference layout -------------------- */
+/* name = the reference's variable name (TRACER, UVEL, VVEL, RHO, PSURF, GRADPX, GRADPY, UBTROP,
+ * VBTROP, PGUESS, FW, FW_OLD, SMF, SMFT, STF, TFW, SHF_QSW, ZX, ZY, DH, DHU, VDC, VVC, RHS, grid
+ * fields DXU ... ); tl = logical time level; n = tracer / vector component. */
+int pop_get_field(pop_ctx *ctx, const char *name, int tl, int n, double *host, long long count);
+int pop_set_field(pop_ctx *ctx, const char *name, int tl, int n, const double *host, long long count);
+int pop_get_ifield(pop_ctx *ctx, const char *name, int *host, long long count);
+long long pop_field_count(const pop_ctx *ctx, const char *name);
+/* device pointer of a field (for zero-copy host frameworks); 0 if unknown */
+void *pop_field_device_ptr(pop_ctx *ctx, const char *name, int tl, int n);
+
+/* ---- the step_mod.F90:126-911 call sequence --------------------------------- */
+int pop_time_manager(pop_ctx *ctx);              /* time_management.F90:1823-1847, 2139-2234 */
+int pop_dhdt(pop_ctx *ctx);                      /* surface_hgt.F90:131   dhdt(DH,DHU) */
+int pop_baroclinic_driver(pop_ctx *ctx);         /* baroclinic.F90:578    baroclinic_driver(ZX,ZY,DH,DHU,err) */
+int pop_barotropic_driver(pop_ctx *ctx);         /* barotropic.F90:267    barotropic_driver(ZX,ZY,err)
+                                                    (includes the ZX,ZY halo of step_mod.F90:405-423) */
+int pop_baroclinic_correct_adjust(pop_ctx *ctx); /* baroclinic.F90:1217 */
+int pop_step_tail(pop_ctx *ctx);                 /* step_mod.F90:467-832  halos, +barotropic, PGUESS,
+                                                    averaging step / time-level rotation */
+int pop_step(pop_ctx *ctx);                      /* step_mod.F90:126      step(errorCode) */
+
+/* ---- POP_HaloMod / POP_ReductionsMod / POP_SolversMod surface --------------- */
+/* POP_HaloUpdate(array, halo, fieldLoc, fieldKind, errorCode, fillValue)
+ * mpi/POP_HaloMod.F90:1732-1773; on a device-resident field */
+int pop_halo_update(pop_ctx *ctx, const char *name, int tl, int n);
+/* host-array variants used at init time and by the unit-test rule of
+ * test/unit/halo/POP.F90Dipole (nz = product of trailing dims) */
+int pop_halo_update_host_r8(pop_ctx *ctx, double *array, int nz, double fill);
+int pop_halo_update_host_i4(pop_ctx *ctx, int *array, int nz, int fill);
+/* POP_GlobalSum(array, dist, fieldLoc, errorCode, mMask) mpi/POP_ReductionsMod.F90:144-389
+ * (b4b formulation :348-383); mask_name may be NULL */
+int pop_global_sum(pop_ctx *ctx, const char *name, int tl, int n, const char *mask_name, double *result);
+/* POP_SolversRun(sfcPressure, rhsClinic, errorCode) POP_SolversMod.F90:327;
+ * operates on PSURF(newtime) and RHS in place */
+int pop_solver_run(pop_ctx *ctx);
+/* POP_SolversGetDiagnostics(iterationCount, residual, errorCode) :1158 */
+int pop_solver_get_diagnostics(const pop_ctx *ctx, int *iterations, double *rms_residual);
+/* state(k,kk,TEMPK,SALTK,this_block,RHOOUT,...) state_mod.F90:258 on n device-resident or
+ * host points (host variant stages through the GPU) */
+int pop_state_host(pop_ctx *ctx, int kk, const double *T, const double *S, double *rho,
+                   double *drhodt, double *drhods, long long n);
+
+/* ---- multi-rank transport: the library packs/unpacks on the GPU and asks the
+ *      host to move bytes (RCCL via torch.distributed in bench.py, MPI/RCCL from
+ *      Fortran).  Buffers are device pointers owned by the host framework. ---- */
+typedef int (*pop_exchange_fn)(void *user, int nmsg, const int *peer, const long long *send_off,
+                               const long long *send_cnt, const long long *recv_off,
+                               const long long *recv_cnt);   /* offsets/counts in doubles */
+typedef int (*pop_allreduce_fn)(void *user, long long off, long long cnt);
+int pop_set_comm(pop_ctx *ctx, void *dev_sendbuf, void *dev_recvbuf, void *dev_redbuf,
+                 long long buf_doubles, pop_exchange_fn xchg, pop_allreduce_fn allred, void *user);
+long long pop_comm_buffer_doubles(const pop_ctx *ctx);   /* size the host must provide */
+/* halo plan introspection (host logic, testable without a GPU) */
+int pop_halo_plan_counts(const pop_ctx *ctx, int *n_local_copies, int *n_fill, int *n_peers);
+int pop_halo_plan_peer(const pop_ctx *ctx, int ipeer, int *peer_rank, int *n_send, int *n_recv);
+int pop_halo_plan_lists(const pop_ctx *ctx, int ipeer, int *send_src /* n_send */, int *recv_dst /* n_recv */);
+int pop_halo_plan_local(const pop_ctx *ctx, int *dst, int *src /* n_local_copies */, int *fill_dst /* n_fill */);
+
+/* ---- timers (timers.F90 phase names STEP/BAROCLINIC/BAROTROPIC/3D-UPDATE) --- */
+int pop_timers_reset(pop_ctx *ctx);
+int pop_timer_ms(pop_ctx *ctx, const char *name, double *total_ms, int *calls);
+/* bench support: time `reps` launches of one named kernel phase with HIP events on the
+ * stream it runs on; returns average ms */
+int pop_time_phase(pop_ctx *ctx, const char *phase, int reps, double *avg_ms);
+int pop_device_sync(pop_ctx *ctx);
+/* run all launches on the host framework's HIP stream (e.g. torch.cuda.current_stream().cuda_stream) */
+int pop_set_stream(pop_ctx *ctx, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,249 @@
+"""pop2-cesm_amd: host-side mirror of the reference's step interface over libpop_amd.so.
+
+The product is the HIP library (csrc/ -> libpop_amd.so, C ABI in include/pop_amd.h).  This
+module is plumbing: a ctypes binding whose method names follow the reference routines
+(step_mod.F90 `step`, baroclinic.F90 `baroclinic_driver`, barotropic.F90 `barotropic_driver`,
+POP_HaloMod `POP_HaloUpdate`, POP_ReductionsMod `POP_GlobalSum`, POP_SolversMod
+`POP_SolversRun` / `POP_SolversGetDiagnostics`, blocks.F90 `get_block`), used by bench.py and
+the tests.  There is no CPU fallback: a missing library or GPU raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpop_amd.so")
+POP_CREATE_HOST_ONLY = 1
+
+XCHG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong),
+                      C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
+ALLRED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_longlong, C.c_longlong)
+
+
+def build(verbose=False):
+    """Compile libpop_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise RuntimeError("libpop_amd.so is missing: run __graft_entry__.build() (no CPU fallback exists)")
+    L = C.CDLL(_SO)
+    vp, ci, cd, cs, ll = C.c_void_p, C.c_int, C.c_double, C.c_char_p, C.c_longlong
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    sig = {
+        "pop_create": (ci, [vp, ci, ci, ci, C.POINTER(vp)]), "pop_destroy": (ci, [vp]),
+        "pop_last_error": (cs, [vp]), "pop_get_dim": (ci, [vp, cs]), "pop_get_scalar": (cd, [vp, cs]),
+        "pop_get_block": (ci, [vp, ci, pi, pi, pi]), "pop_local_block_ids": (ci, [vp, pi]),
+        "pop_get_field": (ci, [vp, cs, ci, ci, pd, ll]), "pop_set_field": (ci, [vp, cs, ci, ci, pd, ll]),
+        "pop_get_ifield": (ci, [vp, cs, pi, ll]), "pop_field_count": (ll, [vp, cs]),
+        "pop_field_device_ptr": (vp, [vp, cs, ci, ci]),
+        "pop_time_manager": (ci, [vp]), "pop_dhdt": (ci, [vp]), "pop_baroclinic_driver": (ci, [vp]),
+        "pop_barotropic_driver": (ci, [vp]), "pop_baroclinic_correct_adjust": (ci, [vp]),
+        "pop_step_tail": (ci, [vp]), "pop_step": (ci, [vp]),
+        "pop_halo_update": (ci, [vp, cs, ci, ci]),
+        "pop_halo_update_host_r8": (ci, [vp, pd, ci, cd]), "pop_halo_update_host_i4": (ci, [vp, pi, ci, ci]),
+        "pop_global_sum": (ci, [vp, cs, ci, ci, cs, pd]), "pop_solver_run": (ci, [vp]),
+        "pop_solver_get_diagnostics": (ci, [vp, pi, pd]),
+        "pop_state_host": (ci, [vp, ci, pd, pd, pd, pd, pd, ll]),
+        "pop_set_comm": (ci, [vp, vp, vp, vp, ll, XCHG_FN, ALLRED_FN, vp]),
+        "pop_comm_buffer_doubles": (ll, [vp]), "pop_set_stream": (ci, [vp, vp]),
+        "pop_halo_plan_counts": (ci, [vp, pi, pi, pi]), "pop_halo_plan_peer": (ci, [vp, ci, pi, pi, pi]),
+        "pop_halo_plan_lists": (ci, [vp, ci, pi, pi]), "pop_halo_plan_local": (ci, [vp, pi, pi, pi]),
+        "pop_timers_reset": (ci, [vp]), "pop_timer_ms": (ci, [vp, cs, pd, pi]),
+        "pop_time_phase": (ci, [vp, cs, ci, pd]), "pop_device_sync": (ci, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)       # AttributeError here = the library does not export the ABI
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+ABI_SYMBOLS = None
+
+
+def abi_symbols():
+    """Names declared in include/pop_amd.h (parsed), for the export check."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(_HERE), "include", "pop_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pop_[a-z0-9_]+)\s*\(", hdr)) - {"pop_exchange_fn", "pop_allreduce_fn"})
+
+
+class PopError(RuntimeError):
+    pass
+
+
+class PopModel:
+    """One rank's model instance.  Array views are numpy arrays shaped
+    (nblocks_local, [km,] ny_block, nx_block) = the reference layout read in C order."""
+
+    def __init__(self, cfg, rank=0, nranks=1, host_only=False):
+        self.L = lib()
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        e = self.L.pop_create(C.byref(cfg), rank, nranks, POP_CREATE_HOST_ONLY if host_only else 0, C.byref(self.h))
+        if e:
+            msg = self.L.pop_last_error(self.h).decode() if self.h else "pop_create failed"
+            raise PopError(msg)
+        d = self.dim
+        self.nxb, self.nyb, self.km, self.nt = d("nx_block"), d("ny_block"), d("km"), d("nt")
+        self.nblocks, self.nblocks_tot = d("nblocks"), d("nblocks_tot")
+        self._cb = None
+
+    def close(self):
+        if self.h:
+            self.L.pop_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def _chk(self, e):
+        if e:
+            raise PopError(self.L.pop_last_error(self.h).decode())
+
+    def dim(self, name):
+        return self.L.pop_get_dim(self.h, name.encode())
+
+    def scalar(self, name):
+        return self.L.pop_get_scalar(self.h, name.encode())
+
+    # ---- blocks.F90 get_block
+    def get_block(self, block_id):
+        out = (C.c_int * 8)()
+        ig, jg = (C.c_int * self.nxb)(), (C.c_int * self.nyb)()
+        self._chk(self.L.pop_get_block(self.h, block_id, out, ig, jg))
+        keys = ("block_id", "local_id", "ib", "ie", "jb", "je", "iblock", "jblock")
+        blk = dict(zip(keys, list(out)))
+        blk["i_glob"], blk["j_glob"] = np.array(ig), np.array(jg)
+        return blk
+
+    def local_block_ids(self):
+        ids = (C.c_int * self.nblocks)()
+        self.L.pop_local_block_ids(self.h, ids)
+        return list(ids)
+
+    # ---- fields
+    def _shape(self, name):
+        cnt = self.L.pop_field_count(self.h, name.encode())
+        n2 = self.nxb * self.nyb * self.nblocks
+        nz = cnt // n2
+        return (self.nblocks, self.nyb, self.nxb) if nz == 1 else (self.nblocks, nz, self.nyb, self.nxb)
+
+    def get(self, name, tl=1, n=0):
+        shp = self._shape(name)
+        a = np.empty(shp, dtype=np.float64)
+        self._chk(self.L.pop_get_field(self.h, name.encode(), tl, n, a.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+        return a
+
+    def set(self, name, arr, tl=1, n=0):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        self._chk(self.L.pop_set_field(self.h, name.encode(), tl, n, a.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+
+    def geti(self, name):
+        a = np.empty((self.nblocks, self.nyb, self.nxb), dtype=np.int32)
+        self._chk(self.L.pop_get_ifield(self.h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_int)), a.size))
+        return a
+
+    # ---- step_mod.F90 sequence
+    def time_manager(self):
+        self._chk(self.L.pop_time_manager(self.h))
+
+    def dhdt(self):
+        self._chk(self.L.pop_dhdt(self.h))
+
+    def baroclinic_driver(self):
+        self._chk(self.L.pop_baroclinic_driver(self.h))
+
+    def barotropic_driver(self):
+        self._chk(self.L.pop_barotropic_driver(self.h))
+
+    def baroclinic_correct_adjust(self):
+        self._chk(self.L.pop_baroclinic_correct_adjust(self.h))
+
+    def step_tail(self):
+        self._chk(self.L.pop_step_tail(self.h))
+
+    def step(self):
+        self._chk(self.L.pop_step(self.h))
+
+    def sync(self):
+        self._chk(self.L.pop_device_sync(self.h))
+
+    # ---- POP_HaloUpdate / POP_GlobalSum / POP_Solvers*
+    def halo_update(self, name, tl=1, n=0):
+        self._chk(self.L.pop_halo_update(self.h, name.encode(), tl, n))
+
+    def halo_update_host(self, arr, fill=0):
+        a = arr
+        nz = a.size // (self.nxb * self.nyb * self.nblocks_tot)
+        if a.dtype == np.int32:
+            self._chk(self.L.pop_halo_update_host_i4(self.h, a.ctypes.data_as(C.POINTER(C.c_int)), nz, int(fill)))
+        else:
+            self._chk(self.L.pop_halo_update_host_r8(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), nz, float(fill)))
+
+    def global_sum(self, name, tl=1, n=0, mask=None):
+        r = C.c_double()
+        self._chk(self.L.pop_global_sum(self.h, name.encode(), tl, n, mask.encode() if mask else None, C.byref(r)))
+        return r.value
+
+    def solver_run(self):
+        self._chk(self.L.pop_solver_run(self.h))
+
+    def solver_diagnostics(self):
+        it, rms = C.c_int(), C.c_double()
+        self.L.pop_solver_get_diagnostics(self.h, C.byref(it), C.byref(rms))
+        return it.value, rms.value
+
+    def state(self, kk, T, S, derivs=False):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        rho = np.empty_like(T)
+        dt_ = np.empty_like(T) if derivs else None
+        ds_ = np.empty_like(T) if derivs else None
+        P = C.POINTER(C.c_double)
+        self._chk(self.L.pop_state_host(self.h, kk, T.ctypes.data_as(P), S.ctypes.data_as(P), rho.ctypes.data_as(P),
+                                        dt_.ctypes.data_as(P) if derivs else None,
+                                        ds_.ctypes.data_as(P) if derivs else None, T.size))
+        return (rho, dt_, ds_) if derivs else rho
+
+    # ---- timers / bench support
+    def timers_reset(self):
+        self.L.pop_timers_reset(self.h)
+
+    def timer(self, name):
+        ms, calls = C.c_double(), C.c_int()
+        self.L.pop_timer_ms(self.h, name.encode(), C.byref(ms), C.byref(calls))
+        return ms.value, calls.value
+
+    def time_phase(self, phase, reps=10):
+        ms = C.c_double()
+        self._chk(self.L.pop_time_phase(self.h, phase.encode(), reps, C.byref(ms)))
+        return ms.value
+
+    # ---- halo plan introspection
+    def halo_plan(self):
+        nl, nf, npeer = C.c_int(), C.c_int(), C.c_int()
+        self.L.pop_halo_plan_counts(self.h, C.byref(nl), C.byref(nf), C.byref(npeer))
+        dst, src, fill = (C.c_int * max(nl.value, 1))(), (C.c_int * max(nl.value, 1))(), (C.c_int * max(nf.value, 1))()
+        self.L.pop_halo_plan_local(self.h, dst, src, fill)
+        plan = {"copy_dst": np.array(dst[:nl.value]), "copy_src": np.array(src[:nl.value]),
+                "fill_dst": np.array(fill[:nf.value]), "peers": []}
+        for ip in range(npeer.value):
+            r, ns, nr = C.c_int(), C.c_int(), C.c_int()
+            self.L.pop_halo_plan_peer(self.h, ip, C.byref(r), C.byref(ns), C.byref(nr))
+            s, d = (C.c_int * max(ns.value, 1))(), (C.c_int * max(nr.value, 1))()
+            self.L.pop_halo_plan_lists(self.h, ip, s, d)
+            plan["peers"].append({"rank": r.value, "send_src": np.array(s[:ns.value]), "recv_dst": np.array(d[:nr.value])})
+        return plan

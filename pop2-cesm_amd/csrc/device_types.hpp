@@ -1,0 +1,32 @@
+// device_types.hpp -- device-side view of the model passed by value to kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pop_internal.hpp"
+
+namespace pop {
+
+// Time-invariant data resident in HBM.  2-D fields are (nxb,nyb,nblocks) i-fastest; vertical
+// arrays are 1-based with slot 0 (index k is wave-uniform, so they are read by scalar loads).
+struct DevGrid {
+  int nxb, nyb, km, nt, nblocks, ib, ie, jb, je;   // ib..je are 1-based like the reference
+  int n2;                                          // nxb*nyb
+  long long n3;                                    // n2*km
+  const double *dz, *dzw, *zt, *zw, *c2dz, *dzr, *dz2r, *dzwr, *pressz, *bouss, *afac_t, *afac_u;
+  const double *DXU, *DYU, *DXUR, *DYUR, *UAREA_R, *TAREA_R, *TAREA, *FCOR, *HU, *HUR;
+  const double *AU0, *AUN, *AUE, *AUNE, *RCALCT;
+  const int *KMT, *KMU, *KMTN, *KMTS, *KMTE, *KMTW, *KMTEE, *KMTNN;
+  const double *DTN, *DTS, *DTE, *DTW;
+  const double *DUC, *DUN, *DUS, *DUE, *DUW, *DMC, *DMN, *DMS, *DME, *DMW, *DUM, *KXU, *KYU;
+  const double *WNE, *WEa, *WNo, *WC0, *mMask, *CHECKER, *CONSTNT;
+  const double *SMF1, *SMF2, *SMFT1, *SMFT2;
+};
+
+// scalar parameters of the current step (step_mod.F90:302-320)
+struct StepParams {
+  double c2dtu, c2dtp, beta, gamma, dtp, grav;
+  double am, ah, bottom_drag, const_vvc, const_vdc, convect_diff, convect_visc;
+  double rich_bckgrnd_vvc, rich_bckgrnd_vdc, rich_mix;
+  int leapfrogts, pavg, impcor, reset_to_freezing, nvdc;
+};
+
+}  // namespace pop

@@ -1,0 +1,556 @@
+// kernels_baroclinic.hpp -- HIP kernels of the baroclinic step (gfx950).
+//
+// Mapping: one thread owns one water column (i,j,block) and marches k with all k-carried
+// quantities (vertical velocity, vertical fluxes, hydrostatic pressure sums) in registers --
+// the reference keeps these in module-level save arrays (advection.F90:96-97,
+// vertical_mix.F90:131-135, pressure_grad.F90:56-58).  Lanes of a wavefront are 64 consecutive
+// i, so every level read is one fully coalesced 512-byte request; horizontal neighbours are
+// re-read through L1/L2.  All kernels are HBM-bound (no dense contraction -> no MFMA).
+// Arithmetic is written in the reference's evaluation order and compiled with
+// -ffp-contract=off so results match the CPU restatement to rounding of the library
+// functions only.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace pop {
+
+// ------------------------------------------------------------------------------------------
+// dhdt  (surface_hgt.F90:208-286) + tgrid_to_ugrid (grid.F90:3399-3413)
+// ------------------------------------------------------------------------------------------
+__global__ void k_dhdt(DevGrid g, StepParams sp, const double *__restrict__ PC, const double *__restrict__ PO,
+                       const double *__restrict__ FW_OLD, double *__restrict__ DH, double *__restrict__ DHU) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  auto dh = [&](long long q) { return (PC[q] - PO[q]) / (sp.grav * sp.dtp) - FW_OLD[q]; };
+  DH[c.q2] = dh(c.q2);
+  double u = 0.0;
+  if (c.i < g.nxb - 1 && c.j < g.nyb - 1) {
+    u = g.AU0[c.q2] * dh(c.q2) + g.AUN[c.q2] * dh(c.q2 + g.nxb) + g.AUE[c.q2] * dh(c.q2 + 1) + g.AUNE[c.q2] * dh(c.q2 + g.nxb + 1);
+    if (!(g.KMU[c.q2] >= 1)) u = 0.0;
+  }
+  DHU[c.q2] = u;
+}
+
+// ------------------------------------------------------------------------------------------
+// state over whole 3-D arrays (state_mod.F90:258-498): RHO = rho(T,S,pressz(k)).  3-D parallel.
+// ------------------------------------------------------------------------------------------
+__global__ void k_state3d(DevGrid g, const double *__restrict__ T, const double *__restrict__ S, double *__restrict__ RHO) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  const long long o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
+  const MwjfP P = mwjf_level(g.pressz[k]);
+  RHO[o] = mwjf_rho<false>(P, T[o], S[o], nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// vmix_coeffs_const with convection_type='diffusion' (vmix_const.F90:205-228).  3-D parallel.
+// VDC is stored (nxb,nyb,0:km+1,block); VVC (nxb,nyb,km,block).
+// ------------------------------------------------------------------------------------------
+__global__ void k_vmix_const(DevGrid g, StepParams sp, const double *__restrict__ TM, const double *__restrict__ SM,
+                             double *__restrict__ VDC, double *__restrict__ VVC) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  const int kp1 = min(k + 1, g.km);
+  const long long o = (long long)b * g.n3 + p2;
+  const MwjfP P = mwjf_level(g.pressz[kp1]);
+  const double rhok = mwjf_rho<false>(P, TM[o + (long long)(k - 1) * g.n2], SM[o + (long long)(k - 1) * g.n2], nullptr, nullptr);
+  const double rhokp = mwjf_rho<false>(P, TM[o + (long long)(kp1 - 1) * g.n2], SM[o + (long long)(kp1 - 1) * g.n2], nullptr, nullptr);
+  const double vvconv = (sp.convect_visc != 0.0) ? sp.convect_visc : sp.const_vvc;
+  double vdc = sp.const_vdc, vvc = sp.const_vvc;
+  if (rhok > rhokp && k < g.KMT[(long long)b * g.n2 + p2]) { vdc = sp.convect_diff; vvc = vvconv; }
+  VDC[((long long)b * (g.km + 2) + k) * g.n2 + p2] = vdc;
+  VVC[o + (long long)(k - 1) * g.n2] = vvc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tracer right-hand side: the k loop of baroclinic_driver's first block loop
+// (baroclinic.F90:700-870) = tracer_update (:1981-2300) with
+//   hdifft_del2 (hmix_del2.F90:1030-1095), comp_flux_vel (advection.F90:2068-2127),
+//   advt_centered (:2243-2301), vdifft (vertical_mix.F90:770-840), fresh-water and KPP
+//   non-local sources, and the RHS/predictor store (:2212-2237).
+// Algorithmic traffic per cell (SURVEY.md 8d phase B): 12 words with KPP, 9 without.
+// ------------------------------------------------------------------------------------------
+struct TracerRhsArgs {
+  const double *TCUR[2], *TOLD[2], *TMIX[2];
+  double *TNEW[2];
+  const double *UCUR, *VCUR, *VDC[2], *KPP_SRC[2], *STF[2], *TFW[2];
+  const double *HDT[2];     // del4 only: precomputed biharmonic term per tracer (else null)
+  const double *DH, *PCUR, *POLD;
+  double c2dtt;
+  int use_kpp_src;
+};
+
+template <bool DEL4>
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
+  Col c;
+  if (!col_setup(g, c, true)) return;
+  const int nxb = g.nxb, km = g.km;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2], kmtn = g.KMTN[c.q2], kmts = g.KMTS[c.q2], kmte = g.KMTE[c.q2], kmtw = g.KMTW[c.q2];
+  const double dtn = g.DTN[c.q2], dts = g.DTS[c.q2], dte = g.DTE[c.q2], dtw = g.DTW[c.q2];
+  const double dyu00 = g.DYU[c.q2], dyu0m = g.DYU[c.q2 - nxb], dyum0 = g.DYU[c.q2 - 1], dyumm = g.DYU[c.q2 - 1 - nxb];
+  const double dxu00 = g.DXU[c.q2], dxu0m = g.DXU[c.q2 - nxb], dxum0 = g.DXU[c.q2 - 1], dxumm = g.DXU[c.q2 - 1 - nxb];
+  const double tarear = g.TAREA_R[c.q2];
+  const double psfac = (a.PCUR[c.q2] - a.POLD[c.q2]);
+  double wtk = a.DH[c.q2];
+  double vtf[2];
+  double tc_km1[2] = {0.0, 0.0}, tc_k[2], tc_kp1[2], to_k[2], to_kp1[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) { tc_k[n] = a.TCUR[n][c.base3]; to_k[n] = a.TOLD[n][c.base3]; }
+  const long long vdcbase = ((long long)c.b * (km + 2)) * n2 + c.p2;
+  for (int k = 1; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    const int kp1 = (k < km) ? k + 1 : km;
+    const long long okp = c.base3 + (long long)(kp1 - 1) * n2;
+    // face flux velocities
+    const double u00 = a.UCUR[o], u0m = a.UCUR[o - nxb], um0 = a.UCUR[o - 1], umm = a.UCUR[o - 1 - nxb];
+    const double v00 = a.VCUR[o], v0m = a.VCUR[o - nxb], vm0 = a.VCUR[o - 1], vmm = a.VCUR[o - 1 - nxb];
+    const double UTE = 0.5 * (u00 * dyu00 + u0m * dyu0m);
+    const double UTW = 0.5 * (um0 * dyum0 + umm * dyumm);
+    const double VTN = 0.5 * (v00 * dxu00 + vm0 * dxum0);
+    const double VTS = 0.5 * (v0m * dxu0m + vmm * dxumm);
+    const double hdiv = VTN - VTS + UTE - UTW;
+    double wtkb = 0.0;
+    if (k < km) { const double FC = hdiv * tarear; wtkb = (k < kmt) ? wtk + g.dz[k] * FC : 0.0; }
+    const double CN = (k <= kmtn && k <= kmt) ? dtn : 0.0, CS = (k <= kmts && k <= kmt) ? dts : 0.0;
+    const double CE = (k <= kmte && k <= kmt) ? dte : 0.0, CW = (k <= kmtw && k <= kmt) ? dtw : 0.0;
+    const double CC = -(CN + CS + CE + CW);
+    const double dz2rk = g.dz2r[k], dzrk = g.dzr[k], dzwrk = g.dzwr[k];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      tc_kp1[n] = a.TCUR[n][okp];
+      to_kp1[n] = a.TOLD[n][okp];
+      double FT;
+      if (DEL4) FT = a.HDT[n][o];
+      else {
+        const double *TM = a.TMIX[n];
+        FT = sp.ah * (CC * TM[o] + CN * TM[o + nxb] + CS * TM[o - nxb] + CE * TM[o + 1] + CW * TM[o - 1]);
+      }
+      const double *TC = a.TCUR[n];
+      double L = 0.5 * (hdiv * tc_k[n] + VTN * TC[o + nxb] - VTS * TC[o - nxb] + UTE * TC[o + 1] - UTW * TC[o - 1]) * tarear;
+      if (k != 1) L = L + dz2rk * wtk * (tc_km1[n] + tc_k[n]);
+      if (k < km) L = L - dz2rk * wtkb * (tc_k[n] + tc_kp1[n]);
+      FT = FT - L;
+      if (k == 1) vtf[n] = (kmt >= 1) ? a.STF[n][c.q2] : 0.0;
+      const double vtfb = (kmt > k) ? a.VDC[n][vdcbase + (long long)k * n2] * (to_k[n] - to_kp1[n]) * dzwrk : 0.0;
+      const double vd = (k <= kmt) ? (vtf[n] - vtfb) * dzrk : 0.0;
+      vtf[n] = vtfb;
+      FT = FT + vd;
+      if (k == 1) FT = FT + g.dzr[1] * a.TFW[n][c.q2];
+      double src = 0.0;
+      if (a.use_kpp_src) src = src + a.KPP_SRC[n][o];
+      FT = FT + src;
+      if (k == 1 && sp.pavg) {
+        if (kmt > 0) a.TNEW[n][o] = a.c2dtt * FT - 2.0 * tc_k[n] * psfac / (sp.grav * g.dz[1]);
+      } else {
+        a.TNEW[n][o] = (k <= kmt) ? a.c2dtt * FT : 0.0;
+      }
+      tc_km1[n] = tc_k[n]; tc_k[n] = tc_kp1[n]; to_k[n] = to_kp1[n];
+    }
+    wtk = wtkb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Implicit vertical mixing of tracers: impvmixt (vertical_mix.F90:1263-1368) and
+// impvmixt_correct (:1563-1658).  Thomas algorithm, one thread per column; E is kept in a
+// scratch field, F in a scratch field, both only touched by the owning thread.
+//   MODE 0: predictor/standard  TNEW = TOLD + F,  rhs = TNEW(k)
+//   MODE 1: corrector           TNEW = TNEW + F,  rhs = RHS1 at k=1 only
+// PRE (MODE 0 only): the k=1 update of baroclinic_correct_adjust for the no-pressure-averaging
+//   branch (baroclinic.F90:1330-1338) applied to TNEW(1) before the solve.
+// POST: freeze clamp (baroclinic.F90:1418-1421) + state -> RHO(new) (:1468-1475)
+// ------------------------------------------------------------------------------------------
+struct ImpvmixtArgs {
+  double *TNEW[2];
+  const double *TOLD[2], *TCUR[2], *VDC[2];
+  const double *PSFC;                 // surface pressure on the LHS
+  const double *POLD, *PCUR, *PNEW, *PMIX;
+  double *E, *F, *RHO;
+  double c2dtt;
+  int nfirst, nlast;                  // 1-based tracer range
+};
+
+template <int MODE, bool PRE, bool POST>
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_impvmixt(DevGrid g, StepParams sp, ImpvmixtArgs a) {
+  Col c;
+  if (!col_setup(g, c, true)) return;
+  const int km = g.km;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  const double hfac1 = g.dz[1] / a.c2dtt;
+  const double H1 = hfac1 + a.PSFC[c.q2] / (sp.grav * a.c2dtt);
+  const long long vdcbase = ((long long)c.b * (km + 2)) * n2 + c.p2;
+  for (int n = a.nfirst - 1; n <= a.nlast - 1; ++n) {
+    double *TN = a.TNEW[n];
+    const double *VDC = a.VDC[n];
+    double rhs1 = 0.0;
+    if (MODE == 1) {
+      if (kmt > 0)
+        rhs1 = ((2.0 * a.TCUR[n][c.base3] - a.TOLD[n][c.base3]) * (a.PCUR[c.q2] - a.POLD[c.q2]) -
+                TN[c.base3] * (a.PNEW[c.q2] - a.PCUR[c.q2])) / (sp.grav * g.dz[1]);
+    }
+    double t1 = TN[c.base3];
+    if (PRE) {
+      if (kmt > 0) t1 = t1 - a.TOLD[n][c.base3] * (a.PNEW[c.q2] - a.PMIX[c.q2]) / (sp.grav * g.dz[1]);
+    }
+    double A = g.afac_t[1] * VDC[vdcbase + n2];
+    double D = H1 + A;
+    double Ek = A / D;
+    double B = H1 * Ek;
+    double Fk = (MODE == 1) ? hfac1 * rhs1 / D : hfac1 * t1 / D;
+    a.E[c.base3] = Ek;
+    a.F[c.base3] = Fk;
+    for (int k = 2; k <= km; ++k) {
+      const long long o = c.base3 + (long long)(k - 1) * n2;
+      const double C = A;
+      const double hf = g.dz[k] / a.c2dtt;
+      A = g.afac_t[k] * VDC[vdcbase + (long long)k * n2];
+      if (k > kmt) { Fk = 0.0; }
+      else {
+        D = (k == kmt) ? hf + B : hf + A + B;
+        Ek = A / D;
+        B = (hf + B) * Ek;
+        Fk = (MODE == 1) ? C * Fk / D : (hf * TN[o] + C * Fk) / D;
+        a.E[o] = Ek;
+      }
+      a.F[o] = Fk;
+    }
+    // back substitution and update, bottom to top
+    double Fkp1 = 0.0;
+    for (int k = km; k >= 1; --k) {
+      const long long o = c.base3 + (long long)(k - 1) * n2;
+      double f = a.F[o];
+      if (k < km && k < kmt) f = f + a.E[o] * Fkp1;
+      Fkp1 = f;
+      double tn = (MODE == 1) ? TN[o] + f : a.TOLD[n][o] + f;
+      if (POST && n == 0 && k == 1 && sp.reset_to_freezing) tn = fmax(tn, -2.0);
+      TN[o] = tn;
+    }
+  }
+  if (POST) {
+    for (int k = 1; k <= km; ++k) {
+      const long long o = c.base3 + (long long)(k - 1) * n2;
+      const MwjfP P = mwjf_level(g.pressz[k]);
+      a.RHO[o] = mwjf_rho<false>(P, a.TNEW[0][o], a.TNEW[1][o], nullptr, nullptr);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Momentum right-hand side: the k loop of baroclinic_driver's second block loop
+// (baroclinic.F90:966-1048) = clinic (:1724-1890) with advu (advection.F90:1307-1491),
+// Coriolis, gradp (pressure_grad.F90:258-301) + grad (operators.F90:178-187),
+// hdiffu_del2 (hmix_del2.F90:892-927), vdiffu (vertical_mix.F90:935-1010), the implicit
+// Coriolis solve and the vertical integrals ZX, ZY (:1013-1057).
+// Algorithmic traffic per cell (SURVEY.md 8d phase E): 10 words.
+// ------------------------------------------------------------------------------------------
+struct MomentumRhsArgs {
+  const double *UCUR, *VCUR, *UOLD, *VOLD, *UMIX, *VMIX;
+  const double *RHOOLD, *RHOCUR, *RHONEW, *VVC, *DHU;
+  const double *HDU, *HDV;   // del4 only: precomputed biharmonic friction
+  double *UNEW, *VNEW, *ZX, *ZY;
+};
+
+template <bool DEL4>
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
+  Col c;
+  if (!col_setup(g, c, true)) return;
+  const int nxb = g.nxb, km = g.km;
+  const long long n2 = g.n2;
+  const int kmu = g.KMU[c.q2];
+  double dyu[3][3], dxu[3][3];
+#pragma unroll
+  for (int dj = -1; dj <= 1; ++dj)
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+      dyu[dj + 1][di + 1] = g.DYU[c.q2 + dj * nxb + di];
+      dxu[dj + 1][di + 1] = g.DXU[c.q2 + dj * nxb + di];
+    }
+  const double uar = g.UAREA_R[c.q2], fcor = g.FCOR[c.q2], kxu = g.KXU[c.q2], kyu = g.KYU[c.q2];
+  const double dxur = g.DXUR[c.q2], dyur = g.DYUR[c.q2], hur = g.HUR[c.q2];
+  const double cc_h = g.DUC[c.q2] + g.DUM[c.q2];
+  const double dun = g.DUN[c.q2], dus = g.DUS[c.q2], due = g.DUE[c.q2], duw = g.DUW[c.q2];
+  const double dmc = g.DMC[c.q2], dmn = g.DMN[c.q2], dms = g.DMS[c.q2], dme = g.DME[c.q2], dmw = g.DMW[c.q2];
+  const double smfx = (kmu >= 1) ? g.SMF1[c.q2] : 0.0, smfy = (kmu >= 1) ? g.SMF2[c.q2] : 0.0;
+  double wuk = a.DHU[c.q2];
+  double vuf = smfx, vvf = smfy;
+  double rhokmx = 0.0, rhokmy = 0.0, sumx = 0.0, sumy = 0.0, zx = 0.0, zy = 0.0;
+  double uc_km1 = 0.0, vc_km1 = 0.0, uc_k = a.UCUR[c.base3], vc_k = a.VCUR[c.base3];
+  double uo_k = a.UOLD[c.base3], vo_k = a.VOLD[c.base3];
+  for (int k = 1; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    const int kp1 = (k < km) ? k + 1 : km;
+    const long long okp = c.base3 + (long long)(kp1 - 1) * n2;
+    const double uc_kp1 = a.UCUR[okp], vc_kp1 = a.VCUR[okp], uo_kp1 = a.UOLD[okp], vo_kp1 = a.VOLD[okp];
+    double u[3][3], v[3][3], ud[3][3], vd[3][3];
+#pragma unroll
+    for (int dj = -1; dj <= 1; ++dj)
+#pragma unroll
+      for (int di = -1; di <= 1; ++di) {
+        const double uu = (di == 0 && dj == 0) ? uc_k : a.UCUR[o + dj * nxb + di];
+        const double vv = (di == 0 && dj == 0) ? vc_k : a.VCUR[o + dj * nxb + di];
+        u[dj + 1][di + 1] = uu; v[dj + 1][di + 1] = vv;
+        ud[dj + 1][di + 1] = uu * dyu[dj + 1][di + 1];
+        vd[dj + 1][di + 1] = vv * dxu[dj + 1][di + 1];
+      }
+#define UD(di, dj) ud[(dj) + 1][(di) + 1]
+#define VD(di, dj) vd[(dj) + 1][(di) + 1]
+#define UU(di, dj) u[(dj) + 1][(di) + 1]
+#define VV(di, dj) v[(dj) + 1][(di) + 1]
+    const double UUW = 0.25 * (UD(0, 0) + UD(-1, 0)) + 0.125 * (UD(0, -1) + UD(-1, -1) + UD(0, 1) + UD(-1, 1));
+    const double UUE = 0.25 * (UD(1, 0) + UD(0, 0)) + 0.125 * (UD(1, -1) + UD(0, -1) + UD(1, 1) + UD(0, 1));   // = UUW(i+1,j)
+    const double VUS = 0.25 * (VD(0, 0) + VD(0, -1)) + 0.125 * (VD(-1, 0) + VD(-1, -1) + VD(1, 0) + VD(1, -1));
+    const double VUN = 0.25 * (VD(0, 1) + VD(0, 0)) + 0.125 * (VD(-1, 1) + VD(-1, 0) + VD(1, 1) + VD(1, 0));   // = VUS(i,j+1)
+    const double wukb = wuk + g.c2dz[k] * 0.5 * (VUN - VUS + UUE - UUW) * uar;
+    const double cc = VUN - VUS + UUE - UUW;
+    double LU = 0.5 * (cc * UU(0, 0) + VUN * UU(0, 1) - VUS * UU(0, -1) + UUE * UU(1, 0) - UUW * UU(-1, 0)) * uar;
+    double LV = 0.5 * (cc * VV(0, 0) + VUN * VV(0, 1) - VUS * VV(0, -1) + UUE * VV(1, 0) - UUW * VV(-1, 0)) * uar;
+    if (k == 1) { LU = LU + g.dzr[k] * wuk * uc_k; LV = LV + g.dzr[k] * wuk * vc_k; }
+    else { LU = LU + g.dz2r[k] * wuk * (uc_km1 + uc_k); LV = LV + g.dz2r[k] * wuk * (vc_km1 + vc_k); }
+    if (k < km) { LU = LU - g.dz2r[k] * wukb * (uc_k + uc_kp1); LV = LV - g.dz2r[k] * wukb * (vc_k + vc_kp1); }
+    if (k <= kmu) {
+      LU = LU + uc_k * vc_k * kyu - vc_k * vc_k * kxu;
+      LV = LV + uc_k * vc_k * kxu - uc_k * uc_k * kyu;
+    } else { LU = 0.0; LV = 0.0; }
+    double FX = -LU, FY = -LV;
+    // Coriolis (baroclinic.F90:1764-1781)
+    if (sp.impcor && sp.leapfrogts) {
+      FX = FX + fcor * (sp.gamma * vc_k + (1.0 - sp.gamma) * vo_k);
+      FY = FY - fcor * (sp.gamma * uc_k + (1.0 - sp.gamma) * uo_k);
+    } else if (!sp.impcor && sp.leapfrogts) {
+      FX = FX + fcor * vc_k; FY = FY - fcor * uc_k;
+    } else {
+      FX = FX + fcor * vo_k; FY = FY - fcor * uo_k;
+    }
+    // hydrostatic pressure gradient
+    {
+      const double bk = g.bouss[k];
+      double f00, f10, f01, f11;
+      if (sp.pavg) {
+        f00 = 0.25 * (a.RHONEW[o] + 2.0 * a.RHOCUR[o] + a.RHOOLD[o]) * bk;
+        f10 = 0.25 * (a.RHONEW[o + 1] + 2.0 * a.RHOCUR[o + 1] + a.RHOOLD[o + 1]) * bk;
+        f01 = 0.25 * (a.RHONEW[o + nxb] + 2.0 * a.RHOCUR[o + nxb] + a.RHOOLD[o + nxb]) * bk;
+        f11 = 0.25 * (a.RHONEW[o + nxb + 1] + 2.0 * a.RHOCUR[o + nxb + 1] + a.RHOOLD[o + nxb + 1]) * bk;
+      } else {
+        f00 = a.RHOCUR[o] * bk; f10 = a.RHOCUR[o + 1] * bk; f01 = a.RHOCUR[o + nxb] * bk; f11 = a.RHOCUR[o + nxb + 1] * bk;
+      }
+      double rhokx = 0.0, rhoky = 0.0;
+      if (k <= kmu) {
+        rhokx = dxur * 0.5 * (f11 - f00 - f01 + f10);
+        rhoky = dyur * 0.5 * (f11 - f00 + f01 - f10);
+      }
+      if (k == 1) { rhokmx = rhokx; rhokmy = rhoky; sumx = 0.0; sumy = 0.0; }
+      const double factor = g.dzw[k - 1] * sp.grav * 0.5;
+      sumx = sumx + factor * (rhokx + rhokmx);
+      sumy = sumy + factor * (rhoky + rhokmy);
+      rhokmx = rhokx; rhokmy = rhoky;
+      FX = FX - sumx; FY = FY - sumy;
+    }
+    // horizontal friction
+    {
+      double hdu, hdv;
+      if (DEL4) { hdu = a.HDU[o]; hdv = a.HDV[o]; }
+      else {
+        const double *UM = a.UMIX, *VM = a.VMIX;
+        const double um0 = UM[o], umn = UM[o + nxb], ums = UM[o - nxb], ume = UM[o + 1], umw = UM[o - 1];
+        const double vm0 = VM[o], vmn = VM[o + nxb], vms = VM[o - nxb], vme = VM[o + 1], vmw = VM[o - 1];
+        hdu = sp.am * ((cc_h * um0 + dun * umn + dus * ums + due * ume + duw * umw) +
+                       (dmc * vm0 + dmn * vmn + dms * vms + dme * vme + dmw * vmw));
+        hdv = sp.am * ((cc_h * vm0 + dun * vmn + dus * vms + due * vme + duw * vmw) -
+                       (dmc * um0 + dmn * umn + dms * ums + dme * ume + dmw * umw));
+        if (k > kmu) { hdu = 0.0; hdv = 0.0; }
+      }
+      FX = FX + hdu; FY = FY + hdv;
+    }
+    // vertical friction (explicit part) with quadratic bottom drag
+    {
+      const double vvc = a.VVC[o];
+      double vufb = vvc * (uo_k - uo_kp1) * g.dzwr[k];
+      double vvfb = vvc * (vo_k - vo_kp1) * g.dzwr[k];
+      if (k == kmu) {
+        const double vmag = sp.bottom_drag * sqrt(uo_k * uo_k + vo_k * vo_k);
+        vufb = vmag * uo_k; vvfb = vmag * vo_k;
+      }
+      const double vdu = (k <= kmu) ? (vuf - vufb) * g.dzr[k] : 0.0;
+      const double vdv = (k <= kmu) ? (vvf - vvfb) * g.dzr[k] : 0.0;
+      vuf = vufb; vvf = vvfb;
+      FX = FX + vdu; FY = FY + vdv;
+    }
+    if (k > kmu) { FX = 0.0; FY = 0.0; }
+    if (sp.impcor) {
+      const double W1 = sp.c2dtu * sp.beta * fcor;
+      const double W2 = sp.c2dtu / (1.0 + W1 * W1);
+      a.UNEW[o] = (FX + W1 * FY) * W2;
+      a.VNEW[o] = (FY - W1 * FX) * W2;
+    } else { a.UNEW[o] = sp.c2dtu * FX; a.VNEW[o] = sp.c2dtu * FY; }
+    zx = zx + FX * g.dz[k]; zy = zy + FY * g.dz[k];
+    wuk = wukb;
+    uc_km1 = uc_k; vc_km1 = vc_k; uc_k = uc_kp1; vc_k = vc_kp1; uo_k = uo_kp1; vo_k = vo_kp1;
+#undef UD
+#undef VD
+#undef UU
+#undef VV
+  }
+  a.ZX[c.q2] = zx * hur;
+  a.ZY[c.q2] = zy * hur;
+}
+
+// ------------------------------------------------------------------------------------------
+// impvmixu (vertical_mix.F90:1762-1868) + add old velocity + removal of the vertical mean
+// and land zeroing (baroclinic.F90:1077-1129).  One thread per column.
+// ------------------------------------------------------------------------------------------
+struct ImpvmixuArgs {
+  double *UNEW, *VNEW, *E;
+  const double *UOLD, *VOLD, *VVC;
+};
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_impvmixu_norm(DevGrid g, StepParams sp, ImpvmixuArgs a) {
+  Col c;
+  if (!col_setup(g, c, true)) return;
+  const int km = g.km;
+  const long long n2 = g.n2;
+  const int kmu = g.KMU[c.q2];
+  const double hur = g.HUR[c.q2];
+  const double hf1 = g.dz[1] / sp.c2dtu;
+  double A = g.afac_u[1] * a.VVC[c.base3];
+  double D = hf1 + A;
+  double Ek = A / D;
+  double B = hf1 * Ek;
+  double F1 = hf1 * a.UNEW[c.base3] / D, F2 = hf1 * a.VNEW[c.base3] / D;
+  a.E[c.base3] = Ek; a.UNEW[c.base3] = F1; a.VNEW[c.base3] = F2;
+  for (int k = 2; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    const double C = A;
+    const double hf = g.dz[k] / sp.c2dtu;
+    A = g.afac_u[k] * a.VVC[o];
+    if (k <= kmu) {
+      D = (k < kmu) ? hf + A + B : hf + B;
+      Ek = A / D;
+      B = (hf + B) * Ek;
+      F1 = (hf * a.UNEW[o] + C * F1) / D;
+      F2 = (hf * a.VNEW[o] + C * F2) / D;
+      a.E[o] = Ek;
+    } else { F1 = 0.0; F2 = 0.0; }
+    a.UNEW[o] = F1; a.VNEW[o] = F2;
+  }
+  double F1p = 0.0, F2p = 0.0;
+  for (int k = km; k >= 1; --k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    double f1 = a.UNEW[o], f2 = a.VNEW[o];
+    if (k < km && k < kmu) { const double e = a.E[o]; f1 = f1 + e * F1p; f2 = f2 + e * F2p; }
+    F1p = f1; F2p = f2;
+    a.UNEW[o] = a.UOLD[o] + f1;
+    a.VNEW[o] = a.VOLD[o] + f2;
+  }
+  double w1 = 0.0, w2 = 0.0;
+  for (int k = 1; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    w1 = w1 + a.UNEW[o] * g.dz[k];
+    w2 = w2 + a.VNEW[o] * g.dz[k];
+  }
+  w1 = w1 * hur; w2 = w2 * hur;
+  for (int k = 1; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    if (k <= kmu) { a.UNEW[o] = a.UNEW[o] - w1; a.VNEW[o] = a.VNEW[o] - w2; }
+    else { a.UNEW[o] = 0.0; a.VNEW[o] = 0.0; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// step tail (step_mod.F90:572-592): add the barotropic velocity where k <= KMU.  3-D parallel.
+// ------------------------------------------------------------------------------------------
+__global__ void k_add_barotropic(DevGrid g, double *__restrict__ UNEW, double *__restrict__ VNEW,
+                                 const double *__restrict__ UB, const double *__restrict__ VB) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  const long long q2 = (long long)b * g.n2 + p2;
+  if (k <= g.KMU[q2]) {
+    const long long o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
+    UNEW[o] = UNEW[o] + UB[q2];
+    VNEW[o] = VNEW[o] + VB[q2];
+  }
+}
+
+// PGUESS (step_mod.F90:634-640); on averaging steps the :793-794 correction is applied by k_avg2d
+__global__ void k_pguess(long long n, double *__restrict__ PG, const double *__restrict__ PN, const double *__restrict__ PC,
+                         const double *__restrict__ PO) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) PG[p] = 3.0 * (PN[p] - PC[p]) + PO[p];
+}
+
+// ------------------------------------------------------------------------------------------
+// averaging step (step_mod.F90:663-796)
+// ------------------------------------------------------------------------------------------
+struct Avg2dArgs {
+  double *UBO, *UBC, *VBO, *VBC, *GXO, *GXC, *GYO, *GYC, *PO, *PC, *PG, *FW_OLD;
+  const double *UBN, *VBN, *GXN, *GYN, *PN, *FW;
+  double *T1O[2], *T1C[2];         // level-1 slices of TRACER(old), TRACER(cur) base pointers (3-D arrays)
+  const double *T1N[2];
+  double dz1, grav;
+};
+__global__ void k_avg2d(DevGrid g, Avg2dArgs a) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const long long q = c.q2;
+  a.UBO[q] = 0.5 * (a.UBO[q] + a.UBC[q]); a.VBO[q] = 0.5 * (a.VBO[q] + a.VBC[q]);
+  a.UBC[q] = 0.5 * (a.UBC[q] + a.UBN[q]); a.VBC[q] = 0.5 * (a.VBC[q] + a.VBN[q]);
+  a.GXO[q] = 0.5 * (a.GXO[q] + a.GXC[q]); a.GYO[q] = 0.5 * (a.GYO[q] + a.GYC[q]);
+  a.GXC[q] = 0.5 * (a.GXC[q] + a.GXN[q]); a.GYC[q] = 0.5 * (a.GYC[q] + a.GYN[q]);
+  a.FW_OLD[q] = 0.5 * (a.FW[q] + a.FW_OLD[q]);
+  const double po = a.PO[q], pc = a.PC[q], pn = a.PN[q];
+  const double pfo = 0.5 * (po + pc), pfc = 0.5 * (pc + pn);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const double to = a.T1O[n][c.base3], tc = a.T1C[n][c.base3], tn = a.T1N[n][c.base3];
+    double t = 0.5 * ((a.dz1 + po / a.grav) * to + (a.dz1 + pc / a.grav) * tc);
+    t = t / (a.dz1 + pfo / a.grav);
+    const double mn = fmin(to, tc), mx = fmax(to, tc);
+    if (t < mn) t = mn;
+    if (t > mx) t = mx;
+    a.T1O[n][c.base3] = t;
+    double t2 = 0.5 * ((a.dz1 + pc / a.grav) * tc + (a.dz1 + pn / a.grav) * tn);
+    t2 = t2 / (a.dz1 + pfc / a.grav);
+    const double mn2 = fmin(tc, tn), mx2 = fmax(tc, tn);
+    if (t2 < mn2) t2 = mn2;
+    if (t2 > mx2) t2 = mx2;
+    a.T1C[n][c.base3] = t2;
+  }
+  a.PO[q] = pfo; a.PC[q] = pfc;
+  a.PG[q] = 0.5 * (a.PG[q] + pn);
+}
+struct Avg3dArgs {
+  double *UO, *UC, *VO, *VC, *TO[2], *TC[2], *RO, *RC;
+  const double *UN, *VN, *TN[2];
+};
+// 3-D fields: U,V all levels; tracers k >= 2 here, k == 1 in k_avg2d (run first); then RHO(old,cur)
+__global__ void k_avg3d(DevGrid g, Avg3dArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  const long long o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
+  const double uc = a.UC[o], vc = a.VC[o];
+  a.UO[o] = 0.5 * (a.UO[o] + uc); a.VO[o] = 0.5 * (a.VO[o] + vc);
+  a.UC[o] = 0.5 * (uc + a.UN[o]); a.VC[o] = 0.5 * (vc + a.VN[o]);
+  double to[2], tc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    if (k >= 2) {
+      const double c0 = a.TC[n][o];
+      to[n] = 0.5 * (a.TO[n][o] + c0);
+      tc[n] = 0.5 * (c0 + a.TN[n][o]);
+      a.TO[n][o] = to[n]; a.TC[n][o] = tc[n];
+    } else { to[n] = a.TO[n][o]; tc[n] = a.TC[n][o]; }
+  }
+  const MwjfP P = mwjf_level(g.pressz[k]);
+  a.RO[o] = mwjf_rho<false>(P, to[0], to[1], nullptr, nullptr);
+  a.RC[o] = mwjf_rho<false>(P, tc[0], tc[1], nullptr, nullptr);
+}
+
+}  // namespace pop

@@ -1,0 +1,378 @@
+// kernels_barotropic.hpp -- HIP kernels of the barotropic driver, the PCG / ChronGear solvers,
+// halo gather/scatter and the deterministic (b4b-style) global reductions.
+//
+// All 2-D work is tiny compared with the 3-D phases (O(1/km)); what matters here is launch
+// count and latency, so the solver fuses every vector update with the matvec and the
+// per-workgroup partial dot products, keeps all scalars on the device, and only returns to
+// the host every convergenceCheckFreq iterations.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace pop {
+
+#define POP_RED_THREADS 256
+
+// ---- barotropic.F90:417-571: RHS assembly, part 1 (pointwise, whole array) ---------------
+struct BtropArgs {
+  const double *ZX, *ZY, *GXC, *GXO, *GYC, *GYO, *UBO, *VBO, *PCUR, *FW, *PGUESS;
+  double *UH, *VH, *W3, *W4, *RHS, *centerWgt, *PNEW, *GXN, *GYN, *UBN, *VBN;
+  const double *GXR, *GYR;    // reference gradient for the velocity update (old on leapfrog, cur otherwise)
+  const double *scal;         // device scalars: [0] = xcheck
+  double rcheck, rconst;
+};
+__global__ void k_btrop_rhs1(DevGrid g, StepParams sp, BtropArgs a) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const long long q = c.q2;
+  double W3, W4;
+  if (sp.leapfrogts) {
+    W3 = sp.c2dtp * (a.ZX[q] - sp.gamma * a.GXC[q] - (1.0 - sp.gamma) * a.GXO[q]);
+    W4 = sp.c2dtp * (a.ZY[q] - sp.gamma * a.GYC[q] - (1.0 - sp.gamma) * a.GYO[q]);
+  } else {
+    W3 = sp.c2dtp * (a.ZX[q] - a.GXC[q]);
+    W4 = sp.c2dtp * (a.ZY[q] - a.GYC[q]);
+  }
+  double uh, vh;
+  if (sp.impcor) {
+    const double W1 = sp.c2dtp * sp.beta * g.FCOR[q];
+    const double W2 = 1.0 / (1.0 + W1 * W1);
+    uh = W2 * (W3 + W1 * W4) + a.UBO[q];
+    vh = W2 * (W4 - W1 * W3) + a.VBO[q];
+  } else { uh = W3 + a.UBO[q]; vh = W4 + a.VBO[q]; }
+  a.UH[q] = uh; a.VH[q] = vh;
+  const double gx = sp.leapfrogts ? a.GXO[q] : a.GXC[q], gy = sp.leapfrogts ? a.GYO[q] : a.GYC[q];
+  a.W3[q] = g.HU[q] * (uh + sp.beta * sp.c2dtp * gx);
+  a.W4[q] = g.HU[q] * (vh + sp.beta * sp.c2dtp * gy);
+}
+// part 2: div (operators.F90:101-113), diagonal term, operator centre weight, initial guess
+__global__ void k_btrop_rhs2(DevGrid g, StepParams sp, BtropArgs a) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const long long q = c.q2;
+  const int nxb = g.nxb;
+  double d = 0.0;
+  if (c.i >= 1 && c.j >= 1 && 1 <= g.KMT[q])
+    d = 0.5 * (a.W3[q] * g.DYU[q] + a.W3[q - nxb] * g.DYU[q - nxb] - a.W3[q - 1] * g.DYU[q - 1] - a.W3[q - 1 - nxb] * g.DYU[q - 1 - nxb] +
+               a.W4[q] * g.DXU[q] + a.W4[q - 1] * g.DXU[q - 1] - a.W4[q - nxb] * g.DXU[q - nxb] - a.W4[q - 1 - nxb] * g.DXU[q - 1 - nxb]);
+  double rhs = d / (sp.beta * sp.c2dtp);
+  const double dc = (g.KMT[q] >= 1) ? g.TAREA[q] / (sp.beta * sp.c2dtp * sp.dtp * sp.grav) : 0.0;
+  rhs = rhs - dc * a.PCUR[q] - a.FW[q] * g.TAREA[q] / (sp.beta * sp.c2dtp);
+  a.RHS[q] = rhs;
+  a.centerWgt[q] = g.WC0[q] - dc;
+  a.PNEW[q] = a.PGUESS[q];
+}
+// barotropic.F90:622-679: null-space removal (whole array)
+__global__ void k_btrop_fin1(DevGrid g, BtropArgs a) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const long long q = c.q2;
+  const double xcheck = a.scal[0];
+  a.PNEW[q] = a.PNEW[q] + g.CONSTNT[q] * a.rcheck * xcheck - g.CHECKER[q] * a.rconst * xcheck;
+}
+// grad of the new surface pressure (operators.F90:178-187) and new barotropic velocity
+__global__ void k_btrop_fin2(DevGrid g, StepParams sp, BtropArgs a) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const long long q = c.q2;
+  const int nxb = g.nxb;
+  double gx = 0.0, gy = 0.0;
+  if (c.i < g.nxb - 1 && c.j < g.nyb - 1 && 1 <= g.KMU[q]) {
+    const double f00 = a.PNEW[q], f10 = a.PNEW[q + 1], f01 = a.PNEW[q + nxb], f11 = a.PNEW[q + nxb + 1];
+    gx = g.DXUR[q] * 0.5 * (f11 - f00 - f01 + f10);
+    gy = g.DYUR[q] * 0.5 * (f11 - f00 + f01 - f10);
+  }
+  a.GXN[q] = gx; a.GYN[q] = gy;
+  a.UBN[q] = a.UH[q] - sp.beta * sp.c2dtp * (gx - a.GXR[q]);
+  a.VBN[q] = a.VH[q] - sp.beta * sp.c2dtp * (gy - a.GYR[q]);
+}
+
+// ---- deterministic reductions --------------------------------------------------------------
+// Stage 1 is fused into the producing kernels: each workgroup reduces its 256 cells with a
+// fixed LDS tree and writes partial[(blk*nchunk + chunk)*nfields + f].  Stage 2 (one workgroup)
+// adds the partials of every POP block in fixed order -> block sums (the b4b block-sum vector of
+// mpi/POP_ReductionsMod.F90:348-383), then the block sums in global block-id order.
+template <int NF>
+__device__ __forceinline__ void wg_reduce_store(double (&v)[NF], double *partial, int slot) {
+  __shared__ double sh[NF][POP_RED_THREADS];
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) sh[f][t] = v[f];
+  __syncthreads();
+  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) sh[f][t] = sh[f][t] + sh[f][t + s];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) partial[(long long)slot * NF + f] = sh[f][0];
+  }
+}
+// Stage 2: blocksum[gid[b]*NF+f] = ordered sum of partials of local block b.  One workgroup per
+// (local block); threads take strided subsets sequentially, then a fixed tree.
+template <int NF>
+__global__ void k_block_sums(const double *__restrict__ partial, int nchunk, const int *__restrict__ gid,
+                             double *__restrict__ blocksum) {
+  __shared__ double sh[NF][POP_RED_THREADS];
+  const int t = threadIdx.x, b = blockIdx.x;
+  double v[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) v[f] = 0.0;
+  for (int cidx = t; cidx < nchunk; cidx += POP_RED_THREADS)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) v[f] = v[f] + partial[((long long)b * nchunk + cidx) * NF + f];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) sh[f][t] = v[f];
+  __syncthreads();
+  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) sh[f][t] = sh[f][t] + sh[f][t + s];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) blocksum[(long long)gid[b] * NF + f] = sh[f][0];
+  }
+}
+
+// Solver scalars kept on the device
+struct SolverScalars {
+  double eta0, eta1, alpha, beta_cg, rr, sum0, sum1, xcheck;
+  double rho_old, sigma;   // ChronGear
+};
+enum { FIN_PCG_RZ = 1, FIN_PCG_SQ = 2, FIN_RR = 3, FIN_XCHECK = 4, FIN_CG_INIT = 5, FIN_CG_ITER = 6, FIN_PLAIN = 7 };
+// Stage 3: global sum over the block-sum vector in block-id order + scalar recurrences
+// (POP_SolversMod.F90:1365-1420 for pcg, :2159-2170 for ChronGear).  Single thread.
+template <int NF>
+__global__ void k_finalize(const double *__restrict__ blocksum, int nblocks_tot, SolverScalars *s, int mode) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double g[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) g[f] = 0.0;
+  for (int b = 0; b < nblocks_tot; ++b)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) g[f] = g[f] + blocksum[(long long)b * NF + f];
+  s->sum0 = g[0];
+  if (NF > 1) s->sum1 = g[NF > 1 ? 1 : 0];
+  switch (mode) {
+    case FIN_PCG_RZ: s->eta1 = g[0]; s->beta_cg = s->eta1 / s->eta0; break;               // s = z + s*(eta1/eta0)
+    case FIN_PCG_SQ: s->eta0 = s->eta1; s->eta1 = s->eta0 / g[0]; s->alpha = s->eta1; break;
+    case FIN_RR: s->rr = g[0]; break;
+    case FIN_XCHECK: s->xcheck = g[0]; break;
+    case FIN_CG_INIT: s->rho_old = g[0]; s->sigma = g[NF > 1 ? 1 : 0]; s->alpha = s->rho_old / s->sigma; break;
+    case FIN_CG_ITER: {
+      const double rho = g[0], delta = g[NF > 1 ? 1 : 0];
+      s->beta_cg = rho / s->rho_old;
+      s->sigma = delta - (s->beta_cg * s->beta_cg) * s->sigma;
+      s->alpha = rho / s->sigma;
+      s->rho_old = rho;
+    } break;
+    default: break;
+  }
+}
+
+// generic masked product sum over the physical domain: partial of a*b*mask (b, mask optional)
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_dot_partial(DevGrid g, const double *__restrict__ A, const double *__restrict__ Bv, const double *__restrict__ M,
+              double *__restrict__ partial) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb;
+    if (i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je) {
+      const long long q = (long long)b * g.n2 + p2;
+      double x = A[q];
+      if (Bv) x = x * Bv[q];
+      if (M) x = x * M[q];
+      v[0] = x;
+    }
+  }
+  wg_reduce_store<1>(v, partial, b * gridDim.x + blockIdx.x);
+}
+
+// ---- btropOperator (POP_SolversMod.F90:2414-2426) at one point -----------------------------
+__device__ __forceinline__ double btrop_op(const DevGrid &g, const double *__restrict__ C, const double *__restrict__ X,
+                                           long long q, int nxb) {
+  return C[q] * X[q] + g.WNo[q] * X[q + nxb] + g.WNo[q - nxb] * X[q - nxb] + g.WEa[q] * X[q + 1] + g.WEa[q - 1] * X[q - 1] +
+         g.WNE[q] * X[q + nxb + 1] + g.WNE[q - nxb] * X[q - nxb + 1] + g.WNE[q - 1] * X[q + nxb - 1] + g.WNE[q - 1 - nxb] * X[q - nxb - 1];
+}
+__device__ __forceinline__ bool op_range(const DevGrid &g, int i, int j) {   // i,j = 2..n-1 (1-based)
+  return i >= 1 && i <= g.nxb - 2 && j >= 1 && j <= g.nyb - 2;
+}
+__device__ __forceinline__ bool interior(const DevGrid &g, int i, int j) {
+  return i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je;
+}
+
+struct SolverArgs {
+  double *X, *R, *S0, *S1, *Q, *Z, *AZ;
+  const double *Bv, *C;      // right-hand side, centre weight
+  double *partial;
+  SolverScalars *sc;
+};
+// r = b - A x  (whole array; :1273-1283).  WITH_RR: also partial (r,r) (:1452-1458, :2188-2199)
+template <bool WITH_RR>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_residual(DevGrid g, SolverArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    const double ax = op_range(g, i, j) ? btrop_op(g, a.C, a.X, q, g.nxb) : 0.0;
+    const double r = a.Bv[q] - ax;
+    a.R[q] = r;
+    if (WITH_RR && interior(g, i, j)) v[0] = (r * r) * g.mMask[q];
+  }
+  if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + blockIdx.x);
+}
+// PCG step A (:1320-1345, :1433-1438 of the previous iteration): x += alpha s; r -= alpha q (if
+// UPDATE); z = r/diag; partial (r,z)
+template <bool UPDATE>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_pcg_a(DevGrid g, SolverArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    double r = a.R[q];
+    if (UPDATE) {
+      const double al = a.sc->alpha;
+      a.X[q] = a.X[q] + al * a.S0[q];
+      r = r - al * a.Q[q];
+      a.R[q] = r;
+    }
+    const double cw = a.C[q];
+    const double z = (cw != 0.0) ? r / cw : 0.0;
+    a.Z[q] = z;
+    if (interior(g, i, j)) v[0] = (r * z) * g.mMask[q];
+  }
+  wg_reduce_store<1>(v, a.partial, b * gridDim.x + blockIdx.x);
+}
+// x,r update only (before a convergence check)
+__global__ void k_pcg_xr(DevGrid g, SolverArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const long long q = (long long)b * g.n2 + p2;
+  const double al = a.sc->alpha;
+  a.X[q] = a.X[q] + al * a.S0[q];
+  a.R[q] = a.R[q] - al * a.Q[q];
+}
+// PCG step B (:1377-1399): s_new = z + s_old*(eta1/eta0) evaluated at the 9 stencil points from
+// the old direction buffer (no race: S0 is read, S1 written); q = A s_new; partial (q,s)
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_pcg_b(DevGrid g, SolverArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    const double bt = a.sc->beta_cg;
+    auto sn = [&](long long qq) { return a.Z[qq] + a.S0[qq] * bt; };
+    const double s = sn(q);
+    a.S1[q] = s;
+    double aq = 0.0;
+    if (op_range(g, i, j)) {
+      aq = a.C[q] * s + g.WNo[q] * sn(q + nxb) + g.WNo[q - nxb] * sn(q - nxb) + g.WEa[q] * sn(q + 1) + g.WEa[q - 1] * sn(q - 1) +
+           g.WNE[q] * sn(q + nxb + 1) + g.WNE[q - nxb] * sn(q - nxb + 1) + g.WNE[q - 1] * sn(q + nxb - 1) + g.WNE[q - 1 - nxb] * sn(q - nxb - 1);
+    }
+    a.Q[q] = aq;
+    if (interior(g, i, j)) v[0] = (aq * s) * g.mMask[q];
+  }
+  wg_reduce_store<1>(v, a.partial, b * gridDim.x + blockIdx.x);
+}
+
+// ---- ChronGear (POP_SolversMod.F90:2040-2210) -----------------------------------------------
+// init: z = r*A0R; s = z; q = A s; partial (r,z), (s,q)
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_cg_init(DevGrid g, SolverArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  double v[2] = {0.0, 0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    auto zf = [&](long long qq) { const double cw = a.C[qq]; return a.R[qq] * ((cw != 0.0) ? 1.0 / cw : 0.0); };
+    const double z = zf(q);
+    a.Z[q] = z; a.S0[q] = z;
+    double aq = 0.0;
+    if (op_range(g, i, j))
+      aq = a.C[q] * z + g.WNo[q] * zf(q + nxb) + g.WNo[q - nxb] * zf(q - nxb) + g.WEa[q] * zf(q + 1) + g.WEa[q - 1] * zf(q - 1) +
+           g.WNE[q] * zf(q + nxb + 1) + g.WNE[q - nxb] * zf(q - nxb + 1) + g.WNE[q - 1] * zf(q + nxb - 1) + g.WNE[q - 1 - nxb] * zf(q - nxb - 1);
+    a.Q[q] = aq;
+    if (interior(g, i, j)) { v[0] = (a.R[q] * z) * g.mMask[q]; v[1] = (z * aq) * g.mMask[q]; }
+  }
+  wg_reduce_store<2>(v, a.partial, b * gridDim.x + blockIdx.x);
+}
+// z = r*A0R (whole array; the halo of Z follows)
+__global__ void k_cg_z(DevGrid g, SolverArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const long long q = (long long)b * g.n2 + p2;
+  const double cw = a.C[q];
+  a.Z[q] = a.R[q] * ((cw != 0.0) ? 1.0 / cw : 0.0);
+}
+// az = A z; partial (r,z), (az,z)
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_cg_az(DevGrid g, SolverArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  double v[2] = {0.0, 0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    const double az = op_range(g, i, j) ? btrop_op(g, a.C, a.Z, q, g.nxb) : 0.0;
+    a.AZ[q] = az;
+    if (interior(g, i, j)) { const double z = a.Z[q]; v[0] = (a.R[q] * z) * g.mMask[q]; v[1] = (az * z) * g.mMask[q]; }
+  }
+  wg_reduce_store<2>(v, a.partial, b * gridDim.x + blockIdx.x);
+}
+// s = z + beta s; q = az + beta q; x += alpha s; r -= alpha q   (FIRST: x,r only with the init alpha)
+template <bool FIRST>
+__global__ void k_cg_update(DevGrid g, SolverArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const long long q = (long long)b * g.n2 + p2;
+  const double al = a.sc->alpha;
+  double s = a.S0[q], qq = a.Q[q];
+  if (!FIRST) {
+    const double bt = a.sc->beta_cg;
+    s = a.Z[q] + bt * s;
+    qq = a.AZ[q] + bt * qq;
+    a.S0[q] = s; a.Q[q] = qq;
+  }
+  a.X[q] = a.X[q] + al * s;
+  a.R[q] = a.R[q] - al * qq;
+}
+
+// ---- halo update kernels (index lists from the plan) ---------------------------------------
+// ghost <- interior copies between blocks of this rank, and fill values; one thread per
+// (cell, level); field layout (n2 cells, nz levels, blocks): cell index = blk*n2 + p2
+__global__ void k_halo_local(double *__restrict__ F, const int *__restrict__ dst, const int *__restrict__ src, int ncopy,
+                             const int *__restrict__ filld, int nfill, double fill, int nz, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (t < ncopy) {
+    const int d = dst[t], s = src[t];
+    F[((long long)(d / n2) * nz + k) * n2 + d % n2] = F[((long long)(s / n2) * nz + k) * n2 + s % n2];
+  } else if (t < ncopy + nfill) {
+    const int d = filld[t - ncopy];
+    F[((long long)(d / n2) * nz + k) * n2 + d % n2] = fill;
+  }
+}
+// pack cells into a message buffer laid out [level][cell]
+__global__ void k_halo_pack(const double *__restrict__ F, const int *__restrict__ src, int n, double *__restrict__ buf, int nz, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (t >= n) return;
+  const int s = src[t];
+  buf[(long long)k * n + t] = F[((long long)(s / n2) * nz + k) * n2 + s % n2];
+}
+__global__ void k_halo_unpack(double *__restrict__ F, const int *__restrict__ dst, int n, const double *__restrict__ buf, int nz, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (t >= n) return;
+  const int d = dst[t];
+  F[((long long)(d / n2) * nz + k) * n2 + d % n2] = buf[(long long)k * n + t];
+}
+
+}  // namespace pop

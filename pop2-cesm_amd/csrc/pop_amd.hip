@@ -1,0 +1,846 @@
+// pop_amd.hip -- context, launch orchestration (the step_mod.F90 call sequence) and the C ABI of
+// libpop_amd.so.  gfx950 only.  See include/pop_amd.h for the boundary and DESIGN.md for the
+// kernel list.  The product path has no CPU fallback: every compute entry point fails loudly
+// when the context was created host-only or no HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include "kernels_baroclinic.hpp"
+#include "kernels_barotropic.hpp"
+#include "kernels_mix.hpp"
+
+using namespace pop;
+
+#define HIPCHK(ctx, call)                                                                       \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+      return 1;                                                                                 \
+    }                                                                                           \
+  } while (0)
+
+struct PhaseTimer { double ms = 0; int calls = 0; };
+
+struct DevPeer { int rank; int *send_src = nullptr, *recv_dst = nullptr; int nsend = 0, nrecv = 0; };
+
+struct pop_ctx {
+  HostModel h;
+  bool host_only = true;
+  std::string err;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  DevGrid g{};
+  std::map<std::string, double *> d2;     // device 2-D fields (local blocks)
+  std::map<std::string, int *> di2;
+  std::vector<void *> allocs;
+  // prognostic state, physical slots; logical levels via oldt/curt/newt
+  double *TR[MAXNT][3] = {}, *U[3] = {}, *V[3] = {}, *RHO[3] = {};
+  double *PS[3] = {}, *GX[3] = {}, *GY[3] = {}, *UB[3] = {}, *VB[3] = {};
+  double *PGUESS = nullptr, *FW = nullptr, *FW_OLD = nullptr, *SHF_QSW = nullptr;
+  double *STF[MAXNT] = {}, *TFW[MAXNT] = {}, *KPP_SRC[MAXNT] = {}, *VDC[2] = {}, *VVC = nullptr;
+  double *DH = nullptr, *DHU = nullptr, *ZX = nullptr, *ZY = nullptr, *UH = nullptr, *VH = nullptr;
+  double *W3 = nullptr, *W4 = nullptr, *RHS = nullptr, *centerWgt = nullptr;
+  double *E3 = nullptr, *F3 = nullptr, *S3a = nullptr, *S3b = nullptr, *S3c = nullptr, *S3d = nullptr;
+  double *HBLT = nullptr, *HMXL = nullptr;
+  MixDev mix{};
+  // solver
+  double *R = nullptr, *S0 = nullptr, *S1 = nullptr, *Q = nullptr, *Z = nullptr, *AZ = nullptr;
+  double *partial = nullptr, *blocksum = nullptr;
+  SolverScalars *sc = nullptr;
+  int *gid = nullptr;
+  int nchunk = 0, numIterations = 0;
+  double rmsResidual = 0.0;
+  // halo plan on device
+  int *copy_dst = nullptr, *copy_src = nullptr, *fill_dst = nullptr;
+  int ncopy = 0, nfill = 0;
+  std::vector<DevPeer> peers;
+  // comm hooks
+  double *sendbuf = nullptr, *recvbuf = nullptr, *redbuf = nullptr;
+  long long comm_doubles = 0;
+  pop_exchange_fn xchg = nullptr;
+  pop_allreduce_fn allred = nullptr;
+  void *comm_user = nullptr;
+  // time stepping
+  int oldt = 0, curt = 1, newt = 2, mixt = 1;
+  int first_step = 1, leapfrogts = 1, f_euler_ts = 0, avg_ts = 0, nsteps_total = 0, nsteps_this_interval = 0;
+  double c2dtt = 0, c2dtu = 0, c2dtp = 0, beta = 0;
+  std::map<std::string, PhaseTimer> timers;
+  bool timing = false;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(pop_ctx *c, T **p, size_t n, bool zero = true) {
+  void *v = nullptr;
+  HIPCHK(c, hipMalloc(&v, std::max<size_t>(n, 1) * sizeof(T)));
+  c->allocs.push_back(v);
+  if (zero) HIPCHK(c, hipMemset(v, 0, std::max<size_t>(n, 1) * sizeof(T)));
+  *p = (T *)v;
+  return 0;
+}
+template <class T>
+int dev_upload(pop_ctx *c, T **p, const T *src, size_t n) {
+  if (dev_alloc(c, p, n, false)) return 1;
+  HIPCHK(c, hipMemcpy(*p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+// extract the local blocks of an all-blocks host field
+template <class T>
+std::vector<T> local_part(const HostModel &h, const std::vector<T> &all) {
+  std::vector<T> out(h.n2 * h.nblocks);
+  for (int lb = 0; lb < h.nblocks; ++lb)
+    std::copy(all.begin() + (size_t)(h.local_ids[lb] - 1) * h.n2, all.begin() + (size_t)h.local_ids[lb] * h.n2, out.begin() + (size_t)lb * h.n2);
+  return out;
+}
+
+dim3 grid_cols(const pop_ctx *c) { return dim3((c->g.n2 + POP_COL_THREADS - 1) / POP_COL_THREADS, c->g.nblocks); }
+dim3 grid_2d(const pop_ctx *c) { return dim3((c->g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS, c->g.nblocks); }
+dim3 grid_3d(const pop_ctx *c) { return dim3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks); }
+
+StepParams step_params(const pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  StepParams s{};
+  s.c2dtu = c->c2dtu; s.c2dtp = c->c2dtp; s.beta = c->beta; s.gamma = 1.0 - 2.0 * (1.0 / 3.0);
+  s.dtp = c->h.dtp; s.grav = GRAV;
+  s.am = cf.am; s.ah = cf.ah; s.bottom_drag = cf.bottom_drag;
+  s.const_vvc = cf.const_vvc; s.const_vdc = cf.const_vdc; s.convect_diff = cf.convect_diff; s.convect_visc = cf.convect_visc;
+  s.rich_bckgrnd_vvc = cf.rich_bckgrnd_vvc; s.rich_bckgrnd_vdc = cf.rich_bckgrnd_vdc; s.rich_mix = cf.rich_mix;
+  s.leapfrogts = c->leapfrogts; s.pavg = (cf.lpressure_avg && c->leapfrogts) ? 1 : 0;
+  s.impcor = cf.impcor; s.reset_to_freezing = cf.reset_to_freezing;
+  s.nvdc = (cf.vmix_choice == 3) ? 2 : 1;
+  return s;
+}
+
+struct ScopedPhase {   // optional HIP-event timing of a phase on the launch stream
+  pop_ctx *c; const char *name; hipEvent_t e0 = nullptr, e1 = nullptr;
+  ScopedPhase(pop_ctx *c_, const char *n) : c(c_), name(n) {
+    if (c->timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
+  }
+  ~ScopedPhase() {
+    if (c->timing) {
+      hipEventRecord(e1, c->stream); hipEventSynchronize(e1);
+      float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+      auto &t = c->timers[name]; t.ms += ms; t.calls += 1;
+      hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// halo update of a device-resident field with nz levels (mpi/POP_HaloMod.F90:1732-2071 2-D,
+// :2766-3211 3-D): local ghost copies + fills in one launch, then one packed message per peer
+// ---------------------------------------------------------------------------------------------
+int halo_update(pop_ctx *c, double *F, int nz, double fill = 0.0) {
+  const int n2 = c->g.n2;
+  if (!c->peers.empty()) {
+    if (!c->xchg || !c->sendbuf) { c->err = "halo_update: multi-rank run without pop_set_comm"; return 1; }
+    std::vector<int> peer; std::vector<long long> soff, scnt, roff, rcnt;
+    long long so = 0, ro = 0;
+    for (auto &p : c->peers) {
+      if (p.nsend) hipLaunchKernelGGL(k_halo_pack, dim3((p.nsend + 255) / 256, nz), dim3(256), 0, c->stream, F, p.send_src, p.nsend, c->sendbuf + so, nz, n2);
+      peer.push_back(p.rank); soff.push_back(so); scnt.push_back((long long)p.nsend * nz); roff.push_back(ro); rcnt.push_back((long long)p.nrecv * nz);
+      so += (long long)p.nsend * nz; ro += (long long)p.nrecv * nz;
+    }
+    if (so > c->comm_doubles || ro > c->comm_doubles) { c->err = "halo_update: comm buffer too small"; return 1; }
+    if (c->xchg(c->comm_user, (int)peer.size(), peer.data(), soff.data(), scnt.data(), roff.data(), rcnt.data())) {
+      c->err = "halo_update: host exchange callback failed"; return 1;
+    }
+    ro = 0;
+    for (auto &p : c->peers) {
+      if (p.nrecv) hipLaunchKernelGGL(k_halo_unpack, dim3((p.nrecv + 255) / 256, nz), dim3(256), 0, c->stream, F, p.recv_dst, p.nrecv, c->recvbuf + ro, nz, n2);
+      ro += (long long)p.nrecv * nz;
+    }
+  }
+  const int nloc = c->ncopy + c->nfill;
+  if (nloc) hipLaunchKernelGGL(k_halo_local, dim3((nloc + 255) / 256, nz), dim3(256), 0, c->stream, F, c->copy_dst, c->copy_src, c->ncopy, c->fill_dst, c->nfill, fill, nz, n2);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// stage 2+3 of a reduction whose partials are already in c->partial
+template <int NF>
+int reduce_finish(pop_ctx *c, int mode) {
+  double *bs = c->blocksum;
+  if (c->h.nranks > 1) {
+    if (!c->allred || !c->redbuf) { c->err = "global sum: multi-rank run without pop_set_comm"; return 1; }
+    bs = c->redbuf;
+    HIPCHK(c, hipMemsetAsync(bs, 0, sizeof(double) * NF * c->h.nblocks_tot, c->stream));
+  }
+  hipLaunchKernelGGL(k_block_sums<NF>, dim3(c->g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->gid, bs);
+  if (c->h.nranks > 1 && c->allred(c->comm_user, 0, (long long)NF * c->h.nblocks_tot)) { c->err = "global sum: allreduce callback failed"; return 1; }
+  hipLaunchKernelGGL(k_finalize<NF>, dim3(1), dim3(1), 0, c->stream, bs, c->h.nblocks_tot, c->sc, mode);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int read_scalars(pop_ctx *c, SolverScalars *out) {
+  HIPCHK(c, hipMemcpyAsync(out, c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+SolverArgs solver_args(pop_ctx *c) {
+  SolverArgs a{};
+  a.X = c->PS[c->newt]; a.R = c->R; a.S0 = c->S0; a.S1 = c->S1; a.Q = c->Q; a.Z = c->Z; a.AZ = c->AZ;
+  a.Bv = c->RHS; a.C = c->centerWgt; a.partial = c->partial; a.sc = c->sc;
+  return a;
+}
+
+// POP_SolversRun -> pcg (POP_SolversMod.F90:1255-1503), diagonal preconditioner
+int solver_pcg(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  SolverScalars init{}; init.eta0 = 1.0;
+  HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->S0, 0, sizeof(double) * c->g.n2 * c->g.nblocks, c->stream));
+  SolverArgs a = solver_args(c);
+  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  if (halo_update(c, c->R, 1)) return 1;
+  c->numIterations = cf.max_iterations;
+  double rr = 0.0;
+  bool pending = false;   // x,r update of the previous iteration not yet applied
+  for (int m = 1; m <= cf.max_iterations; ++m) {
+    a = solver_args(c);
+    if (pending) hipLaunchKernelGGL(k_pcg_a<true>, G, B, 0, c->stream, c->g, a);
+    else hipLaunchKernelGGL(k_pcg_a<false>, G, B, 0, c->stream, c->g, a);
+    if (reduce_finish<1>(c, FIN_PCG_RZ)) return 1;
+    hipLaunchKernelGGL(k_pcg_b, G, B, 0, c->stream, c->g, a);
+    std::swap(c->S0, c->S1);
+    if (halo_update(c, c->Q, 1)) return 1;
+    if (reduce_finish<1>(c, FIN_PCG_SQ)) return 1;
+    pending = true;
+    if (m % cf.convergence_check_freq == 0) {
+      a = solver_args(c);
+      hipLaunchKernelGGL(k_pcg_xr, G, B, 0, c->stream, c->g, a);
+      pending = false;
+      hipLaunchKernelGGL(k_residual<true>, G, B, 0, c->stream, c->g, a);
+      if (halo_update(c, c->R, 1)) return 1;
+      if (reduce_finish<1>(c, FIN_RR)) return 1;
+      SolverScalars s;
+      if (read_scalars(c, &s)) return 1;
+      rr = s.rr;
+      if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
+    }
+  }
+  if (pending) { a = solver_args(c); hipLaunchKernelGGL(k_pcg_xr, G, B, 0, c->stream, c->g, a); }
+  c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
+  HIPCHK(c, hipGetLastError());
+  if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCG: solver not converged"; return 2; }
+  return 0;
+}
+
+// ChronGear (POP_SolversMod.F90:1960-2266), diagonal preconditioner
+int solver_chrongear(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  SolverScalars init{};
+  HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  SolverArgs a = solver_args(c);
+  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  if (halo_update(c, c->R, 1)) return 1;
+  hipLaunchKernelGGL(k_cg_init, G, B, 0, c->stream, c->g, a);
+  if (halo_update(c, c->Q, 1)) return 1;
+  if (reduce_finish<2>(c, FIN_CG_INIT)) return 1;
+  hipLaunchKernelGGL(k_cg_update<true>, G, B, 0, c->stream, c->g, a);
+  c->numIterations = cf.max_iterations;
+  double rr = 0.0;
+  for (int m = 1; m <= cf.max_iterations; ++m) {
+    hipLaunchKernelGGL(k_cg_z, G, B, 0, c->stream, c->g, a);
+    if (halo_update(c, c->Z, 1)) return 1;
+    hipLaunchKernelGGL(k_cg_az, G, B, 0, c->stream, c->g, a);
+    if (reduce_finish<2>(c, FIN_CG_ITER)) return 1;
+    hipLaunchKernelGGL(k_cg_update<false>, G, B, 0, c->stream, c->g, a);
+    if (m % cf.convergence_check_freq == 0) {
+      hipLaunchKernelGGL(k_residual<true>, G, B, 0, c->stream, c->g, a);
+      if (halo_update(c, c->R, 1)) return 1;
+      if (reduce_finish<1>(c, FIN_RR)) return 1;
+      SolverScalars s;
+      if (read_scalars(c, &s)) return 1;
+      rr = s.rr;
+      if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
+    }
+  }
+  c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
+  HIPCHK(c, hipGetLastError());
+  if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversChronGear: solver not converged"; return 2; }
+  return 0;
+}
+
+int need_device(pop_ctx *c) {
+  if (!c) return 1;
+  if (c->host_only) { c->err = "context was created host-only: no GPU path available (there is no CPU fallback)"; return 1; }
+  return 0;
+}
+
+// resolve a named field: device pointer, element count (local), whether tl / n apply
+int resolve(pop_ctx *c, const std::string &name, int tl, int n, double **ptr, long long *count) {
+  const long long a2 = (long long)c->g.n2 * c->g.nblocks, a3 = (long long)c->g.n3 * c->g.nblocks;
+  const int t = tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt;
+  auto ok = [&](double *p, long long cnt) { *ptr = p; *count = cnt; return p ? 0 : 1; };
+  if (name == "TRACER") return (n >= 0 && n < c->h.nt) ? ok(c->TR[n][t], a3) : 1;
+  if (name == "UVEL") return ok(c->U[t], a3);
+  if (name == "VVEL") return ok(c->V[t], a3);
+  if (name == "RHO") return ok(c->RHO[t], a3);
+  if (name == "PSURF") return ok(c->PS[t], a2);
+  if (name == "GRADPX") return ok(c->GX[t], a2);
+  if (name == "GRADPY") return ok(c->GY[t], a2);
+  if (name == "UBTROP") return ok(c->UB[t], a2);
+  if (name == "VBTROP") return ok(c->VB[t], a2);
+  if (name == "PGUESS") return ok(c->PGUESS, a2);
+  if (name == "FW") return ok(c->FW, a2);
+  if (name == "FW_OLD") return ok(c->FW_OLD, a2);
+  if (name == "SHF_QSW") return ok(c->SHF_QSW, a2);
+  if (name == "STF") return (n >= 0 && n < c->h.nt) ? ok(c->STF[n], a2) : 1;
+  if (name == "TFW") return (n >= 0 && n < c->h.nt) ? ok(c->TFW[n], a2) : 1;
+  if (name == "KPP_SRC") return (n >= 0 && n < c->h.nt) ? ok(c->KPP_SRC[n], a3) : 1;
+  if (name == "VDC") return (n == 0 || n == 1) ? ok(c->VDC[n], (long long)c->g.n2 * (c->g.km + 2) * c->g.nblocks) : 1;
+  if (name == "VVC") return ok(c->VVC, a3);
+  if (name == "DH") return ok(c->DH, a2);
+  if (name == "DHU") return ok(c->DHU, a2);
+  if (name == "ZX") return ok(c->ZX, a2);
+  if (name == "ZY") return ok(c->ZY, a2);
+  if (name == "UH") return ok(c->UH, a2);
+  if (name == "VH") return ok(c->VH, a2);
+  if (name == "RHS") return ok(c->RHS, a2);
+  if (name == "centerWgt") return ok(c->centerWgt, a2);
+  if (name == "HBLT") return ok(c->HBLT, a2);
+  if (name == "HMXL") return ok(c->HMXL, a2);
+  if (name == "SMF") return ok(c->d2[n == 0 ? "SMF1" : "SMF2"], a2);
+  if (name == "SMFT") return ok(c->d2[n == 0 ? "SMFT1" : "SMFT2"], a2);
+  auto it = c->d2.find(name);
+  if (it != c->d2.end()) return ok(it->second, a2);
+  return 1;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx **out) {
+  if (!cfg || !out || nranks < 1 || rank < 0 || rank >= nranks) return 1;
+  pop_ctx *c = new pop_ctx();
+  *out = c;
+  c->h.c = *cfg; c->h.rank = rank; c->h.nranks = nranks;
+  if (host_build(c->h)) { c->err = c->h.err; return 1; }
+  c->host_only = (flags & POP_CREATE_HOST_ONLY) != 0;
+  if (c->host_only) return 0;
+  if (cfg->nt != 2) { c->err = "device kernels are built for nt = 2 (T,S) in this round"; return 1; }
+  if (cfg->tadvect != 1) { c->err = "only centered tracer advection is built in this round"; return 1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { c->err = "no HIP device available; libpop_amd has no CPU fallback"; return 1; }
+  HIPCHK(c, hipStreamCreate(&c->stream));
+  c->own_stream = true;
+  HostModel &h = c->h;
+  DevGrid &g = c->g;
+  g.nxb = h.nxb; g.nyb = h.nyb; g.km = h.km; g.nt = h.nt; g.nblocks = h.nblocks;
+  g.n2 = (int)h.n2; g.n3 = (long long)h.n3;
+  g.ib = NGHOST + 1; g.ie = h.nxb - NGHOST; g.jb = NGHOST + 1; g.je = h.nyb - NGHOST;
+  // vertical arrays
+  {
+    struct { const double **dst; std::vector<double> *src; } V[] = {
+      {&g.dz, &h.dz}, {&g.dzw, &h.dzw}, {&g.zt, &h.zt}, {&g.zw, &h.zw}, {&g.c2dz, &h.c2dz}, {&g.dzr, &h.dzr}, {&g.dz2r, &h.dz2r},
+      {&g.dzwr, &h.dzwr}, {&g.pressz, &h.pressz}, {&g.bouss, &h.bouss}, {&g.afac_t, &h.afac_t}, {&g.afac_u, &h.afac_u}};
+    for (auto &v : V) { double *p; if (dev_upload(c, &p, v.src->data(), v.src->size())) return 1; *v.dst = p; }
+  }
+  // 2-D fields: upload the local blocks of every host field
+  for (auto &kv : h.f2) { auto loc = local_part(h, kv.second); double *p; if (dev_upload(c, &p, loc.data(), loc.size())) return 1; c->d2[kv.first] = p; }
+  for (auto &kv : h.i2) { auto loc = local_part(h, kv.second); int *p; if (dev_upload(c, &p, loc.data(), loc.size())) return 1; c->di2[kv.first] = p; }
+#define G2(f) g.f = c->d2[#f]
+  G2(DXU); G2(DYU); G2(DXUR); G2(DYUR); G2(UAREA_R); G2(TAREA_R); G2(TAREA); G2(FCOR); G2(HU); G2(HUR);
+  G2(AU0); G2(AUN); G2(AUE); G2(AUNE); G2(RCALCT); G2(DTN); G2(DTS); G2(DTE); G2(DTW);
+  G2(DUC); G2(DUN); G2(DUS); G2(DUE); G2(DUW); G2(DMC); G2(DMN); G2(DMS); G2(DME); G2(DMW); G2(DUM); G2(KXU); G2(KYU);
+  G2(mMask); G2(CHECKER); G2(CONSTNT); G2(SMF1); G2(SMF2); G2(SMFT1); G2(SMFT2);
+#undef G2
+  g.WNE = c->d2["btropWgtNE"]; g.WEa = c->d2["btropWgtEast"]; g.WNo = c->d2["btropWgtNorth"]; g.WC0 = c->d2["centerWgtIndep"];
+#define GI(f) g.f = c->di2[#f]
+  GI(KMT); GI(KMU); GI(KMTN); GI(KMTS); GI(KMTE); GI(KMTW); GI(KMTEE); GI(KMTNN);
+#undef GI
+  const size_t a2 = h.n2 * h.nblocks, a3 = h.n3 * h.nblocks;
+  for (int t = 0; t < 3; ++t) {
+    for (int n = 0; n < h.nt; ++n) if (dev_alloc(c, &c->TR[n][t], a3)) return 1;
+    if (dev_alloc(c, &c->U[t], a3) || dev_alloc(c, &c->V[t], a3) || dev_alloc(c, &c->RHO[t], a3)) return 1;
+    if (dev_alloc(c, &c->PS[t], a2) || dev_alloc(c, &c->GX[t], a2) || dev_alloc(c, &c->GY[t], a2) || dev_alloc(c, &c->UB[t], a2) || dev_alloc(c, &c->VB[t], a2)) return 1;
+  }
+  for (int n = 0; n < h.nt; ++n)
+    if (dev_alloc(c, &c->STF[n], a2) || dev_alloc(c, &c->TFW[n], a2) || dev_alloc(c, &c->KPP_SRC[n], a3)) return 1;
+  for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->VDC[n], (size_t)(h.km + 2) * a2)) return 1;
+  double **two[] = {&c->PGUESS, &c->FW, &c->FW_OLD, &c->SHF_QSW, &c->DH, &c->DHU, &c->ZX, &c->ZY, &c->UH, &c->VH, &c->W3, &c->W4, &c->RHS,
+                    &c->R, &c->S0, &c->S1, &c->Q, &c->Z, &c->AZ, &c->HBLT, &c->HMXL};
+  for (auto p : two) if (dev_alloc(c, p, a2)) return 1;
+  c->centerWgt = c->d2["centerWgt"];
+  double **three[] = {&c->VVC, &c->E3, &c->F3, &c->S3a, &c->S3b, &c->S3c, &c->S3d};
+  for (auto p : three) if (dev_alloc(c, p, a3)) return 1;
+  c->nchunk = (g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS;
+  if (dev_alloc(c, &c->partial, (size_t)c->nchunk * h.nblocks * 2) || dev_alloc(c, &c->blocksum, (size_t)h.nblocks_tot * 2)) return 1;
+  if (dev_alloc(c, &c->sc, 1)) return 1;
+  { std::vector<int> gid(h.nblocks); for (int lb = 0; lb < h.nblocks; ++lb) gid[lb] = h.local_ids[lb] - 1; if (dev_upload(c, &c->gid, gid.data(), gid.size())) return 1; }
+  // halo plan lists
+  c->ncopy = (int)h.halo.copy_dst.size(); c->nfill = (int)h.halo.fill_dst.size();
+  if (c->ncopy && (dev_upload(c, &c->copy_dst, h.halo.copy_dst.data(), c->ncopy) || dev_upload(c, &c->copy_src, h.halo.copy_src.data(), c->ncopy))) return 1;
+  if (c->nfill && dev_upload(c, &c->fill_dst, h.halo.fill_dst.data(), c->nfill)) return 1;
+  for (auto &pp : h.halo.peers) {
+    DevPeer d; d.rank = pp.rank; d.nsend = (int)pp.send_src.size(); d.nrecv = (int)pp.recv_dst.size();
+    if (d.nsend && dev_upload(c, &d.send_src, pp.send_src.data(), d.nsend)) return 1;
+    if (d.nrecv && dev_upload(c, &d.recv_dst, pp.recv_dst.data(), d.nrecv)) return 1;
+    c->peers.push_back(d);
+  }
+  // vmix_const: constant coefficients for all time (vmix_const.F90:121-122)
+  if (cfg->vmix_choice == 1) {
+    std::vector<double> v((size_t)(h.km + 2) * a2, cfg->const_vdc), w(a3, cfg->const_vvc);
+    HIPCHK(c, hipMemcpy(c->VDC[0], v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->VVC, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (mix_create(c->h, c->g, c->mix, c->allocs, c->err)) return 1;
+  // initial state (initial.F90:1389-1427, 1660-1676): T,S on all three levels, RHO(cur), RHO(old)
+  c->oldt = 0; c->curt = 1; c->newt = 2; c->mixt = 1;
+  for (int t = 0; t < 3; ++t) {
+    HIPCHK(c, hipMemcpy(c->TR[0][t], h.f3["TEMP0"].data(), a3 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->TR[1][t], h.f3["SALT0"].data(), a3 * sizeof(double), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->curt], c->TR[1][c->curt], c->RHO[c->curt]);
+  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->oldt], c->TR[1][c->oldt], c->RHO[c->oldt]);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  h.f3.clear();
+  return 0;
+}
+
+int pop_destroy(pop_ctx *c) {
+  if (!c) return 0;
+  for (void *p : c->allocs) hipFree(p);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+const char *pop_last_error(const pop_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int pop_get_dim(const pop_ctx *c, const char *name) {
+  const std::string n(name);
+  if (n == "nx_block") return c->h.nxb;
+  if (n == "ny_block") return c->h.nyb;
+  if (n == "km") return c->h.km;
+  if (n == "nt") return c->h.nt;
+  if (n == "nblocks") return c->h.nblocks;
+  if (n == "nblocks_tot") return c->h.nblocks_tot;
+  if (n == "nblocks_x") return c->h.nbx;
+  if (n == "nblocks_y") return c->h.nby;
+  if (n == "nghost") return NGHOST;
+  if (n == "oldtime") return c->oldt;
+  if (n == "curtime") return c->curt;
+  if (n == "newtime") return c->newt;
+  if (n == "leapfrogts") return c->leapfrogts;
+  if (n == "avg_ts") return c->avg_ts;
+  if (n == "nsteps_total") return c->nsteps_total;
+  if (n == "nsteps_per_interval") return c->h.nsteps_per_interval;
+  if (n == "rank") return c->h.rank;
+  if (n == "nranks") return c->h.nranks;
+  return -1;
+}
+double pop_get_scalar(const pop_ctx *c, const char *name) {
+  const std::string n(name);
+  if (n == "dtt") return c->h.dtt;
+  if (n == "dtu") return c->h.dtu;
+  if (n == "dtp") return c->h.dtp;
+  if (n == "residualNorm") return c->h.residualNorm;
+  if (n == "convergenceCriterion") return c->h.convergenceCriterion;
+  if (n == "rcheck") return c->h.rcheck;
+  if (n == "rconst") return c->h.rconst;
+  if (n == "uarea_equator") return c->h.uarea_equator;
+  if (n == "rmsResidual") return c->rmsResidual;
+  return NAN;
+}
+int pop_get_block(const pop_ctx *c, int block_id, int *out8, int *i_glob, int *j_glob) {
+  if (block_id < 1 || block_id > c->h.nblocks_tot) return 1;   // get_block: invalid block_id (blocks.F90:309-311)
+  const BlockInfo &B = c->h.all_blocks[block_id - 1];
+  if (out8) { int v[8] = {B.block_id, B.local_id, B.ib, B.ie, B.jb, B.je, B.iblock, B.jblock}; std::copy(v, v + 8, out8); }
+  if (i_glob) std::copy(B.i_glob.begin(), B.i_glob.end(), i_glob);
+  if (j_glob) std::copy(B.j_glob.begin(), B.j_glob.end(), j_glob);
+  return 0;
+}
+int pop_local_block_ids(const pop_ctx *c, int *ids) { std::copy(c->h.local_ids.begin(), c->h.local_ids.end(), ids); return 0; }
+
+long long pop_field_count(const pop_ctx *c, const char *name) {
+  const std::string n(name);
+  const long long a2 = (long long)c->h.n2 * c->h.nblocks, a3 = (long long)c->h.n3 * c->h.nblocks;
+  for (const char *s : {"TRACER", "UVEL", "VVEL", "RHO", "KPP_SRC", "VVC"}) if (n == s) return a3;
+  if (n == "VDC") return (long long)c->h.n2 * (c->h.km + 2) * c->h.nblocks;
+  return a2;
+}
+int pop_get_field(pop_ctx *c, const char *name, int tl, int n, double *host, long long count) {
+  const std::string nm(name);
+  if (c->host_only) {   // host-only contexts expose the init-time 2-D fields of the local blocks
+    std::string key = nm;
+    if (nm == "SMF") key = n == 0 ? "SMF1" : "SMF2";
+    if (nm == "SMFT") key = n == 0 ? "SMFT1" : "SMFT2";
+    auto it = c->h.f2.find(key);
+    if (it == c->h.f2.end()) { c->err = "unknown field " + nm; return 1; }
+    auto loc = local_part(c->h, it->second);
+    if ((long long)loc.size() != count) { c->err = "count mismatch for " + nm; return 1; }
+    std::copy(loc.begin(), loc.end(), host);
+    return 0;
+  }
+  double *p; long long cnt;
+  if (resolve(c, nm, tl, n, &p, &cnt)) { c->err = "unknown field " + nm; return 1; }
+  if (cnt != count) { c->err = "count mismatch for " + nm; return 1; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(host, p, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *host, long long count) {
+  if (need_device(c)) return 1;
+  double *p; long long cnt;
+  if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
+  if (cnt != count) { c->err = std::string("count mismatch for ") + name; return 1; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(p, host, cnt * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+int pop_get_ifield(pop_ctx *c, const char *name, int *host, long long count) {
+  auto it = c->h.i2.find(name);
+  if (it == c->h.i2.end()) { c->err = std::string("unknown integer field ") + name; return 1; }
+  auto loc = local_part(c->h, it->second);
+  if ((long long)loc.size() != count) { c->err = "count mismatch"; return 1; }
+  std::copy(loc.begin(), loc.end(), host);
+  return 0;
+}
+void *pop_field_device_ptr(pop_ctx *c, const char *name, int tl, int n) {
+  if (c->host_only) return nullptr;
+  double *p; long long cnt;
+  return resolve(c, name, tl, n, &p, &cnt) ? nullptr : (void *)p;
+}
+
+// ---- time_manager + set_switches (time_management.F90:1823-1847, 2139-2234) ----------------
+int pop_time_manager(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  c->leapfrogts = 1; c->f_euler_ts = 0; c->avg_ts = 0;
+  c->nsteps_total += 1;
+  if (cf.tmix_opt == 2) { c->nsteps_this_interval += 1; if (c->nsteps_this_interval > c->h.nsteps_per_interval) c->nsteps_this_interval = 1; }
+  if (c->first_step) { c->leapfrogts = 0; c->f_euler_ts = 1; c->first_step = 0; }
+  if (cf.tmix_opt == 1 && c->nsteps_total % cf.time_mix_freq == 0) c->avg_ts = 1;
+  if (cf.tmix_opt == 2) {
+    const int n = c->nsteps_this_interval;
+    if (n == 2) c->avg_ts = 1;
+    else if (n != 1 && (n + 1) % cf.time_mix_freq != 0 && n % cf.time_mix_freq == 0) c->avg_ts = 1;
+  }
+  // step_mod.F90:302-320
+  if (c->leapfrogts) { c->mixt = c->oldt; c->beta = 1.0 / 3.0; c->c2dtt = 2.0 * c->h.dt[1]; c->c2dtu = 2.0 * c->h.dtu; c->c2dtp = 2.0 * c->h.dtp; }
+  else { c->mixt = c->curt; c->beta = 0.5; c->c2dtt = c->h.dt[1]; c->c2dtu = c->h.dtu; c->c2dtp = c->h.dtp; }
+  return 0;
+}
+
+int pop_dhdt(pop_ctx *c) {
+  if (need_device(c)) return 1;
+  ScopedPhase ph(c, "DHDT");
+  hipLaunchKernelGGL(k_dhdt, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, step_params(c),
+                     c->PS[c->curt], c->PS[c->oldt], c->FW_OLD, c->DH, c->DHU);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// launchers of the individual baroclinic phases (also used by pop_time_phase)
+static int phase_vmix(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  const StepParams sp = step_params(c);
+  if (cf.vmix_choice == 1)
+    hipLaunchKernelGGL(k_vmix_const, grid_3d(c), dim3(256), 0, c->stream, c->g, sp, c->TR[0][c->mixt], c->TR[1][c->mixt], c->VDC[0], c->VVC);
+  else {
+    MixState ms{};
+    for (int n = 0; n < 2; ++n) { ms.TMIX[n] = c->TR[n][c->mixt]; ms.KPP_SRC[n] = c->KPP_SRC[n]; ms.STF[n] = c->STF[n]; ms.VDC[n] = c->VDC[n]; }
+    ms.UMIX = c->U[c->mixt]; ms.VMIX = c->V[c->mixt]; ms.UCUR = c->U[c->curt]; ms.VCUR = c->V[c->curt]; ms.RHOMIX = c->RHO[c->mixt];
+    ms.VVC = c->VVC; ms.SHF_QSW = c->SHF_QSW; ms.HBLT = c->HBLT; ms.HMXL = c->HMXL;
+    ms.S3a = c->S3a; ms.S3b = c->S3b; ms.S3c = c->S3c; ms.S3d = c->S3d; ms.E3 = c->E3; ms.F3 = c->F3;
+    if (mix_vmix_coeffs(c->h, c->g, sp, c->mix, ms, c->stream, c->err)) return 1;
+  }
+  return 0;
+}
+static int phase_hmix_tracer(pop_ctx *c) {   // del4 only: biharmonic tracer mixing into S3a, S3b
+  if (c->h.c.hmix_tracer != 4) return 0;
+  return mix_hdifft_del4(c->h, c->g, step_params(c), c->mix, c->TR[0][c->mixt], c->TR[1][c->mixt], c->S3a, c->S3b, c->S3c, c->S3d, c->stream, c->err);
+}
+static int phase_tracer_rhs(pop_ctx *c) {
+  const StepParams sp = step_params(c);
+  TracerRhsArgs a{};
+  for (int n = 0; n < 2; ++n) {
+    a.TCUR[n] = c->TR[n][c->curt]; a.TOLD[n] = c->TR[n][c->oldt]; a.TMIX[n] = c->TR[n][c->mixt]; a.TNEW[n] = c->TR[n][c->newt];
+    a.VDC[n] = c->VDC[sp.nvdc == 2 ? n : 0]; a.KPP_SRC[n] = c->KPP_SRC[n]; a.STF[n] = c->STF[n]; a.TFW[n] = c->TFW[n];
+  }
+  a.HDT[0] = c->S3a; a.HDT[1] = c->S3b;
+  a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
+  a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
+  if (c->h.c.hmix_tracer == 4) hipLaunchKernelGGL(k_tracer_rhs<true>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, a);
+  else hipLaunchKernelGGL(k_tracer_rhs<false>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, a);
+  return 0;
+}
+static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {
+  const StepParams sp = step_params(c);
+  ImpvmixtArgs a{};
+  for (int n = 0; n < 2; ++n) { a.TNEW[n] = c->TR[n][c->newt]; a.TOLD[n] = c->TR[n][c->oldt]; a.TCUR[n] = c->TR[n][c->curt]; a.VDC[n] = c->VDC[sp.nvdc == 2 ? n : 0]; }
+  a.PSFC = psfc; a.POLD = c->PS[c->oldt]; a.PCUR = c->PS[c->curt]; a.PNEW = c->PS[c->newt]; a.PMIX = c->PS[c->mixt];
+  a.E = c->E3; a.F = c->F3; a.RHO = c->RHO[c->newt]; a.c2dtt = c->c2dtt; a.nfirst = 1; a.nlast = 2;
+  return a;
+}
+static int phase_impvmixt_pred(pop_ctx *c) {
+  hipLaunchKernelGGL((k_impvmixt<0, false, false>), grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), impvmixt_args(c, c->PS[c->curt]));
+  return 0;
+}
+static int phase_state_new(pop_ctx *c) {
+  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->newt], c->TR[1][c->newt], c->RHO[c->newt]);
+  return 0;
+}
+static int phase_hmix_momentum(pop_ctx *c) {   // del4 only: biharmonic friction into S3a, S3b
+  if (c->h.c.hmix_momentum != 4) return 0;
+  return mix_hdiffu_del4(c->h, c->g, step_params(c), c->mix, c->U[c->mixt], c->V[c->mixt], c->S3a, c->S3b, c->S3c, c->S3d, c->stream, c->err);
+}
+static int phase_momentum_rhs(pop_ctx *c) {
+  MomentumRhsArgs a{};
+  a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.UOLD = c->U[c->oldt]; a.VOLD = c->V[c->oldt]; a.UMIX = c->U[c->mixt]; a.VMIX = c->V[c->mixt];
+  a.RHOOLD = c->RHO[c->oldt]; a.RHOCUR = c->RHO[c->curt]; a.RHONEW = c->RHO[c->newt]; a.VVC = c->VVC; a.DHU = c->DHU;
+  a.HDU = c->S3a; a.HDV = c->S3b;
+  a.UNEW = c->U[c->newt]; a.VNEW = c->V[c->newt]; a.ZX = c->ZX; a.ZY = c->ZY;
+  if (c->h.c.hmix_momentum == 4) hipLaunchKernelGGL(k_momentum_rhs<true>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), a);
+  else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), a);
+  return 0;
+}
+static int phase_impvmixu(pop_ctx *c) {
+  ImpvmixuArgs a{c->U[c->newt], c->V[c->newt], c->E3, c->U[c->oldt], c->V[c->oldt], c->VVC};
+  hipLaunchKernelGGL(k_impvmixu_norm, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), a);
+  return 0;
+}
+static int phase_correct(pop_ctx *c) {
+  const StepParams sp = step_params(c);
+  if (sp.pavg) hipLaunchKernelGGL((k_impvmixt<1, false, true>), grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, impvmixt_args(c, c->PS[c->newt]));
+  else hipLaunchKernelGGL((k_impvmixt<0, true, true>), grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, impvmixt_args(c, c->PS[c->newt]));
+  return 0;
+}
+static int phase_add_btrop(pop_ctx *c) {
+  hipLaunchKernelGGL(k_add_barotropic, grid_3d(c), dim3(256), 0, c->stream, c->g, c->U[c->newt], c->V[c->newt], c->UB[c->newt], c->VB[c->newt]);
+  return 0;
+}
+
+int pop_baroclinic_driver(pop_ctx *c) {
+  if (need_device(c)) return 1;
+  ScopedPhase ph(c, "BAROCLINIC");
+  const StepParams sp = step_params(c);
+  if (phase_vmix(c) || phase_hmix_tracer(c) || phase_tracer_rhs(c)) return 1;
+  if (sp.pavg) {
+    if (phase_impvmixt_pred(c)) return 1;
+    if (halo_update(c, c->TR[0][c->newt], c->g.km) || halo_update(c, c->TR[1][c->newt], c->g.km)) return 1;
+    if (phase_state_new(c)) return 1;
+  }
+  if (phase_hmix_momentum(c) || phase_momentum_rhs(c) || phase_impvmixu(c)) return 1;
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int pop_solver_run(pop_ctx *c) {
+  if (need_device(c)) return 1;
+  return c->h.c.solver_choice == 2 ? solver_chrongear(c) : solver_pcg(c);
+}
+int pop_solver_get_diagnostics(const pop_ctx *c, int *it, double *rms) {
+  if (it) *it = c->numIterations;
+  if (rms) *rms = c->rmsResidual;
+  return 0;
+}
+
+int pop_barotropic_driver(pop_ctx *c) {
+  if (need_device(c)) return 1;
+  ScopedPhase ph(c, "BAROTROPIC");
+  const StepParams sp = step_params(c);
+  if (halo_update(c, c->ZX, 1) || halo_update(c, c->ZY, 1)) return 1;
+  BtropArgs a{};
+  a.ZX = c->ZX; a.ZY = c->ZY; a.GXC = c->GX[c->curt]; a.GXO = c->GX[c->oldt]; a.GYC = c->GY[c->curt]; a.GYO = c->GY[c->oldt];
+  a.UBO = c->UB[c->oldt]; a.VBO = c->VB[c->oldt]; a.PCUR = c->PS[c->curt]; a.FW = c->FW; a.PGUESS = c->PGUESS;
+  a.UH = c->UH; a.VH = c->VH; a.W3 = c->W3; a.W4 = c->W4; a.RHS = c->RHS; a.centerWgt = c->centerWgt; a.PNEW = c->PS[c->newt];
+  a.GXN = c->GX[c->newt]; a.GYN = c->GY[c->newt]; a.UBN = c->UB[c->newt]; a.VBN = c->VB[c->newt];
+  a.GXR = c->leapfrogts ? c->GX[c->oldt] : c->GX[c->curt]; a.GYR = c->leapfrogts ? c->GY[c->oldt] : c->GY[c->curt];
+  a.scal = &c->sc->xcheck; a.rcheck = c->h.rcheck; a.rconst = c->h.rconst;
+  const dim3 G((c->g.n2 + 255) / 256, c->g.nblocks), B(256);
+  hipLaunchKernelGGL(k_btrop_rhs1, G, B, 0, c->stream, c->g, sp, a);
+  hipLaunchKernelGGL(k_btrop_rhs2, G, B, 0, c->stream, c->g, sp, a);
+  if (halo_update(c, c->RHS, 1)) return 1;
+  const int e = pop_solver_run(c);
+  if (e) return e;
+  hipLaunchKernelGGL(k_dot_partial, grid_2d(c), dim3(POP_RED_THREADS), 0, c->stream, c->g, c->PS[c->newt], c->g.CHECKER, (const double *)nullptr, c->partial);
+  if (reduce_finish<1>(c, FIN_XCHECK)) return 1;
+  hipLaunchKernelGGL(k_btrop_fin1, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_btrop_fin2, G, B, 0, c->stream, c->g, sp, a);
+  if (halo_update(c, c->PS[c->newt], 1) || halo_update(c, c->GX[c->newt], 1) || halo_update(c, c->GY[c->newt], 1)) return 1;
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int pop_baroclinic_correct_adjust(pop_ctx *c) {
+  if (need_device(c)) return 1;
+  ScopedPhase ph(c, "CORRECT_ADJUST");
+  if (phase_correct(c)) return 1;
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int pop_step_tail(pop_ctx *c) {
+  if (need_device(c)) return 1;
+  ScopedPhase ph(c, "3D-UPDATE");
+  const int km = c->g.km;
+  if (halo_update(c, c->UB[c->newt], 1) || halo_update(c, c->VB[c->newt], 1)) return 1;
+  if (halo_update(c, c->U[c->newt], km) || halo_update(c, c->V[c->newt], km) || halo_update(c, c->RHO[c->newt], km)) return 1;
+  for (int n = 0; n < c->h.nt; ++n) if (halo_update(c, c->TR[n][c->newt], km)) return 1;
+  if (phase_add_btrop(c)) return 1;
+  const long long a2 = (long long)c->g.n2 * c->g.nblocks;
+  hipLaunchKernelGGL(k_pguess, dim3((a2 + 255) / 256), dim3(256), 0, c->stream, a2, c->PGUESS, c->PS[c->newt], c->PS[c->curt], c->PS[c->oldt]);
+  if (c->avg_ts) {
+    const int o = c->oldt, cu = c->curt, nw = c->newt;
+    Avg2dArgs a{};
+    a.UBO = c->UB[o]; a.UBC = c->UB[cu]; a.VBO = c->VB[o]; a.VBC = c->VB[cu]; a.GXO = c->GX[o]; a.GXC = c->GX[cu]; a.GYO = c->GY[o]; a.GYC = c->GY[cu];
+    a.PO = c->PS[o]; a.PC = c->PS[cu]; a.PG = c->PGUESS; a.FW_OLD = c->FW_OLD;
+    a.UBN = c->UB[nw]; a.VBN = c->VB[nw]; a.GXN = c->GX[nw]; a.GYN = c->GY[nw]; a.PN = c->PS[nw]; a.FW = c->FW;
+    for (int n = 0; n < 2; ++n) { a.T1O[n] = c->TR[n][o]; a.T1C[n] = c->TR[n][cu]; a.T1N[n] = c->TR[n][nw]; }
+    a.dz1 = c->h.dz[1]; a.grav = GRAV;
+    hipLaunchKernelGGL(k_avg2d, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, a);
+    Avg3dArgs b{};
+    b.UO = c->U[o]; b.UC = c->U[cu]; b.VO = c->V[o]; b.VC = c->V[cu]; b.RO = c->RHO[o]; b.RC = c->RHO[cu]; b.UN = c->U[nw]; b.VN = c->V[nw];
+    for (int n = 0; n < 2; ++n) { b.TO[n] = c->TR[n][o]; b.TC[n] = c->TR[n][cu]; b.TN[n] = c->TR[n][nw]; }
+    hipLaunchKernelGGL(k_avg3d, grid_3d(c), dim3(256), 0, c->stream, c->g, b);
+  } else {
+    HIPCHK(c, hipMemcpyAsync(c->FW_OLD, c->FW, a2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const int tmp = c->oldt; c->oldt = c->curt; c->curt = c->newt; c->newt = tmp;   // step_mod.F90:827-830
+  }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+int pop_step(pop_ctx *c) {
+  if (need_device(c)) return 1;
+  ScopedPhase ph(c, "STEP");
+  int e;
+  if ((e = pop_time_manager(c)) || (e = pop_dhdt(c)) || (e = pop_baroclinic_driver(c)) || (e = pop_barotropic_driver(c)) ||
+      (e = pop_baroclinic_correct_adjust(c)) || (e = pop_step_tail(c))) return e;
+  return 0;
+}
+
+int pop_halo_update(pop_ctx *c, const char *name, int tl, int n) {
+  if (need_device(c)) return 1;
+  double *p; long long cnt;
+  if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
+  const int nz = (int)(cnt / ((long long)c->g.n2 * c->g.nblocks));
+  return halo_update(c, p, nz);
+}
+// host-array halo: valid for single-rank decompositions (all blocks local), used at init time
+int pop_halo_update_host_r8(pop_ctx *c, double *array, int nz, double fill) {
+  if (c->h.nranks != 1) { c->err = "host halo update needs all blocks on one rank"; return 1; }
+  host_halo_r8(c->h, array, nz, fill);
+  return 0;
+}
+int pop_halo_update_host_i4(pop_ctx *c, int *array, int nz, int fill) {
+  if (c->h.nranks != 1) { c->err = "host halo update needs all blocks on one rank"; return 1; }
+  host_halo_i4(c->h, array, nz, fill);
+  return 0;
+}
+int pop_global_sum(pop_ctx *c, const char *name, int tl, int n, const char *mask_name, double *result) {
+  if (need_device(c)) return 1;
+  double *p, *mk = nullptr; long long cnt;
+  if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
+  if (mask_name && resolve(c, mask_name, 0, 0, &mk, &cnt)) { c->err = std::string("unknown mask ") + mask_name; return 1; }
+  hipLaunchKernelGGL(k_dot_partial, grid_2d(c), dim3(POP_RED_THREADS), 0, c->stream, c->g, p, (const double *)nullptr, mk, c->partial);
+  if (reduce_finish<1>(c, FIN_PLAIN)) return 1;
+  SolverScalars s;
+  if (read_scalars(c, &s)) return 1;
+  *result = s.sum0;
+  return 0;
+}
+int pop_state_host(pop_ctx *c, int kk, const double *T, const double *S, double *rho, double *drhodt, double *drhods, long long n) {
+  if (need_device(c)) return 1;
+  return mix_state_host(c->h, c->g, kk, T, S, rho, drhodt, drhods, n, c->stream, c->err);
+}
+
+int pop_set_comm(pop_ctx *c, void *sb, void *rb, void *red, long long buf_doubles, pop_exchange_fn x, pop_allreduce_fn ar, void *user) {
+  c->sendbuf = (double *)sb; c->recvbuf = (double *)rb; c->redbuf = (double *)red; c->comm_doubles = buf_doubles;
+  c->xchg = x; c->allred = ar; c->comm_user = user;
+  return 0;
+}
+int pop_set_stream(pop_ctx *c, void *hip_stream) {   // run on the host framework's stream (e.g. torch's current stream)
+  if (need_device(c)) return 1;
+  if (c->own_stream && c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+  c->stream = (hipStream_t)hip_stream; c->own_stream = false;
+  return 0;
+}
+long long pop_comm_buffer_doubles(const pop_ctx *c) {
+  long long cells = 0;
+  for (auto &p : c->h.halo.peers) cells += (long long)std::max(p.send_src.size(), p.recv_dst.size());
+  return std::max<long long>(cells * std::max(c->h.km, 1), 4LL * c->h.nblocks_tot);
+}
+int pop_halo_plan_counts(const pop_ctx *c, int *nl, int *nf, int *np) {
+  if (nl) *nl = (int)c->h.halo.copy_dst.size();
+  if (nf) *nf = (int)c->h.halo.fill_dst.size();
+  if (np) *np = (int)c->h.halo.peers.size();
+  return 0;
+}
+int pop_halo_plan_peer(const pop_ctx *c, int ip, int *rank, int *ns, int *nr) {
+  if (ip < 0 || ip >= (int)c->h.halo.peers.size()) return 1;
+  const PeerPlan &p = c->h.halo.peers[ip];
+  if (rank) *rank = p.rank;
+  if (ns) *ns = (int)p.send_src.size();
+  if (nr) *nr = (int)p.recv_dst.size();
+  return 0;
+}
+int pop_halo_plan_lists(const pop_ctx *c, int ip, int *send_src, int *recv_dst) {
+  if (ip < 0 || ip >= (int)c->h.halo.peers.size()) return 1;
+  const PeerPlan &p = c->h.halo.peers[ip];
+  if (send_src) std::copy(p.send_src.begin(), p.send_src.end(), send_src);
+  if (recv_dst) std::copy(p.recv_dst.begin(), p.recv_dst.end(), recv_dst);
+  return 0;
+}
+int pop_halo_plan_local(const pop_ctx *c, int *dst, int *src, int *fill_dst) {
+  const HaloPlan &P = c->h.halo;
+  if (dst) std::copy(P.copy_dst.begin(), P.copy_dst.end(), dst);
+  if (src) std::copy(P.copy_src.begin(), P.copy_src.end(), src);
+  if (fill_dst) std::copy(P.fill_dst.begin(), P.fill_dst.end(), fill_dst);
+  return 0;
+}
+
+int pop_timers_reset(pop_ctx *c) { c->timers.clear(); c->timing = true; return 0; }
+int pop_timer_ms(pop_ctx *c, const char *name, double *ms, int *calls) {
+  auto it = c->timers.find(name);
+  if (it == c->timers.end()) { if (ms) *ms = 0; if (calls) *calls = 0; return 1; }
+  if (ms) *ms = it->second.ms;
+  if (calls) *calls = it->second.calls;
+  return 0;
+}
+int pop_device_sync(pop_ctx *c) {
+  if (need_device(c)) return 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+// time `reps` launches of one kernel phase with HIP events on the launch stream (state is left as
+// the phase leaves it; callers use it between steps for roofline measurement only)
+int pop_time_phase(pop_ctx *c, const char *phase, int reps, double *avg_ms) {
+  if (need_device(c)) return 1;
+  const std::string p(phase);
+  int (*fn)(pop_ctx *) = nullptr;
+  if (p == "vmix") fn = phase_vmix;
+  else if (p == "tracer_rhs") fn = phase_tracer_rhs;
+  else if (p == "impvmixt") fn = phase_impvmixt_pred;
+  else if (p == "state") fn = phase_state_new;
+  else if (p == "momentum_rhs") fn = phase_momentum_rhs;
+  else if (p == "impvmixu") fn = phase_impvmixu;
+  else if (p == "correct") fn = phase_correct;
+  else if (p == "add_btrop") fn = phase_add_btrop;
+  else if (p == "hmix_tracer") fn = phase_hmix_tracer;
+  else if (p == "hmix_momentum") fn = phase_hmix_momentum;
+  if (!fn) { c->err = "unknown phase " + p; return 1; }
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  if (fn(c)) return 1;   // warm
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; ++r) if (fn(c)) return 1;
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *avg_ms = ms / std::max(reps, 1);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// pop_internal.hpp -- internal types of libpop_amd (MI355X-native POP2 dynamics core).
+//
+// Data layout on the device (DESIGN.md "Layout"): every field is stored per rank as
+// (i, j, k, local_block) with i fastest -- the reference's own block layout
+// (source/prognostic.F90:47-66) -- so one wavefront reads 64 consecutive i of one level
+// (512 B, fully coalesced) and a thread owns a water column and marches k in registers.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/pop_amd.h"
+
+namespace pop {
+
+constexpr int NGHOST = 2;          // blocks.F90:51-56
+constexpr double GRAV = 980.6;     // pop_constants.F90:235 (non-CCSMCOUPLED)
+constexpr double OMEGA = 7.292123625e-5;
+constexpr double RADIUS = 6370.0e5;
+constexpr int MAXNT = 8;
+
+struct BlockInfo {                 // blocks.F90:30-39 type(block)
+  int block_id, local_id, ib, ie, jb, je, iblock, jblock;
+  std::vector<int> i_glob, j_glob;
+};
+
+// ---- halo plan (mpi/POP_HaloMod.F90:142-1640 POP_HaloCreate, restated as flat index lists)
+struct PeerPlan {
+  int rank;
+  std::vector<int> send_src;   // local 2-D cell index (block*n2 + j*nxb + i) to pack, in message order
+  std::vector<int> recv_dst;   // local 2-D cell index to unpack into, in message order
+};
+struct HaloPlan {
+  std::vector<int> copy_dst, copy_src;  // ghost <- interior copies between blocks of this rank
+  std::vector<int> fill_dst;            // ghosts outside closed boundaries / padding: fill value
+  std::vector<PeerPlan> peers;
+  long long max_msg_cells = 0;          // sum over peers of max(send, recv) cells
+};
+
+// ---- host-side model: everything init-time (restates grid.F90, hmix_del*.F90 init,
+//      POP_SolversInit, init_barotropic, init_ts) on the local blocks of this rank
+struct HostModel {
+  pop_config c{};
+  int rank = 0, nranks = 1;
+  int nxb = 0, nyb = 0, km = 0, nt = 2;
+  int nbx = 0, nby = 0, nblocks_tot = 0, nblocks = 0;   // nblocks = local
+  size_t n2 = 0, n3 = 0;
+  std::vector<BlockInfo> all_blocks;      // every block of the decomposition (1-based id = index+1)
+  std::vector<int> local_ids;             // global ids (1-based) of this rank's blocks
+  std::vector<int> block_owner;           // rank owning block id-1
+  std::vector<int> block_local;           // local index of block id-1 on its owner
+  // vertical grid, 1-based with slot 0 (dzw(0), dzwr(0))
+  std::vector<double> dz, dzw, zt, zw, c2dz, dzr, dz2r, dzwr, pressz, bouss, dt, afac_t, afac_u;
+  // named 2-D / 3-D fields on local blocks
+  std::map<std::string, std::vector<double>> f2;   // (nxb,nyb,nblocks)
+  std::map<std::string, std::vector<int>> i2;
+  std::map<std::string, std::vector<double>> f3;   // (nxb,nyb,km,nblocks), initial state only
+  double uarea_equator = 0, residualNorm = 0, convergenceCriterion = 0, rcheck = 0, rconst = 0;
+  double dtt = 0, dtu = 0, dtp = 0;
+  int nsteps_per_interval = 0;
+  HaloPlan halo;
+  std::string err;
+
+  std::vector<double> &F(const std::string &n) { return f2[n]; }
+  std::vector<int> &I(const std::string &n) { return i2[n]; }
+};
+
+int host_build(HostModel &h);            // host_setup.cpp
+void build_halo_plan(HostModel &h);      // halo_plan.cpp
+void host_halo_r8(const HostModel &h, double *a, int nz, double fill);   // single-rank host halo
+void host_halo_i4(const HostModel &h, int *a, int nz, int fill);
+double host_global_sum(const HostModel &h, const double *a, const double *mask);
+
+}  // namespace pop

@@ -65,7 +65,7 @@ def named_config(name, **kw):
         c = base_config(nx_global=192, ny_global=128, km=20, block_size_x=16, block_size_y=16,
                         vmix_choice=2, steps_per_day=24, am=1.0e8, ah=1.0e7)
     elif name == "tiny":    # small multi-block case for fast CPU parity
-        c = base_config(nx_global=48, ny_global=40, km=12, block_size_x=12, block_size_y=10,
+        c = base_config(nx_global=48, ny_global=40, km=16, block_size_x=12, block_size_y=10,
                         vmix_choice=1, steps_per_day=24, am=3.0e9, ah=1.0e7)
     elif name == "gx3v7":
         c = base_config(nx_global=100, ny_global=116, km=60, block_size_x=100, block_size_y=116,

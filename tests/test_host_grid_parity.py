@@ -1,0 +1,74 @@
+"""Host logic of libpop_amd (no GPU): block decomposition, internal grid, masks, operator
+coefficients and scalars must equal the CPU oracle bit for bit (SURVEY.md 8a rows a1, a2:
+KMT/KMU and index maps bit-exact; all init-time fields are pure functions of the global index)."""
+import numpy as np
+import pytest
+
+from popcfg import named_config
+from orclib import Oracle
+
+FIELDS = ["ULAT", "ULON", "TLAT", "HTN", "HTE", "HUS", "HUW", "DXU", "DYU", "DXT", "DYT", "DXUR", "DYUR",
+          "UAREA", "TAREA", "UAREA_R", "TAREA_R", "AU0", "AUN", "AUE", "AUNE", "FCOR", "FCORT", "HU", "HUR", "HT",
+          "RCALCT", "RCALCU", "AMF", "AHF", "DTN", "DTS", "DTE", "DTW", "DUC", "DUN", "DUS", "DUE", "DUW", "DMC", "DMN",
+          "DMS", "DME", "DMW", "DUM", "KXU", "KYU", "btropWgtNE", "btropWgtEast", "btropWgtNorth", "centerWgtIndep",
+          "mMask", "CHECKER", "CONSTNT"]
+IFIELDS = ["KMT", "KMU", "KMTN", "KMTS", "KMTE", "KMTW", "KMTEE", "KMTNN"]
+
+
+@pytest.mark.parametrize("name,kw", [("tiny", {}), ("test", {}), ("gx3v7", {}), ("tiny", {"lvariable_hmix": 1}),
+                                     ("tiny", {"ew_boundary": 0}), ("tiny", {"tmix_opt": 1})])
+def test_host_fields_bit_exact(pkg, orclib_built, name, kw):
+    cfg = named_config(name, **kw)
+    m = pkg.PopModel(cfg, host_only=True)
+    o = Oracle(cfg)
+    assert (m.nxb, m.nyb, m.km, m.nblocks) == (o.nxb, o.nyb, o.km, o.nblocks)
+    for f in IFIELDS:
+        assert np.array_equal(m.geti(f), o.i2(f)), f
+    for f in FIELDS:
+        a, b = m.get(f), o.f2(f)
+        assert np.array_equal(a, b), "%s max diff %g" % (f, np.abs(a - b).max())
+    for n in (0, 1):
+        assert np.array_equal(m.get("SMF", 1, n), o.f2("SMF", 1, n))
+        assert np.array_equal(m.get("SMFT", 1, n), o.f2("SMFT", 1, n))
+    for s in ("dtt", "dtu", "dtp", "residualNorm", "convergenceCriterion", "rcheck", "rconst", "uarea_equator"):
+        assert m.scalar(s) == o.scalar(s), s
+    assert m.dim("nsteps_per_interval") == o.dim("nsteps_per_interval")
+    # block table (blocks.F90 create_blocks): ids, extents and global index maps
+    ig, jg = o.ivec("i_glob", o.nxb * o.nblocks), o.ivec("j_glob", o.nyb * o.nblocks)
+    for bid in range(1, m.nblocks_tot + 1):
+        blk = m.get_block(bid)
+        assert blk["block_id"] == bid and blk["local_id"] == bid
+        assert np.array_equal(blk["i_glob"], ig[(bid - 1) * o.nxb: bid * o.nxb])
+        assert np.array_equal(blk["j_glob"], jg[(bid - 1) * o.nyb: bid * o.nyb])
+        assert (blk["ib"], blk["ie"], blk["jb"], blk["je"]) == (3, m.nxb - 2, 3, m.nyb - 2)
+    m.close()
+    o.close()
+
+
+def test_host_only_context_refuses_compute(pkg):
+    """The product has no CPU fallback: compute entry points must fail loudly without a GPU."""
+    m = pkg.PopModel(named_config("tiny"), host_only=True)
+    for fn in (m.dhdt, m.baroclinic_driver, m.barotropic_driver, m.baroclinic_correct_adjust, m.step_tail, m.step,
+               m.solver_run):
+        with pytest.raises(pkg.PopError, match="no CPU fallback|host-only"):
+            fn()
+    m.close()
+
+
+def test_abi_exports_every_declared_symbol(pkg):
+    L = pkg.lib()
+    names = pkg.abi_symbols()
+    assert len(names) >= 35
+    for s in names:
+        assert hasattr(L, s), s
+
+
+def test_bad_configs_are_rejected(pkg):
+    with pytest.raises(pkg.PopError, match="divide"):
+        pkg.PopModel(named_config("tiny", block_size_x=13), host_only=True)
+    with pytest.raises(pkg.PopError, match="nt"):
+        pkg.PopModel(named_config("tiny", nt=1), host_only=True)
+    m = pkg.PopModel(named_config("tiny"), host_only=True)
+    assert m.L.pop_get_block(m.h, 0, None, None, None) != 0          # get_block: invalid block_id
+    assert m.L.pop_get_block(m.h, m.nblocks_tot + 1, None, None, None) != 0
+    m.close()
