@@ -1,6 +1,465 @@
-// kernels_kpp.hpp -- KPP vertical mixing (placeholder until the KPP kernels land)
+// kernels_kpp.hpp -- KPP vertical mixing (Large, McWilliams & Doney 1994) as the reference's
+// native path computes it (the `.not. lcvmix` branches of source/vmix_kpp.F90).
+//
+// Column mapping: one thread per (i,j) of the WHOLE block array (ghost columns included,
+// because the boundary-layer depth is smoothed horizontally and the viscosity is averaged to U
+// points afterwards).  Six launches per step:
+//   k_kpp_buoydiff   buoydiff      :3575-3621   DBLOC, DBSFC (O(km*kref) EOS evaluations/column)
+//   k_kpp_interior   ri_iwmix      :1505-1603,1774-1929 + ddmix :3404-3497  interior VISC, VDC
+//   k_kpp_ushear     bldepth       :2293-2325   reference-depth shear^2 at U points
+//   k_kpp_bldepth    bldepth       :2140-2700   bulk Richardson march -> HBLT, KBL (unsmoothed)
+//   k_kpp_blmix      smooth_hblt   :3797-3870 + blmix :2900-3222 + convection / masks :1218-1262
+//                                  + non-local source :1283-1306
+//   k_kpp_vvc        tgrid_to_ugrid of VISC -> VVC    :1253-1262
+// Selections: no tidal / near-inertial-wave / Langmuir mixing, no short-wave penetration
+// (lshort_wave=.false.), lcheckekmo=.false., SMFT available, no partial bottom cells.
+// Integer powers use the usual expansion x**3=(x*x)*x, x**4=(x*x)*(x*x).
+// Diagnostic-only outputs of the reference routine (HMXL, HMXL_DR, tavg fields) are not computed.
 #pragma once
+
 namespace pop {
-inline int kpp_create(HostModel &, const DevGrid &, MixDev &, std::vector<void *> &, std::string &err) { err = "KPP vertical mixing is not built yet"; return 1; }
-inline int kpp_vmix_coeffs(const HostModel &, const DevGrid &, const StepParams &, const MixDev &, const MixState &, hipStream_t, std::string &err) { err = "KPP not built"; return 1; }
+
+struct KppDev {
+  const double *zgrid, *hwide, *bckgrnd_vdc, *bckgrnd_vvc;   // zgrid/hwide: 0..km+1
+  const int *kref;                                          // 1..km: surface-layer reference level
+  double *HBLT0, *USTAR, *BFSFC;                              // 2-D scratch
+  int *KBL0, *KBL;
+  double Vtc, cg, rich_mix;
+  int lrich, ldbl_diff, nsmooth;
+};
+
+constexpr double KPP_EPSSFC = 0.1, KPP_RIINFTY = 0.8, KPP_RRHO0 = 2.55, KPP_DSFMAX = 1.0, KPP_CSTAR = 10.0;
+constexpr double KPP_ZETA_M = -0.2, KPP_ZETA_S = -1.0, KPP_C_M = 8.38, KPP_C_S = 98.96, KPP_A_M = 1.26, KPP_A_S = -28.86;
+constexpr double KPP_CONCV = 1.7, KPP_VONKAR = 0.4, KPP_EPS = 1.0e-10, KPP_EPS2 = 1.0e-20, KPP_RICR = 0.3;
+
+// wscale (vmix_kpp.F90:3296-3337)
+template <bool WANT_M>
+__device__ __forceinline__ void kpp_wscale(double sigma, double hbl, double ustar, double bfsfc, double &wm, double &ws) {
+  const double zetah = sigma * hbl * KPP_VONKAR * bfsfc;
+  const double u3 = (ustar * ustar) * ustar;
+  const double zeta = zetah / (u3 + KPP_EPS);
+  if (WANT_M) {
+    if (zeta >= 0.0) wm = KPP_VONKAR * ustar / (1.0 + 5.0 * zeta);
+    else if (zeta >= KPP_ZETA_M) wm = KPP_VONKAR * ustar * pow(1.0 - 16.0 * zeta, 0.25);
+    else wm = KPP_VONKAR * pow(KPP_A_M * u3 - KPP_C_M * zetah, 1.0 / 3.0);
+  }
+  if (zeta >= 0.0) ws = KPP_VONKAR * ustar / (1.0 + 5.0 * zeta);
+  else if (zeta >= KPP_ZETA_S) ws = KPP_VONKAR * ustar * sqrt(1.0 - 16.0 * zeta);
+  else ws = KPP_VONKAR * pow(KPP_A_S * u3 - KPP_C_S * zetah, 1.0 / 3.0);
+}
+
+__device__ __forceinline__ double tmask(double t) { return (t < -2.0) ? -2.0 : t; }
+
+// ---- buoydiff ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_buoydiff(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
+               double *__restrict__ DBLOC, double *__restrict__ DBSFC) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int km = g.km;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  DBSFC[c.base3] = 0.0;
+  double t_km1 = tmask(T[c.base3]), s_km1 = S[c.base3];
+  for (int k = 2; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    const MwjfP P = mwjf_level(g.pressz[k]);
+    const double t_k = tmask(T[o]), s_k = S[o];
+    const double rhokm = mwjf_rho<false>(P, t_km1, s_km1, nullptr, nullptr);
+    const double rhok = mwjf_rho<false>(P, t_k, s_k, nullptr, nullptr);
+    const double surfthick = KPP_EPSSFC * g.zt[k];
+    const int kref = kp.kref[k];
+    const long long orf = c.base3 + (long long)(kref - 1) * n2;
+    double rhoavg = mwjf_rho<false>(P, tmask(T[orf]), S[orf], nullptr, nullptr);
+    if (kref != 1) {
+      rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
+      for (int kt = 1; kt <= kref - 1; ++kt) {
+        const long long ot = c.base3 + (long long)(kt - 1) * n2;
+        rhoavg = rhoavg + g.dz[kt] * mwjf_rho<false>(P, tmask(T[ot]), S[ot], nullptr, nullptr);
+      }
+      rhoavg = rhoavg / surfthick;
+    }
+    double dbs = 0.0, dbl = 0.0;
+    if (rhok != 0.0) { dbs = GRAV * (1.0 - rhoavg / rhok); dbl = GRAV * (1.0 - rhokm / rhok); }
+    if (k - 1 >= kmt) dbl = 0.0;
+    DBSFC[o] = dbs;
+    DBLOC[o - n2] = dbl;
+    t_km1 = t_k; s_km1 = s_k;
+  }
+  DBLOC[c.base3 + (long long)(km - 1) * n2] = 0.0;
+}
+
+// ---- ri_iwmix + ddmix: interior coefficients -----------------------------------------------
+// VISC: (nxb,nyb,km,block) scratch; VDC1/VDC2: (nxb,nyb,0:km+1,block), levels 0 and km+1 stay 0.
+// RIW: scratch for the (smoothed) Richardson number.
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_interior(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
+               const double *__restrict__ U, const double *__restrict__ V, const double *__restrict__ DBLOC,
+               double *__restrict__ RIW, double *__restrict__ VISC, double *__restrict__ VDC1, double *__restrict__ VDC2) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int km = g.km, nxb = g.nxb;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  const bool edge = (c.i == 0 || c.j == 0);   // ugrid_to_tgrid zeroes the first row and column
+  // pass 1: local Richardson number
+  double prev = 0.0;   // WORK0(k-1)
+  for (int k = 1; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    double vsh = 0.0;
+    if (k < km && !edge) {
+      auto sh = [&](long long q) { const double du = U[q] - U[q + n2], dv = V[q] - V[q + n2]; return du * du + dv * dv; };
+      vsh = 0.25 * sh(o) + 0.25 * sh(o - nxb) + 0.25 * sh(o - 1) + 0.25 * sh(o - 1 - nxb);
+    }
+    const double ri = DBLOC[o] * (kp.zgrid[k] - kp.zgrid[k + 1]) / (vsh + KPP_EPS);
+    const double w0 = (k <= kmt) ? ri : prev;
+    RIW[o] = w0;
+    prev = w0;
+  }
+  // pass 2: 1-2-1 vertical smoothing, nsmooth times (in place, old values carried)
+  for (int n = 0; n < kp.nsmooth; ++n) {
+    double w1 = 0.25 * RIW[c.base3];
+    if (kmt >= 3) {
+      double cur = RIW[c.base3];
+      for (int k = 1; k <= km; ++k) {
+        const long long o = c.base3 + (long long)(k - 1) * n2;
+        const double nxt = (k < km) ? RIW[o + n2] : cur;    // WORK0(km+1) = WORK0(km) (old value)
+        RIW[o] = w1 + 0.5 * cur + 0.25 * nxt;
+        w1 = 0.25 * cur;
+        cur = nxt;
+      }
+    }
+  }
+  // pass 3: coefficients (+ double diffusion)
+  const long long vb = ((long long)c.b * (km + 2)) * n2 + c.p2;
+  double ta_u = 0.0, sb_u = 0.0, t_k = T[c.base3], s_k = S[c.base3];
+  if (kp.ldbl_diff) { const MwjfP P = mwjf_level(g.pressz[1]); (void)mwjf_rho<true>(P, tmask(t_k), s_k, &ta_u, &sb_u); }
+  for (int k = 1; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    double fri = fmax(RIW[o], 0.0) / KPP_RIINFTY;
+    fri = fmin(fri, 1.0);
+    double visc, vd1 = 0.0, vd2 = 0.0;
+    if (kp.lrich) {
+      const double f = 1.0 - fri * fri;
+      const double f3 = (f * f) * f;
+      visc = kp.bckgrnd_vvc[k] + kp.rich_mix * f3;
+      if (k < km) { vd2 = kp.bckgrnd_vdc[k] + kp.rich_mix * f3; vd1 = vd2; }
+    } else {
+      visc = kp.bckgrnd_vvc[k];
+      if (k < km) { vd2 = kp.bckgrnd_vdc[k]; vd1 = vd2; }
+    }
+    if (k >= kmt) { visc = 0.0; vd1 = 0.0; vd2 = 0.0; }
+    if (kp.ldbl_diff) {
+      double alphadt = 0.0, betads = 0.0, ta_n = 0.0, sb_n = 0.0, t_n = 0.0, s_n = 0.0;
+      if (k < km) {
+        t_n = T[o + n2]; s_n = S[o + n2];
+        const MwjfP P = mwjf_level(g.pressz[k + 1]);
+        (void)mwjf_rho<true>(P, tmask(t_n), s_n, &ta_n, &sb_n);
+        alphadt = -0.5 * (ta_u + ta_n) * (t_k - t_n);
+        betads = 0.5 * (sb_u + sb_n) * (s_k - s_n);
+      }
+      if (alphadt > betads && betads > 0.0) {
+        const double rrho = fmin(alphadt / betads, KPP_RRHO0);
+        const double f = 1.0 - (rrho - 1.0) / (KPP_RRHO0 - 1.0);
+        const double diffdd = KPP_DSFMAX * ((f * f) * f);
+        vd1 = vd1 + 0.7 * diffdd; vd2 = vd2 + diffdd;
+      }
+      double rrho = 0.0, diffdd = 0.0, prandtl = 0.0;
+      if (alphadt < 0.0 && betads < 0.0 && alphadt > betads) {
+        rrho = alphadt / betads;
+        diffdd = 1.5e-2 * 0.909 * exp(4.6 * exp(-0.54 * (1.0 / rrho - 1.0)));
+        prandtl = 0.15 * rrho;
+      }
+      if (rrho > 0.5) prandtl = (1.85 - 0.85 / rrho) * rrho;
+      vd1 = vd1 + diffdd; vd2 = vd2 + prandtl * diffdd;
+      ta_u = ta_n; sb_u = sb_n; t_k = t_n; s_k = s_n;
+    }
+    VISC[o] = visc;
+    VDC1[vb + (long long)k * n2] = vd1;
+    VDC2[vb + (long long)k * n2] = vd2;
+  }
+}
+
+// ---- bldepth, part 1: shear^2 between the surface-layer reference velocity and level kl, at U points
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_ushear(DevGrid g, KppDev kp, const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ WU) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int km = g.km;
+  const long long n2 = g.n2;
+  for (int kl = 2; kl <= km; ++kl) {
+    const long long o = c.base3 + (long long)(kl - 1) * n2;
+    const double surfthick = KPP_EPSSFC * g.zt[kl];
+    const int kref = kp.kref[kl];
+    double uref, vref;
+    if (kref > 1) {
+      const long long orf = c.base3 + (long long)(kref - 1) * n2;
+      uref = U[orf] * (surfthick - g.zw[kref - 1]);
+      vref = V[orf] * (surfthick - g.zw[kref - 1]);
+      for (int kt = 1; kt <= kref - 1; ++kt) {
+        const long long ot = c.base3 + (long long)(kt - 1) * n2;
+        uref = uref + g.dz[kt] * U[ot];
+        vref = vref + g.dz[kt] * V[ot];
+      }
+      uref = uref / surfthick; vref = vref / surfthick;
+    } else { uref = U[c.base3]; vref = V[c.base3]; }
+    const double du = uref - U[o], dv = vref - V[o];
+    WU[o] = du * du + dv * dv;
+  }
+}
+
+// ---- bldepth, part 2: bulk Richardson number march -> unsmoothed HBLT, KBL ---------------------
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
+              const double *__restrict__ STF1, const double *__restrict__ STF2, const double *__restrict__ DBLOC,
+              const double *__restrict__ DBSFC, const double *__restrict__ WU) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int km = g.km, nxb = g.nxb;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  const bool edge = (c.i == 0 || c.j == 0);
+  const double s1 = g.SMFT1[c.q2], s2 = g.SMFT2[c.q2];
+  double ustar = sqrt(sqrt(s1 * s1 + s2 * s2));
+  ustar = fmax(ustar, KPP_EPS);
+  double talpha, sbeta;
+  const MwjfP P1 = mwjf_level(g.pressz[1]);
+  const double rho1 = mwjf_rho<true>(P1, tmask(T[c.base3]), S[c.base3], &talpha, &sbeta);
+  double bo = 0.0;
+  if (rho1 != 0.0) bo = GRAV * (-talpha * STF1[c.q2] - sbeta * STF2[c.q2]) / rho1;
+  int kbl = (kmt > 1) ? kmt : 1;
+  double hblt = -kp.zgrid[kbl];
+  double rib_upper = 0.0, rib_up = 0.0, z_upper = 0.0, z_up = kp.zgrid[1];
+  double bfsfc = bo;
+  for (int kl = 2; kl <= km; ++kl) {
+    const long long o = c.base3 + (long long)(kl - 1) * n2;
+    const double surfthick = KPP_EPSSFC * g.zt[kl];
+    const double zkl = -kp.zgrid[kl];
+    double vshear = 0.0;
+    if (!edge) vshear = fmax(fmax(WU[o], WU[o - 1]), fmax(WU[o - nxb], WU[o - 1 - nxb]));
+    bfsfc = bo;
+    const double stable = (bfsfc >= 0.0) ? 1.0 : 0.0;
+    bfsfc = bfsfc + stable * KPP_EPS;
+    double wm_unused = 0.0, ws;
+    kpp_wscale<false>(KPP_EPSSFC, zkl, ustar, bfsfc, wm_unused, ws);
+    const double db = DBLOC[o];
+    const double bfr = sqrt(0.5 * (db + fabs(db) + KPP_EPS2) / (kp.zgrid[kl] - kp.zgrid[kl + 1]));
+    const double zref = -surfthick / 2.0;
+    const double wmm = zkl * ws * bfr * ((kp.Vtc / KPP_RICR) * fmax(2.1 - 200.0 * bfr, KPP_CONCV));
+    const double wk = (kmt >= kl) ? (zref - kp.zgrid[kl]) * DBSFC[o] : 0.0;
+    const double rib_dn = wk / (vshear + wmm + KPP_EPS);
+    if (kbl == kmt && rib_dn > KPP_RICR) {
+      const double slope_up = (rib_upper - rib_up) / (z_up - z_upper);
+      const double d = z_up + zkl;
+      const double a_co = (rib_dn - rib_up - slope_up * (zkl + z_up)) / (d * d);
+      const double b_co = slope_up + 2.0 * a_co * z_up;
+      const double c_co = rib_up + z_up * (a_co * z_up + slope_up) - KPP_RICR;
+      const double sqrt_arg = b_co * b_co - 4.0 * a_co * c_co;
+      if ((fabs(b_co) > KPP_EPS && fabs(a_co) / fabs(b_co) <= KPP_EPS) || sqrt_arg <= 0.0)
+        hblt = -z_up + (z_up + zkl) * (KPP_RICR - rib_up) / (rib_dn - rib_up);
+      else hblt = (-b_co + sqrt(sqrt_arg)) / (2.0 * a_co);
+      kbl = kl;
+    }
+    rib_upper = rib_up; rib_up = rib_dn;
+    z_upper = z_up; z_up = kp.zgrid[kl];
+  }
+  kp.HBLT0[c.q2] = hblt;
+  kp.KBL0[c.q2] = kbl;
+  kp.USTAR[c.q2] = ustar;
+  kp.BFSFC[c.q2] = bfsfc;    // value of the last kl pass (vmix_kpp.F90: no short-wave branch)
+}
+
+// ---- smooth_hblt + blmix + interior convection + masks + non-local source -------------------
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLOC, const double *__restrict__ STF1,
+            const double *__restrict__ STF2, double *__restrict__ VISC, double *__restrict__ VDC1, double *__restrict__ VDC2,
+            double *__restrict__ SRC1, double *__restrict__ SRC2, double *__restrict__ HBLT_OUT) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int km = g.km, nxb = g.nxb;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  const double *zgrid = kp.zgrid, *hwide = kp.hwide;
+  // smooth_hblt(overwrite_hblt=.true., use_hmxl=.false.)
+  double w2 = kp.HBLT0[c.q2];
+  int kbl = kp.KBL0[c.q2];
+  const bool inner = (c.i >= 1 && c.i <= g.nxb - 2 && c.j >= 1 && c.j <= g.nyb - 2);
+  if (inner && kmt != 0) {
+    double cw = 0.125, ce = 0.125, cn = 0.125, cs = 0.125, cc = 0.5;
+    if (g.KMT[c.q2 - 1] == 0) { cc = cc + cw; cw = 0.0; }
+    if (g.KMT[c.q2 + 1] == 0) { cc = cc + ce; ce = 0.0; }
+    if (g.KMT[c.q2 - nxb] == 0) { cc = cc + cs; cs = 0.0; }
+    if (g.KMT[c.q2 + nxb] == 0) { cc = cc + cn; cn = 0.0; }
+    w2 = cw * kp.HBLT0[c.q2 - 1] + ce * kp.HBLT0[c.q2 + 1] + cs * kp.HBLT0[c.q2 - nxb] + cn * kp.HBLT0[c.q2 + nxb] + cc * kp.HBLT0[c.q2];
+  }
+  if (inner && kmt >= 1 && w2 > -zgrid[kmt]) w2 = -zgrid[kmt];
+  const double hblt = fmax(w2, -zgrid[1]);
+  if (inner && kmt != 0)
+    for (int k = 1; k <= km; ++k)
+      if (hblt > -zgrid[k - 1] && hblt <= -zgrid[k]) kbl = max(k, 2);
+  HBLT_OUT[c.q2] = hblt;
+  kp.KBL[c.q2] = kbl;
+  const double ustar = kp.USTAR[c.q2];
+  double bfsfc = kp.BFSFC[c.q2];
+  const double stable = (bfsfc >= 0.0) ? 1.0 : 0.0;
+  bfsfc = bfsfc + stable * KPP_EPS;
+  // blmix: matching at the boundary-layer base
+  double wm, ws;
+  kpp_wscale<true>(KPP_EPSSFC, hblt, ustar, bfsfc, wm, ws);
+  const double casea = 0.5 + ((-zgrid[kbl] - 0.5 * hwide[kbl] - hblt) >= 0.0 ? 0.5 : -0.5);
+  const int nc = (casea > 0.5) ? 1 : 0;
+  const int kn = nc * (kbl - 1) + (1 - nc) * kbl;
+  const double u2 = ustar * ustar;
+  const double f1 = stable * 5.0 * bfsfc / (u2 * u2 + KPP_EPS);
+  const long long vb = ((long long)c.b * (km + 2)) * n2 + c.p2;
+  auto visc_at = [&](int k) { return (k >= 1 && k <= km) ? VISC[c.base3 + (long long)(k - 1) * n2] : 0.0; };
+  double gat1[3] = {0.0, 0.0, 0.0}, dat1[3] = {0.0, 0.0, 0.0};
+  if (kn >= 1 && kn <= km) {
+    const int k = kn;
+    const double dh = 0.5 * hwide[k] - zgrid[k] - hblt;
+    const double R = 1.0 - dh / hwide[k];
+    double fm[3], f0[3], fp[3];
+    fm[0] = visc_at(k - 1); f0[0] = visc_at(k); fp[0] = visc_at(k + 1);
+    fm[1] = VDC2[vb + (long long)(k - 1) * n2]; f0[1] = VDC2[vb + (long long)k * n2]; fp[1] = VDC2[vb + (long long)(k + 1) * n2];
+    fm[2] = VDC1[vb + (long long)(k - 1) * n2]; f0[2] = VDC1[vb + (long long)k * n2]; fp[2] = VDC1[vb + (long long)(k + 1) * n2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double up = (fm[q] - f0[q]) / hwide[k], dn = (f0[q] - fp[q]) / hwide[k + 1];
+      const double Pq = 0.5 * ((1.0 - R) * (up + fabs(up)) + R * (dn + fabs(dn)));
+      const double Hq = f0[q] + Pq * dh;
+      const double wv = (q == 0) ? wm : ws;
+      gat1[q] = Hq / hblt / (wv + KPP_EPS);
+      dat1[q] = fmin(-Pq / (wv + KPP_EPS) + f1 * Hq, 0.0);
+    }
+  }
+  auto shape = [&](double sig, double wv, int q) {
+    return hblt * wv * sig * (1.0 + sig * ((sig - 2.0) + (3.0 - 2.0 * sig) * gat1[q] + (sig - 1.0) * dat1[q]));
+  };
+  double dkm1[3];
+  {
+    const int k = kbl - 1;
+    const double sig = -zgrid[k] / hblt;
+    double wm1, ws1;
+    kpp_wscale<true>(fmin(sig, KPP_EPSSFC), hblt, ustar, bfsfc, wm1, ws1);
+    dkm1[0] = shape(sig, wm1, 0); dkm1[1] = shape(sig, ws1, 1); dkm1[2] = shape(sig, ws1, 2);
+  }
+  // level march: boundary-layer coefficients above KBL, convection + masks, non-local source
+  double flux1_prev = 0.0, flux2_prev = 0.0;   // VDC(k-1)*GHAT(k-1) per tracer class
+  const double stf1 = STF1[c.q2], stf2 = STF2[c.q2];
+  for (int k = 1; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    double visc = VISC[o], vd1 = VDC1[vb + (long long)k * n2], vd2 = VDC2[vb + (long long)k * n2];
+    double ghat = 0.0;
+    if (k < kbl) {
+      const double sig = (-zgrid[k] + 0.5 * hwide[k]) / hblt;
+      double wmk, wsk;
+      kpp_wscale<true>(fmin(sig, KPP_EPSSFC), hblt, ustar, bfsfc, wmk, wsk);
+      double b0 = shape(sig, wmk, 0), b1 = shape(sig, wsk, 1), b2 = shape(sig, wsk, 2);
+      ghat = (1.0 - stable) * kp.cg / (wsk * hblt + KPP_EPS);
+      if (k == kbl - 1 && k <= km - 1) {
+        const double dh = (hblt + zgrid[k]) / (zgrid[k] - zgrid[k + 1]);
+        const double omd = 1.0 - dh;
+        b0 = omd * visc + dh * ((omd * omd) * dkm1[0] + (dh * dh) * (casea * visc + (1.0 - casea) * b0));
+        b1 = omd * vd2 + dh * ((omd * omd) * dkm1[1] + (dh * dh) * (casea * vd2 + (1.0 - casea) * b1));
+        b2 = omd * vd1 + dh * ((omd * omd) * dkm1[2] + (dh * dh) * (casea * vd1 + (1.0 - casea) * b2));
+        ghat = (1.0 - casea) * ghat;
+      }
+      visc = b0; vd2 = b1; vd1 = b2;
+    }
+    if (k <= km - 1) {
+      const double N2 = DBLOC[o] / (zgrid[k] - zgrid[k + 1]);
+      const double fcon = (N2 > 0.0) ? 0.0 : 1.0;
+      double cvv = 0.0, cvd = 0.0;
+      if (k >= kbl) { cvv = sp.convect_visc * fcon; cvd = sp.convect_diff * fcon; }
+      if (k < kmt) { visc = visc + cvv; vd1 = vd1 + cvd; vd2 = vd2 + cvd; }
+      else { visc = 0.0; vd1 = 0.0; vd2 = 0.0; }
+    } else { vd1 = 0.0; vd2 = 0.0; }
+    VISC[o] = visc;
+    VDC1[vb + (long long)k * n2] = vd1;
+    VDC2[vb + (long long)k * n2] = vd2;
+    const double fl1 = vd1 * ghat, fl2 = vd2 * ghat;
+    if (k == 1) { SRC1[o] = stf1 / g.dz[1] * (-fl1); SRC2[o] = stf2 / g.dz[1] * (-fl2); }
+    else { SRC1[o] = stf1 / g.dz[k] * (flux1_prev - fl1); SRC2[o] = stf2 / g.dz[k] * (flux2_prev - fl2); }
+    flux1_prev = fl1; flux2_prev = fl2;
+  }
+}
+
+// ---- VVC = tgrid_to_ugrid(VISC) masked by k < KMU; VVC(km) = 0.  3-D parallel ---------------
+__global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__restrict__ VVC) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
+  const long long q2 = (long long)b * g.n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
+  double v = 0.0;
+  if (k <= g.km - 1 && k < g.KMU[q2] && i < g.nxb - 1 && j < g.nyb - 1)
+    v = g.AU0[q2] * VISC[o] + g.AUN[q2] * VISC[o + nxb] + g.AUE[q2] * VISC[o + 1] + g.AUNE[q2] * VISC[o + nxb + 1];
+  VVC[o] = v;
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static KppDev g_kpp;   // one model per process (one process per GPU)
+
+inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<void *> &allocs, std::string &err) {
+  const pop_config &c = h.c;
+  if (c.lshort_wave || c.lcheckekmo) { err = "KPP: lshort_wave / lcheckekmo are not supported"; return 1; }
+  if (c.num_v_smooth_Ri < 1) { err = "KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)"; return 1; }
+  const int km = h.km;
+  std::vector<double> zgrid(km + 3, 0.0), hwide(km + 3, 0.0), bvdc(km + 3, 0.0), bvvc(km + 3, 0.0);
+  std::vector<int> kref(km + 3, 1);
+  zgrid[0] = KPP_EPS; hwide[0] = KPP_EPS;
+  for (int k = 1; k <= km; ++k) { zgrid[k] = -h.zt[k]; hwide[k] = h.dz[k]; }
+  zgrid[km + 1] = -h.zw[km]; hwide[km + 1] = KPP_EPS;
+  for (int k = 1; k <= km; ++k) {
+    bvdc[k] = c.bckgrnd_vdc1 + c.bckgrnd_vdc2 * std::atan(c.bckgrnd_vdc_linv * (h.zw[k] - c.bckgrnd_vdc_dpth));
+    bvvc[k] = c.Prandtl * bvdc[k];
+    const double surfthick = KPP_EPSSFC * h.zt[k];
+    kref[k] = k;
+    for (int kt = 1; kt <= k; ++kt) if (h.zw[kt] >= surfthick) { kref[k] = kt; break; }
+  }
+  auto up = [&](const void *src, size_t bytes, void **dst) -> int {
+    if (hipMalloc(dst, bytes) != hipSuccess) return 1;
+    allocs.push_back(*dst);
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess ? 1 : 0;
+  };
+  KppDev &k = g_kpp;
+  void *p;
+  if (up(zgrid.data(), zgrid.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.zgrid = (double *)p;
+  if (up(hwide.data(), hwide.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.hwide = (double *)p;
+  if (up(bvdc.data(), bvdc.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.bckgrnd_vdc = (double *)p;
+  if (up(bvvc.data(), bvvc.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.bckgrnd_vvc = (double *)p;
+  if (up(kref.data(), kref.size() * 4, &p)) { err = "kpp alloc"; return 1; } k.kref = (int *)p;
+  const size_t a2 = h.n2 * h.nblocks;
+  std::vector<double> z(a2, 0.0);
+  if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.HBLT0 = (double *)p;
+  if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.USTAR = (double *)p;
+  if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.BFSFC = (double *)p;
+  std::vector<int> zi(a2, 0);
+  if (up(zi.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } k.KBL0 = (int *)p;
+  if (up(zi.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } k.KBL = (int *)p;
+  k.Vtc = std::sqrt(0.2 / KPP_C_S / KPP_EPSSFC) / (KPP_VONKAR * KPP_VONKAR);
+  k.cg = KPP_CSTAR * KPP_VONKAR * std::pow(KPP_C_S * KPP_VONKAR * KPP_EPSSFC, 1.0 / 3.0);
+  k.rich_mix = c.kpp_rich_mix; k.lrich = c.lrich; k.ldbl_diff = c.ldbl_diff; k.nsmooth = c.num_v_smooth_Ri;
+  (void)g; (void)m;
+  return 0;
+}
+
+inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParams &sp, const MixDev &, const MixState &s,
+                           hipStream_t st, std::string &err) {
+  const dim3 GC((g.n2 + POP_COL_THREADS - 1) / POP_COL_THREADS, g.nblocks), BC(POP_COL_THREADS);
+  const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);
+  double *DBLOC = s.S3a, *DBSFC = s.S3b, *WU = s.S3c, *VISC = s.S3d, *RIW = s.E3;
+  hipLaunchKernelGGL(k_kpp_buoydiff, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
+  hipLaunchKernelGGL(k_kpp_ushear, GC, BC, 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
+  hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                     (const double *)DBSFC, (const double *)WU);
+  hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+                     s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+  hipLaunchKernelGGL(k_kpp_vvc, G3, dim3(256), 0, st, g, (const double *)VISC, s.VVC);
+  if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }
+  (void)h;
+  return 0;
+}
+
 }  // namespace pop

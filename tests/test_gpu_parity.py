@@ -58,6 +58,14 @@ def run_phases(gpu, orc, step, tol_state):
     check(gpu, orc, "ZX", tol_state, three_d=False, what=w)
     check(gpu, orc, "ZY", tol_state, three_d=False, what=w)
     check(gpu, orc, "VVC", tol_state, what=w)
+    if gpu.cfg.vmix_choice == 3:
+        a, b = gpu.get("VDC", n=0), orc.vdc(0)
+        assert relerr(interior(a), interior(b)) <= tol_state * 10, "%s VDC(T): %g" % (w, relerr(interior(a), interior(b)))
+        a, b = gpu.get("VDC", n=1), orc.vdc(1)
+        assert relerr(interior(a), interior(b)) <= tol_state * 10, "%s VDC(S)" % w
+        check(gpu, orc, "HBLT", tol_state * 10, three_d=False, what=w)
+        for n in (0, 1):
+            check(gpu, orc, "KPP_SRC", tol_state * 100, n=n, what=w)
     gpu.barotropic_driver(); assert L.orc_barotropic_driver(orc.h) == 0
     w = "step %d barotropic_driver" % step
     it_g, rms_g = gpu.solver_diagnostics()
@@ -83,6 +91,37 @@ def run_phases(gpu, orc, step, tol_state):
     return it_g
 
 
+def force_kpp_case(gpu, orc):
+    """Surface buoyancy forcing + a weakly stratified upper ocean so the KPP boundary layer spans
+    several levels (bulk-Richardson interpolation, shape functions, non-local source all active)."""
+    tlat = orc.f2("TLAT")
+    stf_t = -3.0e-2 * np.sin(tlat) - 1.0e-2          # degC cm/s: cooling (unstable) in the north
+    stf_s = 2.0e-6 * np.cos(2.0 * tlat)
+    kmt = orc.i2("KMT")
+    for tl in (0, 1, 2):
+        for n, slope in ((0, 2.0e-4), (1, -2.0e-9)):
+            T = orc.f3("TRACER", tl, n)
+            z = np.arange(T.shape[1])[None, :, None, None]
+            mix = T[:, 0:1] - slope * z                   # nearly homogeneous upper ocean
+            shallow = (z < 8) & (z < kmt[:, None]) & (np.sin(3 * tlat)[:, None] > 0)
+            T[...] = np.where(shallow, mix, T)
+            gpu.set("TRACER", T, tl=tl, n=n)
+    orc.f2("STF", 1, 0)[...] = stf_t
+    orc.f2("STF", 1, 1)[...] = stf_s
+    gpu.set("STF", stf_t, n=0); gpu.set("STF", stf_s, n=1)
+    # densities of the modified state (init_ts computes RHO for cur and old)
+    import ctypes as C
+    for tl in (0, 1):
+        T, S, R = orc.f3("TRACER", tl, 0), orc.f3("TRACER", tl, 1), orc.f3("RHO", tl)
+        P = C.POINTER(C.c_double)
+        orc.L.orc_state.argtypes = [C.c_void_p, C.c_int, C.c_int, P, P, P, P, P, C.c_int]
+        for k in range(orc.km):
+            t = np.ascontiguousarray(T[:, k]); s_ = np.ascontiguousarray(S[:, k]); r = np.empty_like(t)
+            orc.L.orc_state(orc.h, k + 1, k + 1, t.ctypes.data_as(P), s_.ctypes.data_as(P), r.ctypes.data_as(P), None, None, t.size)
+            R[:, k] = r
+        gpu.set("RHO", R, tl=tl)
+
+
 @pytest.mark.parametrize("name,kw,nsteps", [
     ("tiny", {}, 4),                                   # 16 blocks, const vmix, avgfit (step 2 averages)
     ("tiny", {"solver_choice": 2}, 4),                 # ChronGear
@@ -90,6 +129,8 @@ def run_phases(gpu, orc, step, tol_state):
     ("tiny", {"lpressure_avg": 0, "tmix_opt": 1, "time_mix_freq": 3}, 4),
     ("tiny", {"block_size_x": 48, "block_size_y": 40}, 3),   # one block
     ("gx3v7", {}, 3),
+    ("tiny", {"vmix_choice": 3, "km": 24}, 5),                       # KPP
+    ("tiny", {"vmix_choice": 3, "km": 24, "ldbl_diff": 1}, 5),       # KPP + double diffusion (CESM default)
 ])
 def test_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
     cfg = named_config(name, **kw)
@@ -98,6 +139,8 @@ def test_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
     for n in (0, 1):
         assert np.array_equal(gpu.get("TRACER", 1, n), orc.f3("TRACER", 1, n))
     assert relerr(gpu.get("RHO", 1), orc.f3("RHO", 1)) < 1e-15
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
     tol = TOL_LOCAL
     for s in range(1, nsteps + 1):
         run_phases(gpu, orc, s, tol)
