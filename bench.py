@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("POP_BENCH_WORKLOAD", "gx3v7"))
+    ap.add_argument("--workload", default=os.environ.get("POP_BENCH_WORKLOAD", "gx1v7"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -47,6 +47,7 @@ struct orc_model {
   int first_step, leapfrogts, f_euler_ts, avg_ts, nsteps_total, nsteps_this_interval, nsteps_per_interval;
   /* kpp */
   void *kpp;
+  void *del4;
 };
 
 extern const double orc_grav, orc_omega, orc_radius;

@@ -491,7 +491,7 @@ static void init_del2(orc_model *m) {
   double *DXKX = dalloc(n2), *DYKY = dalloc(n2), *DXKY = dalloc(n2), *DYKX = dalloc(n2);
   /* AMF / AHF */
   for (size_t p = 0; p < n2 * m->nblocks; p++) { m->AMF[p] = 1.0; m->AHF[p] = 1.0; }
-  if (c->lvariable_hmix) {
+  if (c->lvariable_hmix && (c->hmix_momentum == 2 || c->hmix_tracer == 2)) {
     double ref = (2.0 * pi * orc_radius / c->nx_global); ref = ref * ref;
     for (size_t p = 0; p < n2 * m->nblocks; p++) {
       m->AMF[p] = sqrt(m->UAREA[p] / ref);

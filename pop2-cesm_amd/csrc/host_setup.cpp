@@ -365,6 +365,50 @@ int host_build(HostModel &h) {
     });
   }
 
+  // ---------------- del4 operator weights (hmix_del4.F90:218-246, 262-370, 512-577) ----------------
+  if (c.hmix_momentum == 4 || c.hmix_tracer == 4) {
+    auto &A4 = newf("D4AMF"), &H4 = newf("D4AHF");
+    for (size_t p = 0; p < A2; ++p) { A4[p] = 1.0; H4[p] = 1.0; }
+    if (c.lvariable_hmix) {
+      for (size_t p = 0; p < A2; ++p) { A4[p] = std::pow(UAREA[p] / h.uarea_equator, 1.5); H4[p] = std::pow(TAREA[p] / h.uarea_equator, 1.5); }
+      host_halo_r8(h, A4.data(), 1, 0.0);
+      host_halo_r8(h, H4.data(), 1, 0.0);
+    }
+    auto &eUC = newf("d4DUC"), &eUN = newf("d4DUN"), &eUS = newf("d4DUS"), &eUE = newf("d4DUE"), &eUW = newf("d4DUW");
+    auto &eMC = newf("d4DMC"), &eMN = newf("d4DMN"), &eMS = newf("d4DMS"), &eME = newf("d4DME"), &eMW = newf("d4DMW"), &eUM = newf("d4DUM");
+    auto &eTN = newf("d4DTN"), &eTS = newf("d4DTS"), &eTE = newf("d4DTE"), &eTW = newf("d4DTW");
+    std::vector<double> RS(A2), RW(A2), KXT(A2), KYT(A2), Xx(A2), Xy(A2), Yy(A2), Yx(A2), RN(A2), RE(A2);
+    auto each = [&](auto fn) { for (int b = 0; b < NB; ++b) for (int j = 0; j < nyb; ++j) for (int i = 0; i < nxb; ++i) fn(b, i, j, idx(b, i, j)); };
+    each([&](int b, int i, int j, size_t p) {
+      RS[p] = HUS[p] / HTE[p]; RW[p] = HUW[p] / HTN[p];
+      KXT[p] = (HTE[p] - S(HTE, b, i - 1, j)) * TAREA_R[p];
+      KYT[p] = (HTN[p] - S(HTN, b, i, j - 1)) * TAREA_R[p];
+      RN[p] = HTN[p] / HUW[p]; RE[p] = HTE[p] / HUS[p];
+    });
+    each([&](int b, int i, int j, size_t p) {
+      eUS[p] = RS[p] * UAREA_R[p]; eUN[p] = S(RS, b, i, j + 1) * UAREA_R[p];
+      eUW[p] = RW[p] * UAREA_R[p]; eUE[p] = S(RW, b, i + 1, j) * UAREA_R[p];
+      Xx[p] = S(KXT, b, i + 1, j) - KXT[p];     // d/dx of KXT
+      Xy[p] = S(KXT, b, i, j + 1) - KXT[p];     // d/dy of KXT
+      Yy[p] = S(KYT, b, i, j + 1) - KYT[p];
+      Yx[p] = S(KYT, b, i + 1, j) - KYT[p];
+      eTN[p] = RN[p] * TAREA_R[p]; eTS[p] = S(RN, b, i, j - 1) * TAREA_R[p];
+      eTE[p] = RE[p] * TAREA_R[p]; eTW[p] = S(RE, b, i - 1, j) * TAREA_R[p];
+    });
+    each([&](int b, int i, int j, size_t p) {
+      const double DXKX = 0.5 * (Xx[p] + S(Xx, b, i, j + 1)) * DXUR[p];
+      const double DYKX = 0.5 * (Xy[p] + S(Xy, b, i + 1, j)) * DYUR[p];
+      const double DYKY = 0.5 * (Yy[p] + S(Yy, b, i + 1, j)) * DYUR[p];
+      const double DXKY = 0.5 * (Yx[p] + S(Yx, b, i, j + 1)) * DXUR[p];
+      eUM[p] = -(DXKX + DYKY + 2.0 * (KXU[p] * KXU[p] + KYU[p] * KYU[p]));
+      eMC[p] = DXKY - DYKX;
+      eME[p] = 2.0 * KYU[p] / (HTN[p] + S(HTN, b, i + 1, j));
+      eMN[p] = -2.0 * KXU[p] / (HTE[p] + S(HTE, b, i, j + 1));
+      eUC[p] = -(eUN[p] + eUS[p] + eUE[p] + eUW[p]);
+      eMW[p] = -eME[p]; eMS[p] = -eMN[p];
+    });
+  }
+
   // ---------------- barotropic operator, null-space fields ----------------
   auto &WNE = newf("btropWgtNE"), &WEa = newf("btropWgtEast"), &WNo = newf("btropWgtNorth"), &WC0 = newf("centerWgtIndep");
   auto &mMask = newf("mMask"), &CHECKER = newf("CHECKER"), &CONSTNT = newf("CONSTNT");

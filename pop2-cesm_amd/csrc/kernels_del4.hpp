@@ -1,7 +1,68 @@
-// kernels_del4.hpp -- biharmonic horizontal mixing (placeholder until the del4 kernels land)
+// kernels_del4.hpp -- biharmonic horizontal mixing (source/hmix_del4.F90).
+//
+// del4 = Laplacian applied twice.  The first application (with the optional spatial scaling AMF /
+// AHF and the land mask) is one 3-D-parallel kernel that writes the intermediate field on the ring
+// ib-1..ie+1, jb-1..je+1 (hdiffu_del4 :730-790, hdifft_del4 :1021-1043); the second application
+// has exactly the del2 form, so the tracer / momentum right-hand-side kernels consume the
+// intermediate field through their ordinary 5-point path with the del4 coefficient set
+// (init_del4u :262-370, init_del4t :563-577, built on the host).
 #pragma once
+
 namespace pop {
-inline int del4_create(HostModel &, const DevGrid &, MixDev &, std::vector<void *> &, std::string &err) { err = "del4 horizontal mixing is not built yet"; return 1; }
-inline int mix_hdifft_del4(const HostModel &, const DevGrid &, const StepParams &, const MixDev &, const double *, const double *, double *, double *, double *, double *, hipStream_t, std::string &err) { err = "del4 not built"; return 1; }
-inline int mix_hdiffu_del4(const HostModel &, const DevGrid &, const StepParams &, const MixDev &, const double *, const double *, double *, double *, double *, double *, hipStream_t, std::string &err) { err = "del4 not built"; return 1; }
+
+__global__ void k_del4_d2t(DevGrid g, const double *__restrict__ AHF, const double *__restrict__ T0, const double *__restrict__ T1,
+                           double *__restrict__ D0, double *__restrict__ D1) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
+  if (i + 1 < g.ib - 1 || i + 1 > g.ie + 1 || j + 1 < g.jb - 1 || j + 1 > g.je + 1) return;
+  const long long q = (long long)b * g.n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
+  const int kmt = g.KMT[q];
+  const double CN = (k <= g.KMTN[q] && k <= kmt) ? g.DTN[q] : 0.0, CS = (k <= g.KMTS[q] && k <= kmt) ? g.DTS[q] : 0.0;
+  const double CE = (k <= g.KMTE[q] && k <= kmt) ? g.DTE[q] : 0.0, CW = (k <= g.KMTW[q] && k <= kmt) ? g.DTW[q] : 0.0;
+  const double CC = -(CN + CS + CE + CW);
+  const double ahf = AHF[q];
+  D0[o] = ahf * (CC * T0[o] + CN * T0[o + nxb] + CS * T0[o - nxb] + CE * T0[o + 1] + CW * T0[o - 1]);
+  D1[o] = ahf * (CC * T1[o] + CN * T1[o + nxb] + CS * T1[o - nxb] + CE * T1[o + 1] + CW * T1[o - 1]);
+}
+
+__global__ void k_del4_d2u(DevGrid g, const double *__restrict__ AMF, const double *__restrict__ U, const double *__restrict__ V,
+                           double *__restrict__ DU, double *__restrict__ DV) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
+  if (i + 1 < g.ib - 1 || i + 1 > g.ie + 1 || j + 1 < g.jb - 1 || j + 1 > g.je + 1) return;
+  const long long q = (long long)b * g.n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
+  double du = 0.0, dv = 0.0;
+  if (k <= g.KMU[q]) {
+    const double cc = g.DUC[q] + g.DUM[q];
+    const double u0 = U[o], un = U[o + nxb], us = U[o - nxb], ue = U[o + 1], uw = U[o - 1];
+    const double v0 = V[o], vn = V[o + nxb], vs = V[o - nxb], ve = V[o + 1], vw = V[o - 1];
+    du = (cc * u0 + g.DUN[q] * un + g.DUS[q] * us + g.DUE[q] * ue + g.DUW[q] * uw) +
+         (g.DMC[q] * v0 + g.DMN[q] * vn + g.DMS[q] * vs + g.DME[q] * ve + g.DMW[q] * vw);
+    dv = (cc * v0 + g.DUN[q] * vn + g.DUS[q] * vs + g.DUE[q] * ve + g.DUW[q] * vw) -
+         (g.DMC[q] * u0 + g.DMN[q] * un + g.DMS[q] * us + g.DME[q] * ue + g.DMW[q] * uw);
+    const double amf = AMF[q];
+    du = amf * du; dv = amf * dv;
+  }
+  DU[o] = du; DV[o] = dv;
+}
+
+inline int del4_create(HostModel &, const DevGrid &, MixDev &, std::vector<void *> &, std::string &) { return 0; }
+
+inline int mix_hdifft_del4(const HostModel &, const DevGrid &g, const StepParams &, const MixDev &m, const double *T0, const double *T1,
+                           double *D0, double *D1, double *, double *, hipStream_t st, std::string &err) {
+  hipLaunchKernelGGL(k_del4_d2t, dim3((g.n2 + 255) / 256, g.km, g.nblocks), dim3(256), 0, st, g, m.D4AHF, T0, T1, D0, D1);
+  if (hipGetLastError() != hipSuccess) { err = "del4 tracer kernel launch failed"; return 1; }
+  return 0;
+}
+inline int mix_hdiffu_del4(const HostModel &, const DevGrid &g, const StepParams &, const MixDev &m, const double *U, const double *V,
+                           double *DU, double *DV, double *, double *, hipStream_t st, std::string &err) {
+  hipLaunchKernelGGL(k_del4_d2u, dim3((g.n2 + 255) / 256, g.km, g.nblocks), dim3(256), 0, st, g, m.D4AMF, U, V, DU, DV);
+  if (hipGetLastError() != hipSuccess) { err = "del4 momentum kernel launch failed"; return 1; }
+  return 0;
+}
+
 }  // namespace pop

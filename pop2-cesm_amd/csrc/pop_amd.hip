@@ -356,6 +356,12 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   G2(mMask); G2(CHECKER); G2(CONSTNT); G2(SMF1); G2(SMF2); G2(SMFT1); G2(SMFT2);
 #undef G2
   g.WNE = c->d2["btropWgtNE"]; g.WEa = c->d2["btropWgtEast"]; g.WNo = c->d2["btropWgtNorth"]; g.WC0 = c->d2["centerWgtIndep"];
+  if (cfg->hmix_tracer == 4) { g.DTN = c->d2["d4DTN"]; g.DTS = c->d2["d4DTS"]; g.DTE = c->d2["d4DTE"]; g.DTW = c->d2["d4DTW"]; }
+  if (cfg->hmix_momentum == 4) {
+    g.DUC = c->d2["d4DUC"]; g.DUN = c->d2["d4DUN"]; g.DUS = c->d2["d4DUS"]; g.DUE = c->d2["d4DUE"]; g.DUW = c->d2["d4DUW"];
+    g.DMC = c->d2["d4DMC"]; g.DMN = c->d2["d4DMN"]; g.DMS = c->d2["d4DMS"]; g.DME = c->d2["d4DME"]; g.DMW = c->d2["d4DMW"]; g.DUM = c->d2["d4DUM"];
+  }
+  if (cfg->hmix_tracer == 4 || cfg->hmix_momentum == 4) { c->mix.D4AMF = c->d2["D4AMF"]; c->mix.D4AHF = c->d2["D4AHF"]; }
 #define GI(f) g.f = c->di2[#f]
   GI(KMT); GI(KMU); GI(KMTN); GI(KMTS); GI(KMTE); GI(KMTW); GI(KMTEE); GI(KMTNN);
 #undef GI
@@ -567,11 +573,10 @@ static int phase_tracer_rhs(pop_ctx *c) {
     a.TCUR[n] = c->TR[n][c->curt]; a.TOLD[n] = c->TR[n][c->oldt]; a.TMIX[n] = c->TR[n][c->mixt]; a.TNEW[n] = c->TR[n][c->newt];
     a.VDC[n] = c->VDC[sp.nvdc == 2 ? n : 0]; a.KPP_SRC[n] = c->KPP_SRC[n]; a.STF[n] = c->STF[n]; a.TFW[n] = c->TFW[n];
   }
-  a.HDT[0] = c->S3a; a.HDT[1] = c->S3b;
+  if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->S3a; a.TMIX[1] = c->S3b; }   // del4: second Laplacian acts on D2T
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
   a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
-  if (c->h.c.hmix_tracer == 4) hipLaunchKernelGGL(k_tracer_rhs<true>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, a);
-  else hipLaunchKernelGGL(k_tracer_rhs<false>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, a);
+  hipLaunchKernelGGL(k_tracer_rhs<false>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, a);
   return 0;
 }
 static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {
@@ -598,10 +603,9 @@ static int phase_momentum_rhs(pop_ctx *c) {
   MomentumRhsArgs a{};
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.UOLD = c->U[c->oldt]; a.VOLD = c->V[c->oldt]; a.UMIX = c->U[c->mixt]; a.VMIX = c->V[c->mixt];
   a.RHOOLD = c->RHO[c->oldt]; a.RHOCUR = c->RHO[c->curt]; a.RHONEW = c->RHO[c->newt]; a.VVC = c->VVC; a.DHU = c->DHU;
-  a.HDU = c->S3a; a.HDV = c->S3b;
+  if (c->h.c.hmix_momentum == 4) { a.UMIX = c->S3a; a.VMIX = c->S3b; }   // del4: second Laplacian acts on D2U, D2V
   a.UNEW = c->U[c->newt]; a.VNEW = c->V[c->newt]; a.ZX = c->ZX; a.ZY = c->ZY;
-  if (c->h.c.hmix_momentum == 4) hipLaunchKernelGGL(k_momentum_rhs<true>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), a);
-  else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), a);
+  hipLaunchKernelGGL(k_momentum_rhs<false>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), a);
   return 0;
 }
 static int phase_impvmixu(pop_ctx *c) {

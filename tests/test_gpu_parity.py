@@ -129,6 +129,8 @@ def force_kpp_case(gpu, orc):
     ("tiny", {"lpressure_avg": 0, "tmix_opt": 1, "time_mix_freq": 3}, 4),
     ("tiny", {"block_size_x": 48, "block_size_y": 40}, 3),   # one block
     ("gx3v7", {}, 3),
+    ("tiny", {"hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1, "am": -1.0e22, "ah": -1.0e21}, 4),   # del4
+    ("tiny", {"hmix_momentum": 4, "hmix_tracer": 2, "am": -1.0e22}, 3),                                      # mixed
     ("tiny", {"vmix_choice": 3, "km": 24}, 5),                       # KPP
     ("tiny", {"vmix_choice": 3, "km": 24, "ldbl_diff": 1}, 5),       # KPP + double diffusion (CESM default)
 ])

@@ -16,7 +16,9 @@ IFIELDS = ["KMT", "KMU", "KMTN", "KMTS", "KMTE", "KMTW", "KMTEE", "KMTNN"]
 
 
 @pytest.mark.parametrize("name,kw", [("tiny", {}), ("test", {}), ("gx3v7", {}), ("tiny", {"lvariable_hmix": 1}),
-                                     ("tiny", {"ew_boundary": 0}), ("tiny", {"tmix_opt": 1})])
+                                     ("tiny", {"ew_boundary": 0}), ("tiny", {"tmix_opt": 1}),
+                                     ("tiny", {"hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1}),
+                                     ("tiny", {"hmix_momentum": 4, "hmix_tracer": 4})])
 def test_host_fields_bit_exact(pkg, orclib_built, name, kw):
     cfg = named_config(name, **kw)
     m = pkg.PopModel(cfg, host_only=True)
@@ -27,6 +29,10 @@ def test_host_fields_bit_exact(pkg, orclib_built, name, kw):
     for f in FIELDS:
         a, b = m.get(f), o.f2(f)
         assert np.array_equal(a, b), "%s max diff %g" % (f, np.abs(a - b).max())
+    if cfg.hmix_momentum == 4:
+        for f in ("DUC", "DUN", "DUS", "DUE", "DUW", "DMC", "DMN", "DMS", "DME", "DMW", "DUM", "DTN", "DTS", "DTE", "DTW"):
+            assert np.array_equal(m.get("d4" + f), o.f2("d4" + f)), "d4" + f
+        assert np.array_equal(m.get("D4AMF"), o.f2("D4_AMF")) and np.array_equal(m.get("D4AHF"), o.f2("D4_AHF"))
     for n in (0, 1):
         assert np.array_equal(m.get("SMF", 1, n), o.f2("SMF", 1, n))
         assert np.array_equal(m.get("SMFT", 1, n), o.f2("SMFT", 1, n))
