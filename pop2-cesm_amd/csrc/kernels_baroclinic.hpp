@@ -101,6 +101,7 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
 #pragma unroll
   for (int n = 0; n < 2; ++n) { tc_k[n] = a.TCUR[n][c.base3]; to_k[n] = a.TOLD[n][c.base3]; }
   const long long vdcbase = ((long long)c.b * (km + 2)) * n2 + c.p2;
+  double *__restrict__ const TNp[2] = {a.TNEW[0], a.TNEW[1]};   // outputs alias no input
   for (int k = 1; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
     const int kp1 = (k < km) ? k + 1 : km;
@@ -144,9 +145,9 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
       if (a.use_kpp_src) src = src + a.KPP_SRC[n][o];
       FT = FT + src;
       if (k == 1 && sp.pavg) {
-        if (kmt > 0) a.TNEW[n][o] = a.c2dtt * FT - 2.0 * tc_k[n] * psfac / (sp.grav * g.dz[1]);
+        if (kmt > 0) TNp[n][o] = a.c2dtt * FT - 2.0 * tc_k[n] * psfac / (sp.grav * g.dz[1]);
       } else {
-        a.TNEW[n][o] = (k <= kmt) ? a.c2dtt * FT : 0.0;
+        TNp[n][o] = (k <= kmt) ? a.c2dtt * FT : 0.0;
       }
       tc_km1[n] = tc_k[n]; tc_k[n] = tc_kp1[n]; to_k[n] = to_kp1[n];
     }
@@ -185,9 +186,12 @@ k_impvmixt(DevGrid g, StepParams sp, ImpvmixtArgs a) {
   const double hfac1 = g.dz[1] / a.c2dtt;
   const double H1 = hfac1 + a.PSFC[c.q2] / (sp.grav * a.c2dtt);
   const long long vdcbase = ((long long)c.b * (km + 2)) * n2 + c.p2;
+  double *__restrict__ const E = a.E;
+  double *__restrict__ const F = a.F;
   for (int n = a.nfirst - 1; n <= a.nlast - 1; ++n) {
-    double *TN = a.TNEW[n];
-    const double *VDC = a.VDC[n];
+    double *__restrict__ const TN = a.TNEW[n];
+    const double *__restrict__ const VDC = a.VDC[n];
+    const double *__restrict__ const TO = a.TOLD[n];
     double rhs1 = 0.0;
     if (MODE == 1) {
       if (kmt > 0)
@@ -203,31 +207,34 @@ k_impvmixt(DevGrid g, StepParams sp, ImpvmixtArgs a) {
     double Ek = A / D;
     double B = H1 * Ek;
     double Fk = (MODE == 1) ? hfac1 * rhs1 / D : hfac1 * t1 / D;
-    a.E[c.base3] = Ek;
-    a.F[c.base3] = Fk;
+    E[c.base3] = Ek;
+    F[c.base3] = Fk;
+#pragma unroll 4
     for (int k = 2; k <= km; ++k) {
       const long long o = c.base3 + (long long)(k - 1) * n2;
       const double C = A;
       const double hf = g.dz[k] / a.c2dtt;
       A = g.afac_t[k] * VDC[vdcbase + (long long)k * n2];
+      const double tnk = (MODE == 1) ? 0.0 : TN[o];
       if (k > kmt) { Fk = 0.0; }
       else {
         D = (k == kmt) ? hf + B : hf + A + B;
         Ek = A / D;
         B = (hf + B) * Ek;
-        Fk = (MODE == 1) ? C * Fk / D : (hf * TN[o] + C * Fk) / D;
-        a.E[o] = Ek;
+        Fk = (MODE == 1) ? C * Fk / D : (hf * tnk + C * Fk) / D;
+        E[o] = Ek;
       }
-      a.F[o] = Fk;
+      F[o] = Fk;
     }
     // back substitution and update, bottom to top
     double Fkp1 = 0.0;
+#pragma unroll 4
     for (int k = km; k >= 1; --k) {
       const long long o = c.base3 + (long long)(k - 1) * n2;
-      double f = a.F[o];
-      if (k < km && k < kmt) f = f + a.E[o] * Fkp1;
+      double f = F[o];
+      if (k < km && k < kmt) f = f + E[o] * Fkp1;
       Fkp1 = f;
-      double tn = (MODE == 1) ? TN[o] + f : a.TOLD[n][o] + f;
+      double tn = (MODE == 1) ? TN[o] + f : TO[o] + f;
       if (POST && n == 0 && k == 1 && sp.reset_to_freezing) tn = fmax(tn, -2.0);
       TN[o] = tn;
     }
@@ -283,6 +290,8 @@ k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
   double rhokmx = 0.0, rhokmy = 0.0, sumx = 0.0, sumy = 0.0, zx = 0.0, zy = 0.0;
   double uc_km1 = 0.0, vc_km1 = 0.0, uc_k = a.UCUR[c.base3], vc_k = a.VCUR[c.base3];
   double uo_k = a.UOLD[c.base3], vo_k = a.VOLD[c.base3];
+  double *__restrict__ const UNp = a.UNEW;   // outputs alias no input
+  double *__restrict__ const VNp = a.VNEW;
   for (int k = 1; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
     const int kp1 = (k < km) ? k + 1 : km;
@@ -386,9 +395,9 @@ k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
     if (sp.impcor) {
       const double W1 = sp.c2dtu * sp.beta * fcor;
       const double W2 = sp.c2dtu / (1.0 + W1 * W1);
-      a.UNEW[o] = (FX + W1 * FY) * W2;
-      a.VNEW[o] = (FY - W1 * FX) * W2;
-    } else { a.UNEW[o] = sp.c2dtu * FX; a.VNEW[o] = sp.c2dtu * FY; }
+      UNp[o] = (FX + W1 * FY) * W2;
+      VNp[o] = (FY - W1 * FX) * W2;
+    } else { UNp[o] = sp.c2dtu * FX; VNp[o] = sp.c2dtu * FY; }
     zx = zx + FX * g.dz[k]; zy = zy + FY * g.dz[k];
     wuk = wukb;
     uc_km1 = uc_k; vc_km1 = vc_k; uc_k = uc_kp1; vc_k = vc_kp1; uo_k = uo_kp1; vo_k = vo_kp1;
@@ -418,47 +427,58 @@ k_impvmixu_norm(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   const int kmu = g.KMU[c.q2];
   const double hur = g.HUR[c.q2];
   const double hf1 = g.dz[1] / sp.c2dtu;
-  double A = g.afac_u[1] * a.VVC[c.base3];
+  double *__restrict__ const UN = a.UNEW;
+  double *__restrict__ const VN = a.VNEW;
+  double *__restrict__ const E = a.E;
+  const double *__restrict__ const VVC = a.VVC;
+  const double *__restrict__ const UO = a.UOLD;
+  const double *__restrict__ const VO = a.VOLD;
+  double A = g.afac_u[1] * VVC[c.base3];
   double D = hf1 + A;
   double Ek = A / D;
   double B = hf1 * Ek;
-  double F1 = hf1 * a.UNEW[c.base3] / D, F2 = hf1 * a.VNEW[c.base3] / D;
-  a.E[c.base3] = Ek; a.UNEW[c.base3] = F1; a.VNEW[c.base3] = F2;
+  double F1 = hf1 * UN[c.base3] / D, F2 = hf1 * VN[c.base3] / D;
+  E[c.base3] = Ek; UN[c.base3] = F1; VN[c.base3] = F2;
+#pragma unroll 4
   for (int k = 2; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
     const double C = A;
     const double hf = g.dz[k] / sp.c2dtu;
-    A = g.afac_u[k] * a.VVC[o];
+    A = g.afac_u[k] * VVC[o];
+    const double un = UN[o], vn = VN[o];
     if (k <= kmu) {
       D = (k < kmu) ? hf + A + B : hf + B;
       Ek = A / D;
       B = (hf + B) * Ek;
-      F1 = (hf * a.UNEW[o] + C * F1) / D;
-      F2 = (hf * a.VNEW[o] + C * F2) / D;
-      a.E[o] = Ek;
+      F1 = (hf * un + C * F1) / D;
+      F2 = (hf * vn + C * F2) / D;
+      E[o] = Ek;
     } else { F1 = 0.0; F2 = 0.0; }
-    a.UNEW[o] = F1; a.VNEW[o] = F2;
+    UN[o] = F1; VN[o] = F2;
   }
   double F1p = 0.0, F2p = 0.0;
+#pragma unroll 4
   for (int k = km; k >= 1; --k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
-    double f1 = a.UNEW[o], f2 = a.VNEW[o];
-    if (k < km && k < kmu) { const double e = a.E[o]; f1 = f1 + e * F1p; f2 = f2 + e * F2p; }
+    double f1 = UN[o], f2 = VN[o];
+    if (k < km && k < kmu) { const double e = E[o]; f1 = f1 + e * F1p; f2 = f2 + e * F2p; }
     F1p = f1; F2p = f2;
-    a.UNEW[o] = a.UOLD[o] + f1;
-    a.VNEW[o] = a.VOLD[o] + f2;
+    UN[o] = UO[o] + f1;
+    VN[o] = VO[o] + f2;
   }
   double w1 = 0.0, w2 = 0.0;
+#pragma unroll 4
   for (int k = 1; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
-    w1 = w1 + a.UNEW[o] * g.dz[k];
-    w2 = w2 + a.VNEW[o] * g.dz[k];
+    w1 = w1 + UN[o] * g.dz[k];
+    w2 = w2 + VN[o] * g.dz[k];
   }
   w1 = w1 * hur; w2 = w2 * hur;
+#pragma unroll 4
   for (int k = 1; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
-    if (k <= kmu) { a.UNEW[o] = a.UNEW[o] - w1; a.VNEW[o] = a.VNEW[o] - w2; }
-    else { a.UNEW[o] = 0.0; a.VNEW[o] = 0.0; }
+    if (k <= kmu) { UN[o] = UN[o] - w1; VN[o] = VN[o] - w2; }
+    else { UN[o] = 0.0; VN[o] = 0.0; }
   }
 }
 

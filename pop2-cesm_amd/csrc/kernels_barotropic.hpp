@@ -376,3 +376,142 @@ __global__ void k_halo_unpack(double *__restrict__ F, const int *__restrict__ ds
 }
 
 }  // namespace pop
+
+// =============================================================================================
+// Fused single-rank solver path.
+//
+// When every ghost cell of the rank has a local source (one rank owns all blocks) the halo
+// update of the solver vectors is folded into the consuming kernel: a neighbour that is a ghost
+// cell is read at its SOURCE cell (srcmap), which is bit-identical to reading the ghost after
+// POP_HaloUpdate (closed-boundary ghosts read as the fill value 0).  The final stage of each dot
+// product (ordered sum of the workgroup partials, block sums in block-id order -- the same rule as
+// k_block_sums + k_finalize) is recomputed by every workgroup of the NEXT kernel, so an iteration
+// is two launches for pcg and the scalars never leave the device.
+// =============================================================================================
+namespace pop {
+
+struct FusedArgs {
+  double *X, *R, *Z, *S0, *S1, *Q;
+  const double *Bv, *C;
+  double *partA, *partB;      // workgroup partials of (r,z) and (s,q)
+  SolverScalars *sc;
+  const int *srcmap;          // per cell: own index (interior), source cell (ghost), -1 (fill)
+  int nchunk, nblocks;
+};
+
+// ordered total of workgroup partials: per POP block a thread-strided sequential sum + fixed tree,
+// block sums added in block order.  Every thread returns the same value.
+__device__ __forceinline__ double fused_total(const double *__restrict__ partial, int nchunk, int nblocks) {
+  __shared__ double shf[POP_RED_THREADS];
+  const int t = threadIdx.x;
+  double total = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    double v = 0.0;
+    for (int c = t; c < nchunk; c += POP_RED_THREADS) v = v + partial[(long long)b * nchunk + c];
+    shf[t] = v;
+    __syncthreads();
+    for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+      if (t < s) shf[t] = shf[t] + shf[t + s];
+      __syncthreads();
+    }
+    total = total + shf[0];
+    __syncthreads();
+  }
+  return total;
+}
+
+// step A: [x += alpha s; r -= alpha q]; z = r/diag; partial (r,z)
+template <bool UPDATE>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_fpcg_a(DevGrid g, FusedArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  double alpha = 0.0;
+  if (UPDATE) {
+    const double sq = fused_total(a.partB, a.nchunk, a.nblocks);
+    const double rz = a.sc->eta1;
+    alpha = rz / sq;                                   // eta1 = eta0/(s,q), POP_SolversMod.F90:1419
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta0 = rz; a.sc->alpha = alpha; }
+  }
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    double r = a.R[q];
+    if (UPDATE) {
+      a.X[q] = a.X[q] + alpha * a.S0[q];
+      r = r - alpha * a.Q[q];
+      a.R[q] = r;
+    }
+    const double cw = a.C[q];
+    const double z = (cw != 0.0) ? r / cw : 0.0;
+    a.Z[q] = z;
+    if (interior(g, i, j)) v[0] = (r * z) * g.mMask[q];
+  }
+  wg_reduce_store<1>(v, a.partA, b * gridDim.x + blockIdx.x);
+}
+
+// step B: s_new = z + s_old*(eta1/eta0) at the 9 stencil points (ghost neighbours through srcmap);
+// q = A s_new; partial (q,s)
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_fpcg_b(DevGrid g, FusedArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const double rz = fused_total(a.partA, a.nchunk, a.nblocks);
+  const double bt = rz / a.sc->eta0;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta1 = rz; a.sc->beta_cg = bt; }
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    auto sn = [&](long long qq) {
+      const int m = a.srcmap[qq];
+      return (m < 0) ? 0.0 : a.Z[m] + a.S0[m] * bt;
+    };
+    const double s = a.Z[q] + a.S0[q] * bt;
+    a.S1[q] = s;
+    double aq = 0.0;
+    if (interior(g, i, j)) {
+      aq = a.C[q] * s + g.WNo[q] * sn(q + nxb) + g.WNo[q - nxb] * sn(q - nxb) + g.WEa[q] * sn(q + 1) + g.WEa[q - 1] * sn(q - 1) +
+           g.WNE[q] * sn(q + nxb + 1) + g.WNE[q - nxb] * sn(q - nxb + 1) + g.WNE[q - 1] * sn(q + nxb - 1) + g.WNE[q - 1 - nxb] * sn(q - nxb - 1);
+      v[0] = (aq * s) * g.mMask[q];
+    }
+    a.Q[q] = aq;
+  }
+  wg_reduce_store<1>(v, a.partB, b * gridDim.x + blockIdx.x);
+}
+
+// pending x,r update before a convergence check
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_fpcg_xr(DevGrid g, FusedArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const double sq = fused_total(a.partB, a.nchunk, a.nblocks);
+  const double rz = a.sc->eta1;
+  const double alpha = rz / sq;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta0 = rz; a.sc->alpha = alpha; }
+  if (p2 >= g.n2) return;
+  const long long q = (long long)b * g.n2 + p2;
+  a.X[q] = a.X[q] + alpha * a.S0[q];
+  a.R[q] = a.R[q] - alpha * a.Q[q];
+}
+
+// r = b - A x on the physical domain with ghost neighbours of x read at their source; partial (r,r)
+template <bool WITH_RR>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_fresidual(DevGrid g, FusedArgs a) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    if (interior(g, i, j)) {
+      auto xs = [&](long long qq) { const int m = a.srcmap[qq]; return (m < 0) ? 0.0 : a.X[m]; };
+      const double ax = a.C[q] * a.X[q] + g.WNo[q] * xs(q + nxb) + g.WNo[q - nxb] * xs(q - nxb) + g.WEa[q] * xs(q + 1) + g.WEa[q - 1] * xs(q - 1) +
+                        g.WNE[q] * xs(q + nxb + 1) + g.WNE[q - nxb] * xs(q - nxb + 1) + g.WNE[q - 1] * xs(q + nxb - 1) + g.WNE[q - 1 - nxb] * xs(q - nxb - 1);
+      const double r = a.Bv[q] - ax;
+      a.R[q] = r;
+      if (WITH_RR) v[0] = (r * r) * g.mMask[q];
+    }
+  }
+  if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * gridDim.x + blockIdx.x);
+}
+
+}  // namespace pop

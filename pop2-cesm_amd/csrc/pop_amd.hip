@@ -48,7 +48,10 @@ struct pop_ctx {
   double *R = nullptr, *S0 = nullptr, *S1 = nullptr, *Q = nullptr, *Z = nullptr, *AZ = nullptr;
   double *partial = nullptr, *blocksum = nullptr;
   SolverScalars *sc = nullptr;
-  int *gid = nullptr;
+  int *gid = nullptr, *srcmap = nullptr;
+  SolverScalars *host_sc = nullptr;                       // pinned
+  std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
+  bool no_graph = false, fused_ok = false;
   int nchunk = 0, numIterations = 0;
   double rmsResidual = 0.0;
   // halo plan on device
@@ -230,6 +233,90 @@ int solver_pcg(pop_ctx *c) {
   return 0;
 }
 
+// pcg, fused single-rank form: two launches per iteration, halo folded into the matvec through
+// srcmap, final reduction stage recomputed by the consumer kernel, and one hipGraph replay per
+// convergenceCheckFreq iterations (same arithmetic and summation order as solver_pcg).
+FusedArgs fused_args(pop_ctx *c) {
+  FusedArgs a{};
+  a.X = c->PS[c->newt]; a.R = c->R; a.Z = c->Z; a.S0 = c->S0; a.S1 = c->S1; a.Q = c->Q;
+  a.Bv = c->RHS; a.C = c->centerWgt; a.partA = c->partial; a.partB = c->partial + (size_t)c->nchunk * c->g.nblocks;
+  a.sc = c->sc; a.srcmap = c->srcmap; a.nchunk = c->nchunk; a.nblocks = c->g.nblocks;
+  return a;
+}
+// one check interval: freq iterations, pending update, residual + (r,r) -> host
+int fused_interval(pop_ctx *c, int freq, bool first_has_pending) {
+  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  bool pending = first_has_pending;
+  for (int it = 0; it < freq; ++it) {
+    FusedArgs a = fused_args(c);
+    if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, c->g, a);
+    else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, c->g, a);
+    hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, c->g, a);
+    std::swap(c->S0, c->S1);
+    pending = true;
+  }
+  FusedArgs a = fused_args(c);
+  hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_block_sums<1>, dim3(c->g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->gid, c->blocksum);
+  hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, c->blocksum, c->h.nblocks_tot, c->sc, (int)FIN_RR);
+  HIPCHK(c, hipMemcpyAsync(c->host_sc, c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
+  return 0;
+}
+int solver_pcg_fused(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  const int freq = cf.convergence_check_freq;
+  SolverScalars init{}; init.eta0 = 1.0;
+  HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->S0, 0, sizeof(double) * c->g.n2 * c->g.nblocks, c->stream));
+  hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, c->g, fused_args(c));
+  c->numIterations = cf.max_iterations;
+  double rr = 0.0;
+  const bool use_graph = (freq % 2 == 0) && !c->no_graph;
+  int m = 0;
+  while (m + freq <= cf.max_iterations) {
+    if (use_graph) {
+      // the graph is keyed by the solution array (the time-level rotation cycles three of them)
+      double *X = c->PS[c->newt];
+      hipGraphExec_t exec = nullptr;
+      for (auto &g : c->graphs) if (g.first == X) exec = g.second;
+      if (!exec) {
+        hipGraph_t graph;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int e = fused_interval(c, freq, false);
+        hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+        if (e || ce != hipSuccess) { c->err = "solver graph capture failed"; return 1; }
+        HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        c->graphs.push_back({X, exec});
+      }
+      HIPCHK(c, hipGraphLaunch(exec, c->stream));
+    } else if (fused_interval(c, freq, false)) return 1;
+    m += freq;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rr = c->host_sc->rr;
+    if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
+  }
+  if (c->numIterations == cf.max_iterations && m < cf.max_iterations) {   // remainder without a check
+    bool pending = false;
+    for (; m < cf.max_iterations; ++m) {
+      FusedArgs a = fused_args(c);
+      if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, c->g, a);
+      else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, c->g, a);
+      hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, c->g, a);
+      std::swap(c->S0, c->S1);
+      pending = true;
+    }
+    if (pending) hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, c->g, fused_args(c));
+  }
+  if (halo_update(c, c->PS[c->newt], 1)) return 1;   // ghosts of the solution as POP_SolversRun leaves them
+  c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
+  HIPCHK(c, hipGetLastError());
+  if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCG: solver not converged"; return 2; }
+  return 0;
+}
+
 // ChronGear (POP_SolversMod.F90:1960-2266), diagonal preconditioner
 int solver_chrongear(pop_ctx *c) {
   const pop_config &cf = c->h.c;
@@ -394,6 +481,16 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     if (d.nrecv && dev_upload(c, &d.recv_dst, pp.recv_dst.data(), d.nrecv)) return 1;
     c->peers.push_back(d);
   }
+  {   // source map for the fused solver path: ghost cell -> local source cell, -1 = fill value
+    std::vector<int> sm(a2);
+    for (size_t p = 0; p < a2; ++p) sm[p] = (int)p;
+    for (size_t i = 0; i < h.halo.copy_dst.size(); ++i) sm[h.halo.copy_dst[i]] = h.halo.copy_src[i];
+    for (int d : h.halo.fill_dst) sm[d] = -1;
+    if (dev_upload(c, &c->srcmap, sm.data(), sm.size())) return 1;
+    HIPCHK(c, hipHostMalloc((void **)&c->host_sc, sizeof(SolverScalars)));
+    c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED");
+    c->no_graph = getenv("POP_SOLVER_NOGRAPH") != nullptr;
+  }
   // vmix_const: constant coefficients for all time (vmix_const.F90:121-122)
   if (cfg->vmix_choice == 1) {
     std::vector<double> v((size_t)(h.km + 2) * a2, cfg->const_vdc), w(a3, cfg->const_vvc);
@@ -416,6 +513,8 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
 
 int pop_destroy(pop_ctx *c) {
   if (!c) return 0;
+  for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+  if (c->host_sc) hipHostFree(c->host_sc);
   for (void *p : c->allocs) hipFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -641,7 +740,8 @@ int pop_baroclinic_driver(pop_ctx *c) {
 
 int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
-  return c->h.c.solver_choice == 2 ? solver_chrongear(c) : solver_pcg(c);
+  if (c->h.c.solver_choice == 2) return solver_chrongear(c);
+  return c->fused_ok ? solver_pcg_fused(c) : solver_pcg(c);
 }
 int pop_solver_get_diagnostics(const pop_ctx *c, int *it, double *rms) {
   if (it) *it = c->numIterations;
