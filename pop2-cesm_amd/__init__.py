@@ -238,12 +238,13 @@ class PopModel:
         self.L.pop_halo_plan_counts(self.h, C.byref(nl), C.byref(nf), C.byref(npeer))
         dst, src, fill = (C.c_int * max(nl.value, 1))(), (C.c_int * max(nl.value, 1))(), (C.c_int * max(nf.value, 1))()
         self.L.pop_halo_plan_local(self.h, dst, src, fill)
-        plan = {"copy_dst": np.array(dst[:nl.value]), "copy_src": np.array(src[:nl.value]),
-                "fill_dst": np.array(fill[:nf.value]), "peers": []}
+        ia = lambda x: np.array(x, dtype=np.int64)
+        plan = {"copy_dst": ia(dst[:nl.value]), "copy_src": ia(src[:nl.value]),
+                "fill_dst": ia(fill[:nf.value]), "peers": []}
         for ip in range(npeer.value):
             r, ns, nr = C.c_int(), C.c_int(), C.c_int()
             self.L.pop_halo_plan_peer(self.h, ip, C.byref(r), C.byref(ns), C.byref(nr))
             s, d = (C.c_int * max(ns.value, 1))(), (C.c_int * max(nr.value, 1))()
             self.L.pop_halo_plan_lists(self.h, ip, s, d)
-            plan["peers"].append({"rank": r.value, "send_src": np.array(s[:ns.value]), "recv_dst": np.array(d[:nr.value])})
+            plan["peers"].append({"rank": r.value, "send_src": ia(s[:ns.value]), "recv_dst": ia(d[:nr.value])})
         return plan

@@ -1,0 +1,197 @@
+!|||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||
+! pop_amd_c -- ISO_C_BINDING interfaces of libpop_amd.so (include/pop_amd.h).
+! The Fortran host owns namelists and the step sequence; all model state
+! lives on the GPU behind the opaque handle `pop_ctx`.
+!|||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||
+ module pop_amd_c
+
+   use, intrinsic :: iso_c_binding
+   implicit none
+   public
+
+   integer (c_int), parameter :: POP_CREATE_HOST_ONLY = 1
+
+   ! mirrors `struct pop_config` field for field
+   type, bind(C) :: pop_config
+      integer (c_int) :: nx_global, ny_global, km, nt
+      integer (c_int) :: block_size_x, block_size_y
+      integer (c_int) :: ew_boundary, ns_boundary
+      integer (c_int) :: hmix_momentum, hmix_tracer, lvariable_hmix
+      integer (c_int) :: vmix_choice, tadvect, solver_choice
+      integer (c_int) :: max_iterations, convergence_check_freq
+      integer (c_int) :: tmix_opt, time_mix_freq, steps_per_day
+      integer (c_int) :: lbouss_correct, lpressure_avg, impcor, reset_to_freezing
+      integer (c_int) :: lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri
+      integer (c_int) :: reserved_i(8)
+      real (c_double) :: am, ah
+      real (c_double) :: const_vvc, const_vdc
+      real (c_double) :: convect_diff, convect_visc, bottom_drag, aidif
+      real (c_double) :: rich_bckgrnd_vvc, rich_bckgrnd_vdc, rich_mix
+      real (c_double) :: bckgrnd_vdc1, bckgrnd_vdc2, bckgrnd_vdc_dpth, bckgrnd_vdc_linv
+      real (c_double) :: Prandtl, kpp_rich_mix
+      real (c_double) :: convergence_criterion
+      real (c_double) :: reserved_d(8)
+   end type pop_config
+
+   type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task
+
+   interface
+      integer (c_int) function pop_create(cfg, rank, nranks, flags, ctx) bind(C, name='pop_create')
+         import :: c_int, c_ptr, pop_config
+         type (pop_config), intent(in) :: cfg
+         integer (c_int), value :: rank, nranks, flags
+         type (c_ptr), intent(out) :: ctx
+      end function
+      integer (c_int) function pop_destroy(ctx) bind(C, name='pop_destroy')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      type (c_ptr) function pop_last_error(ctx) bind(C, name='pop_last_error')
+         import :: c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_get_dim(ctx, name) bind(C, name='pop_get_dim')
+         import :: c_int, c_ptr, c_char
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+      end function
+      real (c_double) function pop_get_scalar(ctx, name) bind(C, name='pop_get_scalar')
+         import :: c_double, c_ptr, c_char
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+      end function
+      integer (c_int) function pop_get_block(ctx, block_id, out8, i_glob, j_glob) bind(C, name='pop_get_block')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+         integer (c_int), value :: block_id
+         integer (c_int), intent(out) :: out8(8), i_glob(*), j_glob(*)
+      end function
+      integer (c_int) function pop_local_block_ids(ctx, ids) bind(C, name='pop_local_block_ids')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+         integer (c_int), intent(out) :: ids(*)
+      end function
+      integer (c_int) function pop_get_field(ctx, name, tl, n, host, count) bind(C, name='pop_get_field')
+         import :: c_int, c_ptr, c_char, c_double, c_long_long
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+         integer (c_int), value :: tl, n
+         real (c_double), intent(out) :: host(*)
+         integer (c_long_long), value :: count
+      end function
+      integer (c_int) function pop_set_field(ctx, name, tl, n, host, count) bind(C, name='pop_set_field')
+         import :: c_int, c_ptr, c_char, c_double, c_long_long
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+         integer (c_int), value :: tl, n
+         real (c_double), intent(in) :: host(*)
+         integer (c_long_long), value :: count
+      end function
+      integer (c_int) function pop_get_ifield(ctx, name, host, count) bind(C, name='pop_get_ifield')
+         import :: c_int, c_ptr, c_char, c_long_long
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+         integer (c_int), intent(out) :: host(*)
+         integer (c_long_long), value :: count
+      end function
+      integer (c_int) function pop_time_manager(ctx) bind(C, name='pop_time_manager')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_dhdt(ctx) bind(C, name='pop_dhdt')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_baroclinic_driver(ctx) bind(C, name='pop_baroclinic_driver')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_barotropic_driver(ctx) bind(C, name='pop_barotropic_driver')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_baroclinic_correct_adjust(ctx) bind(C, name='pop_baroclinic_correct_adjust')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_step_tail(ctx) bind(C, name='pop_step_tail')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_step(ctx) bind(C, name='pop_step')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_halo_update(ctx, name, tl, n) bind(C, name='pop_halo_update')
+         import :: c_int, c_ptr, c_char
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+         integer (c_int), value :: tl, n
+      end function
+      integer (c_int) function pop_halo_update_host_r8(ctx, array, nz, fill) bind(C, name='pop_halo_update_host_r8')
+         import :: c_int, c_ptr, c_double
+         type (c_ptr), value :: ctx
+         real (c_double), intent(inout) :: array(*)
+         integer (c_int), value :: nz
+         real (c_double), value :: fill
+      end function
+      integer (c_int) function pop_halo_update_host_i4(ctx, array, nz, fill) bind(C, name='pop_halo_update_host_i4')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+         integer (c_int), intent(inout) :: array(*)
+         integer (c_int), value :: nz, fill
+      end function
+      integer (c_int) function pop_global_sum(ctx, name, tl, n, mask_name, res) bind(C, name='pop_global_sum')
+         import :: c_int, c_ptr, c_char, c_double
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+         integer (c_int), value :: tl, n
+         type (c_ptr), value :: mask_name
+         real (c_double), intent(out) :: res
+      end function
+      integer (c_int) function pop_solver_run(ctx) bind(C, name='pop_solver_run')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_solver_get_diagnostics(ctx, iters, rms) bind(C, name='pop_solver_get_diagnostics')
+         import :: c_int, c_ptr, c_double
+         type (c_ptr), value :: ctx
+         integer (c_int), intent(out) :: iters
+         real (c_double), intent(out) :: rms
+      end function
+      integer (c_int) function pop_device_sync(ctx) bind(C, name='pop_device_sync')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+   end interface
+
+ contains
+
+   ! C string helper: trimmed Fortran string + NUL
+   function cstr(s) result(c)
+      character (*), intent(in) :: s
+      character (kind=c_char) :: c(len_trim(s)+1)
+      integer :: i
+      do i = 1, len_trim(s)
+         c(i) = s(i:i)
+      end do
+      c(len_trim(s)+1) = c_null_char
+   end function cstr
+
+   ! error text of the last failing call (POP_ErrorSet analogue)
+   subroutine pop_amd_error_message(msg)
+      character (*), intent(out) :: msg
+      type (c_ptr) :: p
+      character (kind=c_char), pointer :: f(:)
+      integer :: i
+      msg = ' '
+      p = pop_last_error(pop_ctx)
+      if (.not. c_associated(p)) return
+      call c_f_pointer(p, f, [len(msg)])
+      do i = 1, len(msg)
+         if (f(i) == c_null_char) exit
+         msg(i:i) = f(i)
+      end do
+   end subroutine pop_amd_error_message
+
+ end module pop_amd_c

@@ -1,0 +1,225 @@
+!|||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||
+! Modules with the reference's names and argument lists whose bodies forward
+! to the C ABI of libpop_amd.so.  A maintainer drops these in place of the
+! reference modules of the same name (source/blocks.F90, surface_hgt.F90,
+! baroclinic.F90, barotropic.F90, POP_SolversMod.F90, mpi/POP_HaloMod.F90,
+! mpi/POP_ReductionsMod.F90, step_mod.F90); see INTEGRATION.md.
+! Error convention: integer errorCode, POP_Success = 0 on success
+! (source/POP_ErrorMod.F90:82-250); callers re-tag and return.
+!|||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||
+
+ module kinds_mod            ! source/kinds_mod.F90:31-38
+   use, intrinsic :: iso_c_binding
+   implicit none
+   integer, parameter, public :: int_kind = c_int, log_kind = kind(.true.), r8 = c_double, char_len = 256
+   integer, parameter, public :: POP_i4 = c_int, POP_r8 = c_double, POP_Success = 0, POP_Fail = 1
+ end module kinds_mod
+
+!-----------------------------------------------------------------------
+ module blocks               ! source/blocks.F90:30-63, 282-320
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   type, public :: block
+      integer (int_kind) :: block_id, local_id, ib, ie, jb, je, iblock, jblock
+      integer (int_kind), dimension(:), pointer :: i_glob, j_glob
+   end type
+   integer (int_kind), parameter, public :: nghost = 2
+   integer (int_kind), public :: nx_block, ny_block, nblocks_tot, nblocks_x, nblocks_y, nblocks_clinic
+   public :: get_block, init_blocks_from_ctx
+ contains
+   subroutine init_blocks_from_ctx
+      nx_block       = pop_get_dim(pop_ctx, cstr('nx_block'))
+      ny_block       = pop_get_dim(pop_ctx, cstr('ny_block'))
+      nblocks_tot    = pop_get_dim(pop_ctx, cstr('nblocks_tot'))
+      nblocks_x      = pop_get_dim(pop_ctx, cstr('nblocks_x'))
+      nblocks_y      = pop_get_dim(pop_ctx, cstr('nblocks_y'))
+      nblocks_clinic = pop_get_dim(pop_ctx, cstr('nblocks'))
+   end subroutine
+   function get_block(block_id, local_id)
+      integer (int_kind), intent(in) :: block_id, local_id
+      type (block) :: get_block
+      integer (c_int) :: o(8), ierr
+      allocate(get_block%i_glob(nx_block), get_block%j_glob(ny_block))
+      ierr = pop_get_block(pop_ctx, block_id, o, get_block%i_glob, get_block%j_glob)
+      if (ierr /= 0) stop 'get_block: invalid block_id'       ! exit_POP(sigAbort,...) blocks.F90:309-311
+      get_block%block_id = o(1); get_block%local_id = local_id
+      get_block%ib = o(3); get_block%ie = o(4); get_block%jb = o(5); get_block%je = o(6)
+      get_block%iblock = o(7); get_block%jblock = o(8)
+   end function get_block
+ end module blocks
+
+!-----------------------------------------------------------------------
+ module POP_HaloMod          ! mpi/POP_HaloMod.F90:79-89, 1732-1773
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   public :: POP_HaloUpdate, POP_HaloUpdateField
+   interface POP_HaloUpdate
+      module procedure POP_HaloUpdate2DR8, POP_HaloUpdate3DR8, POP_HaloUpdate2DI4
+   end interface
+ contains
+   ! device-resident field, addressed by the reference's variable name
+   subroutine POP_HaloUpdateField(name, timeLevel, n, errorCode)
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_halo_update(pop_ctx, cstr(name), timeLevel, n)
+   end subroutine
+   ! host arrays (init-time fields): array(nx_block,ny_block,nblocks)
+   subroutine POP_HaloUpdate2DR8(array, errorCode, fillValue)
+      real (POP_r8), dimension(:,:,:), intent(inout) :: array
+      integer (POP_i4), intent(out) :: errorCode
+      real (POP_r8), intent(in), optional :: fillValue
+      real (POP_r8) :: fill
+      fill = 0.0_POP_r8
+      if (present(fillValue)) fill = fillValue
+      errorCode = pop_halo_update_host_r8(pop_ctx, array, 1, fill)
+   end subroutine
+   subroutine POP_HaloUpdate3DR8(array, errorCode, fillValue)
+      real (POP_r8), dimension(:,:,:,:), intent(inout) :: array    ! (nx,ny,nz,nblocks)
+      integer (POP_i4), intent(out) :: errorCode
+      real (POP_r8), intent(in), optional :: fillValue
+      real (POP_r8) :: fill
+      fill = 0.0_POP_r8
+      if (present(fillValue)) fill = fillValue
+      errorCode = pop_halo_update_host_r8(pop_ctx, array, size(array,3), fill)
+   end subroutine
+   subroutine POP_HaloUpdate2DI4(array, errorCode, fillValue)
+      integer (POP_i4), dimension(:,:,:), intent(inout) :: array
+      integer (POP_i4), intent(out) :: errorCode
+      integer (POP_i4), intent(in), optional :: fillValue
+      integer (POP_i4) :: fill
+      fill = 0
+      if (present(fillValue)) fill = fillValue
+      errorCode = pop_halo_update_host_i4(pop_ctx, array, 1, fill)
+   end subroutine
+ end module POP_HaloMod
+
+!-----------------------------------------------------------------------
+ module POP_ReductionsMod    ! mpi/POP_ReductionsMod.F90:144-389
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   public :: POP_GlobalSum
+ contains
+   ! global sum of a device-resident field over the physical domain, optionally times mMask
+   function POP_GlobalSum(name, timeLevel, n, errorCode, mMask) result(globalSum)
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      integer (POP_i4), intent(out) :: errorCode
+      character (*), intent(in), optional :: mMask
+      real (POP_r8) :: globalSum
+      character (kind=c_char), allocatable, target :: m(:)
+      if (present(mMask)) then
+         m = cstr(mMask)
+         errorCode = pop_global_sum(pop_ctx, cstr(name), timeLevel, n, c_loc(m), globalSum)
+      else
+         errorCode = pop_global_sum(pop_ctx, cstr(name), timeLevel, n, c_null_ptr, globalSum)
+      endif
+   end function POP_GlobalSum
+ end module POP_ReductionsMod
+
+!-----------------------------------------------------------------------
+ module POP_SolversMod       ! source/POP_SolversMod.F90:43-47
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   public :: POP_SolversRun, POP_SolversGetDiagnostics
+ contains
+   ! operates on PSURF(:,:,newtime,:) and the barotropic RHS, both device resident
+   subroutine POP_SolversRun(errorCode)
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_solver_run(pop_ctx)
+   end subroutine
+   subroutine POP_SolversGetDiagnostics(iterationCount, residual, errorCode)
+      integer (POP_i4), intent(out) :: iterationCount, errorCode
+      real (POP_r8), intent(out) :: residual
+      errorCode = pop_solver_get_diagnostics(pop_ctx, iterationCount, residual)
+   end subroutine
+ end module POP_SolversMod
+
+!-----------------------------------------------------------------------
+ module surface_hgt          ! source/surface_hgt.F90:131
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   public :: dhdt
+ contains
+   ! DH, DHU stay on the device; the optional host copies keep the reference signature usable
+   subroutine dhdt(DH, DHU)
+      real (r8), dimension(:,:,:), intent(out), optional :: DH, DHU
+      integer (c_int) :: ierr
+      ierr = pop_dhdt(pop_ctx)
+      if (present(DH))  ierr = pop_get_field(pop_ctx, cstr('DH'),  1, 0, DH,  int(size(DH), c_long_long))
+      if (present(DHU)) ierr = pop_get_field(pop_ctx, cstr('DHU'), 1, 0, DHU, int(size(DHU), c_long_long))
+   end subroutine dhdt
+ end module surface_hgt
+
+!-----------------------------------------------------------------------
+ module baroclinic           ! source/baroclinic.F90:578, 1217
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   public :: baroclinic_driver, baroclinic_correct_adjust
+ contains
+   subroutine baroclinic_driver(errorCode, ZX, ZY)
+      integer (POP_i4), intent(out) :: errorCode
+      real (r8), dimension(:,:,:), intent(out), optional :: ZX, ZY   ! host copies on request
+      integer (c_int) :: ierr
+      errorCode = pop_baroclinic_driver(pop_ctx)
+      if (errorCode /= POP_Success) return
+      if (present(ZX)) ierr = pop_get_field(pop_ctx, cstr('ZX'), 1, 0, ZX, int(size(ZX), c_long_long))
+      if (present(ZY)) ierr = pop_get_field(pop_ctx, cstr('ZY'), 1, 0, ZY, int(size(ZY), c_long_long))
+   end subroutine
+   subroutine baroclinic_correct_adjust
+      integer (c_int) :: ierr
+      ierr = pop_baroclinic_correct_adjust(pop_ctx)
+   end subroutine
+ end module baroclinic
+
+!-----------------------------------------------------------------------
+ module barotropic           ! source/barotropic.F90:267
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   public :: barotropic_driver
+ contains
+   subroutine barotropic_driver(errorCode)
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_barotropic_driver(pop_ctx)
+   end subroutine
+ end module barotropic
+
+!-----------------------------------------------------------------------
+ module step_mod             ! source/step_mod.F90:126-911
+   use kinds_mod
+   use pop_amd_c
+   use surface_hgt, only: dhdt
+   use baroclinic, only: baroclinic_driver, baroclinic_correct_adjust
+   use barotropic, only: barotropic_driver
+   implicit none
+   private
+   public :: step
+ contains
+   ! the reference's call sequence, phase by phase (step_mod.F90:296-832)
+   subroutine step(errorCode)
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_time_manager(pop_ctx)             ! time_manager / set_switches
+      if (errorCode /= POP_Success) return
+      call dhdt()                                       ! :361
+      call baroclinic_driver(errorCode)                 ! :369
+      if (errorCode /= POP_Success) return              ! 'step: error in baroclinic driver'
+      call barotropic_driver(errorCode)                 ! :405-445 (ZX,ZY halo + solver)
+      if (errorCode /= POP_Success) return              ! 'Step: error in barotropic'
+      call baroclinic_correct_adjust                    ! :458
+      errorCode = pop_step_tail(pop_ctx)                ! :467-832
+   end subroutine step
+ end module step_mod

@@ -1,0 +1,67 @@
+"""Generates the committed golden vectors with the CPU oracle (oracle/libpop_oracle.so).
+
+The reference holds no fixtures for advection / hmix / vmix / the solver, so these
+vectors pin the path against the CPU restatement of the reference algorithm: inputs are fully
+determined by the configuration (synthetic grid, Levitus profile + analytic perturbation, analytic
+wind) plus the surface fluxes set in prepare(); outputs are the prognostic fields after N steps.
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/golden_*.npz
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from popcfg import named_config  # noqa: E402
+
+FIELDS = [("TRACER", True), ("UVEL", True), ("VVEL", True), ("RHO", True), ("PSURF", False), ("UBTROP", False)]
+NSTEPS = {"const": 4, "kpp_del4": 4}
+
+
+def config(case):
+    small = dict(nx_global=24, ny_global=20, km=16, block_size_x=12, block_size_y=10)
+    if case == "const":
+        return named_config("tiny", **small)
+    if case == "kpp_del4":
+        return named_config("tiny", vmix_choice=3, ldbl_diff=1, hmix_momentum=4, hmix_tracer=4, lvariable_hmix=1,
+                            am=-1.0e23, ah=-1.0e22, solver_choice=2, **small)
+    raise KeyError(case)
+
+
+def surface_fluxes(tlat):
+    return -2.0e-2 * np.sin(tlat) - 5.0e-3, 2.0e-6 * np.cos(2.0 * tlat)
+
+
+def prepare(model, case):
+    """Set the surface tracer fluxes (the KPP case needs buoyancy forcing).  `model` is an Oracle or a
+    PopModel-like object with f2()/set()."""
+    if case != "kpp_del4":
+        return
+    tlat = model.f2("TLAT") if hasattr(model, "f2") else model.get("TLAT")
+    st, ss = surface_fluxes(tlat)
+    if hasattr(model, "f2"):
+        model.f2("STF", 1, 0)[...] = st
+        model.f2("STF", 1, 1)[...] = ss
+    else:
+        model.set("STF", st, n=0)
+        model.set("STF", ss, n=1)
+
+
+def main():
+    from orclib import Oracle
+    for case in NSTEPS:
+        o = Oracle(config(case))
+        prepare(o, case)
+        iters = [o.step() for _ in range(NSTEPS[case])]
+        out = {"nsteps": NSTEPS[case], "iters": np.array(iters)}
+        for name, three_d in FIELDS:
+            out[name] = (o.f3 if three_d else o.f2)(name, 1, 0).copy()
+        np.savez_compressed(os.path.join(HERE, "golden_%s.npz" % case), **out)
+        print(case, "iters", iters, "Tmax", out["TRACER"].max())
+        o.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""N > 1 logic on CPU (gloo, world_size 2 and 4): block ownership, the halo message plan and the
+b4b block-sum all-reduce.  Each rank builds a host-only context (no GPU), packs its outgoing cells
+exactly as the device pack kernel would (plan index lists), exchanges through torch.distributed and
+unpacks; the result must satisfy the reference's halo rule (test/unit/halo/POP.F90Dipole:134-147)
+and equal the single-rank halo bit for bit.  The block-sum vector all-reduce must reproduce the
+single-rank global sum bitwise (mpi/POP_ReductionsMod.F90:348-383)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, kw, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as ge
+    from popcfg import named_config
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        cfg = named_config("tiny", **kw)
+        m = pkg.PopModel(cfg, rank=rank, nranks=world, host_only=True)
+        ref = pkg.PopModel(cfg, host_only=True)                 # single-rank view of the same domain
+        ids = m.local_block_ids()
+        nb, ny, nx, n2 = m.nblocks, m.nyb, m.nxb, m.nyb * m.nxb
+        nz = 3
+        # field = iGlobal + jGlobal (+1000 k) on the physical domain, ghosts -999
+        full = np.full((ref.nblocks, nz, ny, nx), -999.0)
+        for b in range(ref.nblocks):
+            blk = ref.get_block(b + 1)
+            g = (blk["i_glob"][None, :] + blk["j_glob"][:, None]).astype(float)
+            for k in range(nz):
+                full[b, k, 2:-2, 2:-2] = g[2:-2, 2:-2] + 1000.0 * k
+        loc = np.stack([full[bid - 1] for bid in ids]).copy()     # (nb, nz, ny, nx)
+        flat = loc.reshape(nb, nz, n2)
+        plan = m.halo_plan()
+        cell = lambda idx: (idx // n2, idx % n2)
+        ops, recv_bufs = [], []
+        for p in plan["peers"]:
+            sb, sc = cell(p["send_src"])
+            send = torch.from_numpy(np.ascontiguousarray(flat[sb, :, sc].T))      # [level][cell], as k_halo_pack
+            rbuf = torch.empty((nz, len(p["recv_dst"])), dtype=torch.float64)
+            recv_bufs.append((p, rbuf))
+            ops.append(dist.P2POp(dist.irecv, rbuf, p["rank"]))
+            ops.append(dist.P2POp(dist.isend, send, p["rank"]))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        for p, rbuf in recv_bufs:
+            db, dc = cell(p["recv_dst"])
+            flat[db, :, dc] = rbuf.numpy().T
+        db, dc = cell(plan["copy_dst"]); sb, sc = cell(plan["copy_src"])
+        flat[db, :, dc] = flat[sb, :, sc]
+        fb, fc = cell(plan["fill_dst"])
+        flat[fb, :, fc] = 0.0
+        # expected: the single-rank host halo of the full field
+        exp = full.copy()
+        ref.halo_update_host(exp)
+        ok_halo = all(np.array_equal(loc[i], exp[bid - 1]) for i, bid in enumerate(ids))
+        # b4b global sum: local block sums -> all-reduce of the block vector -> ordered sum
+        rng = np.random.default_rng(5)
+        field = rng.standard_normal((ref.nblocks, ny, nx))
+        vec = torch.zeros(ref.nblocks, dtype=torch.float64)
+        for bid in ids:
+            s = 0.0
+            for row in field[bid - 1, 2:-2, 2:-2]:
+                for v in row:
+                    s = s + v
+            vec[bid - 1] = s
+        dist.all_reduce(vec)
+        total = 0.0
+        for v in vec.tolist():
+            total = total + v
+        serial = 0.0
+        for b in range(ref.nblocks):
+            s = 0.0
+            for row in field[b, 2:-2, 2:-2]:
+                for v in row:
+                    s = s + v
+            serial = serial + s
+        q.put((rank, ok_halo, total == serial, len(plan["peers"]), sorted(ids)))
+        m.close(); ref.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kw", [(2, {}), (4, {}), (2, {"block_size_x": 48, "block_size_y": 20}),
+                                      (2, {"ew_boundary": 0})])
+def test_halo_plan_and_block_sums_over_gloo(pkg, world, kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owned = []
+    for rank, ok_halo, ok_sum, npeers, ids in res:
+        assert ok_halo, "rank %d: exchanged halo differs from the single-rank halo" % rank
+        assert ok_sum, "rank %d: b4b block-sum all-reduce differs from the serial sum" % rank
+        assert npeers >= 1
+        owned += ids
+    assert sorted(owned) == list(range(1, max(owned) + 1))
