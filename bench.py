@@ -57,7 +57,8 @@ class TorchComm:
     """RCCL transport for the library's halo messages and block-sum all-reduce.  The library packs
     into / unpacks from torch-owned device buffers; everything runs on torch's current stream."""
 
-    def __init__(self, pkg, model, rank, nranks):
+    def __init__(self, pkg, model, rank, nranks, staged=False):
+        # staged=True: CPU-staged transport over a gloo group (tests on one GPU); default: RCCL
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -65,19 +66,29 @@ class TorchComm:
         dev = torch.device("cuda", torch.cuda.current_device())
         self.send = torch.zeros(n, dtype=torch.float64, device=dev)
         self.recv = torch.zeros(n, dtype=torch.float64, device=dev)
-        self.red = torch.zeros(max(4 * model.nblocks_tot, 8), dtype=torch.float64, device=dev)
+        nred = max(int(model.L.pop_reduce_buffer_doubles(model.h)), 8)
+        self.red = torch.zeros(nred, dtype=torch.float64, device=dev)
 
         def xchg(user, nmsg, peer, soff, scnt, roff, rcnt):
             try:
-                ops = []
+                ops, back = [], []
+                if staged:
+                    torch.cuda.synchronize()
                 for i in range(nmsg):
                     if rcnt[i]:
-                        ops.append(dist.P2POp(dist.irecv, self.recv[roff[i]:roff[i] + rcnt[i]], peer[i]))
+                        dst = self.recv[roff[i]:roff[i] + rcnt[i]]
+                        buf = torch.empty(rcnt[i], dtype=torch.float64) if staged else dst
+                        if staged:
+                            back.append((dst, buf))
+                        ops.append(dist.P2POp(dist.irecv, buf, peer[i]))
                     if scnt[i]:
-                        ops.append(dist.P2POp(dist.isend, self.send[soff[i]:soff[i] + scnt[i]], peer[i]))
+                        src = self.send[soff[i]:soff[i] + scnt[i]]
+                        ops.append(dist.P2POp(dist.isend, src.cpu() if staged else src, peer[i]))
                 if ops:
                     for r in dist.batch_isend_irecv(ops):
                         r.wait()
+                for dst, buf in back:
+                    dst.copy_(buf)
                 return 0
             except Exception as e:  # noqa: BLE001
                 print("exchange failed:", e, file=sys.stderr)
@@ -85,14 +96,25 @@ class TorchComm:
 
         def allred(user, off, cnt):
             try:
-                dist.all_reduce(self.red[off:off + cnt])
+                if staged:
+                    torch.cuda.synchronize()
+                    h = self.red[off:off + cnt].cpu()
+                    dist.all_reduce(h)
+                    self.red[off:off + cnt].copy_(h)
+                else:
+                    dist.all_reduce(self.red[off:off + cnt])
                 return 0
             except Exception as e:  # noqa: BLE001
                 print("allreduce failed:", e, file=sys.stderr)
                 return 1
 
         self._x, self._a = pkg.XCHG_FN(xchg), pkg.ALLRED_FN(allred)
-        model._chk(model.L.pop_set_stream(model.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        # a dedicated non-default stream shared by the library's kernels and torch's collectives
+        # (graph capture is not allowed on the legacy default stream)
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
+        model._chk(model.L.pop_set_stream(model.h, C.c_void_p(self.stream.cuda_stream)))
+        model._chk(model.L.pop_set_reduce_buffer(model.h, C.c_void_p(self.red.data_ptr()), nred))
         model._chk(model.L.pop_set_comm(model.h, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr()),
                                         C.c_void_p(self.red.data_ptr()), n, self._x, self._a, None))
 
@@ -129,17 +151,23 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libpop_amd has no CPU fallback")
-    torch.cuda.set_device(local)
+    # POP_BENCH_BACKEND=gloo: CPU-staged transport so the N>1 path can be rehearsed on a 1-GPU box
+    backend = os.environ.get("POP_BENCH_BACKEND", "nccl")
+    dev = local % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     import __graft_entry__ as ge
     pkg = ge.load_package()
     cfg = workload_config(args.workload, world)
     model = pkg.PopModel(cfg, rank=rank, nranks=world)
-    comm = TorchComm(pkg, model, rank, world) if world > 1 else None  # noqa: F841
+    comm = TorchComm(pkg, model, rank, world, staged=(backend != "nccl")) if world > 1 else None  # noqa: F841
 
     def barrier():
         model.sync()
@@ -159,7 +187,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_step = 1e3 * elapsed / args.steps

@@ -133,6 +133,9 @@ typedef int (*pop_allreduce_fn)(void *user, long long off, long long cnt);
 int pop_set_comm(pop_ctx *ctx, void *dev_sendbuf, void *dev_recvbuf, void *dev_redbuf,
                  long long buf_doubles, pop_exchange_fn xchg, pop_allreduce_fn allred, void *user);
 long long pop_comm_buffer_doubles(const pop_ctx *ctx);   /* size the host must provide */
+/* reduce buffer (block-sum vectors; in replicated-barotropic mode also the gathered RHS + guess) */
+long long pop_reduce_buffer_doubles(const pop_ctx *ctx);
+int pop_set_reduce_buffer(pop_ctx *ctx, void *dev_redbuf, long long doubles);
 /* halo plan introspection (host logic, testable without a GPU) */
 int pop_halo_plan_counts(const pop_ctx *ctx, int *n_local_copies, int *n_fill, int *n_peers);
 int pop_halo_plan_peer(const pop_ctx *ctx, int ipeer, int *peer_rank, int *n_send, int *n_recv);

@@ -60,6 +60,7 @@ def lib():
         "pop_state_host": (ci, [vp, ci, pd, pd, pd, pd, pd, ll]),
         "pop_set_comm": (ci, [vp, vp, vp, vp, ll, XCHG_FN, ALLRED_FN, vp]),
         "pop_comm_buffer_doubles": (ll, [vp]), "pop_set_stream": (ci, [vp, vp]),
+        "pop_reduce_buffer_doubles": (ll, [vp]), "pop_set_reduce_buffer": (ci, [vp, vp, ll]),
         "pop_halo_plan_counts": (ci, [vp, pi, pi, pi]), "pop_halo_plan_peer": (ci, [vp, ci, pi, pi, pi]),
         "pop_halo_plan_lists": (ci, [vp, ci, pi, pi]), "pop_halo_plan_local": (ci, [vp, pi, pi, pi]),
         "pop_timers_reset": (ci, [vp]), "pop_timer_ms": (ci, [vp, cs, pd, pi]),

@@ -61,4 +61,25 @@ void build_halo_plan(HostModel &h) {
   }
 }
 
+// source map over ALL blocks (single-rank view of the decomposition): interior cells map to
+// themselves, ghosts to the interior cell that owns their global index, -1 where the fill value applies
+std::vector<int> global_srcmap(const HostModel &h) {
+  const pop_config &c = h.c;
+  std::vector<int> sm(h.n2 * h.nblocks_tot);
+  for (int b = 0; b < h.nblocks_tot; ++b) {
+    const BlockInfo &B = h.all_blocks[b];
+    for (int j = 1; j <= h.nyb; ++j)
+      for (int i = 1; i <= h.nxb; ++i) {
+        const int cell = b * (int)h.n2 + (j - 1) * h.nxb + (i - 1);
+        if (i >= B.ib && i <= B.ie && j >= B.jb && j <= B.je) { sm[cell] = cell; continue; }
+        const int gi = B.i_glob[i - 1], gj = B.j_glob[j - 1];
+        if (gi <= 0 || gj <= 0) { sm[cell] = -1; continue; }
+        const int sbx = (gi - 1) / c.block_size_x, sby = (gj - 1) / c.block_size_y;
+        const int si = gi - sbx * c.block_size_x + NGHOST, sj = gj - sby * c.block_size_y + NGHOST;
+        sm[cell] = (sby * h.nbx + sbx) * (int)h.n2 + (sj - 1) * h.nxb + (si - 1);
+      }
+  }
+  return sm;
+}
+
 }  // namespace pop

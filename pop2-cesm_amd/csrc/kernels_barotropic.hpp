@@ -514,4 +514,27 @@ k_fresidual(DevGrid g, FusedArgs a) {
   if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * gridDim.x + blockIdx.x);
 }
 
+// view of the 2-D system the fused solver works on
+struct SolveView {
+  DevGrid g;
+  double *X, *R, *Z, *S0, *S1, *Q, *RHS, *C, *partial, *blocksum;
+  int *srcmap, *gid;
+  int nchunk, nblocks_tot;
+};
+// ghost cells <- source cells / fill value (every source is an interior cell of the same array)
+__global__ void k_halo_srcmap(double *__restrict__ X, const int *__restrict__ srcmap, long long n) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int m = srcmap[q];
+  if (m != (int)q) X[q] = (m < 0) ? 0.0 : X[m];
+}
+// operator centre weight on all blocks (barotropic.F90:535-554, POP_SolversMod.F90:1144)
+__global__ void k_center_all(DevGrid g, StepParams sp, const double *__restrict__ TAREA, const int *__restrict__ KMT,
+                             double *__restrict__ C, long long n) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const double dc = (KMT[q] >= 1) ? TAREA[q] / (sp.beta * sp.c2dtp * sp.dtp * sp.grav) : 0.0;
+  C[q] = g.WC0[q] - dc;
+}
+
 }  // namespace pop

@@ -51,7 +51,9 @@ struct pop_ctx {
   int *gid = nullptr, *srcmap = nullptr;
   SolverScalars *host_sc = nullptr;                       // pinned
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
-  bool no_graph = false, fused_ok = false;
+  bool no_graph = false, fused_ok = false, replicated = false;
+  SolveView gv{};                                         // replicated barotropic mode: all blocks
+  double *gTAREA = nullptr; int *gKMT = nullptr;
   int nchunk = 0, numIterations = 0;
   double rmsResidual = 0.0;
   // halo plan on device
@@ -60,7 +62,7 @@ struct pop_ctx {
   std::vector<DevPeer> peers;
   // comm hooks
   double *sendbuf = nullptr, *recvbuf = nullptr, *redbuf = nullptr;
-  long long comm_doubles = 0;
+  long long comm_doubles = 0, red_doubles = 0;
   pop_exchange_fn xchg = nullptr;
   pop_allreduce_fn allred = nullptr;
   void *comm_user = nullptr;
@@ -233,44 +235,47 @@ int solver_pcg(pop_ctx *c) {
   return 0;
 }
 
-// pcg, fused single-rank form: two launches per iteration, halo folded into the matvec through
-// srcmap, final reduction stage recomputed by the consumer kernel, and one hipGraph replay per
-// convergenceCheckFreq iterations (same arithmetic and summation order as solver_pcg).
-FusedArgs fused_args(pop_ctx *c) {
+// pcg, fused form: two launches per iteration, halo folded into the matvec through srcmap, final
+// reduction stage recomputed by the consumer kernel, and one hipGraph replay per
+// convergenceCheckFreq iterations (same arithmetic and summation order as solver_pcg).  It runs on a
+// SolveView: the rank's own blocks (single rank), or -- replicated barotropic mode -- every block
+// of the decomposition on every rank.
+FusedArgs fused_args(pop_ctx *c, const SolveView &v) {
   FusedArgs a{};
-  a.X = c->PS[c->newt]; a.R = c->R; a.Z = c->Z; a.S0 = c->S0; a.S1 = c->S1; a.Q = c->Q;
-  a.Bv = c->RHS; a.C = c->centerWgt; a.partA = c->partial; a.partB = c->partial + (size_t)c->nchunk * c->g.nblocks;
-  a.sc = c->sc; a.srcmap = c->srcmap; a.nchunk = c->nchunk; a.nblocks = c->g.nblocks;
+  a.X = v.X; a.R = v.R; a.Z = v.Z; a.S0 = v.S0; a.S1 = v.S1; a.Q = v.Q;
+  a.Bv = v.RHS; a.C = v.C; a.partA = v.partial; a.partB = v.partial + (size_t)v.nchunk * v.g.nblocks;
+  a.sc = c->sc; a.srcmap = v.srcmap; a.nchunk = v.nchunk; a.nblocks = v.g.nblocks;
   return a;
 }
+dim3 view_grid(const SolveView &v) { return dim3((v.g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS, v.g.nblocks); }
 // one check interval: freq iterations, pending update, residual + (r,r) -> host
-int fused_interval(pop_ctx *c, int freq, bool first_has_pending) {
-  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
+  const dim3 G = view_grid(v), B(POP_RED_THREADS);
   bool pending = first_has_pending;
   for (int it = 0; it < freq; ++it) {
-    FusedArgs a = fused_args(c);
-    if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, c->g, a);
-    else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, c->g, a);
-    hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, c->g, a);
-    std::swap(c->S0, c->S1);
+    FusedArgs a = fused_args(c, v);
+    if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
+    else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
+    hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, v.g, a);
+    std::swap(v.S0, v.S1);
     pending = true;
   }
-  FusedArgs a = fused_args(c);
-  hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, c->g, a);
-  hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, c->g, a);
-  hipLaunchKernelGGL(k_block_sums<1>, dim3(c->g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->gid, c->blocksum);
-  hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, c->blocksum, c->h.nblocks_tot, c->sc, (int)FIN_RR);
+  FusedArgs a = fused_args(c, v);
+  hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, a);
+  hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, v.g, a);
+  hipLaunchKernelGGL(k_block_sums<1>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, v.partial, v.nchunk, v.gid, v.blocksum);
+  hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, v.blocksum, v.nblocks_tot, c->sc, (int)FIN_RR);
   HIPCHK(c, hipMemcpyAsync(c->host_sc, c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
   return 0;
 }
-int solver_pcg_fused(pop_ctx *c) {
+int solver_pcg_fused(pop_ctx *c, SolveView &v) {
   const pop_config &cf = c->h.c;
-  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  const dim3 G = view_grid(v), B(POP_RED_THREADS);
   const int freq = cf.convergence_check_freq;
   SolverScalars init{}; init.eta0 = 1.0;
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->S0, 0, sizeof(double) * c->g.n2 * c->g.nblocks, c->stream));
-  hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, c->g, fused_args(c));
+  HIPCHK(c, hipMemsetAsync(v.S0, 0, sizeof(double) * v.g.n2 * v.g.nblocks, c->stream));
+  hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, v.g, fused_args(c, v));
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
   const bool use_graph = (freq % 2 == 0) && !c->no_graph;
@@ -278,21 +283,20 @@ int solver_pcg_fused(pop_ctx *c) {
   while (m + freq <= cf.max_iterations) {
     if (use_graph) {
       // the graph is keyed by the solution array (the time-level rotation cycles three of them)
-      double *X = c->PS[c->newt];
       hipGraphExec_t exec = nullptr;
-      for (auto &g : c->graphs) if (g.first == X) exec = g.second;
+      for (auto &g : c->graphs) if (g.first == v.X) exec = g.second;
       if (!exec) {
         hipGraph_t graph;
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        const int e = fused_interval(c, freq, false);
+        const int e = fused_interval(c, v, freq, false);
         hipError_t ce = hipStreamEndCapture(c->stream, &graph);
         if (e || ce != hipSuccess) { c->err = "solver graph capture failed"; return 1; }
         HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         hipGraphDestroy(graph);
-        c->graphs.push_back({X, exec});
+        c->graphs.push_back({v.X, exec});
       }
       HIPCHK(c, hipGraphLaunch(exec, c->stream));
-    } else if (fused_interval(c, freq, false)) return 1;
+    } else if (fused_interval(c, v, freq, false)) return 1;
     m += freq;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     rr = c->host_sc->rr;
@@ -301,19 +305,56 @@ int solver_pcg_fused(pop_ctx *c) {
   if (c->numIterations == cf.max_iterations && m < cf.max_iterations) {   // remainder without a check
     bool pending = false;
     for (; m < cf.max_iterations; ++m) {
-      FusedArgs a = fused_args(c);
-      if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, c->g, a);
-      else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, c->g, a);
-      hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, c->g, a);
-      std::swap(c->S0, c->S1);
+      FusedArgs a = fused_args(c, v);
+      if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
+      else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
+      hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, v.g, a);
+      std::swap(v.S0, v.S1);
       pending = true;
     }
-    if (pending) hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, c->g, fused_args(c));
+    if (pending) hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, fused_args(c, v));
   }
-  if (halo_update(c, c->PS[c->newt], 1)) return 1;   // ghosts of the solution as POP_SolversRun leaves them
+  // ghosts of the solution as POP_SolversRun leaves them (every ghost has a source inside the view)
+  const long long ncell = (long long)v.g.n2 * v.g.nblocks;
+  hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, v.X, v.srcmap, ncell);
   c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
   HIPCHK(c, hipGetLastError());
   if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCG: solver not converged"; return 2; }
+  return 0;
+}
+SolveView local_view(pop_ctx *c) {
+  SolveView v{};
+  v.g = c->g; v.X = c->PS[c->newt]; v.R = c->R; v.Z = c->Z; v.S0 = c->S0; v.S1 = c->S1; v.Q = c->Q;
+  v.RHS = c->RHS; v.C = c->centerWgt; v.partial = c->partial; v.blocksum = c->blocksum;
+  v.srcmap = c->srcmap; v.gid = c->gid; v.nchunk = c->nchunk; v.nblocks_tot = c->h.nblocks_tot;
+  return v;
+}
+// Replicated barotropic mode (small 2-D problems on several GPUs): the tropic distribution of the
+// reference (domain.F90:433-543, POP_RedistributeBlocks around the solve, POP_SolversMod.F90:390-417,
+// 481) taken to its limit -- every rank gathers RHS and the first guess of ALL blocks with one
+// all-reduce of disjoint contributions, runs the fused solver on the whole 2-D domain with no
+// per-iteration communication, and keeps its own blocks.  Arithmetic and iteration count equal the
+// single-rank run (same blocks, same b4b sums).
+int solver_pcg_replicated(pop_ctx *c) {
+  SolveView &v = c->gv;
+  const size_t n2 = c->g.n2, NG = n2 * c->h.nblocks_tot;
+  double *PN = c->PS[c->newt];
+  HIPCHK(c, hipMemsetAsync(c->redbuf, 0, sizeof(double) * 2 * NG, c->stream));
+  for (int lb = 0; lb < c->g.nblocks; ++lb) {
+    const size_t go = (size_t)(c->h.local_ids[lb] - 1) * n2;
+    HIPCHK(c, hipMemcpyAsync(c->redbuf + go, c->RHS + lb * n2, n2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->redbuf + NG + go, PN + lb * n2, n2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (c->allred(c->comm_user, 0, (long long)(2 * NG))) { c->err = "replicated solve: allreduce callback failed"; return 1; }
+  HIPCHK(c, hipMemcpyAsync(v.RHS, c->redbuf, NG * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(v.X, c->redbuf + NG, NG * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_center_all, dim3((unsigned)((NG + 255) / 256)), dim3(256), 0, c->stream, v.g, step_params(c), c->gTAREA, c->gKMT, v.C, (long long)NG);
+  const int e = solver_pcg_fused(c, v);
+  if (e) return e;
+  for (int lb = 0; lb < c->g.nblocks; ++lb) {
+    const size_t go = (size_t)(c->h.local_ids[lb] - 1) * n2;
+    HIPCHK(c, hipMemcpyAsync(PN + lb * n2, v.X + go, n2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
   return 0;
 }
 
@@ -490,6 +531,28 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     HIPCHK(c, hipHostMalloc((void **)&c->host_sc, sizeof(SolverScalars)));
     c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED");
     c->no_graph = getenv("POP_SOLVER_NOGRAPH") != nullptr;
+    c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && h.nblocks_tot <= 8 &&
+                    (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !getenv("POP_SOLVER_DISTRIBUTED");
+    if (c->replicated) {
+      const size_t NG = h.n2 * h.nblocks_tot;
+      SolveView &v = c->gv;
+      v.g = c->g; v.g.nblocks = h.nblocks_tot;
+      double *p;
+      if (dev_upload(c, &p, h.f2["btropWgtNE"].data(), NG)) return 1; v.g.WNE = p;
+      if (dev_upload(c, &p, h.f2["btropWgtEast"].data(), NG)) return 1; v.g.WEa = p;
+      if (dev_upload(c, &p, h.f2["btropWgtNorth"].data(), NG)) return 1; v.g.WNo = p;
+      if (dev_upload(c, &p, h.f2["centerWgtIndep"].data(), NG)) return 1; v.g.WC0 = p;
+      if (dev_upload(c, &p, h.f2["mMask"].data(), NG)) return 1; v.g.mMask = p;
+      if (dev_upload(c, &c->gTAREA, h.f2["TAREA"].data(), NG)) return 1;
+      if (dev_upload(c, &c->gKMT, h.i2["KMT"].data(), NG)) return 1;
+      double **vecs[] = {&v.X, &v.R, &v.Z, &v.S0, &v.S1, &v.Q, &v.RHS, &v.C};
+      for (auto q : vecs) if (dev_alloc(c, q, NG)) return 1;
+      if (dev_alloc(c, &v.partial, (size_t)c->nchunk * h.nblocks_tot * 2) || dev_alloc(c, &v.blocksum, (size_t)h.nblocks_tot * 2)) return 1;
+      std::vector<int> gsm = global_srcmap(h), gid(h.nblocks_tot);
+      for (int b = 0; b < h.nblocks_tot; ++b) gid[b] = b;
+      if (dev_upload(c, &v.srcmap, gsm.data(), gsm.size()) || dev_upload(c, &v.gid, gid.data(), gid.size())) return 1;
+      v.nchunk = c->nchunk; v.nblocks_tot = h.nblocks_tot;
+    }
   }
   // vmix_const: constant coefficients for all time (vmix_const.F90:121-122)
   if (cfg->vmix_choice == 1) {
@@ -741,7 +804,12 @@ int pop_baroclinic_driver(pop_ctx *c) {
 int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
   if (c->h.c.solver_choice == 2) return solver_chrongear(c);
-  return c->fused_ok ? solver_pcg_fused(c) : solver_pcg(c);
+  if (c->replicated) {
+    if (!c->allred || !c->redbuf || c->red_doubles < 2LL * c->g.n2 * c->h.nblocks_tot) { c->err = "replicated solve needs pop_set_comm with a reduce buffer of pop_reduce_buffer_doubles()"; return 1; }
+    return solver_pcg_replicated(c);
+  }
+  if (c->fused_ok) { SolveView v = local_view(c); const int e = solver_pcg_fused(c, v); c->S0 = v.S0; c->S1 = v.S1; return e; }
+  return solver_pcg(c);
 }
 int pop_solver_get_diagnostics(const pop_ctx *c, int *it, double *rms) {
   if (it) *it = c->numIterations;
@@ -860,9 +928,16 @@ int pop_state_host(pop_ctx *c, int kk, const double *T, const double *S, double 
 }
 
 int pop_set_comm(pop_ctx *c, void *sb, void *rb, void *red, long long buf_doubles, pop_exchange_fn x, pop_allreduce_fn ar, void *user) {
-  c->sendbuf = (double *)sb; c->recvbuf = (double *)rb; c->redbuf = (double *)red; c->comm_doubles = buf_doubles;
+  c->sendbuf = (double *)sb; c->recvbuf = (double *)rb; c->comm_doubles = buf_doubles;
+  if (red) { c->redbuf = (double *)red; if (c->red_doubles == 0) c->red_doubles = 4LL * c->h.nblocks_tot; }
   c->xchg = x; c->allred = ar; c->comm_user = user;
   return 0;
+}
+int pop_set_reduce_buffer(pop_ctx *c, void *dev_redbuf, long long doubles) { c->redbuf = (double *)dev_redbuf; c->red_doubles = doubles; return 0; }
+long long pop_reduce_buffer_doubles(const pop_ctx *c) {
+  long long n = 4LL * c->h.nblocks_tot;
+  if (c->replicated) n = std::max(n, 2LL * (long long)c->h.n2 * c->h.nblocks_tot);
+  return n;
 }
 int pop_set_stream(pop_ctx *c, void *hip_stream) {   // run on the host framework's stream (e.g. torch's current stream)
   if (need_device(c)) return 1;

@@ -73,5 +73,6 @@ void build_halo_plan(HostModel &h);      // halo_plan.cpp
 void host_halo_r8(const HostModel &h, double *a, int nz, double fill);   // single-rank host halo
 void host_halo_i4(const HostModel &h, int *a, int nz, int fill);
 double host_global_sum(const HostModel &h, const double *a, const double *mask);
+std::vector<int> global_srcmap(const HostModel &h);   // all blocks: ghost -> source cell, -1 = fill
 
 }  // namespace pop

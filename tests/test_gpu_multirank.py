@@ -1,0 +1,29 @@
+"""Several ranks sharing the one GPU of the test box (CPU-staged gloo transport): the multi-rank
+paths of libpop_amd (peer halo messages, block-sum all-reduce, replicated barotropic solve) must
+reproduce the single-rank run bit for bit.  See tests/mr_gpu_check.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("nranks,kw", [
+    (2, "block_size_x=48,block_size_y=20"),                       # replicated barotropic solve
+    (2, ""),                                                      # 16 blocks: distributed solve
+    (3, "block_size_x=24,block_size_y=20,vmix_choice=3,km=24"),   # uneven block ownership, KPP
+])
+def test_multirank_equals_single_rank(nranks, kw):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+           os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3", "--kw", kw]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert "MR_GPU_CHECK OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
