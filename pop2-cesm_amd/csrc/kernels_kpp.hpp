@@ -50,43 +50,40 @@ __device__ __forceinline__ void kpp_wscale(double sigma, double hbl, double usta
 
 __device__ __forceinline__ double tmask(double t) { return (t < -2.0) ? -2.0 : t; }
 
-// ---- buoydiff ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(POP_COL_THREADS)
+// ---- buoydiff: 3-D parallel, one thread per (i,j,k); level k yields DBSFC(k) and DBLOC(k-1) ------
+__global__ void __launch_bounds__(256)
 k_kpp_buoydiff(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
                double *__restrict__ DBLOC, double *__restrict__ DBSFC) {
-  Col c;
-  if (!col_setup(g, c, false)) return;
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
   const int km = g.km;
   const long long n2 = g.n2;
-  const int kmt = g.KMT[c.q2];
-  DBSFC[c.base3] = 0.0;
-  double t_km1 = tmask(T[c.base3]), s_km1 = S[c.base3];
-  for (int k = 2; k <= km; ++k) {
-    const long long o = c.base3 + (long long)(k - 1) * n2;
-    const MwjfP P = mwjf_level(g.pressz[k]);
-    const double t_k = tmask(T[o]), s_k = S[o];
-    const double rhokm = mwjf_rho<false>(P, t_km1, s_km1, nullptr, nullptr);
-    const double rhok = mwjf_rho<false>(P, t_k, s_k, nullptr, nullptr);
-    const double surfthick = KPP_EPSSFC * g.zt[k];
-    const int kref = kp.kref[k];
-    const long long orf = c.base3 + (long long)(kref - 1) * n2;
-    double rhoavg = mwjf_rho<false>(P, tmask(T[orf]), S[orf], nullptr, nullptr);
-    if (kref != 1) {
-      rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
-      for (int kt = 1; kt <= kref - 1; ++kt) {
-        const long long ot = c.base3 + (long long)(kt - 1) * n2;
-        rhoavg = rhoavg + g.dz[kt] * mwjf_rho<false>(P, tmask(T[ot]), S[ot], nullptr, nullptr);
-      }
-      rhoavg = rhoavg / surfthick;
+  const long long base3 = (long long)b * g.n3 + p2;
+  const long long o = base3 + (long long)(k - 1) * n2;
+  if (k == 1) { DBSFC[o] = 0.0; return; }
+  const int kmt = g.KMT[(long long)b * n2 + p2];
+  const MwjfP P = mwjf_level(g.pressz[k]);
+  const double rhokm = mwjf_rho<false>(P, tmask(T[o - n2]), S[o - n2], nullptr, nullptr);
+  const double rhok = mwjf_rho<false>(P, tmask(T[o]), S[o], nullptr, nullptr);
+  const double surfthick = KPP_EPSSFC * g.zt[k];
+  const int kref = kp.kref[k];
+  const long long orf = base3 + (long long)(kref - 1) * n2;
+  double rhoavg = mwjf_rho<false>(P, tmask(T[orf]), S[orf], nullptr, nullptr);
+  if (kref != 1) {
+    rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
+    for (int kt = 1; kt <= kref - 1; ++kt) {
+      const long long ot = base3 + (long long)(kt - 1) * n2;
+      rhoavg = rhoavg + g.dz[kt] * mwjf_rho<false>(P, tmask(T[ot]), S[ot], nullptr, nullptr);
     }
-    double dbs = 0.0, dbl = 0.0;
-    if (rhok != 0.0) { dbs = GRAV * (1.0 - rhoavg / rhok); dbl = GRAV * (1.0 - rhokm / rhok); }
-    if (k - 1 >= kmt) dbl = 0.0;
-    DBSFC[o] = dbs;
-    DBLOC[o - n2] = dbl;
-    t_km1 = t_k; s_km1 = s_k;
+    rhoavg = rhoavg / surfthick;
   }
-  DBLOC[c.base3 + (long long)(km - 1) * n2] = 0.0;
+  double dbs = 0.0, dbl = 0.0;
+  if (rhok != 0.0) { dbs = GRAV * (1.0 - rhoavg / rhok); dbl = GRAV * (1.0 - rhokm / rhok); }
+  if (k - 1 >= kmt) dbl = 0.0;
+  DBSFC[o] = dbs;
+  DBLOC[o - n2] = dbl;
+  if (k == km) DBLOC[o] = 0.0;
 }
 
 // ---- ri_iwmix + ddmix: interior coefficients -----------------------------------------------
@@ -180,32 +177,32 @@ k_kpp_interior(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
   }
 }
 
-// ---- bldepth, part 1: shear^2 between the surface-layer reference velocity and level kl, at U points
-__global__ void __launch_bounds__(POP_COL_THREADS)
+// ---- bldepth, part 1: shear^2 between the surface-layer reference velocity and level kl at U
+// points; 3-D parallel, one thread per (i,j,kl)
+__global__ void __launch_bounds__(256)
 k_kpp_ushear(DevGrid g, KppDev kp, const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ WU) {
-  Col c;
-  if (!col_setup(g, c, false)) return;
-  const int km = g.km;
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int kl = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2 || kl < 2) return;
   const long long n2 = g.n2;
-  for (int kl = 2; kl <= km; ++kl) {
-    const long long o = c.base3 + (long long)(kl - 1) * n2;
-    const double surfthick = KPP_EPSSFC * g.zt[kl];
-    const int kref = kp.kref[kl];
-    double uref, vref;
-    if (kref > 1) {
-      const long long orf = c.base3 + (long long)(kref - 1) * n2;
-      uref = U[orf] * (surfthick - g.zw[kref - 1]);
-      vref = V[orf] * (surfthick - g.zw[kref - 1]);
-      for (int kt = 1; kt <= kref - 1; ++kt) {
-        const long long ot = c.base3 + (long long)(kt - 1) * n2;
-        uref = uref + g.dz[kt] * U[ot];
-        vref = vref + g.dz[kt] * V[ot];
-      }
-      uref = uref / surfthick; vref = vref / surfthick;
-    } else { uref = U[c.base3]; vref = V[c.base3]; }
-    const double du = uref - U[o], dv = vref - V[o];
-    WU[o] = du * du + dv * dv;
-  }
+  const long long base3 = (long long)b * g.n3 + p2;
+  const long long o = base3 + (long long)(kl - 1) * n2;
+  const double surfthick = KPP_EPSSFC * g.zt[kl];
+  const int kref = kp.kref[kl];
+  double uref, vref;
+  if (kref > 1) {
+    const long long orf = base3 + (long long)(kref - 1) * n2;
+    uref = U[orf] * (surfthick - g.zw[kref - 1]);
+    vref = V[orf] * (surfthick - g.zw[kref - 1]);
+    for (int kt = 1; kt <= kref - 1; ++kt) {
+      const long long ot = base3 + (long long)(kt - 1) * n2;
+      uref = uref + g.dz[kt] * U[ot];
+      vref = vref + g.dz[kt] * V[ot];
+    }
+    uref = uref / surfthick; vref = vref / surfthick;
+  } else { uref = U[base3]; vref = V[base3]; }
+  const double du = uref - U[o], dv = vref - V[o];
+  WU[o] = du * du + dv * dv;
 }
 
 // ---- bldepth, part 2: bulk Richardson number march -> unsmoothed HBLT, KBL ---------------------
@@ -449,9 +446,9 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   const dim3 GC((g.n2 + POP_COL_THREADS - 1) / POP_COL_THREADS, g.nblocks), BC(POP_COL_THREADS);
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);
   double *DBLOC = s.S3a, *DBSFC = s.S3b, *WU = s.S3c, *VISC = s.S3d, *RIW = s.E3;
-  hipLaunchKernelGGL(k_kpp_buoydiff, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
-  hipLaunchKernelGGL(k_kpp_ushear, GC, BC, 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
+  hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
   hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                      (const double *)DBSFC, (const double *)WU);
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],

@@ -1,0 +1,171 @@
+// kernels_thomas_reg.hpp -- implicit vertical mixing with the whole water column in registers.
+//
+// The generic Thomas kernels (kernels_baroclinic.hpp) stage the elimination coefficients E and the
+// partial solution F through scratch fields in HBM and re-read the column three to four times.
+// For the production level counts (km = 60: gx3v7 / gx1v7, km = 62: tx0.1v3) these kernels are
+// compiled with KM as a template constant: every level loop is fully unrolled, E/F/U/V live in
+// VGPRs (<= 512 per lane on gfx950 at one wave per SIMD), all column loads are issued up front
+// (deep memory-level parallelism instead of occupancy), and each field is read once and written
+// once -- the algorithmic traffic of SURVEY.md 8(d) phases C, F and G.
+// Arithmetic and evaluation order are identical to the generic kernels (vertical_mix.F90:1263-1368,
+// 1563-1658, 1762-1868; baroclinic.F90:1077-1129, 1418-1475).
+#pragma once
+#include "kernels_baroclinic.hpp"
+
+namespace pop {
+
+template <int KM, int MODE, bool PRE, bool POST>
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
+  Col c;
+  if (!col_setup(g, c, true)) return;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  const double hfac1 = g.dz[1] / a.c2dtt;
+  const double H1 = hfac1 + a.PSFC[c.q2] / (sp.grav * a.c2dtt);
+  const long long vdcbase = ((long long)c.b * (KM + 2)) * n2 + c.p2;
+  double Ea[KM], Fa[KM];   // VDC -> E and TNEW -> F, in registers
+  {
+    const int n = a.nfirst - 1 + blockIdx.z;            // one tracer per thread (launch z = tracer count)
+    double *__restrict__ const TN = a.TNEW[n];
+    const double *__restrict__ const VDC = a.VDC[n];
+    const double *__restrict__ const TO = a.TOLD[n];
+    // all column loads up front
+#pragma unroll
+    for (int k = 1; k <= KM; ++k) {
+      Ea[k - 1] = VDC[vdcbase + (long long)k * n2];
+      Fa[k - 1] = TN[c.base3 + (long long)(k - 1) * n2];
+    }
+    double rhs1 = 0.0;
+    if (MODE == 1) {
+      if (kmt > 0)
+        rhs1 = ((2.0 * a.TCUR[n][c.base3] - TO[c.base3]) * (a.PCUR[c.q2] - a.POLD[c.q2]) -
+                Fa[0] * (a.PNEW[c.q2] - a.PCUR[c.q2])) / (sp.grav * g.dz[1]);
+    }
+    double t1 = Fa[0];
+    if (PRE) {
+      if (kmt > 0) t1 = t1 - TO[c.base3] * (a.PNEW[c.q2] - a.PMIX[c.q2]) / (sp.grav * g.dz[1]);
+    }
+    double A = g.afac_t[1] * Ea[0];
+    double D = H1 + A;
+    double Ek = A / D;
+    double B = H1 * Ek;
+    double Fk = (MODE == 1) ? hfac1 * rhs1 / D : hfac1 * t1 / D;
+    double tn1 = Fa[0];     // TNEW(1) before the update (MODE 1 adds the increment to it)
+    Ea[0] = Ek; Fa[0] = Fk;
+    (void)tn1;
+#pragma unroll
+    for (int k = 2; k <= KM; ++k) {
+      const double C = A;
+      const double hf = g.dz[k] / a.c2dtt;
+      A = g.afac_t[k] * Ea[k - 1];
+      const double tn = Fa[k - 1];
+      if (k > kmt) { Fk = 0.0; }
+      else {
+        D = (k == kmt) ? hf + B : hf + A + B;
+        Ek = A / D;
+        B = (hf + B) * Ek;
+        Fk = (MODE == 1) ? C * Fk / D : (hf * tn + C * Fk) / D;
+        Ea[k - 1] = Ek;
+      }
+      Fa[k - 1] = Fk;
+    }
+    double Fkp1 = 0.0;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = KM; k >= 1; --k) {
+      double f = Fa[k - 1];
+      if (k < KM && k < kmt) f = f + Ea[k - 1] * Fkp1;
+      Fkp1 = f;
+      // base value: TOLD (MODE 0) or the incoming TNEW (MODE 1), read here; a compiler barrier every
+      // 8 levels bounds how many of these loads are in flight (register budget)
+      if ((k & 7) == 0) asm volatile("" ::: "memory");
+      const long long ob = c.base3 + (long long)(k - 1) * n2;
+      double tn = ((MODE == 1) ? TN[ob] : TO[ob]) + f;
+      if (POST && n == 0 && k == 1 && sp.reset_to_freezing) tn = fmax(tn, -2.0);
+      TN[c.base3 + (long long)(k - 1) * n2] = tn;
+    }
+  }
+}
+
+// one velocity component per thread (blockIdx.z = 0: U, 1: V): the two solves share only the
+// elimination coefficients, which each thread recomputes, so the column fits two register arrays
+// and the launch has twice the waves
+template <int KM>
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_impvmixu_reg(DevGrid g, StepParams sp, ImpvmixuArgs a) {
+  Col c;
+  if (!col_setup(g, c, true)) return;
+  const long long n2 = g.n2;
+  const int kmu = g.KMU[c.q2];
+  const double hur = g.HUR[c.q2];
+  const bool isv = (blockIdx.z == 1);
+  double *__restrict__ const XN = isv ? a.VNEW : a.UNEW;
+  const double *__restrict__ const XO = isv ? a.VOLD : a.UOLD;
+  const double *__restrict__ const VVC = a.VVC;
+  double Xa[KM], Ea[KM];
+#pragma unroll
+  for (int k = 1; k <= KM; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    Xa[k - 1] = XN[o]; Ea[k - 1] = VVC[o];
+  }
+  const double hf1 = g.dz[1] / sp.c2dtu;
+  double A = g.afac_u[1] * Ea[0];
+  double D = hf1 + A;
+  double Ek = A / D;
+  double B = hf1 * Ek;
+  double F1 = hf1 * Xa[0] / D;
+  Ea[0] = Ek; Xa[0] = F1;
+#pragma unroll
+  for (int k = 2; k <= KM; ++k) {
+    const double C = A;
+    const double hf = g.dz[k] / sp.c2dtu;
+    A = g.afac_u[k] * Ea[k - 1];
+    if (k <= kmu) {
+      D = (k < kmu) ? hf + A + B : hf + B;
+      Ek = A / D;
+      B = (hf + B) * Ek;
+      F1 = (hf * Xa[k - 1] + C * F1) / D;
+      Ea[k - 1] = Ek;
+    } else { F1 = 0.0; }
+    Xa[k - 1] = F1;
+  }
+  double F1p = 0.0;
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int k = KM; k >= 1; --k) {
+    double f1 = Xa[k - 1];
+    if (k < KM && k < kmu) f1 = f1 + Ea[k - 1] * F1p;
+    F1p = f1;
+    if ((k & 7) == 0) asm volatile("" ::: "memory");     // bound the old-velocity loads in flight
+    Xa[k - 1] = XO[c.base3 + (long long)(k - 1) * n2] + f1;
+  }
+  double w1 = 0.0;
+#pragma unroll
+  for (int k = 1; k <= KM; ++k) w1 = w1 + Xa[k - 1] * g.dz[k];
+  w1 = w1 * hur;
+#pragma unroll
+  for (int k = 1; k <= KM; ++k) XN[c.base3 + (long long)(k - 1) * n2] = (k <= kmu) ? Xa[k - 1] - w1 : 0.0;
+}
+
+// dispatch on the level count: register kernels for the production grids, generic otherwise
+template <int MODE, bool PRE, bool POST>
+inline void launch_impvmixt(const DevGrid &g, const StepParams &sp, const ImpvmixtArgs &a, dim3 G, hipStream_t st, bool allow_reg) {
+  const dim3 B(POP_COL_THREADS);
+  const dim3 G2(G.x, G.y, a.nlast - a.nfirst + 1);
+  if (allow_reg && (g.km == 60 || g.km == 62)) {
+    if (g.km == 60) hipLaunchKernelGGL((k_impvmixt_reg<60, MODE, PRE, POST>), G2, B, 0, st, g, sp, a);
+    else hipLaunchKernelGGL((k_impvmixt_reg<62, MODE, PRE, POST>), G2, B, 0, st, g, sp, a);
+    // the density of the finished tracers (baroclinic.F90:1468-1475) as its own 3-D-parallel pass
+    if (POST) hipLaunchKernelGGL(k_state3d, dim3((g.n2 + 255) / 256, g.km, g.nblocks), dim3(256), 0, st, g, (const double *)a.TNEW[0], (const double *)a.TNEW[1], a.RHO);
+  } else hipLaunchKernelGGL((k_impvmixt<MODE, PRE, POST>), G, B, 0, st, g, sp, a);
+}
+inline void launch_impvmixu(const DevGrid &g, const StepParams &sp, const ImpvmixuArgs &a, dim3 G, hipStream_t st, bool allow_reg) {
+  const dim3 B(POP_COL_THREADS);
+  const dim3 G2(G.x, G.y, 2);
+  if (allow_reg && g.km == 60) hipLaunchKernelGGL(k_impvmixu_reg<60>, G2, B, 0, st, g, sp, a);
+  else if (allow_reg && g.km == 62) hipLaunchKernelGGL(k_impvmixu_reg<62>, G2, B, 0, st, g, sp, a);
+  else hipLaunchKernelGGL(k_impvmixu_norm, G, B, 0, st, g, sp, a);
+}
+
+}  // namespace pop

@@ -8,6 +8,7 @@
 #include "kernels_baroclinic.hpp"
 #include "kernels_barotropic.hpp"
 #include "kernels_mix.hpp"
+#include "kernels_thomas_reg.hpp"
 
 using namespace pop;
 
@@ -52,6 +53,7 @@ struct pop_ctx {
   SolverScalars *host_sc = nullptr;                       // pinned
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
   bool no_graph = false, fused_ok = false, replicated = false;
+  bool reg_thomas = true;                                  // column-in-registers Thomas kernels (km = 60, 62)
   SolveView gv{};                                         // replicated barotropic mode: all blocks
   double *gTAREA = nullptr; int *gKMT = nullptr;
   int nchunk = 0, numIterations = 0;
@@ -531,6 +533,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     HIPCHK(c, hipHostMalloc((void **)&c->host_sc, sizeof(SolverScalars)));
     c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED");
     c->no_graph = getenv("POP_SOLVER_NOGRAPH") != nullptr;
+    c->reg_thomas = getenv("POP_GENERIC_THOMAS") == nullptr;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !getenv("POP_SOLVER_DISTRIBUTED");
     if (c->replicated) {
@@ -750,7 +753,7 @@ static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {
   return a;
 }
 static int phase_impvmixt_pred(pop_ctx *c) {
-  hipLaunchKernelGGL((k_impvmixt<0, false, false>), grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), impvmixt_args(c, c->PS[c->curt]));
+  launch_impvmixt<0, false, false>(c->g, step_params(c), impvmixt_args(c, c->PS[c->curt]), grid_cols(c), c->stream, c->reg_thomas);
   return 0;
 }
 static int phase_state_new(pop_ctx *c) {
@@ -772,13 +775,13 @@ static int phase_momentum_rhs(pop_ctx *c) {
 }
 static int phase_impvmixu(pop_ctx *c) {
   ImpvmixuArgs a{c->U[c->newt], c->V[c->newt], c->E3, c->U[c->oldt], c->V[c->oldt], c->VVC};
-  hipLaunchKernelGGL(k_impvmixu_norm, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), a);
+  launch_impvmixu(c->g, step_params(c), a, grid_cols(c), c->stream, c->reg_thomas);
   return 0;
 }
 static int phase_correct(pop_ctx *c) {
   const StepParams sp = step_params(c);
-  if (sp.pavg) hipLaunchKernelGGL((k_impvmixt<1, false, true>), grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, impvmixt_args(c, c->PS[c->newt]));
-  else hipLaunchKernelGGL((k_impvmixt<0, true, true>), grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, impvmixt_args(c, c->PS[c->newt]));
+  if (sp.pavg) launch_impvmixt<1, false, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas);
+  else launch_impvmixt<0, true, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas);
   return 0;
 }
 static int phase_add_btrop(pop_ctx *c) {
