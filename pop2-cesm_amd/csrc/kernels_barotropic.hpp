@@ -420,11 +420,17 @@ __device__ __forceinline__ double fused_total(const double *__restrict__ partial
   return total;
 }
 
-// step A: [x += alpha s; r -= alpha q]; z = r/diag; partial (r,z)
+// step A: [x += alpha s; r -= alpha q]; z = r/diag; partial (r,z).  The cell's operands are loaded
+// before the ordered total of the previous partials is formed, so memory latency overlaps it.
 template <bool UPDATE>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_a(DevGrid g, FusedArgs a) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const bool live = p2 < g.n2;
+  const long long q = (long long)b * g.n2 + (live ? p2 : 0);
+  double r = a.R[q], x = 0.0, s0 = 0.0, qq = 0.0;
+  if (UPDATE) { x = a.X[q]; s0 = a.S0[q]; qq = a.Q[q]; }
+  const double cw = a.C[q], mk = g.mMask[q];
   double alpha = 0.0;
   if (UPDATE) {
     const double sq = fused_total(a.partB, a.nchunk, a.nblocks);
@@ -433,46 +439,66 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta0 = rz; a.sc->alpha = alpha; }
   }
   double v[1] = {0.0};
-  if (p2 < g.n2) {
+  if (live) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
-    const long long q = (long long)b * g.n2 + p2;
-    double r = a.R[q];
     if (UPDATE) {
-      a.X[q] = a.X[q] + alpha * a.S0[q];
-      r = r - alpha * a.Q[q];
+      a.X[q] = x + alpha * s0;
+      r = r - alpha * qq;
       a.R[q] = r;
     }
-    const double cw = a.C[q];
     const double z = (cw != 0.0) ? r / cw : 0.0;
     a.Z[q] = z;
-    if (interior(g, i, j)) v[0] = (r * z) * g.mMask[q];
+    if (interior(g, i, j)) v[0] = (r * z) * mk;
   }
   wg_reduce_store<1>(v, a.partA, b * gridDim.x + blockIdx.x);
 }
 
-// step B: s_new = z + s_old*(eta1/eta0) at the 9 stencil points (ghost neighbours through srcmap);
-// q = A s_new; partial (q,s)
+// step B: s_new = z + s_old*(eta1/eta0) at the 9 stencil points; q = A s_new; partial (q,s).
+// Only cells on the rim of the physical domain can have ghost neighbours: they read them through
+// srcmap (bit-identical to reading the ghost after a halo update); all other cells index directly.
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_b(DevGrid g, FusedArgs a) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const bool live = p2 < g.n2;
+  const int pp = live ? p2 : 0;
+  const int i = pp % g.nxb, j = pp / g.nxb, nxb = g.nxb;
+  const long long q = (long long)b * g.n2 + pp;
+  const bool inner = live && interior(g, i, j);
+  const bool rim = inner && (i + 1 == g.ib || i + 1 == g.ie || j + 1 == g.jb || j + 1 == g.je);
+  // gather operands first (independent loads in flight while the total is formed)
+  const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+  double zv[9], sv[9], wv[9];
+  zv[0] = a.Z[q]; sv[0] = a.S0[q];
+#pragma unroll
+  for (int t = 1; t < 9; ++t) { zv[t] = 0.0; sv[t] = 0.0; }
+  if (inner) {
+    if (!rim) {
+#pragma unroll
+      for (int t = 1; t < 9; ++t) { zv[t] = a.Z[q + off[t]]; sv[t] = a.S0[q + off[t]]; }
+    } else {
+#pragma unroll
+      for (int t = 1; t < 9; ++t) {
+        const int m = a.srcmap[q + off[t]];
+        if (m >= 0) { zv[t] = a.Z[m]; sv[t] = a.S0[m]; }
+      }
+    }
+    wv[0] = a.C[q]; wv[1] = g.WNo[q]; wv[2] = g.WNo[q - nxb]; wv[3] = g.WEa[q]; wv[4] = g.WEa[q - 1];
+    wv[5] = g.WNE[q]; wv[6] = g.WNE[q - nxb]; wv[7] = g.WNE[q - 1]; wv[8] = g.WNE[q - 1 - nxb];
+  }
+  const double mk = g.mMask[q];
   const double rz = fused_total(a.partA, a.nchunk, a.nblocks);
   const double bt = rz / a.sc->eta0;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta1 = rz; a.sc->beta_cg = bt; }
   double v[1] = {0.0};
-  if (p2 < g.n2) {
-    const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
-    const long long q = (long long)b * g.n2 + p2;
-    auto sn = [&](long long qq) {
-      const int m = a.srcmap[qq];
-      return (m < 0) ? 0.0 : a.Z[m] + a.S0[m] * bt;
-    };
-    const double s = a.Z[q] + a.S0[q] * bt;
+  if (live) {
+    const double s = zv[0] + sv[0] * bt;
     a.S1[q] = s;
     double aq = 0.0;
-    if (interior(g, i, j)) {
-      aq = a.C[q] * s + g.WNo[q] * sn(q + nxb) + g.WNo[q - nxb] * sn(q - nxb) + g.WEa[q] * sn(q + 1) + g.WEa[q - 1] * sn(q - 1) +
-           g.WNE[q] * sn(q + nxb + 1) + g.WNE[q - nxb] * sn(q - nxb + 1) + g.WNE[q - 1] * sn(q + nxb - 1) + g.WNE[q - 1 - nxb] * sn(q - nxb - 1);
-      v[0] = (aq * s) * g.mMask[q];
+    if (inner) {
+      aq = wv[0] * s;
+#pragma unroll
+      for (int t = 1; t < 9; ++t) aq = aq + wv[t] * (zv[t] + sv[t] * bt);
+      v[0] = (aq * s) * mk;
     }
     a.Q[q] = aq;
   }
