@@ -397,14 +397,23 @@ struct FusedArgs {
   SolverScalars *sc;
   const int *srcmap;          // per cell: own index (interior), source cell (ghost), -1 (fill)
   int nchunk, nblocks;
+  // large grids: the per-block ordered sums of the partials are formed by k_block_sums between the
+  // solver kernels (bsA/bsB) instead of being recomputed by every workgroup (O(#workgroups^2) reads)
+  const double *bsA, *bsB;
+  int presummed;
 };
 
 // ordered total of workgroup partials: per POP block a thread-strided sequential sum + fixed tree,
 // block sums added in block order.  Every thread returns the same value.
-__device__ __forceinline__ double fused_total(const double *__restrict__ partial, int nchunk, int nblocks) {
+__device__ __forceinline__ double fused_total(const double *__restrict__ partial, int nchunk, int nblocks,
+                                              const double *__restrict__ bs, int presummed) {
   __shared__ double shf[POP_RED_THREADS];
   const int t = threadIdx.x;
   double total = 0.0;
+  if (presummed) {                       // block sums already formed (same ordered rule): add in block order
+    for (int b = 0; b < nblocks; ++b) total = total + bs[b];
+    return total;
+  }
   for (int b = 0; b < nblocks; ++b) {
     double v = 0.0;
     for (int c = t; c < nchunk; c += POP_RED_THREADS) v = v + partial[(long long)b * nchunk + c];
@@ -433,7 +442,7 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
   const double cw = a.C[q], mk = g.mMask[q];
   double alpha = 0.0;
   if (UPDATE) {
-    const double sq = fused_total(a.partB, a.nchunk, a.nblocks);
+    const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, a.presummed);
     const double rz = a.sc->eta1;
     alpha = rz / sq;                                   // eta1 = eta0/(s,q), POP_SolversMod.F90:1419
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta0 = rz; a.sc->alpha = alpha; }
@@ -486,7 +495,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
     wv[5] = g.WNE[q]; wv[6] = g.WNE[q - nxb]; wv[7] = g.WNE[q - 1]; wv[8] = g.WNE[q - 1 - nxb];
   }
   const double mk = g.mMask[q];
-  const double rz = fused_total(a.partA, a.nchunk, a.nblocks);
+  const double rz = fused_total(a.partA, a.nchunk, a.nblocks, a.bsA, a.presummed);
   const double bt = rz / a.sc->eta0;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta1 = rz; a.sc->beta_cg = bt; }
   double v[1] = {0.0};
@@ -509,7 +518,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_xr(DevGrid g, FusedArgs a) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  const double sq = fused_total(a.partB, a.nchunk, a.nblocks);
+  const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, a.presummed);
   const double rz = a.sc->eta1;
   const double alpha = rz / sq;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta0 = rz; a.sc->alpha = alpha; }

@@ -49,10 +49,11 @@ struct pop_ctx {
   double *R = nullptr, *S0 = nullptr, *S1 = nullptr, *Q = nullptr, *Z = nullptr, *AZ = nullptr;
   double *partial = nullptr, *blocksum = nullptr;
   SolverScalars *sc = nullptr;
-  int *gid = nullptr, *srcmap = nullptr;
+  int *gid = nullptr, *srcmap = nullptr, *iota = nullptr;
   SolverScalars *host_sc = nullptr;                       // pinned
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
   bool no_graph = false, fused_ok = false, replicated = false;
+  bool force_presum = false;
   bool reg_thomas = true;                                  // column-in-registers Thomas kernels (km = 60, 62)
   SolveView gv{};                                         // replicated barotropic mode: all blocks
   double *gTAREA = nullptr; int *gKMT = nullptr;
@@ -247,7 +248,13 @@ FusedArgs fused_args(pop_ctx *c, const SolveView &v) {
   a.X = v.X; a.R = v.R; a.Z = v.Z; a.S0 = v.S0; a.S1 = v.S1; a.Q = v.Q;
   a.Bv = v.RHS; a.C = v.C; a.partA = v.partial; a.partB = v.partial + (size_t)v.nchunk * v.g.nblocks;
   a.sc = c->sc; a.srcmap = v.srcmap; a.nchunk = v.nchunk; a.nblocks = v.g.nblocks;
+  a.bsA = v.blocksum + 2 * v.nblocks_tot; a.bsB = v.blocksum + 3 * v.nblocks_tot;
+  a.presummed = ((long long)v.nchunk * v.g.nblocks > 2048 || c->force_presum) ? 1 : 0;
   return a;
+}
+// large grids: ordered block sums of a partial array between solver kernels (view-local block order)
+void presum(pop_ctx *c, const SolveView &v, const double *partial, double *bs) {
+  hipLaunchKernelGGL(k_block_sums<1>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->iota, bs);
 }
 dim3 view_grid(const SolveView &v) { return dim3((v.g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS, v.g.nblocks); }
 // one check interval: freq iterations, pending update, residual + (r,r) -> host
@@ -258,7 +265,9 @@ int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
     FusedArgs a = fused_args(c, v);
     if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
     else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
+    if (a.presummed) presum(c, v, a.partA, (double *)a.bsA);
     hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, v.g, a);
+    if (a.presummed) presum(c, v, a.partB, (double *)a.bsB);
     std::swap(v.S0, v.S1);
     pending = true;
   }
@@ -310,7 +319,9 @@ int solver_pcg_fused(pop_ctx *c, SolveView &v) {
       FusedArgs a = fused_args(c, v);
       if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
       else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
+      if (a.presummed) presum(c, v, a.partA, (double *)a.bsA);
       hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, v.g, a);
+      if (a.presummed) presum(c, v, a.partB, (double *)a.bsB);
       std::swap(v.S0, v.S1);
       pending = true;
     }
@@ -511,7 +522,8 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   double **three[] = {&c->VVC, &c->E3, &c->F3, &c->S3a, &c->S3b, &c->S3c, &c->S3d};
   for (auto p : three) if (dev_alloc(c, p, a3)) return 1;
   c->nchunk = (g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS;
-  if (dev_alloc(c, &c->partial, (size_t)c->nchunk * h.nblocks * 2) || dev_alloc(c, &c->blocksum, (size_t)h.nblocks_tot * 2)) return 1;
+  if (dev_alloc(c, &c->partial, (size_t)c->nchunk * h.nblocks * 2) || dev_alloc(c, &c->blocksum, (size_t)h.nblocks_tot * 4)) return 1;
+  { std::vector<int> io(h.nblocks_tot); for (int b = 0; b < h.nblocks_tot; ++b) io[b] = b; if (dev_upload(c, &c->iota, io.data(), io.size())) return 1; }
   if (dev_alloc(c, &c->sc, 1)) return 1;
   { std::vector<int> gid(h.nblocks); for (int lb = 0; lb < h.nblocks; ++lb) gid[lb] = h.local_ids[lb] - 1; if (dev_upload(c, &c->gid, gid.data(), gid.size())) return 1; }
   // halo plan lists
@@ -534,6 +546,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED");
     c->no_graph = getenv("POP_SOLVER_NOGRAPH") != nullptr;
     c->reg_thomas = getenv("POP_GENERIC_THOMAS") == nullptr;
+    c->force_presum = getenv("POP_SOLVER_PRESUM") != nullptr;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !getenv("POP_SOLVER_DISTRIBUTED");
     if (c->replicated) {
@@ -550,7 +563,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
       if (dev_upload(c, &c->gKMT, h.i2["KMT"].data(), NG)) return 1;
       double **vecs[] = {&v.X, &v.R, &v.Z, &v.S0, &v.S1, &v.Q, &v.RHS, &v.C};
       for (auto q : vecs) if (dev_alloc(c, q, NG)) return 1;
-      if (dev_alloc(c, &v.partial, (size_t)c->nchunk * h.nblocks_tot * 2) || dev_alloc(c, &v.blocksum, (size_t)h.nblocks_tot * 2)) return 1;
+      if (dev_alloc(c, &v.partial, (size_t)c->nchunk * h.nblocks_tot * 2) || dev_alloc(c, &v.blocksum, (size_t)h.nblocks_tot * 4)) return 1;
       std::vector<int> gsm = global_srcmap(h), gid(h.nblocks_tot);
       for (int b = 0; b < h.nblocks_tot; ++b) gid[b] = b;
       if (dev_upload(c, &v.srcmap, gsm.data(), gsm.size()) || dev_upload(c, &v.gid, gid.data(), gid.size())) return 1;
