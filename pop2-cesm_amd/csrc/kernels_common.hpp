@@ -13,8 +13,15 @@ struct Col {
   long long q2;           // b*n2 + p2
   long long base3;        // b*n3 + p2   (+ (k-1)*n2 for level k)
 };
+// XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (blocks b and b+8
+// share one L2, MI355X_MICROARCH.md), so consecutive blockIdx.x are mapped to tiles that are nT/8
+// apart: every XCD then owns one contiguous band of the (i,j) plane and the j+-1 rows re-read by
+// neighbouring workgroups hit that XCD's own L2 instead of being fetched once per XCD.
+// gridDim.x must be a multiple of 8 (col_grid_x); surplus tiles idle.
+__host__ __device__ inline int col_grid_x(int n2, int threads) { const int nt = (n2 + threads - 1) / threads; return 8 * ((nt + 7) / 8); }
 __device__ __forceinline__ bool col_setup(const DevGrid &g, Col &c, bool interior_only) {
-  c.p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  c.p2 = tile * blockDim.x + threadIdx.x;
   c.b = blockIdx.y;
   if (c.p2 >= g.n2) return false;
   c.i = c.p2 % g.nxb;

@@ -103,7 +103,7 @@ std::vector<T> local_part(const HostModel &h, const std::vector<T> &all) {
   return out;
 }
 
-dim3 grid_cols(const pop_ctx *c) { return dim3((c->g.n2 + POP_COL_THREADS - 1) / POP_COL_THREADS, c->g.nblocks); }
+dim3 grid_cols(const pop_ctx *c) { return dim3(col_grid_x(c->g.n2, POP_COL_THREADS), c->g.nblocks); }
 dim3 grid_2d(const pop_ctx *c) { return dim3((c->g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS, c->g.nblocks); }
 dim3 grid_3d(const pop_ctx *c) { return dim3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks); }
 
@@ -718,7 +718,7 @@ int pop_time_manager(pop_ctx *c) {
 int pop_dhdt(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "DHDT");
-  hipLaunchKernelGGL(k_dhdt, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, step_params(c),
+  hipLaunchKernelGGL(k_dhdt, dim3(col_grid_x(c->g.n2, 256), c->g.nblocks), dim3(256), 0, c->stream, c->g, step_params(c),
                      c->PS[c->curt], c->PS[c->oldt], c->FW_OLD, c->DH, c->DHU);
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -845,7 +845,7 @@ int pop_barotropic_driver(pop_ctx *c) {
   a.GXN = c->GX[c->newt]; a.GYN = c->GY[c->newt]; a.UBN = c->UB[c->newt]; a.VBN = c->VB[c->newt];
   a.GXR = c->leapfrogts ? c->GX[c->oldt] : c->GX[c->curt]; a.GYR = c->leapfrogts ? c->GY[c->oldt] : c->GY[c->curt];
   a.scal = &c->sc->xcheck; a.rcheck = c->h.rcheck; a.rconst = c->h.rconst;
-  const dim3 G((c->g.n2 + 255) / 256, c->g.nblocks), B(256);
+  const dim3 G(col_grid_x(c->g.n2, 256), c->g.nblocks), B(256);
   hipLaunchKernelGGL(k_btrop_rhs1, G, B, 0, c->stream, c->g, sp, a);
   hipLaunchKernelGGL(k_btrop_rhs2, G, B, 0, c->stream, c->g, sp, a);
   if (halo_update(c, c->RHS, 1)) return 1;
@@ -886,7 +886,7 @@ int pop_step_tail(pop_ctx *c) {
     a.UBN = c->UB[nw]; a.VBN = c->VB[nw]; a.GXN = c->GX[nw]; a.GYN = c->GY[nw]; a.PN = c->PS[nw]; a.FW = c->FW;
     for (int n = 0; n < 2; ++n) { a.T1O[n] = c->TR[n][o]; a.T1C[n] = c->TR[n][cu]; a.T1N[n] = c->TR[n][nw]; }
     a.dz1 = c->h.dz[1]; a.grav = GRAV;
-    hipLaunchKernelGGL(k_avg2d, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, a);
+    hipLaunchKernelGGL(k_avg2d, dim3(col_grid_x(c->g.n2, 256), c->g.nblocks), dim3(256), 0, c->stream, c->g, a);
     Avg3dArgs b{};
     b.UO = c->U[o]; b.UC = c->U[cu]; b.VO = c->V[o]; b.VC = c->V[cu]; b.RO = c->RHO[o]; b.RC = c->RHO[cu]; b.UN = c->U[nw]; b.VN = c->V[nw];
     for (int n = 0; n < 2; ++n) { b.TO[n] = c->TR[n][o]; b.TC[n] = c->TR[n][cu]; b.TN[n] = c->TR[n][nw]; }
