@@ -83,7 +83,7 @@ struct TracerRhsArgs {
 };
 
 template <bool DEL4>
-__global__ void __launch_bounds__(POP_COL_THREADS)
+__global__ void __launch_bounds__(POP_STENCIL_MAX_THREADS)
 k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
   Col c;
   if (!col_setup(g, c, true)) return;
@@ -264,7 +264,7 @@ struct MomentumRhsArgs {
 };
 
 template <bool DEL4>
-__global__ void __launch_bounds__(POP_COL_THREADS)
+__global__ void __launch_bounds__(POP_STENCIL_MAX_THREADS)
 k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
   Col c;
   if (!col_setup(g, c, true)) return;

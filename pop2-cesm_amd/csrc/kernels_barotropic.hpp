@@ -120,7 +120,21 @@ __global__ void k_block_sums(const double *__restrict__ partial, int nchunk, con
   double v[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) v[f] = 0.0;
-  for (int cidx = t; cidx < nchunk; cidx += POP_RED_THREADS)
+  // same left-to-right order as a plain strided loop; the loads of 16 terms are issued before their
+  // adds so the chain costs one memory latency per 16 terms instead of one per term
+  int cidx = t;
+  for (; cidx + 15 * POP_RED_THREADS < nchunk; cidx += 16 * POP_RED_THREADS) {
+    double w[16][NF];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) w[u][f] = partial[((long long)b * nchunk + cidx + u * POP_RED_THREADS) * NF + f];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int f = 0; f < NF; ++f) v[f] = v[f] + w[u][f];
+  }
+  for (; cidx < nchunk; cidx += POP_RED_THREADS)
 #pragma unroll
     for (int f = 0; f < NF; ++f) v[f] = v[f] + partial[((long long)b * nchunk + cidx) * NF + f];
 #pragma unroll

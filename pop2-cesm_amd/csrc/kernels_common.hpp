@@ -5,6 +5,7 @@
 namespace pop {
 
 #define POP_COL_THREADS 64   // one wavefront per workgroup for column-march kernels
+#define POP_STENCIL_MAX_THREADS 512   // stencil column kernels: up to 64 x 8 rows per workgroup
 
 // Column-kernel prologue: one thread per (i,j) of local block b; returns false for threads
 // outside the physical domain ib..ie, jb..je (or outside the block).
@@ -19,13 +20,24 @@ struct Col {
 // neighbouring workgroups hit that XCD's own L2 instead of being fetched once per XCD.
 // gridDim.x must be a multiple of 8 (col_grid_x); surplus tiles idle.
 __host__ __device__ inline int col_grid_x(int n2, int threads) { const int nt = (n2 + threads - 1) / threads; return 8 * ((nt + 7) / 8); }
+__host__ inline int col_grid_x2d(int nxb, int nyb, int tx, int ty) { const int nt = ((nxb + tx - 1) / tx) * ((nyb + ty - 1) / ty); return 8 * ((nt + 7) / 8); }
 __device__ __forceinline__ bool col_setup(const DevGrid &g, Col &c, bool interior_only) {
-  const int tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  c.p2 = tile * blockDim.x + threadIdx.x;
+  const int tile = g.xcd_remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   c.b = blockIdx.y;
-  if (c.p2 >= g.n2) return false;
-  c.i = c.p2 % g.nxb;
-  c.j = c.p2 / g.nxb;
+  if (blockDim.y > 1) {
+    // 2-D workgroup (stencil kernels): blockDim.y consecutive rows of one 64-wide i strip, one wave per
+    // row, so the j+-1 rows a wave reads are the rows its sibling waves on the same CU are reading
+    const int tiles_i = (g.nxb + blockDim.x - 1) / blockDim.x;
+    c.i = (tile % tiles_i) * blockDim.x + threadIdx.x;
+    c.j = (tile / tiles_i) * blockDim.y + threadIdx.y;
+    if (c.i >= g.nxb || c.j >= g.nyb) return false;
+    c.p2 = c.j * g.nxb + c.i;
+  } else {
+    c.p2 = tile * blockDim.x + threadIdx.x;
+    if (c.p2 >= g.n2) return false;
+    c.i = c.p2 % g.nxb;
+    c.j = c.p2 / g.nxb;
+  }
   if (interior_only && (c.i + 1 < g.ib || c.i + 1 > g.ie || c.j + 1 < g.jb || c.j + 1 > g.je)) return false;
   c.q2 = (long long)c.b * g.n2 + c.p2;
   c.base3 = (long long)c.b * g.n3 + c.p2;

@@ -83,8 +83,12 @@ k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
       const long long ob = c.base3 + (long long)(k - 1) * n2;
       double tn = ((MODE == 1) ? TN[ob] : TO[ob]) + f;
       if (POST && n == 0 && k == 1 && sp.reset_to_freezing) tn = fmax(tn, -2.0);
-      TN[c.base3 + (long long)(k - 1) * n2] = tn;
+      Fa[k - 1] = tn;
     }
+    // one store burst after the last load: loads and stores retire through the same in-order counter,
+    // so a store between two loads would make the second load's wait cover the store's round trip
+#pragma unroll
+    for (int k = 1; k <= KM; ++k) TN[c.base3 + (long long)(k - 1) * n2] = Fa[k - 1];
   }
 }
 

@@ -54,6 +54,7 @@ struct pop_ctx {
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
   bool no_graph = false, fused_ok = false, replicated = false;
   bool force_presum = false;
+  bool reg_thomas_t = true;
   bool reg_thomas = true;                                  // column-in-registers Thomas kernels (km = 60, 62)
   SolveView gv{};                                         // replicated barotropic mode: all blocks
   double *gTAREA = nullptr; int *gKMT = nullptr;
@@ -104,6 +105,13 @@ std::vector<T> local_part(const HostModel &h, const std::vector<T> &all) {
 }
 
 dim3 grid_cols(const pop_ctx *c) { return dim3(col_grid_x(c->g.n2, POP_COL_THREADS), c->g.nblocks); }
+// stencil column kernels: workgroup = 64 x rows tile (kernels_common.hpp col_setup)
+int stencil_rows() { static int r = getenv("POP_STENCIL_ROWS") ? atoi(getenv("POP_STENCIL_ROWS")) : 1; return r < 1 ? 1 : r; }
+dim3 block_stencil() { return dim3(POP_COL_THREADS, stencil_rows()); }
+dim3 grid_stencil(const pop_ctx *c) {
+  if (stencil_rows() == 1) return grid_cols(c);
+  return dim3(col_grid_x2d(c->g.nxb, c->g.nyb, POP_COL_THREADS, stencil_rows()), c->g.nblocks);
+}
 dim3 grid_2d(const pop_ctx *c) { return dim3((c->g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS, c->g.nblocks); }
 dim3 grid_3d(const pop_ctx *c) { return dim3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks); }
 
@@ -479,6 +487,10 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   DevGrid &g = c->g;
   g.nxb = h.nxb; g.nyb = h.nyb; g.km = h.km; g.nt = h.nt; g.nblocks = h.nblocks;
   g.n2 = (int)h.n2; g.n3 = (long long)h.n3;
+  // XCD-banded tile order pays when one level of the block fits the L2s (measured: gx1v7 fabric re-fetch
+  // 3.2x -> 1.3x, -6% time; tx0.1v3 +20% time), POP_XCD_REMAP=0|1 overrides
+  g.xcd_remap = (h.n2 * h.nblocks <= (1u << 19)) ? 1 : 0;
+  if (getenv("POP_XCD_REMAP")) g.xcd_remap = atoi(getenv("POP_XCD_REMAP"));
   g.ib = NGHOST + 1; g.ie = h.nxb - NGHOST; g.jb = NGHOST + 1; g.je = h.nyb - NGHOST;
   // vertical arrays
   {
@@ -546,6 +558,11 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED");
     c->no_graph = getenv("POP_SOLVER_NOGRAPH") != nullptr;
     c->reg_thomas = getenv("POP_GENERIC_THOMAS") == nullptr;
+    // tracer solve: the register kernel (1 wave/SIMD, deep load batches) wins while the launch is
+    // latency-bound (gx1v7: 0.19 vs 0.30 ms); on bandwidth-bound grids the generic march is faster
+    // (tx0.1v3: 9.9 vs 11.6 ms).  The velocity solve is faster in registers at both sizes.
+    c->reg_thomas_t = c->reg_thomas && (h.n2 * h.nblocks <= (1u << 19));
+    if (getenv("POP_REG_THOMAS_T")) c->reg_thomas_t = atoi(getenv("POP_REG_THOMAS_T")) != 0;
     c->force_presum = getenv("POP_SOLVER_PRESUM") != nullptr;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !getenv("POP_SOLVER_DISTRIBUTED");
@@ -754,7 +771,7 @@ static int phase_tracer_rhs(pop_ctx *c) {
   if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->S3a; a.TMIX[1] = c->S3b; }   // del4: second Laplacian acts on D2T
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
   a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
-  hipLaunchKernelGGL(k_tracer_rhs<false>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, sp, a);
+  hipLaunchKernelGGL(k_tracer_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
   return 0;
 }
 static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {
@@ -766,7 +783,7 @@ static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {
   return a;
 }
 static int phase_impvmixt_pred(pop_ctx *c) {
-  launch_impvmixt<0, false, false>(c->g, step_params(c), impvmixt_args(c, c->PS[c->curt]), grid_cols(c), c->stream, c->reg_thomas);
+  launch_impvmixt<0, false, false>(c->g, step_params(c), impvmixt_args(c, c->PS[c->curt]), grid_cols(c), c->stream, c->reg_thomas_t);
   return 0;
 }
 static int phase_state_new(pop_ctx *c) {
@@ -783,7 +800,7 @@ static int phase_momentum_rhs(pop_ctx *c) {
   a.RHOOLD = c->RHO[c->oldt]; a.RHOCUR = c->RHO[c->curt]; a.RHONEW = c->RHO[c->newt]; a.VVC = c->VVC; a.DHU = c->DHU;
   if (c->h.c.hmix_momentum == 4) { a.UMIX = c->S3a; a.VMIX = c->S3b; }   // del4: second Laplacian acts on D2U, D2V
   a.UNEW = c->U[c->newt]; a.VNEW = c->V[c->newt]; a.ZX = c->ZX; a.ZY = c->ZY;
-  hipLaunchKernelGGL(k_momentum_rhs<false>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, step_params(c), a);
+  hipLaunchKernelGGL(k_momentum_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
   return 0;
 }
 static int phase_impvmixu(pop_ctx *c) {
@@ -793,8 +810,8 @@ static int phase_impvmixu(pop_ctx *c) {
 }
 static int phase_correct(pop_ctx *c) {
   const StepParams sp = step_params(c);
-  if (sp.pavg) launch_impvmixt<1, false, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas);
-  else launch_impvmixt<0, true, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas);
+  if (sp.pavg) launch_impvmixt<1, false, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t);
+  else launch_impvmixt<0, true, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t);
   return 0;
 }
 static int phase_add_btrop(pop_ctx *c) {
