@@ -197,7 +197,36 @@ def main():
     pkg = ge.load_package()
     cfg = workload_config(args.workload, world)
     model = pkg.PopModel(cfg, rank=rank, nranks=world)
-    comm = TorchComm(pkg, model, rank, world, staged=(backend != "nccl")) if world > 1 else None  # noqa: F841
+    comm, transport = None, "none"
+    if world > 1:
+        # default: the library's own RCCL transport (stream-ordered ncclSend/Recv/AllReduce, no host call per
+        # message); POP_BENCH_TRANSPORT=torch keeps the torch.distributed callbacks.  A failed self-test on
+        # any rank makes every rank fall back to the callbacks.
+        want_native = backend == "nccl" and os.environ.get("POP_BENCH_TRANSPORT", "rccl") == "rccl"
+        ok = 0
+        if want_native:
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = pkg.PopModel.rccl_unique_id()
+                except pkg.PopError as e:
+                    print("rccl transport unavailable:", e, file=sys.stderr)
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
+                try:
+                    model.comm_init_rccl(box[0])
+                    model.comm_selftest()
+                    ok = 1
+                except pkg.PopError as e:
+                    print("rank %d: rccl transport failed its self-test: %s" % (rank, e), file=sys.stderr)
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if ok:
+            transport = "rccl-native"
+        else:
+            comm = TorchComm(pkg, model, rank, world, staged=(backend != "nccl"))  # noqa: F841
+            transport = "torch.distributed/" + backend
 
     def barrier():
         model.sync()
@@ -256,7 +285,7 @@ def main():
                    "block_size": [cfg.block_size_x, cfg.block_size_y], "steps_per_day": cfg.steps_per_day,
                    "hmix": "del%d" % cfg.hmix_momentum, "vmix": ["const", "rich", "kpp"][vm],
                    "solver": ["pcg", "ChronGear"][cfg.solver_choice - 1], "pcg_iters_per_step": float(np.mean(iters)),
-                   "cells_local_with_ghosts": ncell_local},
+                   "cells_local_with_ghosts": ncell_local, "transport": transport},
         "roofline": roof,
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

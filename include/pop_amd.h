@@ -136,6 +136,15 @@ long long pop_comm_buffer_doubles(const pop_ctx *ctx);   /* size the host must p
 /* reduce buffer (block-sum vectors; in replicated-barotropic mode also the gathered RHS + guess) */
 long long pop_reduce_buffer_doubles(const pop_ctx *ctx);
 int pop_set_reduce_buffer(pop_ctx *ctx, void *dev_redbuf, long long doubles);
+/* in-library RCCL transport (replaces the communicator set-up of mpi/POP_CommMod.F90:70-135 and the
+ * MPI calls of mpi/POP_HaloMod.F90:1865-1960, mpi/POP_ReductionsMod.F90:348-383): rank 0 obtains a
+ * 128-byte id, the host broadcasts it by whatever means it has (MPI_Bcast, torch.distributed), every
+ * rank calls pop_comm_init_rccl.  Halo messages and block-sum all-reduces are then enqueued on the
+ * context's stream with no host round trip.  librccl is opened at run time. */
+int pop_rccl_unique_id(unsigned char *id128);
+int pop_comm_init_rccl(pop_ctx *ctx, const unsigned char *id128);
+/* checks the installed transport (either kind): an all-reduce of known values + a self message */
+int pop_comm_selftest(pop_ctx *ctx);
 /* halo plan introspection (host logic, testable without a GPU) */
 int pop_halo_plan_counts(const pop_ctx *ctx, int *n_local_copies, int *n_fill, int *n_peers);
 int pop_halo_plan_peer(const pop_ctx *ctx, int ipeer, int *peer_rank, int *n_send, int *n_recv);

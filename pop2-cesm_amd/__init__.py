@@ -61,6 +61,8 @@ def lib():
         "pop_set_comm": (ci, [vp, vp, vp, vp, ll, XCHG_FN, ALLRED_FN, vp]),
         "pop_comm_buffer_doubles": (ll, [vp]), "pop_set_stream": (ci, [vp, vp]),
         "pop_reduce_buffer_doubles": (ll, [vp]), "pop_set_reduce_buffer": (ci, [vp, vp, ll]),
+        "pop_rccl_unique_id": (ci, [C.c_char_p]), "pop_comm_init_rccl": (ci, [vp, C.c_char_p]),
+        "pop_comm_selftest": (ci, [vp]),
         "pop_halo_plan_counts": (ci, [vp, pi, pi, pi]), "pop_halo_plan_peer": (ci, [vp, ci, pi, pi, pi]),
         "pop_halo_plan_lists": (ci, [vp, ci, pi, pi]), "pop_halo_plan_local": (ci, [vp, pi, pi, pi]),
         "pop_timers_reset": (ci, [vp]), "pop_timer_ms": (ci, [vp, cs, pd, pi]),
@@ -234,6 +236,22 @@ class PopModel:
         return ms.value
 
     # ---- halo plan introspection
+    # ---- in-library RCCL transport (include/pop_amd.h) ----
+    @staticmethod
+    def rccl_unique_id():
+        """128-byte id made on rank 0; broadcast it, then every rank calls comm_init_rccl(id)."""
+        buf = C.create_string_buffer(128)
+        if lib().pop_rccl_unique_id(buf):
+            raise PopError("pop_rccl_unique_id failed (librccl not loadable?)")
+        return buf.raw
+
+    def comm_init_rccl(self, id128):
+        assert len(id128) == 128
+        self._chk(self.L.pop_comm_init_rccl(self.h, C.c_char_p(id128)))
+
+    def comm_selftest(self):
+        self._chk(self.L.pop_comm_selftest(self.h))
+
     def halo_plan(self):
         nl, nf, npeer = C.c_int(), C.c_int(), C.c_int()
         self.L.pop_halo_plan_counts(self.h, C.byref(nl), C.byref(nf), C.byref(npeer))

@@ -9,6 +9,7 @@
 #include "kernels_barotropic.hpp"
 #include "kernels_mix.hpp"
 #include "kernels_thomas_reg.hpp"
+#include "rccl_transport.hpp"
 
 using namespace pop;
 
@@ -70,6 +71,7 @@ struct pop_ctx {
   pop_exchange_fn xchg = nullptr;
   pop_allreduce_fn allred = nullptr;
   void *comm_user = nullptr;
+  RcclTransport *rccl_tr = nullptr;                       // in-library RCCL transport (pop_comm_init_rccl)
   // time stepping
   int oldt = 0, curt = 1, newt = 2, mixt = 1;
   int first_step = 1, leapfrogts = 1, f_euler_ts = 0, avg_ts = 0, nsteps_total = 0, nsteps_this_interval = 0;
@@ -161,7 +163,7 @@ int halo_update(pop_ctx *c, double *F, int nz, double fill = 0.0) {
     }
     if (so > c->comm_doubles || ro > c->comm_doubles) { c->err = "halo_update: comm buffer too small"; return 1; }
     if (c->xchg(c->comm_user, (int)peer.size(), peer.data(), soff.data(), scnt.data(), roff.data(), rcnt.data())) {
-      c->err = "halo_update: host exchange callback failed"; return 1;
+      c->err = "halo_update: exchange failed" + (c->rccl_tr ? ": " + c->rccl_tr->err : std::string(" in the host callback")); return 1;
     }
     ro = 0;
     for (auto &p : c->peers) {
@@ -611,6 +613,11 @@ int pop_destroy(pop_ctx *c) {
   if (!c) return 0;
   for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
   if (c->host_sc) hipHostFree(c->host_sc);
+  if (c->rccl_tr) {
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->rccl_tr->comm) rccl().CommDestroy(c->rccl_tr->comm);
+    delete c->rccl_tr;
+  }
   for (void *p : c->allocs) hipFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -966,6 +973,60 @@ int pop_set_comm(pop_ctx *c, void *sb, void *rb, void *red, long long buf_double
   c->xchg = x; c->allred = ar; c->comm_user = user;
   return 0;
 }
+// ---- in-library RCCL transport ------------------------------------------------------------------
+int pop_rccl_unique_id(unsigned char *id128) {
+  std::string err;
+  if (rccl().load(err)) return 1;
+  RcclApi::UniqueId id;
+  if (rccl().GetUniqueId(&id)) return 1;
+  std::memcpy(id128, id.internal, 128);
+  return 0;
+}
+int pop_comm_init_rccl(pop_ctx *c, const unsigned char *id128) {
+  if (need_device(c)) return 1;
+  if (c->rccl_tr) { c->err = "pop_comm_init_rccl: transport already initialised"; return 1; }
+  if (rccl().load(c->err)) return 1;
+  RcclApi::UniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  RcclTransport *t = new RcclTransport();
+  const int rc = rccl().CommInitRank(&t->comm, c->h.nranks, id, c->h.rank);
+  if (rc) { c->err = "pop_comm_init_rccl: ncclCommInitRank: " + rccl().what(rc); delete t; return 1; }
+  c->rccl_tr = t;
+  t->stream = &c->stream;
+  const long long nb = pop_comm_buffer_doubles(c), nr = std::max<long long>(pop_reduce_buffer_doubles(c), 8);
+  if (dev_alloc(c, &t->send, (size_t)nb) || dev_alloc(c, &t->recv, (size_t)nb) || dev_alloc(c, &t->red, (size_t)nr)) return 1;
+  c->sendbuf = t->send; c->recvbuf = t->recv; c->comm_doubles = nb;
+  c->redbuf = t->red; c->red_doubles = nr;
+  c->xchg = rccl_exchange; c->allred = rccl_allreduce; c->comm_user = t;
+  return 0;
+}
+// transport self-test (also the single-rank check of the RCCL binding): every rank contributes
+// rank+1 in slot `rank` of the reduce buffer and passes one value round the ring of ranks
+int pop_comm_selftest(pop_ctx *c) {
+  if (need_device(c)) return 1;
+  if (!c->xchg || !c->allred || !c->redbuf || !c->sendbuf) { c->err = "pop_comm_selftest: no transport installed"; return 1; }
+  const int nr = c->h.nranks;
+  if (c->red_doubles < nr) { c->err = "pop_comm_selftest: reduce buffer too small"; return 1; }
+  std::vector<double> v(nr, 0.0);
+  v[c->h.rank] = c->h.rank + 1.0;
+  HIPCHK(c, hipMemcpyAsync(c->redbuf, v.data(), sizeof(double) * nr, hipMemcpyHostToDevice, c->stream));
+  if (c->allred(c->comm_user, 0, nr)) { c->err = "pop_comm_selftest: allreduce failed" + (c->rccl_tr ? ": " + c->rccl_tr->err : std::string()); return 1; }
+  HIPCHK(c, hipMemcpyAsync(v.data(), c->redbuf, sizeof(double) * nr, hipMemcpyDeviceToHost, c->stream));
+  const double probe = 1000.0 + c->h.rank;
+  double back = 0.0;
+  HIPCHK(c, hipMemcpyAsync(c->sendbuf, &probe, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  // ring: one value to rank+1, one from rank-1 (a self message on one rank)
+  const int nxt = (c->h.rank + 1) % nr, prv = (c->h.rank + nr - 1) % nr;
+  const int peer[2] = {nxt, prv};
+  const long long z2[2] = {0, 0}, sc1[2] = {1, 0}, rc1[2] = {nxt == prv ? 1 : 0, 1};
+  if (c->xchg(c->comm_user, nxt == prv ? 1 : 2, peer, z2, sc1, z2, rc1)) { c->err = "pop_comm_selftest: exchange failed" + (c->rccl_tr ? ": " + c->rccl_tr->err : std::string()); return 1; }
+  HIPCHK(c, hipMemcpyAsync(&back, c->recvbuf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int r = 0; r < nr; ++r) if (v[r] != r + 1.0) { c->err = "pop_comm_selftest: all-reduce returned a wrong sum"; return 1; }
+  if (back != 1000.0 + prv) { c->err = "pop_comm_selftest: ring send/recv returned a wrong value"; return 1; }
+  return 0;
+}
+
 int pop_set_reduce_buffer(pop_ctx *c, void *dev_redbuf, long long doubles) { c->redbuf = (double *)dev_redbuf; c->red_doubles = doubles; return 0; }
 long long pop_reduce_buffer_doubles(const pop_ctx *c) {
   long long n = 4LL * c->h.nblocks_tot;

@@ -163,6 +163,20 @@
          import :: c_int, c_ptr
          type (c_ptr), value :: ctx
       end function
+      ! in-library RCCL transport (include/pop_amd.h)
+      integer (c_int) function pop_rccl_unique_id(id128) bind(C, name='pop_rccl_unique_id')
+         import :: c_int, c_signed_char
+         integer (c_signed_char), intent(out) :: id128(128)
+      end function
+      integer (c_int) function pop_comm_init_rccl(ctx, id128) bind(C, name='pop_comm_init_rccl')
+         import :: c_int, c_ptr, c_signed_char
+         type (c_ptr), value :: ctx
+         integer (c_signed_char), intent(in) :: id128(128)
+      end function
+      integer (c_int) function pop_comm_selftest(ctx) bind(C, name='pop_comm_selftest')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
    end interface
 
  contains

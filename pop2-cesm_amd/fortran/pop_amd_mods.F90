@@ -51,6 +51,31 @@
  end module blocks
 
 !-----------------------------------------------------------------------
+ module POP_CommMod          ! mpi/POP_CommMod.F90:70-135 (POP_CommInit: MPI_COMM_DUP of the ocean communicator)
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   public :: POP_CommCreateRccl, POP_CommInitRccl
+ contains
+   ! The ocean communicator of the GPU ranks is an RCCL communicator owned by the library.  Rank 0
+   ! makes the 128-byte id; the driver broadcasts it with the MPI it already has
+   ! (call MPI_BCAST(id, 128, MPI_BYTE, 0, POP_Communicator, ierr)) and every task then calls
+   ! POP_CommInitRccl.  After that halo updates and global sums run entirely on the device stream.
+   subroutine POP_CommCreateRccl(id, errorCode)
+      integer (c_signed_char), intent(out) :: id(128)
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_rccl_unique_id(id)
+   end subroutine
+   subroutine POP_CommInitRccl(id, errorCode)
+      integer (c_signed_char), intent(in) :: id(128)
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_comm_init_rccl(pop_ctx, id)
+      if (errorCode == POP_Success) errorCode = pop_comm_selftest(pop_ctx)
+   end subroutine
+ end module POP_CommMod
+
+!-----------------------------------------------------------------------
  module POP_HaloMod          ! mpi/POP_HaloMod.F90:79-89, 1732-1773
    use kinds_mod
    use pop_amd_c

@@ -38,6 +38,7 @@ def main():
     cfg = named_config(args.config, **kw)
     m = pkg.PopModel(cfg, rank=rank, nranks=world)
     comm = bench.TorchComm(pkg, m, rank, world, staged=True)   # noqa: F841
+    m.comm_selftest()                                          # all-reduce of known values + a self message
     ref = pkg.PopModel(cfg) if True else None                  # every rank keeps a single-rank twin
     ids = m.local_block_ids()
     ok = True
