@@ -9,7 +9,8 @@ namespace pop {
 // arrays are 1-based with slot 0 (index k is wave-uniform, so they are read by scalar loads).
 struct DevGrid {
   int nxb, nyb, km, nt, nblocks, ib, ie, jb, je;   // ib..je are 1-based like the reference
-  int xcd_remap;                                   // column kernels: XCD-banded tile order (small grids)
+  int xcd_remap;                                   // column kernels: workgroup order (kernels_common.hpp col_setup)
+  int red_tiles;                                   // 2-D reduction kernels: 64x4 tiles in XCD-strided columns
   int n2;                                          // nxb*nyb
   long long n3;                                    // n2*km
   const double *dz, *dzw, *zt, *zw, *c2dz, *dzr, *dz2r, *dzwr, *pressz, *bouss, *afac_t, *afac_u;

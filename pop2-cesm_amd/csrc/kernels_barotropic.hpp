@@ -193,7 +193,7 @@ __global__ void k_finalize(const double *__restrict__ blocksum, int nblocks_tot,
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_dot_partial(DevGrid g, const double *__restrict__ A, const double *__restrict__ Bv, const double *__restrict__ M,
               double *__restrict__ partial) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   double v[1] = {0.0};
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
@@ -231,7 +231,7 @@ struct SolverArgs {
 template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_residual(DevGrid g, SolverArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   double v[1] = {0.0};
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
@@ -248,7 +248,7 @@ k_residual(DevGrid g, SolverArgs a) {
 template <bool UPDATE>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_pcg_a(DevGrid g, SolverArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   double v[1] = {0.0};
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
@@ -269,7 +269,7 @@ k_pcg_a(DevGrid g, SolverArgs a) {
 }
 // x,r update only (before a convergence check)
 __global__ void k_pcg_xr(DevGrid g, SolverArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   if (p2 >= g.n2) return;
   const long long q = (long long)b * g.n2 + p2;
   const double al = a.sc->alpha;
@@ -280,7 +280,7 @@ __global__ void k_pcg_xr(DevGrid g, SolverArgs a) {
 // the old direction buffer (no race: S0 is read, S1 written); q = A s_new; partial (q,s)
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_pcg_b(DevGrid g, SolverArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   double v[1] = {0.0};
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
@@ -304,7 +304,7 @@ k_pcg_b(DevGrid g, SolverArgs a) {
 // init: z = r*A0R; s = z; q = A s; partial (r,z), (s,q)
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_cg_init(DevGrid g, SolverArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   double v[2] = {0.0, 0.0};
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
@@ -323,7 +323,7 @@ k_cg_init(DevGrid g, SolverArgs a) {
 }
 // z = r*A0R (whole array; the halo of Z follows)
 __global__ void k_cg_z(DevGrid g, SolverArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   if (p2 >= g.n2) return;
   const long long q = (long long)b * g.n2 + p2;
   const double cw = a.C[q];
@@ -332,7 +332,7 @@ __global__ void k_cg_z(DevGrid g, SolverArgs a) {
 // az = A z; partial (r,z), (az,z)
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_cg_az(DevGrid g, SolverArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   double v[2] = {0.0, 0.0};
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
@@ -346,7 +346,7 @@ k_cg_az(DevGrid g, SolverArgs a) {
 // s = z + beta s; q = az + beta q; x += alpha s; r -= alpha q   (FIRST: x,r only with the init alpha)
 template <bool FIRST>
 __global__ void k_cg_update(DevGrid g, SolverArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   if (p2 >= g.n2) return;
   const long long q = (long long)b * g.n2 + p2;
   const double al = a.sc->alpha;
@@ -448,7 +448,7 @@ __device__ __forceinline__ double fused_total(const double *__restrict__ partial
 template <bool UPDATE>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_a(DevGrid g, FusedArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const long long q = (long long)b * g.n2 + (live ? p2 : 0);
   double r = a.R[q], x = 0.0, s0 = 0.0, qq = 0.0;
@@ -481,7 +481,7 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
 // srcmap (bit-identical to reading the ghost after a halo update); all other cells index directly.
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_b(DevGrid g, FusedArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const int pp = live ? p2 : 0;
   const int i = pp % g.nxb, j = pp / g.nxb, nxb = g.nxb;
@@ -531,7 +531,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
 // pending x,r update before a convergence check
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_xr(DevGrid g, FusedArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, a.presummed);
   const double rz = a.sc->eta1;
   const double alpha = rz / sq;
@@ -546,7 +546,7 @@ k_fpcg_xr(DevGrid g, FusedArgs a) {
 template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fresidual(DevGrid g, FusedArgs a) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  const int p2 = red_cell(g), b = blockIdx.y;
   double v[1] = {0.0};
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;

@@ -14,25 +14,51 @@ struct Col {
   long long q2;           // b*n2 + p2
   long long base3;        // b*n3 + p2   (+ (k-1)*n2 for level k)
 };
-// XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (blocks b and b+8
-// share one L2, MI355X_MICROARCH.md), so consecutive blockIdx.x are mapped to tiles that are nT/8
-// apart: every XCD then owns one contiguous band of the (i,j) plane and the j+-1 rows re-read by
-// neighbouring workgroups hit that XCD's own L2 instead of being fetched once per XCD.
-// gridDim.x must be a multiple of 8 (col_grid_x); surplus tiles idle.
+// XCD-aware tile order.  The hardware deals workgroups round-robin over the 8 XCDs (workgroup w runs on
+// XCD w % 8, each with its own 4 MB L2; MI355X_MICROARCH.md), so with the natural order the rows j+-1 a
+// stencil re-reads were fetched by workgroups of OTHER XCDs and every L2 fetches them again.
+//   g.xcd_remap == 1 (small grids, everything co-resident): XCD x owns one contiguous band of the
+//     linear tile order.
+//   g.xcd_remap == 2 (large grids): tiles are blockDim.x wide, blockDim.y rows high; XCD x owns the
+//     tile COLUMNS ti = x (mod 8) and walks them row by row, so all XCDs stream the same rows at the
+//     same time (DRAM page locality of the natural order is kept) and the vertical neighbour of a
+//     tile is the tile the same XCD touched a few workgroups earlier.  The ntx % 8 left-over columns
+//     are dealt out tile by tile so every XCD gets the same number of workgroups.
+// The launch grid's x size comes from tile_grid_x(); surplus workgroups idle.
+struct TileId { int ti, tj; bool valid; };
+__host__ __device__ inline int tile_grid_x(int nxb, int nyb, int tw, int th) {
+  const int ntx = (nxb + tw - 1) / tw, nty = (nyb + th - 1) / th;
+  const int full = ntx >> 3, rem = ntx & 7;
+  return 8 * (full * nty + (rem * nty + 7) / 8);
+}
+__device__ __forceinline__ TileId tile_of_block(int nxb, int nyb, int tw, int th) {
+  const int ntx = (nxb + tw - 1) / tw, nty = (nyb + th - 1) / th;
+  const int full = ntx >> 3, rem = ntx & 7;
+  const int x = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  TileId t;
+  if (seq < full * nty) { t.tj = seq / full; t.ti = x + 8 * (seq % full); t.valid = true; }
+  else {
+    const int r = (seq - full * nty) * 8 + x;
+    t.valid = r < rem * nty;
+    t.tj = t.valid ? r / rem : 0; t.ti = t.valid ? 8 * full + r % rem : 0;
+  }
+  return t;
+}
 __host__ __device__ inline int col_grid_x(int n2, int threads) { const int nt = (n2 + threads - 1) / threads; return 8 * ((nt + 7) / 8); }
-__host__ inline int col_grid_x2d(int nxb, int nyb, int tx, int ty) { const int nt = ((nxb + tx - 1) / tx) * ((nyb + ty - 1) / ty); return 8 * ((nt + 7) / 8); }
+// launch grid x for a col_setup kernel with `threads` x 1 workgroups
+__host__ inline int col_grid(const DevGrid &g, int threads) {
+  return g.xcd_remap == 2 ? tile_grid_x(g.nxb, g.nyb, threads, 1) : col_grid_x(g.n2, threads);
+}
 __device__ __forceinline__ bool col_setup(const DevGrid &g, Col &c, bool interior_only) {
-  const int tile = g.xcd_remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   c.b = blockIdx.y;
-  if (blockDim.y > 1) {
-    // 2-D workgroup (stencil kernels): blockDim.y consecutive rows of one 64-wide i strip, one wave per
-    // row, so the j+-1 rows a wave reads are the rows its sibling waves on the same CU are reading
-    const int tiles_i = (g.nxb + blockDim.x - 1) / blockDim.x;
-    c.i = (tile % tiles_i) * blockDim.x + threadIdx.x;
-    c.j = (tile / tiles_i) * blockDim.y + threadIdx.y;
-    if (c.i >= g.nxb || c.j >= g.nyb) return false;
+  if (g.xcd_remap == 2) {
+    const TileId t = tile_of_block(g.nxb, g.nyb, blockDim.x, blockDim.y);
+    c.i = t.ti * blockDim.x + threadIdx.x;
+    c.j = t.tj * blockDim.y + threadIdx.y;
+    if (!t.valid || c.i >= g.nxb || c.j >= g.nyb) return false;
     c.p2 = c.j * g.nxb + c.i;
   } else {
+    const int tile = g.xcd_remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     c.p2 = tile * blockDim.x + threadIdx.x;
     if (c.p2 >= g.n2) return false;
     c.i = c.p2 % g.nxb;
@@ -42,6 +68,20 @@ __device__ __forceinline__ bool col_setup(const DevGrid &g, Col &c, bool interio
   c.q2 = (long long)c.b * g.n2 + c.p2;
   c.base3 = (long long)c.b * g.n3 + c.p2;
   return true;
+}
+// 2-D reduction kernels (POP_RED_THREADS = 256 threads, one partial per workgroup): cell of this thread,
+// or g.n2 (not a cell) for surplus threads.  Large grids use 64 x 4 tiles in the XCD-strided column order.
+__host__ inline int red_grid_x(const DevGrid &g) {
+  return g.red_tiles ? tile_grid_x(g.nxb, g.nyb, 64, 4) : (g.n2 + 255) / 256;
+}
+__device__ __forceinline__ int red_cell(const DevGrid &g) {
+  if (g.red_tiles) {
+    const TileId t = tile_of_block(g.nxb, g.nyb, 64, 4);
+    const int i = t.ti * 64 + (threadIdx.x & 63), j = t.tj * 4 + (threadIdx.x >> 6);
+    return (t.valid && i < g.nxb && j < g.nyb) ? j * g.nxb + i : g.n2;
+  }
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  return p2 < g.n2 ? p2 : g.n2;
 }
 
 // ---- McDougall, Wright, Jackett & Feistel (2003) equation of state as used by the

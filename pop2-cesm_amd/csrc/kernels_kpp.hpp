@@ -443,7 +443,7 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
 
 inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParams &sp, const MixDev &, const MixState &s,
                            hipStream_t st, std::string &err) {
-  const dim3 GC(col_grid_x(g.n2, POP_COL_THREADS), g.nblocks), BC(POP_COL_THREADS);
+  const dim3 GC(col_grid(g, POP_COL_THREADS), g.nblocks), BC(POP_COL_THREADS);
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);
   double *DBLOC = s.S3a, *DBSFC = s.S3b, *WU = s.S3c, *VISC = s.S3d, *RIW = s.E3;
   hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);

@@ -106,15 +106,14 @@ std::vector<T> local_part(const HostModel &h, const std::vector<T> &all) {
   return out;
 }
 
-dim3 grid_cols(const pop_ctx *c) { return dim3(col_grid_x(c->g.n2, POP_COL_THREADS), c->g.nblocks); }
-// stencil column kernels: workgroup = 64 x rows tile (kernels_common.hpp col_setup)
-int stencil_rows() { static int r = getenv("POP_STENCIL_ROWS") ? atoi(getenv("POP_STENCIL_ROWS")) : 1; return r < 1 ? 1 : r; }
-dim3 block_stencil() { return dim3(POP_COL_THREADS, stencil_rows()); }
-dim3 grid_stencil(const pop_ctx *c) {
-  if (stencil_rows() == 1) return grid_cols(c);
-  return dim3(col_grid_x2d(c->g.nxb, c->g.nyb, POP_COL_THREADS, stencil_rows()), c->g.nblocks);
+// column kernels: one wave per workgroup; tile order per kernels_common.hpp col_setup
+dim3 grid_cols(const pop_ctx *c) {
+  if (c->g.xcd_remap == 2) return dim3(tile_grid_x(c->g.nxb, c->g.nyb, POP_COL_THREADS, 1), c->g.nblocks);
+  return dim3(col_grid(c->g, POP_COL_THREADS), c->g.nblocks);
 }
-dim3 grid_2d(const pop_ctx *c) { return dim3((c->g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS, c->g.nblocks); }
+dim3 block_stencil() { return dim3(POP_COL_THREADS, 1); }
+dim3 grid_stencil(const pop_ctx *c) { return grid_cols(c); }
+dim3 grid_2d(const pop_ctx *c) { return dim3(red_grid_x(c->g), c->g.nblocks); }
 dim3 grid_3d(const pop_ctx *c) { return dim3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks); }
 
 StepParams step_params(const pop_ctx *c) {
@@ -266,7 +265,7 @@ FusedArgs fused_args(pop_ctx *c, const SolveView &v) {
 void presum(pop_ctx *c, const SolveView &v, const double *partial, double *bs) {
   hipLaunchKernelGGL(k_block_sums<1>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->iota, bs);
 }
-dim3 view_grid(const SolveView &v) { return dim3((v.g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS, v.g.nblocks); }
+dim3 view_grid(const SolveView &v) { return dim3(red_grid_x(v.g), v.g.nblocks); }
 // one check interval: freq iterations, pending update, residual + (r,r) -> host
 int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
@@ -489,10 +488,16 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   DevGrid &g = c->g;
   g.nxb = h.nxb; g.nyb = h.nyb; g.km = h.km; g.nt = h.nt; g.nblocks = h.nblocks;
   g.n2 = (int)h.n2; g.n3 = (long long)h.n3;
-  // XCD-banded tile order pays when one level of the block fits the L2s (measured: gx1v7 fabric re-fetch
-  // 3.2x -> 1.3x, -6% time; tx0.1v3 +20% time), POP_XCD_REMAP=0|1 overrides
+  // workgroup order (kernels_common.hpp).  Measured on MI355X: the XCD-banded order cuts fabric re-fetch of
+  // the stencil kernels from 3.2x to 1.3x of the algorithmic reads at gx1v7 (-6% time) but costs +20% at
+  // tx0.1v3; row-aligned tile columns (mode 2 / POP_RED_TILES) lose 128-B alignment of the rows
+  // (nx_block*8 B is not a multiple of 128) and cost +10% (columns) / +2% (solver) at tx0.1v3, where
+  // the 256 MB infinity cache already absorbs the re-fetch.  Large grids therefore keep the natural
+  // linear order; the other orders stay selectable (POP_XCD_REMAP=0|1|2, POP_RED_TILES=0|1) and tested.
   g.xcd_remap = (h.n2 * h.nblocks <= (1u << 19)) ? 1 : 0;
   if (getenv("POP_XCD_REMAP")) g.xcd_remap = atoi(getenv("POP_XCD_REMAP"));
+  g.red_tiles = 0;
+  if (getenv("POP_RED_TILES")) g.red_tiles = atoi(getenv("POP_RED_TILES"));
   g.ib = NGHOST + 1; g.ie = h.nxb - NGHOST; g.jb = NGHOST + 1; g.je = h.nyb - NGHOST;
   // vertical arrays
   {
@@ -535,7 +540,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   c->centerWgt = c->d2["centerWgt"];
   double **three[] = {&c->VVC, &c->E3, &c->F3, &c->S3a, &c->S3b, &c->S3c, &c->S3d};
   for (auto p : three) if (dev_alloc(c, p, a3)) return 1;
-  c->nchunk = (g.n2 + POP_RED_THREADS - 1) / POP_RED_THREADS;
+  c->nchunk = red_grid_x(g);
   if (dev_alloc(c, &c->partial, (size_t)c->nchunk * h.nblocks * 2) || dev_alloc(c, &c->blocksum, (size_t)h.nblocks_tot * 4)) return 1;
   { std::vector<int> io(h.nblocks_tot); for (int b = 0; b < h.nblocks_tot; ++b) io[b] = b; if (dev_upload(c, &c->iota, io.data(), io.size())) return 1; }
   if (dev_alloc(c, &c->sc, 1)) return 1;
@@ -742,7 +747,7 @@ int pop_time_manager(pop_ctx *c) {
 int pop_dhdt(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "DHDT");
-  hipLaunchKernelGGL(k_dhdt, dim3(col_grid_x(c->g.n2, 256), c->g.nblocks), dim3(256), 0, c->stream, c->g, step_params(c),
+  hipLaunchKernelGGL(k_dhdt, dim3(col_grid(c->g, 256), c->g.nblocks), dim3(256), 0, c->stream, c->g, step_params(c),
                      c->PS[c->curt], c->PS[c->oldt], c->FW_OLD, c->DH, c->DHU);
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -869,7 +874,7 @@ int pop_barotropic_driver(pop_ctx *c) {
   a.GXN = c->GX[c->newt]; a.GYN = c->GY[c->newt]; a.UBN = c->UB[c->newt]; a.VBN = c->VB[c->newt];
   a.GXR = c->leapfrogts ? c->GX[c->oldt] : c->GX[c->curt]; a.GYR = c->leapfrogts ? c->GY[c->oldt] : c->GY[c->curt];
   a.scal = &c->sc->xcheck; a.rcheck = c->h.rcheck; a.rconst = c->h.rconst;
-  const dim3 G(col_grid_x(c->g.n2, 256), c->g.nblocks), B(256);
+  const dim3 G(col_grid(c->g, 256), c->g.nblocks), B(256);
   hipLaunchKernelGGL(k_btrop_rhs1, G, B, 0, c->stream, c->g, sp, a);
   hipLaunchKernelGGL(k_btrop_rhs2, G, B, 0, c->stream, c->g, sp, a);
   if (halo_update(c, c->RHS, 1)) return 1;
@@ -910,7 +915,7 @@ int pop_step_tail(pop_ctx *c) {
     a.UBN = c->UB[nw]; a.VBN = c->VB[nw]; a.GXN = c->GX[nw]; a.GYN = c->GY[nw]; a.PN = c->PS[nw]; a.FW = c->FW;
     for (int n = 0; n < 2; ++n) { a.T1O[n] = c->TR[n][o]; a.T1C[n] = c->TR[n][cu]; a.T1N[n] = c->TR[n][nw]; }
     a.dz1 = c->h.dz[1]; a.grav = GRAV;
-    hipLaunchKernelGGL(k_avg2d, dim3(col_grid_x(c->g.n2, 256), c->g.nblocks), dim3(256), 0, c->stream, c->g, a);
+    hipLaunchKernelGGL(k_avg2d, dim3(col_grid(c->g, 256), c->g.nblocks), dim3(256), 0, c->stream, c->g, a);
     Avg3dArgs b{};
     b.UO = c->U[o]; b.UC = c->U[cu]; b.VO = c->V[o]; b.VC = c->V[cu]; b.RO = c->RHO[o]; b.RC = c->RHO[cu]; b.UN = c->U[nw]; b.VN = c->V[nw];
     for (int n = 0; n < 2; ++n) { b.TO[n] = c->TR[n][o]; b.TC[n] = c->TR[n][cu]; b.TN[n] = c->TR[n][nw]; }

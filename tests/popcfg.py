@@ -67,6 +67,9 @@ def named_config(name, **kw):
     elif name == "tiny":    # small multi-block case for fast CPU parity
         c = base_config(nx_global=48, ny_global=40, km=16, block_size_x=12, block_size_y=10,
                         vmix_choice=1, steps_per_day=24, am=3.0e9, ah=1.0e7)
+    elif name == "wide":    # many 64-/256-wide tile columns in i: exercises the large-grid XCD tile order
+        c = base_config(nx_global=2112, ny_global=16, km=16, block_size_x=2112, block_size_y=16,
+                        vmix_choice=1, steps_per_day=96, am=1.0e7, ah=1.0e6)
     elif name == "gx3v7":
         c = base_config(nx_global=100, ny_global=116, km=60, block_size_x=100, block_size_y=116,
                         vmix_choice=1, steps_per_day=12, am=3.0e9, ah=1.0e7)

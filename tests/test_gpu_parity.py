@@ -150,6 +150,28 @@ def test_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
     gpu.close(); orc.close()
 
 
+@pytest.mark.parametrize("kw,nsteps", [
+    ({}, 3),
+    ({"block_size_x": 1056}, 3),                                           # two blocks side by side
+    ({"vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e19, "ah": -1.0e18}, 3),   # KPP + del4
+])
+def test_large_grid_tile_order_matches_oracle(pkg, orclib_built, monkeypatch, kw, nsteps):
+    """POP_XCD_REMAP=2 forces the tile-column workgroup order production uses above 2^19 columns
+    (kernels_common.hpp) on a grid small enough for the oracle: full 8-column groups, left-over
+    columns and surplus workgroups all occur (2116 = 33 x 64 + 4 = 8 x 256 + 68)."""
+    monkeypatch.setenv("POP_XCD_REMAP", "2")
+    monkeypatch.setenv("POP_RED_TILES", "1")
+    cfg = named_config("wide", **kw)
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
+    tol = TOL_LOCAL
+    for s in range(1, nsteps + 1):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+    gpu.close(); orc.close()
+
+
 def test_state_known_answer_and_derivatives(pkg, orclib_built):
     """state_mod.F90:413-414: rho(S=35 psu, theta=20 C, p=200 bar) -- the comment quotes
     1.033213242; the reference's own coefficient set evaluates to 1.0332133866 (see
