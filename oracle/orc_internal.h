@@ -48,6 +48,7 @@ struct orc_model {
   /* kpp */
   void *kpp;
   void *del4;
+  void *upw3;
 };
 
 extern const double orc_grav, orc_omega, orc_radius;

@@ -409,6 +409,58 @@ int host_build(HostModel &h) {
     });
   }
 
+  // ---------------- third-order upwind interpolation weights (advection.F90:420-562) ----------------
+  // Defined where the reference defines them: zonal on ib-1..ie x jb..je, poloidal on ib..ie x jb-1..je.
+  if (c.tadvect == 2) {
+    const int km = h.km;
+    const std::vector<double> &dz = h.dz;
+    std::vector<double> dzc(km + 2);
+    dzc[0] = dz[1];
+    for (int k = 1; k <= km; ++k) dzc[k] = dz[k];
+    dzc[km + 1] = dzc[km];
+    for (auto &v : h.upw_z) v.assign(km + 1, 0.0);
+    std::vector<double> &azp = h.upw_z[0], &bzp = h.upw_z[1], &gzp = h.upw_z[2], &azm = h.upw_z[3], &bzm = h.upw_z[4], &dzm = h.upw_z[5];
+    for (int k = 1; k <= km - 1; ++k) {
+      azp[k] = dz[k] * (2.0 * dz[k] + dzc[k - 1]) / ((dz[k] + dz[k + 1]) * (dzc[k - 1] + 2.0 * dz[k] + dz[k + 1]));
+      bzp[k] = dz[k + 1] * (2.0 * dz[k] + dzc[k - 1]) / ((dz[k] + dz[k + 1]) * (dz[k] + dzc[k - 1]));
+      gzp[k] = -(dz[k] * dz[k + 1]) / ((dz[k] + dzc[k - 1]) * (dz[k + 1] + dzc[k - 1] + 2.0 * dz[k]));
+    }
+    bzp[1] = bzp[1] + gzp[1]; gzp[1] = 0.0;
+    azp[km] = 0.0; bzp[km] = 0.0; gzp[km] = 0.0;
+    for (int k = 1; k <= km - 1; ++k) {
+      azm[k] = dz[k] * (2.0 * dz[k + 1] + dzc[k + 2]) / ((dz[k] + dz[k + 1]) * (dz[k + 1] + dzc[k + 2]));
+      bzm[k] = dz[k + 1] * (2.0 * dz[k + 1] + dzc[k + 2]) / ((dz[k] + dz[k + 1]) * (dz[k] + dzc[k + 2] + 2.0 * dz[k + 1]));
+      dzm[k] = -(dz[k] * dz[k + 1]) / ((dz[k + 1] + dzc[k + 2]) * (dz[k] + dzc[k + 2] + 2.0 * dz[k + 1]));
+    }
+    azm[km - 1] = azm[km - 1] + dzm[km - 1]; dzm[km - 1] = 0.0;
+    azm[km] = 0.0; bzm[km] = 0.0; dzm[km] = 0.0;
+    auto &AXP = newf("TALFXP"), &BXP = newf("TBETXP"), &GXP = newf("TGAMXP"), &AXM = newf("TALFXM"), &BXM = newf("TBETXM"), &DXM = newf("TDELXM");
+    auto &AYP = newf("TALFYP"), &BYP = newf("TBETYP"), &GYP = newf("TGAMYP"), &AYM = newf("TALFYM"), &BYM = newf("TBETYM"), &DYM = newf("TDELYM");
+    const int ib = NGHOST, ie = nxb - NGHOST - 1, jb = NGHOST, je = nyb - NGHOST - 1;   // 0-based physical domain
+    for (int b = 0; b < NB; ++b) {
+      for (int j = jb; j <= je; ++j) for (int i = ib - 1; i <= ie; ++i) {
+        const size_t p = idx(b, i, j);
+        const double dxc = DXT[p], dxcw = DXT[p - 1], dxce = DXT[p + 1], dxce2 = DXT[p + 2];
+        AXP[p] = dxc * (2.0 * dxc + dxcw) / ((dxc + dxce) * (dxcw + 2.0 * dxc + dxce));
+        BXP[p] = dxce * (2.0 * dxc + dxcw) / ((dxc + dxcw) * (dxc + dxce));
+        GXP[p] = -(dxc * dxce) / ((dxc + dxcw) * (dxcw + 2.0 * dxc + dxce));
+        AXM[p] = dxc * (2.0 * dxce + dxce2) / ((dxc + dxce) * (dxce + dxce2));
+        BXM[p] = dxce * (2.0 * dxce + dxce2) / ((dxc + dxce) * (dxc + 2.0 * dxce + dxce2));
+        DXM[p] = -(dxc * dxce) / ((dxce2 + dxce) * (dxc + 2.0 * dxce + dxce2));
+      }
+      for (int j = jb - 1; j <= je; ++j) for (int i = ib; i <= ie; ++i) {
+        const size_t p = idx(b, i, j);
+        const double dyc = DYT[p], dycs = DYT[p - nxb], dycn = DYT[p + nxb], dycn2 = DYT[p + 2 * (size_t)nxb];
+        AYP[p] = dyc * (2.0 * dyc + dycs) / ((dyc + dycn) * (dycs + 2.0 * dyc + dycn));
+        BYP[p] = dycn * (2.0 * dyc + dycs) / ((dyc + dycn) * (dycs + dyc));
+        GYP[p] = -(dyc * dycn) / ((dyc + dycs) * (dycs + 2.0 * dyc + dycn));
+        AYM[p] = dyc * (2.0 * dycn + dycn2) / ((dyc + dycn) * (dycn + dycn2));
+        BYM[p] = dycn * (2.0 * dycn + dycn2) / ((dyc + dycn) * (dyc + 2.0 * dycn + dycn2));
+        DYM[p] = -(dyc * dycn) / ((dycn2 + dycn) * (dyc + 2.0 * dycn + dycn2));
+      }
+    }
+  }
+
   // ---------------- barotropic operator, null-space fields ----------------
   auto &WNE = newf("btropWgtNE"), &WEa = newf("btropWgtEast"), &WNo = newf("btropWgtNorth"), &WC0 = newf("centerWgtIndep");
   auto &mMask = newf("mMask"), &CHECKER = newf("CHECKER"), &CONSTNT = newf("CONSTNT");

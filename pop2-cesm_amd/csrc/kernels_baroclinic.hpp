@@ -72,6 +72,24 @@ __global__ void k_vmix_const(DevGrid g, StepParams sp, const double *__restrict_
 //   non-local sources, and the RHS/predictor store (:2212-2237).
 // Algorithmic traffic per cell (SURVEY.md 8d phase B): 12 words with KPP, 9 without.
 // ------------------------------------------------------------------------------------------
+// third-order upwind weights (advection.F90:420-562): six per direction {alf+,bet+,gam+,alf-,bet-,del-}
+struct Upw3Dev {
+  const double *cx[6], *cy[6];     // (nx,ny,block)
+  const double *cz[6];             // 1..km
+};
+// one face value of hupw3 (advection.F90:2560-2590 / :2617-2648): `flux` is the face flux weight whose
+// sign selects the upwind side; kA/kB/kC are the KMT of the cells the stencil may reach
+// (east|north, west|south, east-east|north-north); x(-1), x(0), x(+1), x(+2) along the direction
+__device__ __forceinline__ double upw3_face(int k, double flux, int kA, int kB, int kC, const double (&w)[6],
+                                            double xm1, double x0, double xp1, double xp2) {
+  double work, ap, bp, gp, am, dm;
+  if (k <= kA) { work = w[1]; ap = w[0]; } else { work = w[1] + w[0]; ap = 0.0; }
+  if (k <= kB) { bp = work; gp = w[2]; } else { bp = work + w[2]; gp = 0.0; }
+  if (k <= kC) { am = w[3]; dm = w[5]; } else { am = w[3] + w[5]; dm = 0.0; }
+  const double bm = w[4];
+  return (flux > 0.0) ? ap * xp1 + bp * x0 + gp * xm1 : am * xp1 + bm * x0 + dm * xp2;
+}
+
 struct TracerRhsArgs {
   const double *TCUR[2], *TOLD[2], *TMIX[2];
   double *TNEW[2];
@@ -80,9 +98,14 @@ struct TracerRhsArgs {
   const double *DH, *PCUR, *POLD;
   double c2dtt;
   int use_kpp_src;
+  Upw3Dev up;               // UPW3 only
 };
 
-template <bool DEL4>
+// UPW3: advt_upwind3 + hupw3 (advection.F90:2313-2481, 2488-2676) in place of advt_centered.  The east
+// face value of the west neighbour and the north face value of the south neighbour are recomputed by
+// this thread (same operands, same order as the neighbour's own evaluation), the flux through the
+// top face (AUX) is carried in a register, and four tracer levels k-1..k+2 are kept in registers.
+template <bool DEL4, bool UPW3>
 __global__ void __launch_bounds__(POP_STENCIL_MAX_THREADS)
 k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
   Col c;
@@ -100,6 +123,21 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
   double tc_km1[2] = {0.0, 0.0}, tc_k[2], tc_kp1[2], to_k[2], to_kp1[2];
 #pragma unroll
   for (int n = 0; n < 2; ++n) { tc_k[n] = a.TCUR[n][c.base3]; to_k[n] = a.TOLD[n][c.base3]; }
+  // upwind3: weights at this cell, its west neighbour (x) and its south neighbour (y)
+  double wx0[6], wxw[6], wy0[6], wys[6], aux[2] = {0.0, 0.0};
+  int kmtee = 0, kmtnn = 0, kEw = 0, kWw = 0, kEEw = 0, kNs = 0, kSs = 0, kNNs = 0;
+  double tarear_w = 0.0, tarear_s = 0.0;
+  if (UPW3) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      wx0[t] = a.up.cx[t][c.q2]; wxw[t] = a.up.cx[t][c.q2 - 1];
+      wy0[t] = a.up.cy[t][c.q2]; wys[t] = a.up.cy[t][c.q2 - nxb];
+    }
+    kmtee = g.KMTEE[c.q2]; kmtnn = g.KMTNN[c.q2];
+    kEw = g.KMTE[c.q2 - 1]; kWw = g.KMTW[c.q2 - 1]; kEEw = g.KMTEE[c.q2 - 1];
+    kNs = g.KMTN[c.q2 - nxb]; kSs = g.KMTS[c.q2 - nxb]; kNNs = g.KMTNN[c.q2 - nxb];
+    tarear_w = g.TAREA_R[c.q2 - 1]; tarear_s = g.TAREA_R[c.q2 - nxb];
+  }
   const long long vdcbase = ((long long)c.b * (km + 2)) * n2 + c.p2;
   double *__restrict__ const TNp[2] = {a.TNEW[0], a.TNEW[1]};   // outputs alias no input
   for (int k = 1; k <= km; ++k) {
@@ -131,9 +169,36 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
         FT = sp.ah * (CC * TM[o] + CN * TM[o + nxb] + CS * TM[o - nxb] + CE * TM[o + 1] + CW * TM[o - 1]);
       }
       const double *TC = a.TCUR[n];
-      double L = 0.5 * (hdiv * tc_k[n] + VTN * TC[o + nxb] - VTS * TC[o - nxb] + UTE * TC[o + 1] - UTW * TC[o - 1]) * tarear;
-      if (k != 1) L = L + dz2rk * wtk * (tc_km1[n] + tc_k[n]);
-      if (k < km) L = L - dz2rk * wtkb * (tc_k[n] + tc_kp1[n]);
+      double L;
+      if (UPW3) {
+        const double FVN = VTN * tarear, FVS = -VTS * tarear, FUE = UTE * tarear, FUW = -UTW * tarear;
+        const double xw2 = TC[o - 2], xw1 = TC[o - 1], xe1 = TC[o + 1], xe2 = TC[o + 2];
+        const double xs2 = TC[o - 2 * (long long)nxb], xs1 = TC[o - nxb], xn1 = TC[o + nxb], xn2 = TC[o + 2 * (long long)nxb];
+        const double te = upw3_face(k, FUE, kmte, kmtw, kmtee, wx0, xw1, tc_k[n], xe1, xe2);
+        const double tew = upw3_face(k, UTW * tarear_w, kEw, kWw, kEEw, wxw, xw2, xw1, tc_k[n], xe1);
+        L = FUE * te + FUW * tew;
+        const double tn = upw3_face(k, FVN, kmtn, kmts, kmtnn, wy0, xs1, tc_k[n], xn1, xn2);
+        const double tns = upw3_face(k, VTS * tarear_s, kNs, kSs, kNNs, wys, xs2, xs1, tc_k[n], xn1);
+        L = L + FVN * tn + FVS * tns;
+        // vertical: flux through the bottom face (:2397-2432)
+        double azminus, dzminus;
+        if (k < kmt - 1) { azminus = a.up.cz[3][k]; dzminus = a.up.cz[5][k]; } else { azminus = a.up.cz[3][k] + a.up.cz[5][k]; dzminus = 0.0; }
+        double auxb = 0.0;
+        if (k <= km - 1) {
+          double tplus = a.up.cz[0][k] * tc_kp1[n] + a.up.cz[1][k] * tc_k[n];
+          if (k > 1) tplus = tplus + a.up.cz[2][k] * tc_km1[n];
+          double tminus = azminus * tc_kp1[n] + a.up.cz[4][k] * tc_k[n];
+          if (k < km - 1) tminus = tminus + dzminus * TC[o + 2 * n2];
+          auxb = (wtkb - fabs(wtkb)) * tplus + (wtkb + fabs(wtkb)) * tminus;
+        }
+        if (k == 1) L = L - dz2rk * auxb;
+        else L = L + dz2rk * (aux[n] - auxb);
+        aux[n] = auxb;
+      } else {
+        L = 0.5 * (hdiv * tc_k[n] + VTN * TC[o + nxb] - VTS * TC[o - nxb] + UTE * TC[o + 1] - UTW * TC[o - 1]) * tarear;
+        if (k != 1) L = L + dz2rk * wtk * (tc_km1[n] + tc_k[n]);
+        if (k < km) L = L - dz2rk * wtkb * (tc_k[n] + tc_kp1[n]);
+      }
       FT = FT - L;
       if (k == 1) vtf[n] = (kmt >= 1) ? a.STF[n][c.q2] : 0.0;
       const double vtfb = (kmt > k) ? a.VDC[n][vdcbase + (long long)k * n2] * (to_k[n] - to_kp1[n]) * dzwrk : 0.0;

@@ -71,6 +71,7 @@ struct pop_ctx {
   pop_exchange_fn xchg = nullptr;
   pop_allreduce_fn allred = nullptr;
   void *comm_user = nullptr;
+  Upw3Dev upw3{};                                          // tadvect = 2
   RcclTransport *rccl_tr = nullptr;                       // in-library RCCL transport (pop_comm_init_rccl)
   // time stepping
   int oldt = 0, curt = 1, newt = 2, mixt = 1;
@@ -479,7 +480,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   c->host_only = (flags & POP_CREATE_HOST_ONLY) != 0;
   if (c->host_only) return 0;
   if (cfg->nt != 2) { c->err = "device kernels are built for nt = 2 (T,S) in this round"; return 1; }
-  if (cfg->tadvect != 1) { c->err = "only centered tracer advection is built in this round"; return 1; }
+  if (cfg->tadvect != 1 && cfg->tadvect != 2) { c->err = "tadvect: 1 (centered) and 2 (upwind3) are built; lw_lim is not"; return 1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { c->err = "no HIP device available; libpop_amd has no CPU fallback"; return 1; }
   HIPCHK(c, hipStreamCreate(&c->stream));
@@ -522,6 +523,15 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     g.DMC = c->d2["d4DMC"]; g.DMN = c->d2["d4DMN"]; g.DMS = c->d2["d4DMS"]; g.DME = c->d2["d4DME"]; g.DMW = c->d2["d4DMW"]; g.DUM = c->d2["d4DUM"];
   }
   if (cfg->hmix_tracer == 4 || cfg->hmix_momentum == 4) { c->mix.D4AMF = c->d2["D4AMF"]; c->mix.D4AHF = c->d2["D4AHF"]; }
+  if (cfg->tadvect == 2) {
+    const char *nx[6] = {"TALFXP", "TBETXP", "TGAMXP", "TALFXM", "TBETXM", "TDELXM"};
+    const char *ny[6] = {"TALFYP", "TBETYP", "TGAMYP", "TALFYM", "TBETYM", "TDELYM"};
+    for (int t = 0; t < 6; ++t) {
+      c->upw3.cx[t] = c->d2[nx[t]]; c->upw3.cy[t] = c->d2[ny[t]];
+      double *p; if (dev_upload(c, &p, h.upw_z[t].data(), h.upw_z[t].size())) return 1;
+      c->upw3.cz[t] = p;
+    }
+  }
 #define GI(f) g.f = c->di2[#f]
   GI(KMT); GI(KMU); GI(KMTN); GI(KMTS); GI(KMTE); GI(KMTW); GI(KMTEE); GI(KMTNN);
 #undef GI
@@ -783,7 +793,10 @@ static int phase_tracer_rhs(pop_ctx *c) {
   if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->S3a; a.TMIX[1] = c->S3b; }   // del4: second Laplacian acts on D2T
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
   a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
-  hipLaunchKernelGGL(k_tracer_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+  if (c->h.c.tadvect == 2) {
+    a.up = c->upw3;
+    hipLaunchKernelGGL((k_tracer_rhs<false, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+  } else hipLaunchKernelGGL((k_tracer_rhs<false, false>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
   return 0;
 }
 static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {

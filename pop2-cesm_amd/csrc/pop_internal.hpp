@@ -54,6 +54,7 @@ struct HostModel {
   std::vector<int> block_local;           // local index of block id-1 on its owner
   // vertical grid, 1-based with slot 0 (dzw(0), dzwr(0))
   std::vector<double> dz, dzw, zt, zw, c2dz, dzr, dz2r, dzwr, pressz, bouss, dt, afac_t, afac_u;
+  std::vector<double> upw_z[6];           // upwind3 vertical weights talfzp,tbetzp,tgamzp,talfzm,tbetzm,tdelzm (1..km)
   // named 2-D / 3-D fields on local blocks
   std::map<std::string, std::vector<double>> f2;   // (nxb,nyb,nblocks)
   std::map<std::string, std::vector<int>> i2;

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from popcfg import named_config  # noqa: E402
 
 FIELDS = [("TRACER", True), ("UVEL", True), ("VVEL", True), ("RHO", True), ("PSURF", False), ("UBTROP", False)]
-NSTEPS = {"const": 4, "kpp_del4": 4}
+NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5}
 
 
 def config(case):
@@ -27,6 +27,8 @@ def config(case):
     if case == "kpp_del4":
         return named_config("tiny", vmix_choice=3, ldbl_diff=1, hmix_momentum=4, hmix_tracer=4, lvariable_hmix=1,
                             am=-1.0e23, ah=-1.0e22, solver_choice=2, **small)
+    if case == "upwind3":     # third-order upwind tracer advection + Richardson vmix
+        return named_config("tiny", tadvect=2, vmix_choice=2, **small)
     raise KeyError(case)
 
 
@@ -51,7 +53,10 @@ def prepare(model, case):
 
 def main():
     from orclib import Oracle
+    only = sys.argv[1:]
     for case in NSTEPS:
+        if only and case not in only:
+            continue
         o = Oracle(config(case))
         prepare(o, case)
         iters = [o.step() for _ in range(NSTEPS[case])]

@@ -133,6 +133,9 @@ def force_kpp_case(gpu, orc):
     ("tiny", {"hmix_momentum": 4, "hmix_tracer": 2, "am": -1.0e22}, 3),                                      # mixed
     ("tiny", {"vmix_choice": 3, "km": 24}, 5),                       # KPP
     ("tiny", {"vmix_choice": 3, "km": 24, "ldbl_diff": 1}, 5),       # KPP + double diffusion (CESM default)
+    ("tiny", {"tadvect": 2}, 5),                                     # third-order upwind tracer advection
+    ("tiny", {"tadvect": 2, "vmix_choice": 3, "km": 24, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21}, 4),
+    ("gx3v7", {"tadvect": 2}, 3),
 ])
 def test_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
     cfg = named_config(name, **kw)

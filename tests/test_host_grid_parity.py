@@ -18,7 +18,8 @@ IFIELDS = ["KMT", "KMU", "KMTN", "KMTS", "KMTE", "KMTW", "KMTEE", "KMTNN"]
 @pytest.mark.parametrize("name,kw", [("tiny", {}), ("test", {}), ("gx3v7", {}), ("tiny", {"lvariable_hmix": 1}),
                                      ("tiny", {"ew_boundary": 0}), ("tiny", {"tmix_opt": 1}),
                                      ("tiny", {"hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1}),
-                                     ("tiny", {"hmix_momentum": 4, "hmix_tracer": 4})])
+                                     ("tiny", {"hmix_momentum": 4, "hmix_tracer": 4}),
+                                     ("tiny", {"tadvect": 2}), ("gx3v7", {"tadvect": 2})])
 def test_host_fields_bit_exact(pkg, orclib_built, name, kw):
     cfg = named_config(name, **kw)
     m = pkg.PopModel(cfg, host_only=True)
@@ -33,6 +34,9 @@ def test_host_fields_bit_exact(pkg, orclib_built, name, kw):
         for f in ("DUC", "DUN", "DUS", "DUE", "DUW", "DMC", "DMN", "DMS", "DME", "DMW", "DUM", "DTN", "DTS", "DTE", "DTW"):
             assert np.array_equal(m.get("d4" + f), o.f2("d4" + f)), "d4" + f
         assert np.array_equal(m.get("D4AMF"), o.f2("D4_AMF")) and np.array_equal(m.get("D4AHF"), o.f2("D4_AHF"))
+    if cfg.tadvect == 2:     # third-order upwind weights (advection.F90:420-562)
+        for f in ("TALFXP", "TBETXP", "TGAMXP", "TALFXM", "TBETXM", "TDELXM", "TALFYP", "TBETYP", "TGAMYP", "TALFYM", "TBETYM", "TDELYM"):
+            assert np.array_equal(m.get(f), o.f2(f)), f
     for n in (0, 1):
         assert np.array_equal(m.get("SMF", 1, n), o.f2("SMF", 1, n))
         assert np.array_equal(m.get("SMFT", 1, n), o.f2("SMFT", 1, n))
