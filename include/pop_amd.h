@@ -104,7 +104,8 @@ int pop_step(pop_ctx *ctx);                      /* step_mod.F90:126      step(e
 
 /* ---- POP_HaloMod / POP_ReductionsMod / POP_SolversMod surface --------------- */
 /* POP_HaloUpdate(array, halo, fieldLoc, fieldKind, errorCode, fillValue)
- * mpi/POP_HaloMod.F90:1732-1773; on a device-resident field */
+ * mpi/POP_HaloMod.F90:1732-1773 (2-D), :2766-3211 (3-D), :4122-4585 (4-D: n = -1 updates every
+ * tracer of a field with a tracer dimension); on a device-resident field */
 int pop_halo_update(pop_ctx *ctx, const char *name, int tl, int n);
 /* host-array variants used at init time and by the unit-test rule of
  * test/unit/halo/POP.F90Dipole (nz = product of trailing dims) */
@@ -113,9 +114,21 @@ int pop_halo_update_host_i4(pop_ctx *ctx, int *array, int nz, int fill);
 /* POP_GlobalSum(array, dist, fieldLoc, errorCode, mMask) mpi/POP_ReductionsMod.F90:144-389
  * (b4b formulation :348-383); mask_name may be NULL */
 int pop_global_sum(pop_ctx *ctx, const char *name, int tl, int n, const char *mask_name, double *result);
+/* the other members of the generic interface (mpi/POP_ReductionsMod.F90:50-64), same b4b rule:
+ *   POP_GlobalSumNfields2DR8 :823-1084, POP_GlobalSumProd2DR8 :1395-1618,
+ *   POP_GlobalSumScalarR8 :1091-1191 (one value per task), POP_GlobalSum2DI4 :621-816 (integer field) */
+int pop_global_sum_nfields(pop_ctx *ctx, int nfields, const char *const *names, const int *tl, const int *n,
+                           const char *mask_name, double *results);
+int pop_global_sum_prod(pop_ctx *ctx, const char *name_a, int tl_a, int n_a, const char *name_b, int tl_b, int n_b,
+                        const char *mask_name, double *result);
+int pop_global_sum_scalar(pop_ctx *ctx, double local_value, double *result);
+int pop_global_sum_i4(pop_ctx *ctx, const char *int_field_name, long long *result);
 /* POP_SolversRun(sfcPressure, rhsClinic, errorCode) POP_SolversMod.F90:327;
  * operates on PSURF(newtime) and RHS in place */
 int pop_solver_run(pop_ctx *ctx);
+/* POP_SolversDiagonal(diagonalCorrection(nx_block,ny_block), blockIndx, errorCode) :1110-1151:
+ * centre weight of local block blockIndx (1-based) = time-independent part - correction (host array) */
+int pop_solver_diagonal(pop_ctx *ctx, int block_local, const double *diagonal_correction);
 /* POP_SolversGetDiagnostics(iterationCount, residual, errorCode) :1158 */
 int pop_solver_get_diagnostics(const pop_ctx *ctx, int *iterations, double *rms_residual);
 /* state(k,kk,TEMPK,SALTK,this_block,RHOOUT,...) state_mod.F90:258 on n device-resident or

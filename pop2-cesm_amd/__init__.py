@@ -56,6 +56,10 @@ def lib():
         "pop_halo_update": (ci, [vp, cs, ci, ci]),
         "pop_halo_update_host_r8": (ci, [vp, pd, ci, cd]), "pop_halo_update_host_i4": (ci, [vp, pi, ci, ci]),
         "pop_global_sum": (ci, [vp, cs, ci, ci, cs, pd]), "pop_solver_run": (ci, [vp]),
+        "pop_global_sum_nfields": (ci, [vp, ci, C.POINTER(cs), pi, pi, cs, pd]),
+        "pop_global_sum_prod": (ci, [vp, cs, ci, ci, cs, ci, ci, cs, pd]),
+        "pop_global_sum_scalar": (ci, [vp, cd, pd]), "pop_global_sum_i4": (ci, [vp, cs, C.POINTER(ll)]),
+        "pop_solver_diagonal": (ci, [vp, ci, pd]),
         "pop_solver_get_diagnostics": (ci, [vp, pi, pd]),
         "pop_state_host": (ci, [vp, ci, pd, pd, pd, pd, pd, ll]),
         "pop_set_comm": (ci, [vp, vp, vp, vp, ll, XCHG_FN, ALLRED_FN, vp]),
@@ -200,6 +204,35 @@ class PopModel:
         r = C.c_double()
         self._chk(self.L.pop_global_sum(self.h, name.encode(), tl, n, mask.encode() if mask else None, C.byref(r)))
         return r.value
+
+    def global_sum_nfields(self, names, tl=1, n=0, mask=None):
+        nf = len(names)
+        arr = (C.c_char_p * nf)(*[x.encode() for x in names])
+        tls, ns = (C.c_int * nf)(*([tl] * nf)), (C.c_int * nf)(*([n] * nf))
+        out = (C.c_double * nf)()
+        self._chk(self.L.pop_global_sum_nfields(self.h, nf, arr, tls, ns, mask.encode() if mask else None, out))
+        return list(out)
+
+    def global_sum_prod(self, a, b, tl_a=1, n_a=0, tl_b=1, n_b=0, mask=None):
+        r = C.c_double()
+        self._chk(self.L.pop_global_sum_prod(self.h, a.encode(), tl_a, n_a, b.encode(), tl_b, n_b,
+                                             mask.encode() if mask else None, C.byref(r)))
+        return r.value
+
+    def global_sum_scalar(self, x):
+        r = C.c_double()
+        self._chk(self.L.pop_global_sum_scalar(self.h, float(x), C.byref(r)))
+        return r.value
+
+    def global_sum_i4(self, name):
+        r = C.c_longlong()
+        self._chk(self.L.pop_global_sum_i4(self.h, name.encode(), C.byref(r)))
+        return r.value
+
+    def solver_diagonal(self, block_local, corr):
+        a = np.ascontiguousarray(corr, dtype=np.float64)
+        assert a.size == self.nxb * self.nyb
+        self._chk(self.L.pop_solver_diagonal(self.h, block_local, a.ctypes.data_as(C.POINTER(C.c_double))))
 
     def solver_run(self):
         self._chk(self.L.pop_solver_run(self.h))

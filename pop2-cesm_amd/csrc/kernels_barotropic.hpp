@@ -208,6 +208,12 @@ k_dot_partial(DevGrid g, const double *__restrict__ A, const double *__restrict_
   wg_reduce_store<1>(v, partial, b * gridDim.x + blockIdx.x);
 }
 
+// POP_SolversDiagonal (POP_SolversMod.F90:1110-1151): centre weight of one block = time-independent part - correction
+__global__ void k_solver_diagonal(const double *__restrict__ WC0, const double *__restrict__ corr, double *__restrict__ C, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) C[p] = WC0[p] - corr[p];
+}
+
 // ---- btropOperator (POP_SolversMod.F90:2414-2426) at one point -----------------------------
 __device__ __forceinline__ double btrop_op(const DevGrid &g, const double *__restrict__ C, const double *__restrict__ X,
                                            long long q, int nxb) {

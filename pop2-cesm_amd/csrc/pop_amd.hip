@@ -953,6 +953,13 @@ int pop_step(pop_ctx *c) {
 int pop_halo_update(pop_ctx *c, const char *name, int tl, int n) {
   if (need_device(c)) return 1;
   double *p; long long cnt;
+  if (n < 0) {   // POP_HaloUpdate4DR8 (mpi/POP_HaloMod.F90:4122-4585): every tracer of a (nx,ny,km,nt,block) field
+    if (std::string(name) != "TRACER" && std::string(name) != "KPP_SRC" && std::string(name) != "STF" && std::string(name) != "TFW") {
+      c->err = std::string("pop_halo_update: field has no tracer dimension: ") + name; return 1;
+    }
+    for (int m = 0; m < c->h.nt; ++m) if (pop_halo_update(c, name, tl, m)) return 1;
+    return 0;
+  }
   if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
   const int nz = (int)(cnt / ((long long)c->g.n2 * c->g.nblocks));
   return halo_update(c, p, nz);
@@ -978,6 +985,72 @@ int pop_global_sum(pop_ctx *c, const char *name, int tl, int n, const char *mask
   SolverScalars s;
   if (read_scalars(c, &s)) return 1;
   *result = s.sum0;
+  return 0;
+}
+// POP_GlobalSumProd2DR8 (mpi/POP_ReductionsMod.F90:1395-1618): sum of A*B[*mask] over the physical domain
+int pop_global_sum_prod(pop_ctx *c, const char *name_a, int tl_a, int n_a, const char *name_b, int tl_b, int n_b,
+                        const char *mask_name, double *result) {
+  if (need_device(c)) return 1;
+  double *pa, *pb, *mk = nullptr; long long cnt;
+  if (resolve(c, name_a, tl_a, n_a, &pa, &cnt)) { c->err = std::string("unknown field ") + name_a; return 1; }
+  if (resolve(c, name_b, tl_b, n_b, &pb, &cnt)) { c->err = std::string("unknown field ") + name_b; return 1; }
+  if (mask_name && resolve(c, mask_name, 0, 0, &mk, &cnt)) { c->err = std::string("unknown mask ") + mask_name; return 1; }
+  hipLaunchKernelGGL(k_dot_partial, grid_2d(c), dim3(POP_RED_THREADS), 0, c->stream, c->g, pa, (const double *)pb, mk, c->partial);
+  if (reduce_finish<1>(c, FIN_PLAIN)) return 1;
+  SolverScalars s;
+  if (read_scalars(c, &s)) return 1;
+  *result = s.sum0;
+  return 0;
+}
+// POP_GlobalSumNfields2DR8 (mpi/POP_ReductionsMod.F90:823-1084): several fields, one result each
+int pop_global_sum_nfields(pop_ctx *c, int nf, const char *const *names, const int *tl, const int *n, const char *mask_name, double *results) {
+  for (int f = 0; f < nf; ++f)
+    if (pop_global_sum(c, names[f], tl ? tl[f] : 1, n ? n[f] : 0, mask_name, results + f)) return 1;
+  return 0;
+}
+// POP_GlobalSumScalarR8 (mpi/POP_ReductionsMod.F90:1091-1191): every rank's value lands in
+// its own slot of a zeroed vector, the vector is all-reduced, and the slots are added in rank order
+int pop_global_sum_scalar(pop_ctx *c, double local, double *result) {
+  const int nr = c->h.nranks;
+  if (nr == 1) { *result = local; return 0; }
+  if (need_device(c)) return 1;
+  if (!c->allred || !c->redbuf || c->red_doubles < nr) { c->err = "pop_global_sum_scalar: multi-rank run without a transport"; return 1; }
+  std::vector<double> v(nr, 0.0);
+  v[c->h.rank] = local;
+  HIPCHK(c, hipMemcpyAsync(c->redbuf, v.data(), sizeof(double) * nr, hipMemcpyHostToDevice, c->stream));
+  if (c->allred(c->comm_user, 0, nr)) { c->err = "pop_global_sum_scalar: allreduce failed"; return 1; }
+  HIPCHK(c, hipMemcpyAsync(v.data(), c->redbuf, sizeof(double) * nr, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double t = 0.0;
+  for (int r = 0; r < nr; ++r) t = t + v[r];
+  *result = t;
+  return 0;
+}
+// POP_GlobalSum2DI4 (mpi/POP_ReductionsMod.F90:621-816): init-time integer fields live
+// on the host; integer addition is exact in any order, ranks are combined through the scalar sum
+int pop_global_sum_i4(pop_ctx *c, const char *name, long long *result) {
+  auto it = c->h.i2.find(name);
+  if (it == c->h.i2.end()) { c->err = std::string("unknown integer field ") + name; return 1; }
+  const HostModel &h = c->h;
+  long long s = 0;
+  for (int lb = 0; lb < h.nblocks; ++lb) {
+    const int *a = it->second.data() + (size_t)(h.local_ids[lb] - 1) * h.n2;
+    for (int j = NGHOST; j < h.nyb - NGHOST; ++j) for (int i = NGHOST; i < h.nxb - NGHOST; ++i) s += a[(size_t)j * h.nxb + i];
+  }
+  double tot = 0.0;
+  if (pop_global_sum_scalar(c, (double)s, &tot)) return 1;
+  *result = (long long)tot;
+  return 0;
+}
+// POP_SolversDiagonal(diagonalCorrection, blockIndx, errorCode) POP_SolversMod.F90:1110-1151
+int pop_solver_diagonal(pop_ctx *c, int block_local, const double *diagonal_correction) {
+  if (need_device(c)) return 1;
+  if (block_local < 1 || block_local > c->h.nblocks) { c->err = "pop_solver_diagonal: block index out of range"; return 1; }
+  const int n = (int)c->h.n2;
+  const size_t off = (size_t)(block_local - 1) * n;
+  HIPCHK(c, hipMemcpyAsync(c->Q + off, diagonal_correction, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));   // Q: solver work array
+  hipLaunchKernelGGL(k_solver_diagonal, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->g.WC0 + off, c->Q + off, c->centerWgt + off, n);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 int pop_state_host(pop_ctx *c, int kk, const double *T, const double *S, double *rho, double *drhodt, double *drhods, long long n) {

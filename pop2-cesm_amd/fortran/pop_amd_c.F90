@@ -163,6 +163,32 @@
          import :: c_int, c_ptr
          type (c_ptr), value :: ctx
       end function
+      integer (c_int) function pop_global_sum_prod(ctx, na, tla, nna, nb, tlb, nnb, mask_name, res) bind(C, name='pop_global_sum_prod')
+         import :: c_int, c_ptr, c_char, c_double
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: na(*), nb(*)
+         integer (c_int), value :: tla, nna, tlb, nnb
+         type (c_ptr), value :: mask_name
+         real (c_double), intent(out) :: res
+      end function
+      integer (c_int) function pop_global_sum_scalar(ctx, x, res) bind(C, name='pop_global_sum_scalar')
+         import :: c_int, c_ptr, c_double
+         type (c_ptr), value :: ctx
+         real (c_double), value :: x
+         real (c_double), intent(out) :: res
+      end function
+      integer (c_int) function pop_global_sum_i4(ctx, name, res) bind(C, name='pop_global_sum_i4')
+         import :: c_int, c_ptr, c_char, c_long_long
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+         integer (c_long_long), intent(out) :: res
+      end function
+      integer (c_int) function pop_solver_diagonal(ctx, block_local, corr) bind(C, name='pop_solver_diagonal')
+         import :: c_int, c_ptr, c_double
+         type (c_ptr), value :: ctx
+         integer (c_int), value :: block_local
+         real (c_double), intent(in) :: corr(*)
+      end function
       ! in-library RCCL transport (include/pop_amd.h)
       integer (c_int) function pop_rccl_unique_id(id128) bind(C, name='pop_rccl_unique_id')
          import :: c_int, c_signed_char

@@ -129,8 +129,30 @@
    use pop_amd_c
    implicit none
    private
-   public :: POP_GlobalSum
+   public :: POP_GlobalSum, POP_GlobalSumProd, POP_GlobalSumScalar, POP_GlobalSumI4
  contains
+   ! mpi/POP_ReductionsMod.F90:1395-1618 (product of two device-resident fields)
+   function POP_GlobalSumProd(name1, timeLevel1, name2, timeLevel2, errorCode) result(globalSum)
+      character (*), intent(in) :: name1, name2
+      integer (POP_i4), intent(in) :: timeLevel1, timeLevel2
+      integer (POP_i4), intent(out) :: errorCode
+      real (POP_r8) :: globalSum
+      errorCode = pop_global_sum_prod(pop_ctx, cstr(name1), timeLevel1, 0, cstr(name2), timeLevel2, 0, c_null_ptr, globalSum)
+   end function
+   ! :1091-1191 (one scalar per task)
+   function POP_GlobalSumScalar(scalar, errorCode) result(globalSum)
+      real (POP_r8), intent(in) :: scalar
+      integer (POP_i4), intent(out) :: errorCode
+      real (POP_r8) :: globalSum
+      errorCode = pop_global_sum_scalar(pop_ctx, scalar, globalSum)
+   end function
+   ! :621-816 (integer field, e.g. KMT)
+   function POP_GlobalSumI4(name, errorCode) result(globalSum)
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(out) :: errorCode
+      integer (c_long_long) :: globalSum
+      errorCode = pop_global_sum_i4(pop_ctx, cstr(name), globalSum)
+   end function
    ! global sum of a device-resident field over the physical domain, optionally times mMask
    function POP_GlobalSum(name, timeLevel, n, errorCode, mMask) result(globalSum)
       character (*), intent(in) :: name
@@ -154,8 +176,15 @@
    use pop_amd_c
    implicit none
    private
-   public :: POP_SolversRun, POP_SolversGetDiagnostics
+   public :: POP_SolversRun, POP_SolversGetDiagnostics, POP_SolversDiagonal
  contains
+   ! POP_SolversMod.F90:1110-1151; diagonalCorrection is a host array (nx_block,ny_block)
+   subroutine POP_SolversDiagonal(diagonalCorrection, blockIndx, errorCode)
+      real (POP_r8), dimension(:,:), intent(in) :: diagonalCorrection
+      integer (POP_i4), intent(in) :: blockIndx
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_solver_diagonal(pop_ctx, blockIndx, diagonalCorrection)
+   end subroutine
    ! operates on PSURF(:,:,newtime,:) and the barotropic RHS, both device resident
    subroutine POP_SolversRun(errorCode)
       integer (POP_i4), intent(out) :: errorCode

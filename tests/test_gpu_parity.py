@@ -215,6 +215,15 @@ def test_halo_update_rule_on_device(pkg):
             a3[b, k, 2:-2, 2:-2] = g[2:-2, 2:-2] + 1000.0 * k
     gpu.set("PSURF", a2, tl=2); gpu.halo_update("PSURF", tl=2)
     assert np.array_equal(gpu.get("PSURF", tl=2), exp2)
+    for n in (0, 1):   # 4-D update: all tracers in one call
+        gpu.set("TRACER", a3 + 7.0 * n, tl=2, n=n)
+    gpu.halo_update("TRACER", tl=2, n=-1)
+    for n in (0, 1):
+        got = gpu.get("TRACER", tl=2, n=n)
+        for k in range(km):
+            e = np.where(exp2 != 0, exp2 + 1000.0 * k + 7.0 * n, 0.0)
+            e[:, 2:-2, 2:-2] = exp2[:, 2:-2, 2:-2] + 1000.0 * k + 7.0 * n
+            assert np.array_equal(got[:, k], e), (n, k)
     gpu.set("UVEL", a3, tl=2); gpu.halo_update("UVEL", tl=2)
     got = gpu.get("UVEL", tl=2)
     for k in range(km):
@@ -237,6 +246,37 @@ def test_global_sum_matches_serial_rule(pkg, orclib_built):
     got = gpu.global_sum("RHS"); assert abs(got - ref_nomask) <= 1e-12 * np.abs(interior(a)).sum()
     got = gpu.global_sum("RHS", mask="mMask")
     assert abs(got - (interior(a) * interior(mask)).sum()) <= 1e-12 * np.abs(interior(a)).sum()
+    gpu.close(); orc.close()
+
+
+def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
+    """The other members of the POP_GlobalSum interface (NFields, Prod, Scalar, 2DI4;
+    mpi/POP_ReductionsMod.F90:50-64) and POP_SolversDiagonal (POP_SolversMod.F90:1110-1151)."""
+    cfg = named_config("tiny")
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((gpu.nblocks, gpu.nyb, gpu.nxb)) * 1e2
+    b = rng.standard_normal((gpu.nblocks, gpu.nyb, gpu.nxb))
+    gpu.set("RHS", a); gpu.set("PSURF", b, tl=2)
+    mask = interior(orc.f2("mMask"))
+    scale = np.abs(interior(a)).sum()
+    s1, s2 = gpu.global_sum_nfields(["RHS", "TAREA"], mask="mMask")
+    assert s1 == gpu.global_sum("RHS", mask="mMask") and s2 == gpu.global_sum("TAREA", mask="mMask")
+    got = gpu.global_sum_prod("RHS", "PSURF", tl_b=2, mask="mMask")
+    assert abs(got - (interior(a) * interior(b) * mask).sum()) <= 1e-12 * scale
+    got = gpu.global_sum_prod("RHS", "PSURF", tl_b=2)
+    assert abs(got - (interior(a) * interior(b)).sum()) <= 1e-12 * scale
+    assert gpu.global_sum_scalar(3.25) == 3.25
+    assert gpu.global_sum_i4("KMT") == int(interior(orc.i2("KMT")).sum())
+    # operator diagonal of block 2 <- independent part - correction
+    corr = rng.standard_normal((gpu.nyb, gpu.nxb))
+    before = gpu.get("centerWgt").copy()
+    gpu.solver_diagonal(2, corr)
+    after = gpu.get("centerWgt")
+    assert np.array_equal(after[1], gpu.get("centerWgtIndep")[1] - corr)
+    assert np.array_equal(after[0], before[0]) and np.array_equal(after[2:], before[2:])
+    with pytest.raises(pkg.PopError):
+        gpu.solver_diagonal(gpu.nblocks + 1, corr)
     gpu.close(); orc.close()
 
 
