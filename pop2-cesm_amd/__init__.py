@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libpop_amd.so")
+_SO = os.environ.get("POP_AMD_LIB") or os.path.join(_HERE, "libpop_amd.so")   # POP_AMD_LIB: build-variant experiments
 POP_CREATE_HOST_ONLY = 1
 
 XCHG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong),

@@ -106,7 +106,7 @@ struct TracerRhsArgs {
 // this thread (same operands, same order as the neighbour's own evaluation), the flux through the
 // top face (AUX) is carried in a register, and four tracer levels k-1..k+2 are kept in registers.
 template <bool DEL4, bool UPW3>
-__global__ void __launch_bounds__(POP_STENCIL_MAX_THREADS)
+__global__ void __launch_bounds__(POP_COL_THREADS, POP_TRC_WAVES)
 k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
   Col c;
   if (!col_setup(g, c, true)) return;
@@ -329,7 +329,7 @@ struct MomentumRhsArgs {
 };
 
 template <bool DEL4>
-__global__ void __launch_bounds__(POP_STENCIL_MAX_THREADS)
+__global__ void __launch_bounds__(POP_COL_THREADS, POP_MOM_WAVES)
 k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
   Col c;
   if (!col_setup(g, c, true)) return;

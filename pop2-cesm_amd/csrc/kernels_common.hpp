@@ -5,7 +5,13 @@
 namespace pop {
 
 #define POP_COL_THREADS 64   // one wavefront per workgroup for column-march kernels
-#define POP_STENCIL_MAX_THREADS 512   // stencil column kernels: up to 64 x 8 rows per workgroup
+// waves per SIMD the stencil column kernels are compiled for (second __launch_bounds__ argument)
+#ifndef POP_TRC_WAVES
+#define POP_TRC_WAVES 3
+#endif
+#ifndef POP_MOM_WAVES
+#define POP_MOM_WAVES 2
+#endif
 
 // Column-kernel prologue: one thread per (i,j) of local block b; returns false for threads
 // outside the physical domain ib..ie, jb..je (or outside the block).

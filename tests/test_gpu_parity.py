@@ -249,6 +249,25 @@ def test_global_sum_matches_serial_rule(pkg, orclib_built):
     gpu.close(); orc.close()
 
 
+@pytest.mark.parametrize("kw", [{}, {"vmix_choice": 3, "km": 24, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21},
+                                {"block_size_x": 48, "block_size_y": 40}])
+def test_momentum_kernels_agree_bitwise(pkg, monkeypatch, kw):
+    """The LDS-tiled momentum kernel (default, 64x8 tiles), its 64x4 form and the direct-load kernel
+    evaluate the same expressions in the same order: results must be identical to the last bit."""
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for rows in ("8", "4", "0"):
+        monkeypatch.setenv("POP_MOMENTUM_LDS", rows)
+        m = pkg.PopModel(cfg)
+        for _ in range(3):
+            m.step()
+        out[rows] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF")]
+        m.close()
+    for rows in ("4", "0"):
+        for a, b in zip(out["8"], out[rows]):
+            assert np.array_equal(a, b), rows
+
+
 def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
     """The other members of the POP_GlobalSum interface (NFields, Prod, Scalar, 2DI4;
     mpi/POP_ReductionsMod.F90:50-64) and POP_SolversDiagonal (POP_SolversMod.F90:1110-1151)."""
