@@ -107,6 +107,29 @@ __device__ __forceinline__ MwjfP mwjf_level(double pbar) {
   c.d3 = 3.68390573e-7 + (p * p) * -3.03175128e-16;
   return c;
 }
+// the pressure-independent part of an evaluation (clamped T, S*1000 and its square root) and the rest;
+// mwjf_eval(c, prep) == mwjf_rho<false>(c, T, S) bit for bit (same operations in the same order)
+struct MwjfTS { double TQ, SQ, SQR; };
+__device__ __forceinline__ MwjfTS mwjf_prep(double TK, double SK) {
+  MwjfTS r;
+  r.TQ = fmin(TK, 999.0); r.TQ = fmax(r.TQ, -2.0);
+  double SQ = fmin(SK, 0.999); SQ = fmax(SQ, 0.0);
+  r.SQ = 1000.0 * SQ;
+  r.SQR = sqrt(r.SQ);
+  return r;
+}
+__device__ __forceinline__ double mwjf_eval(const MwjfP &c, const MwjfTS &x) {
+  const double n1 = 7.35212840e+0 * 0.001, n3 = 3.98476704e-4 * 0.001;
+  const double ns1t1 = -7.23268813e-3 * 0.001, ns2t0 = 2.12382341e-3 * 0.001;
+  const double d2 = -4.60835542e-5, d4 = 1.80809186e-10, ds1t0 = 2.14691708e-3, ds1t1 = -9.27062484e-6;
+  const double ds1t3 = -1.78343643e-10, dsqt0 = 4.76534122e-6, dsqt2 = 1.63410736e-9;
+  const double TQ = x.TQ, SQ = x.SQ, SQR = x.SQR;
+  const double W1 = c.n0 + TQ * (n1 + TQ * (c.n2 + n3 * TQ)) + SQ * (c.ns1t0 + ns1t1 * TQ + ns2t0 * SQ);
+  const double W2 = c.d0 + TQ * (c.d1 + TQ * (d2 + TQ * (c.d3 + d4 * TQ))) +
+                    SQ * (ds1t0 + TQ * (ds1t1 + TQ * TQ * ds1t3) + SQR * (dsqt0 + TQ * TQ * dsqt2));
+  const double DEN = 1.0 / W2;
+  return W1 * DEN;
+}
 template <bool DERIV>
 __device__ __forceinline__ double mwjf_rho(const MwjfP &c, double TK, double SK, double *drdt, double *drds) {
   const double n1 = 7.35212840e+0 * 0.001, n3 = 3.98476704e-4 * 0.001;

@@ -72,7 +72,15 @@ k_kpp_buoydiff(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
   double rhoavg = mwjf_rho<false>(P, tmask(T[orf]), S[orf], nullptr, nullptr);
   if (kref != 1) {
     rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
-    for (int kt = 1; kt <= kref - 1; ++kt) {
+    int kt = 1;
+    for (; kt + 3 <= kref - 1; kt += 4) {      // loads of 4 levels in flight, same order of additions
+      double tt[4], ss[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { const long long ot = base3 + (long long)(kt + t - 1) * n2; tt[t] = T[ot]; ss[t] = S[ot]; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) rhoavg = rhoavg + g.dz[kt + t] * mwjf_rho<false>(P, tmask(tt[t]), ss[t], nullptr, nullptr);
+    }
+    for (; kt <= kref - 1; ++kt) {
       const long long ot = base3 + (long long)(kt - 1) * n2;
       rhoavg = rhoavg + g.dz[kt] * mwjf_rho<false>(P, tmask(T[ot]), S[ot], nullptr, nullptr);
     }
@@ -84,6 +92,97 @@ k_kpp_buoydiff(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
   DBSFC[o] = dbs;
   DBLOC[o - n2] = dbl;
   if (k == km) DBLOC[o] = 0.0;
+}
+
+// ---- buoydiff, column form for bandwidth-bound grids ------------------------------------------
+// The 3-D-parallel kernel re-reads the top kref levels of T and S for every level (66 GB through the
+// fabric at tx0.1v3 for 17 GB of algorithmic traffic) and repeats the pressure-independent half of
+// every equation-of-state evaluation.  Here one thread owns a column: the clamped T, 1000*S and its
+// square root of the top KR levels sit in registers (KR >= max kref, checked by the host), every
+// field is read once, and only the pressure-dependent polynomials are re-evaluated.  Same operations
+// in the same order as k_kpp_buoydiff.
+template <int KR>
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_buoydiff_col(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
+                   double *__restrict__ DBLOC, double *__restrict__ DBSFC) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int km = g.km;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  MwjfTS top[KR + 1];
+#pragma unroll
+  for (int t = 1; t <= KR; ++t) {
+    const int kk = (t <= km) ? t : km;
+    const long long o = c.base3 + (long long)(kk - 1) * n2;
+    top[t] = mwjf_prep(tmask(T[o]), S[o]);
+  }
+  DBSFC[c.base3] = 0.0;
+  MwjfTS xkm = top[1];
+  for (int k = 2; k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    const MwjfTS xk = mwjf_prep(tmask(T[o]), S[o]);
+    const MwjfP P = mwjf_level(g.pressz[k]);
+    const double rhokm = mwjf_eval(P, xkm);
+    const double rhok = mwjf_eval(P, xk);
+    const double surfthick = KPP_EPSSFC * g.zt[k];
+    const int kref = kp.kref[k];
+    MwjfTS xr = top[1];
+#pragma unroll
+    for (int t = 2; t <= KR; ++t) if (t == kref) xr = top[t];
+    double rhoavg = mwjf_eval(P, xr);
+    if (kref != 1) {
+      rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
+#pragma unroll
+      for (int kt = 1; kt <= KR - 1; ++kt)
+        if (kt <= kref - 1) rhoavg = rhoavg + g.dz[kt] * mwjf_eval(P, top[kt]);
+      rhoavg = rhoavg / surfthick;
+    }
+    double dbs = 0.0, dbl = 0.0;
+    if (rhok != 0.0) { dbs = GRAV * (1.0 - rhoavg / rhok); dbl = GRAV * (1.0 - rhokm / rhok); }
+    if (k - 1 >= kmt) dbl = 0.0;
+    DBSFC[o] = dbs;
+    DBLOC[o - n2] = dbl;
+    if (k == km) DBLOC[o] = 0.0;
+    xkm = xk;
+  }
+}
+
+// ---- bldepth part 1, column form: U, V of the top KR levels in registers, each level read once ----
+template <int KR>
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_ushear_col(DevGrid g, KppDev kp, const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ WU) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int km = g.km;
+  const long long n2 = g.n2;
+  double ur[KR + 1], vr[KR + 1];
+#pragma unroll
+  for (int t = 1; t <= KR; ++t) {
+    const int kk = (t <= km) ? t : km;
+    const long long o = c.base3 + (long long)(kk - 1) * n2;
+    ur[t] = U[o]; vr[t] = V[o];
+  }
+  for (int kl = 2; kl <= km; ++kl) {
+    const long long o = c.base3 + (long long)(kl - 1) * n2;
+    const double ukl = U[o], vkl = V[o];
+    const double surfthick = KPP_EPSSFC * g.zt[kl];
+    const int kref = kp.kref[kl];
+    double uref, vref;
+    if (kref > 1) {
+      double uk = ur[1], vk = vr[1];
+#pragma unroll
+      for (int t = 2; t <= KR; ++t) if (t == kref) { uk = ur[t]; vk = vr[t]; }
+      uref = uk * (surfthick - g.zw[kref - 1]);
+      vref = vk * (surfthick - g.zw[kref - 1]);
+#pragma unroll
+      for (int kt = 1; kt <= KR - 1; ++kt)
+        if (kt <= kref - 1) { uref = uref + g.dz[kt] * ur[kt]; vref = vref + g.dz[kt] * vr[kt]; }
+      uref = uref / surfthick; vref = vref / surfthick;
+    } else { uref = ur[1]; vref = vr[1]; }
+    const double du = uref - ukl, dv = vref - vkl;
+    WU[o] = du * du + dv * dv;
+  }
 }
 
 // ---- ri_iwmix + ddmix: interior coefficients -----------------------------------------------
@@ -194,7 +293,17 @@ k_kpp_ushear(DevGrid g, KppDev kp, const double *__restrict__ U, const double *_
     const long long orf = base3 + (long long)(kref - 1) * n2;
     uref = U[orf] * (surfthick - g.zw[kref - 1]);
     vref = V[orf] * (surfthick - g.zw[kref - 1]);
-    for (int kt = 1; kt <= kref - 1; ++kt) {
+    // same left-to-right sum; the loads of 8 levels are issued before their adds (the chain otherwise
+    // pays one L2 round trip per level)
+    int kt = 1;
+    for (; kt + 7 <= kref - 1; kt += 8) {
+      double uu[8], vv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const long long ot = base3 + (long long)(kt + t - 1) * n2; uu[t] = U[ot]; vv[t] = V[ot]; }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { uref = uref + g.dz[kt + t] * uu[t]; vref = vref + g.dz[kt + t] * vv[t]; }
+    }
+    for (; kt <= kref - 1; ++kt) {
       const long long ot = base3 + (long long)(kt - 1) * n2;
       uref = uref + g.dz[kt] * U[ot];
       vref = vref + g.dz[kt] * V[ot];
@@ -395,7 +504,9 @@ __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static KppDev g_kpp;   // one model per process (one process per GPU)
+// per-context KPP state (MixDev::kpp)
+struct KppHost { KppDev dev; int max_kref = 1; int col = 0; };   // col: bit 0 = ushear, bit 1 = buoydiff in column form
+inline void kpp_destroy(MixDev &m) { delete (KppHost *)m.kpp; m.kpp = nullptr; }
 
 inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<void *> &allocs, std::string &err) {
   const pop_config &c = h.c;
@@ -419,7 +530,9 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
     allocs.push_back(*dst);
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess ? 1 : 0;
   };
-  KppDev &k = g_kpp;
+  KppHost *K = new KppHost();
+  m.kpp = K;
+  KppDev &k = K->dev;
   void *p;
   if (up(zgrid.data(), zgrid.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.zgrid = (double *)p;
   if (up(hwide.data(), hwide.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.hwide = (double *)p;
@@ -437,18 +550,31 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   k.Vtc = std::sqrt(0.2 / KPP_C_S / KPP_EPSSFC) / (KPP_VONKAR * KPP_VONKAR);
   k.cg = KPP_CSTAR * KPP_VONKAR * std::pow(KPP_C_S * KPP_VONKAR * KPP_EPSSFC, 1.0 / 3.0);
   k.rich_mix = c.kpp_rich_mix; k.lrich = c.lrich; k.ldbl_diff = c.ldbl_diff; k.nsmooth = c.num_v_smooth_Ri;
+  K->max_kref = 1;
+  for (int kk = 1; kk <= km; ++kk) K->max_kref = std::max(K->max_kref, kref[kk]);
+  // column (register) forms: bandwidth-bound grids only -- below ~2^19 columns the 3-D-parallel forms win on
+  // parallelism.  Measured at tx0.1v3: ushear 11.2 -> 2.7 ms; buoydiff 15.5 -> 16.3 ms (its 3 x 24 register
+  // doubles leave one wave per SIMD for a VALU-bound kernel), so only ushear switches by default.
+  // POP_KPP_COL = bit mask (1 ushear, 2 buoydiff) overrides.
+  K->col = ((h.n2 * h.nblocks > (1u << 19)) && K->max_kref <= 24) ? 1 : 0;
+  if (getenv("POP_KPP_COL")) K->col = (K->max_kref <= 24) ? atoi(getenv("POP_KPP_COL")) : 0;
   (void)g; (void)m;
   return 0;
 }
 
-inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParams &sp, const MixDev &, const MixState &s,
+inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParams &sp, const MixDev &m, const MixState &s,
                            hipStream_t st, std::string &err) {
+  const KppHost &KH = *(const KppHost *)m.kpp;
+  const KppDev &g_kpp = KH.dev;
+  const int g_kpp_col = KH.col;
   const dim3 GC(col_grid(g, POP_COL_THREADS), g.nblocks), BC(POP_COL_THREADS);
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);
   double *DBLOC = s.S3a, *DBSFC = s.S3b, *WU = s.S3c, *VISC = s.S3d, *RIW = s.E3;
-  hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  if (g_kpp_col & 2) hipLaunchKernelGGL(k_kpp_buoydiff_col<24>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  else hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
-  hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
+  if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
+  else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
   hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                      (const double *)DBSFC, (const double *)WU);
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],

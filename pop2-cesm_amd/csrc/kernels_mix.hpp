@@ -11,6 +11,7 @@ struct MixDev {          // device-resident constants of the mixing schemes
   const double *d4DTN = nullptr, *d4DTS = nullptr, *d4DTE = nullptr, *d4DTW = nullptr;
   const double *d4DUC = nullptr, *d4DUN = nullptr, *d4DUS = nullptr, *d4DUE = nullptr, *d4DUW = nullptr;
   const double *d4DMC = nullptr, *d4DMN = nullptr, *d4DMS = nullptr, *d4DME = nullptr, *d4DMW = nullptr, *d4DUM = nullptr;
+  void *kpp = nullptr;     // KppHost (kernels_kpp.hpp), owned by the context
 };
 struct MixState {        // per-step field pointers handed to the mixing kernels
   const double *TMIX[2], *UMIX, *VMIX, *UCUR, *VCUR, *RHOMIX, *STF[2], *SHF_QSW;

@@ -636,6 +636,7 @@ int pop_destroy(pop_ctx *c) {
     if (c->rccl_tr->comm) rccl().CommDestroy(c->rccl_tr->comm);
     delete c->rccl_tr;
   }
+  kpp_destroy(c->mix);
   for (void *p : c->allocs) hipFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;

@@ -268,6 +268,26 @@ def test_momentum_kernels_agree_bitwise(pkg, monkeypatch, kw):
             assert np.array_equal(a, b), rows
 
 
+@pytest.mark.parametrize("kw", [{"vmix_choice": 3, "km": 24}, {"vmix_choice": 3, "km": 24, "ldbl_diff": 1, "block_size_x": 48, "block_size_y": 40}])
+def test_kpp_column_kernels_agree_bitwise(pkg, orclib_built, monkeypatch, kw):
+    """buoydiff / ushear exist in a 3-D-parallel form (small grids) and a column form with the top
+    reference levels in registers (large grids; POP_KPP_COL is a bit mask that forces either): same operations in the same
+    order, so every output of the step must be identical to the last bit."""
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for mode in ("3", "0"):
+        monkeypatch.setenv("POP_KPP_COL", mode)
+        m, orc = pkg.PopModel(cfg), Oracle(cfg)
+        force_kpp_case(m, orc)
+        orc.close()
+        for _ in range(3):
+            m.step()
+        out[mode] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "VVC", "HBLT")]
+        m.close()
+    for a, b in zip(out["3"], out["0"]):
+        assert np.array_equal(a, b)
+
+
 def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
     """The other members of the POP_GlobalSum interface (NFields, Prod, Scalar, 2DI4;
     mpi/POP_ReductionsMod.F90:50-64) and POP_SolversDiagonal (POP_SolversMod.F90:1110-1151)."""
