@@ -43,7 +43,8 @@ typedef struct pop_config {
   int solver_choice;          /* 1 pcg, 2 ChronGear     (POP_SolversMod.F90:442-472) */
   int max_iterations;
   int convergence_check_freq;
-  int tmix_opt;               /* 0 none, 1 avg, 2 avgfit (time_management.F90:2170-2213) */
+  int tmix_opt;               /* 0 none, 1 avg, 2 avgfit (time_management.F90:2170-2213), 3 robert
+                               * (Robert-Asselin-Williams filter, step_mod.F90:919-1350) */
   int time_mix_freq;
   int steps_per_day;          /* dt_option='steps_per_day', dt_count */
   int lbouss_correct, lpressure_avg, impcor, reset_to_freezing;
@@ -56,7 +57,9 @@ typedef struct pop_config {
   double bckgrnd_vdc1, bckgrnd_vdc2, bckgrnd_vdc_dpth, bckgrnd_vdc_linv;
   double Prandtl, kpp_rich_mix;
   double convergence_criterion;
-  double reserved_d[8];       /* [0] = amplitude of the synthetic initial T perturbation */
+  double reserved_d[8];       /* [0] = amplitude of the synthetic initial T perturbation;
+                               * [1], [2] = robert_alpha, robert_nu for tmix_opt = 3 (0 = defaults 0.53, 0.20,
+                               * time_management.F90:461-462) */
 } pop_config;
 
 typedef struct pop_ctx pop_ctx;

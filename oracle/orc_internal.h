@@ -49,6 +49,7 @@ struct orc_model {
   void *kpp;
   void *del4;
   void *upw3;
+  void *rf;
 };
 
 extern const double orc_grav, orc_omega, orc_radius;

@@ -513,6 +513,32 @@ int host_build(HostModel &h) {
   h.dtu = h.dtt; h.dtp = h.dtt;
   for (int k = 1; k <= h.km; ++k) h.dt[k] = h.dtt * 1.0;
 
+  // ---------------- Robert filter coefficients, budget areas and volumes ----------------
+  // time_management.F90:897-945; step_mod.F90:1577-1615 (MASK_TRBUDGET = KMT >= k; without region masks the
+  // open-ocean mask is KMT >= k .and. RCALCT > 0, grid.F90:1112-1121)
+  if (c.tmix_opt == 3) {
+    double alpha = c.reserved_d[1], nu = c.reserved_d[2];
+    if (alpha == 0.0) alpha = 0.53;
+    if (nu == 0.0) nu = 0.20;
+    h.robert_curtime = 0.5 * nu * alpha;
+    h.robert_newtime = 0.5 * nu * (alpha - 1.0);
+    h.rf_nonzero_newtime = !(h.robert_newtime == 0.0);
+    if (h.rf_nonzero_newtime && std::fabs(alpha - 1.0) <= 1.0e-6) { h.robert_curtime = 0.5 * nu; h.robert_newtime = 0.0; h.rf_nonzero_newtime = 0; }
+    std::vector<double> mask(A2);
+    const std::vector<int> &KMTi = h.i2["KMT"];
+    const std::vector<double> &RC = h.f2["RCALCT"];
+    for (int k = 1; k <= h.km; ++k) {
+      for (size_t p = 0; p < A2; ++p) mask[p] = (KMTi[p] >= k) ? 1.0 : 0.0;
+      const double bg = host_global_sum(h, TAREA.data(), mask.data());
+      if (k == 1) h.bgtarea_t_1 = bg;
+      const double rfthick = bg * h.dz[k];
+      if (k >= 2) h.rf_volume_2_km = h.rf_volume_2_km + rfthick;
+      for (size_t p = 0; p < A2; ++p) mask[p] = (KMTi[p] >= k && RC[p] > 0.0) ? 1.0 : 0.0;
+      const double oo = host_global_sum(h, TAREA.data(), mask.data());
+      if (k >= 2) h.open_ocean_volume_2_km = h.open_ocean_volume_2_km + oo * h.dz[k];
+    }
+  }
+
   // ---------------- analytic wind stress ----------------
   auto &SMFX = newf("SMF1"), &SMFY = newf("SMF2"), &SMFTX = newf("SMFT1"), &SMFTY = newf("SMFT2");
   for (size_t p = 0; p < A2; ++p) {

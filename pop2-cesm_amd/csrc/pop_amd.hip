@@ -10,6 +10,7 @@
 #include "kernels_mix.hpp"
 #include "kernels_thomas_reg.hpp"
 #include "kernels_momentum_lds.hpp"
+#include "kernels_rf.hpp"
 #include "rccl_transport.hpp"
 
 using namespace pop;
@@ -73,6 +74,7 @@ struct pop_ctx {
   pop_exchange_fn xchg = nullptr;
   pop_allreduce_fn allred = nullptr;
   void *comm_user = nullptr;
+  double rf_S[MAXNT] = {}, rf_S_prev[MAXNT] = {}; bool rf_S_prev_valid[MAXNT] = {};   // Robert filter
   Upw3Dev upw3{};                                          // tadvect = 2
   RcclTransport *rccl_tr = nullptr;                       // in-library RCCL transport (pop_comm_init_rccl)
   // time stepping
@@ -677,6 +679,13 @@ double pop_get_scalar(const pop_ctx *c, const char *name) {
   if (n == "rconst") return c->h.rconst;
   if (n == "uarea_equator") return c->h.uarea_equator;
   if (n == "rmsResidual") return c->rmsResidual;
+  if (n == "robert_curtime") return c->h.robert_curtime;
+  if (n == "robert_newtime") return c->h.robert_newtime;
+  if (n == "rf_volume_2_km") return c->h.rf_volume_2_km;
+  if (n == "open_ocean_volume_2_km") return c->h.open_ocean_volume_2_km;
+  if (n == "bgtarea_t_1") return c->h.bgtarea_t_1;
+  if (n == "rf_S1") return c->rf_S[0];
+  if (n == "rf_S2") return c->rf_S[1];
   return NAN;
 }
 int pop_get_block(const pop_ctx *c, int block_id, int *out8, int *i_glob, int *j_glob) {
@@ -918,6 +927,67 @@ int pop_baroclinic_correct_adjust(pop_ctx *c) {
   return 0;
 }
 
+// b4b global sum of a device array (physical domain) times an optional mask; result on the host
+static int global_sum_dev(pop_ctx *c, const double *p, const double *mask, double *result) {
+  hipLaunchKernelGGL(k_dot_partial, grid_2d(c), dim3(POP_RED_THREADS), 0, c->stream, c->g, p, (const double *)nullptr, mask, c->partial);
+  if (reduce_finish<1>(c, FIN_PLAIN)) return 1;
+  SolverScalars s;
+  if (read_scalars(c, &s)) return 1;
+  *result = s.sum0;
+  return 0;
+}
+
+// step_RF (step_mod.F90:919-1350): Robert-Asselin-Williams filter of curtime (and newtime) with the
+// volume-conserving adjustment of PSURF and the tracers, then the leapfrog index rotation
+static int step_rf(pop_ctx *c) {
+  const HostModel &h = c->h;
+  const int o = c->oldt, cu = c->curt, nw = c->newt, nt = h.nt;
+  const long long a2 = (long long)c->g.n2 * c->g.nblocks, a3 = (long long)c->g.n3 * c->g.nblocks;
+  RfParams p{h.robert_newtime, h.robert_curtime, h.rf_nonzero_newtime, h.dz[1], GRAV};
+  auto filt = [&](double *const F[3], long long n) {
+    hipLaunchKernelGGL(k_rf_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, (const double *)F[o], F[cu], F[nw], p);
+  };
+  filt(c->UB, a2); filt(c->VB, a2); filt(c->GX, a2); filt(c->GY, a2); filt(c->U, a3); filt(c->V, a3);
+  double *WORKN[2] = {c->W3, c->W4}, *WB = c->UH;          // 2-D work arrays free at this point of the step
+  RfTracerArgs ta{};
+  RfSurfArgs sa{};
+  for (int n = 0; n < 2; ++n) {
+    ta.TO[n] = c->TR[n][o]; ta.TC[n] = c->TR[n][cu]; ta.TN[n] = c->TR[n][nw]; ta.WORKN[n] = WORKN[n];
+    sa.TO[n] = c->TR[n][o]; sa.TC[n] = c->TR[n][cu]; sa.TN[n] = c->TR[n][nw]; sa.WORKN[n] = WORKN[n];
+  }
+  sa.PO = c->PS[o]; sa.PC = c->PS[cu]; sa.PN = c->PS[nw];
+  const dim3 GC = grid_cols(c);
+  hipLaunchKernelGGL(k_rf_tracer_interior, dim3(GC.x, GC.y, nt), dim3(POP_COL_THREADS), 0, c->stream, c->g, p, ta);
+  double svol[MAXNT] = {};
+  for (int n = 0; n < nt; ++n) if (global_sum_dev(c, WORKN[n], nullptr, &svol[n])) return 1;
+  hipLaunchKernelGGL(k_rf_surface, dim3((unsigned)((a2 + 255) / 256), nt), dim3(256), 0, c->stream, c->g, p, sa);
+  for (int n = 0; n < nt; ++n) { double s1; if (global_sum_dev(c, WORKN[n], nullptr, &s1)) return 1; svol[n] = svol[n] + s1; }
+  hipLaunchKernelGGL(k_rf_psurf, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, c->g, p, (const double *)c->PS[o], c->PS[cu], c->PS[nw], WB);
+  double rf_sump;
+  if (global_sum_dev(c, WB, c->g.CONSTNT, &rf_sump)) return 1;      // MASK_TRBUDGET(:,:,1) = (KMT >= 1) = CONSTNT
+  rf_sump = rf_sump / h.bgtarea_t_1;
+  hipLaunchKernelGGL(k_rf_psurf_adjust, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, c->g, p, rf_sump, c->PS[cu], c->PS[nw],
+                     c->TR[0][cu], c->TR[0][nw], c->TR[1][cu], c->TR[1][nw], WB);
+  double vsurf, vsurf_oo;
+  if (global_sum_dev(c, WB, c->g.CONSTNT, &vsurf) || global_sum_dev(c, WB, c->g.RCALCT, &vsurf_oo)) return 1;
+  const double rf_ocean_norm = h.open_ocean_volume_2_km + vsurf_oo;   // fully coupled normalisation (:1166-1172)
+  (void)vsurf;
+  for (int n = 0; n < nt; ++n) {
+    c->rf_S[n] = svol[n] / rf_ocean_norm;
+    const double factor = (!c->rf_S_prev_valid[n] || h.rf_nonzero_newtime) ? c->rf_S[n] : 0.5 * (c->rf_S[n] + c->rf_S_prev[n]);
+    hipLaunchKernelGGL(k_rf_conserve, grid_3d(c), dim3(256), 0, c->stream, c->g, p, factor * h.robert_newtime, factor * h.robert_curtime,
+                       c->TR[n][cu], c->TR[n][nw]);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->FW_OLD, c->FW, a2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, (const double *)c->TR[0][cu], (const double *)c->TR[1][cu], c->RHO[cu]);
+  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, (const double *)c->TR[0][nw], (const double *)c->TR[1][nw], c->RHO[nw]);
+  hipLaunchKernelGGL(k_pguess, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, a2, c->PGUESS, c->PS[nw], c->PS[cu], c->PS[o]);
+  c->oldt = cu; c->curt = nw; c->newt = o;                              // step_mod.F90:1318-1322
+  if (!h.rf_nonzero_newtime) for (int n = 0; n < nt; ++n) { c->rf_S_prev[n] = c->rf_S[n]; c->rf_S_prev_valid[n] = true; }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
 int pop_step_tail(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "3D-UPDATE");
@@ -941,6 +1011,8 @@ int pop_step_tail(pop_ctx *c) {
     b.UO = c->U[o]; b.UC = c->U[cu]; b.VO = c->V[o]; b.VC = c->V[cu]; b.RO = c->RHO[o]; b.RC = c->RHO[cu]; b.UN = c->U[nw]; b.VN = c->V[nw];
     for (int n = 0; n < 2; ++n) { b.TO[n] = c->TR[n][o]; b.TC[n] = c->TR[n][cu]; b.TN[n] = c->TR[n][nw]; }
     hipLaunchKernelGGL(k_avg3d, grid_3d(c), dim3(256), 0, c->stream, c->g, b);
+  } else if (c->h.c.tmix_opt == 3) {                                   // step_mod.F90:798-802
+    if (step_rf(c)) return 1;
   } else {
     HIPCHK(c, hipMemcpyAsync(c->FW_OLD, c->FW, a2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     const int tmp = c->oldt; c->oldt = c->curt; c->curt = c->newt; c->newt = tmp;   // step_mod.F90:827-830

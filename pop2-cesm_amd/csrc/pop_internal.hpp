@@ -62,6 +62,9 @@ struct HostModel {
   double uarea_equator = 0, residualNorm = 0, convergenceCriterion = 0, rcheck = 0, rconst = 0;
   double dtt = 0, dtu = 0, dtp = 0;
   int nsteps_per_interval = 0;
+  // Robert filter (tmix_opt = 3): time_management.F90:897-945, step_mod.F90:1577-1615
+  double robert_curtime = 0, robert_newtime = 0, bgtarea_t_1 = 0, rf_volume_2_km = 0, open_ocean_volume_2_km = 0;
+  int rf_nonzero_newtime = 0;
   HaloPlan halo;
   std::string err;
 

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from popcfg import named_config  # noqa: E402
 
 FIELDS = [("TRACER", True), ("UVEL", True), ("VVEL", True), ("RHO", True), ("PSURF", False), ("UBTROP", False)]
-NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5}
+NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6}
 
 
 def config(case):
@@ -29,6 +29,8 @@ def config(case):
                             am=-1.0e23, ah=-1.0e22, solver_choice=2, **small)
     if case == "upwind3":     # third-order upwind tracer advection + Richardson vmix
         return named_config("tiny", tadvect=2, vmix_choice=2, **small)
+    if case == "robert":      # Robert-Asselin-Williams time filter (step_RF) instead of averaging steps
+        return named_config("tiny", tmix_opt=3, **small)
     raise KeyError(case)
 
 

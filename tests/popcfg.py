@@ -54,9 +54,19 @@ def base_config(**kw):
     c.Prandtl, c.kpp_rich_mix = 10.0, 50.0
     c.convergence_criterion = 1.0e-12
     c.reserved_d[0] = 1.0e-2          # init T perturbation amplitude
-    for k, v in kw.items():
-        setattr(c, k, v)
+    _apply(c, kw)
     return c
+
+
+def _apply(c, kw):
+    """Set fields by name; robert_alpha / robert_nu live in reserved_d[1], [2] (tmix_opt = 3)."""
+    for k, v in kw.items():
+        if k == "robert_alpha":
+            c.reserved_d[1] = v
+        elif k == "robert_nu":
+            c.reserved_d[2] = v
+        else:
+            setattr(c, k, v)
 
 
 def named_config(name, **kw):
@@ -83,6 +93,5 @@ def named_config(name, **kw):
                         lvariable_hmix=1, am=-27.0e17, ah=-3.0e17, convergence_criterion=1.0e-13)
     else:
         raise KeyError(name)
-    for k, v in kw.items():
-        setattr(c, k, v)
+    _apply(c, kw)
     return c

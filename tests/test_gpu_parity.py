@@ -136,6 +136,8 @@ def force_kpp_case(gpu, orc):
     ("tiny", {"tadvect": 2}, 5),                                     # third-order upwind tracer advection
     ("tiny", {"tadvect": 2, "vmix_choice": 3, "km": 24, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21}, 4),
     ("gx3v7", {"tadvect": 2}, 3),
+    ("tiny", {"tmix_opt": 3}, 5),                                    # Robert-Asselin-Williams filter (alpha 0.53, nu 0.2)
+    ("tiny", {"tmix_opt": 3, "robert_alpha": 1.0, "vmix_choice": 3, "km": 24}, 5),   # classic Robert-Asselin: previous-step averaging
 ])
 def test_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
     cfg = named_config(name, **kw)
@@ -286,6 +288,34 @@ def test_kpp_column_kernels_agree_bitwise(pkg, orclib_built, monkeypatch, kw):
         m.close()
     for a, b in zip(out["3"], out["0"]):
         assert np.array_equal(a, b)
+
+
+def test_robert_filter_conserves_tracer_volume(pkg, orclib_built):
+    """step_RF_diag (step_mod.F90:1362-1430): <T*volume> of curtime is the same before and after the
+    filter (exact when robert_newtime = 0 and no previous-step averaging applies: first filtered step)."""
+    cfg = named_config("tiny", tmix_opt=3, robert_alpha=1.0)
+    gpu = pkg.PopModel(cfg)
+    orc = Oracle(cfg)
+    dz = orc.v1("dz")[1:cfg.km + 1].copy()      # copy: the view dies with the oracle
+    tarea = interior(gpu.get("TAREA")); kmt = interior(gpu.geti("KMT"))
+    orc.close()
+
+    def trvol(tl, n):
+        T = gpu.get("TRACER", tl, n)[:, :, 2:-2, 2:-2]
+        P = interior(gpu.get("PSURF", tl))
+        thick = np.broadcast_to(dz[None, :, None, None], T.shape).copy()
+        thick[:, 0] = dz[0] + P / 980.6
+        mask = (np.arange(1, cfg.km + 1)[None, :, None, None] <= kmt[:, None])
+        return float((tarea[:, None] * thick * mask * T).sum())
+
+    gpu.step()                       # forward-Euler step: filter acts on old = cur
+    gpu.time_manager(); gpu.dhdt(); gpu.baroclinic_driver(); gpu.barotropic_driver(); gpu.baroclinic_correct_adjust()
+    pre = [trvol(1, n) for n in (0, 1)]
+    gpu.step_tail()                  # filter + rotation: the filtered curtime is now oldtime
+    post = [trvol(0, n) for n in (0, 1)]
+    for a, b in zip(pre, post):
+        assert abs(a - b) <= 1e-12 * abs(a), (a, b)
+    gpu.close()
 
 
 def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
