@@ -40,7 +40,8 @@ typedef struct pop_config {
   int lvariable_hmix;         /* hmix_del2.F90:223, hmix_del4.F90:200 */
   int vmix_choice;            /* 1 const, 2 rich, 3 kpp (vertical_mix.F90:280-296) */
   int tadvect;                /* 1 centered, 2 upwind3  (advection.F90:1667-1729) */
-  int solver_choice;          /* 1 pcg, 2 ChronGear     (POP_SolversMod.F90:442-472) */
+  int solver_choice;          /* 1 pcg, 2 ChronGear, 3 PCSI with Lanczos eigenvalue bounds
+                               * (POP_SolversMod.F90:442-472, 1510-1835, 2699-2990); diagonal preconditioner */
   int max_iterations;
   int convergence_check_freq;
   int tmix_opt;               /* 0 none, 1 avg, 2 avgfit (time_management.F90:2170-2213), 3 robert
@@ -49,7 +50,8 @@ typedef struct pop_config {
   int steps_per_day;          /* dt_option='steps_per_day', dt_count */
   int lbouss_correct, lpressure_avg, impcor, reset_to_freezing;
   int lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri; /* vmix_kpp_nml */
-  int reserved_i[8];
+  int reserved_i[8];          /* [0] = maxlanczosstep (0 = 20), [1] = convergenceCheckStart (0 = 60) for PCSI
+                               * (POP_SolversMod.F90:626-640) */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;
@@ -59,7 +61,7 @@ typedef struct pop_config {
   double convergence_criterion;
   double reserved_d[8];       /* [0] = amplitude of the synthetic initial T perturbation;
                                * [1], [2] = robert_alpha, robert_nu for tmix_opt = 3 (0 = defaults 0.53, 0.20,
-                               * time_management.F90:461-462) */
+                               * time_management.F90:461-462); [3] = LanczosconvergenceCriterion (0 = 0.1) */
 } pop_config;
 
 typedef struct pop_ctx pop_ctx;

@@ -50,6 +50,7 @@ struct orc_model {
   void *del4;
   void *upw3;
   void *rf;
+  void *pcsi;
 };
 
 extern const double orc_grav, orc_omega, orc_radius;

@@ -577,6 +577,9 @@ int host_build(HostModel &h) {
     }
   }
   build_halo_plan(h);
+  // ---------------- P-CSI preprocessing (POP_SolversPrep) ----------------
+  if (c.solver_choice == 3 && host_pcsi_prep(h)) return 1;
+  if (c.solver_choice < 1 || c.solver_choice > 3) { h.err = "solver_choice: 1 pcg, 2 ChronGear, 3 PCSI"; return 1; }
   return 0;
 }
 

@@ -1,0 +1,91 @@
+// kernels_pcsi.hpp -- P-CSI (Preconditioned Classical Stiefel Iteration), diagonal preconditioner:
+// POP_SolversMod.F90:1510-1835.  The iteration needs no inner product: per step
+//     r' = r * (1/diag);  halo(r');  dx = omega_k r' + (gamma omega_k - 1) dx;  x += dx;  r = b - A x
+// and (r,r) only every convergenceCheckFreq steps from convergenceCheckStart on.
+//
+// Fused form (all blocks on this GPU): ONE launch per iteration.  A thread forms the updated x of its
+// cell and of its 8 neighbours (each neighbour's update is recomputed with exactly the operations its
+// own thread uses, ghosts read at their source cell through srcmap = the value a halo update would
+// deliver), applies the 9-point operator and writes r, dx, x into the other half of a ping-pong pair,
+// so no thread reads what another writes in the same launch.  The omega_k sequence depends only on the
+// Lanczos eigenvalue bounds: it is tabulated once on the device and indexed by base + j, where j is
+// baked into the launch and `base` is a device word the host bumps per interval -- so one hipGraph
+// serves every interval of every solve.
+#pragma once
+#include "kernels_barotropic.hpp"
+
+namespace pop {
+
+struct PcsiArgs {
+  const double *Xi, *Ri, *Qi;      // state in
+  double *Xo, *Ro, *Qo;            // state out
+  const double *Bv, *C;
+  const double *omega;             // 1-based table of omega_k; entry 0 = 1/gamma (the start-up step, :1664)
+  const int *base;                 // iteration number of the interval's first step, minus 1
+  const int *srcmap;
+  double *partial;
+  double csy;
+  int j;                           // step inside the interval (1-based); j = 0: start-up step
+};
+
+// unfused building blocks (multi-rank path and cross-check): whole-array operations as the reference has them
+__global__ void k_pcsi_precond(DevGrid g, double *__restrict__ R, const double *__restrict__ C, long long n) {   // :1705-1712
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const double a0r = (C[q] != 0.0) ? 1.0 / C[q] : 0.0;
+  R[q] = R[q] * a0r;
+}
+template <bool FIRST>
+__global__ void k_pcsi_update(const double *__restrict__ R, double *__restrict__ Q, double *__restrict__ X, long long n,
+                              const double *__restrict__ omega, const int *__restrict__ base, int j, double csy) {   // :1664, :1742-1745
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  double dx;
+  if (FIRST) dx = omega[0] * R[q];
+  else { const double om = omega[*base + j]; dx = om * R[q] + (csy * om - 1.0) * Q[q]; }
+  Q[q] = dx;
+  X[q] = X[q] + dx;
+}
+
+// fused step
+template <bool FIRST, bool WITH_RR>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_pcsi_step(DevGrid g, PcsiArgs a) {
+  const int p2 = red_cell(g), b = blockIdx.y, nxb = g.nxb;
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % nxb, j = p2 / nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    if (interior(g, i, j)) {
+      const double om = FIRST ? a.omega[0] : a.omega[*a.base + a.j];
+      const double cq = FIRST ? 0.0 : a.csy * om - 1.0;
+      auto upd = [&](long long m, double &dx) {      // updated x of cell m (and its increment)
+        const double cw = a.C[m];
+        const double a0r = (cw != 0.0) ? 1.0 / cw : 0.0;
+        const double rp = a.Ri[m] * a0r;
+        dx = FIRST ? om * rp : om * rp + cq * a.Qi[m];
+        return a.Xi[m] + dx;
+      };
+      const bool rim = (i + 1 == g.ib || i + 1 == g.ie || j + 1 == g.jb || j + 1 == g.je);
+      const int off[8] = {nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+      double dx0, xn[8];
+      const double x0 = upd(q, dx0);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        long long m = q + off[t];
+        if (rim) m = a.srcmap[m];
+        double dxt;
+        xn[t] = (m >= 0) ? upd(m, dxt) : 0.0;
+      }
+      // btropOperator :2414-2426, same order as btrop_op
+      const double ax = a.C[q] * x0 + g.WNo[q] * xn[0] + g.WNo[q - nxb] * xn[1] + g.WEa[q] * xn[2] + g.WEa[q - 1] * xn[3] +
+                        g.WNE[q] * xn[4] + g.WNE[q - nxb] * xn[5] + g.WNE[q - 1] * xn[6] + g.WNE[q - 1 - nxb] * xn[7];
+      const double r = a.Bv[q] - ax;
+      a.Qo[q] = dx0; a.Xo[q] = x0; a.Ro[q] = r;
+      if (WITH_RR) v[0] = (r * r) * g.mMask[q];
+    }
+  }
+  if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + blockIdx.x);
+}
+
+}  // namespace pop

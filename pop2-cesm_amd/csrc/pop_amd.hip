@@ -11,6 +11,7 @@
 #include "kernels_thomas_reg.hpp"
 #include "kernels_momentum_lds.hpp"
 #include "kernels_rf.hpp"
+#include "kernels_pcsi.hpp"
 #include "rccl_transport.hpp"
 
 using namespace pop;
@@ -74,6 +75,8 @@ struct pop_ctx {
   pop_exchange_fn xchg = nullptr;
   pop_allreduce_fn allred = nullptr;
   void *comm_user = nullptr;
+  double *pcsi_omega = nullptr; int *pcsi_base = nullptr; double pcsi_csy = 0;        // P-CSI: omega_k table, interval base
+  std::vector<std::pair<std::pair<double *, int>, hipGraphExec_t>> pcsi_graphs;   // keyed by (solution array, variant)
   double rf_S[MAXNT] = {}, rf_S_prev[MAXNT] = {}; bool rf_S_prev_valid[MAXNT] = {};   // Robert filter
   Upw3Dev upw3{};                                          // tadvect = 2
   RcclTransport *rccl_tr = nullptr;                       // in-library RCCL transport (pop_comm_init_rccl)
@@ -422,6 +425,132 @@ int solver_chrongear(pop_ctx *c) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// P-CSI (POP_SolversMod.F90:1510-1835), diagonal preconditioner.  kernels_pcsi.hpp describes the
+// fused one-launch-per-iteration form; solver_pcsi is the operation-by-operation form that also
+// serves multi-rank runs (one halo update per iteration, no collective except at the checks).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_set_int(int *p, int v) { *p = v; }
+
+int pcsi_check_start(const pop_ctx *c) { return c->h.c.reserved_i[1] > 0 ? c->h.c.reserved_i[1] : 60; }   // convergenceCheckStart :636
+
+int solver_pcsi(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  const long long a2 = (long long)c->g.n2 * c->g.nblocks;
+  const dim3 G1((unsigned)((a2 + 255) / 256)), B1(256);
+  SolverScalars init{};
+  HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  SolverArgs a = solver_args(c);
+  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_pcsi_precond, G1, B1, 0, c->stream, c->g, c->R, (const double *)c->centerWgt, a2);
+  if (halo_update(c, c->R, 1)) return 1;
+  hipLaunchKernelGGL(k_pcsi_update<true>, G1, B1, 0, c->stream, (const double *)c->R, c->Q, a.X, a2, (const double *)c->pcsi_omega,
+                     (const int *)c->pcsi_base, 0, c->pcsi_csy);
+  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  c->numIterations = cf.max_iterations;
+  double rr = 0.0;
+  const int start = pcsi_check_start(c);
+  for (int m = 1; m <= cf.max_iterations; ++m) {
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->pcsi_base, m - 1);
+    hipLaunchKernelGGL(k_pcsi_precond, G1, B1, 0, c->stream, c->g, c->R, (const double *)c->centerWgt, a2);
+    if (halo_update(c, c->R, 1)) return 1;
+    hipLaunchKernelGGL(k_pcsi_update<false>, G1, B1, 0, c->stream, (const double *)c->R, c->Q, a.X, a2, (const double *)c->pcsi_omega,
+                       (const int *)c->pcsi_base, 1, c->pcsi_csy);
+    const bool check = (m % cf.convergence_check_freq == 0) && m >= start;
+    if (check) hipLaunchKernelGGL(k_residual<true>, G, B, 0, c->stream, c->g, a);
+    else hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+    if (check) {
+      if (reduce_finish<1>(c, FIN_RR)) return 1;
+      SolverScalars s;
+      if (read_scalars(c, &s)) return 1;
+      rr = s.rr;
+      if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
+    }
+  }
+  c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
+  HIPCHK(c, hipGetLastError());
+  if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCSI: solver not converged"; return 2; }
+  return 0;
+}
+
+// fused form; state ping-pongs between (X, R, Q) and (Z, AZ, S1)
+struct PcsiBufs { double *X[2], *R[2], *Q[2]; };
+static PcsiArgs pcsi_args(pop_ctx *c, const PcsiBufs &bf, int in, int j) {
+  PcsiArgs a{};
+  a.Xi = bf.X[in]; a.Ri = bf.R[in]; a.Qi = bf.Q[in]; a.Xo = bf.X[1 - in]; a.Ro = bf.R[1 - in]; a.Qo = bf.Q[1 - in];
+  a.Bv = c->RHS; a.C = c->centerWgt; a.omega = c->pcsi_omega; a.base = c->pcsi_base; a.srcmap = c->srcmap; a.partial = c->partial;
+  a.csy = c->pcsi_csy; a.j = j;
+  return a;
+}
+// `freq` steps starting from buffer `in`; the last one also forms (r,r) -> host when with_rr
+static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool with_rr) {
+  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  for (int j = 1; j <= freq; ++j) {
+    const PcsiArgs a = pcsi_args(c, bf, in, j);
+    if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step<false, true>), G, B, 0, c->stream, c->g, a);
+    else hipLaunchKernelGGL((k_pcsi_step<false, false>), G, B, 0, c->stream, c->g, a);
+    in = 1 - in;
+  }
+  if (with_rr) {
+    hipLaunchKernelGGL(k_block_sums<1>, dim3(c->g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->gid, c->blocksum);
+    hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, c->blocksum, c->h.nblocks_tot, c->sc, (int)FIN_RR);
+    hipMemcpyAsync(c->host_sc, c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream);
+  }
+}
+int solver_pcsi_fused(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  const int freq = cf.convergence_check_freq, start = pcsi_check_start(c);
+  PcsiBufs bf{{c->PS[c->newt], c->Z}, {c->R, c->AZ}, {c->Q, c->S1}};
+  SolverScalars init{};
+  HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  // r0 = b - A x0 (ghosts of x0 read at their sources), then the start-up step x1 = x0 + r0'/gamma, r1 = b - A x1
+  {
+    SolveView v = local_view(c);
+    hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, c->g, fused_args(c, v));
+  }
+  hipLaunchKernelGGL((k_pcsi_step<true, false>), G, B, 0, c->stream, c->g, pcsi_args(c, bf, 0, 0));
+  int in = 1;
+  c->numIterations = cf.max_iterations;
+  double rr = 0.0;
+  int m = 0;
+  while (m < cf.max_iterations) {
+    const int n = std::min(freq, cf.max_iterations - m);
+    const bool with_rr = (n == freq) && ((m + n) % freq == 0) && (m + n >= start);
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->pcsi_base, m);
+    if (!c->no_graph && n == freq) {
+      const int variant = in * 2 + (with_rr ? 1 : 0);
+      hipGraphExec_t exec = nullptr;
+      for (auto &gk : c->pcsi_graphs) if (gk.first.first == bf.X[0] && gk.first.second == variant) exec = gk.second;
+      if (!exec) {
+        hipGraph_t graph;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        pcsi_interval(c, bf, in, n, with_rr);
+        if (hipStreamEndCapture(c->stream, &graph) != hipSuccess) { c->err = "P-CSI graph capture failed"; return 1; }
+        HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        c->pcsi_graphs.push_back({{bf.X[0], variant}, exec});
+      }
+      HIPCHK(c, hipGraphLaunch(exec, c->stream));
+    } else pcsi_interval(c, bf, in, n, with_rr);
+    if (n % 2) in = 1 - in;
+    m += n;
+    if (with_rr) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      rr = c->host_sc->rr;
+      if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
+    }
+  }
+  const long long ncell = (long long)c->g.n2 * c->g.nblocks;
+  if (in == 1) HIPCHK(c, hipMemcpyAsync(bf.X[0], bf.X[1], sizeof(double) * ncell, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, bf.X[0], c->srcmap, ncell);
+  c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
+  HIPCHK(c, hipGetLastError());
+  if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCSI: solver not converged"; return 2; }
+  return 0;
+}
+
 int need_device(pop_ctx *c) {
   if (!c) return 1;
   if (c->host_only) { c->err = "context was created host-only: no GPU path available (there is no CPU fallback)"; return 1; }
@@ -577,6 +706,17 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     if (dev_upload(c, &c->srcmap, sm.data(), sm.size())) return 1;
     HIPCHK(c, hipHostMalloc((void **)&c->host_sc, sizeof(SolverScalars)));
     c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED");
+    if (cfg->solver_choice == 3) {   // omega_k of P-CSI (POP_SolversMod.F90:1617-1620, 1695): a function of the eigenvalue bounds only
+      const double csalpha = 2.0 / (h.pcsi_max_eig - h.pcsi_min_eig);
+      const double csbeta = (h.pcsi_max_eig + h.pcsi_min_eig) / (h.pcsi_max_eig - h.pcsi_min_eig);
+      const double csy = csbeta / csalpha;
+      std::vector<double> om(cfg->max_iterations + 2);
+      om[0] = 1.0 / csy;
+      double csomga = 2.0 / csy;
+      for (int m = 1; m <= cfg->max_iterations; ++m) { csomga = 1.0 / (csy - csomga / (4.0 * csalpha * csalpha)); om[m] = csomga; }
+      c->pcsi_csy = csy;
+      if (dev_upload(c, &c->pcsi_omega, om.data(), om.size()) || dev_alloc(c, &c->pcsi_base, 1)) return 1;
+    }
     c->no_graph = getenv("POP_SOLVER_NOGRAPH") != nullptr;
     if (getenv("POP_MOMENTUM_LDS")) c->mom_lds_rows = atoi(getenv("POP_MOMENTUM_LDS"));
     c->reg_thomas = getenv("POP_GENERIC_THOMAS") == nullptr;
@@ -632,6 +772,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
 int pop_destroy(pop_ctx *c) {
   if (!c) return 0;
   for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+  for (auto &g : c->pcsi_graphs) hipGraphExecDestroy(g.second);
   if (c->host_sc) hipHostFree(c->host_sc);
   if (c->rccl_tr) {
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -679,6 +820,9 @@ double pop_get_scalar(const pop_ctx *c, const char *name) {
   if (n == "rconst") return c->h.rconst;
   if (n == "uarea_equator") return c->h.uarea_equator;
   if (n == "rmsResidual") return c->rmsResidual;
+  if (n == "PcsiMaxEigs") return c->h.pcsi_max_eig;
+  if (n == "PcsiMinEigs") return c->h.pcsi_min_eig;
+  if (n == "lanczos_steps") return (double)c->h.pcsi_lanczos_steps;
   if (n == "robert_curtime") return c->h.robert_curtime;
   if (n == "robert_newtime") return c->h.robert_newtime;
   if (n == "rf_volume_2_km") return c->h.rf_volume_2_km;
@@ -879,6 +1023,7 @@ int pop_baroclinic_driver(pop_ctx *c) {
 int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
   if (c->h.c.solver_choice == 2) return solver_chrongear(c);
+  if (c->h.c.solver_choice == 3) return c->fused_ok ? solver_pcsi_fused(c) : solver_pcsi(c);
   if (c->replicated) {
     if (!c->allred || !c->redbuf || c->red_doubles < 2LL * c->g.n2 * c->h.nblocks_tot) { c->err = "replicated solve needs pop_set_comm with a reduce buffer of pop_reduce_buffer_doubles()"; return 1; }
     return solver_pcg_replicated(c);

@@ -65,6 +65,9 @@ struct HostModel {
   // Robert filter (tmix_opt = 3): time_management.F90:897-945, step_mod.F90:1577-1615
   double robert_curtime = 0, robert_newtime = 0, bgtarea_t_1 = 0, rf_volume_2_km = 0, open_ocean_volume_2_km = 0;
   int rf_nonzero_newtime = 0;
+  // P-CSI (solver_choice = 3): Lanczos eigenvalue bounds from host_pcsi_prep (POP_SolversMod.F90:181-320)
+  double pcsi_max_eig = 0, pcsi_min_eig = 0;
+  int pcsi_lanczos_steps = 0;
   HaloPlan halo;
   std::string err;
 
@@ -73,6 +76,7 @@ struct HostModel {
 };
 
 int host_build(HostModel &h);            // host_setup.cpp
+int host_pcsi_prep(HostModel &h);        // host_pcsi.cpp
 void build_halo_plan(HostModel &h);      // halo_plan.cpp
 void host_halo_r8(const HostModel &h, double *a, int nz, double fill);   // single-rank host halo
 void host_halo_i4(const HostModel &h, int *a, int nz, int fill);

@@ -20,6 +20,8 @@ def _port():
     (2, "block_size_x=48,block_size_y=20"),                       # replicated barotropic solve
     (2, ""),                                                      # 16 blocks: distributed solve
     (3, "block_size_x=24,block_size_y=20,vmix_choice=3,km=24"),   # uneven block ownership, KPP
+    (2, "solver_choice=3"),                                       # P-CSI: one halo update per iteration, no collective
+    (2, "tmix_opt=3,tadvect=2"),                                  # Robert filter sums + upwind3 across ranks
 ])
 def test_multirank_equals_single_rank(nranks, kw):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),

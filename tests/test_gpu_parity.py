@@ -136,6 +136,9 @@ def force_kpp_case(gpu, orc):
     ("tiny", {"tadvect": 2}, 5),                                     # third-order upwind tracer advection
     ("tiny", {"tadvect": 2, "vmix_choice": 3, "km": 24, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21}, 4),
     ("gx3v7", {"tadvect": 2}, 3),
+    ("tiny", {"solver_choice": 3}, 4),                               # P-CSI (no inner product per iteration)
+    ("gx3v7", {"solver_choice": 3}, 3),
+    ("tiny", {"solver_choice": 3, "block_size_x": 48, "block_size_y": 40, "vmix_choice": 3, "km": 24}, 4),
     ("tiny", {"tmix_opt": 3}, 5),                                    # Robert-Asselin-Williams filter (alpha 0.53, nu 0.2)
     ("tiny", {"tmix_opt": 3, "robert_alpha": 1.0, "vmix_choice": 3, "km": 24}, 5),   # classic Robert-Asselin: previous-step averaging
 ])
@@ -347,6 +350,25 @@ def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
     with pytest.raises(pkg.PopError):
         gpu.solver_diagonal(gpu.nblocks + 1, corr)
     gpu.close(); orc.close()
+
+
+def test_fused_pcsi_is_bitwise_the_unfused_pcsi(pkg, monkeypatch):
+    """P-CSI: the one-launch-per-iteration form (neighbour updates recomputed in the matvec, ping-pong state,
+    hipGraph per check interval) against the operation-by-operation form with explicit halo updates."""
+    cfg = named_config("tiny", block_size_x=24, block_size_y=20, solver_choice=3)
+    a = pkg.PopModel(cfg)
+    monkeypatch.setenv("POP_SOLVER_UNFUSED", "1")
+    b = pkg.PopModel(cfg)
+    monkeypatch.delenv("POP_SOLVER_UNFUSED")
+    monkeypatch.setenv("POP_SOLVER_NOGRAPH", "1")
+    c = pkg.PopModel(cfg)
+    for _ in range(4):
+        a.step(); b.step(); c.step()
+        assert a.solver_diagnostics() == b.solver_diagnostics() == c.solver_diagnostics()
+    for name in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER"):
+        assert np.array_equal(a.get(name), b.get(name)), name
+        assert np.array_equal(a.get(name), c.get(name)), name
+    a.close(); b.close(); c.close()
 
 
 def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch):

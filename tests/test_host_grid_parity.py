@@ -20,7 +20,8 @@ IFIELDS = ["KMT", "KMU", "KMTN", "KMTS", "KMTE", "KMTW", "KMTEE", "KMTNN"]
                                      ("tiny", {"hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1}),
                                      ("tiny", {"hmix_momentum": 4, "hmix_tracer": 4}),
                                      ("tiny", {"tadvect": 2}), ("gx3v7", {"tadvect": 2}),
-                                     ("tiny", {"tmix_opt": 3}), ("tiny", {"tmix_opt": 3, "robert_alpha": 1.0, "robert_nu": 0.1})])
+                                     ("tiny", {"tmix_opt": 3}), ("tiny", {"tmix_opt": 3, "robert_alpha": 1.0, "robert_nu": 0.1}),
+                                     ("tiny", {"solver_choice": 3}), ("gx3v7", {"solver_choice": 3}), ("test", {"solver_choice": 3})])
 def test_host_fields_bit_exact(pkg, orclib_built, name, kw):
     cfg = named_config(name, **kw)
     m = pkg.PopModel(cfg, host_only=True)
@@ -43,6 +44,10 @@ def test_host_fields_bit_exact(pkg, orclib_built, name, kw):
         assert np.array_equal(m.get("SMFT", 1, n), o.f2("SMFT", 1, n))
     for s in ("dtt", "dtu", "dtp", "residualNorm", "convergenceCriterion", "rcheck", "rconst", "uarea_equator"):
         assert m.scalar(s) == o.scalar(s), s
+    if cfg.solver_choice == 3:   # P-CSI preprocessing: Lanczos eigenvalue bounds (POP_SolversMod.F90:2699-2990)
+        for s in ("PcsiMaxEigs", "PcsiMinEigs", "lanczos_steps"):
+            assert m.scalar(s) == o.scalar(s), s
+        assert 0.0 < m.scalar("PcsiMinEigs") < m.scalar("PcsiMaxEigs")
     if cfg.tmix_opt == 3:    # Robert filter coefficients, budget area and volumes (time_management.F90:897, step_mod.F90:1606)
         for s in ("robert_curtime", "robert_newtime", "bgtarea_t_1", "rf_volume_2_km", "open_ocean_volume_2_km"):
             assert m.scalar(s) == o.scalar(s), s
