@@ -19,7 +19,7 @@ namespace pop {
 struct PcsiArgs {
   const double *Xi, *Ri, *Qi;      // state in
   double *Xo, *Ro, *Qo;            // state out
-  const double *Bv, *C;
+  const double *Bv, *C, *A0R;      // A0R = 1/diag (k_pcsi_a0r)
   const double *omega;             // 1-based table of omega_k; entry 0 = 1/gamma (the start-up step, :1664)
   const int *base;                 // iteration number of the interval's first step, minus 1
   const int *srcmap;
@@ -47,7 +47,25 @@ __global__ void k_pcsi_update(const double *__restrict__ R, double *__restrict__
   X[q] = X[q] + dx;
 }
 
-// fused step
+// 1/diag (0 where the diagonal vanishes), formed once per solve as the reference does (:1592-1605)
+__global__ void k_pcsi_a0r(const double *__restrict__ C, double *__restrict__ A0R, long long n) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  A0R[q] = (C[q] != 0.0) ? 1.0 / C[q] : 0.0;
+}
+// r = b - A x of the fused residual kernel, scaled in place to r' = r * (1/diag)
+__global__ void k_pcsi_scale(DevGrid g, double *__restrict__ R, const double *__restrict__ A0R) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const int i = p2 % g.nxb, j = p2 / g.nxb;
+  if (!interior(g, i, j)) return;
+  const long long q = (long long)b * g.n2 + p2;
+  R[q] = R[q] * A0R[q];
+}
+
+// fused step.  The residual arrays hold the PRECONDITIONED residual r' = r * (1/diag): the product the
+// reference forms at the top of the next iteration (:1705-1712) is formed here by the thread that just
+// computed r, so a neighbour's update needs three loads (r', dx, x) and no division.
 template <bool FIRST, bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_pcsi_step(DevGrid g, PcsiArgs a) {
@@ -59,29 +77,34 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
     if (interior(g, i, j)) {
       const double om = FIRST ? a.omega[0] : a.omega[*a.base + a.j];
       const double cq = FIRST ? 0.0 : a.csy * om - 1.0;
-      auto upd = [&](long long m, double &dx) {      // updated x of cell m (and its increment)
-        const double cw = a.C[m];
-        const double a0r = (cw != 0.0) ? 1.0 / cw : 0.0;
-        const double rp = a.Ri[m] * a0r;
-        dx = FIRST ? om * rp : om * rp + cq * a.Qi[m];
-        return a.Xi[m] + dx;
-      };
       const bool rim = (i + 1 == g.ib || i + 1 == g.ie || j + 1 == g.jb || j + 1 == g.je);
       const int off[8] = {nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
-      double dx0, xn[8];
-      const double x0 = upd(q, dx0);
+      // gather first: every load is independent
+      double rp[9], qo[9], xo[9];
+      long long m[9];
+      m[0] = q;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        long long m = q + off[t];
-        if (rim) m = a.srcmap[m];
-        double dxt;
-        xn[t] = (m >= 0) ? upd(m, dxt) : 0.0;
+      for (int t = 0; t < 8; ++t) { long long mm = q + off[t]; if (rim) mm = a.srcmap[mm]; m[t + 1] = mm; }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const bool ok = m[t] >= 0;
+        const long long mm = ok ? m[t] : q;
+        rp[t] = a.Ri[mm]; xo[t] = a.Xi[mm]; qo[t] = FIRST ? 0.0 : a.Qi[mm];
+        if (!ok) { rp[t] = 0.0; xo[t] = 0.0; qo[t] = 0.0; }
+      }
+      const double w[9] = {a.C[q], g.WNo[q], g.WNo[q - nxb], g.WEa[q], g.WEa[q - 1], g.WNE[q], g.WNE[q - nxb], g.WNE[q - 1], g.WNE[q - 1 - nxb]};
+      const double bq = a.Bv[q], a0r = a.A0R[q];
+      double xn[9], dx0 = 0.0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const double dx = FIRST ? om * rp[t] : om * rp[t] + cq * qo[t];
+        if (t == 0) dx0 = dx;
+        xn[t] = (m[t] >= 0) ? xo[t] + dx : 0.0;
       }
       // btropOperator :2414-2426, same order as btrop_op
-      const double ax = a.C[q] * x0 + g.WNo[q] * xn[0] + g.WNo[q - nxb] * xn[1] + g.WEa[q] * xn[2] + g.WEa[q - 1] * xn[3] +
-                        g.WNE[q] * xn[4] + g.WNE[q - nxb] * xn[5] + g.WNE[q - 1] * xn[6] + g.WNE[q - 1 - nxb] * xn[7];
-      const double r = a.Bv[q] - ax;
-      a.Qo[q] = dx0; a.Xo[q] = x0; a.Ro[q] = r;
+      const double ax = w[0] * xn[0] + w[1] * xn[1] + w[2] * xn[2] + w[3] * xn[3] + w[4] * xn[4] + w[5] * xn[5] + w[6] * xn[6] + w[7] * xn[7] + w[8] * xn[8];
+      const double r = bq - ax;
+      a.Qo[q] = dx0; a.Xo[q] = xn[0]; a.Ro[q] = r * a0r;
       if (WITH_RR) v[0] = (r * r) * g.mMask[q];
     }
   }

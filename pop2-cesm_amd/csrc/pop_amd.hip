@@ -479,7 +479,7 @@ struct PcsiBufs { double *X[2], *R[2], *Q[2]; };
 static PcsiArgs pcsi_args(pop_ctx *c, const PcsiBufs &bf, int in, int j) {
   PcsiArgs a{};
   a.Xi = bf.X[in]; a.Ri = bf.R[in]; a.Qi = bf.Q[in]; a.Xo = bf.X[1 - in]; a.Ro = bf.R[1 - in]; a.Qo = bf.Q[1 - in];
-  a.Bv = c->RHS; a.C = c->centerWgt; a.omega = c->pcsi_omega; a.base = c->pcsi_base; a.srcmap = c->srcmap; a.partial = c->partial;
+  a.Bv = c->RHS; a.C = c->centerWgt; a.A0R = c->S0; a.omega = c->pcsi_omega; a.base = c->pcsi_base; a.srcmap = c->srcmap; a.partial = c->partial;
   a.csy = c->pcsi_csy; a.j = j;
   return a;
 }
@@ -508,7 +508,10 @@ int solver_pcsi_fused(pop_ctx *c) {
   // r0 = b - A x0 (ghosts of x0 read at their sources), then the start-up step x1 = x0 + r0'/gamma, r1 = b - A x1
   {
     SolveView v = local_view(c);
+    const long long a2 = (long long)c->g.n2 * c->g.nblocks;
+    hipLaunchKernelGGL(k_pcsi_a0r, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->centerWgt, c->S0, a2);
     hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, c->g, fused_args(c, v));
+    hipLaunchKernelGGL(k_pcsi_scale, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, c->R, (const double *)c->S0);
   }
   hipLaunchKernelGGL((k_pcsi_step<true, false>), G, B, 0, c->stream, c->g, pcsi_args(c, bf, 0, 0));
   int in = 1;
