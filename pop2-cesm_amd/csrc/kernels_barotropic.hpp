@@ -112,11 +112,12 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NF], double *partial
 }
 // Stage 2: blocksum[gid[b]*NF+f] = ordered sum of partials of local block b.  One workgroup per
 // (local block); threads take strided subsets sequentially, then a fixed tree.
+// ordered sum of the nchunk partials of one block (all NF fields) by one workgroup: thread-strided
+// left-to-right sums, then a fixed tree; result valid in thread 0
 template <int NF>
-__global__ void k_block_sums(const double *__restrict__ partial, int nchunk, const int *__restrict__ gid,
-                             double *__restrict__ blocksum) {
+__device__ __forceinline__ void block_sum_ordered(const double *__restrict__ pb, int nchunk, double (&out)[NF]) {
   __shared__ double sh[NF][POP_RED_THREADS];
-  const int t = threadIdx.x, b = blockIdx.x;
+  const int t = threadIdx.x;
   double v[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) v[f] = 0.0;
@@ -128,7 +129,7 @@ __global__ void k_block_sums(const double *__restrict__ partial, int nchunk, con
 #pragma unroll
     for (int u = 0; u < 16; ++u)
 #pragma unroll
-      for (int f = 0; f < NF; ++f) w[u][f] = partial[((long long)b * nchunk + cidx + u * POP_RED_THREADS) * NF + f];
+      for (int f = 0; f < NF; ++f) w[u][f] = pb[((long long)cidx + u * POP_RED_THREADS) * NF + f];
 #pragma unroll
     for (int u = 0; u < 16; ++u)
 #pragma unroll
@@ -136,7 +137,7 @@ __global__ void k_block_sums(const double *__restrict__ partial, int nchunk, con
   }
   for (; cidx < nchunk; cidx += POP_RED_THREADS)
 #pragma unroll
-    for (int f = 0; f < NF; ++f) v[f] = v[f] + partial[((long long)b * nchunk + cidx) * NF + f];
+    for (int f = 0; f < NF; ++f) v[f] = v[f] + pb[(long long)cidx * NF + f];
 #pragma unroll
   for (int f = 0; f < NF; ++f) sh[f][t] = v[f];
   __syncthreads();
@@ -147,9 +148,33 @@ __global__ void k_block_sums(const double *__restrict__ partial, int nchunk, con
     }
     __syncthreads();
   }
-  if (t == 0) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f) blocksum[(long long)gid[b] * NF + f] = sh[f][0];
+  for (int f = 0; f < NF; ++f) out[f] = sh[f][0];
+}
+template <int NF>
+__global__ void k_block_sums(const double *__restrict__ partial, int nchunk, const int *__restrict__ gid,
+                             double *__restrict__ blocksum) {
+  const int b = blockIdx.x;
+  double r[NF];
+  block_sum_ordered<NF>(partial + (long long)b * nchunk * NF, nchunk, r);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) blocksum[(long long)gid[b] * NF + f] = r[f];
+  }
+}
+// the whole block-sum vector of the decomposition in one launch (grid = nblocks_tot): own blocks get their
+// ordered sum, the others 0, ready for the all-reduce (replaces memset + k_block_sums)
+template <int NF>
+__global__ void k_block_sums_global(const double *__restrict__ partial, int nchunk, const int *__restrict__ local_of_gid,
+                                    double *__restrict__ blocksum) {
+  const int bg = blockIdx.x, lb = local_of_gid[bg];
+  double r[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) r[f] = 0.0;
+  if (lb >= 0) block_sum_ordered<NF>(partial + (long long)lb * nchunk * NF, nchunk, r);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) blocksum[(long long)bg * NF + f] = r[f];
   }
 }
 
@@ -393,6 +418,23 @@ __global__ void k_halo_unpack(double *__restrict__ F, const int *__restrict__ ds
   if (t >= n) return;
   const int d = dst[t];
   F[((long long)(d / n2) * nz + k) * n2 + d % n2] = buf[(long long)k * n + t];
+}
+
+// all peers in one launch: element t of the concatenated list belongs to the message that starts at
+// start[t] cells into the buffer and has cnt[t] cells per level (message = level-major, as above)
+__global__ void k_halo_pack_all(const double *__restrict__ F, const int *__restrict__ src, const int *__restrict__ start,
+                                const int *__restrict__ cnt, int n, double *__restrict__ buf, int nz, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (t >= n) return;
+  const int s = src[t], st = start[t], m = cnt[t];
+  buf[(long long)st * nz + (long long)k * m + (t - st)] = F[((long long)(s / n2) * nz + k) * n2 + s % n2];
+}
+__global__ void k_halo_unpack_all(double *__restrict__ F, const int *__restrict__ dst, const int *__restrict__ start,
+                                  const int *__restrict__ cnt, int n, const double *__restrict__ buf, int nz, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (t >= n) return;
+  const int d = dst[t], st = start[t], m = cnt[t];
+  F[((long long)(d / n2) * nz + k) * n2 + d % n2] = buf[(long long)st * nz + (long long)k * m + (t - st)];
 }
 
 }  // namespace pop

@@ -26,6 +26,7 @@ struct PcsiArgs {
   double *partial;
   double csy;
   int j;                           // step inside the interval (1-based); j = 0: start-up step
+  int remote_ghosts;               // multi-rank: also advance dx, x at ghosts owned by other ranks
 };
 
 // unfused building blocks (multi-rank path and cross-check): whole-array operations as the reference has them
@@ -106,6 +107,13 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
       const double r = bq - ax;
       a.Qo[q] = dx0; a.Xo[q] = xn[0]; a.Ro[q] = r * a0r;
       if (WITH_RR) v[0] = (r * r) * g.mMask[q];
+    } else if (a.remote_ghosts && a.srcmap[q] == q) {
+      // ghost owned by another rank (multi-rank fused form): its r' arrived by the halo exchange; dx and x
+      // are advanced here with the owner's arithmetic, so they never need to be exchanged
+      const double om = FIRST ? a.omega[0] : a.omega[*a.base + a.j];
+      const double rp = a.Ri[q];
+      const double dx = FIRST ? om * rp : om * rp + (a.csy * om - 1.0) * a.Qi[q];
+      a.Qo[q] = dx; a.Xo[q] = a.Xi[q] + dx;
     }
   }
   if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + blockIdx.x);

@@ -53,7 +53,7 @@ struct pop_ctx {
   double *R = nullptr, *S0 = nullptr, *S1 = nullptr, *Q = nullptr, *Z = nullptr, *AZ = nullptr;
   double *partial = nullptr, *blocksum = nullptr;
   SolverScalars *sc = nullptr;
-  int *gid = nullptr, *srcmap = nullptr, *iota = nullptr;
+  int *gid = nullptr, *srcmap = nullptr, *iota = nullptr, *loc_of_gid = nullptr;
   SolverScalars *host_sc = nullptr;                       // pinned
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
   bool no_graph = false, fused_ok = false, replicated = false;
@@ -69,6 +69,9 @@ struct pop_ctx {
   int *copy_dst = nullptr, *copy_src = nullptr, *fill_dst = nullptr;
   int ncopy = 0, nfill = 0;
   std::vector<DevPeer> peers;
+  // all peers concatenated (one pack / unpack launch per halo update)
+  int *sa_src = nullptr, *sa_start = nullptr, *sa_cnt = nullptr, *ra_dst = nullptr, *ra_start = nullptr, *ra_cnt = nullptr;
+  int nsend_all = 0, nrecv_all = 0;
   // comm hooks
   double *sendbuf = nullptr, *recvbuf = nullptr, *redbuf = nullptr;
   long long comm_doubles = 0, red_doubles = 0;
@@ -157,27 +160,28 @@ struct ScopedPhase {   // optional HIP-event timing of a phase on the launch str
 // halo update of a device-resident field with nz levels (mpi/POP_HaloMod.F90:1732-2071 2-D,
 // :2766-3211 3-D): local ghost copies + fills in one launch, then one packed message per peer
 // ---------------------------------------------------------------------------------------------
+// remote part only: one pack launch, the exchange, one unpack launch
+int halo_remote(pop_ctx *c, double *F, int nz) {
+  if (c->peers.empty()) return 0;
+  const int n2 = c->g.n2;
+  if (!c->xchg || !c->sendbuf) { c->err = "halo_update: multi-rank run without pop_set_comm"; return 1; }
+  std::vector<int> peer; std::vector<long long> soff, scnt, roff, rcnt;
+  long long so = 0, ro = 0;
+  for (auto &p : c->peers) {
+    peer.push_back(p.rank); soff.push_back(so); scnt.push_back((long long)p.nsend * nz); roff.push_back(ro); rcnt.push_back((long long)p.nrecv * nz);
+    so += (long long)p.nsend * nz; ro += (long long)p.nrecv * nz;
+  }
+  if (so > c->comm_doubles || ro > c->comm_doubles) { c->err = "halo_update: comm buffer too small"; return 1; }
+  if (c->nsend_all) hipLaunchKernelGGL(k_halo_pack_all, dim3((c->nsend_all + 255) / 256, nz), dim3(256), 0, c->stream, (const double *)F, c->sa_src, c->sa_start, c->sa_cnt, c->nsend_all, c->sendbuf, nz, n2);
+  if (c->xchg(c->comm_user, (int)peer.size(), peer.data(), soff.data(), scnt.data(), roff.data(), rcnt.data())) {
+    c->err = "halo_update: exchange failed" + (c->rccl_tr ? ": " + c->rccl_tr->err : std::string(" in the host callback")); return 1;
+  }
+  if (c->nrecv_all) hipLaunchKernelGGL(k_halo_unpack_all, dim3((c->nrecv_all + 255) / 256, nz), dim3(256), 0, c->stream, F, c->ra_dst, c->ra_start, c->ra_cnt, c->nrecv_all, (const double *)c->recvbuf, nz, n2);
+  return 0;
+}
 int halo_update(pop_ctx *c, double *F, int nz, double fill = 0.0) {
   const int n2 = c->g.n2;
-  if (!c->peers.empty()) {
-    if (!c->xchg || !c->sendbuf) { c->err = "halo_update: multi-rank run without pop_set_comm"; return 1; }
-    std::vector<int> peer; std::vector<long long> soff, scnt, roff, rcnt;
-    long long so = 0, ro = 0;
-    for (auto &p : c->peers) {
-      if (p.nsend) hipLaunchKernelGGL(k_halo_pack, dim3((p.nsend + 255) / 256, nz), dim3(256), 0, c->stream, F, p.send_src, p.nsend, c->sendbuf + so, nz, n2);
-      peer.push_back(p.rank); soff.push_back(so); scnt.push_back((long long)p.nsend * nz); roff.push_back(ro); rcnt.push_back((long long)p.nrecv * nz);
-      so += (long long)p.nsend * nz; ro += (long long)p.nrecv * nz;
-    }
-    if (so > c->comm_doubles || ro > c->comm_doubles) { c->err = "halo_update: comm buffer too small"; return 1; }
-    if (c->xchg(c->comm_user, (int)peer.size(), peer.data(), soff.data(), scnt.data(), roff.data(), rcnt.data())) {
-      c->err = "halo_update: exchange failed" + (c->rccl_tr ? ": " + c->rccl_tr->err : std::string(" in the host callback")); return 1;
-    }
-    ro = 0;
-    for (auto &p : c->peers) {
-      if (p.nrecv) hipLaunchKernelGGL(k_halo_unpack, dim3((p.nrecv + 255) / 256, nz), dim3(256), 0, c->stream, F, p.recv_dst, p.nrecv, c->recvbuf + ro, nz, n2);
-      ro += (long long)p.nrecv * nz;
-    }
-  }
+  if (halo_remote(c, F, nz)) return 1;
   const int nloc = c->ncopy + c->nfill;
   if (nloc) hipLaunchKernelGGL(k_halo_local, dim3((nloc + 255) / 256, nz), dim3(256), 0, c->stream, F, c->copy_dst, c->copy_src, c->ncopy, c->fill_dst, c->nfill, fill, nz, n2);
   HIPCHK(c, hipGetLastError());
@@ -191,9 +195,8 @@ int reduce_finish(pop_ctx *c, int mode) {
   if (c->h.nranks > 1) {
     if (!c->allred || !c->redbuf) { c->err = "global sum: multi-rank run without pop_set_comm"; return 1; }
     bs = c->redbuf;
-    HIPCHK(c, hipMemsetAsync(bs, 0, sizeof(double) * NF * c->h.nblocks_tot, c->stream));
-  }
-  hipLaunchKernelGGL(k_block_sums<NF>, dim3(c->g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->gid, bs);
+    hipLaunchKernelGGL(k_block_sums_global<NF>, dim3(c->h.nblocks_tot), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->loc_of_gid, bs);
+  } else hipLaunchKernelGGL(k_block_sums<NF>, dim3(c->g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->gid, bs);
   if (c->h.nranks > 1 && c->allred(c->comm_user, 0, (long long)NF * c->h.nblocks_tot)) { c->err = "global sum: allreduce callback failed"; return 1; }
   hipLaunchKernelGGL(k_finalize<NF>, dim3(1), dim3(1), 0, c->stream, bs, c->h.nblocks_tot, c->sc, mode);
   HIPCHK(c, hipGetLastError());
@@ -365,6 +368,68 @@ SolveView local_view(pop_ctx *c) {
 // all-reduce of disjoint contributions, runs the fused solver on the whole 2-D domain with no
 // per-iteration communication, and keeps its own blocks.  Arithmetic and iteration count equal the
 // single-rank run (same blocks, same b4b sums).
+// pcg, fused form for blocks spread over ranks: the same two kernels per iteration as solver_pcg_fused; ghosts
+// with a source on this rank are read there (srcmap), ghosts owned by another rank are read in place after ONE
+// halo exchange per iteration (z; the search direction at those ghosts is then advanced locally with the same
+// arithmetic as on its owner), and the two dot products go through the b4b block-sum vector and an
+// all-reduce.  9 stream operations per iteration instead of 16 in solver_pcg; bitwise the same results.
+int solver_pcg_fused_dist(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  SolveView v = local_view(c);
+  const dim3 G = view_grid(v), B(POP_RED_THREADS);
+  const int nbt = c->h.nblocks_tot;
+  if (!c->allred || !c->redbuf || c->red_doubles < 2LL * nbt) { c->err = "distributed pcg: no transport / reduce buffer"; return 1; }
+  auto args = [&]() {
+    FusedArgs a = fused_args(c, v);
+    a.presummed = 1; a.nblocks = nbt; a.bsA = c->redbuf; a.bsB = c->redbuf + nbt;
+    return a;
+  };
+  auto allsum = [&](const double *partial, long long off) -> int {   // ordered block sums of every rank -> all ranks
+    hipLaunchKernelGGL(k_block_sums_global<1>, dim3(nbt), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->loc_of_gid, c->redbuf + off);
+    if (c->allred(c->comm_user, off, nbt)) { c->err = "distributed pcg: allreduce failed"; return 1; }
+    return 0;
+  };
+  SolverScalars init{}; init.eta0 = 1.0;
+  HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(v.S0, 0, sizeof(double) * v.g.n2 * v.g.nblocks, c->stream));
+  hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, v.g, args());
+  c->numIterations = cf.max_iterations;
+  double rr = 0.0;
+  bool pending = false;
+  for (int m = 1; m <= cf.max_iterations; ++m) {
+    FusedArgs a = args();
+    if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
+    else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
+    if (allsum(a.partA, 0) || halo_remote(c, v.Z, 1)) return 1;
+    hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, v.g, a);
+    if (allsum(a.partB, nbt)) return 1;
+    std::swap(v.S0, v.S1);
+    pending = true;
+    if (m % cf.convergence_check_freq == 0) {
+      a = args();
+      hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, a);
+      pending = false;
+      hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, v.g, a);
+      if (allsum(a.partA, 0)) return 1;
+      hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, c->redbuf, nbt, c->sc, (int)FIN_RR);
+      SolverScalars s;
+      if (read_scalars(c, &s)) return 1;
+      rr = s.rr;
+      if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
+    }
+  }
+  if (pending) hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, args());
+  // ghosts of the solution as POP_SolversRun leaves them: remote ones were advanced with their owners'
+  // arithmetic, the ones with a source on this rank are copied now (srcmap is the identity on remote ghosts)
+  const long long ncell = (long long)v.g.n2 * v.g.nblocks;
+  hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, v.X, v.srcmap, ncell);
+  c->S0 = v.S0; c->S1 = v.S1;
+  c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
+  HIPCHK(c, hipGetLastError());
+  if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCG: solver not converged"; return 2; }
+  return 0;
+}
+
 int solver_pcg_replicated(pop_ctx *c) {
   SolveView &v = c->gv;
   const size_t n2 = c->g.n2, NG = n2 * c->h.nblocks_tot;
@@ -554,6 +619,59 @@ int solver_pcsi_fused(pop_ctx *c) {
   return 0;
 }
 
+// fused P-CSI with blocks spread over ranks: one halo exchange (r') and one launch per iteration, a block-sum
+// all-reduce only at the convergence checks
+int solver_pcsi_fused_dist(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  const int freq = cf.convergence_check_freq, start = pcsi_check_start(c), nbt = c->h.nblocks_tot;
+  if (!c->allred || !c->redbuf || c->red_doubles < nbt) { c->err = "distributed P-CSI: no transport / reduce buffer"; return 1; }
+  PcsiBufs bf{{c->PS[c->newt], c->Z}, {c->R, c->AZ}, {c->Q, c->S1}};
+  SolverScalars init{};
+  HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  const long long a2 = (long long)c->g.n2 * c->g.nblocks;
+  {
+    SolveView v = local_view(c);
+    hipLaunchKernelGGL(k_pcsi_a0r, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->centerWgt, c->S0, a2);
+    hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, c->g, fused_args(c, v));
+    hipLaunchKernelGGL(k_pcsi_scale, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, c->R, (const double *)c->S0);
+  }
+  auto step = [&](int in, int j, bool first, bool rr) -> int {
+    if (halo_remote(c, bf.R[in], 1)) return 1;
+    PcsiArgs a = pcsi_args(c, bf, in, j);
+    a.remote_ghosts = 1;
+    if (first) hipLaunchKernelGGL((k_pcsi_step<true, false>), G, B, 0, c->stream, c->g, a);
+    else if (rr) hipLaunchKernelGGL((k_pcsi_step<false, true>), G, B, 0, c->stream, c->g, a);
+    else hipLaunchKernelGGL((k_pcsi_step<false, false>), G, B, 0, c->stream, c->g, a);
+    return 0;
+  };
+  if (step(0, 0, true, false)) return 1;
+  int in = 1;
+  c->numIterations = cf.max_iterations;
+  double rr = 0.0;
+  for (int m = 1; m <= cf.max_iterations; ++m) {
+    const bool check = (m % freq == 0) && m >= start;
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->pcsi_base, m - 1);
+    if (step(in, 1, false, check)) return 1;
+    in = 1 - in;
+    if (check) {
+      hipLaunchKernelGGL(k_block_sums_global<1>, dim3(nbt), dim3(POP_RED_THREADS), 0, c->stream, (const double *)c->partial, c->nchunk, c->loc_of_gid, c->redbuf);
+      if (c->allred(c->comm_user, 0, nbt)) { c->err = "distributed P-CSI: allreduce failed"; return 1; }
+      hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, c->redbuf, nbt, c->sc, (int)FIN_RR);
+      SolverScalars s;
+      if (read_scalars(c, &s)) return 1;
+      rr = s.rr;
+      if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
+    }
+  }
+  if (in == 1) HIPCHK(c, hipMemcpyAsync(bf.X[0], bf.X[1], sizeof(double) * a2, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, bf.X[0], c->srcmap, a2);
+  c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
+  HIPCHK(c, hipGetLastError());
+  if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCSI: solver not converged"; return 2; }
+  return 0;
+}
+
 int need_device(pop_ctx *c) {
   if (!c) return 1;
   if (c->host_only) { c->err = "context was created host-only: no GPU path available (there is no CPU fallback)"; return 1; }
@@ -691,6 +809,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   { std::vector<int> io(h.nblocks_tot); for (int b = 0; b < h.nblocks_tot; ++b) io[b] = b; if (dev_upload(c, &c->iota, io.data(), io.size())) return 1; }
   if (dev_alloc(c, &c->sc, 1)) return 1;
   { std::vector<int> gid(h.nblocks); for (int lb = 0; lb < h.nblocks; ++lb) gid[lb] = h.local_ids[lb] - 1; if (dev_upload(c, &c->gid, gid.data(), gid.size())) return 1; }
+  { std::vector<int> log(h.nblocks_tot, -1); for (int lb = 0; lb < h.nblocks; ++lb) log[h.local_ids[lb] - 1] = lb; if (dev_upload(c, &c->loc_of_gid, log.data(), log.size())) return 1; }
   // halo plan lists
   c->ncopy = (int)h.halo.copy_dst.size(); c->nfill = (int)h.halo.fill_dst.size();
   if (c->ncopy && (dev_upload(c, &c->copy_dst, h.halo.copy_dst.data(), c->ncopy) || dev_upload(c, &c->copy_src, h.halo.copy_src.data(), c->ncopy))) return 1;
@@ -700,6 +819,17 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     if (d.nsend && dev_upload(c, &d.send_src, pp.send_src.data(), d.nsend)) return 1;
     if (d.nrecv && dev_upload(c, &d.recv_dst, pp.recv_dst.data(), d.nrecv)) return 1;
     c->peers.push_back(d);
+  }
+  {   // concatenated peer lists
+    std::vector<int> ss, st, sc, rd, rt, rc;
+    for (auto &pp : h.halo.peers) {
+      const int s0 = (int)ss.size(), r0 = (int)rd.size();
+      for (int v : pp.send_src) { ss.push_back(v); st.push_back(s0); sc.push_back((int)pp.send_src.size()); }
+      for (int v : pp.recv_dst) { rd.push_back(v); rt.push_back(r0); rc.push_back((int)pp.recv_dst.size()); }
+    }
+    c->nsend_all = (int)ss.size(); c->nrecv_all = (int)rd.size();
+    if (c->nsend_all && (dev_upload(c, &c->sa_src, ss.data(), ss.size()) || dev_upload(c, &c->sa_start, st.data(), st.size()) || dev_upload(c, &c->sa_cnt, sc.data(), sc.size()))) return 1;
+    if (c->nrecv_all && (dev_upload(c, &c->ra_dst, rd.data(), rd.size()) || dev_upload(c, &c->ra_start, rt.data(), rt.size()) || dev_upload(c, &c->ra_cnt, rc.data(), rc.size()))) return 1;
   }
   {   // source map for the fused solver path: ghost cell -> local source cell, -1 = fill value
     std::vector<int> sm(a2);
@@ -1026,12 +1156,17 @@ int pop_baroclinic_driver(pop_ctx *c) {
 int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
   if (c->h.c.solver_choice == 2) return solver_chrongear(c);
-  if (c->h.c.solver_choice == 3) return c->fused_ok ? solver_pcsi_fused(c) : solver_pcsi(c);
+  if (c->h.c.solver_choice == 3) {
+    if (c->fused_ok) return solver_pcsi_fused(c);
+    if (c->h.nranks > 1 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcsi_fused_dist(c);
+    return solver_pcsi(c);
+  }
   if (c->replicated) {
     if (!c->allred || !c->redbuf || c->red_doubles < 2LL * c->g.n2 * c->h.nblocks_tot) { c->err = "replicated solve needs pop_set_comm with a reduce buffer of pop_reduce_buffer_doubles()"; return 1; }
     return solver_pcg_replicated(c);
   }
   if (c->fused_ok) { SolveView v = local_view(c); const int e = solver_pcg_fused(c, v); c->S0 = v.S0; c->S1 = v.S1; return e; }
+  if (c->h.nranks > 1 && c->h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcg_fused_dist(c);
   return solver_pcg(c);
 }
 int pop_solver_get_diagnostics(const pop_ctx *c, int *it, double *rms) {
