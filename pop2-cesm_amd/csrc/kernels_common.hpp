@@ -130,6 +130,30 @@ __device__ __forceinline__ double mwjf_eval(const MwjfP &c, const MwjfTS &x) {
   const double DEN = 1.0 / W2;
   return W1 * DEN;
 }
+// Variant for many evaluations of the same (T,S) at different pressures (KPP buoydiff): the whole second
+// term of the denominator, SQ*(ds1t0 + TQ*(ds1t1 + TQ*TQ*ds1t3) + SQR*(dsqt0 + TQ*TQ*dsqt2)), does not depend on
+// pressure, nor does the square root inside it; it is formed once (same operations, same order) and reused.
+struct MwjfTS2 { double TQ, SQ, A2; };
+__device__ __forceinline__ MwjfTS2 mwjf_prep2(double TK, double SK) {
+  const double ds1t0 = 2.14691708e-3, ds1t1 = -9.27062484e-6, ds1t3 = -1.78343643e-10, dsqt0 = 4.76534122e-6, dsqt2 = 1.63410736e-9;
+  MwjfTS2 r;
+  r.TQ = fmin(TK, 999.0); r.TQ = fmax(r.TQ, -2.0);
+  double SQ = fmin(SK, 0.999); SQ = fmax(SQ, 0.0);
+  r.SQ = 1000.0 * SQ;
+  const double SQR = sqrt(r.SQ), TQ = r.TQ;
+  r.A2 = r.SQ * (ds1t0 + TQ * (ds1t1 + TQ * TQ * ds1t3) + SQR * (dsqt0 + TQ * TQ * dsqt2));
+  return r;
+}
+__device__ __forceinline__ double mwjf_eval2(const MwjfP &c, const MwjfTS2 &x) {
+  const double n1 = 7.35212840e+0 * 0.001, n3 = 3.98476704e-4 * 0.001;
+  const double ns1t1 = -7.23268813e-3 * 0.001, ns2t0 = 2.12382341e-3 * 0.001;
+  const double d2 = -4.60835542e-5, d4 = 1.80809186e-10;
+  const double TQ = x.TQ, SQ = x.SQ;
+  const double W1 = c.n0 + TQ * (n1 + TQ * (c.n2 + n3 * TQ)) + SQ * (c.ns1t0 + ns1t1 * TQ + ns2t0 * SQ);
+  const double W2 = c.d0 + TQ * (c.d1 + TQ * (d2 + TQ * (c.d3 + d4 * TQ))) + x.A2;
+  const double DEN = 1.0 / W2;
+  return W1 * DEN;
+}
 template <bool DERIV>
 __device__ __forceinline__ double mwjf_rho(const MwjfP &c, double TK, double SK, double *drdt, double *drds) {
   const double n1 = 7.35212840e+0 * 0.001, n3 = 3.98476704e-4 * 0.001;

@@ -97,10 +97,10 @@ k_kpp_buoydiff(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
 // ---- buoydiff, column form for bandwidth-bound grids ------------------------------------------
 // The 3-D-parallel kernel re-reads the top kref levels of T and S for every level (66 GB through the
 // fabric at tx0.1v3 for 17 GB of algorithmic traffic) and repeats the pressure-independent half of
-// every equation-of-state evaluation.  Here one thread owns a column: the clamped T, 1000*S and its
-// square root of the top KR levels sit in registers (KR >= max kref, checked by the host), every
-// field is read once, and only the pressure-dependent polynomials are re-evaluated.  Same operations
-// in the same order as k_kpp_buoydiff.
+// every equation-of-state evaluation.  Here one thread owns a column: the clamped T, 1000*S and the
+// pressure-independent second term of the denominator (mwjf_prep2) of the top KR levels sit in registers
+// (KR >= max kref, checked by the host), every field is read once, and only the pressure-dependent
+// polynomials are re-evaluated.  Same operations in the same order as k_kpp_buoydiff.
 template <int KR>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_buoydiff_col(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
@@ -110,32 +110,33 @@ k_kpp_buoydiff_col(DevGrid g, KppDev kp, const double *__restrict__ T, const dou
   const int km = g.km;
   const long long n2 = g.n2;
   const int kmt = g.KMT[c.q2];
-  MwjfTS top[KR + 1];
+  MwjfTS2 top[KR + 1];
 #pragma unroll
   for (int t = 1; t <= KR; ++t) {
     const int kk = (t <= km) ? t : km;
     const long long o = c.base3 + (long long)(kk - 1) * n2;
-    top[t] = mwjf_prep(tmask(T[o]), S[o]);
+    top[t] = mwjf_prep2(tmask(T[o]), S[o]);
   }
   DBSFC[c.base3] = 0.0;
-  MwjfTS xkm = top[1];
+  MwjfTS2 xkm = top[1];
   for (int k = 2; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
-    const MwjfTS xk = mwjf_prep(tmask(T[o]), S[o]);
+    const MwjfTS2 xk = mwjf_prep2(tmask(T[o]), S[o]);
     const MwjfP P = mwjf_level(g.pressz[k]);
-    const double rhokm = mwjf_eval(P, xkm);
-    const double rhok = mwjf_eval(P, xk);
+    const double rhokm = mwjf_eval2(P, xkm);
+    const double rhok = mwjf_eval2(P, xk);
     const double surfthick = KPP_EPSSFC * g.zt[k];
     const int kref = kp.kref[k];
-    MwjfTS xr = top[1];
+    // kref is wave-uniform: the predicated iterations below are skipped as a whole
+    MwjfTS2 xr = top[1];
 #pragma unroll
     for (int t = 2; t <= KR; ++t) if (t == kref) xr = top[t];
-    double rhoavg = mwjf_eval(P, xr);
+    double rhoavg = mwjf_eval2(P, xr);
     if (kref != 1) {
       rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
 #pragma unroll
       for (int kt = 1; kt <= KR - 1; ++kt)
-        if (kt <= kref - 1) rhoavg = rhoavg + g.dz[kt] * mwjf_eval(P, top[kt]);
+        if (kt <= kref - 1) rhoavg = rhoavg + g.dz[kt] * mwjf_eval2(P, top[kt]);
       rhoavg = rhoavg / surfthick;
     }
     double dbs = 0.0, dbl = 0.0;
@@ -553,10 +554,11 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   K->max_kref = 1;
   for (int kk = 1; kk <= km; ++kk) K->max_kref = std::max(K->max_kref, kref[kk]);
   // column (register) forms: bandwidth-bound grids only -- below ~2^19 columns the 3-D-parallel forms win on
-  // parallelism.  Measured at tx0.1v3: ushear 11.2 -> 2.7 ms; buoydiff 15.5 -> 16.3 ms (its 3 x 24 register
-  // doubles leave one wave per SIMD for a VALU-bound kernel), so only ushear switches by default.
-  // POP_KPP_COL = bit mask (1 ushear, 2 buoydiff) overrides.
-  K->col = ((h.n2 * h.nblocks > (1u << 19)) && K->max_kref <= 24) ? 1 : 0;
+  // parallelism.  Measured at tx0.1v3: ushear 11.2 -> 2.7 ms; buoydiff 16.1 -> 14.3 ms (VALU-bound either way:
+  // the column form halves the instruction count by hoisting the pressure-independent half of the equation of
+  // state, but its 3 x 20 register doubles leave one wave per SIMD).  POP_KPP_COL = bit mask (1 ushear,
+  // 2 buoydiff) overrides.
+  K->col = ((h.n2 * h.nblocks > (1u << 19)) && K->max_kref <= 24) ? 3 : 0;
   if (getenv("POP_KPP_COL")) K->col = (K->max_kref <= 24) ? atoi(getenv("POP_KPP_COL")) : 0;
   (void)g; (void)m;
   return 0;
@@ -570,7 +572,8 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   const dim3 GC(col_grid(g, POP_COL_THREADS), g.nblocks), BC(POP_COL_THREADS);
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);
   double *DBLOC = s.S3a, *DBSFC = s.S3b, *WU = s.S3c, *VISC = s.S3d, *RIW = s.E3;
-  if (g_kpp_col & 2) hipLaunchKernelGGL(k_kpp_buoydiff_col<24>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  if ((g_kpp_col & 2) && KH.max_kref <= 20) hipLaunchKernelGGL(k_kpp_buoydiff_col<20>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  else if (g_kpp_col & 2) hipLaunchKernelGGL(k_kpp_buoydiff_col<24>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
   if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
