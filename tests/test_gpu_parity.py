@@ -136,6 +136,9 @@ def force_kpp_case(gpu, orc):
     ("tiny", {"tadvect": 2}, 5),                                     # third-order upwind tracer advection
     ("tiny", {"tadvect": 2, "vmix_choice": 3, "km": 24, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21}, 4),
     ("gx3v7", {"tadvect": 2}, 3),
+    ("test", {}, 10),                                                # BASELINE configs[0]: test_domain_size, 96 blocks, 10 steps
+    ("tiny", {"ew_boundary": 0}, 3),                                 # closed east-west boundary
+    ("tiny", {"impcor": 0, "lbouss_correct": 1, "reset_to_freezing": 0, "tmix_opt": 0}, 3),
     ("tiny", {"solver_choice": 3}, 4),                               # P-CSI (no inner product per iteration)
     ("gx3v7", {"solver_choice": 3}, 3),
     ("tiny", {"solver_choice": 3, "block_size_x": 48, "block_size_y": 40, "vmix_choice": 3, "km": 24}, 4),
