@@ -492,16 +492,24 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
 }
 
 // ---- VVC = tgrid_to_ugrid(VISC) masked by k < KMU; VVC(km) = 0.  3-D parallel ---------------
+#define POP_VVC_KC 8   // levels per thread: the four averaging weights and KMU are loaded once per chunk
 __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__restrict__ VVC) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y + 1, b = blockIdx.z;
+  const int k0 = blockIdx.y * POP_VVC_KC + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
-  const long long q2 = (long long)b * g.n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
-  double v = 0.0;
-  if (k <= g.km - 1 && k < g.KMU[q2] && i < g.nxb - 1 && j < g.nyb - 1)
-    v = g.AU0[q2] * VISC[o] + g.AUN[q2] * VISC[o + nxb] + g.AUE[q2] * VISC[o + 1] + g.AUNE[q2] * VISC[o + nxb + 1];
-  VVC[o] = v;
+  const long long q2 = (long long)b * g.n2 + p2;
+  const bool in = i < g.nxb - 1 && j < g.nyb - 1;
+  const int kmu = g.KMU[q2];
+  const double au0 = g.AU0[q2], aun = g.AUN[q2], aue = g.AUE[q2], aune = g.AUNE[q2];
+  const int k1 = min(k0 + POP_VVC_KC - 1, g.km);
+  for (int k = k0; k <= k1; ++k) {
+    const long long o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
+    double v = 0.0;
+    if (k <= g.km - 1 && k < kmu && in)
+      v = au0 * VISC[o] + aun * VISC[o + nxb] + aue * VISC[o + 1] + aune * VISC[o + nxb + 1];
+    VVC[o] = v;
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------
@@ -582,7 +590,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                      (const double *)DBSFC, (const double *)WU);
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                      s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
-  hipLaunchKernelGGL(k_kpp_vvc, G3, dim3(256), 0, st, g, (const double *)VISC, s.VVC);
+  hipLaunchKernelGGL(k_kpp_vvc, dim3((g.n2 + 255) / 256, (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(256), 0, st, g, (const double *)VISC, s.VVC);
   if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }
   (void)h;
   return 0;
