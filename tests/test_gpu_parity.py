@@ -355,6 +355,25 @@ def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
     gpu.close(); orc.close()
 
 
+@pytest.mark.parametrize("solver", [1, 2, 3])
+def test_solver_error_convention(pkg, orclib_built, solver):
+    """POP_SolversMod.F90:1492-1497: hitting maxIterations is an error (errorCode set, message) unless
+    convergenceCriterion == 0, in which case the solver simply runs maxIterations steps."""
+    cfg = named_config("tiny", solver_choice=solver, max_iterations=20, convergence_check_freq=10)
+    cfg.reserved_i[1] = 10                                  # PCSI: start checking early
+    cfg.convergence_criterion = 1.0e-30                      # unreachable
+    m = pkg.PopModel(cfg)
+    with pytest.raises(pkg.PopError, match="not converged"):
+        m.step()
+    m.close()
+    cfg.convergence_criterion = 0.0
+    m, o = pkg.PopModel(cfg), Oracle(cfg)
+    m.step(); o.step()
+    assert m.solver_diagnostics()[0] == 20 == o.L.orc_solver_iterations(o.h)
+    assert relerr(m.get("PSURF", 1), o.f2("PSURF", 1)) < TOL_SOLVE
+    m.close(); o.close()
+
+
 def test_fused_pcsi_is_bitwise_the_unfused_pcsi(pkg, monkeypatch):
     """P-CSI: the one-launch-per-iteration form (neighbour updates recomputed in the matvec, ping-pong state,
     hipGraph per check interval) against the operation-by-operation form with explicit halo updates."""
