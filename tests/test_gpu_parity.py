@@ -276,6 +276,29 @@ def test_momentum_kernels_agree_bitwise(pkg, monkeypatch, kw):
             assert np.array_equal(a, b), rows
 
 
+@pytest.mark.parametrize("kw,env", [
+    ({"km": 62}, {}),                                                    # tx0.1v3 level count: k_impvmixu_reg<62>, generic tracer solve
+    ({"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21},
+     {"POP_REG_THOMAS_T": "1", "POP_KPP_COL": "3", "POP_XCD_REMAP": "0"}),   # the tx0.1v3 kernel selection + register tracer solve
+    ({"km": 60, "vmix_choice": 3}, {"POP_REG_THOMAS_T": "0", "POP_KPP_COL": "3"}),
+])
+def test_production_level_counts_match_oracle(pkg, orclib_built, monkeypatch, kw, env):
+    """Kernels that are compiled for the production level counts (km = 60, 62) or selected by grid size are
+    forced here on a grid small enough for the oracle, so every kernel the tx0.1v3 / gx1v7 bench runs has a
+    parity case."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = named_config("tiny", **kw)
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
+    tol = TOL_LOCAL
+    for s in range(1, 4):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+    gpu.close(); orc.close()
+
+
 @pytest.mark.parametrize("kw", [{"vmix_choice": 3, "km": 24}, {"vmix_choice": 3, "km": 24, "ldbl_diff": 1, "block_size_x": 48, "block_size_y": 40}])
 def test_kpp_column_kernels_agree_bitwise(pkg, orclib_built, monkeypatch, kw):
     """buoydiff / ushear exist in a 3-D-parallel form (small grids) and a column form with the top
