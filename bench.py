@@ -148,7 +148,7 @@ def cpu_baseline(cfg, budget_s=20.0):
 
 
 # one HIP kernel per phase name (pop_time_phase); 'vmix' is a multi-kernel phase and is listed only
-KERNEL_OF_PHASE = {"tracer_rhs": "k_tracer_rhs", "momentum_rhs": "k_momentum_rhs_lds", "state": "k_state3d",
+KERNEL_OF_PHASE = {"tracer_rhs": "k_tracer_rhs_lds", "momentum_rhs": "k_momentum_rhs_lds", "state": "k_state3d",
                    "impvmixu": "k_impvmixu", "add_btrop": "k_add_barotropic"}
 
 

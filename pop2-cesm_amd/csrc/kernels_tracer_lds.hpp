@@ -1,0 +1,162 @@
+// kernels_tracer_lds.hpp -- tracer right-hand side (centred advection) with the horizontal stencils staged
+// through LDS.  Same arithmetic, evaluation order and results as k_tracer_rhs<false,false>
+// (kernels_baroclinic.hpp; tracer_update, baroclinic.F90:1981-2300); only the source of the neighbours
+// changes.  A workgroup owns a 64 x R tile of columns and marches k; per level every thread loads ITS cell of
+// U, V, T, S (curtime) and the two mixing-time tracers plus one halo cell into a double-buffered LDS tile
+// and reads the 5-point / corner neighbours from there, with the next level's cells already in flight.
+// At tx0.1v3 the direct-load kernel moves 104 GB through the fabric for 43 GB of algorithmic reads and runs at
+// the fabric ceiling; the tile cuts the re-fetch to the halo overhead.
+#pragma once
+#include "kernels_baroclinic.hpp"
+
+namespace pop {
+
+template <int R>
+struct TrcTile {
+  static constexpr int W = POP_COL_THREADS + 2, H = R + 2, N = W * H, NHALO = N - POP_COL_THREADS * R;
+  double u[2][N], v[2][N], tc[2][2][N], tm[2][2][N];
+  static_assert(NHALO <= POP_COL_THREADS * R, "every halo cell needs a thread");
+};
+
+template <int R>
+__global__ void __launch_bounds__(POP_COL_THREADS * R)
+k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
+  using T = TrcTile<R>;
+  __shared__ T t;
+  const int nxb = g.nxb, nyb = g.nyb, km = g.km;
+  const long long n2 = g.n2;
+  const int tiles_i = (nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
+  const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i, b = blockIdx.y;
+  const int i0 = NGHOST + ti * POP_COL_THREADS, j0 = NGHOST + tj * R;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * POP_COL_THREADS + tx;
+  const int i = i0 + tx, j = j0 + ty;
+  const bool inb = i < nxb && j < nyb;
+  const bool act = inb && i + 1 <= g.ie && j + 1 <= g.je;
+  const int p2 = inb ? j * nxb + i : 0;
+  const long long q2 = (long long)b * n2 + p2, base3 = (long long)b * g.n3 + p2;
+  const int lc = (ty + 1) * T::W + tx + 1;
+  int hl = -1; long long hbase = 0; bool hin = false;
+  if (tid < T::NHALO) {
+    int li, lj;
+    if (tid < T::W) { lj = 0; li = tid; }
+    else if (tid < 2 * T::W) { lj = T::H - 1; li = tid - T::W; }
+    else if (tid < 2 * T::W + R) { lj = 1 + (tid - 2 * T::W); li = 0; }
+    else { lj = 1 + (tid - 2 * T::W - R); li = T::W - 1; }
+    hl = lj * T::W + li;
+    const int hi = i0 - 1 + li, hj = j0 - 1 + lj;
+    hin = hi >= 0 && hi < nxb && hj >= 0 && hj < nyb;
+    hbase = (long long)b * g.n3 + (hin ? hj * nxb + hi : 0);
+  }
+  int kmt = 0, kmtn = 0, kmts = 0, kmte = 0, kmtw = 0;
+  double dtn = 0, dts = 0, dte = 0, dtw = 0, dyu00 = 0, dyu0m = 0, dyum0 = 0, dyumm = 0, dxu00 = 0, dxu0m = 0, dxum0 = 0, dxumm = 0;
+  double tarear = 0, psfac = 0, wtk = 0, stf[2] = {0, 0}, tfw[2] = {0, 0};
+  if (act) {
+    kmt = g.KMT[q2]; kmtn = g.KMTN[q2]; kmts = g.KMTS[q2]; kmte = g.KMTE[q2]; kmtw = g.KMTW[q2];
+    dtn = g.DTN[q2]; dts = g.DTS[q2]; dte = g.DTE[q2]; dtw = g.DTW[q2];
+    dyu00 = g.DYU[q2]; dyu0m = g.DYU[q2 - nxb]; dyum0 = g.DYU[q2 - 1]; dyumm = g.DYU[q2 - 1 - nxb];
+    dxu00 = g.DXU[q2]; dxu0m = g.DXU[q2 - nxb]; dxum0 = g.DXU[q2 - 1]; dxumm = g.DXU[q2 - 1 - nxb];
+    tarear = g.TAREA_R[q2];
+    psfac = (a.PCUR[q2] - a.POLD[q2]);
+    wtk = a.DH[q2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { stf[n] = a.STF[n][q2]; tfw[n] = a.TFW[n][q2]; }
+  }
+  const long long vdcbase = ((long long)b * (km + 2)) * n2 + p2;
+  struct Lev { double u, v, tc[2], tm[2], to[2], vdc[2], src[2]; };
+  struct Hal { double u, v, tc[2], tm[2]; };
+  auto load_cell = [&](int k) {
+    Lev L{};
+    if (inb) {
+      const long long o = base3 + (long long)(k - 1) * n2;
+      L.u = a.UCUR[o]; L.v = a.VCUR[o];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        L.tc[n] = a.TCUR[n][o]; L.tm[n] = a.TMIX[n][o]; L.to[n] = a.TOLD[n][o];
+        L.vdc[n] = a.VDC[n][vdcbase + (long long)k * n2];
+        L.src[n] = a.use_kpp_src ? a.KPP_SRC[n][o] : 0.0;
+      }
+    }
+    return L;
+  };
+  auto load_halo = [&](int k) {
+    Hal Hh{};
+    if (hin) {
+      const long long o = hbase + (long long)(k - 1) * n2;
+      Hh.u = a.UCUR[o]; Hh.v = a.VCUR[o];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) { Hh.tc[n] = a.TCUR[n][o]; Hh.tm[n] = a.TMIX[n][o]; }
+    }
+    return Hh;
+  };
+  Lev cur = load_cell(1);
+  Hal hal = load_halo(1);
+  double vtf[2] = {0, 0}, tc_km1[2] = {0.0, 0.0};
+  double *__restrict__ const TNp[2] = {a.TNEW[0], a.TNEW[1]};
+  for (int k = 1; k <= km; ++k) {
+    const int buf = k & 1;
+    t.u[buf][lc] = cur.u; t.v[buf][lc] = cur.v;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { t.tc[buf][n][lc] = cur.tc[n]; t.tm[buf][n][lc] = cur.tm[n]; }
+    if (hl >= 0) {
+      t.u[buf][hl] = hal.u; t.v[buf][hl] = hal.v;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) { t.tc[buf][n][hl] = hal.tc[n]; t.tm[buf][n][hl] = hal.tm[n]; }
+    }
+    const int kp1 = (k < km) ? k + 1 : km;
+    const Lev nxt = load_cell(kp1);
+    const Hal nhal = load_halo(kp1);
+    __syncthreads();
+    if (act) {
+      const long long o = base3 + (long long)(k - 1) * n2;
+      const double u00 = t.u[buf][lc], u0m = t.u[buf][lc - T::W], um0 = t.u[buf][lc - 1], umm = t.u[buf][lc - 1 - T::W];
+      const double v00 = t.v[buf][lc], v0m = t.v[buf][lc - T::W], vm0 = t.v[buf][lc - 1], vmm = t.v[buf][lc - 1 - T::W];
+      const double UTE = 0.5 * (u00 * dyu00 + u0m * dyu0m);
+      const double UTW = 0.5 * (um0 * dyum0 + umm * dyumm);
+      const double VTN = 0.5 * (v00 * dxu00 + vm0 * dxum0);
+      const double VTS = 0.5 * (v0m * dxu0m + vmm * dxumm);
+      const double hdiv = VTN - VTS + UTE - UTW;
+      double wtkb = 0.0;
+      if (k < km) { const double FC = hdiv * tarear; wtkb = (k < kmt) ? wtk + g.dz[k] * FC : 0.0; }
+      const double CN = (k <= kmtn && k <= kmt) ? dtn : 0.0, CS = (k <= kmts && k <= kmt) ? dts : 0.0;
+      const double CE = (k <= kmte && k <= kmt) ? dte : 0.0, CW = (k <= kmtw && k <= kmt) ? dtw : 0.0;
+      const double CC = -(CN + CS + CE + CW);
+      const double dz2rk = g.dz2r[k], dzrk = g.dzr[k], dzwrk = g.dzwr[k];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const double *TM = t.tm[buf][n], *TC = t.tc[buf][n];
+        const double tc_k = cur.tc[n], tc_kp1 = nxt.tc[n], to_k = cur.to[n], to_kp1 = nxt.to[n];
+        double FT = sp.ah * (CC * TM[lc] + CN * TM[lc + T::W] + CS * TM[lc - T::W] + CE * TM[lc + 1] + CW * TM[lc - 1]);
+        double L = 0.5 * (hdiv * tc_k + VTN * TC[lc + T::W] - VTS * TC[lc - T::W] + UTE * TC[lc + 1] - UTW * TC[lc - 1]) * tarear;
+        if (k != 1) L = L + dz2rk * wtk * (tc_km1[n] + tc_k);
+        if (k < km) L = L - dz2rk * wtkb * (tc_k + tc_kp1);
+        FT = FT - L;
+        if (k == 1) vtf[n] = (kmt >= 1) ? stf[n] : 0.0;
+        const double vtfb = (kmt > k) ? cur.vdc[n] * (to_k - to_kp1) * dzwrk : 0.0;
+        const double vd = (k <= kmt) ? (vtf[n] - vtfb) * dzrk : 0.0;
+        vtf[n] = vtfb;
+        FT = FT + vd;
+        if (k == 1) FT = FT + g.dzr[1] * tfw[n];
+        double src = 0.0;
+        if (a.use_kpp_src) src = src + cur.src[n];
+        FT = FT + src;
+        if (k == 1 && sp.pavg) {
+          if (kmt > 0) TNp[n][o] = a.c2dtt * FT - 2.0 * tc_k * psfac / (sp.grav * g.dz[1]);
+        } else {
+          TNp[n][o] = (k <= kmt) ? a.c2dtt * FT : 0.0;
+        }
+        tc_km1[n] = tc_k;
+      }
+      wtk = wtkb;
+    }
+    cur = nxt; hal = nhal;
+  }
+}
+
+template <int R>
+inline void launch_tracer_lds(const DevGrid &g, const StepParams &sp, const TracerRhsArgs &a, hipStream_t st) {
+  const int tiles_i = (g.nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
+  const int tiles_j = (g.nyb - 2 * NGHOST + R - 1) / R;
+  hipLaunchKernelGGL(k_tracer_rhs_lds<R>, dim3(tiles_i * tiles_j, g.nblocks), dim3(POP_COL_THREADS, R), 0, st, g, sp, a);
+}
+
+}  // namespace pop

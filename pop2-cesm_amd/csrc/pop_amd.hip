@@ -10,6 +10,7 @@
 #include "kernels_mix.hpp"
 #include "kernels_thomas_reg.hpp"
 #include "kernels_momentum_lds.hpp"
+#include "kernels_tracer_lds.hpp"
 #include "kernels_rf.hpp"
 #include "kernels_pcsi.hpp"
 #include "rccl_transport.hpp"
@@ -59,6 +60,7 @@ struct pop_ctx {
   bool no_graph = false, fused_ok = false, replicated = false;
   bool force_presum = false;
   bool reg_thomas_t = true;
+  int trc_lds_rows = 8;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
   int mom_lds_rows = 8;                                    // momentum RHS: LDS tile rows (0 = direct-load kernel)
   bool reg_thomas = true;                                  // column-in-registers Thomas kernels (km = 60, 62)
   SolveView gv{};                                         // replicated barotropic mode: all blocks
@@ -852,6 +854,10 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     }
     c->no_graph = getenv("POP_SOLVER_NOGRAPH") != nullptr;
     if (getenv("POP_MOMENTUM_LDS")) c->mom_lds_rows = atoi(getenv("POP_MOMENTUM_LDS"));
+    // tracer RHS through LDS tiles (kernels_tracer_lds.hpp).  Measured against the direct-load kernel: tx0.1v3 15.0 ms ->
+    // 12.8 (64x4 tiles) / 13.6 (64x8); gx1v7 0.260 ms -> 0.208 (64x4) / 0.192 (64x8).  POP_TRACER_LDS=0|4|8 overrides.
+    c->trc_lds_rows = (h.n2 * h.nblocks > (1u << 19)) ? 4 : 8;
+    if (getenv("POP_TRACER_LDS")) c->trc_lds_rows = atoi(getenv("POP_TRACER_LDS"));
     c->reg_thomas = getenv("POP_GENERIC_THOMAS") == nullptr;
     // tracer solve: the register kernel (1 wave/SIMD, deep load batches) wins while the launch is
     // latency-bound (gx1v7: 0.19 vs 0.30 ms); on bandwidth-bound grids the generic march is faster
@@ -1083,6 +1089,8 @@ static int phase_tracer_rhs(pop_ctx *c) {
   if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->S3a; a.TMIX[1] = c->S3b; }   // del4: second Laplacian acts on D2T
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
   a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
+  if (c->h.c.tadvect == 1 && c->trc_lds_rows == 8) { launch_tracer_lds<8>(c->g, sp, a, c->stream); return 0; }
+  if (c->h.c.tadvect == 1 && c->trc_lds_rows == 4) { launch_tracer_lds<4>(c->g, sp, a, c->stream); return 0; }
   if (c->h.c.tadvect == 2) {
     a.up = c->upw3;
     hipLaunchKernelGGL((k_tracer_rhs<false, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);

@@ -260,12 +260,13 @@ def test_global_sum_matches_serial_rule(pkg, orclib_built):
 @pytest.mark.parametrize("kw", [{}, {"vmix_choice": 3, "km": 24, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21},
                                 {"block_size_x": 48, "block_size_y": 40}])
 def test_momentum_kernels_agree_bitwise(pkg, monkeypatch, kw):
-    """The LDS-tiled momentum kernel (default, 64x8 tiles), its 64x4 form and the direct-load kernel
-    evaluate the same expressions in the same order: results must be identical to the last bit."""
+    """The LDS-tiled momentum and tracer right-hand-side kernels (64x8 and 64x4 tiles) and the direct-load
+    kernels evaluate the same expressions in the same order: results must be identical to the last bit."""
     cfg = named_config("tiny", **kw)
     out = {}
     for rows in ("8", "4", "0"):
         monkeypatch.setenv("POP_MOMENTUM_LDS", rows)
+        monkeypatch.setenv("POP_TRACER_LDS", rows)
         m = pkg.PopModel(cfg)
         for _ in range(3):
             m.step()
