@@ -277,6 +277,117 @@ k_kpp_interior(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
   }
 }
 
+// ---- ri_iwmix + ddmix with the Richardson-number column in registers (km = 60, 62) -------------------
+// Same operations as k_kpp_interior; the three passes over the column (local Ri, 1-2-1 smoothing, coefficients)
+// keep Ri in a fully unrolled register array instead of a scratch field, and the velocity differences carry
+// level k+1 into the next iteration: one read of each input, no RIW traffic.
+template <int KM>
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_interior_reg(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
+                   const double *__restrict__ U, const double *__restrict__ V, const double *__restrict__ DBLOC,
+                   double *__restrict__ VISC, double *__restrict__ VDC1, double *__restrict__ VDC2) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int nxb = g.nxb;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  const bool edge = (c.i == 0 || c.j == 0);
+  double riw[KM];
+  {
+    // pass 1: local Richardson number; U, V at the four surrounding U points, level k carried from k+1
+    const long long off4[4] = {0, -(long long)nxb, -1, -1 - (long long)nxb};
+    double uk[4] = {0, 0, 0, 0}, vk[4] = {0, 0, 0, 0};
+    if (!edge) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { uk[t] = U[c.base3 + off4[t]]; vk[t] = V[c.base3 + off4[t]]; }
+    }
+    double prev = 0.0;
+#pragma unroll
+    for (int k = 1; k <= KM; ++k) {
+      const long long o = c.base3 + (long long)(k - 1) * n2;
+      double vsh = 0.0;
+      if (k < KM && !edge) {
+        double sh[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double un = U[o + off4[t] + n2], vn = V[o + off4[t] + n2];
+          const double du = uk[t] - un, dv = vk[t] - vn;
+          sh[t] = du * du + dv * dv;
+          uk[t] = un; vk[t] = vn;
+        }
+        vsh = 0.25 * sh[0] + 0.25 * sh[1] + 0.25 * sh[2] + 0.25 * sh[3];
+      }
+      const double ri = DBLOC[o] * (kp.zgrid[k] - kp.zgrid[k + 1]) / (vsh + KPP_EPS);
+      const double w0 = (k <= kmt) ? ri : prev;
+      riw[k - 1] = w0;
+      prev = w0;
+    }
+  }
+  // pass 2: 1-2-1 vertical smoothing, nsmooth times (old values carried)
+  for (int n = 0; n < kp.nsmooth; ++n) {
+    if (kmt >= 3) {
+      double w1 = 0.25 * riw[0];
+      double cur = riw[0];
+#pragma unroll
+      for (int k = 1; k <= KM; ++k) {
+        const double nxt = (k < KM) ? riw[k] : cur;
+        riw[k - 1] = w1 + 0.5 * cur + 0.25 * nxt;
+        w1 = 0.25 * cur;
+        cur = nxt;
+      }
+    }
+  }
+  // pass 3: coefficients (+ double diffusion)
+  const long long vb = ((long long)c.b * (KM + 2)) * n2 + c.p2;
+  double ta_u = 0.0, sb_u = 0.0, t_k = T[c.base3], s_k = S[c.base3];
+  if (kp.ldbl_diff) { const MwjfP P = mwjf_level(g.pressz[1]); (void)mwjf_rho<true>(P, tmask(t_k), s_k, &ta_u, &sb_u); }
+#pragma unroll
+  for (int k = 1; k <= KM; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    double fri = fmax(riw[k - 1], 0.0) / KPP_RIINFTY;
+    fri = fmin(fri, 1.0);
+    double visc, vd1 = 0.0, vd2 = 0.0;
+    if (kp.lrich) {
+      const double f = 1.0 - fri * fri;
+      const double f3 = (f * f) * f;
+      visc = kp.bckgrnd_vvc[k] + kp.rich_mix * f3;
+      if (k < KM) { vd2 = kp.bckgrnd_vdc[k] + kp.rich_mix * f3; vd1 = vd2; }
+    } else {
+      visc = kp.bckgrnd_vvc[k];
+      if (k < KM) { vd2 = kp.bckgrnd_vdc[k]; vd1 = vd2; }
+    }
+    if (k >= kmt) { visc = 0.0; vd1 = 0.0; vd2 = 0.0; }
+    if (kp.ldbl_diff) {
+      double alphadt = 0.0, betads = 0.0, ta_n = 0.0, sb_n = 0.0, t_n = 0.0, s_n = 0.0;
+      if (k < KM) {
+        t_n = T[o + n2]; s_n = S[o + n2];
+        const MwjfP P = mwjf_level(g.pressz[k + 1]);
+        (void)mwjf_rho<true>(P, tmask(t_n), s_n, &ta_n, &sb_n);
+        alphadt = -0.5 * (ta_u + ta_n) * (t_k - t_n);
+        betads = 0.5 * (sb_u + sb_n) * (s_k - s_n);
+      }
+      if (alphadt > betads && betads > 0.0) {
+        const double rrho = fmin(alphadt / betads, KPP_RRHO0);
+        const double f = 1.0 - (rrho - 1.0) / (KPP_RRHO0 - 1.0);
+        const double diffdd = KPP_DSFMAX * ((f * f) * f);
+        vd1 = vd1 + 0.7 * diffdd; vd2 = vd2 + diffdd;
+      }
+      double rrho = 0.0, diffdd = 0.0, prandtl = 0.0;
+      if (alphadt < 0.0 && betads < 0.0 && alphadt > betads) {
+        rrho = alphadt / betads;
+        diffdd = 1.5e-2 * 0.909 * exp(4.6 * exp(-0.54 * (1.0 / rrho - 1.0)));
+        prandtl = 0.15 * rrho;
+      }
+      if (rrho > 0.5) prandtl = (1.85 - 0.85 / rrho) * rrho;
+      vd1 = vd1 + diffdd; vd2 = vd2 + prandtl * diffdd;
+      ta_u = ta_n; sb_u = sb_n; t_k = t_n; s_k = s_n;
+    }
+    VISC[o] = visc;
+    VDC1[vb + (long long)k * n2] = vd1;
+    VDC2[vb + (long long)k * n2] = vd2;
+  }
+}
+
 // ---- bldepth, part 1: shear^2 between the surface-layer reference velocity and level kl at U
 // points; 3-D parallel, one thread per (i,j,kl)
 __global__ void __launch_bounds__(256)
@@ -566,7 +677,7 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   // the column form halves the instruction count by hoisting the pressure-independent half of the equation of
   // state, but its 3 x 20 register doubles leave one wave per SIMD).  POP_KPP_COL = bit mask (1 ushear,
   // 2 buoydiff) overrides.
-  K->col = ((h.n2 * h.nblocks > (1u << 19)) && K->max_kref <= 24) ? 3 : 0;
+  K->col = (K->max_kref <= 24) ? ((h.n2 * h.nblocks > (1u << 19)) ? 3 : 1) : 0;   // ushear: column form at every size (gx1v7 vmix 0.716 -> 0.692 ms)
   if (getenv("POP_KPP_COL")) K->col = (K->max_kref <= 24) ? atoi(getenv("POP_KPP_COL")) : 0;
   (void)g; (void)m;
   return 0;
@@ -583,7 +694,10 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   if ((g_kpp_col & 2) && KH.max_kref <= 20) hipLaunchKernelGGL(k_kpp_buoydiff_col<20>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if (g_kpp_col & 2) hipLaunchKernelGGL(k_kpp_buoydiff_col<24>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
-  hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
+  static const bool int_reg = !getenv("POP_KPP_INTERIOR_GENERIC");
+  if (int_reg && g.km == 60) hipLaunchKernelGGL(k_kpp_interior_reg<60>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
+  else if (int_reg && g.km == 62) hipLaunchKernelGGL(k_kpp_interior_reg<62>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
+  else hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
   if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
   else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
   hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
