@@ -214,6 +214,21 @@ __global__ void k_finalize(const double *__restrict__ blocksum, int nblocks_tot,
   }
 }
 
+// Convergence check of the fused solvers in ONE launch: ordered block sums of the (r,r) partials (blocks of the
+// view in block-id order, same rule as k_block_sums + k_finalize), result to the device scalars and straight
+// into pinned host memory -- replaces three stream operations (block sums, finalize, copy) by one.
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_rr_total(const double *__restrict__ partial, int nchunk, int nblocks, SolverScalars *s, SolverScalars *host_s) {
+  double total = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    double r[1];
+    block_sum_ordered<1>(partial + (long long)b * nchunk, nchunk, r);
+    total = total + r[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { s->sum0 = total; s->rr = total; host_s->rr = total; }
+}
+
 // generic masked product sum over the physical domain: partial of a*b*mask (b, mask optional)
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_dot_partial(DevGrid g, const double *__restrict__ A, const double *__restrict__ Bv, const double *__restrict__ M,

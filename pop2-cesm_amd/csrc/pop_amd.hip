@@ -296,9 +296,8 @@ int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
   FusedArgs a = fused_args(c, v);
   hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, a);
   hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, v.g, a);
-  hipLaunchKernelGGL(k_block_sums<1>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, v.partial, v.nchunk, v.gid, v.blocksum);
-  hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, v.blocksum, v.nblocks_tot, c->sc, (int)FIN_RR);
-  HIPCHK(c, hipMemcpyAsync(c->host_sc, c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream));
+  // the view holds every block it sums (single rank or replicated), in block-id order
+  hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_sc);
   return 0;
 }
 int solver_pcg_fused(pop_ctx *c, SolveView &v) {
@@ -560,9 +559,7 @@ static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool
     in = 1 - in;
   }
   if (with_rr) {
-    hipLaunchKernelGGL(k_block_sums<1>, dim3(c->g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->gid, c->blocksum);
-    hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, c->blocksum, c->h.nblocks_tot, c->sc, (int)FIN_RR);
-    hipMemcpyAsync(c->host_sc, c->sc, sizeof(SolverScalars), hipMemcpyDeviceToHost, c->stream);
+    hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)c->partial, c->nchunk, c->g.nblocks, c->sc, c->host_sc);
   }
 }
 int solver_pcsi_fused(pop_ctx *c) {
