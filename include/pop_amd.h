@@ -34,7 +34,7 @@ typedef struct pop_config {
   int nx_global, ny_global, km, nt;   /* domain_size.F90 */
   int block_size_x, block_size_y;     /* domain_size.F90 */
   int ew_boundary;            /* 0 closed, 1 cyclic   (domain.F90 ew_boundary_type) */
-  int ns_boundary;            /* 0 closed, 1 cyclic   (tripole: not in this round) */
+  int ns_boundary;            /* 0 closed, 1 cyclic, 2 tripole (halo updates only: the internal grid is lat-lon) */
   int hmix_momentum;          /* 2 del2, 4 del4       (horizontal_mix.F90:427-472) */
   int hmix_tracer;            /* 2 del2, 4 del4 */
   int lvariable_hmix;         /* hmix_del2.F90:223, hmix_del4.F90:200 */
@@ -112,6 +112,13 @@ int pop_step(pop_ctx *ctx);                      /* step_mod.F90:126      step(e
  * mpi/POP_HaloMod.F90:1732-1773 (2-D), :2766-3211 (3-D), :4122-4585 (4-D: n = -1 updates every
  * tracer of a field with a tracer dimension); on a device-resident field */
 int pop_halo_update(pop_ctx *ctx, const char *name, int tl, int n);
+/* the same with the reference's fieldLoc / fieldKind arguments (POP_GridHorzMod / POP_FieldMod constants):
+ * field_loc 0 centre, 1 NE corner, 2 N face, 3 E face; field_kind 0 scalar, 1 vector, 2 angle.  They matter
+ * on a tripole northern boundary only (mpi/POP_HaloMod.F90:1936-2050: mirrored copy with offsets and sign,
+ * symmetrised degenerate top row for NE-corner / N-face fields; single-rank decompositions). */
+int pop_halo_update_loc(pop_ctx *ctx, const char *name, int tl, int n, int field_loc, int field_kind);
+int pop_halo_update_host_r8_loc(pop_ctx *ctx, double *array, int nz, double fill, int field_loc, int field_kind);
+int pop_halo_update_host_i4_loc(pop_ctx *ctx, int *array, int nz, int fill, int field_loc, int field_kind);
 /* host-array variants used at init time and by the unit-test rule of
  * test/unit/halo/POP.F90Dipole (nz = product of trailing dims) */
 int pop_halo_update_host_r8(pop_ctx *ctx, double *array, int nz, double fill);

@@ -68,7 +68,7 @@ static void create_blocks(orc_model *m) {
         int g = js - nghost + j - 1;
         if (g < 1) g = (c->ns_boundary == 1) ? g + c->ny_global : 0;
         if (g > c->ny_global + nghost) g = 0;
-        else if (g > c->ny_global) g = (c->ns_boundary == 1) ? g - c->ny_global : 0;
+        else if (g > c->ny_global) g = (c->ns_boundary == 1) ? g - c->ny_global : (c->ns_boundary == 2) ? -g : 0;   /* tripole: blocks.F90:205-208 */
         else if (g == c->ny_global && j > m->blk_jb[n]) m->blk_je[n] = j;
         jg[j - 1] = g;
       }
@@ -137,6 +137,77 @@ void orc_halo_update_int(orc_model *m, int *a) {
         a[(size_t)b * n2 + (size_t)(j - 1) * nxb + (i - 1)] = v;
       }
   }
+}
+
+/* ------------------------------------------------------------------ */
+/* Tripole northern boundary of a halo update, as the reference does it (mpi/POP_HaloMod.F90:1936-2050 for
+ * 2-D r8; :2280-2394 i4; same in the 3-D/4-D variants): the top haloWidth+1 physical rows of the whole
+ * domain are gathered into a global buffer (POP_HaloMsgCreate :5830-5862: buffer row j <- block row
+ * je-1-haloWidth+j), the degenerate top row is symmetrised for NE-corner and N-face fields, and every cell
+ * of rows je..je+haloWidth of the northern blocks (E-W ghost columns included) is copied out of the mirrored
+ * buffer address (:5864-5882: iSrc = nxGlobal-iGlobal(i)+1, jSrc = haloWidth+3-j) shifted by the location's
+ * offsets, times the sign of the field kind.  loc: 0 centre, 1 NE corner, 2 N face, 3 E face;
+ * kind: 0 scalar, 1 vector, 2 angle.  Call after the ordinary update (north ghosts of the top blocks carry
+ * j_glob < 0 there and receive the fill value first).                                              */
+#define ORC_TRIPOLE_BODY(TYPE, ABSF, AVG)                                                                       \
+  const orc_config *c = &m->c;                                                                                \
+  const int nxb = m->nxb, nyb = m->nyb, nx = c->nx_global, hw = 2;                                            \
+  const size_t n2 = m->n2;                                                                                    \
+  const int isign = (kind == 0) ? 1 : -1;                                                                     \
+  int ioffset = 0, joffset = 0;                                                                               \
+  if (loc == 1) { ioffset = 1; joffset = 1; } else if (loc == 3) { ioffset = 1; } else if (loc == 2) { joffset = 1; } \
+  TYPE *buf = (TYPE *)calloc((size_t)(nx + 1) * (hw + 2), sizeof(TYPE));                                      \
+  for (int k = 0; k < nz; k++) {                                                                              \
+    for (int b = 0; b < m->nblocks; b++) {        /* copy in: northern blocks */                              \
+      const int *ig = m->i_glob + (size_t)b * nxb, *jg = m->j_glob + (size_t)b * nyb;                         \
+      const int ib = m->blk_ib[b], ie = m->blk_ie[b], je = m->blk_je[b];                                      \
+      if (!(jg[je] < 0)) continue;                                                                            \
+      for (int j = 1; j <= hw + 1; j++) for (int i = ib; i <= ie; i++)                                        \
+        buf[(size_t)j * (nx + 1) + ig[i - 1]] = a[((size_t)b * nz + k) * n2 + (size_t)(je - 1 - hw + j - 1) * nxb + (i - 1)]; \
+    }                                                                                                         \
+    TYPE *top = buf + (size_t)(hw + 1) * (nx + 1);                                                            \
+    if (loc == 1) {                                                                                           \
+      for (int i = 1; i <= nx / 2; i++) {                                                                     \
+        const int iDst = nx - i;                                                                              \
+        const TYPE x1 = top[i], x2 = top[iDst];                                                               \
+        const TYPE xavg = AVG(ABSF(x1), ABSF(x2));                                                            \
+        top[i] = isign * ((x2 < 0) ? -xavg : xavg);                                                           \
+        top[iDst] = isign * ((x1 < 0) ? -xavg : xavg);                                                        \
+      }                                                                                                       \
+      top[nx] = isign * top[nx];                                                                              \
+    } else if (loc == 2) {                                                                                    \
+      for (int i = 1; i <= nx / 2; i++) {                                                                     \
+        const int iDst = nx + 1 - i;                                                                          \
+        const TYPE x1 = top[i], x2 = top[iDst];                                                               \
+        const TYPE xavg = AVG(ABSF(x1), ABSF(x2));                                                            \
+        top[i] = isign * ((x2 < 0) ? -xavg : xavg);                                                           \
+        top[iDst] = isign * ((x1 < 0) ? -xavg : xavg);                                                        \
+      }                                                                                                       \
+    }                                                                                                         \
+    for (int b = 0; b < m->nblocks; b++) {        /* copy out */                                              \
+      const int *ig = m->i_glob + (size_t)b * nxb, *jg = m->j_glob + (size_t)b * nyb;                         \
+      const int ie = m->blk_ie[b], je = m->blk_je[b];                                                         \
+      if (!(jg[je] < 0)) continue;                                                                            \
+      for (int j = 1; j <= hw + 1; j++) for (int i = 1; i <= ie + hw; i++) {                                  \
+        int iSrc = nx - ig[i - 1] + 1, jSrc = hw + 3 - j;                                                     \
+        iSrc = iSrc - ioffset; jSrc = jSrc - joffset;                                                         \
+        if (iSrc == 0) iSrc = nx;                                                                             \
+        if (jSrc <= hw + 1)                                                                                   \
+          a[((size_t)b * nz + k) * n2 + (size_t)(je + j - 1 - 1) * nxb + (i - 1)] = isign * buf[(size_t)jSrc * (nx + 1) + iSrc]; \
+      }                                                                                                       \
+    }                                                                                                         \
+  }                                                                                                           \
+  free(buf);
+#define ORC_AVG_R8(x, y) (0.5 * ((x) + (y)))
+#define ORC_AVG_I4(x, y) ((int)lround(0.5 * ((double)(x) + (double)(y))))
+void orc_halo_update_tripole(orc_model *m, double *a, int nz, int loc, int kind) {
+  orc_halo_update(m, a, nz, 0);
+  ORC_TRIPOLE_BODY(double, fabs, ORC_AVG_R8)
+}
+void orc_halo_update_tripole_int(orc_model *m, int *a, int loc, int kind) {
+  const int nz = 1;
+  orc_halo_update_int(m, a);
+  ORC_TRIPOLE_BODY(int, abs, ORC_AVG_I4)
 }
 
 /* ------------------------------------------------------------------ */

@@ -30,7 +30,7 @@ typedef struct {
   int nx_global, ny_global, km, nt;
   int block_size_x, block_size_y;
   int ew_boundary;            /* 0 closed, 1 cyclic */
-  int ns_boundary;            /* 0 closed, 1 cyclic */
+  int ns_boundary;            /* 0 closed, 1 cyclic, 2 tripole (halo updates only) */
   int hmix_momentum;          /* 2 del2, 4 del4 */
   int hmix_tracer;            /* 2 del2, 4 del4 */
   int lvariable_hmix;         /* variable hmix coefficients */
@@ -84,6 +84,9 @@ void   orc_state(orc_model *m, int k, int kk, const double *T, const double *S,
 double orc_state_point(double T, double S_msu, double p_bar);
 void   orc_halo_update(orc_model *m, double *a, int nz, int fieldloc_unused);
 void   orc_halo_update_int(orc_model *m, int *a);
+/* tripole northern boundary (mpi/POP_HaloMod.F90:1936-2050); loc 0 centre, 1 NE corner, 2 N face, 3 E face; kind 0 scalar, 1 vector, 2 angle */
+void   orc_halo_update_tripole(orc_model *m, double *a, int nz, int loc, int kind);
+void   orc_halo_update_tripole_int(orc_model *m, int *a, int loc, int kind);
 double orc_global_sum(orc_model *m, const double *a, const double *mask);
 int    orc_solver_iterations(orc_model *m);
 double orc_solver_rms(orc_model *m);

@@ -55,6 +55,8 @@ def lib():
         "pop_step_tail": (ci, [vp]), "pop_step": (ci, [vp]),
         "pop_halo_update": (ci, [vp, cs, ci, ci]),
         "pop_halo_update_host_r8": (ci, [vp, pd, ci, cd]), "pop_halo_update_host_i4": (ci, [vp, pi, ci, ci]),
+        "pop_halo_update_loc": (ci, [vp, cs, ci, ci, ci, ci]),
+        "pop_halo_update_host_r8_loc": (ci, [vp, pd, ci, cd, ci, ci]), "pop_halo_update_host_i4_loc": (ci, [vp, pi, ci, ci, ci, ci]),
         "pop_global_sum": (ci, [vp, cs, ci, ci, cs, pd]), "pop_solver_run": (ci, [vp]),
         "pop_global_sum_nfields": (ci, [vp, ci, C.POINTER(cs), pi, pi, cs, pd]),
         "pop_global_sum_prod": (ci, [vp, cs, ci, ci, cs, ci, ci, cs, pd]),
@@ -191,6 +193,21 @@ class PopModel:
     # ---- POP_HaloUpdate / POP_GlobalSum / POP_Solvers*
     def halo_update(self, name, tl=1, n=0):
         self._chk(self.L.pop_halo_update(self.h, name.encode(), tl, n))
+
+    LOC = {"center": 0, "NEcorner": 1, "Nface": 2, "Eface": 3}
+    KIND = {"scalar": 0, "vector": 1, "angle": 2}
+
+    def halo_update_loc(self, name, tl=1, n=0, loc="center", kind="scalar"):
+        self._chk(self.L.pop_halo_update_loc(self.h, name.encode(), tl, n, self.LOC[loc], self.KIND[kind]))
+
+    def halo_update_host_loc(self, arr, fill=0, loc="center", kind="scalar"):
+        a = arr
+        nz = a.size // (self.nxb * self.nyb * self.nblocks_tot)
+        if a.dtype == np.int32:
+            self._chk(self.L.pop_halo_update_host_i4_loc(self.h, a.ctypes.data_as(C.POINTER(C.c_int)), nz, int(fill), self.LOC[loc], self.KIND[kind]))
+        else:
+            assert a.dtype == np.float64
+            self._chk(self.L.pop_halo_update_host_r8_loc(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), nz, float(fill), self.LOC[loc], self.KIND[kind]))
 
     def halo_update_host(self, arr, fill=0):
         a = arr

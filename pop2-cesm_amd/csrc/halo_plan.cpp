@@ -59,6 +59,49 @@ void build_halo_plan(HostModel &h) {
     P.max_msg_cells += (long long)std::max(kv.second.send_src.size(), kv.second.recv_dst.size());
     P.peers.push_back(std::move(kv.second));
   }
+  // ---- tripole northern boundary, written as the closed-form rule the reference's unit test states
+  // (test/unit/halo/POP.F90Tripole:330-345 centre, :600-620 E face, :1112-1150 NE corner, N face alike):
+  // ghost row n of a northern block mirrors global row ny+1-n (centre, E face) or ny-n (NE corner, N face) at
+  // column nx-ig+1 (centre, N face) or nx-ig (0 -> nx; E face, NE corner); NE-corner and N-face fields also
+  // replace their top physical row by the symmetrised value of the two degenerate points.
+  if (c.ns_boundary == 2 && h.nranks == 1) {
+    const int nx = c.nx_global, ny = c.ny_global;
+    auto cell_of = [&](int gi, int gj) { int sb, cell; source(gi, gj, sb, cell); return h.block_local[sb] * (int)h.n2 + cell; };
+    for (int loc = 0; loc < 4; ++loc) {
+      TripolePlan &T = P.tripole[loc];
+      const int ioff = (loc == 1 || loc == 3) ? 1 : 0, joff = (loc == 1 || loc == 2) ? 1 : 0;
+      for (int n = 0; n < h.nblocks_tot; ++n) {
+        const BlockInfo &B = h.all_blocks[n];
+        if (!(B.j_glob[B.je] < 0)) continue;                 // j_glob of local row je+1 (0-based index je)
+        const int dl = h.block_local[n];
+        for (int jn = 0; jn <= NGHOST; ++jn) {               // jn = 0: top physical row
+          if (jn == 0 && !joff) continue;
+          const int gj = ny + 1 - jn - joff;                 // source row
+          for (int i = 1; i <= h.nxb; ++i) {
+            const int ig = B.i_glob[i - 1];
+            if (ig <= 0) continue;
+            int si = nx - ig + 1 - ioff; if (si == 0) si = nx;
+            const int dcell = dl * (int)h.n2 + (B.je + jn - 1) * h.nxb + (i - 1);
+            T.dst.push_back(dcell);
+            if (jn == 0) {
+              // row ny after symmetrisation, read at the mirrored column si: its own point is (si), its partner
+              // is the column that mirrors si (ig - ... ) -- the value copied out is the symmetrised value AT si
+              // times isign twice = sign(avg, F(si_partner...)); expressed on global points:
+              //   NE corner: partner of column s is nx - s (s != nx/2, nx);  N face: partner of s is nx + 1 - s
+              // and the copy-out address si is itself the mirror of ig, so the result is the symmetrised value of
+              // column ig: sign(0.5(|F(ig)| + |F(partner(ig))|), F(ig)).
+              const int partner = (loc == 1) ? ((ig == nx || ig == nx / 2) ? ig : nx - ig) : nx + 1 - ig;
+              T.a.push_back(cell_of(ig, ny));
+              T.b.push_back(cell_of(partner, ny));
+            } else {
+              T.a.push_back(cell_of(si, gj));
+              T.b.push_back(-1);
+            }
+          }
+        }
+      }
+    }
+  }
 }
 
 // source map over ALL blocks (single-rank view of the decomposition): interior cells map to

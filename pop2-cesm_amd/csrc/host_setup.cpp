@@ -46,16 +46,17 @@ void make_blocks(HostModel &h) {
       B.ib = NGHOST + 1; B.jb = NGHOST + 1; B.ie = h.nxb - NGHOST; B.je = h.nyb - NGHOST;
       B.i_glob.resize(h.nxb); B.j_glob.resize(h.nyb);
       auto wrap = [](int g, int nglob, int cyclic, int pos1, int lo, int &last) {
-        // g: tentative global index of local position pos1 (1-based); returns the stored index
-        if (g < 1) g = cyclic ? g + nglob : 0;
+        // g: tentative global index of local position pos1 (1-based); returns the stored index;
+        // cyclic == 2: tripole north boundary, the far-side ghost keeps its row as a negative index (blocks.F90:205-208)
+        if (g < 1) g = (cyclic == 1) ? g + nglob : 0;
         if (g > nglob + NGHOST) g = 0;                       // padding
-        else if (g > nglob) g = cyclic ? g - nglob : 0;      // far-side ghost
+        else if (g > nglob) g = (cyclic == 1) ? g - nglob : (cyclic == 2) ? -g : 0;      // far-side ghost
         else if (g == nglob && pos1 > lo) last = pos1;       // last physical point (padded domain)
         return g;
       };
       const int js = jbk * c.block_size_y + 1, is = ibk * c.block_size_x + 1;
-      for (int j = 1; j <= h.nyb; ++j) B.j_glob[j - 1] = wrap(js - NGHOST + j - 1, c.ny_global, c.ns_boundary == 1, j, B.jb, B.je);
-      for (int i = 1; i <= h.nxb; ++i) B.i_glob[i - 1] = wrap(is - NGHOST + i - 1, c.nx_global, c.ew_boundary == 1, i, B.ib, B.ie);
+      for (int j = 1; j <= h.nyb; ++j) B.j_glob[j - 1] = wrap(js - NGHOST + j - 1, c.ny_global, c.ns_boundary, j, B.jb, B.je);
+      for (int i = 1; i <= h.nxb; ++i) B.i_glob[i - 1] = wrap(is - NGHOST + i - 1, c.nx_global, c.ew_boundary == 1 ? 1 : 0, i, B.ib, B.ie);
     }
   // distribution: contiguous runs of block ids per rank (cartesian in j for nbx == 1);
   // clinic and tropic distributions coincide, so POP_RedistributeBlocks is the identity
@@ -145,6 +146,32 @@ static void halo_all(const HostModel &h, T *a, int nz, T fill) {
 void host_halo_r8(const HostModel &h, double *a, int nz, double fill) { halo_all<double>(h, a, nz, fill); }
 void host_halo_i4(const HostModel &h, int *a, int nz, int fill) { halo_all<int>(h, a, nz, fill); }
 
+// tripole pass (HaloPlan::tripole): two phases, because the symmetrised top row reads physical cells it also writes
+template <class T, class Avg>
+static void tripole_all(const HostModel &h, T *a, int nz, int loc, int kind, Avg avg) {
+  const TripolePlan &P = h.halo.tripole[loc];
+  const T isign = (kind == 0) ? (T)1 : (T)-1;
+  const size_t n2 = h.n2;
+  std::vector<T> tmp(P.dst.size());
+  auto at = [&](int cell, int k) -> T & { return a[((size_t)(cell / (int)n2) * nz + k) * n2 + cell % (int)n2]; };
+  for (int k = 0; k < nz; ++k) {
+    for (size_t e = 0; e < P.dst.size(); ++e) {
+      const T x = at(P.a[e], k);
+      if (P.b[e] < 0) tmp[e] = isign * x;
+      else { const T y = at(P.b[e], k); const T m = avg(x < 0 ? -x : x, y < 0 ? -y : y); tmp[e] = (x < 0) ? -m : m; }
+    }
+    for (size_t e = 0; e < P.dst.size(); ++e) at(P.dst[e], k) = tmp[e];
+  }
+}
+void host_halo_r8_loc(const HostModel &h, double *a, int nz, double fill, int loc, int kind) {
+  halo_all<double>(h, a, nz, fill);
+  if (h.c.ns_boundary == 2) tripole_all<double>(h, a, nz, loc, kind, [](double x, double y) { return 0.5 * (x + y); });
+}
+void host_halo_i4_loc(const HostModel &h, int *a, int nz, int fill, int loc, int kind) {
+  halo_all<int>(h, a, nz, fill);
+  if (h.c.ns_boundary == 2) tripole_all<int>(h, a, nz, loc, kind, [](int x, int y) { return (int)std::lround(0.5 * ((double)x + (double)y)); });
+}
+
 // sum over the physical domain, j outer / i inner per block, block sums added in block-id
 // order (serial/global_reductions.F90:237-262; b4b form mpi/POP_ReductionsMod.F90:348-383)
 double host_global_sum(const HostModel &h, const double *a, const double *mask) {
@@ -170,7 +197,10 @@ int host_build(HostModel &h) {
   if (c.nx_global % c.block_size_x || c.ny_global % c.block_size_y) {
     h.err = "block size must divide the global domain (padded blocks not supported)"; return 1;
   }
-  if (c.ns_boundary != 0 && c.ns_boundary != 1) { h.err = "tripole not supported"; return 1; }
+  if (c.ns_boundary < 0 || c.ns_boundary > 2) { h.err = "ns_boundary: 0 closed, 1 cyclic, 2 tripole"; return 1; }
+  if (c.ns_boundary == 2 && (c.ew_boundary != 1 || c.nx_global % 2 || c.block_size_y < NGHOST + 1)) {
+    h.err = "tripole needs a cyclic east-west boundary, even nx_global and blocks of at least nghost+1 rows"; return 1;
+  }
   make_blocks(h);
   if (h.nblocks == 0) { h.err = "rank owns no blocks (more ranks than blocks)"; return 1; }
   if (make_vertical(h)) return 1;

@@ -435,6 +435,29 @@ __global__ void k_halo_unpack(double *__restrict__ F, const int *__restrict__ ds
   F[((long long)(d / n2) * nz + k) * n2 + d % n2] = buf[(long long)k * n + t];
 }
 
+// tripole northern boundary (HaloPlan::tripole): phase 1 evaluates every entry into a buffer, phase 2 stores
+__global__ void k_tripole_eval(const double *__restrict__ F, const int *__restrict__ A, const int *__restrict__ Bc, int n,
+                               double *__restrict__ buf, double isign, int nz, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (t >= n) return;
+  const int ca = A[t], cb = Bc[t];
+  const double x = F[((long long)(ca / n2) * nz + k) * n2 + ca % n2];
+  double r;
+  if (cb < 0) r = isign * x;
+  else {
+    const double y = F[((long long)(cb / n2) * nz + k) * n2 + cb % n2];
+    const double m = 0.5 * (fabs(x) + fabs(y));
+    r = (x < 0.0) ? -m : m;
+  }
+  buf[(long long)k * n + t] = r;
+}
+__global__ void k_tripole_store(double *__restrict__ F, const int *__restrict__ D, int n, const double *__restrict__ buf, int nz, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (t >= n) return;
+  const int d = D[t];
+  F[((long long)(d / n2) * nz + k) * n2 + d % n2] = buf[(long long)k * n + t];
+}
+
 // all peers in one launch: element t of the concatenated list belongs to the message that starts at
 // start[t] cells into the buffer and has cnt[t] cells per level (message = level-major, as above)
 __global__ void k_halo_pack_all(const double *__restrict__ F, const int *__restrict__ src, const int *__restrict__ start,

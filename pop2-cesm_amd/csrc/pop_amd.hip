@@ -74,6 +74,8 @@ struct pop_ctx {
   // all peers concatenated (one pack / unpack launch per halo update)
   int *sa_src = nullptr, *sa_start = nullptr, *sa_cnt = nullptr, *ra_dst = nullptr, *ra_start = nullptr, *ra_cnt = nullptr;
   int nsend_all = 0, nrecv_all = 0;
+  // tripole northern boundary, per field location (single rank)
+  int *tp_dst[4] = {}, *tp_a[4] = {}, *tp_b[4] = {}; int tp_n[4] = {}; double *tp_buf = nullptr;
   // comm hooks
   double *sendbuf = nullptr, *recvbuf = nullptr, *redbuf = nullptr;
   long long comm_doubles = 0, red_doubles = 0;
@@ -181,11 +183,18 @@ int halo_remote(pop_ctx *c, double *F, int nz) {
   if (c->nrecv_all) hipLaunchKernelGGL(k_halo_unpack_all, dim3((c->nrecv_all + 255) / 256, nz), dim3(256), 0, c->stream, F, c->ra_dst, c->ra_start, c->ra_cnt, c->nrecv_all, (const double *)c->recvbuf, nz, n2);
   return 0;
 }
-int halo_update(pop_ctx *c, double *F, int nz, double fill = 0.0) {
+int halo_update(pop_ctx *c, double *F, int nz, double fill = 0.0, int loc = 0, int kind = 0) {
   const int n2 = c->g.n2;
   if (halo_remote(c, F, nz)) return 1;
   const int nloc = c->ncopy + c->nfill;
   if (nloc) hipLaunchKernelGGL(k_halo_local, dim3((nloc + 255) / 256, nz), dim3(256), 0, c->stream, F, c->copy_dst, c->copy_src, c->ncopy, c->fill_dst, c->nfill, fill, nz, n2);
+  if (c->h.c.ns_boundary == 2 && c->tp_n[loc]) {   // tripole northern boundary (mpi/POP_HaloMod.F90:1936-2050)
+    const int n = c->tp_n[loc];
+    if (nz > c->h.km + 2) { c->err = "halo_update: too many levels for the tripole buffer"; return 1; }
+    hipLaunchKernelGGL(k_tripole_eval, dim3((n + 255) / 256, nz), dim3(256), 0, c->stream, (const double *)F, c->tp_a[loc], c->tp_b[loc], n, c->tp_buf,
+                       kind == 0 ? 1.0 : -1.0, nz, n2);
+    hipLaunchKernelGGL(k_tripole_store, dim3((n + 255) / 256, nz), dim3(256), 0, c->stream, F, c->tp_dst[loc], n, (const double *)c->tp_buf, nz, n2);
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -819,6 +828,18 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     if (d.nrecv && dev_upload(c, &d.recv_dst, pp.recv_dst.data(), d.nrecv)) return 1;
     c->peers.push_back(d);
   }
+  if (cfg->ns_boundary == 2) {   // tripole plan (single rank) + evaluation buffer
+    if (h.nranks != 1) { c->err = "tripole halo updates are built for single-rank decompositions"; return 1; }
+    size_t nmax = 0;
+    for (int loc = 0; loc < 4; ++loc) {
+      const TripolePlan &T = h.halo.tripole[loc];
+      c->tp_n[loc] = (int)T.dst.size();
+      nmax = std::max(nmax, T.dst.size());
+      if (c->tp_n[loc] && (dev_upload(c, &c->tp_dst[loc], T.dst.data(), T.dst.size()) || dev_upload(c, &c->tp_a[loc], T.a.data(), T.a.size()) ||
+                           dev_upload(c, &c->tp_b[loc], T.b.data(), T.b.size()))) return 1;
+    }
+    if (dev_alloc(c, &c->tp_buf, nmax * (size_t)(h.km + 2))) return 1;
+  }
   {   // concatenated peer lists
     std::vector<int> ss, st, sc, rd, rt, rc;
     for (auto &pp : h.halo.peers) {
@@ -1311,6 +1332,7 @@ int pop_step_tail(pop_ctx *c) {
 
 int pop_step(pop_ctx *c) {
   if (need_device(c)) return 1;
+  if (c->h.c.ns_boundary == 2) { c->err = "time stepping on a tripole decomposition needs a tripole grid (not built): only halo updates are"; return 1; }
   ScopedPhase ph(c, "STEP");
   int e;
   if ((e = pop_time_manager(c)) || (e = pop_dhdt(c)) || (e = pop_baroclinic_driver(c)) || (e = pop_barotropic_driver(c)) ||
@@ -1331,6 +1353,26 @@ int pop_halo_update(pop_ctx *c, const char *name, int tl, int n) {
   if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
   const int nz = (int)(cnt / ((long long)c->g.n2 * c->g.nblocks));
   return halo_update(c, p, nz);
+}
+int pop_halo_update_loc(pop_ctx *c, const char *name, int tl, int n, int field_loc, int field_kind) {
+  if (need_device(c)) return 1;
+  if (field_loc < 0 || field_loc > 3 || field_kind < 0 || field_kind > 2) { c->err = "pop_halo_update_loc: unknown field location / kind"; return 1; }
+  double *p; long long cnt;
+  if (resolve(c, name, tl, n < 0 ? 0 : n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
+  const int nz = (int)(cnt / ((long long)c->g.n2 * c->g.nblocks));
+  return halo_update(c, p, nz, 0.0, field_loc, field_kind);
+}
+int pop_halo_update_host_r8_loc(pop_ctx *c, double *array, int nz, double fill, int field_loc, int field_kind) {
+  if (c->h.nranks != 1) { c->err = "host halo update needs all blocks on one rank"; return 1; }
+  if (field_loc < 0 || field_loc > 3 || field_kind < 0 || field_kind > 2) { c->err = "unknown field location / kind"; return 1; }
+  host_halo_r8_loc(c->h, array, nz, fill, field_loc, field_kind);
+  return 0;
+}
+int pop_halo_update_host_i4_loc(pop_ctx *c, int *array, int nz, int fill, int field_loc, int field_kind) {
+  if (c->h.nranks != 1) { c->err = "host halo update needs all blocks on one rank"; return 1; }
+  if (field_loc < 0 || field_loc > 3 || field_kind < 0 || field_kind > 2) { c->err = "unknown field location / kind"; return 1; }
+  host_halo_i4_loc(c->h, array, nz, fill, field_loc, field_kind);
+  return 0;
 }
 // host-array halo: valid for single-rank decompositions (all blocks local), used at init time
 int pop_halo_update_host_r8(pop_ctx *c, double *array, int nz, double fill) {

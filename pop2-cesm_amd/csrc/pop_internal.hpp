@@ -33,11 +33,18 @@ struct PeerPlan {
   std::vector<int> send_src;   // local 2-D cell index (block*n2 + j*nxb + i) to pack, in message order
   std::vector<int> recv_dst;   // local 2-D cell index to unpack into, in message order
 };
+// Tripole northern boundary (mpi/POP_HaloMod.F90:1936-2050), per field location: every cell of rows je..je+nghost
+// of the northern blocks is a function of one or two physical cells of the global top rows.
+//   b < 0 : dst = isign * F[a]                                   (mirrored copy; isign = -1 for vector / angle kinds)
+//   b >= 0: dst = sign(0.5*(|F[a]| + |F[b]|), F[a])              (symmetrised degenerate top row, NE-corner / N-face fields)
+// a, b are cells of this rank (single-rank decompositions only).
+struct TripolePlan { std::vector<int> dst, a, b; };
 struct HaloPlan {
   std::vector<int> copy_dst, copy_src;  // ghost <- interior copies between blocks of this rank
   std::vector<int> fill_dst;            // ghosts outside closed boundaries / padding: fill value
   std::vector<PeerPlan> peers;
   long long max_msg_cells = 0;          // sum over peers of max(send, recv) cells
+  TripolePlan tripole[4];               // by location: 0 centre, 1 NE corner, 2 N face, 3 E face (ns_boundary = 2)
 };
 
 // ---- host-side model: everything init-time (restates grid.F90, hmix_del*.F90 init,
@@ -80,6 +87,9 @@ int host_pcsi_prep(HostModel &h);        // host_pcsi.cpp
 void build_halo_plan(HostModel &h);      // halo_plan.cpp
 void host_halo_r8(const HostModel &h, double *a, int nz, double fill);   // single-rank host halo
 void host_halo_i4(const HostModel &h, int *a, int nz, int fill);
+// with field location / kind: the ordinary update, then the tripole pass when ns_boundary = 2
+void host_halo_r8_loc(const HostModel &h, double *a, int nz, double fill, int loc, int kind);
+void host_halo_i4_loc(const HostModel &h, int *a, int nz, int fill, int loc, int kind);
 double host_global_sum(const HostModel &h, const double *a, const double *mask);
 std::vector<int> global_srcmap(const HostModel &h);   // all blocks: ghost -> source cell, -1 = fill
 

@@ -189,6 +189,19 @@
          integer (c_int), value :: block_local
          real (c_double), intent(in) :: corr(*)
       end function
+      integer (c_int) function pop_halo_update_loc(ctx, name, tl, n, loc, kind) bind(C, name='pop_halo_update_loc')
+         import :: c_int, c_ptr, c_char
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+         integer (c_int), value :: tl, n, loc, kind
+      end function
+      integer (c_int) function pop_halo_update_host_r8_loc(ctx, array, nz, fill, loc, kind) bind(C, name='pop_halo_update_host_r8_loc')
+         import :: c_int, c_ptr, c_double
+         type (c_ptr), value :: ctx
+         real (c_double), intent(inout) :: array(*)
+         integer (c_int), value :: nz, loc, kind
+         real (c_double), value :: fill
+      end function
       ! in-library RCCL transport (include/pop_amd.h)
       integer (c_int) function pop_rccl_unique_id(id128) bind(C, name='pop_rccl_unique_id')
          import :: c_int, c_signed_char

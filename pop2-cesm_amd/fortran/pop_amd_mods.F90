@@ -82,26 +82,40 @@
    implicit none
    private
    public :: POP_HaloUpdate, POP_HaloUpdateField
+   ! fieldLoc / fieldKind constants (POP_GridHorzMod.F90, POP_FieldMod.F90), as integers of the C ABI
+   integer (POP_i4), parameter, public :: POP_gridHorzLocCenter = 0, POP_gridHorzLocNEcorner = 1, &
+      POP_gridHorzLocNface = 2, POP_gridHorzLocEface = 3, &
+      POP_fieldKindScalar = 0, POP_fieldKindVector = 1, POP_fieldKindAngle = 2
    interface POP_HaloUpdate
       module procedure POP_HaloUpdate2DR8, POP_HaloUpdate3DR8, POP_HaloUpdate2DI4
    end interface
  contains
    ! device-resident field, addressed by the reference's variable name
-   subroutine POP_HaloUpdateField(name, timeLevel, n, errorCode)
+   subroutine POP_HaloUpdateField(name, timeLevel, n, errorCode, fieldLoc, fieldKind)
       character (*), intent(in) :: name
       integer (POP_i4), intent(in) :: timeLevel, n
       integer (POP_i4), intent(out) :: errorCode
-      errorCode = pop_halo_update(pop_ctx, cstr(name), timeLevel, n)
+      integer (POP_i4), intent(in), optional :: fieldLoc, fieldKind   ! tripole northern boundary only
+      if (present(fieldLoc) .and. present(fieldKind)) then
+         errorCode = pop_halo_update_loc(pop_ctx, cstr(name), timeLevel, n, fieldLoc, fieldKind)
+      else
+         errorCode = pop_halo_update(pop_ctx, cstr(name), timeLevel, n)
+      endif
    end subroutine
    ! host arrays (init-time fields): array(nx_block,ny_block,nblocks)
-   subroutine POP_HaloUpdate2DR8(array, errorCode, fillValue)
+   subroutine POP_HaloUpdate2DR8(array, errorCode, fillValue, fieldLoc, fieldKind)
       real (POP_r8), dimension(:,:,:), intent(inout) :: array
       integer (POP_i4), intent(out) :: errorCode
       real (POP_r8), intent(in), optional :: fillValue
+      integer (POP_i4), intent(in), optional :: fieldLoc, fieldKind
       real (POP_r8) :: fill
       fill = 0.0_POP_r8
       if (present(fillValue)) fill = fillValue
-      errorCode = pop_halo_update_host_r8(pop_ctx, array, 1, fill)
+      if (present(fieldLoc) .and. present(fieldKind)) then
+         errorCode = pop_halo_update_host_r8_loc(pop_ctx, array, 1, fill, fieldLoc, fieldKind)
+      else
+         errorCode = pop_halo_update_host_r8(pop_ctx, array, 1, fill)
+      endif
    end subroutine
    subroutine POP_HaloUpdate3DR8(array, errorCode, fillValue)
       real (POP_r8), dimension(:,:,:,:), intent(inout) :: array    ! (nx,ny,nz,nblocks)

@@ -241,6 +241,37 @@ def test_halo_update_rule_on_device(pkg):
     gpu.close()
 
 
+@pytest.mark.parametrize("loc,kind", [("center", "scalar"), ("center", "vector"), ("NEcorner", "vector"), ("NEcorner", "scalar"),
+                                      ("Nface", "scalar"), ("Eface", "vector")])
+def test_tripole_halo_on_device(pkg, loc, kind):
+    """Device halo update on a tripole decomposition against the rule of test/unit/halo/POP.F90Tripole
+    (2-D and 3-D fields); time stepping on such a decomposition is refused (no tripole grid)."""
+    from test_oracle_fixtures import _tripole_expected
+    cfg = named_config("tiny", ns_boundary=2)
+    m = pkg.PopModel(cfg)
+    nx, ny, nb = cfg.nx_global, cfg.ny_global, m.nblocks
+    rng = np.random.default_rng(9)
+    G = rng.standard_normal((ny, nx)) * 100.0
+    a2 = np.full((nb, m.nyb, m.nxb), -999.0); a3 = np.full((nb, m.km, m.nyb, m.nxb), -999.0)
+    e2 = np.zeros_like(a2); e3 = np.zeros_like(a3)
+    for b in range(nb):
+        blk = m.get_block(b + 1)
+        ig, jg = blk["i_glob"], blk["j_glob"]
+        for j in range(2, m.nyb - 2):
+            a2[b, j, 2:-2] = G[jg[j] - 1, ig[2:-2] - 1]
+        e2[b] = _tripole_expected(G, ig, jg, nx, ny, loc, kind)
+        for k in range(m.km):
+            a3[b, k, 2:-2, 2:-2] = a2[b, 2:-2, 2:-2] * (k + 1)
+            e3[b, k] = _tripole_expected(G * (k + 1), ig, jg, nx, ny, loc, kind)
+    m.set("PSURF", a2, tl=2); m.halo_update_loc("PSURF", tl=2, loc=loc, kind=kind)
+    assert np.array_equal(m.get("PSURF", tl=2), e2)
+    m.set("UVEL", a3, tl=2); m.halo_update_loc("UVEL", tl=2, loc=loc, kind=kind)
+    assert np.array_equal(m.get("UVEL", tl=2), e3)
+    with pytest.raises(pkg.PopError, match="tripole"):
+        m.step()
+    m.close()
+
+
 def test_global_sum_matches_serial_rule(pkg, orclib_built):
     """test/unit/reduction/POP.F90: global sum of a known array (with and without mMask) against a
     serial loop over the physical domain; the GPU tree sum must agree to 1e-14 relative."""
