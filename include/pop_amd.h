@@ -129,6 +129,9 @@ int pop_global_sum(pop_ctx *ctx, const char *name, int tl, int n, const char *ma
 /* the other members of the generic interface (mpi/POP_ReductionsMod.F90:50-64), same b4b rule:
  *   POP_GlobalSumNfields2DR8 :823-1084, POP_GlobalSumProd2DR8 :1395-1618,
  *   POP_GlobalSumScalarR8 :1091-1191 (one value per task), POP_GlobalSum2DI4 :621-816 (integer field) */
+/* with fieldLoc: on a tripole grid fields on north faces (2) / NE corners (1) count the redundant half of the
+ * top row once (:308-341); otherwise identical to pop_global_sum */
+int pop_global_sum_loc(pop_ctx *ctx, const char *name, int tl, int n, const char *mask_name, int field_loc, double *result);
 int pop_global_sum_nfields(pop_ctx *ctx, int nfields, const char *const *names, const int *tl, const int *n,
                            const char *mask_name, double *results);
 int pop_global_sum_prod(pop_ctx *ctx, const char *name_a, int tl_a, int n_a, const char *name_b, int tl_b, int n_b,

@@ -232,6 +232,35 @@ double orc_global_sum(orc_model *m, const double *a, const double *mask) {
   return g;
 }
 
+/* POP_GlobalSum on a tripole grid (mpi/POP_ReductionsMod.F90:308-341): for fields on north faces or NE
+ * corners the top row holds every point twice; the points with iGlobal > nxGlobal/2 are taken out of the
+ * block sum again (added first, then subtracted, as the reference does).  loc: 1 NE corner, 2 N face.   */
+double orc_global_sum_tripole(orc_model *m, const double *a, const double *mask, int loc) {
+  double g = 0.0;
+  const int nxb = m->nxb, nyb = m->nyb;
+  for (int b = 0; b < m->nblocks; b++) {
+    double s = 0.0;
+    const double *A = a + (size_t)b * m->n2;
+    const double *M = mask ? mask + (size_t)b * m->n2 : NULL;
+    for (int j = m->blk_jb[b]; j <= m->blk_je[b]; j++)
+      for (int i = m->blk_ib[b]; i <= m->blk_ie[b]; i++) {
+        size_t p = (size_t)(j - 1) * nxb + (i - 1);
+        if (M) s = s + A[p] * M[p]; else s = s + A[p];
+      }
+    const int *ig = m->i_glob + (size_t)b * nxb, *jg = m->j_glob + (size_t)b * nyb;
+    if (jg[m->blk_je[b]] < 0 && (loc == 1 || loc == 2)) {
+      const int j = m->blk_je[b];
+      for (int i = m->blk_ib[b]; i <= m->blk_ie[b]; i++)
+        if (ig[i - 1] > m->c.nx_global / 2) {
+          size_t p = (size_t)(j - 1) * nxb + (i - 1);
+          if (M) s = s - A[p] * M[p]; else s = s - A[p];
+        }
+    }
+    g = g + s;
+  }
+  return g;
+}
+
 /* ------------------------------------------------------------------ */
 /* vertical grid: source/grid.F90:1549-1709 (vert_grid_internal,
  * compute_dz) and :786-803 (derived quantities)                        */

@@ -88,6 +88,7 @@ void   orc_halo_update_int(orc_model *m, int *a);
 void   orc_halo_update_tripole(orc_model *m, double *a, int nz, int loc, int kind);
 void   orc_halo_update_tripole_int(orc_model *m, int *a, int loc, int kind);
 double orc_global_sum(orc_model *m, const double *a, const double *mask);
+double orc_global_sum_tripole(orc_model *m, const double *a, const double *mask, int loc);
 int    orc_solver_iterations(orc_model *m);
 double orc_solver_rms(orc_model *m);
 

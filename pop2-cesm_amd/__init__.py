@@ -58,6 +58,7 @@ def lib():
         "pop_halo_update_loc": (ci, [vp, cs, ci, ci, ci, ci]),
         "pop_halo_update_host_r8_loc": (ci, [vp, pd, ci, cd, ci, ci]), "pop_halo_update_host_i4_loc": (ci, [vp, pi, ci, ci, ci, ci]),
         "pop_global_sum": (ci, [vp, cs, ci, ci, cs, pd]), "pop_solver_run": (ci, [vp]),
+        "pop_global_sum_loc": (ci, [vp, cs, ci, ci, cs, ci, pd]),
         "pop_global_sum_nfields": (ci, [vp, ci, C.POINTER(cs), pi, pi, cs, pd]),
         "pop_global_sum_prod": (ci, [vp, cs, ci, ci, cs, ci, ci, cs, pd]),
         "pop_global_sum_scalar": (ci, [vp, cd, pd]), "pop_global_sum_i4": (ci, [vp, cs, C.POINTER(ll)]),
@@ -220,6 +221,11 @@ class PopModel:
     def global_sum(self, name, tl=1, n=0, mask=None):
         r = C.c_double()
         self._chk(self.L.pop_global_sum(self.h, name.encode(), tl, n, mask.encode() if mask else None, C.byref(r)))
+        return r.value
+
+    def global_sum_loc(self, name, tl=1, n=0, mask=None, loc="center"):
+        r = C.c_double()
+        self._chk(self.L.pop_global_sum_loc(self.h, name.encode(), tl, n, mask.encode() if mask else None, self.LOC[loc], C.byref(r)))
         return r.value
 
     def global_sum_nfields(self, names, tl=1, n=0, mask=None):

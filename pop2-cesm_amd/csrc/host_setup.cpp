@@ -189,6 +189,30 @@ double host_global_sum(const HostModel &h, const double *a, const double *mask) 
   return g;
 }
 
+// tripole grids: fields on north faces / NE corners hold the top row twice; the points with i_glob > nx/2 are
+// subtracted again from their block sum (mpi/POP_ReductionsMod.F90:308-341)
+double host_global_sum_loc(const HostModel &h, const double *a, const double *mask, int loc) {
+  if (h.c.ns_boundary != 2 || (loc != 1 && loc != 2)) return host_global_sum(h, a, mask);
+  double g = 0.0;
+  for (int b = 0; b < h.nblocks_tot; ++b) {
+    const BlockInfo &B = h.all_blocks[b];
+    double s = 0.0;
+    for (int j = B.jb; j <= B.je; ++j)
+      for (int i = B.ib; i <= B.ie; ++i) {
+        const size_t p = b * h.n2 + (size_t)(j - 1) * h.nxb + (i - 1);
+        s = mask ? s + a[p] * mask[p] : s + a[p];
+      }
+    if (B.j_glob[B.je] < 0)
+      for (int i = B.ib; i <= B.ie; ++i)
+        if (B.i_glob[i - 1] > h.c.nx_global / 2) {
+          const size_t p = b * h.n2 + (size_t)(B.je - 1) * h.nxb + (i - 1);
+          s = mask ? s - a[p] * mask[p] : s - a[p];
+        }
+    g = g + s;
+  }
+  return g;
+}
+
 int host_build(HostModel &h) {
   const pop_config &c = h.c;
   h.km = c.km; h.nt = c.nt;
@@ -607,6 +631,15 @@ int host_build(HostModel &h) {
     }
   }
   build_halo_plan(h);
+  // ---------------- tripole: redundant top-row points of N-face / NE-corner fields ----------------
+  if (c.ns_boundary == 2) {
+    auto &DUP = newf("TRIPOLE_DUP");
+    for (int b = 0; b < NB; ++b) {
+      const BlockInfo &B = h.all_blocks[b];
+      if (!(B.j_glob[B.je] < 0)) continue;
+      for (int i = B.ib; i <= B.ie; ++i) if (B.i_glob[i - 1] > c.nx_global / 2) DUP[idx(b, i - 1, B.je - 1)] = 1.0;
+    }
+  }
   // ---------------- P-CSI preprocessing (POP_SolversPrep) ----------------
   if (c.solver_choice == 3 && host_pcsi_prep(h)) return 1;
   if (c.solver_choice < 1 || c.solver_choice > 3) { h.err = "solver_choice: 1 pcg, 2 ChronGear, 3 PCSI"; return 1; }

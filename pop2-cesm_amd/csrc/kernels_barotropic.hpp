@@ -183,7 +183,7 @@ struct SolverScalars {
   double eta0, eta1, alpha, beta_cg, rr, sum0, sum1, xcheck;
   double rho_old, sigma;   // ChronGear
 };
-enum { FIN_PCG_RZ = 1, FIN_PCG_SQ = 2, FIN_RR = 3, FIN_XCHECK = 4, FIN_CG_INIT = 5, FIN_CG_ITER = 6, FIN_PLAIN = 7 };
+enum { FIN_PCG_RZ = 1, FIN_PCG_SQ = 2, FIN_RR = 3, FIN_XCHECK = 4, FIN_CG_INIT = 5, FIN_CG_ITER = 6, FIN_PLAIN = 7, FIN_TRIPOLE = 8 };
 // Stage 3: global sum over the block-sum vector in block-id order + scalar recurrences
 // (POP_SolversMod.F90:1365-1420 for pcg, :2159-2170 for ChronGear).  Single thread.
 template <int NF>
@@ -197,6 +197,11 @@ __global__ void k_finalize(const double *__restrict__ blocksum, int nblocks_tot,
     for (int f = 0; f < NF; ++f) g[f] = g[f] + blocksum[(long long)b * NF + f];
   s->sum0 = g[0];
   if (NF > 1) s->sum1 = g[NF > 1 ? 1 : 0];
+  if (mode == FIN_TRIPOLE && NF > 1) {   // field 1 = redundant top-row points: taken out of each block sum before the blocks are added
+    double t = 0.0;
+    for (int b = 0; b < nblocks_tot; ++b) t = t + (blocksum[(long long)b * NF] - blocksum[(long long)b * NF + 1]);
+    s->sum0 = t;
+  }
   switch (mode) {
     case FIN_PCG_RZ: s->eta1 = g[0]; s->beta_cg = s->eta1 / s->eta0; break;               // s = z + s*(eta1/eta0)
     case FIN_PCG_SQ: s->eta0 = s->eta1; s->eta1 = s->eta0 / g[0]; s->alpha = s->eta1; break;
@@ -212,6 +217,24 @@ __global__ void k_finalize(const double *__restrict__ blocksum, int nblocks_tot,
     } break;
     default: break;
   }
+}
+
+// partial of (a*mask, a*mask*dup) -- tripole global sums of N-face / NE-corner fields
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_dot_partial_dup(DevGrid g, const double *__restrict__ A, const double *__restrict__ M, const double *__restrict__ DUP,
+                  double *__restrict__ partial) {
+  const int p2 = red_cell(g), b = blockIdx.y;
+  double v[2] = {0.0, 0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb;
+    if (i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je) {
+      const long long q = (long long)b * g.n2 + p2;
+      double x = A[q];
+      if (M) x = x * M[q];
+      v[0] = x; v[1] = x * DUP[q];
+    }
+  }
+  wg_reduce_store<2>(v, partial, b * gridDim.x + blockIdx.x);
 }
 
 // Convergence check of the fused solvers in ONE launch: ordered block sums of the (r,r) partials (blocks of the

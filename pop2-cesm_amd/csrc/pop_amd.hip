@@ -1397,6 +1397,22 @@ int pop_global_sum(pop_ctx *c, const char *name, int tl, int n, const char *mask
   *result = s.sum0;
   return 0;
 }
+// POP_GlobalSum with fieldLoc on a tripole grid (mpi/POP_ReductionsMod.F90:308-341): N-face / NE-corner fields count
+// the redundant half of the top row once
+int pop_global_sum_loc(pop_ctx *c, const char *name, int tl, int n, const char *mask_name, int field_loc, double *result) {
+  if (need_device(c)) return 1;
+  if (c->h.c.ns_boundary != 2 || (field_loc != 1 && field_loc != 2)) return pop_global_sum(c, name, tl, n, mask_name, result);
+  double *p, *mk = nullptr; long long cnt;
+  if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
+  if (mask_name && resolve(c, mask_name, 0, 0, &mk, &cnt)) { c->err = std::string("unknown mask ") + mask_name; return 1; }
+  hipLaunchKernelGGL(k_dot_partial_dup, grid_2d(c), dim3(POP_RED_THREADS), 0, c->stream, c->g, (const double *)p, (const double *)mk,
+                     (const double *)c->d2["TRIPOLE_DUP"], c->partial);
+  if (reduce_finish<2>(c, FIN_TRIPOLE)) return 1;
+  SolverScalars s;
+  if (read_scalars(c, &s)) return 1;
+  *result = s.sum0;
+  return 0;
+}
 // POP_GlobalSumProd2DR8 (mpi/POP_ReductionsMod.F90:1395-1618): sum of A*B[*mask] over the physical domain
 int pop_global_sum_prod(pop_ctx *c, const char *name_a, int tl_a, int n_a, const char *name_b, int tl_b, int n_b,
                         const char *mask_name, double *result) {

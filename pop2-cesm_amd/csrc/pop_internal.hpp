@@ -91,6 +91,7 @@ void host_halo_i4(const HostModel &h, int *a, int nz, int fill);
 void host_halo_r8_loc(const HostModel &h, double *a, int nz, double fill, int loc, int kind);
 void host_halo_i4_loc(const HostModel &h, int *a, int nz, int fill, int loc, int kind);
 double host_global_sum(const HostModel &h, const double *a, const double *mask);
+double host_global_sum_loc(const HostModel &h, const double *a, const double *mask, int loc);
 std::vector<int> global_srcmap(const HostModel &h);   // all blocks: ghost -> source cell, -1 = fill
 
 }  // namespace pop

@@ -41,6 +41,8 @@ def load():
     L.orc_state_point.argtypes = [C.c_double] * 3
     L.orc_halo_update.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]
     L.orc_halo_update_int.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.orc_global_sum_tripole.restype = C.c_double
+    L.orc_global_sum_tripole.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
     L.orc_halo_update_tripole.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int]
     L.orc_halo_update_tripole_int.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int]
     L.orc_global_sum.restype = C.c_double

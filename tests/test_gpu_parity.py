@@ -272,6 +272,29 @@ def test_tripole_halo_on_device(pkg, loc, kind):
     m.close()
 
 
+def test_tripole_global_sum(pkg, orclib_built):
+    """mpi/POP_ReductionsMod.F90:308-341: on a tripole grid N-face / NE-corner fields count the redundant half
+    of the top row once; centre / E-face fields are summed as usual."""
+    import ctypes as C
+    cfg = named_config("tiny", ns_boundary=2)
+    m, o = pkg.PopModel(cfg), Oracle(cfg)
+    rng = np.random.default_rng(21)
+    a = rng.standard_normal((m.nblocks, m.nyb, m.nxb)) * 50.0
+    m.set("RHS", a)
+    P = C.POINTER(C.c_double)
+    ac = np.ascontiguousarray(a); mk = np.ascontiguousarray(o.f2("mMask"))
+    scale = np.abs(interior(a)).sum()
+    for loc, li in (("NEcorner", 1), ("Nface", 2), ("center", 0)):
+        ref = o.L.orc_global_sum_tripole(o.h, ac.ctypes.data_as(P), None, li)
+        refm = o.L.orc_global_sum_tripole(o.h, ac.ctypes.data_as(P), mk.ctypes.data_as(P), li)
+        assert abs(m.global_sum_loc("RHS", loc=loc) - ref) <= 1e-12 * scale
+        assert abs(m.global_sum_loc("RHS", mask="mMask", loc=loc) - refm) <= 1e-12 * scale
+    plain = o.L.orc_global_sum_tripole(o.h, ac.ctypes.data_as(P), None, 0)
+    dup = o.L.orc_global_sum_tripole(o.h, ac.ctypes.data_as(P), None, 1)
+    assert plain != dup                 # the redundant points really are removed
+    m.close(); o.close()
+
+
 def test_global_sum_matches_serial_rule(pkg, orclib_built):
     """test/unit/reduction/POP.F90: global sum of a known array (with and without mMask) against a
     serial loop over the physical domain; the GPU tree sum must agree to 1e-14 relative."""
