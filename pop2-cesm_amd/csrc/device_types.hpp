@@ -10,6 +10,7 @@ namespace pop {
 struct DevGrid {
   int nxb, nyb, km, nt, nblocks, ib, ie, jb, je;   // ib..je are 1-based like the reference
   int xcd_remap;                                   // column kernels: workgroup order (kernels_common.hpp col_setup)
+  int red_band;                                    // 2-D reduction kernels: XCD-banded chunk order
   int red_tiles;                                   // 2-D reduction kernels: 64x4 tiles in XCD-strided columns
   int n2;                                          // nxb*nyb
   long long n3;                                    // n2*km

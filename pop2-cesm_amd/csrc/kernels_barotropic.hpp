@@ -234,7 +234,7 @@ k_dot_partial_dup(DevGrid g, const double *__restrict__ A, const double *__restr
       v[0] = x; v[1] = x * DUP[q];
     }
   }
-  wg_reduce_store<2>(v, partial, b * gridDim.x + blockIdx.x);
+  wg_reduce_store<2>(v, partial, b * gridDim.x + red_chunk(g));
 }
 
 // Convergence check of the fused solvers in ONE launch: ordered block sums of the (r,r) partials (blocks of the
@@ -268,7 +268,7 @@ k_dot_partial(DevGrid g, const double *__restrict__ A, const double *__restrict_
       v[0] = x;
     }
   }
-  wg_reduce_store<1>(v, partial, b * gridDim.x + blockIdx.x);
+  wg_reduce_store<1>(v, partial, b * gridDim.x + red_chunk(g));
 }
 
 // POP_SolversDiagonal (POP_SolversMod.F90:1110-1151): centre weight of one block = time-independent part - correction
@@ -310,7 +310,7 @@ k_residual(DevGrid g, SolverArgs a) {
     a.R[q] = r;
     if (WITH_RR && interior(g, i, j)) v[0] = (r * r) * g.mMask[q];
   }
-  if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + blockIdx.x);
+  if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
 // PCG step A (:1320-1345, :1433-1438 of the previous iteration): x += alpha s; r -= alpha q (if
 // UPDATE); z = r/diag; partial (r,z)
@@ -334,7 +334,7 @@ k_pcg_a(DevGrid g, SolverArgs a) {
     a.Z[q] = z;
     if (interior(g, i, j)) v[0] = (r * z) * g.mMask[q];
   }
-  wg_reduce_store<1>(v, a.partial, b * gridDim.x + blockIdx.x);
+  wg_reduce_store<1>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
 // x,r update only (before a convergence check)
 __global__ void k_pcg_xr(DevGrid g, SolverArgs a) {
@@ -366,7 +366,7 @@ k_pcg_b(DevGrid g, SolverArgs a) {
     a.Q[q] = aq;
     if (interior(g, i, j)) v[0] = (aq * s) * g.mMask[q];
   }
-  wg_reduce_store<1>(v, a.partial, b * gridDim.x + blockIdx.x);
+  wg_reduce_store<1>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
 
 // ---- ChronGear (POP_SolversMod.F90:2040-2210) -----------------------------------------------
@@ -388,7 +388,7 @@ k_cg_init(DevGrid g, SolverArgs a) {
     a.Q[q] = aq;
     if (interior(g, i, j)) { v[0] = (a.R[q] * z) * g.mMask[q]; v[1] = (z * aq) * g.mMask[q]; }
   }
-  wg_reduce_store<2>(v, a.partial, b * gridDim.x + blockIdx.x);
+  wg_reduce_store<2>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
 // z = r*A0R (whole array; the halo of Z follows)
 __global__ void k_cg_z(DevGrid g, SolverArgs a) {
@@ -410,7 +410,7 @@ k_cg_az(DevGrid g, SolverArgs a) {
     a.AZ[q] = az;
     if (interior(g, i, j)) { const double z = a.Z[q]; v[0] = (a.R[q] * z) * g.mMask[q]; v[1] = (az * z) * g.mMask[q]; }
   }
-  wg_reduce_store<2>(v, a.partial, b * gridDim.x + blockIdx.x);
+  wg_reduce_store<2>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
 // s = z + beta s; q = az + beta q; x += alpha s; r -= alpha q   (FIRST: x,r only with the init alpha)
 template <bool FIRST>
@@ -582,7 +582,7 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
     a.Z[q] = z;
     if (interior(g, i, j)) v[0] = (r * z) * mk;
   }
-  wg_reduce_store<1>(v, a.partA, b * gridDim.x + blockIdx.x);
+  wg_reduce_store<1>(v, a.partA, b * gridDim.x + red_chunk(g));
 }
 
 // step B: s_new = z + s_old*(eta1/eta0) at the 9 stencil points; q = A s_new; partial (q,s).
@@ -634,7 +634,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
     }
     a.Q[q] = aq;
   }
-  wg_reduce_store<1>(v, a.partB, b * gridDim.x + blockIdx.x);
+  wg_reduce_store<1>(v, a.partB, b * gridDim.x + red_chunk(g));
 }
 
 // pending x,r update before a convergence check
@@ -669,7 +669,7 @@ k_fresidual(DevGrid g, FusedArgs a) {
       if (WITH_RR) v[0] = (r * r) * g.mMask[q];
     }
   }
-  if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * gridDim.x + blockIdx.x);
+  if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * gridDim.x + red_chunk(g));
 }
 
 // view of the 2-D system the fused solver works on

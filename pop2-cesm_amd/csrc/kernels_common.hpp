@@ -78,7 +78,15 @@ __device__ __forceinline__ bool col_setup(const DevGrid &g, Col &c, bool interio
 // 2-D reduction kernels (POP_RED_THREADS = 256 threads, one partial per workgroup): cell of this thread,
 // or g.n2 (not a cell) for surplus threads.  Large grids use 64 x 4 tiles in the XCD-strided column order.
 __host__ inline int red_grid_x(const DevGrid &g) {
-  return g.red_tiles ? tile_grid_x(g.nxb, g.nyb, 64, 4) : (g.n2 + 255) / 256;
+  if (g.red_tiles) return tile_grid_x(g.nxb, g.nyb, 64, 4);
+  const int nc = (g.n2 + 255) / 256;
+  return g.red_band ? 8 * ((nc + 7) / 8) : nc;
+}
+// chunk (= partial slot) of this workgroup.  red_band: XCD x takes one contiguous band of chunks, so the rows
+// j+-1 of a 9-point stencil were touched by the same XCD a few workgroups earlier; the chunk -> cells map and the
+// order of the partials are unchanged, only which workgroup computes which chunk.
+__device__ __forceinline__ int red_chunk(const DevGrid &g) {
+  return g.red_band ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
 }
 __device__ __forceinline__ int red_cell(const DevGrid &g) {
   if (g.red_tiles) {
@@ -86,8 +94,8 @@ __device__ __forceinline__ int red_cell(const DevGrid &g) {
     const int i = t.ti * 64 + (threadIdx.x & 63), j = t.tj * 4 + (threadIdx.x >> 6);
     return (t.valid && i < g.nxb && j < g.nyb) ? j * g.nxb + i : g.n2;
   }
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
-  return p2 < g.n2 ? p2 : g.n2;
+  const long long p2 = (long long)red_chunk(g) * blockDim.x + threadIdx.x;
+  return p2 < g.n2 ? (int)p2 : g.n2;
 }
 
 // ---- McDougall, Wright, Jackett & Feistel (2003) equation of state as used by the

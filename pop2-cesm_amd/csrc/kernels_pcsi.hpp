@@ -116,7 +116,7 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
       a.Qo[q] = dx; a.Xo[q] = a.Xi[q] + dx;
     }
   }
-  if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + blockIdx.x);
+  if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
 
 }  // namespace pop
