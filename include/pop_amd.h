@@ -132,6 +132,12 @@ int pop_global_sum(pop_ctx *ctx, const char *name, int tl, int n, const char *ma
 /* with fieldLoc: on a tripole grid fields on north faces (2) / NE corners (1) count the redundant half of the
  * top row once (:308-341); otherwise identical to pop_global_sum */
 int pop_global_sum_loc(pop_ctx *ctx, const char *name, int tl, int n, const char *mask_name, int field_loc, double *result);
+/* POP_GlobalCount :2062-2207 (non-zero physical cells), POP_GlobalMaxval/Minval :2670-3223 and
+ * POP_GlobalMaxloc/Minloc :4002-4400 (value and global (i,j) of the first cell attaining it; the optional mask
+ * selects cells whose mask value is non-zero; iloc / jloc may be NULL) */
+int pop_global_count(pop_ctx *ctx, const char *name, int tl, int n, int field_loc, long long *count);
+int pop_global_extreme(pop_ctx *ctx, const char *name, int tl, int n, const char *mask_name, int want_max,
+                       double *value, int *iloc, int *jloc);
 int pop_global_sum_nfields(pop_ctx *ctx, int nfields, const char *const *names, const int *tl, const int *n,
                            const char *mask_name, double *results);
 int pop_global_sum_prod(pop_ctx *ctx, const char *name_a, int tl_a, int n_a, const char *name_b, int tl_b, int n_b,

@@ -58,6 +58,8 @@ def lib():
         "pop_halo_update_loc": (ci, [vp, cs, ci, ci, ci, ci]),
         "pop_halo_update_host_r8_loc": (ci, [vp, pd, ci, cd, ci, ci]), "pop_halo_update_host_i4_loc": (ci, [vp, pi, ci, ci, ci, ci]),
         "pop_global_sum": (ci, [vp, cs, ci, ci, cs, pd]), "pop_solver_run": (ci, [vp]),
+        "pop_global_count": (ci, [vp, cs, ci, ci, ci, C.POINTER(ll)]),
+        "pop_global_extreme": (ci, [vp, cs, ci, ci, cs, ci, pd, pi, pi]),
         "pop_global_sum_loc": (ci, [vp, cs, ci, ci, cs, ci, pd]),
         "pop_global_sum_nfields": (ci, [vp, ci, C.POINTER(cs), pi, pi, cs, pd]),
         "pop_global_sum_prod": (ci, [vp, cs, ci, ci, cs, ci, ci, cs, pd]),
@@ -222,6 +224,18 @@ class PopModel:
         r = C.c_double()
         self._chk(self.L.pop_global_sum(self.h, name.encode(), tl, n, mask.encode() if mask else None, C.byref(r)))
         return r.value
+
+    def global_count(self, name, tl=1, n=0, loc="center"):
+        r = C.c_longlong()
+        self._chk(self.L.pop_global_count(self.h, name.encode(), tl, n, self.LOC[loc], C.byref(r)))
+        return r.value
+
+    def global_extreme(self, name, tl=1, n=0, mask=None, want_max=True):
+        """(value, iGlobal, jGlobal) of the global maximum / minimum"""
+        v, i, j = C.c_double(), C.c_int(), C.c_int()
+        self._chk(self.L.pop_global_extreme(self.h, name.encode(), tl, n, mask.encode() if mask else None, 1 if want_max else 0,
+                                            C.byref(v), C.byref(i), C.byref(j)))
+        return v.value, i.value, j.value
 
     def global_sum_loc(self, name, tl=1, n=0, mask=None, loc="center"):
         r = C.c_double()

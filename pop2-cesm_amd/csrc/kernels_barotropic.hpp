@@ -219,6 +219,45 @@ __global__ void k_finalize(const double *__restrict__ blocksum, int nblocks_tot,
   }
 }
 
+// POP_GlobalMaxval / Minval / Maxloc / Minloc (mpi/POP_ReductionsMod.F90:2670-3223, 4002-4400): per workgroup the
+// extreme value of the physical cells selected by the mask (non-zero = selected) and the smallest cell index that
+// attains it; partial[2*slot] = value, partial[2*slot+1] = cell index within the rank (-1: none selected)
+template <bool ISMAX>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_extreme_partial(DevGrid g, const double *__restrict__ A, const double *__restrict__ M, double *__restrict__ partial) {
+  __shared__ double sv[POP_RED_THREADS], si[POP_RED_THREADS];
+  const int p2 = red_cell(g), b = blockIdx.y, t = threadIdx.x;
+  double v = 0.0, idx = -1.0;
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    if (i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je && (!M || M[q] != 0.0)) { v = A[q]; idx = (double)q; }
+  }
+  sv[t] = v; si[t] = idx;
+  __syncthreads();
+  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) {
+      const double v2 = sv[t + s], i2 = si[t + s];
+      const bool take = i2 >= 0.0 && (si[t] < 0.0 || (ISMAX ? v2 > sv[t] : v2 < sv[t]) || (v2 == sv[t] && i2 < si[t]));
+      if (take) { sv[t] = v2; si[t] = i2; }
+    }
+    __syncthreads();
+  }
+  if (t == 0) { const long long slot = (long long)b * gridDim.x + red_chunk(g); partial[2 * slot] = sv[0]; partial[2 * slot + 1] = si[0]; }
+}
+// POP_GlobalCount (:2062-2207): number of non-zero physical cells, as a sum of exact ones
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_count_partial(DevGrid g, const double *__restrict__ A, const double *__restrict__ DUP, double *__restrict__ partial) {
+  const int p2 = red_cell(g), b = blockIdx.y;
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    if (i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je && A[q] != 0.0 && !(DUP && DUP[q] != 0.0)) v[0] = 1.0;
+  }
+  wg_reduce_store<1>(v, partial, b * gridDim.x + red_chunk(g));
+}
+
 // partial of (a*mask, a*mask*dup) -- tripole global sums of N-face / NE-corner fields
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_dot_partial_dup(DevGrid g, const double *__restrict__ A, const double *__restrict__ M, const double *__restrict__ DUP,

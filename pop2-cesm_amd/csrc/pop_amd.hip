@@ -1418,6 +1418,74 @@ int pop_global_sum_loc(pop_ctx *c, const char *name, int tl, int n, const char *
   *result = s.sum0;
   return 0;
 }
+// every rank's `nv` values side by side (slot vector + sum all-reduce; exact because the other slots are zero)
+static int gather_slots(pop_ctx *c, const double *local, int nv, std::vector<double> &all) {
+  const int nr = c->h.nranks;
+  all.assign((size_t)nv * nr, 0.0);
+  if (nr == 1) { std::copy(local, local + nv, all.begin()); return 0; }
+  if (!c->allred || !c->redbuf || c->red_doubles < (long long)nv * nr) { c->err = "global reduction: multi-rank run without a transport"; return 1; }
+  std::copy(local, local + nv, all.begin() + (size_t)nv * c->h.rank);
+  HIPCHK(c, hipMemcpyAsync(c->redbuf, all.data(), sizeof(double) * all.size(), hipMemcpyHostToDevice, c->stream));
+  if (c->allred(c->comm_user, 0, (long long)all.size())) { c->err = "global reduction: allreduce failed"; return 1; }
+  HIPCHK(c, hipMemcpyAsync(all.data(), c->redbuf, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+// POP_GlobalMaxval/Minval (:2670-3223) and Maxloc/Minloc (:4002-4400): value, and the global (i,j) of the first cell
+// (block order, then j, then i) that attains it; mask_name selects cells with a non-zero mask value
+int pop_global_extreme(pop_ctx *c, const char *name, int tl, int n, const char *mask_name, int want_max, double *value, int *iloc, int *jloc) {
+  if (need_device(c)) return 1;
+  double *p, *mk = nullptr; long long cnt;
+  if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
+  if (mask_name && resolve(c, mask_name, 0, 0, &mk, &cnt)) { c->err = std::string("unknown mask ") + mask_name; return 1; }
+  const dim3 G = grid_2d(c);
+  if (want_max) hipLaunchKernelGGL(k_extreme_partial<true>, G, dim3(POP_RED_THREADS), 0, c->stream, c->g, (const double *)p, (const double *)mk, c->partial);
+  else hipLaunchKernelGGL(k_extreme_partial<false>, G, dim3(POP_RED_THREADS), 0, c->stream, c->g, (const double *)p, (const double *)mk, c->partial);
+  const size_t np = (size_t)G.x * G.y;
+  std::vector<double> part(2 * np);
+  HIPCHK(c, hipMemcpyAsync(part.data(), c->partial, sizeof(double) * part.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double best = 0.0, bidx = -1.0;
+  for (size_t s = 0; s < np; ++s) {
+    const double v = part[2 * s], ix = part[2 * s + 1];
+    if (ix < 0.0) continue;
+    if (bidx < 0.0 || (want_max ? v > best : v < best) || (v == best && ix < bidx)) { best = v; bidx = ix; }
+  }
+  // local cell -> global block id, global (i,j)
+  double loc3[4] = {0.0, -1.0, 0.0, 0.0};   // value, global block id (ordering key), iGlobal, jGlobal
+  if (bidx >= 0.0) {
+    const long long q = (long long)bidx;
+    const int lb = (int)(q / c->g.n2), p2 = (int)(q % c->g.n2), gb = c->h.local_ids[lb] - 1;
+    const BlockInfo &B = c->h.all_blocks[gb];
+    loc3[0] = best; loc3[1] = gb; loc3[2] = B.i_glob[p2 % c->g.nxb]; loc3[3] = B.j_glob[p2 / c->g.nxb];
+  }
+  std::vector<double> all;
+  if (gather_slots(c, loc3, 4, all)) return 1;
+  int win = -1;
+  for (int r = 0; r < c->h.nranks; ++r) {
+    if (all[4 * r + 1] < 0.0) continue;
+    if (win < 0 || (want_max ? all[4 * r] > all[4 * win] : all[4 * r] < all[4 * win]) || (all[4 * r] == all[4 * win] && all[4 * r + 1] < all[4 * win + 1])) win = r;
+  }
+  if (win < 0) { c->err = "pop_global_extreme: the mask selects no physical cell"; return 1; }
+  if (value) *value = all[4 * win];
+  if (iloc) *iloc = (int)all[4 * win + 2];
+  if (jloc) *jloc = (int)all[4 * win + 3];
+  return 0;
+}
+// POP_GlobalCount (:2062-2207): non-zero cells of the physical domain (tripole: redundant top-row points of N-face /
+// NE-corner fields counted once)
+int pop_global_count(pop_ctx *c, const char *name, int tl, int n, int field_loc, long long *count) {
+  if (need_device(c)) return 1;
+  double *p; long long cnt;
+  if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
+  const double *dup = (c->h.c.ns_boundary == 2 && (field_loc == 1 || field_loc == 2)) ? c->d2["TRIPOLE_DUP"] : nullptr;
+  hipLaunchKernelGGL(k_count_partial, grid_2d(c), dim3(POP_RED_THREADS), 0, c->stream, c->g, (const double *)p, dup, c->partial);
+  if (reduce_finish<1>(c, FIN_PLAIN)) return 1;
+  SolverScalars s;
+  if (read_scalars(c, &s)) return 1;
+  *count = (long long)s.sum0;
+  return 0;
+}
 // POP_GlobalSumProd2DR8 (mpi/POP_ReductionsMod.F90:1395-1618): sum of A*B[*mask] over the physical domain
 int pop_global_sum_prod(pop_ctx *c, const char *name_a, int tl_a, int n_a, const char *name_b, int tl_b, int n_b,
                         const char *mask_name, double *result) {

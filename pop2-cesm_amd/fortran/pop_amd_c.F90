@@ -177,6 +177,23 @@
          real (c_double), value :: x
          real (c_double), intent(out) :: res
       end function
+      integer (c_int) function pop_global_count(ctx, name, tl, n, field_loc, res) bind(C, name='pop_global_count')
+         import :: c_int, c_ptr, c_char, c_long_long
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+         integer (c_int), value :: tl, n, field_loc
+         integer (c_long_long), intent(out) :: res
+      end function
+      integer (c_int) function pop_global_extreme(ctx, name, tl, n, mask_name, want_max, val, iloc, jloc) &
+                                                  bind(C, name='pop_global_extreme')
+         import :: c_int, c_ptr, c_char, c_double
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: name(*)
+         integer (c_int), value :: tl, n, want_max
+         type (c_ptr), value :: mask_name
+         real (c_double), intent(out) :: val
+         integer (c_int), intent(out) :: iloc, jloc
+      end function
       integer (c_int) function pop_global_sum_i4(ctx, name, res) bind(C, name='pop_global_sum_i4')
          import :: c_int, c_ptr, c_char, c_long_long
          type (c_ptr), value :: ctx

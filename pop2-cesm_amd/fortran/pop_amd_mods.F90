@@ -144,7 +144,50 @@
    implicit none
    private
    public :: POP_GlobalSum, POP_GlobalSumProd, POP_GlobalSumScalar, POP_GlobalSumI4
+   public :: POP_GlobalCount, POP_GlobalMaxval, POP_GlobalMinval, POP_GlobalMaxloc, POP_GlobalMinloc
  contains
+   ! :2062-2207 (non-zero cells of a device-resident field)
+   function POP_GlobalCount(name, timeLevel, n, errorCode) result(globalCount)
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      integer (POP_i4), intent(out) :: errorCode
+      integer (c_long_long) :: globalCount
+      errorCode = pop_global_count(pop_ctx, cstr(name), timeLevel, n, 0, globalCount)
+   end function
+   ! :2670-2945
+   function POP_GlobalMaxval(name, timeLevel, n, errorCode) result(globalMaxval)
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      integer (POP_i4), intent(out) :: errorCode
+      real (POP_r8) :: globalMaxval
+      integer (c_int) :: i, j
+      errorCode = pop_global_extreme(pop_ctx, cstr(name), timeLevel, n, c_null_ptr, 1, globalMaxval, i, j)
+   end function
+   ! :2948-3223
+   function POP_GlobalMinval(name, timeLevel, n, errorCode) result(globalMinval)
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      integer (POP_i4), intent(out) :: errorCode
+      real (POP_r8) :: globalMinval
+      integer (c_int) :: i, j
+      errorCode = pop_global_extreme(pop_ctx, cstr(name), timeLevel, n, c_null_ptr, 0, globalMinval, i, j)
+   end function
+   ! :4002-4200
+   subroutine POP_GlobalMaxloc(name, timeLevel, n, iLoc, jLoc, maxValue, errorCode)
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      integer (POP_i4), intent(out) :: iLoc, jLoc, errorCode
+      real (POP_r8), intent(out) :: maxValue
+      errorCode = pop_global_extreme(pop_ctx, cstr(name), timeLevel, n, c_null_ptr, 1, maxValue, iLoc, jLoc)
+   end subroutine
+   ! :4200-4400
+   subroutine POP_GlobalMinloc(name, timeLevel, n, iLoc, jLoc, minValue, errorCode)
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      integer (POP_i4), intent(out) :: iLoc, jLoc, errorCode
+      real (POP_r8), intent(out) :: minValue
+      errorCode = pop_global_extreme(pop_ctx, cstr(name), timeLevel, n, c_null_ptr, 0, minValue, iLoc, jLoc)
+   end subroutine
    ! mpi/POP_ReductionsMod.F90:1395-1618 (product of two device-resident fields)
    function POP_GlobalSumProd(name1, timeLevel1, name2, timeLevel2, errorCode) result(globalSum)
       character (*), intent(in) :: name1, name2

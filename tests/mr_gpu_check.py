@@ -50,6 +50,12 @@ def main():
             a = m.get(name, 1, 0); b = ref.get(name, 1, 0)[[i - 1 for i in ids]]
             if not np.array_equal(a, b):
                 print("rank %d step %d: %s differs, max %g" % (rank, s, name, np.abs(a - b).max())); ok = False
+    # global reductions across ranks: same value / location / count as the single-rank twin
+    for want_max in (True, False):
+        if m.global_extreme("PSURF", 1, 0, want_max=want_max) != ref.global_extreme("PSURF", 1, 0, want_max=want_max):
+            print("rank %d: global_extreme(max=%s) differs" % (rank, want_max)); ok = False
+    if m.global_count("UBTROP", 1, 0) != ref.global_count("UBTROP", 1, 0) or m.global_sum("PSURF", 1, 0) != ref.global_sum("PSURF", 1, 0):
+        print("rank %d: global count / sum differs" % rank); ok = False
     t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
         print("MR_GPU_CHECK", "OK" if int(t.item()) == 1 else "FAILED", "world", world, "config", args.config, args.kw)

@@ -272,6 +272,29 @@ def test_tripole_halo_on_device(pkg, loc, kind):
     m.close()
 
 
+def test_global_count_and_extremes(pkg):
+    """test/unit/reduction/POP.F90: global count, maxval / minval and maxloc / minloc against a serial loop over
+    the physical domain, with and without a mask."""
+    cfg = named_config("tiny")
+    m = pkg.PopModel(cfg)
+    rng = np.random.default_rng(33)
+    a = rng.standard_normal((m.nblocks, m.nyb, m.nxb)) * 7.0
+    a[rng.random(a.shape) < 0.3] = 0.0
+    m.set("RHS", a)
+    phys = interior(a)
+    assert m.global_count("RHS") == int(np.count_nonzero(phys))
+    mask = interior(m.get("mMask")) != 0.0
+    for want_max in (True, False):
+        for use_mask in (False, True):
+            sel = np.where(mask, phys, -np.inf if want_max else np.inf) if use_mask else phys
+            ref = sel.max() if want_max else sel.min()
+            b, j, i = np.unravel_index(sel.argmax() if want_max else sel.argmin(), sel.shape)
+            blk = m.get_block(b + 1)
+            v, ig, jg = m.global_extreme("RHS", mask="mMask" if use_mask else None, want_max=want_max)
+            assert v == ref and (ig, jg) == (blk["i_glob"][i + 2], blk["j_glob"][j + 2])
+    m.close()
+
+
 def test_tripole_global_sum(pkg, orclib_built):
     """mpi/POP_ReductionsMod.F90:308-341: on a tripole grid N-face / NE-corner fields count the redundant half
     of the top row once; centre / E-face fields are summed as usual."""
