@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("POP_BENCH_WORKLOAD", "tx0.1v3"))
     ap.add_argument("--solver", default=os.environ.get("POP_BENCH_SOLVER", "pcg"), choices=["pcg", "chrongear", "pcsi"],
                     help="barotropic solver (headline = pcg, BASELINE.json north_star)")
+    ap.add_argument("--precond", default=os.environ.get("POP_BENCH_PRECOND", "diagonal"), choices=["diagonal", "evp"],
+                    help="solver preconditioner (headline = diagonal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -199,6 +201,7 @@ def main():
     pkg = ge.load_package()
     cfg = workload_config(args.workload, world)
     cfg.solver_choice = {"pcg": 1, "chrongear": 2, "pcsi": 3}[args.solver]
+    cfg.reserved_i[2] = 1 if args.precond == "evp" else 0
     model = pkg.PopModel(cfg, rank=rank, nranks=world)
     comm, transport = None, "none"
     if world > 1:
@@ -287,7 +290,7 @@ def main():
         "config": {"workload": args.workload, "grid": [cfg.nx_global, cfg.ny_global, cfg.km], "nt": cfg.nt,
                    "block_size": [cfg.block_size_x, cfg.block_size_y], "steps_per_day": cfg.steps_per_day,
                    "hmix": "del%d" % cfg.hmix_momentum, "vmix": ["const", "rich", "kpp"][vm],
-                   "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "pcg_iters_per_step": float(np.mean(iters)),
+                   "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport},
         "roofline": roof,
     }

@@ -41,7 +41,7 @@ typedef struct pop_config {
   int vmix_choice;            /* 1 const, 2 rich, 3 kpp (vertical_mix.F90:280-296) */
   int tadvect;                /* 1 centered, 2 upwind3  (advection.F90:1667-1729) */
   int solver_choice;          /* 1 pcg, 2 ChronGear, 3 PCSI with Lanczos eigenvalue bounds
-                               * (POP_SolversMod.F90:442-472, 1510-1835, 2699-2990); diagonal preconditioner */
+                               * (POP_SolversMod.F90:442-472, 1510-1835, 2699-2990); preconditioner: reserved_i[2] */
   int max_iterations;
   int convergence_check_freq;
   int tmix_opt;               /* 0 none, 1 avg, 2 avgfit (time_management.F90:2170-2213), 3 robert
@@ -51,7 +51,8 @@ typedef struct pop_config {
   int lbouss_correct, lpressure_avg, impcor, reset_to_freezing;
   int lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri; /* vmix_kpp_nml */
   int reserved_i[8];          /* [0] = maxlanczosstep (0 = 20), [1] = convergenceCheckStart (0 = 60) for PCSI
-                               * (POP_SolversMod.F90:626-640) */
+                               * (POP_SolversMod.F90:626-640); [2] = preconditionerChoice: 0 'diagonal', 1 'evp'
+                               * (:124, :252-290, :2434-2696; any solver_choice) */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;
@@ -150,6 +151,11 @@ int pop_solver_run(pop_ctx *ctx);
 /* POP_SolversDiagonal(diagonalCorrection(nx_block,ny_block), blockIndx, errorCode) :1110-1151:
  * centre weight of local block blockIndx (1-based) = time-independent part - correction (host array) */
 int pop_solver_diagonal(pop_ctx *ctx, int block_local, const double *diagonal_correction);
+/* preconditioner(PX, X, bid) :2268-2369 on every local block: PX = M^-1 X on the physical cells.  M is the EVP
+ * block preconditioner (8x8 sub-block solves, :2434-2696; preconditionerChoice = 'evp') when reserved_i[2] = 1,
+ * else the diagonal (current centre weight).  Private in the reference; exported so that parity tests can pin the
+ * preconditioner on its own.  x_name / px_name: 2-D device fields (time level tl where it applies). */
+int pop_solver_preconditioner(pop_ctx *ctx, const char *x_name, int x_tl, const char *px_name, int px_tl);
 /* POP_SolversGetDiagnostics(iterationCount, residual, errorCode) :1158 */
 int pop_solver_get_diagnostics(const pop_ctx *ctx, int *iterations, double *rms_residual);
 /* state(k,kk,TEMPK,SALTK,this_block,RHOOUT,...) state_mod.F90:258 on n device-resident or

@@ -51,6 +51,7 @@ struct orc_model {
   void *upw3;
   void *rf;
   void *pcsi;
+  void *evp;
 };
 
 extern const double orc_grav, orc_omega, orc_radius;

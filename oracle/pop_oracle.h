@@ -91,6 +91,9 @@ double orc_global_sum(orc_model *m, const double *a, const double *mask);
 double orc_global_sum_tripole(orc_model *m, const double *a, const double *mask, int loc);
 int    orc_solver_iterations(orc_model *m);
 double orc_solver_rms(orc_model *m);
+/* POP_SolversMod.F90:2268-2369 preconditioner on whole arrays (EVP when reserved_i[2] = 1), :2992 partition */
+void orc_preconditioner(orc_model *m, const double *X, double *PX);
+int orc_evp_info(orc_model *m, int what, int idx);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,7 @@ def lib():
         "pop_global_sum_prod": (ci, [vp, cs, ci, ci, cs, ci, ci, cs, pd]),
         "pop_global_sum_scalar": (ci, [vp, cd, pd]), "pop_global_sum_i4": (ci, [vp, cs, C.POINTER(ll)]),
         "pop_solver_diagonal": (ci, [vp, ci, pd]),
+        "pop_solver_preconditioner": (ci, [vp, cs, ci, cs, ci]),
         "pop_solver_get_diagnostics": (ci, [vp, pi, pd]),
         "pop_state_host": (ci, [vp, ci, pd, pd, pd, pd, pd, ll]),
         "pop_set_comm": (ci, [vp, vp, vp, vp, ll, XCHG_FN, ALLRED_FN, vp]),
@@ -270,6 +271,10 @@ class PopModel:
         a = np.ascontiguousarray(corr, dtype=np.float64)
         assert a.size == self.nxb * self.nyb
         self._chk(self.L.pop_solver_diagonal(self.h, block_local, a.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def solver_preconditioner(self, x_name, px_name, x_tl=1, px_tl=1):
+        """PX = M^-1 X on the physical cells (EVP sub-block solves when reserved_i[2] = 1, else the diagonal)"""
+        self._chk(self.L.pop_solver_preconditioner(self.h, x_name.encode(), x_tl, px_name.encode(), px_tl))
 
     def solver_run(self):
         self._chk(self.L.pop_solver_run(self.h))

@@ -63,20 +63,33 @@ int ratqr(int n, double eps1, const std::vector<double> &d, const std::vector<do
 
 }  // namespace
 
-int host_pcsi_prep(HostModel &h) {
-  const pop_config &c = h.c;
-  const size_t n2 = h.n2, A2 = n2 * h.nblocks_tot;
-  const int nxb = h.nxb, nyb = h.nyb, NB = h.nblocks_tot;
-  const std::vector<double> &WNE = h.f2["btropWgtNE"], &WEa = h.f2["btropWgtEast"], &WNo = h.f2["btropWgtNorth"], &WC0 = h.f2["centerWgtIndep"];
-  const std::vector<double> &TAREA = h.f2["TAREA"], &mMask = h.f2["mMask"];
+// barotropic.F90:231-252: centerWgtIndep - TAREA/(alpha*2*dtp*dtp*grav) on ocean points, all blocks
+std::vector<double> host_center_init(HostModel &h) {
+  const size_t A2 = h.n2 * h.nblocks_tot;
+  const std::vector<double> &WC0 = h.f2["centerWgtIndep"], &TAREA = h.f2["TAREA"];
   const std::vector<int> &KMT = h.i2["KMT"];
   const double alpha = 1.0 / 3.0;          // time_management.F90:437
-  std::vector<double> C(A2), A0R(A2), R(A2, 1.0), S(A2), Q(A2, 0.0), Q1(A2, 0.0), P(A2), WORK(A2), WORK1(A2);
+  std::vector<double> C(A2);
   for (size_t p = 0; p < A2; ++p) {
     const double dc = (KMT[p] >= 1) ? TAREA[p] / (alpha * 2.0 * h.dtp * h.dtp * GRAV) : 0.0;
     C[p] = WC0[p] - dc;
-    A0R[p] = (C[p] != 0.0) ? 1.0 / C[p] : 0.0;
   }
+  return C;
+}
+
+int host_pcsi_prep(HostModel &h, const std::vector<double> &C) {
+  const pop_config &c = h.c;
+  const size_t n2 = h.n2, A2 = n2 * h.nblocks_tot;
+  const int nxb = h.nxb, nyb = h.nyb, NB = h.nblocks_tot;
+  const std::vector<double> &WNE = h.f2["btropWgtNE"], &WEa = h.f2["btropWgtEast"], &WNo = h.f2["btropWgtNorth"];
+  const std::vector<double> &mMask = h.f2["mMask"];
+  const bool evp = use_evp(c);             // :2789, :2843, :2884 preconditioner() instead of the diagonal
+  std::vector<double> A0R(A2), R(A2, 1.0), S(A2), Q(A2, 0.0), Q1(A2, 0.0), P(A2), WORK(A2), WORK1(A2);
+  for (size_t p = 0; p < A2; ++p) A0R[p] = (C[p] != 0.0) ? 1.0 / C[p] : 0.0;
+  auto precond = [&](std::vector<double> &out, const std::vector<double> &in) {
+    if (evp) host_evp_apply(h, out.data(), in.data());
+    else for (size_t p = 0; p < A2; ++p) out[p] = in[p] * A0R[p];
+  };
   auto op = [&](std::vector<double> &AX, const std::vector<double> &X) {   // btropOperator :2414-2426 (all but the outer ring)
     std::fill(AX.begin(), AX.end(), 0.0);
     for (int b = 0; b < NB; ++b) for (int j = 1; j <= nyb - 2; ++j) for (int i = 1; i <= nxb - 2; ++i) {
@@ -87,7 +100,8 @@ int host_pcsi_prep(HostModel &h) {
   };
   const int maxstep = c.reserved_i[0] > 0 ? c.reserved_i[0] : 20;       // maxlanczosstep :626
   const double crit = c.reserved_d[3] > 0.0 ? c.reserved_d[3] : 0.1;    // LanczosconvergenceCriterion :616
-  for (size_t p = 0; p < A2; ++p) { S[p] = R[p] * A0R[p]; WORK[p] = S[p] * R[p]; }
+  precond(S, R);
+  for (size_t p = 0; p < A2; ++p) WORK[p] = S[p] * R[p];
   double csc = -host_global_sum(h, WORK.data(), mMask.data()), csa, csb = 0.0, u = 0.0, v = 0.0, mineig = 1.0;
   if (!(csc > 0.0)) { h.err = "PcsiLanczos: start vector has zero norm (singular operator)"; return 1; }
   for (size_t p = 0; p < A2; ++p) Q[p] = (1 / std::sqrt(csc)) * R[p];
@@ -96,14 +110,15 @@ int host_pcsi_prep(HostModel &h) {
   h.pcsi_lanczos_steps = 0;
   for (int m = 1; m <= maxstep; ++m) {
     h.pcsi_lanczos_steps = m;
-    for (size_t p = 0; p < A2; ++p) P[p] = Q[p] * A0R[p];
+    precond(P, Q);
     host_halo_r8(h, P.data(), 1, 0.0);
     op(WORK1, P);
     for (size_t p = 0; p < A2; ++p) { R[p] = WORK1[p] - csb * Q1[p]; WORK[p] = P[p] * R[p]; }
     csa = -host_global_sum(h, WORK.data(), mMask.data());
     for (size_t p = 0; p < A2; ++p) R[p] = R[p] - csa * Q[p];
     host_halo_r8(h, R.data(), 1, 0.0);
-    for (size_t p = 0; p < A2; ++p) { S[p] = R[p] * A0R[p]; WORK[p] = S[p] * R[p]; }
+    precond(S, R);
+    for (size_t p = 0; p < A2; ++p) WORK[p] = S[p] * R[p];
     csc = -host_global_sum(h, WORK.data(), mMask.data());
     csb = std::sqrt(csc);
     vcsa[m] = csa; vcsb[m] = csb;

@@ -641,7 +641,11 @@ int host_build(HostModel &h) {
     }
   }
   // ---------------- P-CSI preprocessing (POP_SolversPrep) ----------------
-  if (c.solver_choice == 3 && host_pcsi_prep(h)) return 1;
+  if (use_evp(c) || c.solver_choice == 3) {   // POP_SolversPrep (POP_SolversMod.F90:181-320): EVP first, then Lanczos
+    const std::vector<double> C0 = host_center_init(h);
+    if (use_evp(c) && host_evp_prep(h, C0)) return 1;
+    if (c.solver_choice == 3 && host_pcsi_prep(h, C0)) return 1;
+  }
   if (c.solver_choice < 1 || c.solver_choice > 3) { h.err = "solver_choice: 1 pcg, 2 ChronGear, 3 PCSI"; return 1; }
   return 0;
 }

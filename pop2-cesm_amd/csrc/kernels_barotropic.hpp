@@ -182,6 +182,7 @@ __global__ void k_block_sums_global(const double *__restrict__ partial, int nchu
 struct SolverScalars {
   double eta0, eta1, alpha, beta_cg, rr, sum0, sum1, xcheck;
   double rho_old, sigma;   // ChronGear
+  double rho2[2], sigma2[2];   // fused ChronGear: (rho_old, sigma) ping-pong between iterations (read [par], write [1-par])
 };
 enum { FIN_PCG_RZ = 1, FIN_PCG_SQ = 2, FIN_RR = 3, FIN_XCHECK = 4, FIN_CG_INIT = 5, FIN_CG_ITER = 6, FIN_PLAIN = 7, FIN_TRIPOLE = 8 };
 // Stage 3: global sum over the block-sum vector in block-id order + scalar recurrences
@@ -207,7 +208,8 @@ __global__ void k_finalize(const double *__restrict__ blocksum, int nblocks_tot,
     case FIN_PCG_SQ: s->eta0 = s->eta1; s->eta1 = s->eta0 / g[0]; s->alpha = s->eta1; break;
     case FIN_RR: s->rr = g[0]; break;
     case FIN_XCHECK: s->xcheck = g[0]; break;
-    case FIN_CG_INIT: s->rho_old = g[0]; s->sigma = g[NF > 1 ? 1 : 0]; s->alpha = s->rho_old / s->sigma; break;
+    case FIN_CG_INIT: s->rho_old = g[0]; s->sigma = g[NF > 1 ? 1 : 0]; s->alpha = s->rho_old / s->sigma;
+      s->rho2[0] = s->rho_old; s->sigma2[0] = s->sigma; break;
     case FIN_CG_ITER: {
       const double rho = g[0], delta = g[NF > 1 ? 1 : 0];
       s->beta_cg = rho / s->rho_old;
@@ -409,7 +411,8 @@ k_pcg_b(DevGrid g, SolverArgs a) {
 }
 
 // ---- ChronGear (POP_SolversMod.F90:2040-2210) -----------------------------------------------
-// init: z = r*A0R; s = z; q = A s; partial (r,z), (s,q)
+// init: z = r*A0R (EXTZ: z already in a.Z, halo included -- EVP preconditioner); s = z; q = A s; partial (r,z), (s,q)
+template <bool EXTZ>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_cg_init(DevGrid g, SolverArgs a) {
   const int p2 = red_cell(g), b = blockIdx.y;
@@ -417,9 +420,10 @@ k_cg_init(DevGrid g, SolverArgs a) {
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
     const long long q = (long long)b * g.n2 + p2;
-    auto zf = [&](long long qq) { const double cw = a.C[qq]; return a.R[qq] * ((cw != 0.0) ? 1.0 / cw : 0.0); };
+    auto zf = [&](long long qq) { if (EXTZ) return a.Z[qq]; const double cw = a.C[qq]; return a.R[qq] * ((cw != 0.0) ? 1.0 / cw : 0.0); };
     const double z = zf(q);
-    a.Z[q] = z; a.S0[q] = z;
+    if (!EXTZ) a.Z[q] = z;
+    a.S0[q] = z;
     double aq = 0.0;
     if (op_range(g, i, j))
       aq = a.C[q] * z + g.WNo[q] * zf(q + nxb) + g.WNo[q - nxb] * zf(q - nxb) + g.WEa[q] * zf(q + 1) + g.WEa[q - 1] * zf(q - 1) +
@@ -554,6 +558,7 @@ namespace pop {
 
 struct FusedArgs {
   double *X, *R, *Z, *S0, *S1, *Q;
+  double *AZ; const double *A0R;   // fused ChronGear: A z, 1/diag
   const double *Bv, *C;
   double *partA, *partB;      // workgroup partials of (r,z) and (s,q)
   SolverScalars *sc;
@@ -674,6 +679,100 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
     a.Q[q] = aq;
   }
   wg_reduce_store<1>(v, a.partB, b * gridDim.x + red_chunk(g));
+}
+
+// ---- fused ChronGear (POP_SolversMod.F90:2100-2210): two launches per iteration ----------------------------
+// ordered totals of two interleaved partial fields (same rule as fused_total, both fields in one pass)
+__device__ __forceinline__ void fused_total2(const double *__restrict__ partial, int nchunk, int nblocks,
+                                             const double *__restrict__ bs, int presummed, double &t0, double &t1) {
+  __shared__ double shf[2][POP_RED_THREADS];
+  const int t = threadIdx.x;
+  t0 = 0.0; t1 = 0.0;
+  if (presummed) {
+    for (int b = 0; b < nblocks; ++b) { t0 = t0 + bs[2 * b]; t1 = t1 + bs[2 * b + 1]; }
+    return;
+  }
+  for (int b = 0; b < nblocks; ++b) {
+    double v0 = 0.0, v1 = 0.0;
+    for (int c = t; c < nchunk; c += POP_RED_THREADS) {
+      const double2 w = *reinterpret_cast<const double2 *>(partial + 2 * ((long long)b * nchunk + c));
+      v0 = v0 + w.x; v1 = v1 + w.y;
+    }
+    shf[0][t] = v0; shf[1][t] = v1;
+    __syncthreads();
+    for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+      if (t < s) { shf[0][t] = shf[0][t] + shf[0][t + s]; shf[1][t] = shf[1][t] + shf[1][t + s]; }
+      __syncthreads();
+    }
+    t0 = t0 + shf[0][0]; t1 = t1 + shf[1][0];
+    __syncthreads();
+  }
+}
+// step A (:2117-2157): z = r*A0R at the nine stencil points (ghost neighbours at their source cell, which is what
+// the halo update of z delivers), az = A z, partial (r,z), (az,z)
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_fcg_a(DevGrid g, FusedArgs a) {
+  const int p2 = red_cell(g), b = blockIdx.y;
+  const bool live = p2 < g.n2;
+  const int pp = live ? p2 : 0;
+  const int i = pp % g.nxb, j = pp / g.nxb, nxb = g.nxb;
+  const long long q = (long long)b * g.n2 + pp;
+  const bool inner = live && interior(g, i, j);
+  double v[2] = {0.0, 0.0};
+  if (inner) {
+    const bool rim = (i + 1 == g.ib || i + 1 == g.ie || j + 1 == g.jb || j + 1 == g.je);
+    const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+    double zv[9], wv[9];
+    const double r = a.R[q];
+    zv[0] = r * a.A0R[q];
+    if (!rim) {
+#pragma unroll
+      for (int t = 1; t < 9; ++t) zv[t] = a.R[q + off[t]] * a.A0R[q + off[t]];
+    } else {
+#pragma unroll
+      for (int t = 1; t < 9; ++t) {
+        const int m = a.srcmap[q + off[t]];
+        zv[t] = (m >= 0) ? a.R[m] * a.A0R[m] : 0.0;
+      }
+    }
+    wv[0] = a.C[q]; wv[1] = g.WNo[q]; wv[2] = g.WNo[q - nxb]; wv[3] = g.WEa[q]; wv[4] = g.WEa[q - 1];
+    wv[5] = g.WNE[q]; wv[6] = g.WNE[q - nxb]; wv[7] = g.WNE[q - 1]; wv[8] = g.WNE[q - 1 - nxb];
+    double az = wv[0] * zv[0];
+#pragma unroll
+    for (int t = 1; t < 9; ++t) az = az + wv[t] * zv[t];
+    a.Z[q] = zv[0]; a.AZ[q] = az;
+    const double mk = g.mMask[q];
+    v[0] = (r * zv[0]) * mk; v[1] = (az * zv[0]) * mk;
+  }
+  wg_reduce_store<2>(v, a.partA, b * gridDim.x + red_chunk(g));
+}
+// step B (:2159-2186): scalar recurrences from the two totals, then s = z + beta s; q = az + beta q; x += alpha s;
+// r -= alpha q on the physical cells (ghost values of these vectors are never read in the fused form)
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_fcg_b(DevGrid g, FusedArgs a, int par) {
+  const int p2 = red_cell(g), b = blockIdx.y;
+  const bool live = p2 < g.n2;
+  const int pp = live ? p2 : 0;
+  const int i = pp % g.nxb, j = pp / g.nxb;
+  const long long q = (long long)b * g.n2 + pp;
+  const bool inner = live && interior(g, i, j);
+  double z = 0.0, az = 0.0, s = 0.0, qq = 0.0, x = 0.0, r = 0.0;
+  if (inner) { z = a.Z[q]; az = a.AZ[q]; s = a.S0[q]; qq = a.Q[q]; x = a.X[q]; r = a.R[q]; }
+  double rho, delta;
+  fused_total2(a.partA, a.nchunk, a.nblocks, a.bsA, a.presummed, rho, delta);
+  const double bt = rho / a.sc->rho2[par];
+  const double sigma = delta - (bt * bt) * a.sc->sigma2[par];
+  const double al = rho / sigma;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    a.sc->rho2[1 - par] = rho; a.sc->sigma2[1 - par] = sigma; a.sc->alpha = al; a.sc->beta_cg = bt; a.sc->rho_old = rho; a.sc->sigma = sigma;
+  }
+  if (inner) {
+    s = z + bt * s;
+    qq = az + bt * qq;
+    a.S0[q] = s; a.Q[q] = qq;
+    a.X[q] = x + al * s;
+    a.R[q] = r - al * qq;
+  }
 }
 
 // pending x,r update before a convergence check

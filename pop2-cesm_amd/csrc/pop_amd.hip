@@ -13,6 +13,7 @@
 #include "kernels_tracer_lds.hpp"
 #include "kernels_rf.hpp"
 #include "kernels_pcsi.hpp"
+#include "kernels_evp.hpp"
 #include "rccl_transport.hpp"
 
 using namespace pop;
@@ -82,6 +83,7 @@ struct pop_ctx {
   pop_exchange_fn xchg = nullptr;
   pop_allreduce_fn allred = nullptr;
   void *comm_user = nullptr;
+  EvpDev evp{}; bool use_evp = false;                                                // EVP block preconditioner (reserved_i[2] = 1)
   double *pcsi_omega = nullptr; int *pcsi_base = nullptr; double pcsi_csy = 0;        // P-CSI: omega_k table, interval base
   std::vector<std::pair<std::pair<double *, int>, hipGraphExec_t>> pcsi_graphs;   // keyed by (solution array, variant)
   double rf_S[MAXNT] = {}, rf_S_prev[MAXNT] = {}; bool rf_S_prev_valid[MAXNT] = {};   // Robert filter
@@ -226,7 +228,15 @@ SolverArgs solver_args(pop_ctx *c) {
   return a;
 }
 
-// POP_SolversRun -> pcg (POP_SolversMod.F90:1255-1503), diagonal preconditioner
+// preconditioner() with preconditionerChoice = 'evp' (:2331-2366): PX <- sub-block solves of X on the physical cells
+int evp_apply(pop_ctx *c, const double *X, double *PX) {
+  hipLaunchKernelGGL(k_evp_apply, dim3((unsigned)((c->evp.S + POP_EVP_THREADS - 1) / POP_EVP_THREADS)), dim3(POP_EVP_THREADS), 0, c->stream,
+                     c->evp, c->g.nxb, X, PX);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// POP_SolversRun -> pcg (POP_SolversMod.F90:1255-1503), diagonal or EVP preconditioner
 int solver_pcg(pop_ctx *c) {
   const pop_config &cf = c->h.c;
   const dim3 G = grid_2d(c), B(POP_RED_THREADS);
@@ -241,7 +251,12 @@ int solver_pcg(pop_ctx *c) {
   bool pending = false;   // x,r update of the previous iteration not yet applied
   for (int m = 1; m <= cf.max_iterations; ++m) {
     a = solver_args(c);
-    if (pending) hipLaunchKernelGGL(k_pcg_a<true>, G, B, 0, c->stream, c->g, a);
+    if (c->use_evp) {   // :1322-1362: z = M^-1 r by sub-block solves, (r,z), halo of z
+      if (pending) hipLaunchKernelGGL(k_pcg_xr, G, B, 0, c->stream, c->g, a);
+      if (evp_apply(c, c->R, c->Z)) return 1;
+      hipLaunchKernelGGL(k_dot_partial, G, B, 0, c->stream, c->g, (const double *)c->R, (const double *)c->Z, c->g.mMask, c->partial);
+      if (halo_update(c, c->Z, 1)) return 1;
+    } else if (pending) hipLaunchKernelGGL(k_pcg_a<true>, G, B, 0, c->stream, c->g, a);
     else hipLaunchKernelGGL(k_pcg_a<false>, G, B, 0, c->stream, c->g, a);
     if (reduce_finish<1>(c, FIN_PCG_RZ)) return 1;
     hipLaunchKernelGGL(k_pcg_b, G, B, 0, c->stream, c->g, a);
@@ -472,14 +487,18 @@ int solver_chrongear(pop_ctx *c) {
   SolverArgs a = solver_args(c);
   hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
   if (halo_update(c, c->R, 1)) return 1;
-  hipLaunchKernelGGL(k_cg_init, G, B, 0, c->stream, c->g, a);
+  if (c->use_evp) {   // :2009-2032
+    if (evp_apply(c, c->R, c->Z) || halo_update(c, c->Z, 1)) return 1;
+    hipLaunchKernelGGL(k_cg_init<true>, G, B, 0, c->stream, c->g, a);
+  } else hipLaunchKernelGGL(k_cg_init<false>, G, B, 0, c->stream, c->g, a);
   if (halo_update(c, c->Q, 1)) return 1;
   if (reduce_finish<2>(c, FIN_CG_INIT)) return 1;
   hipLaunchKernelGGL(k_cg_update<true>, G, B, 0, c->stream, c->g, a);
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
   for (int m = 1; m <= cf.max_iterations; ++m) {
-    hipLaunchKernelGGL(k_cg_z, G, B, 0, c->stream, c->g, a);
+    if (c->use_evp) { if (evp_apply(c, c->R, c->Z)) return 1; }
+    else hipLaunchKernelGGL(k_cg_z, G, B, 0, c->stream, c->g, a);
     if (halo_update(c, c->Z, 1)) return 1;
     hipLaunchKernelGGL(k_cg_az, G, B, 0, c->stream, c->g, a);
     if (reduce_finish<2>(c, FIN_CG_ITER)) return 1;
@@ -494,6 +513,87 @@ int solver_chrongear(pop_ctx *c) {
       if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
     }
   }
+  c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
+  HIPCHK(c, hipGetLastError());
+  if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversChronGear: solver not converged"; return 2; }
+  return 0;
+}
+
+// ChronGear, fused form for one rank: the start-up pass as in solver_chrongear, then two launches per iteration
+// (k_fcg_a, k_fcg_b: the z halo folded into the matvec through srcmap, scalar recurrences recomputed by every
+// workgroup from the ordered totals) and one hipGraph replay per check interval.  Same arithmetic and summation
+// order as solver_chrongear: bitwise the same solution and iteration count.
+static int cg_fused_iterations(pop_ctx *c, SolveView &v, int n, int &par) {
+  const dim3 G = view_grid(v), B(POP_RED_THREADS);
+  for (int it = 0; it < n; ++it) {
+    FusedArgs a = fused_args(c, v);
+    a.AZ = c->AZ; a.A0R = v.S1;
+    hipLaunchKernelGGL(k_fcg_a, G, B, 0, c->stream, v.g, a);
+    if (a.presummed) hipLaunchKernelGGL(k_block_sums<2>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, (const double *)a.partA, v.nchunk, (const int *)c->iota, (double *)a.bsA);
+    hipLaunchKernelGGL(k_fcg_b, G, B, 0, c->stream, v.g, a, par);
+    par = 1 - par;
+  }
+  return 0;
+}
+static int cg_fused_interval(pop_ctx *c, SolveView &v, int freq) {
+  const dim3 G = view_grid(v), B(POP_RED_THREADS);
+  int par = 0;
+  cg_fused_iterations(c, v, freq, par);
+  hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, v.g, fused_args(c, v));
+  hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_sc);
+  return 0;
+}
+int solver_chrongear_fused(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  SolveView v = local_view(c);
+  const dim3 G = view_grid(v), B(POP_RED_THREADS);
+  const int freq = cf.convergence_check_freq;
+  const long long a2 = (long long)c->g.n2 * c->g.nblocks;
+  SolverScalars init{};
+  HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  SolverArgs a = solver_args(c);
+  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  if (halo_update(c, c->R, 1)) return 1;
+  hipLaunchKernelGGL(k_cg_init<false>, G, B, 0, c->stream, c->g, a);
+  if (halo_update(c, c->Q, 1)) return 1;
+  if (reduce_finish<2>(c, FIN_CG_INIT)) return 1;
+  hipLaunchKernelGGL(k_cg_update<true>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_pcsi_a0r, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->centerWgt, v.S1, a2);
+  c->numIterations = cf.max_iterations;
+  double rr = 0.0;
+  const bool use_graph = (freq % 2 == 0) && !c->no_graph;   // even: the (rho, sigma) ping-pong ends where it started
+  int m = 0;
+  while (m + freq <= cf.max_iterations) {
+    if (use_graph) {
+      hipGraphExec_t exec = nullptr;
+      for (auto &g : c->graphs) if (g.first == v.X) exec = g.second;
+      if (!exec) {
+        hipGraph_t graph;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int e = cg_fused_interval(c, v, freq);
+        hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+        if (e || ce != hipSuccess) { c->err = "solver graph capture failed"; return 1; }
+        HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        c->graphs.push_back({v.X, exec});
+      }
+      HIPCHK(c, hipGraphLaunch(exec, c->stream));
+    } else {
+      int par = (m / freq * freq) & 1;   // odd freq: the ping-pong slot carries over between intervals
+      cg_fused_iterations(c, v, freq, par);
+      hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, v.g, fused_args(c, v));
+      hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_sc);
+    }
+    m += freq;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rr = c->host_sc->rr;
+    if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
+  }
+  if (c->numIterations == cf.max_iterations && m < cf.max_iterations) {   // remainder without a check
+    int par = m & 1;
+    cg_fused_iterations(c, v, cf.max_iterations - m, par);
+  }
+  hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, v.X, v.srcmap, a2);
   c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
   HIPCHK(c, hipGetLastError());
   if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversChronGear: solver not converged"; return 2; }
@@ -518,7 +618,14 @@ int solver_pcsi(pop_ctx *c) {
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   SolverArgs a = solver_args(c);
   hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
-  hipLaunchKernelGGL(k_pcsi_precond, G1, B1, 0, c->stream, c->g, c->R, (const double *)c->centerWgt, a2);
+  auto precond = [&]() -> int {   // r' = M^-1 r in place (:1646-1660, :1738-1752)
+    if (c->use_evp) {
+      if (evp_apply(c, c->R, c->Z)) return 1;
+      HIPCHK(c, hipMemcpyAsync(c->R, c->Z, sizeof(double) * a2, hipMemcpyDeviceToDevice, c->stream));
+    } else hipLaunchKernelGGL(k_pcsi_precond, G1, B1, 0, c->stream, c->g, c->R, (const double *)c->centerWgt, a2);
+    return 0;
+  };
+  if (precond()) return 1;
   if (halo_update(c, c->R, 1)) return 1;
   hipLaunchKernelGGL(k_pcsi_update<true>, G1, B1, 0, c->stream, (const double *)c->R, c->Q, a.X, a2, (const double *)c->pcsi_omega,
                      (const int *)c->pcsi_base, 0, c->pcsi_csy);
@@ -528,7 +635,7 @@ int solver_pcsi(pop_ctx *c) {
   const int start = pcsi_check_start(c);
   for (int m = 1; m <= cf.max_iterations; ++m) {
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->pcsi_base, m - 1);
-    hipLaunchKernelGGL(k_pcsi_precond, G1, B1, 0, c->stream, c->g, c->R, (const double *)c->centerWgt, a2);
+    if (precond()) return 1;
     if (halo_update(c, c->R, 1)) return 1;
     hipLaunchKernelGGL(k_pcsi_update<false>, G1, B1, 0, c->stream, (const double *)c->R, c->Q, a.X, a2, (const double *)c->pcsi_omega,
                        (const int *)c->pcsi_base, 1, c->pcsi_csy);
@@ -875,6 +982,32 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
       c->pcsi_csy = csy;
       if (dev_upload(c, &c->pcsi_omega, om.data(), om.size()) || dev_alloc(c, &c->pcsi_base, 1)) return 1;
     }
+    if (use_evp(*cfg)) {   // EVP sub-blocks of the local blocks, coefficient arrays transposed to [cell][sub-block]
+      const EvpHost &E = h.evp;
+      const size_t nsb = (size_t)E.xnb * E.ynb, S = nsb * h.nblocks;
+      constexpr int NC = EVP_LD * EVP_LD, NR = EVP_LE * EVP_LE;
+      std::vector<int4> meta(S);
+      std::vector<double> cc(S * NC), ne(S * NC), icc(S * NC), ine(S * NC), rinv(S * NR);
+      for (int lb = 0; lb < h.nblocks; ++lb) {
+        const size_t gb = (size_t)h.local_ids[lb] - 1;
+        for (int j = 1; j <= E.ynb; ++j) for (int i = 1; i <= E.xnb; ++i) {
+          const size_t sl = lb * nsb + (size_t)(j - 1) * E.xnb + (i - 1), sg = gb * nsb + (size_t)(j - 1) * E.xnb + (i - 1);
+          const int is = E.xidx[i], ie = E.xidx[i + 1] + 1, js = E.yidx[j], je = E.yidx[j + 1] + 1;
+          meta[sl] = make_int4((int)(lb * h.n2 + (size_t)(js - 1) * h.nxb + (is - 1)), (ie - is + 1) | ((je - js + 1) << 8), E.land[sg], 0);
+          for (int q = 0; q < NC; ++q) {
+            cc[q * S + sl] = E.cc[sg * NC + q]; ne[q * S + sl] = E.ne[sg * NC + q];
+            icc[q * S + sl] = E.icc[sg * NC + q]; ine[q * S + sl] = E.ine[sg * NC + q];
+          }
+          for (int q = 0; q < NR; ++q) rinv[q * S + sl] = E.rinv[sg * NR + q];
+        }
+      }
+      int4 *dm; double *d0, *d1, *d2, *d3, *d4;
+      if (dev_upload(c, &dm, meta.data(), S) || dev_upload(c, &d0, cc.data(), cc.size()) || dev_upload(c, &d1, ne.data(), ne.size()) ||
+          dev_upload(c, &d2, icc.data(), icc.size()) || dev_upload(c, &d3, ine.data(), ine.size()) || dev_upload(c, &d4, rinv.data(), rinv.size())) return 1;
+      c->evp = EvpDev{(long long)S, dm, d0, d1, d2, d3, d4};
+      c->use_evp = true;
+      c->fused_ok = false;
+    }
     c->no_graph = getenv("POP_SOLVER_NOGRAPH") != nullptr;
     if (getenv("POP_MOMENTUM_LDS")) c->mom_lds_rows = atoi(getenv("POP_MOMENTUM_LDS"));
     // tracer RHS through LDS tiles (kernels_tracer_lds.hpp).  Measured against the direct-load kernel: tx0.1v3 15.0 ms ->
@@ -888,7 +1021,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     c->reg_thomas_t = c->reg_thomas && (h.n2 * h.nblocks <= (1u << 19));
     if (getenv("POP_REG_THOMAS_T")) c->reg_thomas_t = atoi(getenv("POP_REG_THOMAS_T")) != 0;
     c->force_presum = getenv("POP_SOLVER_PRESUM") != nullptr;
-    c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && h.nblocks_tot <= 8 &&
+    c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && !use_evp(*cfg) && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !getenv("POP_SOLVER_DISTRIBUTED");
     if (c->replicated) {
       const size_t NG = h.n2 * h.nblocks_tot;
@@ -1186,12 +1319,14 @@ int pop_baroclinic_driver(pop_ctx *c) {
 
 int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
-  if (c->h.c.solver_choice == 2) return solver_chrongear(c);
+  if (c->h.c.solver_choice == 2) return (c->fused_ok && !c->use_evp) ? solver_chrongear_fused(c) : solver_chrongear(c);
   if (c->h.c.solver_choice == 3) {
+    if (c->use_evp) return solver_pcsi(c);
     if (c->fused_ok) return solver_pcsi_fused(c);
     if (c->h.nranks > 1 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcsi_fused_dist(c);
     return solver_pcsi(c);
   }
+  if (c->use_evp) return solver_pcg(c);
   if (c->replicated) {
     if (!c->allred || !c->redbuf || c->red_doubles < 2LL * c->g.n2 * c->h.nblocks_tot) { c->err = "replicated solve needs pop_set_comm with a reduce buffer of pop_reduce_buffer_doubles()"; return 1; }
     return solver_pcg_replicated(c);
@@ -1199,6 +1334,18 @@ int pop_solver_run(pop_ctx *c) {
   if (c->fused_ok) { SolveView v = local_view(c); const int e = solver_pcg_fused(c, v); c->S0 = v.S0; c->S1 = v.S1; return e; }
   if (c->h.nranks > 1 && c->h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcg_fused_dist(c);
   return solver_pcg(c);
+}
+int pop_solver_preconditioner(pop_ctx *c, const char *x_name, int x_tl, const char *px_name, int px_tl) {
+  if (need_device(c)) return 1;
+  double *x, *px; long long cnt, a2 = (long long)c->g.n2 * c->g.nblocks;
+  if (resolve(c, x_name, x_tl, 0, &x, &cnt) || cnt != a2) { c->err = std::string("unknown 2-D field ") + x_name; return 1; }
+  if (resolve(c, px_name, px_tl, 0, &px, &cnt) || cnt != a2 || px == x) { c->err = std::string("unknown 2-D field ") + px_name; return 1; }
+  HIPCHK(c, hipMemsetAsync(px, 0, sizeof(double) * a2, c->stream));
+  if (c->use_evp) return evp_apply(c, x, px);
+  HIPCHK(c, hipMemcpyAsync(px, x, sizeof(double) * a2, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_pcsi_precond, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, c->g, px, (const double *)c->centerWgt, a2);
+  HIPCHK(c, hipGetLastError());
+  return 0;
 }
 int pop_solver_get_diagnostics(const pop_ctx *c, int *it, double *rms) {
   if (it) *it = c->numIterations;

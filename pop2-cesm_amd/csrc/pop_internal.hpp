@@ -47,6 +47,18 @@ struct HaloPlan {
   TripolePlan tripole[4];               // by location: 0 centre, 1 NE corner, 2 N face, 3 E face (ns_boundary = 2)
 };
 
+// ---- EVP block preconditioner (reserved_i[2] = 1; POP_SolversMod.F90:252-290, 2434-2696): sub-blocks of at most
+//      EVP_BS x EVP_BS cells with a one-cell rim, for every block of the decomposition
+constexpr int EVP_BS = 8, EVP_LD = EVP_BS + 2, EVP_LE = 2 * EVP_BS - 1;
+struct EvpHost {
+  int xnb = 0, ynb = 0;                     // sub-blocks per block in x, y
+  std::vector<int> xidx, yidx;              // 1-based start indices xidx[1..xnb+1] (EvpBlockPartition)
+  // sub-block s = (block*ynb + j-1)*xnb + i-1; (a,c) of the sub-block with rim at (a-1) + EVP_LD*(c-1)
+  std::vector<double> cc, ne, icc, ine;     // centre / NE weight and their inverses
+  std::vector<double> rinv;                 // inverse influence matrix, (k,j) at (k-1) + EVP_LE*(j-1)
+  std::vector<int> land;                    // 1: diagonal scaling instead of the EVP solve
+};
+
 // ---- host-side model: everything init-time (restates grid.F90, hmix_del*.F90 init,
 //      POP_SolversInit, init_barotropic, init_ts) on the local blocks of this rank
 struct HostModel {
@@ -75,6 +87,7 @@ struct HostModel {
   // P-CSI (solver_choice = 3): Lanczos eigenvalue bounds from host_pcsi_prep (POP_SolversMod.F90:181-320)
   double pcsi_max_eig = 0, pcsi_min_eig = 0;
   int pcsi_lanczos_steps = 0;
+  EvpHost evp;
   HaloPlan halo;
   std::string err;
 
@@ -83,7 +96,11 @@ struct HostModel {
 };
 
 int host_build(HostModel &h);            // host_setup.cpp
-int host_pcsi_prep(HostModel &h);        // host_pcsi.cpp
+std::vector<double> host_center_init(HostModel &h);                      // centre weight POP_SolversPrep sees (host_pcsi.cpp)
+int host_pcsi_prep(HostModel &h, const std::vector<double> &C);         // host_pcsi.cpp
+int host_evp_prep(HostModel &h, const std::vector<double> &C);          // host_evp.cpp
+void host_evp_apply(const HostModel &h, double *PX, const double *X);   // all blocks
+inline bool use_evp(const pop_config &c) { return c.reserved_i[2] == 1; }
 void build_halo_plan(HostModel &h);      // halo_plan.cpp
 void host_halo_r8(const HostModel &h, double *a, int nz, double fill);   // single-rank host halo
 void host_halo_i4(const HostModel &h, int *a, int nz, int fill);

@@ -206,6 +206,12 @@
          integer (c_int), value :: block_local
          real (c_double), intent(in) :: corr(*)
       end function
+      integer (c_int) function pop_solver_preconditioner(ctx, xname, xtl, pxname, pxtl) bind(C, name='pop_solver_preconditioner')
+         import :: c_int, c_ptr, c_char
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: xname(*), pxname(*)
+         integer (c_int), value :: xtl, pxtl
+      end function
       integer (c_int) function pop_halo_update_loc(ctx, name, tl, n, loc, kind) bind(C, name='pop_halo_update_loc')
          import :: c_int, c_ptr, c_char
          type (c_ptr), value :: ctx

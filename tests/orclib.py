@@ -45,6 +45,9 @@ def load():
     L.orc_global_sum_tripole.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
     L.orc_halo_update_tripole.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int]
     L.orc_halo_update_tripole_int.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int]
+    L.orc_preconditioner.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_preconditioner.restype = None
+    L.orc_evp_info.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_global_sum.restype = C.c_double
     L.orc_global_sum.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return L
@@ -106,6 +109,15 @@ class Oracle:
         if not p:
             raise KeyError(name)
         return np.ctypeslib.as_array(p, shape=(self.km + 3,))
+
+    def preconditioner(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        px = np.empty_like(x)
+        self.L.orc_preconditioner(self.h, x.ctypes.data_as(C.POINTER(C.c_double)), px.ctypes.data_as(C.POINTER(C.c_double)))
+        return px
+
+    def evp_info(self, what, idx=0):
+        return self.L.orc_evp_info(self.h, what, idx)
 
     def step(self):
         e = self.L.orc_step(self.h)

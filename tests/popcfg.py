@@ -59,9 +59,12 @@ def base_config(**kw):
 
 
 def _apply(c, kw):
-    """Set fields by name; robert_alpha / robert_nu live in reserved_d[1], [2] (tmix_opt = 3)."""
+    """Set fields by name; robert_alpha / robert_nu live in reserved_d[1], [2] (tmix_opt = 3),
+    precond_choice (0 diagonal, 1 evp) in reserved_i[2]."""
     for k, v in kw.items():
-        if k == "robert_alpha":
+        if k == "precond_choice":
+            c.reserved_i[2] = v
+        elif k == "robert_alpha":
             c.reserved_d[1] = v
         elif k == "robert_nu":
             c.reserved_d[2] = v

@@ -26,6 +26,8 @@ def _port():
     (2, "solver_choice=3", {"POP_SOLVER_UNFUSED": "1"}),              # P-CSI operation by operation
     (4, "solver_choice=3,block_size_x=24,block_size_y=20", {}),       # P-CSI, one block per rank
     (2, "solver_choice=2", {}),                                       # ChronGear
+    (2, "precond_choice=1", {}),                                      # EVP preconditioner, pcg: extra z halo per iteration
+    (3, "precond_choice=1,solver_choice=3,block_size_x=24,block_size_y=20", {}),   # P-CSI + EVP, uneven ownership
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3 across ranks
 ])
 def test_multirank_equals_single_rank(nranks, kw, env):

@@ -142,6 +142,11 @@ def force_kpp_case(gpu, orc):
     ("tiny", {"solver_choice": 3}, 4),                               # P-CSI (no inner product per iteration)
     ("gx3v7", {"solver_choice": 3}, 3),
     ("tiny", {"solver_choice": 3, "block_size_x": 48, "block_size_y": 40, "vmix_choice": 3, "km": 24}, 4),
+    ("tiny", {"precond_choice": 1}, 4),                              # EVP block preconditioner, pcg
+    ("tiny", {"precond_choice": 1, "solver_choice": 2, "block_size_x": 16, "block_size_y": 20}, 4),   # ChronGear + EVP, 8/6/6 pieces
+    ("tiny", {"precond_choice": 1, "solver_choice": 3}, 4),          # P-CSI + EVP (Lanczos through the preconditioner)
+    ("gx3v7", {"precond_choice": 1}, 3),
+    ("test", {"precond_choice": 1, "solver_choice": 3}, 4),
     ("tiny", {"tmix_opt": 3}, 5),                                    # Robert-Asselin-Williams filter (alpha 0.53, nu 0.2)
     ("tiny", {"tmix_opt": 3, "robert_alpha": 1.0, "vmix_choice": 3, "km": 24}, 5),   # classic Robert-Asselin: previous-step averaging
 ])
@@ -456,6 +461,30 @@ def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
     gpu.close(); orc.close()
 
 
+@pytest.mark.parametrize("name,kw", [("tiny", {}), ("tiny", {"block_size_x": 16, "block_size_y": 20}), ("gx3v7", {})])
+def test_evp_preconditioner_is_bitwise_the_oracle(pkg, orclib_built, name, kw):
+    """preconditioner() on its own (POP_SolversMod.F90:2268-2369, 2618-2696): the sub-block marches are sequential
+    and written in the reference's operation order on both sides, so PX agrees bit for bit; the eigenvalue bounds
+    P-CSI derives through it (Lanczos on the host) are identical too."""
+    cfg = named_config(name, precond_choice=1, solver_choice=3, **kw)
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    assert gpu.scalar("PcsiMaxEigs") == orc.scalar("PcsiMaxEigs") and gpu.scalar("PcsiMinEigs") == orc.scalar("PcsiMinEigs")
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((gpu.nblocks, gpu.nyb, gpu.nxb))
+    gpu.set("RHS", x)
+    gpu.solver_preconditioner("RHS", "DH")
+    assert np.array_equal(gpu.get("DH"), orc.preconditioner(x))
+    gpu.close(); orc.close()
+    # diagonal choice through the same entry
+    cfg = named_config(name, **kw)
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    gpu.step(); orc.step()
+    gpu.set("RHS", x)
+    gpu.solver_preconditioner("RHS", "DH")
+    assert np.array_equal(interior(gpu.get("DH")), interior(orc.preconditioner(x)))
+    gpu.close(); orc.close()
+
+
 @pytest.mark.parametrize("solver", [1, 2, 3])
 def test_solver_error_convention(pkg, orclib_built, solver):
     """POP_SolversMod.F90:1492-1497: hitting maxIterations is an error (errorCode set, message) unless
@@ -494,11 +523,12 @@ def test_fused_pcsi_is_bitwise_the_unfused_pcsi(pkg, monkeypatch):
     a.close(); b.close(); c.close()
 
 
-def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch):
-    """The single-rank fused PCG (halo folded into the matvec, in-kernel final reduction, hipGraph
+@pytest.mark.parametrize("kw", [{}, {"solver_choice": 2}, {"solver_choice": 2, "convergence_check_freq": 5, "max_iterations": 203}])
+def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
+    """The single-rank fused PCG / ChronGear (halo folded into the matvec, in-kernel final reduction, hipGraph
     replay) must produce exactly the bits of the plain kernel-per-operation path."""
     import os
-    cfg = named_config("tiny", block_size_x=24, block_size_y=20)      # 4 blocks
+    cfg = named_config("tiny", block_size_x=24, block_size_y=20, **kw)      # 4 blocks
     a = pkg.PopModel(cfg)
     monkeypatch.setenv("POP_SOLVER_UNFUSED", "1")
     b = pkg.PopModel(cfg)
