@@ -97,6 +97,17 @@ long long pop_field_count(const pop_ctx *ctx, const char *name);
 /* device pointer of a field (for zero-copy host frameworks); 0 if unknown */
 void *pop_field_device_ptr(pop_ctx *ctx, const char *name, int tl, int n);
 
+/* ---- restart files: write_restart (restart.F90:1095-1715) / read_restart (:184-1088) in the reference's 'bin'
+ * format (io_binary.F90): <path> = direct-access records of nx_global*ny_global r8 (native byte order, a 3-D field
+ * = km records), <path>.hdr = text header with the scalars as "&GLOBAL" attributes and one "&NAME ... id:int:<first
+ * record> ... /" section per field.  Fields: {UBTROP,VBTROP,PSURF,GRADPX,GRADPY}_{CUR,OLD}, PGUESS, FW_OLD,
+ * FW_FREEZE (zeros), {UVEL,VVEL,TEMP,SALT}_{CUR,OLD}.  Every rank writes / reads the rows of its own blocks
+ * (shared file system), rank 0 writes the header.  Reading applies the land masks and halo updates of
+ * read_restart :881-1040, recomputes RHO at both time levels (initial.F90:1665-1681) and continues with leapfrog
+ * steps (first_step = .false., initial.F90:1088).  flags bit 0: the data file is byte-swapped. */
+int pop_write_restart(pop_ctx *ctx, const char *path);
+int pop_read_restart(pop_ctx *ctx, const char *path, int flags);
+
 /* ---- the step_mod.F90:126-911 call sequence --------------------------------- */
 int pop_time_manager(pop_ctx *ctx);              /* time_management.F90:1823-1847, 2139-2234 */
 int pop_dhdt(pop_ctx *ctx);                      /* surface_hgt.F90:131   dhdt(DH,DHU) */

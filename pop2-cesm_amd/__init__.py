@@ -64,6 +64,7 @@ def lib():
         "pop_global_sum_nfields": (ci, [vp, ci, C.POINTER(cs), pi, pi, cs, pd]),
         "pop_global_sum_prod": (ci, [vp, cs, ci, ci, cs, ci, ci, cs, pd]),
         "pop_global_sum_scalar": (ci, [vp, cd, pd]), "pop_global_sum_i4": (ci, [vp, cs, C.POINTER(ll)]),
+        "pop_write_restart": (ci, [vp, cs]), "pop_read_restart": (ci, [vp, cs, ci]),
         "pop_solver_diagonal": (ci, [vp, ci, pd]),
         "pop_solver_preconditioner": (ci, [vp, cs, ci, cs, ci]),
         "pop_solver_get_diagnostics": (ci, [vp, pi, pd]),
@@ -271,6 +272,13 @@ class PopModel:
         a = np.ascontiguousarray(corr, dtype=np.float64)
         assert a.size == self.nxb * self.nyb
         self._chk(self.L.pop_solver_diagonal(self.h, block_local, a.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def write_restart(self, path):
+        """POP binary restart (<path> + <path>.hdr), restart.F90:1095-1715"""
+        self._chk(self.L.pop_write_restart(self.h, os.fsencode(path)))
+
+    def read_restart(self, path, byteswap=False):
+        self._chk(self.L.pop_read_restart(self.h, os.fsencode(path), 1 if byteswap else 0))
 
     def solver_preconditioner(self, x_name, px_name, x_tl=1, px_tl=1):
         """PX = M^-1 X on the physical cells (EVP sub-block solves when reserved_i[2] = 1, else the diagonal)"""

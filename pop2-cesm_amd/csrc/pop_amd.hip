@@ -14,6 +14,8 @@
 #include "kernels_rf.hpp"
 #include "kernels_pcsi.hpp"
 #include "kernels_evp.hpp"
+#include <fcntl.h>
+#include <unistd.h>
 #include "rccl_transport.hpp"
 
 using namespace pop;
@@ -1185,6 +1187,118 @@ void *pop_field_device_ptr(pop_ctx *c, const char *name, int tl, int n) {
   if (c->host_only) return nullptr;
   double *p; long long cnt;
   return resolve(c, name, tl, n, &p, &cnt) ? nullptr : (void *)p;
+}
+
+// ---- restart files (restart.F90 write_restart :1095-1715, read_restart :184-1088; 'bin' format of io_binary.F90)
+static std::string fmt_r8(double v) { char b[40]; snprintf(b, sizeof b, "%.17g", v); return b; }
+int pop_write_restart(pop_ctx *c, const char *path) {
+  if (need_device(c)) return 1;
+  const HostModel &h = c->h;
+  const std::vector<RestartField> fields = restart_fields(h);
+  if (h.rank == 0) {
+    // calendar of a run that starts 0001-01-01 00:00 with 365-day years (time_management.F90 defaults)
+    const double secs = (double)c->nsteps_total * h.dtt;
+    const long long day = (long long)(secs / 86400.0);
+    const int sod = (int)(secs - 86400.0 * (double)day);
+    static const int mdays[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+    int doy = (int)(day % 365), month = 1;
+    while (doy >= mdays[month - 1]) { doy -= mdays[month - 1]; ++month; }
+    std::vector<RestartAttr> at = {
+      {"title", "char", "POP restart"}, {"history", "char", "written by libpop_amd"}, {"conventions", "char", "POP binary restart"},
+      {"runid", "char", "pop_amd"}, {"iyear", "int", std::to_string(1 + day / 365)}, {"imonth", "int", std::to_string(month)},
+      {"iday", "int", std::to_string(doy + 1)}, {"ihour", "int", std::to_string(sod / 3600)}, {"iminute", "int", std::to_string(sod % 3600 / 60)},
+      {"isecond", "int", std::to_string(sod % 60)}, {"iyear0", "int", "1"}, {"imonth0", "int", "1"}, {"iday0", "int", "1"},
+      {"ihour0", "int", "0"}, {"iminute0", "int", "0"}, {"isecond0", "int", "0"}, {"dtt", "r8", fmt_r8(h.dtt)},
+      {"elapsed_days", "int", std::to_string(day)}, {"seconds_this_day", "r8", fmt_r8((double)sod)},
+      {"nsteps_total", "int", std::to_string(c->nsteps_total)},
+      {"nsteps_this_interval", "int", std::to_string(c->nsteps_this_interval)},   // extension: exact restart inside an averaging interval
+    };
+    if (h.c.tmix_opt == 3) {
+      static const char *tn[2] = {"TEMP", "SALT"};
+      for (int n = 0; n < 2; ++n) if (c->rf_S_prev_valid[n]) at.push_back({std::string("rf_S_prev_") + tn[n], "r8", fmt_r8(c->rf_S_prev[n])});
+    }
+    if (restart_write_header(h, path, at, fields, c->err)) return 1;
+  }
+  const int fd = open(path, O_WRONLY | O_CREAT, 0644);
+  if (fd < 0) { c->err = std::string("cannot open ") + path + " for writing"; return 1; }
+  const size_t a2 = (size_t)c->g.n2 * c->g.nblocks, a3 = (size_t)c->g.n3 * c->g.nblocks;
+  std::vector<double> buf(a3);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = 0;
+  for (const RestartField &f : fields) {
+    const size_t cnt = f.ndims == 3 ? a3 : a2;
+    if (f.dev.empty()) std::fill(buf.begin(), buf.begin() + cnt, 0.0);
+    else {
+      double *p; long long n;
+      if (resolve(c, f.dev, f.tl, f.n, &p, &n) || (size_t)n != cnt) { c->err = "restart: unknown field " + f.dev; rc = 1; break; }
+      if (hipMemcpy(buf.data(), p, cnt * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { c->err = "restart: device copy failed"; rc = 1; break; }
+    }
+    const int nz = f.ndims == 3 ? h.km : 1;
+    for (int k = 0; k < nz && !rc; ++k)
+      rc = restart_slab_io(h, fd, f.id + k, buf.data() + (size_t)k * h.n2, f.ndims == 3 ? h.n3 : h.n2, true, false, c->err);
+    if (rc) break;
+  }
+  if (close(fd) != 0 && !rc) { c->err = "restart: close failed"; rc = 1; }
+  return rc;
+}
+
+int pop_read_restart(pop_ctx *c, const char *path, int flags) {
+  if (need_device(c)) return 1;
+  const HostModel &h = c->h;
+  std::map<std::string, std::map<std::string, std::string>> sec;
+  if (restart_parse_header(path, sec, c->err)) return 1;
+  std::vector<RestartField> fields = restart_fields(h);
+  for (RestartField &f : fields) {   // record of each field from the header (define_field_binary :1075-1080), not from our own order
+    auto it = sec.find(f.name);
+    if (it == sec.end() || !it->second.count("id")) {
+      if (f.dev.empty()) { f.id = -1; continue; }                    // FW_FREEZE is not used here
+      c->err = "could not find field in binary header file: " + f.name; return 1;
+    }
+    f.id = atoi(it->second["id"].c_str());
+    if (it->second.count("nfield_dims") && atoi(it->second["nfield_dims"].c_str()) != f.ndims) { c->err = "restart: wrong rank for " + f.name; return 1; }
+  }
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) { c->err = std::string("cannot open ") + path; return 1; }
+  const std::vector<int> KMT = local_part(h, c->h.i2["KMT"]), KMU = local_part(h, c->h.i2["KMU"]);
+  const size_t a2 = (size_t)c->g.n2 * c->g.nblocks, a3 = (size_t)c->g.n3 * c->g.nblocks;
+  std::vector<double> buf(a3);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc = 0;
+  for (const RestartField &f : fields) {
+    if (f.dev.empty() || f.id < 0) continue;
+    const size_t cnt = f.ndims == 3 ? a3 : a2;
+    std::fill(buf.begin(), buf.begin() + cnt, 0.0);
+    const int nz = f.ndims == 3 ? h.km : 1;
+    for (int k = 0; k < nz && !rc; ++k)
+      rc = restart_slab_io(h, fd, f.id + k, buf.data() + (size_t)k * h.n2, f.ndims == 3 ? h.n3 : h.n2, false, (flags & 1) != 0, c->err);
+    if (rc) break;
+    restart_mask(h, f, buf.data(), KMT, KMU);
+    double *p; long long n;
+    if (resolve(c, f.dev, f.tl, f.n, &p, &n) || (size_t)n != cnt) { c->err = "restart: unknown field " + f.dev; rc = 1; break; }
+    if (hipMemcpy(p, buf.data(), cnt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { c->err = "restart: device copy failed"; rc = 1; break; }
+    if (halo_update(c, p, nz)) { rc = 1; break; }                    // read_restart :960-1040 (fillValue 0)
+  }
+  close(fd);
+  if (rc) return rc;
+  // init_ts :1665-1681: density of both time levels from the tracers just read
+  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->curt], c->TR[1][c->curt], c->RHO[c->curt]);
+  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->oldt], c->TR[1][c->oldt], c->RHO[c->oldt]);
+  HIPCHK(c, hipGetLastError());
+  // scalars: initial.F90:1088 first_step = .false.; time_management.F90:1426 nsteps_this_interval = 0 unless the file says otherwise
+  std::map<std::string, std::string> &g = sec["GLOBAL"];
+  if (!g.count("nsteps_total")) { c->err = "restart: header has no nsteps_total"; return 1; }
+  c->nsteps_total = atoi(g["nsteps_total"].c_str());
+  c->nsteps_this_interval = g.count("nsteps_this_interval") ? atoi(g["nsteps_this_interval"].c_str()) : 0;
+  c->first_step = 0;
+  if (h.c.tmix_opt == 3) {
+    static const char *tn[2] = {"TEMP", "SALT"};
+    for (int n = 0; n < 2; ++n) {
+      const std::string key = std::string("rf_S_prev_") + tn[n];
+      c->rf_S_prev_valid[n] = g.count(key) != 0;                     // extract_attrib_file(..., from_file=rf_S_prev_valid) :516-519
+      if (c->rf_S_prev_valid[n]) c->rf_S_prev[n] = strtod(g[key].c_str(), nullptr);
+    }
+  }
+  return 0;
 }
 
 // ---- time_manager + set_switches (time_management.F90:1823-1847, 2139-2234) ----------------

@@ -96,6 +96,19 @@ struct HostModel {
 };
 
 int host_build(HostModel &h);            // host_setup.cpp
+// ---- POP binary restart files (host_restart.cpp; restart.F90, io_binary.F90)
+struct RestartField {
+  std::string name, dev; int tl, n, ndims, id;       // file name; device field, time level (0 old, 1 cur), tracer; first record
+  std::string long_name, units, grid_loc;
+  int mask;                                          // 1 CALCU, 2 CALCT, 3 k > KMU, 4 k > KMT (read_restart :881-935)
+};
+struct RestartAttr { std::string name, type, value; };
+std::vector<RestartField> restart_fields(const HostModel &h);
+int restart_write_header(const HostModel &h, const std::string &path, const std::vector<RestartAttr> &attrs,
+                         const std::vector<RestartField> &fields, std::string &err);
+int restart_parse_header(const std::string &path, std::map<std::string, std::map<std::string, std::string>> &sec, std::string &err);
+int restart_slab_io(const HostModel &h, int fd, long long rec, double *loc, size_t blk_stride, bool write, bool swap, std::string &err);
+void restart_mask(const HostModel &h, const RestartField &f, double *loc, const std::vector<int> &KMT, const std::vector<int> &KMU);
 std::vector<double> host_center_init(HostModel &h);                      // centre weight POP_SolversPrep sees (host_pcsi.cpp)
 int host_pcsi_prep(HostModel &h, const std::vector<double> &C);         // host_pcsi.cpp
 int host_evp_prep(HostModel &h, const std::vector<double> &C);          // host_evp.cpp

@@ -206,6 +206,17 @@
          integer (c_int), value :: block_local
          real (c_double), intent(in) :: corr(*)
       end function
+      integer (c_int) function pop_write_restart(ctx, path) bind(C, name='pop_write_restart')
+         import :: c_int, c_ptr, c_char
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: path(*)
+      end function
+      integer (c_int) function pop_read_restart(ctx, path, flags) bind(C, name='pop_read_restart')
+         import :: c_int, c_ptr, c_char
+         type (c_ptr), value :: ctx
+         character (kind=c_char), intent(in) :: path(*)
+         integer (c_int), value :: flags
+      end function
       integer (c_int) function pop_solver_preconditioner(ctx, xname, xtl, pxname, pxtl) bind(C, name='pop_solver_preconditioner')
          import :: c_int, c_ptr, c_char
          type (c_ptr), value :: ctx

@@ -334,3 +334,25 @@
       errorCode = pop_step_tail(pop_ctx)                ! :467-832
    end subroutine step
  end module step_mod
+
+!-----------------------------------------------------------------------
+ module restart              ! source/restart.F90:184, 1095 ('bin' format of io_binary.F90)
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   public :: read_restart, write_restart
+ contains
+   ! read_restart(in_filename, ..., errorCode): fields, land masks, halos, RHO, leapfrog continuation
+   subroutine read_restart(in_filename, errorCode)
+      character (*), intent(in) :: in_filename
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_read_restart(pop_ctx, cstr(in_filename), 0)
+   end subroutine
+   ! write_restart(restart_type): the file name is built by the caller (create_restart_suffix :1909)
+   subroutine write_restart(out_filename, errorCode)
+      character (*), intent(in) :: out_filename
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_write_restart(pop_ctx, cstr(out_filename))
+   end subroutine
+ end module restart

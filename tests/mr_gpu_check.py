@@ -56,6 +56,27 @@ def main():
             print("rank %d: global_extreme(max=%s) differs" % (rank, want_max)); ok = False
     if m.global_count("UBTROP", 1, 0) != ref.global_count("UBTROP", 1, 0) or m.global_sum("PSURF", 1, 0) != ref.global_sum("PSURF", 1, 0):
         print("rank %d: global count / sum differs" % rank); ok = False
+    # restart file written by all ranks together (each its own rows), read back by all ranks and by the single-rank twin
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), "mr_restart_%s.bin" % os.environ.get("MASTER_PORT", "0"))
+    m.write_restart(path)
+    dist.barrier()
+    m2 = pkg.PopModel(cfg, rank=rank, nranks=world)
+    comm2 = bench.TorchComm(pkg, m2, rank, world, staged=True)   # noqa: F841
+    m2.read_restart(path)
+    ref2 = pkg.PopModel(cfg); ref2.read_restart(path)
+    for s in range(2):
+        m.step(); m2.step(); ref2.step()
+    for name in ("TRACER", "UVEL", "PSURF", "UBTROP"):
+        a = m.get(name, 1, 0)
+        if not (np.array_equal(a, m2.get(name, 1, 0)) and np.array_equal(a, ref2.get(name, 1, 0)[[i - 1 for i in ids]])):
+            print("rank %d: %s differs after the restart round trip" % (rank, name)); ok = False
+    dist.barrier()
+    if rank == 0:
+        for f in (path, path + ".hdr"):
+            if os.path.exists(f):
+                os.remove(f)
+    m2.close(); ref2.close()
     t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
         print("MR_GPU_CHECK", "OK" if int(t.item()) == 1 else "FAILED", "world", world, "config", args.config, args.kw)
