@@ -12,6 +12,7 @@ struct DevGrid {
   int xcd_remap;                                   // column kernels: workgroup order (kernels_common.hpp col_setup)
   int red_band;                                    // 2-D reduction kernels: XCD-banded chunk order
   int red_tiles;                                   // 2-D reduction kernels: 64x4 tiles in XCD-strided columns
+  int lds_order;                                   // LDS-tiled stencil kernels: 1 = XCD patch order (kernels_common.hpp lds_tile)
   int n2;                                          // nxb*nyb
   long long n3;                                    // n2*km
   const double *dz, *dzw, *zt, *zw, *c2dz, *dzr, *dz2r, *dzwr, *pressz, *bouss, *afac_t, *afac_u;

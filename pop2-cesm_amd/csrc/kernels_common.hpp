@@ -50,6 +50,32 @@ __device__ __forceinline__ TileId tile_of_block(int nxb, int nyb, int tw, int th
   }
   return t;
 }
+// Workgroup -> tile of the LDS-tiled stencil kernels (64 x R column tiles, ntx x nty of them per block).
+// lds_order 1: the tiles are numbered patch by patch (patches of 4 x 8 tiles, row-major inside a patch, patches
+// row-major), and runs of 32 consecutive numbers are dealt to the XCDs in turn (workgroup w runs on XCD w % 8, 32
+// CUs each): the workgroups an XCD runs at the same time form a compact patch, so the halo rows / columns one tile
+// shares with its neighbours are fetched into that XCD's L2 once instead of once per XCD.
+__host__ __device__ inline int lds_grid_x(int lds_order, int ntx, int nty) {
+  const int nt = ntx * nty;
+  return lds_order ? 256 * ((nt + 255) / 256) : nt;
+}
+__device__ __forceinline__ bool lds_tile(int lds_order, int ntx, int nty, int &ti, int &tj) {
+  if (!lds_order) { ti = blockIdx.x % ntx; tj = blockIdx.x / ntx; return true; }
+  constexpr int PW = 4, PH = 8;
+  const int e = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int gi = ((s >> 5) * 8 + e) * 32 + (s & 31);
+  if (gi >= ntx * nty) return false;
+  const int row_tiles = PH * ntx, full_rows = nty / PH;
+  int Pj, r, h;
+  if (gi >= full_rows * row_tiles) { Pj = full_rows; r = gi - full_rows * row_tiles; h = nty - full_rows * PH; }
+  else { Pj = gi / row_tiles; r = gi % row_tiles; h = PH; }
+  const int patch_tiles = h * PW, nfullp = ntx / PW;
+  int Pi, w, rr;
+  if (r < nfullp * patch_tiles) { Pi = r / patch_tiles; w = PW; rr = r % patch_tiles; }
+  else { Pi = nfullp; w = ntx - nfullp * PW; rr = r - nfullp * patch_tiles; }
+  ti = Pi * PW + rr % w; tj = Pj * PH + rr / w;
+  return true;
+}
 __host__ __device__ inline int col_grid_x(int n2, int threads) { const int nt = (n2 + threads - 1) / threads; return 8 * ((nt + 7) / 8); }
 // launch grid x for a col_setup kernel with `threads` x 1 workgroups
 __host__ inline int col_grid(const DevGrid &g, int threads) {

@@ -29,7 +29,9 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a) {
   const long long n2 = g.n2;
   // tiles start at the first physical column/row (0-based NGHOST)
   const int tiles_i = (nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
-  const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i, b = blockIdx.y;
+  const int tiles_j = (nyb - 2 * NGHOST + R - 1) / R, b = blockIdx.y;
+  int ti, tj;
+  if (!lds_tile(g.lds_order, tiles_i, tiles_j, ti, tj)) return;
   const int i0 = NGHOST + ti * POP_COL_THREADS, j0 = NGHOST + tj * R;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * POP_COL_THREADS + tx;
   const int i = i0 + tx, j = j0 + ty;
@@ -214,7 +216,7 @@ template <int R>
 inline void launch_momentum_lds(const DevGrid &g, const StepParams &sp, const MomentumRhsArgs &a, hipStream_t st) {
   const int tiles_i = (g.nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
   const int tiles_j = (g.nyb - 2 * NGHOST + R - 1) / R;
-  hipLaunchKernelGGL(k_momentum_rhs_lds<R>, dim3(tiles_i * tiles_j, g.nblocks), dim3(POP_COL_THREADS, R), 0, st, g, sp, a);
+  hipLaunchKernelGGL(k_momentum_rhs_lds<R>, dim3(lds_grid_x(g.lds_order, tiles_i, tiles_j), g.nblocks), dim3(POP_COL_THREADS, R), 0, st, g, sp, a);
 }
 
 }  // namespace pop

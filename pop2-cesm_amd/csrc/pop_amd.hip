@@ -873,6 +873,8 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   // 2-D solver / reduction kernels: XCD-banded chunk order (same chunks, same partial order, only the workgroup ->
   // chunk assignment changes, so results are bitwise unchanged): gx1v7 4.31 -> 4.01 ms per step (the 9-point
   // matvec finds its j+-1 rows in the XCD's own L2), tx0.1v3 177.1 -> 175.2.  POP_RED_BAND=0 restores the natural order.
+  g.lds_order = 1;
+  if (getenv("POP_LDS_ORDER")) g.lds_order = atoi(getenv("POP_LDS_ORDER"));
   g.red_band = 1;
   if (getenv("POP_RED_BAND")) g.red_band = atoi(getenv("POP_RED_BAND"));
   g.ib = NGHOST + 1; g.ie = h.nxb - NGHOST; g.jb = NGHOST + 1; g.je = h.nyb - NGHOST;
