@@ -5,6 +5,7 @@
 #   profiles/summarize_r01.py turns it into the committed summaries.
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out/prof
 cd /tmp && export TMPDIR=/tmp
 for wl in gx1v7 tx0.1v3; do
   if [ $wl = gx1v7 ]; then S=20; else S=3; fi
