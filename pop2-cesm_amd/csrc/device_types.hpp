@@ -23,6 +23,7 @@ struct DevGrid {
   const double *DUC, *DUN, *DUS, *DUE, *DUW, *DMC, *DMN, *DMS, *DME, *DMW, *DUM, *KXU, *KYU;
   const double *WNE, *WEa, *WNo, *WC0, *mMask, *CHECKER, *CONSTNT;
   const double *SMF1, *SMF2, *SMFT1, *SMFT2;
+  const unsigned char *mMask8;                     // mMask (exactly 0 or 1) as bytes: the fused solver kernels read 1 B instead of 8
 };
 
 // scalar parameters of the current step (step_mod.F90:302-320)

@@ -606,7 +606,7 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
   const long long q = (long long)b * g.n2 + (live ? p2 : 0);
   double r = a.R[q], x = 0.0, s0 = 0.0, qq = 0.0;
   if (UPDATE) { x = a.X[q]; s0 = a.S0[q]; qq = a.Q[q]; }
-  const double cw = a.C[q], mk = g.mMask[q];
+  const double cw = a.C[q], mk = (double)g.mMask8[q];
   double alpha = 0.0;
   if (UPDATE) {
     const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, a.presummed);
@@ -661,7 +661,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
     wv[0] = a.C[q]; wv[1] = g.WNo[q]; wv[2] = g.WNo[q - nxb]; wv[3] = g.WEa[q]; wv[4] = g.WEa[q - 1];
     wv[5] = g.WNE[q]; wv[6] = g.WNE[q - nxb]; wv[7] = g.WNE[q - 1]; wv[8] = g.WNE[q - 1 - nxb];
   }
-  const double mk = g.mMask[q];
+  const double mk = (double)g.mMask8[q];
   const double rz = fused_total(a.partA, a.nchunk, a.nblocks, a.bsA, a.presummed);
   const double bt = rz / a.sc->eta0;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta1 = rz; a.sc->beta_cg = bt; }
@@ -741,7 +741,7 @@ k_fcg_a(DevGrid g, FusedArgs a) {
 #pragma unroll
     for (int t = 1; t < 9; ++t) az = az + wv[t] * zv[t];
     a.Z[q] = zv[0]; a.AZ[q] = az;
-    const double mk = g.mMask[q];
+    const double mk = (double)g.mMask8[q];
     v[0] = (r * zv[0]) * mk; v[1] = (az * zv[0]) * mk;
   }
   wg_reduce_store<2>(v, a.partA, b * gridDim.x + red_chunk(g));
@@ -804,7 +804,7 @@ k_fresidual(DevGrid g, FusedArgs a) {
                         g.WNE[q] * xs(q + nxb + 1) + g.WNE[q - nxb] * xs(q - nxb + 1) + g.WNE[q - 1] * xs(q + nxb - 1) + g.WNE[q - 1 - nxb] * xs(q - nxb - 1);
       const double r = a.Bv[q] - ax;
       a.R[q] = r;
-      if (WITH_RR) v[0] = (r * r) * g.mMask[q];
+      if (WITH_RR) v[0] = (r * r) * (double)g.mMask8[q];
     }
   }
   if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * gridDim.x + red_chunk(g));

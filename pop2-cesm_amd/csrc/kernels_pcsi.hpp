@@ -106,7 +106,7 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
       const double ax = w[0] * xn[0] + w[1] * xn[1] + w[2] * xn[2] + w[3] * xn[3] + w[4] * xn[4] + w[5] * xn[5] + w[6] * xn[6] + w[7] * xn[7] + w[8] * xn[8];
       const double r = bq - ax;
       a.Qo[q] = dx0; a.Xo[q] = xn[0]; a.Ro[q] = r * a0r;
-      if (WITH_RR) v[0] = (r * r) * g.mMask[q];
+      if (WITH_RR) v[0] = (r * r) * (double)g.mMask8[q];
     } else if (a.remote_ghosts && a.srcmap[q] == q) {
       // ghost owned by another rank (multi-rank fused form): its r' arrived by the halo exchange; dx and x
       // are advanced here with the owner's arithmetic, so they never need to be exchanged

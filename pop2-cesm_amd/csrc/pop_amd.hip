@@ -892,6 +892,17 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   G2(DXU); G2(DYU); G2(DXUR); G2(DYUR); G2(UAREA_R); G2(TAREA_R); G2(TAREA); G2(FCOR); G2(HU); G2(HUR);
   G2(AU0); G2(AUN); G2(AUE); G2(AUNE); G2(RCALCT); G2(DTN); G2(DTS); G2(DTE); G2(DTW);
   G2(DUC); G2(DUN); G2(DUS); G2(DUE); G2(DUW); G2(DMC); G2(DMN); G2(DMS); G2(DME); G2(DMW); G2(DUM); G2(KXU); G2(KYU);
+  {   // byte copy of the solver mask (RCALCT: exactly 0 or 1, POP_SolversMod.F90:886)
+    const std::vector<double> mm = local_part(h, h.f2["mMask"]);
+    std::vector<unsigned char> m8(mm.size());
+    for (size_t p = 0; p < mm.size(); ++p) {
+      if (mm[p] != 0.0 && mm[p] != 1.0) { c->err = "solver mask is not 0/1"; return 1; }
+      m8[p] = mm[p] != 0.0;
+    }
+    unsigned char *d8;
+    if (dev_upload(c, &d8, m8.data(), m8.size())) return 1;
+    g.mMask8 = d8;
+  }
   G2(mMask); G2(CHECKER); G2(CONSTNT); G2(SMF1); G2(SMF2); G2(SMFT1); G2(SMFT2);
 #undef G2
   g.WNE = c->d2["btropWgtNE"]; g.WEa = c->d2["btropWgtEast"]; g.WNo = c->d2["btropWgtNorth"]; g.WC0 = c->d2["centerWgtIndep"];
@@ -1037,6 +1048,8 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
       if (dev_upload(c, &p, h.f2["btropWgtNorth"].data(), NG)) return 1; v.g.WNo = p;
       if (dev_upload(c, &p, h.f2["centerWgtIndep"].data(), NG)) return 1; v.g.WC0 = p;
       if (dev_upload(c, &p, h.f2["mMask"].data(), NG)) return 1; v.g.mMask = p;
+      { std::vector<unsigned char> m8(NG); for (size_t q = 0; q < NG; ++q) m8[q] = h.f2["mMask"][q] != 0.0;
+        unsigned char *d8; if (dev_upload(c, &d8, m8.data(), NG)) return 1; v.g.mMask8 = d8; }
       if (dev_upload(c, &c->gTAREA, h.f2["TAREA"].data(), NG)) return 1;
       if (dev_upload(c, &c->gKMT, h.i2["KMT"].data(), NG)) return 1;
       double **vecs[] = {&v.X, &v.R, &v.Z, &v.S0, &v.S1, &v.Q, &v.RHS, &v.C};
