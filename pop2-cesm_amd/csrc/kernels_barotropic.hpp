@@ -775,6 +775,93 @@ k_fcg_b(DevGrid g, FusedArgs a, int par) {
   }
 }
 
+// step B with two horizontally adjacent cells per thread (large grids with an even row pitch): the chunk of 256
+// consecutive cells is handled by 128 threads, the pair (q, q+1) shares its three stencil rows of z and s, which are
+// read as (q-1), (q, q+1) as one 16-byte load, (q+2): 14 load instructions per cell instead of 28.  Same operations
+// in the same order per cell, and the 256 products are reduced by the same tree as in k_fpcg_b: bitwise equal.
+__global__ void __launch_bounds__(POP_RED_THREADS / 2)
+k_fpcg_b2(DevGrid g, FusedArgs a) {
+  __shared__ double sh[POP_RED_THREADS];
+  const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
+  const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;     // first cell of the pair (even)
+  const bool live0 = p0 < g.n2, live1 = p0 + 1 < g.n2;
+  const int pp = live0 ? (int)p0 : 0;
+  const int i = pp % nxb, j = pp / nxb;
+  const long long q = (long long)b * g.n2 + pp;
+  // fast path: both cells strictly inside the physical domain of the same row (no ghost neighbour, no srcmap)
+  const bool fast = live1 && i + 1 > g.ib && i + 2 < g.ie && j + 1 > g.jb && j + 1 < g.je;
+  double v0 = 0.0, v1 = 0.0;
+  double zr[3][4], sr[3][4];
+  double2 cc, no0, nom, ea0, ne0, nem;
+  double eaw = 0.0, ne0w = 0.0, nemw = 0.0, mk0 = 0.0, mk1 = 0.0;
+  if (fast) {   // operands first: the loads are in flight while the total is formed
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const long long o = q + (long long)(r - 1) * nxb;
+      const double2 zc = *reinterpret_cast<const double2 *>(a.Z + o), sc = *reinterpret_cast<const double2 *>(a.S0 + o);
+      zr[r][0] = a.Z[o - 1]; zr[r][1] = zc.x; zr[r][2] = zc.y; zr[r][3] = a.Z[o + 2];
+      sr[r][0] = a.S0[o - 1]; sr[r][1] = sc.x; sr[r][2] = sc.y; sr[r][3] = a.S0[o + 2];
+    }
+    cc = *reinterpret_cast<const double2 *>(a.C + q);
+    no0 = *reinterpret_cast<const double2 *>(g.WNo + q); nom = *reinterpret_cast<const double2 *>(g.WNo + q - nxb);
+    ea0 = *reinterpret_cast<const double2 *>(g.WEa + q); eaw = g.WEa[q - 1];
+    ne0 = *reinterpret_cast<const double2 *>(g.WNE + q); nem = *reinterpret_cast<const double2 *>(g.WNE + q - nxb);
+    ne0w = g.WNE[q - 1]; nemw = g.WNE[q - 1 - nxb];
+    mk0 = (double)g.mMask8[q]; mk1 = (double)g.mMask8[q + 1];
+  }
+  // presummed block sums only (host selects this kernel for large grids): no barrier inside
+  const double rz = fused_total(a.partA, a.nchunk, a.nblocks, a.bsA, 1);
+  const double bt = rz / a.sc->eta0;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { a.sc->eta1 = rz; a.sc->beta_cg = bt; }
+  if (fast) {
+    // rows: 0 = j-1, 1 = j, 2 = j+1; columns: 0 = q-1, 1 = q, 2 = q+1, 3 = q+2
+#define SN(r, c) (zr[r][c] + sr[r][c] * bt)
+    const double sA = SN(1, 1), sB = SN(1, 2);
+    double aqA = cc.x * sA;
+    aqA = aqA + no0.x * SN(2, 1); aqA = aqA + nom.x * SN(0, 1); aqA = aqA + ea0.x * SN(1, 2); aqA = aqA + eaw * SN(1, 0);
+    aqA = aqA + ne0.x * SN(2, 2); aqA = aqA + nem.x * SN(0, 2); aqA = aqA + ne0w * SN(2, 0); aqA = aqA + nemw * SN(0, 0);
+    double aqB = cc.y * sB;
+    aqB = aqB + no0.y * SN(2, 2); aqB = aqB + nom.y * SN(0, 2); aqB = aqB + ea0.y * SN(1, 3); aqB = aqB + ea0.x * SN(1, 1);
+    aqB = aqB + ne0.y * SN(2, 3); aqB = aqB + nem.y * SN(0, 3); aqB = aqB + ne0.x * SN(2, 1); aqB = aqB + nem.x * SN(0, 1);
+#undef SN
+    *reinterpret_cast<double2 *>(a.S1 + q) = make_double2(sA, sB);
+    *reinterpret_cast<double2 *>(a.Q + q) = make_double2(aqA, aqB);
+    v0 = (aqA * sA) * mk0; v1 = (aqB * sB) * mk1;
+  } else {
+    // generic path, cell by cell (rim of the physical domain, ghost cells, ragged end of the block)
+    const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (!(e == 0 ? live0 : live1)) continue;
+      const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
+      const long long qq = (long long)b * g.n2 + p2;
+      const double s = a.Z[qq] + a.S0[qq] * bt;
+      double aq = 0.0, vv = 0.0;
+      if (interior(g, ii, jj)) {
+        const double wv[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};
+        aq = wv[0] * s;
+#pragma unroll
+        for (int n = 1; n < 9; ++n) {
+          const int m = a.srcmap[qq + off[n]];
+          const double sn = (m >= 0) ? a.Z[m] + a.S0[m] * bt : 0.0 + 0.0 * bt;
+          aq = aq + wv[n] * sn;
+        }
+        vv = (aq * s) * (double)g.mMask8[qq];
+      }
+      a.S1[qq] = s; a.Q[qq] = aq;
+      if (e == 0) v0 = vv; else v1 = vv;
+    }
+  }
+  // the tree of wg_reduce_store<1> over the 256 cells of the chunk
+  sh[2 * t] = v0; sh[2 * t + 1] = v1;
+  __syncthreads();
+  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) sh[t] = sh[t] + sh[t + s];
+    __syncthreads();
+  }
+  if (t == 0) a.partB[(long long)b * gridDim.x + red_chunk(g)] = sh[0];
+}
+
 // pending x,r update before a convergence check
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_xr(DevGrid g, FusedArgs a) {

@@ -61,6 +61,7 @@ struct pop_ctx {
   SolverScalars *host_sc = nullptr;                       // pinned
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
   bool no_graph = false, fused_ok = false, replicated = false;
+  bool fpcg_one_cell = false;   // POP_FPCG_B2=0: one cell per thread in step B of the fused pcg even on large grids
   bool force_presum = false;
   bool reg_thomas_t = true;
   int trc_lds_rows = 8;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
@@ -305,6 +306,13 @@ void presum(pop_ctx *c, const SolveView &v, const double *partial, double *bs) {
   hipLaunchKernelGGL(k_block_sums<1>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->iota, bs);
 }
 dim3 view_grid(const SolveView &v) { return dim3(red_grid_x(v.g), v.g.nblocks); }
+// step B of the fused pcg: two cells per thread on large grids (presummed block sums, even row pitch), else one
+void launch_fpcg_b(pop_ctx *c, const SolveView &v, const FusedArgs &a) {
+  const dim3 G = view_grid(v);
+  if (a.presummed && (v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell)
+    hipLaunchKernelGGL(k_fpcg_b2, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
+  else hipLaunchKernelGGL(k_fpcg_b, G, dim3(POP_RED_THREADS), 0, c->stream, v.g, a);
+}
 // one check interval: freq iterations, pending update, residual + (r,r) -> host
 int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
@@ -314,7 +322,7 @@ int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
     if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
     else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
     if (a.presummed) presum(c, v, a.partA, (double *)a.bsA);
-    hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, v.g, a);
+    launch_fpcg_b(c, v, a);
     if (a.presummed) presum(c, v, a.partB, (double *)a.bsB);
     std::swap(v.S0, v.S1);
     pending = true;
@@ -367,7 +375,7 @@ int solver_pcg_fused(pop_ctx *c, SolveView &v) {
       if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
       else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
       if (a.presummed) presum(c, v, a.partA, (double *)a.bsA);
-      hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, v.g, a);
+      launch_fpcg_b(c, v, a);
       if (a.presummed) presum(c, v, a.partB, (double *)a.bsB);
       std::swap(v.S0, v.S1);
       pending = true;
@@ -428,7 +436,7 @@ int solver_pcg_fused_dist(pop_ctx *c) {
     if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
     else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
     if (allsum(a.partA, 0) || halo_remote(c, v.Z, 1)) return 1;
-    hipLaunchKernelGGL(k_fpcg_b, G, B, 0, c->stream, v.g, a);
+    launch_fpcg_b(c, v, a);
     if (allsum(a.partB, nbt)) return 1;
     std::swap(v.S0, v.S1);
     pending = true;
@@ -1036,6 +1044,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     c->reg_thomas_t = c->reg_thomas && (h.n2 * h.nblocks <= (1u << 19));
     if (getenv("POP_REG_THOMAS_T")) c->reg_thomas_t = atoi(getenv("POP_REG_THOMAS_T")) != 0;
     c->force_presum = getenv("POP_SOLVER_PRESUM") != nullptr;
+    c->fpcg_one_cell = getenv("POP_FPCG_B2") && atoi(getenv("POP_FPCG_B2")) == 0;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && !use_evp(*cfg) && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !getenv("POP_SOLVER_DISTRIBUTED");
     if (c->replicated) {

@@ -535,13 +535,17 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
     monkeypatch.delenv("POP_SOLVER_UNFUSED")
     monkeypatch.setenv("POP_SOLVER_NOGRAPH", "1")
     c = pkg.PopModel(cfg)
-    monkeypatch.setenv("POP_SOLVER_PRESUM", "1")          # the large-grid reduction scheme
+    monkeypatch.setenv("POP_SOLVER_PRESUM", "1")          # the large-grid reduction scheme (pcg: two cells per thread in step B)
     d = pkg.PopModel(cfg)
+    monkeypatch.setenv("POP_FPCG_B2", "0")                # ... with one cell per thread
+    e = pkg.PopModel(cfg)
+    monkeypatch.delenv("POP_FPCG_B2")
     for _ in range(4):
-        a.step(); b.step(); c.step(); d.step()
-        assert a.solver_diagnostics() == b.solver_diagnostics() == c.solver_diagnostics() == d.solver_diagnostics()
+        a.step(); b.step(); c.step(); d.step(); e.step()
+        assert a.solver_diagnostics() == b.solver_diagnostics() == c.solver_diagnostics() == d.solver_diagnostics() == e.solver_diagnostics()
     for name in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER"):
         assert np.array_equal(a.get(name), b.get(name)), name
         assert np.array_equal(a.get(name), c.get(name)), name
         assert np.array_equal(a.get(name), d.get(name)), name
-    a.close(); b.close(); c.close(); d.close()
+        assert np.array_equal(a.get(name), e.get(name)), name
+    a.close(); b.close(); c.close(); d.close(); e.close()
