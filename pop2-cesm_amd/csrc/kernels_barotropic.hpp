@@ -746,6 +746,80 @@ k_fcg_a(DevGrid g, FusedArgs a) {
   }
   wg_reduce_store<2>(v, a.partA, b * gridDim.x + red_chunk(g));
 }
+// step A with two horizontally adjacent cells per thread (large grids, even row pitch; see k_fpcg_b2): the pair shares
+// its three stencil rows of r and A0R.  Same operations per cell, same reduction tree: bitwise equal to k_fcg_a.
+__global__ void __launch_bounds__(POP_RED_THREADS / 2)
+k_fcg_a2(DevGrid g, FusedArgs a) {
+  __shared__ double sh[2][POP_RED_THREADS];
+  const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
+  const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;
+  const bool live0 = p0 < g.n2, live1 = p0 + 1 < g.n2;
+  const int pp = live0 ? (int)p0 : 0;
+  const int i = pp % nxb, j = pp / nxb;
+  const long long q = (long long)b * g.n2 + pp;
+  const bool fast = live1 && i + 1 > g.ib && i + 2 < g.ie && j + 1 > g.jb && j + 1 < g.je;
+  double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [cell][field]
+  if (fast) {
+    double zr[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const long long o = q + (long long)(r - 1) * nxb;
+      const double2 rc = *reinterpret_cast<const double2 *>(a.R + o), ac = *reinterpret_cast<const double2 *>(a.A0R + o);
+      zr[r][0] = a.R[o - 1] * a.A0R[o - 1]; zr[r][1] = rc.x * ac.x; zr[r][2] = rc.y * ac.y; zr[r][3] = a.R[o + 2] * a.A0R[o + 2];
+    }
+    const double2 rr = *reinterpret_cast<const double2 *>(a.R + q);
+    const double2 cc = *reinterpret_cast<const double2 *>(a.C + q);
+    const double2 no0 = *reinterpret_cast<const double2 *>(g.WNo + q), nom = *reinterpret_cast<const double2 *>(g.WNo + q - nxb);
+    const double2 ea0 = *reinterpret_cast<const double2 *>(g.WEa + q);
+    const double eaw = g.WEa[q - 1];
+    const double2 ne0 = *reinterpret_cast<const double2 *>(g.WNE + q), nem = *reinterpret_cast<const double2 *>(g.WNE + q - nxb);
+    const double ne0w = g.WNE[q - 1], nemw = g.WNE[q - 1 - nxb];
+    double azA = cc.x * zr[1][1];
+    azA = azA + no0.x * zr[2][1]; azA = azA + nom.x * zr[0][1]; azA = azA + ea0.x * zr[1][2]; azA = azA + eaw * zr[1][0];
+    azA = azA + ne0.x * zr[2][2]; azA = azA + nem.x * zr[0][2]; azA = azA + ne0w * zr[2][0]; azA = azA + nemw * zr[0][0];
+    double azB = cc.y * zr[1][2];
+    azB = azB + no0.y * zr[2][2]; azB = azB + nom.y * zr[0][2]; azB = azB + ea0.y * zr[1][3]; azB = azB + ea0.x * zr[1][1];
+    azB = azB + ne0.y * zr[2][3]; azB = azB + nem.y * zr[0][3]; azB = azB + ne0.x * zr[2][1]; azB = azB + nem.x * zr[0][1];
+    *reinterpret_cast<double2 *>(a.Z + q) = make_double2(zr[1][1], zr[1][2]);
+    *reinterpret_cast<double2 *>(a.AZ + q) = make_double2(azA, azB);
+    const double mk0 = (double)g.mMask8[q], mk1 = (double)g.mMask8[q + 1];
+    v[0][0] = (rr.x * zr[1][1]) * mk0; v[0][1] = (azA * zr[1][1]) * mk0;
+    v[1][0] = (rr.y * zr[1][2]) * mk1; v[1][1] = (azB * zr[1][2]) * mk1;
+  } else {
+    const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (!(e == 0 ? live0 : live1)) continue;
+      const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
+      const long long qq = (long long)b * g.n2 + p2;
+      if (!interior(g, ii, jj)) continue;
+      const double r = a.R[qq];
+      const double z0 = r * a.A0R[qq];
+      const double wv[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};
+      double az = wv[0] * z0;
+#pragma unroll
+      for (int n = 1; n < 9; ++n) {
+        const int m = a.srcmap[qq + off[n]];
+        az = az + wv[n] * ((m >= 0) ? a.R[m] * a.A0R[m] : 0.0);
+      }
+      a.Z[qq] = z0; a.AZ[qq] = az;
+      const double mk = (double)g.mMask8[qq];
+      v[e][0] = (r * z0) * mk; v[e][1] = (az * z0) * mk;
+    }
+  }
+  // the tree of wg_reduce_store<2> over the 256 cells of the chunk
+#pragma unroll
+  for (int f = 0; f < 2; ++f) { sh[f][2 * t] = v[0][f]; sh[f][2 * t + 1] = v[1][f]; }
+  __syncthreads();
+  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) { sh[0][t] = sh[0][t] + sh[0][t + s]; sh[1][t] = sh[1][t] + sh[1][t + s]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const long long slot = (long long)b * gridDim.x + red_chunk(g);
+    a.partA[2 * slot] = sh[0][0]; a.partA[2 * slot + 1] = sh[1][0];
+  }
+}
 // step B (:2159-2186): scalar recurrences from the two totals, then s = z + beta s; q = az + beta q; x += alpha s;
 // r -= alpha q on the physical cells (ghost values of these vectors are never read in the fused form)
 __global__ void __launch_bounds__(POP_RED_THREADS)

@@ -538,7 +538,8 @@ static int cg_fused_iterations(pop_ctx *c, SolveView &v, int n, int &par) {
   for (int it = 0; it < n; ++it) {
     FusedArgs a = fused_args(c, v);
     a.AZ = c->AZ; a.A0R = v.S1;
-    hipLaunchKernelGGL(k_fcg_a, G, B, 0, c->stream, v.g, a);
+    if (a.presummed && (v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell) hipLaunchKernelGGL(k_fcg_a2, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
+    else hipLaunchKernelGGL(k_fcg_a, G, B, 0, c->stream, v.g, a);
     if (a.presummed) hipLaunchKernelGGL(k_block_sums<2>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, (const double *)a.partA, v.nchunk, (const int *)c->iota, (double *)a.bsA);
     hipLaunchKernelGGL(k_fcg_b, G, B, 0, c->stream, v.g, a, par);
     par = 1 - par;

@@ -99,6 +99,30 @@ __global__ void __launch_bounds__(TW * TH) tilemarch(Arrs A, int nx, int ny, int
     A.o[0][(size_t)k * n2 + p2] = s0; A.o[1][(size_t)k * n2 + p2] = s1;
   }
 }
+// tile march with two adjacent columns per thread (16-byte loads): TW x TH threads cover 2*TW x TH columns
+template <int TW, int TH>
+__global__ void __launch_bounds__(TW * TH) tilemarch2(Arrs A, int nx, int ny, int km, int tiles_i) {
+  const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i;
+  const int i = ti * 2 * TW + 2 * threadIdx.x, j = tj * TH + threadIdx.y;
+  if (i + 1 >= nx || j >= ny) return;
+  const size_t n2 = (size_t)nx * ny, p2 = (size_t)j * nx + i;
+  double2 nxt[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) nxt[a] = *reinterpret_cast<const double2 *>(A.a[a] + p2);
+  for (int k = 0; k < km; ++k) {
+    double2 cur[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) cur[a] = nxt[a];
+    const int kn = k + 1 < km ? k + 1 : k;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) nxt[a] = *reinterpret_cast<const double2 *>(A.a[a] + (size_t)kn * n2 + p2);
+    double2 s0 = make_double2(0, 0), s1 = make_double2(0, 0);
+#pragma unroll
+    for (int a = 0; a < NA; a += 2) { s0.x += cur[a].x; s0.y += cur[a].y; s1.x += cur[a + 1].x; s1.y += cur[a + 1].y; }
+    *reinterpret_cast<double2 *>(A.o[0] + (size_t)k * n2 + p2) = s0;
+    *reinterpret_cast<double2 *>(A.o[1] + (size_t)k * n2 + p2) = s1;
+  }
+}
 int main() {
   const int nx = (getenv("NX") ? atoi(getenv("NX")) : 3604), ny = 2404, km = 62;
   const size_t n = (size_t)nx * ny * km;
@@ -134,5 +158,8 @@ int main() {
 #define TM(TW, TH) timeit("tile march " #TW "x" #TH, [&] { const int tI = (nx + TW - 1) / TW, tJ = (ny + TH - 1) / TH; \
     hipLaunchKernelGGL((tilemarch<TW, TH>), dim3(tI * tJ), dim3(TW, TH), 0, 0, A, nx, ny, km, tI); });
   TM(64, 1) TM(64, 2) TM(64, 4) TM(64, 8) TM(64, 16) TM(128, 1) TM(256, 1) TM(512, 1) TM(128, 4) TM(256, 2)
+#define TM2(TW, TH) timeit("tile march2 (16B) " #TW "x" #TH, [&] { const int tI = (nx + 2 * TW - 1) / (2 * TW), tJ = (ny + TH - 1) / TH; \
+    hipLaunchKernelGGL((tilemarch2<TW, TH>), dim3(tI * tJ), dim3(TW, TH), 0, 0, A, nx, ny, km, tI); });
+  TM2(64, 1) TM2(64, 4) TM2(64, 8) TM2(32, 8) TM2(32, 16)
   return 0;
 }
