@@ -119,4 +119,87 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
   if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
 
+// fused step with two horizontally adjacent cells per thread (large grids with an even row pitch; not the first
+// step): the pair shares its three stencil rows of (r', dx, x), read as (q-1), (q, q+1) in one 16-byte load, (q+2).
+// Same operations per cell in the same order and the same reduction tree as k_pcsi_step: bitwise equal.
+template <bool WITH_RR>
+__global__ void __launch_bounds__(POP_RED_THREADS / 2)
+k_pcsi_step2(DevGrid g, PcsiArgs a) {
+  __shared__ double sh[POP_RED_THREADS];
+  const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
+  const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;
+  const bool live0 = p0 < g.n2, live1 = p0 + 1 < g.n2;
+  const int pp = live0 ? (int)p0 : 0;
+  const int i = pp % nxb, j = pp / nxb;
+  const long long q = (long long)b * g.n2 + pp;
+  const bool fast = live1 && i + 1 > g.ib && i + 2 < g.ie && j + 1 > g.jb && j + 1 < g.je;
+  const double om = a.omega[*a.base + a.j];
+  const double cq = a.csy * om - 1.0;
+  double v0 = 0.0, v1 = 0.0;
+  if (fast) {
+    double xn[3][4], dxc[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const long long o = q + (long long)(r - 1) * nxb;
+      const double2 rc = *reinterpret_cast<const double2 *>(a.Ri + o), qc = *reinterpret_cast<const double2 *>(a.Qi + o),
+                    xc = *reinterpret_cast<const double2 *>(a.Xi + o);
+      const double d0 = om * a.Ri[o - 1] + cq * a.Qi[o - 1], d1 = om * rc.x + cq * qc.x, d2 = om * rc.y + cq * qc.y,
+                   d3 = om * a.Ri[o + 2] + cq * a.Qi[o + 2];
+      xn[r][0] = a.Xi[o - 1] + d0; xn[r][1] = xc.x + d1; xn[r][2] = xc.y + d2; xn[r][3] = a.Xi[o + 2] + d3;
+      if (r == 1) { dxc[0] = d1; dxc[1] = d2; }
+    }
+    const double2 cc = *reinterpret_cast<const double2 *>(a.C + q);
+    const double2 no0 = *reinterpret_cast<const double2 *>(g.WNo + q), nom = *reinterpret_cast<const double2 *>(g.WNo + q - nxb);
+    const double2 ea0 = *reinterpret_cast<const double2 *>(g.WEa + q);
+    const double eaw = g.WEa[q - 1];
+    const double2 ne0 = *reinterpret_cast<const double2 *>(g.WNE + q), nem = *reinterpret_cast<const double2 *>(g.WNE + q - nxb);
+    const double ne0w = g.WNE[q - 1], nemw = g.WNE[q - 1 - nxb];
+    const double2 bq = *reinterpret_cast<const double2 *>(a.Bv + q), a0r = *reinterpret_cast<const double2 *>(a.A0R + q);
+    const double axA = cc.x * xn[1][1] + no0.x * xn[2][1] + nom.x * xn[0][1] + ea0.x * xn[1][2] + eaw * xn[1][0] +
+                       ne0.x * xn[2][2] + nem.x * xn[0][2] + ne0w * xn[2][0] + nemw * xn[0][0];
+    const double axB = cc.y * xn[1][2] + no0.y * xn[2][2] + nom.y * xn[0][2] + ea0.y * xn[1][3] + ea0.x * xn[1][1] +
+                       ne0.y * xn[2][3] + nem.y * xn[0][3] + ne0.x * xn[2][1] + nem.x * xn[0][1];
+    const double rA = bq.x - axA, rB = bq.y - axB;
+    *reinterpret_cast<double2 *>(a.Qo + q) = make_double2(dxc[0], dxc[1]);
+    *reinterpret_cast<double2 *>(a.Xo + q) = make_double2(xn[1][1], xn[1][2]);
+    *reinterpret_cast<double2 *>(a.Ro + q) = make_double2(rA * a0r.x, rB * a0r.y);
+    if (WITH_RR) { v0 = (rA * rA) * (double)g.mMask8[q]; v1 = (rB * rB) * (double)g.mMask8[q + 1]; }
+  } else {
+    const int off[8] = {nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (!(e == 0 ? live0 : live1)) continue;
+      const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
+      const long long qq = (long long)b * g.n2 + p2;
+      if (interior(g, ii, jj)) {
+        double xn[9], dx0 = 0.0;
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+          const long long m = (n == 0) ? qq : (long long)a.srcmap[qq + off[n - 1]];
+          double x = 0.0;
+          if (m >= 0) { const double dx = om * a.Ri[m] + cq * a.Qi[m]; if (n == 0) dx0 = dx; x = a.Xi[m] + dx; }
+          xn[n] = x;
+        }
+        const double w[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};
+        const double ax = w[0] * xn[0] + w[1] * xn[1] + w[2] * xn[2] + w[3] * xn[3] + w[4] * xn[4] + w[5] * xn[5] + w[6] * xn[6] + w[7] * xn[7] + w[8] * xn[8];
+        const double r = a.Bv[qq] - ax;
+        a.Qo[qq] = dx0; a.Xo[qq] = xn[0]; a.Ro[qq] = r * a.A0R[qq];
+        if (WITH_RR) { const double vv = (r * r) * (double)g.mMask8[qq]; if (e == 0) v0 = vv; else v1 = vv; }
+      } else if (a.remote_ghosts && a.srcmap[qq] == qq) {
+        const double dx = om * a.Ri[qq] + cq * a.Qi[qq];
+        a.Qo[qq] = dx; a.Xo[qq] = a.Xi[qq] + dx;
+      }
+    }
+  }
+  if (WITH_RR) {   // the tree of wg_reduce_store<1> over the 256 cells of the chunk
+    sh[2 * t] = v0; sh[2 * t + 1] = v1;
+    __syncthreads();
+    for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+      if (t < s) sh[t] = sh[t] + sh[t + s];
+      __syncthreads();
+    }
+    if (t == 0) a.partial[(long long)b * gridDim.x + red_chunk(g)] = sh[0];
+  }
+}
+
 }  // namespace pop

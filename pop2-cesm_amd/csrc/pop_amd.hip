@@ -63,6 +63,7 @@ struct pop_ctx {
   bool no_graph = false, fused_ok = false, replicated = false;
   bool fpcg_one_cell = false;   // POP_FPCG_B2=0: one cell per thread in step B of the fused pcg even on large grids
   bool force_presum = false;
+  bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
   bool reg_thomas_t = true;
   int trc_lds_rows = 8;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
   int mom_lds_rows = 8;                                    // momentum RHS: LDS tile rows (0 = direct-load kernel)
@@ -681,7 +682,10 @@ static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool
   const dim3 G = grid_2d(c), B(POP_RED_THREADS);
   for (int j = 1; j <= freq; ++j) {
     const PcsiArgs a = pcsi_args(c, bf, in, j);
-    if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step<false, true>), G, B, 0, c->stream, c->g, a);
+    if (c->pcsi_two_cell) {
+      if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step2<true>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, c->g, a);
+      else hipLaunchKernelGGL((k_pcsi_step2<false>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, c->g, a);
+    } else if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step<false, true>), G, B, 0, c->stream, c->g, a);
     else hipLaunchKernelGGL((k_pcsi_step<false, false>), G, B, 0, c->stream, c->g, a);
     in = 1 - in;
   }
@@ -767,6 +771,8 @@ int solver_pcsi_fused_dist(pop_ctx *c) {
     PcsiArgs a = pcsi_args(c, bf, in, j);
     a.remote_ghosts = 1;
     if (first) hipLaunchKernelGGL((k_pcsi_step<true, false>), G, B, 0, c->stream, c->g, a);
+    else if (c->pcsi_two_cell && rr) hipLaunchKernelGGL((k_pcsi_step2<true>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, c->g, a);
+    else if (c->pcsi_two_cell) hipLaunchKernelGGL((k_pcsi_step2<false>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, c->g, a);
     else if (rr) hipLaunchKernelGGL((k_pcsi_step<false, true>), G, B, 0, c->stream, c->g, a);
     else hipLaunchKernelGGL((k_pcsi_step<false, false>), G, B, 0, c->stream, c->g, a);
     return 0;
@@ -1046,6 +1052,8 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     if (getenv("POP_REG_THOMAS_T")) c->reg_thomas_t = atoi(getenv("POP_REG_THOMAS_T")) != 0;
     c->force_presum = getenv("POP_SOLVER_PRESUM") != nullptr;
     c->fpcg_one_cell = getenv("POP_FPCG_B2") && atoi(getenv("POP_FPCG_B2")) == 0;
+    c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && (long long)c->nchunk * h.nblocks > 2048;
+    if (getenv("POP_PCSI_STEP2")) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && atoi(getenv("POP_PCSI_STEP2")) != 0;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && !use_evp(*cfg) && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !getenv("POP_SOLVER_DISTRIBUTED");
     if (c->replicated) {

@@ -514,13 +514,17 @@ def test_fused_pcsi_is_bitwise_the_unfused_pcsi(pkg, monkeypatch):
     monkeypatch.delenv("POP_SOLVER_UNFUSED")
     monkeypatch.setenv("POP_SOLVER_NOGRAPH", "1")
     c = pkg.PopModel(cfg)
+    monkeypatch.delenv("POP_SOLVER_NOGRAPH")
+    monkeypatch.setenv("POP_PCSI_STEP2", "1")             # two cells per thread (the large-grid form)
+    d = pkg.PopModel(cfg)
     for _ in range(4):
-        a.step(); b.step(); c.step()
-        assert a.solver_diagnostics() == b.solver_diagnostics() == c.solver_diagnostics()
+        a.step(); b.step(); c.step(); d.step()
+        assert a.solver_diagnostics() == b.solver_diagnostics() == c.solver_diagnostics() == d.solver_diagnostics()
     for name in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER"):
         assert np.array_equal(a.get(name), b.get(name)), name
         assert np.array_equal(a.get(name), c.get(name)), name
-    a.close(); b.close(); c.close()
+        assert np.array_equal(a.get(name), d.get(name)), name
+    a.close(); b.close(); c.close(); d.close()
 
 
 @pytest.mark.parametrize("kw", [{}, {"solver_choice": 2}, {"solver_choice": 2, "convergence_check_freq": 5, "max_iterations": 203}])
