@@ -94,6 +94,8 @@ double orc_solver_rms(orc_model *m);
 /* POP_SolversMod.F90:2268-2369 preconditioner on whole arrays (EVP when reserved_i[2] = 1), :2992 partition */
 void orc_preconditioner(orc_model *m, const double *X, double *PX);
 int orc_evp_info(orc_model *m, int what, int idx);
+void orc_btrop_operator(orc_model *m, const double *X, double *AX);   /* POP_SolversMod.F90:2414-2426 */
+int orc_solver_run(orc_model *m, double *X, const double *B);         /* :327-417 */
 
 #ifdef __cplusplus
 }

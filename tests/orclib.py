@@ -48,6 +48,9 @@ def load():
     L.orc_preconditioner.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.orc_preconditioner.restype = None
     L.orc_evp_info.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_btrop_operator.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_btrop_operator.restype = None
+    L.orc_solver_run.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.orc_global_sum.restype = C.c_double
     L.orc_global_sum.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return L
@@ -115,6 +118,31 @@ class Oracle:
         px = np.empty_like(x)
         self.L.orc_preconditioner(self.h, x.ctypes.data_as(C.POINTER(C.c_double)), px.ctypes.data_as(C.POINTER(C.c_double)))
         return px
+
+    def _dp(self, a):
+        return a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def halo(self, a, nz=1):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.L.orc_halo_update(self.h, self._dp(a), nz, 0)
+        return a
+
+    def global_sum(self, a, mask=None):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.float64)
+        return self.L.orc_global_sum(self.h, self._dp(a), None if mk is None else self._dp(mk))
+
+    def btrop_operator(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        ax = np.empty_like(x)
+        self.L.orc_btrop_operator(self.h, self._dp(x), self._dp(ax))
+        return ax
+
+    def solver_run(self, x, b):
+        x = np.ascontiguousarray(x, dtype=np.float64).copy()
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        rc = self.L.orc_solver_run(self.h, self._dp(x), self._dp(b))
+        return rc, x
 
     def evp_info(self, what, idx=0):
         return self.L.orc_evp_info(self.h, what, idx)

@@ -485,6 +485,56 @@ def test_evp_preconditioner_is_bitwise_the_oracle(pkg, orclib_built, name, kw):
     gpu.close(); orc.close()
 
 
+@pytest.mark.parametrize("kw", [{}, {"tadvect": 2}, {"hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21},
+                                {"block_size_x": 48, "block_size_y": 40}])
+def test_uniform_tracers_stay_uniform_in_the_interior(pkg, kw):
+    """The scheme's own invariant on the device (see the oracle twin in tests/test_oracle_fixtures.py): with
+    wind-driven flow, uniform T and S stay EXACTLY uniform away from the surface layer and the sea floor --
+    advection consistent with continuity, del2 / del4 of a constant = 0, vertical mixing of a constant = 0."""
+    cfg = named_config("tiny", **kw)
+    m = pkg.PopModel(cfg)
+    kmt = m.geti("KMT")
+    k = np.arange(1, m.km + 1)[None, :, None, None]
+    wet = k <= kmt[:, None]
+    for tl in (0, 1, 2):
+        m.set("TRACER", np.where(wet, 10.0, 0.0), tl, 0)
+        m.set("TRACER", np.where(wet, 0.035, 0.0), tl, 1)
+    for _ in range(6):
+        m.step()
+    assert np.abs(m.get("UVEL", 1)).max() > 1.0
+    mid = slice(7, m.km - 3)
+    for n, val in ((0, 10.0), (1, 0.035)):
+        f = m.get("TRACER", 1, n)
+        assert np.array_equal(f[:, mid][wet[:, mid]], np.full(int(wet[:, mid].sum()), val))
+        assert np.abs(np.where(wet, f - val, 0.0)).max() < 1e-4 * val
+    m.close()
+
+
+@pytest.mark.parametrize("kw", [{}, {"solver_choice": 2}, {"solver_choice": 3}, {"precond_choice": 1}, {"solver_choice": 3, "precond_choice": 1},
+                                {"block_size_x": 48, "block_size_y": 40}])
+def test_solvers_recover_a_manufactured_solution(pkg, orclib_built, kw):
+    """b = A x_true (operator of the oracle, same centre weight) for a random x_true on the ocean points: the
+    device solvers recover it from a zero first guess, with the oracle's iteration count."""
+    cfg = named_config("tiny", convergence_criterion=1.0e-13, **kw)
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    gpu.step(); orc.step()
+    assert np.array_equal(gpu.get("centerWgt"), orc.f2("centerWgt"))
+    rng = np.random.default_rng(4)
+    mask = orc.f2("mMask").copy()
+    x_true = orc.halo(rng.standard_normal(mask.shape) * 1.0e3 * mask)
+    b = orc.halo(orc.btrop_operator(x_true))
+    rc, x_orc = orc.solver_run(np.zeros_like(x_true), b)
+    assert rc == 0
+    gpu.set("RHS", b)
+    gpu.set("PSURF", np.zeros_like(b), 2)
+    gpu.solver_run()
+    x = gpu.get("PSURF", 2)
+    assert gpu.solver_diagnostics()[0] == orc.L.orc_solver_iterations(orc.h)
+    assert np.abs(interior(x - x_true)).max() <= 1e-7 * np.abs(x_true).max()
+    assert np.abs(interior(x - x_orc)).max() <= 1e-9 * np.abs(x_true).max()
+    gpu.close(); orc.close()
+
+
 @pytest.mark.parametrize("solver", [1, 2, 3])
 def test_solver_error_convention(pkg, orclib_built, solver):
     """POP_SolversMod.F90:1492-1497: hitting maxIterations is an error (errorCode set, message) unless
