@@ -119,32 +119,70 @@ class TorchComm:
                                         C.c_void_p(self.red.data_ptr()), n, self._x, self._a, None))
 
 
+_CPU_CHILD = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from popcfg import PopConfig
+from orclib import Oracle
+cfg = PopConfig.from_buffer_copy(bytes.fromhex(sys.argv[2]))
+budget, nmax = float(sys.argv[3]), int(sys.argv[4])
+o = Oracle(cfg)
+o.step()                      # forward-Euler first step excluded (BASELINE.md procedure)
+print("READY", flush=True)
+sys.stdin.readline()          # all processes start the timed steps together
+t0 = time.time(); n = 0
+while True:
+    o.step(); n += 1
+    if time.time() - t0 > budget or n >= nmax:
+        break
+print("DONE %d %.6f" % (n, time.time() - t0), flush=True)
+"""
+
+
 def cpu_baseline(cfg, budget_s=20.0):
-    """Time the CPU oracle (single thread) for a bounded number of steps.  Workloads the scalar oracle
-    cannot step in seconds are sampled on a sub-domain with the same options (same km, physics, time
-    step); the rate is scaled by the column ratio (the oracle's cost is linear in columns)."""
+    """Time the CPU oracle on the host cores for a bounded number of steps.  C = min(cores, 16) processes (the
+    oracle is a scalar port; POP_BENCH_CPU_CORES overrides) each step an equal sub-domain with the workload's
+    options (same km, physics, time step) at the same time -- the block decomposition an MPI run of the reference
+    would use, without its messages.  The sub-domain is at most 10 M cells and at most 1/C of the domain; the step
+    time of the full domain is the slowest process's time per step divided by the fraction of the columns the C
+    samples cover (the oracle's cost is linear in columns).  Children are started as separate programs (this
+    process has initialised the GPU and must not fork)."""
     import copy
-    from orclib import Oracle
-    scale, sample_cfg = 1.0, cfg
+    import subprocess
+    cores = int(os.environ.get("POP_BENCH_CPU_CORES", min(os.cpu_count() or 1, 16)))
     ncol = cfg.nx_global * cfg.ny_global
-    if ncol * cfg.km > 20_000_000:
-        sample_cfg = copy.copy(cfg)
-        div = 2
-        while (cfg.nx_global // div) * (cfg.ny_global // div) * cfg.km > 10_000_000:
-            div *= 2
-        sample_cfg.nx_global, sample_cfg.ny_global = cfg.nx_global // div, cfg.ny_global // div
-        sample_cfg.block_size_x, sample_cfg.block_size_y = sample_cfg.nx_global, sample_cfg.ny_global
-        scale = (sample_cfg.nx_global * sample_cfg.ny_global) / float(ncol)
-    o = Oracle(sample_cfg)
-    o.step()                      # forward-Euler first step excluded (BASELINE.md procedure)
-    t0 = time.time(); n = 0
-    while True:
-        o.step(); n += 1
-        if time.time() - t0 > budget_s or n >= 10:
-            break
-    dt = (time.time() - t0) / n
-    o.close()
-    return dt / scale, n, sample_cfg, scale
+    div = 1
+    while div * div < cores or (cfg.nx_global // div) * (cfg.ny_global // div) * cfg.km > 10_000_000:
+        div *= 2
+    while cfg.nx_global % div or cfg.ny_global % div:
+        div //= 2
+    cores = min(cores, div * div)
+    sample_cfg = copy.copy(cfg)
+    sample_cfg.nx_global, sample_cfg.ny_global = cfg.nx_global // div, cfg.ny_global // div
+    sample_cfg.block_size_x, sample_cfg.block_size_y = sample_cfg.nx_global, sample_cfg.ny_global
+    scale = cores * (sample_cfg.nx_global * sample_cfg.ny_global) / float(ncol)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-c", _CPU_CHILD, ROOT, bytes(sample_cfg).hex(), str(budget_s), "10"],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env) for _ in range(cores)]
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "READY":
+                raise RuntimeError("cpu baseline child failed to start")
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        res = [p.stdout.readline().split() for p in procs]
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except OSError:
+                pass
+            p.wait()
+    if any(len(r) != 3 or r[0] != "DONE" for r in res):
+        raise RuntimeError("cpu baseline child failed")
+    n = min(int(r[1]) for r in res)
+    dt = max(float(r[2]) / int(r[1]) for r in res)
+    return dt / scale, n, sample_cfg, scale, cores
 
 
 # one HIP kernel per phase name (pop_time_phase); 'vmix' is a multi-kernel phase and is listed only
@@ -295,14 +333,13 @@ def main():
         "roofline": roof,
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        dt, n, scfg, scale = cpu_baseline(cfg)
-        what = ("the full %s workload" % args.workload) if scale == 1.0 else (
-            "a %dx%dx%d sub-domain of %s (same options; %.5f of the columns, rate scaled by that ratio)"
-            % (scfg.nx_global, scfg.ny_global, scfg.km, args.workload, scale))
+        dt, n, scfg, scale, cores = cpu_baseline(cfg)
+        what = "%d concurrent %dx%dx%d sub-domains of %s, one per core (same options; together %.4f of the columns, " \
+               "step time scaled by that ratio)" % (cores, scfg.nx_global, scfg.ny_global, scfg.km, args.workload, scale)
         out["cpu_baseline"] = {"value": round(86400.0 / (dt * cfg.steps_per_day * 365.0), 5), "unit": "SYPD",
-                               "ms_per_step": round(dt * 1e3, 2), "cores": 1, "kind": "port",
-                               "sample": "%d leapfrog steps of %s, single-thread C oracle "
-                                         "(restated reference algorithm, not the upstream binary)" % (n, what)}
+                               "ms_per_step": round(dt * 1e3, 2), "cores": cores, "kind": "port",
+                               "sample": "%d leapfrog steps of %s; scalar C oracle (restated reference algorithm, "
+                                         "not the upstream binary), no inter-domain messages" % (n, what)}
     if rank == 0:
         print(json.dumps(out))
     model.close()
