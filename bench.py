@@ -318,6 +318,11 @@ def main():
             "traffic": pmc_traffic(args.workload, kern) if world == 1 else None,
             "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, profiles/r01_pmc_traffic.json",
             "alg_bytes_per_launch": phases[dom]["alg_GB"] * 1e9, "avg_launch_ms": phases[dom]["ms"], "phases": phases}
+    # both baroclinic stencil kernels together (tracer + momentum right-hand sides): algorithmic bytes / summed time
+    pair_gb = phases["tracer_rhs"]["alg_GB"] + phases["momentum_rhs"]["alg_GB"]
+    pair_ms = phases["tracer_rhs"]["ms"] + phases["momentum_rhs"]["ms"]
+    roof["baroclinic_stencils"] = {"kernels": [KERNEL_OF_PHASE["tracer_rhs"], KERNEL_OF_PHASE["momentum_rhs"]],
+                                   "achieved": round(pair_gb / (pair_ms * 1e-3), 1), "frac": round(pair_gb / (pair_ms * 1e-3) / HBM_PEAK_GBS, 4)}
     step_words = sum(v[vm] for k, v in PHASE_WORDS.items() if k in phases)
     roof["step_alg_GBps"] = round(step_words * 8.0 * ncell_phys * world / 1e9 / (elapsed / args.steps), 1)
 

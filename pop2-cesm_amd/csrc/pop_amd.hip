@@ -489,7 +489,7 @@ int solver_pcg_replicated(pop_ctx *c) {
   return 0;
 }
 
-// ChronGear (POP_SolversMod.F90:1960-2266), diagonal preconditioner
+// ChronGear (POP_SolversMod.F90:1960-2266), diagonal or EVP preconditioner
 int solver_chrongear(pop_ctx *c) {
   const pop_config &cf = c->h.c;
   const dim3 G = grid_2d(c), B(POP_RED_THREADS);
@@ -613,7 +613,7 @@ int solver_chrongear_fused(pop_ctx *c) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// P-CSI (POP_SolversMod.F90:1510-1835), diagonal preconditioner.  kernels_pcsi.hpp describes the
+// P-CSI (POP_SolversMod.F90:1510-1835), diagonal or EVP preconditioner (EVP: operation-by-operation form only).  kernels_pcsi.hpp describes the
 // fused one-launch-per-iteration form; solver_pcsi is the operation-by-operation form that also
 // serves multi-rank runs (one halo update per iteration, no collective except at the checks).
 // ---------------------------------------------------------------------------------------------
