@@ -16,6 +16,28 @@ def _port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def test_gx1v7_two_ranks_equal_single_rank():
+    """BASELINE configs[3] rehearsed on one GPU: gx1v7 (KPP, pcg) in two j-bands -- the replicated barotropic solve
+    and the 3-D halo exchanges at production size -- is bit for bit the single-rank run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+           os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "gx1v7", "--steps", "2", "--kw", "block_size_y=192"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ))
+    assert "MR_GPU_CHECK OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_large_grid_two_ranks_equal_single_rank():
+    """The large-grid kernel selection of tx0.1v3 (del4 + KPP, 62 levels; presummed block sums, two-cell solver
+    kernels, column KPP, 64x4 tracer tiles, fused distributed pcg) on a quarter-size domain in two j-bands: bit for
+    bit the single-rank run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+           os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tx0.1v3", "--steps", "2",
+           "--kw", "nx_global=1800,ny_global=1200,block_size_x=1800,block_size_y=600"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ))
+    assert "MR_GPU_CHECK OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("nranks,kw,env", [
     (2, "block_size_x=48,block_size_y=20", {}),                       # replicated barotropic solve
     (2, "", {}),                                                      # 16 blocks: fused distributed pcg (one z halo per iteration)
