@@ -947,7 +947,8 @@ k_fpcg_xr(DevGrid g, FusedArgs a) {
   if (p2 >= g.n2) return;
   const long long q = (long long)b * g.n2 + p2;
   a.X[q] = a.X[q] + alpha * a.S0[q];
-  a.R[q] = a.R[q] - alpha * a.Q[q];
+  // r -= alpha q is not formed: every use of this kernel is followed by r = b - A x (convergence check) or by the
+  // end of the solve, so the reference's update (:1433-1438) would be overwritten or never read
 }
 
 // r = b - A x on the physical domain with ghost neighbours of x read at their source; partial (r,r)
@@ -969,6 +970,68 @@ k_fresidual(DevGrid g, FusedArgs a) {
     }
   }
   if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * gridDim.x + red_chunk(g));
+}
+
+// r = b - A x with two horizontally adjacent cells per thread (large grids, even row pitch; see k_fpcg_b2): bitwise
+// equal to k_fresidual
+template <bool WITH_RR>
+__global__ void __launch_bounds__(POP_RED_THREADS / 2)
+k_fresidual2(DevGrid g, FusedArgs a) {
+  __shared__ double sh[POP_RED_THREADS];
+  const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
+  const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;
+  const bool live0 = p0 < g.n2, live1 = p0 + 1 < g.n2;
+  const int pp = live0 ? (int)p0 : 0;
+  const int i = pp % nxb, j = pp / nxb;
+  const long long q = (long long)b * g.n2 + pp;
+  const bool fast = live1 && i + 1 > g.ib && i + 2 < g.ie && j + 1 > g.jb && j + 1 < g.je;
+  double v0 = 0.0, v1 = 0.0;
+  if (fast) {
+    double xr[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const long long o = q + (long long)(r - 1) * nxb;
+      const double2 xc = *reinterpret_cast<const double2 *>(a.X + o);
+      xr[r][0] = a.X[o - 1]; xr[r][1] = xc.x; xr[r][2] = xc.y; xr[r][3] = a.X[o + 2];
+    }
+    const double2 cc = *reinterpret_cast<const double2 *>(a.C + q);
+    const double2 no0 = *reinterpret_cast<const double2 *>(g.WNo + q), nom = *reinterpret_cast<const double2 *>(g.WNo + q - nxb);
+    const double2 ea0 = *reinterpret_cast<const double2 *>(g.WEa + q);
+    const double eaw = g.WEa[q - 1];
+    const double2 ne0 = *reinterpret_cast<const double2 *>(g.WNE + q), nem = *reinterpret_cast<const double2 *>(g.WNE + q - nxb);
+    const double ne0w = g.WNE[q - 1], nemw = g.WNE[q - 1 - nxb];
+    const double2 bv = *reinterpret_cast<const double2 *>(a.Bv + q);
+    const double axA = cc.x * xr[1][1] + no0.x * xr[2][1] + nom.x * xr[0][1] + ea0.x * xr[1][2] + eaw * xr[1][0] +
+                       ne0.x * xr[2][2] + nem.x * xr[0][2] + ne0w * xr[2][0] + nemw * xr[0][0];
+    const double axB = cc.y * xr[1][2] + no0.y * xr[2][2] + nom.y * xr[0][2] + ea0.y * xr[1][3] + ea0.x * xr[1][1] +
+                       ne0.y * xr[2][3] + nem.y * xr[0][3] + ne0.x * xr[2][1] + nem.x * xr[0][1];
+    const double rA = bv.x - axA, rB = bv.y - axB;
+    *reinterpret_cast<double2 *>(a.R + q) = make_double2(rA, rB);
+    if (WITH_RR) { v0 = (rA * rA) * (double)g.mMask8[q]; v1 = (rB * rB) * (double)g.mMask8[q + 1]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (!(e == 0 ? live0 : live1)) continue;
+      const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
+      const long long qq = (long long)b * g.n2 + p2;
+      if (!interior(g, ii, jj)) continue;
+      auto xs = [&](long long m0) { const int m = a.srcmap[m0]; return (m < 0) ? 0.0 : a.X[m]; };
+      const double ax = a.C[qq] * a.X[qq] + g.WNo[qq] * xs(qq + nxb) + g.WNo[qq - nxb] * xs(qq - nxb) + g.WEa[qq] * xs(qq + 1) + g.WEa[qq - 1] * xs(qq - 1) +
+                        g.WNE[qq] * xs(qq + nxb + 1) + g.WNE[qq - nxb] * xs(qq - nxb + 1) + g.WNE[qq - 1] * xs(qq + nxb - 1) + g.WNE[qq - 1 - nxb] * xs(qq - nxb - 1);
+      const double r = a.Bv[qq] - ax;
+      a.R[qq] = r;
+      if (WITH_RR) { const double vv = (r * r) * (double)g.mMask8[qq]; if (e == 0) v0 = vv; else v1 = vv; }
+    }
+  }
+  if (WITH_RR) {
+    sh[2 * t] = v0; sh[2 * t + 1] = v1;
+    __syncthreads();
+    for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+      if (t < s) sh[t] = sh[t] + sh[t + s];
+      __syncthreads();
+    }
+    if (t == 0) a.partA[(long long)b * gridDim.x + red_chunk(g)] = sh[0];
+  }
 }
 
 // view of the 2-D system the fused solver works on

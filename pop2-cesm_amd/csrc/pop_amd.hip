@@ -307,6 +307,14 @@ void presum(pop_ctx *c, const SolveView &v, const double *partial, double *bs) {
   hipLaunchKernelGGL(k_block_sums<1>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->iota, bs);
 }
 dim3 view_grid(const SolveView &v) { return dim3(red_grid_x(v.g), v.g.nblocks); }
+// r = b - A x (+ partial (r,r)) of the fused solvers: two cells per thread on large grids, else one
+template <bool WITH_RR>
+void launch_fresidual(pop_ctx *c, const SolveView &v, const FusedArgs &a) {
+  const dim3 G = view_grid(v);
+  if (a.presummed && (v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell)
+    hipLaunchKernelGGL(k_fresidual2<WITH_RR>, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
+  else hipLaunchKernelGGL(k_fresidual<WITH_RR>, G, dim3(POP_RED_THREADS), 0, c->stream, v.g, a);
+}
 // step B of the fused pcg: two cells per thread on large grids (presummed block sums, even row pitch), else one
 void launch_fpcg_b(pop_ctx *c, const SolveView &v, const FusedArgs &a) {
   const dim3 G = view_grid(v);
@@ -330,7 +338,7 @@ int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
   }
   FusedArgs a = fused_args(c, v);
   hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, a);
-  hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, v.g, a);
+  launch_fresidual<true>(c, v, a);
   // the view holds every block it sums (single rank or replicated), in block-id order
   hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_sc);
   return 0;
@@ -342,7 +350,7 @@ int solver_pcg_fused(pop_ctx *c, SolveView &v) {
   SolverScalars init{}; init.eta0 = 1.0;
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(v.S0, 0, sizeof(double) * v.g.n2 * v.g.nblocks, c->stream));
-  hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, v.g, fused_args(c, v));
+  launch_fresidual<false>(c, v, fused_args(c, v));
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
   const bool use_graph = (freq % 2 == 0) && !c->no_graph;
@@ -428,7 +436,7 @@ int solver_pcg_fused_dist(pop_ctx *c) {
   SolverScalars init{}; init.eta0 = 1.0;
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(v.S0, 0, sizeof(double) * v.g.n2 * v.g.nblocks, c->stream));
-  hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, v.g, args());
+  launch_fresidual<false>(c, v, args());
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
   bool pending = false;
@@ -445,7 +453,7 @@ int solver_pcg_fused_dist(pop_ctx *c) {
       a = args();
       hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, a);
       pending = false;
-      hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, v.g, a);
+      launch_fresidual<true>(c, v, a);
       if (allsum(a.partA, 0)) return 1;
       hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, c->redbuf, nbt, c->sc, (int)FIN_RR);
       SolverScalars s;
@@ -548,10 +556,9 @@ static int cg_fused_iterations(pop_ctx *c, SolveView &v, int n, int &par) {
   return 0;
 }
 static int cg_fused_interval(pop_ctx *c, SolveView &v, int freq) {
-  const dim3 G = view_grid(v), B(POP_RED_THREADS);
   int par = 0;
   cg_fused_iterations(c, v, freq, par);
-  hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, v.g, fused_args(c, v));
+  launch_fresidual<true>(c, v, fused_args(c, v));
   hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_sc);
   return 0;
 }
@@ -593,7 +600,7 @@ int solver_chrongear_fused(pop_ctx *c) {
     } else {
       int par = (m / freq * freq) & 1;   // odd freq: the ping-pong slot carries over between intervals
       cg_fused_iterations(c, v, freq, par);
-      hipLaunchKernelGGL(k_fresidual<true>, G, B, 0, c->stream, v.g, fused_args(c, v));
+      launch_fresidual<true>(c, v, fused_args(c, v));
       hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_sc);
     }
     m += freq;
