@@ -127,8 +127,10 @@ int main() {
   const int nx = (getenv("NX") ? atoi(getenv("NX")) : 3604), ny = 2404, km = 62;
   const size_t n = (size_t)nx * ny * km;
   Arrs A;
-  for (int a = 0; a < NA; ++a) { double *p; if (hipMalloc(&p, n * 8) != hipSuccess) { printf("alloc failed\n"); return 1; } hipMemset(p, 0, n * 8); A.a[a] = p; }
-  for (int a = 0; a < 2; ++a) { double *p; hipMalloc(&p, n * 8); A.o[a] = p; }
+  // STAGGER=<bytes>: array a starts a*STAGGER bytes into its allocation (does the relative placement of the streams matter?)
+  const size_t stag = getenv("STAGGER") ? (size_t)atol(getenv("STAGGER")) / 8 : 0;
+  for (int a = 0; a < NA; ++a) { double *p; if (hipMalloc(&p, (n + 16 * stag) * 8) != hipSuccess) { printf("alloc failed\n"); return 1; } hipMemset(p, 0, (n + 16 * stag) * 8); A.a[a] = p + a * stag; }
+  for (int a = 0; a < 2; ++a) { double *p; hipMalloc(&p, (n + 16 * stag) * 8); A.o[a] = p + (NA + a) * stag; }
   const int tiles_i = (nx + 63) / 64, tiles_j = (ny + 7) / 8;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int layout = 0; layout < 2; ++layout) {
