@@ -183,6 +183,9 @@ struct SolverScalars {
   double eta0, eta1, alpha, beta_cg, rr, sum0, sum1, xcheck;
   double rho_old, sigma;   // ChronGear
   double rho2[2], sigma2[2];   // fused ChronGear: (rho_old, sigma) ping-pong between iterations (read [par], write [1-par])
+  // fused solvers with one check interval of look-ahead: `stop` is raised by the check that meets the convergence
+  // criterion and turns the kernels of the interval already enqueued behind it into no-ops; `icnt` counts the checks
+  int stop, icnt;
 };
 enum { FIN_PCG_RZ = 1, FIN_PCG_SQ = 2, FIN_RR = 3, FIN_XCHECK = 4, FIN_CG_INIT = 5, FIN_CG_ITER = 6, FIN_PLAIN = 7, FIN_TRIPOLE = 8 };
 // Stage 3: global sum over the block-sum vector in block-id order + scalar recurrences
@@ -282,7 +285,8 @@ k_dot_partial_dup(DevGrid g, const double *__restrict__ A, const double *__restr
 // view in block-id order, same rule as k_block_sums + k_finalize), result to the device scalars and straight
 // into pinned host memory -- replaces three stream operations (block sums, finalize, copy) by one.
 __global__ void __launch_bounds__(POP_RED_THREADS)
-k_rr_total(const double *__restrict__ partial, int nchunk, int nblocks, SolverScalars *s, SolverScalars *host_s) {
+k_rr_total(const double *__restrict__ partial, int nchunk, int nblocks, SolverScalars *s, double *host_ring, double criterion) {
+  if (s->stop) return;
   double total = 0.0;
   for (int b = 0; b < nblocks; ++b) {
     double r[1];
@@ -290,7 +294,12 @@ k_rr_total(const double *__restrict__ partial, int nchunk, int nblocks, SolverSc
     total = total + r[0];
     __syncthreads();
   }
-  if (threadIdx.x == 0) { s->sum0 = total; s->rr = total; host_s->rr = total; }
+  if (threadIdx.x == 0) {   // result of check number icnt into the pinned ring the host reads after the interval's event
+    s->sum0 = total; s->rr = total;
+    host_ring[s->icnt & 7] = total;
+    s->icnt = s->icnt + 1;
+    if (total < criterion) s->stop = 1;
+  }
 }
 
 // generic masked product sum over the physical domain: partial of a*b*mask (b, mask optional)
@@ -601,6 +610,7 @@ __device__ __forceinline__ double fused_total(const double *__restrict__ partial
 template <bool UPDATE>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_a(DevGrid g, FusedArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const long long q = (long long)b * g.n2 + (live ? p2 : 0);
@@ -634,6 +644,7 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
 // srcmap (bit-identical to reading the ghost after a halo update); all other cells index directly.
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_b(DevGrid g, FusedArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const int pp = live ? p2 : 0;
@@ -712,6 +723,7 @@ __device__ __forceinline__ void fused_total2(const double *__restrict__ partial,
 // the halo update of z delivers), az = A z, partial (r,z), (az,z)
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fcg_a(DevGrid g, FusedArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const int pp = live ? p2 : 0;
@@ -750,6 +762,7 @@ k_fcg_a(DevGrid g, FusedArgs a) {
 // its three stencil rows of r and A0R.  Same operations per cell, same reduction tree: bitwise equal to k_fcg_a.
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fcg_a2(DevGrid g, FusedArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   __shared__ double sh[2][POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;
@@ -824,6 +837,7 @@ k_fcg_a2(DevGrid g, FusedArgs a) {
 // r -= alpha q on the physical cells (ghost values of these vectors are never read in the fused form)
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fcg_b(DevGrid g, FusedArgs a, int par) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const int pp = live ? p2 : 0;
@@ -855,6 +869,7 @@ k_fcg_b(DevGrid g, FusedArgs a, int par) {
 // in the same order per cell, and the 256 products are reduced by the same tree as in k_fpcg_b: bitwise equal.
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fpcg_b2(DevGrid g, FusedArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;     // first cell of the pair (even)
@@ -939,6 +954,7 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
 // pending x,r update before a convergence check
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_xr(DevGrid g, FusedArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   const int p2 = red_cell(g), b = blockIdx.y;
   const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, a.presummed);
   const double rz = a.sc->eta1;
@@ -955,6 +971,7 @@ k_fpcg_xr(DevGrid g, FusedArgs a) {
 template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fresidual(DevGrid g, FusedArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   const int p2 = red_cell(g), b = blockIdx.y;
   double v[1] = {0.0};
   if (p2 < g.n2) {
@@ -977,6 +994,7 @@ k_fresidual(DevGrid g, FusedArgs a) {
 template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fresidual2(DevGrid g, FusedArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;

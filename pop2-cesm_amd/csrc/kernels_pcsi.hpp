@@ -24,6 +24,7 @@ struct PcsiArgs {
   const int *base;                 // iteration number of the interval's first step, minus 1
   const int *srcmap;
   double *partial;
+  const SolverScalars *sc;         // stop flag of the look-ahead scheme (kernels_barotropic.hpp)
   double csy;
   int j;                           // step inside the interval (1-based); j = 0: start-up step
   int remote_ghosts;               // multi-rank: also advance dx, x at ghosts owned by other ranks
@@ -70,6 +71,7 @@ __global__ void k_pcsi_scale(DevGrid g, double *__restrict__ R, const double *__
 template <bool FIRST, bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_pcsi_step(DevGrid g, PcsiArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   const int p2 = red_cell(g), b = blockIdx.y, nxb = g.nxb;
   double v[1] = {0.0};
   if (p2 < g.n2) {
@@ -125,6 +127,7 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
 template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_pcsi_step2(DevGrid g, PcsiArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;

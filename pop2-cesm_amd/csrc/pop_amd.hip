@@ -59,6 +59,8 @@ struct pop_ctx {
   SolverScalars *sc = nullptr;
   int *gid = nullptr, *srcmap = nullptr, *iota = nullptr, *loc_of_gid = nullptr;
   SolverScalars *host_sc = nullptr;                       // pinned
+  double *host_rr = nullptr;                              // pinned ring of (r,r) check results (k_rr_total)
+  hipEvent_t chk_ev[4] = {};                              // one event per check interval in flight
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
   bool no_graph = false, fused_ok = false, replicated = false;
   bool fpcg_one_cell = false;   // POP_FPCG_B2=0: one cell per thread in step B of the fused pcg even on large grids
@@ -340,9 +342,42 @@ int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
   hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, a);
   launch_fresidual<true>(c, v, a);
   // the view holds every block it sums (single rank or replicated), in block-id order
-  hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_sc);
+  hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_rr, c->h.convergenceCriterion);
   return 0;
 }
+// Check intervals with one interval of look-ahead.  `enqueue(i)` puts interval i on the stream (a hipGraph replay or
+// plain launches) and returns whether it ends with a convergence check (k_rr_total).  The host keeps at most two checked
+// intervals in flight and examines them in order; the check that meets the criterion raises the device stop flag, so the
+// interval already enqueued behind it does nothing, and the GPU never idles while the host looks at a residual.
+// Returns the index of the converged interval or -1; rr = last residual seen.
+template <class Enqueue>
+int run_intervals(pop_ctx *c, int nint, Enqueue enqueue, double &rr, int &err) {
+  int next = 0, ring = 0, head = 0;          // ring: checks enqueued; head: checks examined
+  int idx[8] = {};
+  err = 0;
+  auto fill = [&]() {
+    while (next < nint && ring - head < 2) {
+      const int chk = enqueue(next);
+      if (chk < 0) { err = 1; return; }
+      if (chk) {
+        if (hipEventRecord(c->chk_ev[ring & 3], c->stream) != hipSuccess) { err = 1; return; }
+        idx[ring & 7] = next; ++ring;
+      }
+      ++next;
+    }
+  };
+  fill();
+  while (!err && head < ring) {
+    if (hipEventSynchronize(c->chk_ev[head & 3]) != hipSuccess) { err = 1; break; }
+    rr = c->host_rr[head & 7];
+    const int i = idx[head & 7];
+    ++head;
+    if (rr < c->h.convergenceCriterion) return i;
+    fill();
+  }
+  return -1;
+}
+
 int solver_pcg_fused(pop_ctx *c, SolveView &v) {
   const pop_config &cf = c->h.c;
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
@@ -354,29 +389,30 @@ int solver_pcg_fused(pop_ctx *c, SolveView &v) {
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
   const bool use_graph = (freq % 2 == 0) && !c->no_graph;
-  int m = 0;
-  while (m + freq <= cf.max_iterations) {
+  int m = 0, lerr = 0;
+  const int nint = cf.max_iterations / freq;
+  const int conv = run_intervals(c, nint, [&](int) -> int {
     if (use_graph) {
       // the graph is keyed by the solution array (the time-level rotation cycles three of them)
       hipGraphExec_t exec = nullptr;
       for (auto &g : c->graphs) if (g.first == v.X) exec = g.second;
       if (!exec) {
         hipGraph_t graph;
-        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1;
         const int e = fused_interval(c, v, freq, false);
         hipError_t ce = hipStreamEndCapture(c->stream, &graph);
-        if (e || ce != hipSuccess) { c->err = "solver graph capture failed"; return 1; }
-        HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        if (e || ce != hipSuccess) return -1;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) return -1;
         hipGraphDestroy(graph);
         c->graphs.push_back({v.X, exec});
       }
-      HIPCHK(c, hipGraphLaunch(exec, c->stream));
-    } else if (fused_interval(c, v, freq, false)) return 1;
-    m += freq;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    rr = c->host_sc->rr;
-    if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
-  }
+      if (hipGraphLaunch(exec, c->stream) != hipSuccess) return -1;
+    } else if (fused_interval(c, v, freq, false)) return -1;
+    return 1;
+  }, rr, lerr);
+  if (lerr) { c->err = "fused pcg: interval launch failed"; return 1; }
+  if (conv >= 0) c->numIterations = (conv + 1) * freq;
+  m = nint * freq;
   if (c->numIterations == cf.max_iterations && m < cf.max_iterations) {   // remainder without a check
     bool pending = false;
     for (; m < cf.max_iterations; ++m) {
@@ -559,7 +595,7 @@ static int cg_fused_interval(pop_ctx *c, SolveView &v, int freq) {
   int par = 0;
   cg_fused_iterations(c, v, freq, par);
   launch_fresidual<true>(c, v, fused_args(c, v));
-  hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_sc);
+  hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_rr, c->h.convergenceCriterion);
   return 0;
 }
 int solver_chrongear_fused(pop_ctx *c) {
@@ -581,33 +617,34 @@ int solver_chrongear_fused(pop_ctx *c) {
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
   const bool use_graph = (freq % 2 == 0) && !c->no_graph;   // even: the (rho, sigma) ping-pong ends where it started
-  int m = 0;
-  while (m + freq <= cf.max_iterations) {
+  int m = 0, lerr = 0;
+  const int nint = cf.max_iterations / freq;
+  const int conv = run_intervals(c, nint, [&](int i) -> int {
     if (use_graph) {
       hipGraphExec_t exec = nullptr;
       for (auto &g : c->graphs) if (g.first == v.X) exec = g.second;
       if (!exec) {
         hipGraph_t graph;
-        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1;
         const int e = cg_fused_interval(c, v, freq);
         hipError_t ce = hipStreamEndCapture(c->stream, &graph);
-        if (e || ce != hipSuccess) { c->err = "solver graph capture failed"; return 1; }
-        HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        if (e || ce != hipSuccess) return -1;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) return -1;
         hipGraphDestroy(graph);
         c->graphs.push_back({v.X, exec});
       }
-      HIPCHK(c, hipGraphLaunch(exec, c->stream));
+      if (hipGraphLaunch(exec, c->stream) != hipSuccess) return -1;
     } else {
-      int par = (m / freq * freq) & 1;   // odd freq: the ping-pong slot carries over between intervals
+      int par = (i * freq) & 1;   // odd freq: the ping-pong slot carries over between intervals
       cg_fused_iterations(c, v, freq, par);
       launch_fresidual<true>(c, v, fused_args(c, v));
-      hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_sc);
+      hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_rr, c->h.convergenceCriterion);
     }
-    m += freq;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    rr = c->host_sc->rr;
-    if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
-  }
+    return 1;
+  }, rr, lerr);
+  if (lerr) { c->err = "fused ChronGear: interval launch failed"; return 1; }
+  if (conv >= 0) c->numIterations = (conv + 1) * freq;
+  m = nint * freq;
   if (c->numIterations == cf.max_iterations && m < cf.max_iterations) {   // remainder without a check
     int par = m & 1;
     cg_fused_iterations(c, v, cf.max_iterations - m, par);
@@ -680,7 +717,7 @@ struct PcsiBufs { double *X[2], *R[2], *Q[2]; };
 static PcsiArgs pcsi_args(pop_ctx *c, const PcsiBufs &bf, int in, int j) {
   PcsiArgs a{};
   a.Xi = bf.X[in]; a.Ri = bf.R[in]; a.Qi = bf.Q[in]; a.Xo = bf.X[1 - in]; a.Ro = bf.R[1 - in]; a.Qo = bf.Q[1 - in];
-  a.Bv = c->RHS; a.C = c->centerWgt; a.A0R = c->S0; a.omega = c->pcsi_omega; a.base = c->pcsi_base; a.srcmap = c->srcmap; a.partial = c->partial;
+  a.Bv = c->RHS; a.C = c->centerWgt; a.A0R = c->S0; a.omega = c->pcsi_omega; a.base = c->pcsi_base; a.srcmap = c->srcmap; a.partial = c->partial; a.sc = c->sc;
   a.csy = c->pcsi_csy; a.j = j;
   return a;
 }
@@ -697,7 +734,7 @@ static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool
     in = 1 - in;
   }
   if (with_rr) {
-    hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)c->partial, c->nchunk, c->g.nblocks, c->sc, c->host_sc);
+    hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)c->partial, c->nchunk, c->g.nblocks, c->sc, c->host_rr, c->h.convergenceCriterion);
   }
 }
 int solver_pcsi_fused(pop_ctx *c) {
@@ -719,10 +756,14 @@ int solver_pcsi_fused(pop_ctx *c) {
   int in = 1;
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
-  int m = 0;
-  while (m < cf.max_iterations) {
-    const int n = std::min(freq, cf.max_iterations - m);
-    const bool with_rr = (n == freq) && ((m + n) % freq == 0) && (m + n >= start);
+  // intervals of `freq` steps (the last one may be shorter); those that end on a multiple of freq at or after
+  // convergenceCheckStart carry a check.  in_before[i]: ping-pong half interval i starts from
+  const int nint = (cf.max_iterations + freq - 1) / freq;
+  std::vector<int> in_after(nint + 1, in);
+  int lerr = 0;
+  const int conv = run_intervals(c, nint, [&](int i) -> int {
+    const int m = i * freq, n = std::min(freq, cf.max_iterations - m);
+    const bool with_rr = (n == freq) && (m + n >= start);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->pcsi_base, m);
     if (!c->no_graph && n == freq) {
       const int variant = in * 2 + (with_rr ? 1 : 0);
@@ -730,23 +771,21 @@ int solver_pcsi_fused(pop_ctx *c) {
       for (auto &gk : c->pcsi_graphs) if (gk.first.first == bf.X[0] && gk.first.second == variant) exec = gk.second;
       if (!exec) {
         hipGraph_t graph;
-        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return -1;
         pcsi_interval(c, bf, in, n, with_rr);
-        if (hipStreamEndCapture(c->stream, &graph) != hipSuccess) { c->err = "P-CSI graph capture failed"; return 1; }
-        HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        if (hipStreamEndCapture(c->stream, &graph) != hipSuccess) return -1;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) return -1;
         hipGraphDestroy(graph);
         c->pcsi_graphs.push_back({{bf.X[0], variant}, exec});
       }
-      HIPCHK(c, hipGraphLaunch(exec, c->stream));
+      if (hipGraphLaunch(exec, c->stream) != hipSuccess) return -1;
     } else pcsi_interval(c, bf, in, n, with_rr);
     if (n % 2) in = 1 - in;
-    m += n;
-    if (with_rr) {
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      rr = c->host_sc->rr;
-      if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
-    }
-  }
+    in_after[i] = in;
+    return with_rr ? 1 : 0;
+  }, rr, lerr);
+  if (lerr) { c->err = "fused P-CSI: interval launch failed"; return 1; }
+  if (conv >= 0) { c->numIterations = (conv + 1) * freq; in = in_after[conv]; }   // later intervals did nothing on the device
   const long long ncell = (long long)c->g.n2 * c->g.nblocks;
   if (in == 1) HIPCHK(c, hipMemcpyAsync(bf.X[0], bf.X[1], sizeof(double) * ncell, hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, bf.X[0], c->srcmap, ncell);
@@ -1007,6 +1046,8 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     for (int d : h.halo.fill_dst) sm[d] = -1;
     if (dev_upload(c, &c->srcmap, sm.data(), sm.size())) return 1;
     HIPCHK(c, hipHostMalloc((void **)&c->host_sc, sizeof(SolverScalars)));
+    HIPCHK(c, hipHostMalloc((void **)&c->host_rr, 8 * sizeof(double)));
+    for (auto &e : c->chk_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED");
     if (cfg->solver_choice == 3) {   // omega_k of P-CSI (POP_SolversMod.F90:1617-1620, 1695): a function of the eigenvalue bounds only
       const double csalpha = 2.0 / (h.pcsi_max_eig - h.pcsi_min_eig);
@@ -1111,6 +1152,8 @@ int pop_destroy(pop_ctx *c) {
   for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
   for (auto &g : c->pcsi_graphs) hipGraphExecDestroy(g.second);
   if (c->host_sc) hipHostFree(c->host_sc);
+  if (c->host_rr) hipHostFree(c->host_rr);
+  for (auto &e : c->chk_ev) if (e) hipEventDestroy(e);
   if (c->rccl_tr) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->rccl_tr->comm) rccl().CommDestroy(c->rccl_tr->comm);
