@@ -24,8 +24,11 @@ def content(m, cfg, dz, tl, n):
     return tot
 
 
-def test_gx1v7_full_size_matches_oracle(pkg, orclib_built):
-    cfg = named_config("gx1v7")
+@pytest.mark.parametrize("kw", [{}, {"solver_choice": 2}, {"solver_choice": 3}, {"tmix_opt": 3, "tadvect": 2}])
+def test_gx1v7_full_size_matches_oracle(pkg, orclib_built, kw):
+    """BASELINE configs[2] (KPP + pcg) and the CESM production choices on the same grid: ChronGear, P-CSI, and the
+    Robert filter with third-order upwind advection."""
+    cfg = named_config("gx1v7", **kw)
     gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
     for s in range(2):
         gpu.step(); it = orc.step()
