@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from popcfg import named_config  # noqa: E402
 
 FIELDS = [("TRACER", True), ("UVEL", True), ("VVEL", True), ("RHO", True), ("PSURF", False), ("UBTROP", False)]
-NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6}
+NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6, "pcsi_evp": 4}
 
 
 def config(case):
@@ -31,6 +31,8 @@ def config(case):
         return named_config("tiny", tadvect=2, vmix_choice=2, **small)
     if case == "robert":      # Robert-Asselin-Williams time filter (step_RF) instead of averaging steps
         return named_config("tiny", tmix_opt=3, **small)
+    if case == "pcsi_evp":    # CESM's production solver pair: P-CSI with the EVP block preconditioner (one 24x20 block: 8/8/8 x 8/6/6 pieces)
+        return named_config("tiny", solver_choice=3, precond_choice=1, nx_global=24, ny_global=20, km=16, block_size_x=24, block_size_y=20)
     raise KeyError(case)
 
 
