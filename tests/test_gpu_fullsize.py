@@ -41,8 +41,9 @@ def test_gx1v7_full_size_matches_oracle(pkg, orclib_built, kw):
     gpu.close(); orc.close()
 
 
-def test_tx01v3_full_size_properties(pkg, orclib_built):
-    cfg = named_config("tx0.1v3")
+@pytest.mark.parametrize("kw", [{}, {"solver_choice": 3}])
+def test_tx01v3_full_size_properties(pkg, orclib_built, kw):
+    cfg = named_config("tx0.1v3", **kw)
     small = named_config("tx0.1v3", nx_global=36, ny_global=24, block_size_x=36, block_size_y=24)
     o = Oracle(small)                      # vertical grid only (same km, same generator)
     dz = o.v1("dz")[1:cfg.km + 1].copy()
