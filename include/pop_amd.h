@@ -167,6 +167,12 @@ int pop_solver_diagonal(pop_ctx *ctx, int block_local, const double *diagonal_co
  * else the diagonal (current centre weight).  Private in the reference; exported so that parity tests can pin the
  * preconditioner on its own.  x_name / px_name: 2-D device fields (time level tl where it applies). */
 int pop_solver_preconditioner(pop_ctx *ctx, const char *x_name, int x_tl, const char *px_name, int px_tl);
+/* operators.F90 as stand-alone calls on device fields at level k (the time step has them inlined in its kernels):
+ * op 0  grad(k, GRADX, GRADY, F)   :126-192   F at T points  -> o1, o2 at U points (0 where k > KMU)
+ * op 1  div(k, DIV, UX, UY)        :49-119    a, b at U points -> o1 at T points, times the cell area (0 where k > KMT)
+ * op 2  zcurl(k, CURL, UX, UY)     :199-272   a, b at U points -> o1 at T points, times the cell area
+ * A 3-D field name selects its level-k slab; tl applies to names with time levels. */
+int pop_operator(pop_ctx *ctx, int op, int k, const char *a_name, const char *b_name, int tl, const char *o1_name, const char *o2_name);
 /* POP_SolversGetDiagnostics(iterationCount, residual, errorCode) :1158 */
 int pop_solver_get_diagnostics(const pop_ctx *ctx, int *iterations, double *rms_residual);
 /* state(k,kk,TEMPK,SALTK,this_block,RHOOUT,...) state_mod.F90:258 on n device-resident or

@@ -95,7 +95,9 @@ double orc_solver_rms(orc_model *m);
 void orc_preconditioner(orc_model *m, const double *X, double *PX);
 int orc_evp_info(orc_model *m, int what, int idx);
 void orc_btrop_operator(orc_model *m, const double *X, double *AX);   /* POP_SolversMod.F90:2414-2426 */
-int orc_solver_run(orc_model *m, double *X, const double *B);         /* :327-417 */
+int orc_solver_run(orc_model *m, double *X, const double *B);
+/* operators.F90: 0 grad :126-192, 1 div :49-119, 2 zcurl :199-272 on whole 2-D fields at level k */
+void orc_operator(orc_model *m, int op, int k, const double *A, const double *B, double *O1, double *O2);         /* :327-417 */
 
 #ifdef __cplusplus
 }

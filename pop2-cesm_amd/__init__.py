@@ -67,6 +67,7 @@ def lib():
         "pop_write_restart": (ci, [vp, cs]), "pop_read_restart": (ci, [vp, cs, ci]),
         "pop_solver_diagonal": (ci, [vp, ci, pd]),
         "pop_solver_preconditioner": (ci, [vp, cs, ci, cs, ci]),
+        "pop_operator": (ci, [vp, ci, ci, cs, cs, ci, cs, cs]),
         "pop_solver_get_diagnostics": (ci, [vp, pi, pd]),
         "pop_state_host": (ci, [vp, ci, pd, pd, pd, pd, pd, ll]),
         "pop_set_comm": (ci, [vp, vp, vp, vp, ll, XCHG_FN, ALLRED_FN, vp]),
@@ -283,6 +284,11 @@ class PopModel:
     def solver_preconditioner(self, x_name, px_name, x_tl=1, px_tl=1):
         """PX = M^-1 X on the physical cells (EVP sub-block solves when reserved_i[2] = 1, else the diagonal)"""
         self._chk(self.L.pop_solver_preconditioner(self.h, x_name.encode(), x_tl, px_name.encode(), px_tl))
+
+    def operator(self, op, k, a, b=None, o1="DH", o2="DHU", tl=1):
+        """operators.F90 grad / div / zcurl at level k on named device fields (results in o1 [, o2])"""
+        self._chk(self.L.pop_operator(self.h, {"grad": 0, "div": 1, "zcurl": 2}[op], k, a.encode(), (b or a).encode(), tl,
+                                      o1.encode(), o2.encode()))
 
     def solver_run(self):
         self._chk(self.L.pop_solver_run(self.h))

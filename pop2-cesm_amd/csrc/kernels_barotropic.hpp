@@ -86,6 +86,38 @@ __global__ void k_btrop_fin2(DevGrid g, StepParams sp, BtropArgs a) {
   a.VBN[q] = a.VH[q] - sp.beta * sp.c2dtp * (gy - a.GYR[q]);
 }
 
+// ---- operators.F90 as stand-alone entry points (pop_operator): grad :126-192, div :49-119, zcurl :199-272 on one
+// horizontal slab at level k (the time step itself has them inlined in its kernels)
+__global__ void k_operator(DevGrid g, int op, int k, const double *__restrict__ A, const double *__restrict__ Bf,
+                           double *__restrict__ O1, double *__restrict__ O2, long long blk_stride_in, long long blk_stride_out) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
+  const long long q = (long long)b * g.n2 + p2, qi = (long long)b * blk_stride_in + p2, qo = (long long)b * blk_stride_out + p2;
+  if (op == 0) {
+    double gx = 0.0, gy = 0.0;
+    if (i < nxb - 1 && j < g.nyb - 1 && k <= g.KMU[q]) {
+      const double f00 = A[qi], f10 = A[qi + 1], f01 = A[qi + nxb], f11 = A[qi + nxb + 1];
+      gx = g.DXUR[q] * 0.5 * (f11 - f00 - f01 + f10);
+      gy = g.DYUR[q] * 0.5 * (f11 - f00 + f01 - f10);
+    }
+    O1[qo] = gx; O2[qo] = gy;
+    return;
+  }
+  double r = 0.0;
+  if (i >= 1 && j >= 1 && k <= g.KMT[q]) {
+    const double dy00 = g.DYU[q], dy0m = g.DYU[q - nxb], dym0 = g.DYU[q - 1], dymm = g.DYU[q - 1 - nxb];
+    const double dx00 = g.DXU[q], dx0m = g.DXU[q - nxb], dxm0 = g.DXU[q - 1], dxmm = g.DXU[q - 1 - nxb];
+    if (op == 1)
+      r = 0.5 * (A[qi] * dy00 + A[qi - nxb] * dy0m - A[qi - 1] * dym0 - A[qi - 1 - nxb] * dymm +
+                 Bf[qi] * dx00 + Bf[qi - 1] * dxm0 - Bf[qi - nxb] * dx0m - Bf[qi - 1 - nxb] * dxmm);
+    else
+      r = 0.5 * (Bf[qi] * dy00 + Bf[qi - nxb] * dy0m - Bf[qi - 1] * dym0 - Bf[qi - 1 - nxb] * dymm -
+                 A[qi] * dx00 - A[qi - 1] * dxm0 + A[qi - nxb] * dx0m + A[qi - 1 - nxb] * dxmm);
+  }
+  O1[qo] = r;
+}
+
 // ---- deterministic reductions --------------------------------------------------------------
 // Stage 1 is fused into the producing kernels: each workgroup reduces its 256 cells with a
 // fixed LDS tree and writes partial[(blk*nchunk + chunk)*nfields + f].  Stage 2 (one workgroup)

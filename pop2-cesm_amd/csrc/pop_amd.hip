@@ -1544,6 +1544,30 @@ int pop_solver_preconditioner(pop_ctx *c, const char *x_name, int x_tl, const ch
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+// grad / div / zcurl of operators.F90 on device fields.  A 3-D field name selects its level-k slab.
+int pop_operator(pop_ctx *c, int op, int k, const char *a_name, const char *b_name, int tl, const char *o1_name, const char *o2_name) {
+  if (need_device(c)) return 1;
+  if (op < 0 || op > 2 || k < 1 || k > c->g.km) { c->err = "pop_operator: op 0 grad, 1 div, 2 zcurl; 1 <= k <= km"; return 1; }
+  const long long a2 = (long long)c->g.n2 * c->g.nblocks, a3 = (long long)c->g.n3 * c->g.nblocks;
+  auto slab = [&](const char *name, int t, double **p, long long *stride) -> int {
+    long long cnt;
+    if (!name || resolve(c, name, t, 0, p, &cnt) || (cnt != a2 && cnt != a3)) { c->err = std::string("pop_operator: unknown field ") + (name ? name : "(null)"); return 1; }
+    *stride = cnt == a3 ? c->g.n3 : c->g.n2;
+    if (cnt == a3) *p += (long long)(k - 1) * c->g.n2;
+    return 0;
+  };
+  double *A, *B, *O1, *O2 = nullptr; long long sa, sb, so1, so2 = 0;
+  if (slab(a_name, tl, &A, &sa)) return 1;
+  B = A; sb = sa;
+  if (op != 0 && slab(b_name, tl, &B, &sb)) return 1;
+  if (slab(o1_name, tl, &O1, &so1)) return 1;
+  if (op == 0 && slab(o2_name, tl, &O2, &so2)) return 1;
+  if (sb != sa || (op == 0 && so2 != so1)) { c->err = "pop_operator: the two inputs (outputs) must have the same rank"; return 1; }
+  hipLaunchKernelGGL(k_operator, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, op, k,
+                     (const double *)A, (const double *)B, O1, O2 ? O2 : O1, sa, so1);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 int pop_solver_get_diagnostics(const pop_ctx *c, int *it, double *rms) {
   if (it) *it = c->numIterations;
   if (rms) *rms = c->rmsResidual;

@@ -217,6 +217,12 @@
          character (kind=c_char), intent(in) :: path(*)
          integer (c_int), value :: flags
       end function
+      integer (c_int) function pop_operator(ctx, op, k, aname, bname, tl, o1name, o2name) bind(C, name='pop_operator')
+         import :: c_int, c_ptr, c_char
+         type (c_ptr), value :: ctx
+         integer (c_int), value :: op, k, tl
+         character (kind=c_char), intent(in) :: aname(*), bname(*), o1name(*), o2name(*)
+      end function
       integer (c_int) function pop_solver_preconditioner(ctx, xname, xtl, pxname, pxtl) bind(C, name='pop_solver_preconditioner')
          import :: c_int, c_ptr, c_char
          type (c_ptr), value :: ctx

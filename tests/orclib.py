@@ -51,6 +51,8 @@ def load():
     L.orc_btrop_operator.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.orc_btrop_operator.restype = None
     L.orc_solver_run.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_operator.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 4
+    L.orc_operator.restype = None
     L.orc_global_sum.restype = C.c_double
     L.orc_global_sum.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     return L
@@ -137,6 +139,14 @@ class Oracle:
         ax = np.empty_like(x)
         self.L.orc_btrop_operator(self.h, self._dp(x), self._dp(ax))
         return ax
+
+    def operator(self, op, k, a, b=None):
+        """op: 'grad' -> (GX, GY); 'div' / 'zcurl' -> field at T points"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = a if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        o1, o2 = np.empty_like(a), np.empty_like(a)
+        self.L.orc_operator(self.h, {'grad': 0, 'div': 1, 'zcurl': 2}[op], k, self._dp(a), self._dp(b), self._dp(o1), self._dp(o2))
+        return (o1, o2) if op == 'grad' else o1
 
     def solver_run(self, x, b):
         x = np.ascontiguousarray(x, dtype=np.float64).copy()

@@ -535,6 +535,31 @@ def test_solvers_recover_a_manufactured_solution(pkg, orclib_built, kw):
     gpu.close(); orc.close()
 
 
+def test_operators_are_bitwise_the_oracle(pkg, orclib_built):
+    """operators.F90 grad / div / zcurl as stand-alone entry points (pop_operator), on 2-D fields and on a level of
+    3-D fields: same expressions in the same order as the oracle, so the results are identical."""
+    cfg = named_config("tiny")
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    rng = np.random.default_rng(12)
+    s2 = (gpu.nblocks, gpu.nyb, gpu.nxb)
+    f, u, v = (rng.standard_normal(s2) for _ in range(3))
+    gpu.set("PSURF", f); gpu.set("UBTROP", u); gpu.set("VBTROP", v)
+    gpu.operator("grad", 1, "PSURF", o1="GRADPX", o2="GRADPY")
+    gx, gy = orc.operator("grad", 1, f)
+    assert np.array_equal(gpu.get("GRADPX"), gx) and np.array_equal(gpu.get("GRADPY"), gy)
+    for op in ("div", "zcurl"):
+        gpu.operator(op, 1, "UBTROP", "VBTROP", o1="DH")
+        assert np.array_equal(gpu.get("DH"), orc.operator(op, 1, u, v)), op
+    k = 5
+    u3 = rng.standard_normal((gpu.nblocks, gpu.km, gpu.nyb, gpu.nxb)); v3 = rng.standard_normal(u3.shape)
+    gpu.set("UVEL", u3); gpu.set("VVEL", v3)
+    gpu.operator("zcurl", k, "UVEL", "VVEL", o1="DH")
+    assert np.array_equal(gpu.get("DH"), orc.operator("zcurl", k, u3[:, k - 1], v3[:, k - 1]))
+    gpu.operator("div", k, "UVEL", "VVEL", o1="VVC")             # 3-D output: its level-k slab
+    assert np.array_equal(gpu.get("VVC")[:, k - 1], orc.operator("div", k, u3[:, k - 1], v3[:, k - 1]))
+    gpu.close(); orc.close()
+
+
 @pytest.mark.parametrize("solver", [1, 2, 3])
 def test_solver_error_convention(pkg, orclib_built, solver):
     """POP_SolversMod.F90:1492-1497: hitting maxIterations is an error (errorCode set, message) unless
