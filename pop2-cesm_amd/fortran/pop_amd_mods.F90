@@ -356,3 +356,82 @@
       errorCode = pop_write_restart(pop_ctx, cstr(out_filename))
    end subroutine
  end module restart
+
+!-----------------------------------------------------------------------
+ module global_reductions    ! mpi/global_reductions.F90:35-41 (legacy names; fields are device-resident and named)
+   use kinds_mod
+   use pop_amd_c
+   use POP_ReductionsMod
+   implicit none
+   private
+   public :: global_sum, global_sum_prod, global_count, global_maxval, global_minval
+ contains
+   function global_sum(name, timeLevel, n, mMask) result(s)        ! :383-614
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      character (*), intent(in), optional :: mMask
+      real (POP_r8) :: s
+      integer (POP_i4) :: errorCode
+      if (present(mMask)) then
+         s = POP_GlobalSum(name, timeLevel, n, errorCode, mMask=mMask)
+      else
+         s = POP_GlobalSum(name, timeLevel, n, errorCode)
+      endif
+   end function
+   function global_sum_prod(name1, timeLevel1, name2, timeLevel2) result(s)   ! :1143-1395
+      character (*), intent(in) :: name1, name2
+      integer (POP_i4), intent(in) :: timeLevel1, timeLevel2
+      real (POP_r8) :: s
+      integer (POP_i4) :: errorCode
+      s = POP_GlobalSumProd(name1, timeLevel1, name2, timeLevel2, errorCode)
+   end function
+   function global_count(name, timeLevel, n) result(c)              ! :1906-2006
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      integer (c_long_long) :: c
+      integer (POP_i4) :: errorCode
+      c = POP_GlobalCount(name, timeLevel, n, errorCode)
+   end function
+   function global_maxval(name, timeLevel, n) result(v)             ! :2277-2400
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      real (POP_r8) :: v
+      integer (POP_i4) :: errorCode
+      v = POP_GlobalMaxval(name, timeLevel, n, errorCode)
+   end function
+   function global_minval(name, timeLevel, n) result(v)             ! :2600-2730
+      character (*), intent(in) :: name
+      integer (POP_i4), intent(in) :: timeLevel, n
+      real (POP_r8) :: v
+      integer (POP_i4) :: errorCode
+      v = POP_GlobalMinval(name, timeLevel, n, errorCode)
+   end function
+ end module global_reductions
+
+!-----------------------------------------------------------------------
+ module operators            ! source/operators.F90:34 (grad, div, zcurl on named device fields at level k)
+   use kinds_mod
+   use pop_amd_c
+   implicit none
+   private
+   public :: grad, div, zcurl
+ contains
+   subroutine grad(k, gradxName, gradyName, fName, timeLevel, errorCode)      ! :126-192
+      integer (POP_i4), intent(in) :: k, timeLevel
+      character (*), intent(in) :: gradxName, gradyName, fName
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_operator(pop_ctx, 0, k, cstr(fName), cstr(fName), timeLevel, cstr(gradxName), cstr(gradyName))
+   end subroutine
+   subroutine div(k, divName, uxName, uyName, timeLevel, errorCode)           ! :49-119
+      integer (POP_i4), intent(in) :: k, timeLevel
+      character (*), intent(in) :: divName, uxName, uyName
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_operator(pop_ctx, 1, k, cstr(uxName), cstr(uyName), timeLevel, cstr(divName), cstr(divName))
+   end subroutine
+   subroutine zcurl(k, curlName, uxName, uyName, timeLevel, errorCode)        ! :199-272
+      integer (POP_i4), intent(in) :: k, timeLevel
+      character (*), intent(in) :: curlName, uxName, uyName
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_operator(pop_ctx, 2, k, cstr(uxName), cstr(uyName), timeLevel, cstr(curlName), cstr(curlName))
+   end subroutine
+ end module operators
