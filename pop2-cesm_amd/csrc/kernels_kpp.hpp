@@ -625,8 +625,18 @@ __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__
 
 // ---- host side ---------------------------------------------------------------------------------
 // per-context KPP state (MixDev::kpp)
-struct KppHost { KppDev dev; int max_kref = 1; int col = 0; };   // col: bit 0 = ushear, bit 1 = buoydiff in column form
-inline void kpp_destroy(MixDev &m) { delete (KppHost *)m.kpp; m.kpp = nullptr; }
+// col: bit 0 = ushear, bit 1 = buoydiff in column form.  side / ev_*: second HIP stream on which the shear kernel (needs only
+// U, V; consumed by bldepth) runs beside buoydiff + interior (POP_KPP_SIDE_STREAM=0 keeps everything on one stream)
+struct KppHost { KppDev dev; int max_kref = 1; int col = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+inline void kpp_destroy(MixDev &m) {
+  KppHost *k = (KppHost *)m.kpp;
+  if (k) {
+    if (k->ev_fork) hipEventDestroy(k->ev_fork);
+    if (k->ev_join) hipEventDestroy(k->ev_join);
+    if (k->side) hipStreamDestroy(k->side);
+  }
+  delete k; m.kpp = nullptr;
+}
 
 inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<void *> &allocs, std::string &err) {
   const pop_config &c = h.c;
@@ -652,6 +662,11 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   };
   KppHost *K = new KppHost();
   m.kpp = K;
+  if (!(getenv("POP_KPP_SIDE_STREAM") && atoi(getenv("POP_KPP_SIDE_STREAM")) == 0)) {
+    if (hipStreamCreateWithFlags(&K->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&K->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&K->ev_join, hipEventDisableTiming) != hipSuccess) { err = "kpp: side stream"; return 1; }
+  }
   KppDev &k = K->dev;
   void *p;
   if (up(zgrid.data(), zgrid.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.zgrid = (double *)p;
@@ -691,6 +706,13 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   const dim3 GC(col_grid(g, POP_COL_THREADS), g.nblocks), BC(POP_COL_THREADS);
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);
   double *DBLOC = s.S3a, *DBSFC = s.S3b, *WU = s.S3c, *VISC = s.S3d, *RIW = s.E3;
+  // the shear of the velocity against its surface-layer reference needs only U and V: on the side stream it overlaps the
+  // (VALU-bound) buoydiff and the interior kernel; bldepth waits for it
+  const hipStream_t su = KH.side ? KH.side : st;
+  if (KH.side) { hipEventRecord(KH.ev_fork, st); hipStreamWaitEvent(KH.side, KH.ev_fork, 0); }
+  if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
+  else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
+  if (KH.side) hipEventRecord(KH.ev_join, KH.side);
   if ((g_kpp_col & 2) && KH.max_kref <= 20) hipLaunchKernelGGL(k_kpp_buoydiff_col<20>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if (g_kpp_col & 2) hipLaunchKernelGGL(k_kpp_buoydiff_col<24>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
@@ -698,8 +720,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   if (int_reg && g.km == 60) hipLaunchKernelGGL(k_kpp_interior_reg<60>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else if (int_reg && g.km == 62) hipLaunchKernelGGL(k_kpp_interior_reg<62>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
-  if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
-  else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
+  if (KH.side) hipStreamWaitEvent(st, KH.ev_join, 0);
   hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                      (const double *)DBSFC, (const double *)WU);
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
