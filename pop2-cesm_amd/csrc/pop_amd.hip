@@ -51,6 +51,10 @@ struct pop_ctx {
   double *DH = nullptr, *DHU = nullptr, *ZX = nullptr, *ZY = nullptr, *UH = nullptr, *VH = nullptr;
   double *W3 = nullptr, *W4 = nullptr, *RHS = nullptr, *centerWgt = nullptr;
   double *E3 = nullptr, *F3 = nullptr, *S3a = nullptr, *S3b = nullptr, *S3c = nullptr, *S3d = nullptr;
+  // del4: the first Laplacians need only the mix-time fields, so they run on a side stream beside the vertical-mixing
+  // coefficients (own output buffers d2t / d2u instead of the shared scratch; POP_DEL4_SIDE=0: in line, scratch reused)
+  double *d2t[2] = {nullptr, nullptr}, *d2u[2] = {nullptr, nullptr};
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_d2t = nullptr, ev_d2u = nullptr;
   double *HBLT = nullptr, *HMXL = nullptr;
   MixDev mix{};
   // solver
@@ -1000,6 +1004,14 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   c->centerWgt = c->d2["centerWgt"];
   double **three[] = {&c->VVC, &c->E3, &c->F3, &c->S3a, &c->S3b, &c->S3c, &c->S3d};
   for (auto p : three) if (dev_alloc(c, p, a3)) return 1;
+  c->d2t[0] = c->S3a; c->d2t[1] = c->S3b; c->d2u[0] = c->S3a; c->d2u[1] = c->S3b;
+  if ((cfg->hmix_tracer == 4 || cfg->hmix_momentum == 4) && !(getenv("POP_DEL4_SIDE") && atoi(getenv("POP_DEL4_SIDE")) == 0)) {
+    if (dev_alloc(c, &c->d2t[0], a3) || dev_alloc(c, &c->d2t[1], a3) || dev_alloc(c, &c->d2u[0], a3) || dev_alloc(c, &c->d2u[1], a3)) return 1;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2t, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2u, hipEventDisableTiming));
+  }
   c->nchunk = red_grid_x(g);
   if (dev_alloc(c, &c->partial, (size_t)c->nchunk * h.nblocks * 2) || dev_alloc(c, &c->blocksum, (size_t)h.nblocks_tot * 4)) return 1;
   { std::vector<int> io(h.nblocks_tot); for (int b = 0; b < h.nblocks_tot; ++b) io[b] = b; if (dev_upload(c, &c->iota, io.data(), io.size())) return 1; }
@@ -1153,6 +1165,10 @@ int pop_destroy(pop_ctx *c) {
   for (auto &g : c->pcsi_graphs) hipGraphExecDestroy(g.second);
   if (c->host_sc) hipHostFree(c->host_sc);
   if (c->host_rr) hipHostFree(c->host_rr);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_d2t) hipEventDestroy(c->ev_d2t);
+  if (c->ev_d2u) hipEventDestroy(c->ev_d2u);
+  if (c->side) hipStreamDestroy(c->side);
   for (auto &e : c->chk_ev) if (e) hipEventDestroy(e);
   if (c->rccl_tr) {
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -1428,9 +1444,9 @@ static int phase_vmix(pop_ctx *c) {
   }
   return 0;
 }
-static int phase_hmix_tracer(pop_ctx *c) {   // del4 only: biharmonic tracer mixing into S3a, S3b
+static int phase_hmix_tracer(pop_ctx *c, hipStream_t st = nullptr) {   // del4 only: first Laplacian of the tracers into d2t
   if (c->h.c.hmix_tracer != 4) return 0;
-  return mix_hdifft_del4(c->h, c->g, step_params(c), c->mix, c->TR[0][c->mixt], c->TR[1][c->mixt], c->S3a, c->S3b, c->S3c, c->S3d, c->stream, c->err);
+  return mix_hdifft_del4(c->h, c->g, step_params(c), c->mix, c->TR[0][c->mixt], c->TR[1][c->mixt], c->d2t[0], c->d2t[1], c->S3c, c->S3d, st ? st : c->stream, c->err);
 }
 static int phase_tracer_rhs(pop_ctx *c) {
   const StepParams sp = step_params(c);
@@ -1439,7 +1455,7 @@ static int phase_tracer_rhs(pop_ctx *c) {
     a.TCUR[n] = c->TR[n][c->curt]; a.TOLD[n] = c->TR[n][c->oldt]; a.TMIX[n] = c->TR[n][c->mixt]; a.TNEW[n] = c->TR[n][c->newt];
     a.VDC[n] = c->VDC[sp.nvdc == 2 ? n : 0]; a.KPP_SRC[n] = c->KPP_SRC[n]; a.STF[n] = c->STF[n]; a.TFW[n] = c->TFW[n];
   }
-  if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->S3a; a.TMIX[1] = c->S3b; }   // del4: second Laplacian acts on D2T
+  if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->d2t[0]; a.TMIX[1] = c->d2t[1]; }   // del4: second Laplacian acts on D2T
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
   a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
   if (c->h.c.tadvect == 1 && c->trc_lds_rows == 8) { launch_tracer_lds<8>(c->g, sp, a, c->stream); return 0; }
@@ -1466,15 +1482,15 @@ static int phase_state_new(pop_ctx *c) {
   hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->newt], c->TR[1][c->newt], c->RHO[c->newt]);
   return 0;
 }
-static int phase_hmix_momentum(pop_ctx *c) {   // del4 only: biharmonic friction into S3a, S3b
+static int phase_hmix_momentum(pop_ctx *c, hipStream_t st = nullptr) {   // del4 only: first Laplacian of the velocity into d2u
   if (c->h.c.hmix_momentum != 4) return 0;
-  return mix_hdiffu_del4(c->h, c->g, step_params(c), c->mix, c->U[c->mixt], c->V[c->mixt], c->S3a, c->S3b, c->S3c, c->S3d, c->stream, c->err);
+  return mix_hdiffu_del4(c->h, c->g, step_params(c), c->mix, c->U[c->mixt], c->V[c->mixt], c->d2u[0], c->d2u[1], c->S3c, c->S3d, st ? st : c->stream, c->err);
 }
 static int phase_momentum_rhs(pop_ctx *c) {
   MomentumRhsArgs a{};
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.UOLD = c->U[c->oldt]; a.VOLD = c->V[c->oldt]; a.UMIX = c->U[c->mixt]; a.VMIX = c->V[c->mixt];
   a.RHOOLD = c->RHO[c->oldt]; a.RHOCUR = c->RHO[c->curt]; a.RHONEW = c->RHO[c->newt]; a.VVC = c->VVC; a.DHU = c->DHU;
-  if (c->h.c.hmix_momentum == 4) { a.UMIX = c->S3a; a.VMIX = c->S3b; }   // del4: second Laplacian acts on D2U, D2V
+  if (c->h.c.hmix_momentum == 4) { a.UMIX = c->d2u[0]; a.VMIX = c->d2u[1]; }   // del4: second Laplacian acts on D2U, D2V
   a.UNEW = c->U[c->newt]; a.VNEW = c->V[c->newt]; a.ZX = c->ZX; a.ZY = c->ZY;
   // 3x3 stencils staged through LDS (kernels_momentum_lds.hpp): 64x8 tiles measured -11 % (tx0.1v3) / -12 % (gx1v7)
   // against the direct-load kernel, 64x4 +8 %; POP_MOMENTUM_LDS=0|4|8 selects (read at pop_create)
@@ -1503,13 +1519,27 @@ int pop_baroclinic_driver(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "BAROCLINIC");
   const StepParams sp = step_params(c);
-  if (phase_vmix(c) || phase_hmix_tracer(c) || phase_tracer_rhs(c)) return 1;
+  const bool fork = c->side && (c->h.c.hmix_tracer == 4 || c->h.c.hmix_momentum == 4);
+  if (fork) {   // del4 first Laplacians beside the vertical-mixing coefficients
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if (phase_hmix_tracer(c, c->side)) return 1;
+    HIPCHK(c, hipEventRecord(c->ev_d2t, c->side));
+    if (phase_hmix_momentum(c, c->side)) return 1;
+    HIPCHK(c, hipEventRecord(c->ev_d2u, c->side));
+  }
+  if (phase_vmix(c)) return 1;
+  if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2t, 0));
+  else if (phase_hmix_tracer(c)) return 1;
+  if (phase_tracer_rhs(c)) return 1;
   if (sp.pavg) {
     if (phase_impvmixt_pred(c)) return 1;
     if (halo_update(c, c->TR[0][c->newt], c->g.km) || halo_update(c, c->TR[1][c->newt], c->g.km)) return 1;
     if (phase_state_new(c)) return 1;
   }
-  if (phase_hmix_momentum(c) || phase_momentum_rhs(c) || phase_impvmixu(c)) return 1;
+  if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2u, 0));
+  else if (phase_hmix_momentum(c)) return 1;
+  if (phase_momentum_rhs(c) || phase_impvmixu(c)) return 1;
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -2058,8 +2088,8 @@ int pop_time_phase(pop_ctx *c, const char *phase, int reps, double *avg_ms) {
   else if (p == "impvmixu") fn = phase_impvmixu;
   else if (p == "correct") fn = phase_correct;
   else if (p == "add_btrop") fn = phase_add_btrop;
-  else if (p == "hmix_tracer") fn = phase_hmix_tracer;
-  else if (p == "hmix_momentum") fn = phase_hmix_momentum;
+  else if (p == "hmix_tracer") fn = [](pop_ctx *x) { return phase_hmix_tracer(x); };
+  else if (p == "hmix_momentum") fn = [](pop_ctx *x) { return phase_hmix_momentum(x); };
   if (!fn) { c->err = "unknown phase " + p; return 1; }
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
