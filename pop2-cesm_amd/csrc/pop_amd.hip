@@ -54,7 +54,8 @@ struct pop_ctx {
   // del4: the first Laplacians need only the mix-time fields, so they run on a side stream beside the vertical-mixing
   // coefficients (own output buffers d2t / d2u instead of the shared scratch; POP_DEL4_SIDE=0: in line, scratch reused)
   double *d2t[2] = {nullptr, nullptr}, *d2u[2] = {nullptr, nullptr};
-  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_d2t = nullptr, ev_d2u = nullptr;
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_d2t = nullptr, ev_d2u = nullptr, ev_vmixu = nullptr;
+  bool side_del4 = false, vmixu_pending = false;   // implicit vertical mixing of U,V in flight on the side stream
   double *HBLT = nullptr, *HMXL = nullptr;
   MixDev mix{};
   // solver
@@ -1005,12 +1006,16 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   double **three[] = {&c->VVC, &c->E3, &c->F3, &c->S3a, &c->S3b, &c->S3c, &c->S3d};
   for (auto p : three) if (dev_alloc(c, p, a3)) return 1;
   c->d2t[0] = c->S3a; c->d2t[1] = c->S3b; c->d2u[0] = c->S3a; c->d2u[1] = c->S3b;
-  if ((cfg->hmix_tracer == 4 || cfg->hmix_momentum == 4) && !(getenv("POP_DEL4_SIDE") && atoi(getenv("POP_DEL4_SIDE")) == 0)) {
-    if (dev_alloc(c, &c->d2t[0], a3) || dev_alloc(c, &c->d2t[1], a3) || dev_alloc(c, &c->d2u[0], a3) || dev_alloc(c, &c->d2u[1], a3)) return 1;
+  if (!(getenv("POP_SIDE_STREAM") && atoi(getenv("POP_SIDE_STREAM")) == 0)) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2t, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2u, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_vmixu, hipEventDisableTiming));
+    if ((cfg->hmix_tracer == 4 || cfg->hmix_momentum == 4) && !(getenv("POP_DEL4_SIDE") && atoi(getenv("POP_DEL4_SIDE")) == 0)) {
+      if (dev_alloc(c, &c->d2t[0], a3) || dev_alloc(c, &c->d2t[1], a3) || dev_alloc(c, &c->d2u[0], a3) || dev_alloc(c, &c->d2u[1], a3)) return 1;
+      c->side_del4 = true;
+    }
   }
   c->nchunk = red_grid_x(g);
   if (dev_alloc(c, &c->partial, (size_t)c->nchunk * h.nblocks * 2) || dev_alloc(c, &c->blocksum, (size_t)h.nblocks_tot * 4)) return 1;
@@ -1168,7 +1173,8 @@ int pop_destroy(pop_ctx *c) {
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_d2t) hipEventDestroy(c->ev_d2t);
   if (c->ev_d2u) hipEventDestroy(c->ev_d2u);
-  if (c->side) hipStreamDestroy(c->side);
+  if (c->ev_vmixu) hipEventDestroy(c->ev_vmixu);
+  if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
   for (auto &e : c->chk_ev) if (e) hipEventDestroy(e);
   if (c->rccl_tr) {
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -1245,6 +1251,11 @@ long long pop_field_count(const pop_ctx *c, const char *name) {
   if (n == "VDC") return (long long)c->h.n2 * (c->h.km + 2) * c->h.nblocks;
   return a2;
 }
+// wait for side-stream work whose results the launch stream (or the host) is about to use
+static int join_side(pop_ctx *c) {
+  if (c->vmixu_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_vmixu, 0)); c->vmixu_pending = false; }
+  return 0;
+}
 int pop_get_field(pop_ctx *c, const char *name, int tl, int n, double *host, long long count) {
   const std::string nm(name);
   if (c->host_only) {   // host-only contexts expose the init-time 2-D fields of the local blocks
@@ -1261,6 +1272,7 @@ int pop_get_field(pop_ctx *c, const char *name, int tl, int n, double *host, lon
   double *p; long long cnt;
   if (resolve(c, nm, tl, n, &p, &cnt)) { c->err = "unknown field " + nm; return 1; }
   if (cnt != count) { c->err = "count mismatch for " + nm; return 1; }
+  if (join_side(c)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(host, p, cnt * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
@@ -1270,6 +1282,7 @@ int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *hos
   double *p; long long cnt;
   if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
   if (cnt != count) { c->err = std::string("count mismatch for ") + name; return 1; }
+  if (join_side(c)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(p, host, cnt * sizeof(double), hipMemcpyHostToDevice));
   return 0;
@@ -1284,6 +1297,7 @@ int pop_get_ifield(pop_ctx *c, const char *name, int *host, long long count) {
 }
 void *pop_field_device_ptr(pop_ctx *c, const char *name, int tl, int n) {
   if (c->host_only) return nullptr;
+  join_side(c);   // the caller may read the field on the launch stream
   double *p; long long cnt;
   return resolve(c, name, tl, n, &p, &cnt) ? nullptr : (void *)p;
 }
@@ -1291,7 +1305,7 @@ void *pop_field_device_ptr(pop_ctx *c, const char *name, int tl, int n) {
 // ---- restart files (restart.F90 write_restart :1095-1715, read_restart :184-1088; 'bin' format of io_binary.F90)
 static std::string fmt_r8(double v) { char b[40]; snprintf(b, sizeof b, "%.17g", v); return b; }
 int pop_write_restart(pop_ctx *c, const char *path) {
-  if (need_device(c)) return 1;
+  if (need_device(c) || join_side(c)) return 1;
   const HostModel &h = c->h;
   const std::vector<RestartField> fields = restart_fields(h);
   if (h.rank == 0) {
@@ -1342,7 +1356,7 @@ int pop_write_restart(pop_ctx *c, const char *path) {
 }
 
 int pop_read_restart(pop_ctx *c, const char *path, int flags) {
-  if (need_device(c)) return 1;
+  if (need_device(c) || join_side(c)) return 1;
   const HostModel &h = c->h;
   std::map<std::string, std::map<std::string, std::string>> sec;
   if (restart_parse_header(path, sec, c->err)) return 1;
@@ -1499,11 +1513,12 @@ static int phase_momentum_rhs(pop_ctx *c) {
   else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
   return 0;
 }
-static int phase_impvmixu(pop_ctx *c) {
+static int phase_impvmixu(pop_ctx *c, hipStream_t st = nullptr) {
   ImpvmixuArgs a{c->U[c->newt], c->V[c->newt], c->E3, c->U[c->oldt], c->V[c->oldt], c->VVC};
-  launch_impvmixu(c->g, step_params(c), a, grid_cols(c), c->stream, c->reg_thomas);
+  launch_impvmixu(c->g, step_params(c), a, grid_cols(c), st ? st : c->stream, c->reg_thomas);
   return 0;
 }
+
 static int phase_correct(pop_ctx *c) {
   const StepParams sp = step_params(c);
   if (sp.pavg) launch_impvmixt<1, false, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t);
@@ -1519,7 +1534,7 @@ int pop_baroclinic_driver(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "BAROCLINIC");
   const StepParams sp = step_params(c);
-  const bool fork = c->side && (c->h.c.hmix_tracer == 4 || c->h.c.hmix_momentum == 4);
+  const bool fork = c->side_del4;
   if (fork) {   // del4 first Laplacians beside the vertical-mixing coefficients
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -1539,7 +1554,16 @@ int pop_baroclinic_driver(pop_ctx *c) {
   }
   if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2u, 0));
   else if (phase_hmix_momentum(c)) return 1;
-  if (phase_momentum_rhs(c) || phase_impvmixu(c)) return 1;
+  if (phase_momentum_rhs(c)) return 1;
+  // the implicit vertical mixing of U, V is not needed before the step tail: with the register kernel (no shared scratch)
+  // it runs on the side stream beside the barotropic solver, whose one-workgroup reduction kernels leave the GPU idle
+  if (c->side && c->reg_thomas && (c->g.km == 60 || c->g.km == 62) && !getenv("POP_VMIXU_INLINE")) {
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if (phase_impvmixu(c, c->side)) return 1;
+    HIPCHK(c, hipEventRecord(c->ev_vmixu, c->side));
+    c->vmixu_pending = true;
+  } else if (phase_impvmixu(c)) return 1;
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1564,6 +1588,7 @@ int pop_solver_run(pop_ctx *c) {
 }
 int pop_solver_preconditioner(pop_ctx *c, const char *x_name, int x_tl, const char *px_name, int px_tl) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   double *x, *px; long long cnt, a2 = (long long)c->g.n2 * c->g.nblocks;
   if (resolve(c, x_name, x_tl, 0, &x, &cnt) || cnt != a2) { c->err = std::string("unknown 2-D field ") + x_name; return 1; }
   if (resolve(c, px_name, px_tl, 0, &px, &cnt) || cnt != a2 || px == x) { c->err = std::string("unknown 2-D field ") + px_name; return 1; }
@@ -1577,6 +1602,7 @@ int pop_solver_preconditioner(pop_ctx *c, const char *x_name, int x_tl, const ch
 // grad / div / zcurl of operators.F90 on device fields.  A 3-D field name selects its level-k slab.
 int pop_operator(pop_ctx *c, int op, int k, const char *a_name, const char *b_name, int tl, const char *o1_name, const char *o2_name) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   if (op < 0 || op > 2 || k < 1 || k > c->g.km) { c->err = "pop_operator: op 0 grad, 1 div, 2 zcurl; 1 <= k <= km"; return 1; }
   const long long a2 = (long long)c->g.n2 * c->g.nblocks, a3 = (long long)c->g.n3 * c->g.nblocks;
   auto slab = [&](const char *name, int t, double **p, long long *stride) -> int {
@@ -1704,6 +1730,7 @@ int pop_step_tail(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "3D-UPDATE");
   const int km = c->g.km;
+  if (join_side(c)) return 1;
   if (halo_update(c, c->UB[c->newt], 1) || halo_update(c, c->VB[c->newt], 1)) return 1;
   if (halo_update(c, c->U[c->newt], km) || halo_update(c, c->V[c->newt], km) || halo_update(c, c->RHO[c->newt], km)) return 1;
   for (int n = 0; n < c->h.nt; ++n) if (halo_update(c, c->TR[n][c->newt], km)) return 1;
@@ -1745,6 +1772,7 @@ int pop_step(pop_ctx *c) {
 
 int pop_halo_update(pop_ctx *c, const char *name, int tl, int n) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   double *p; long long cnt;
   if (n < 0) {   // POP_HaloUpdate4DR8 (mpi/POP_HaloMod.F90:4122-4585): every tracer of a (nx,ny,km,nt,block) field
     if (std::string(name) != "TRACER" && std::string(name) != "KPP_SRC" && std::string(name) != "STF" && std::string(name) != "TFW") {
@@ -1759,6 +1787,7 @@ int pop_halo_update(pop_ctx *c, const char *name, int tl, int n) {
 }
 int pop_halo_update_loc(pop_ctx *c, const char *name, int tl, int n, int field_loc, int field_kind) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   if (field_loc < 0 || field_loc > 3 || field_kind < 0 || field_kind > 2) { c->err = "pop_halo_update_loc: unknown field location / kind"; return 1; }
   double *p; long long cnt;
   if (resolve(c, name, tl, n < 0 ? 0 : n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
@@ -1790,6 +1819,7 @@ int pop_halo_update_host_i4(pop_ctx *c, int *array, int nz, int fill) {
 }
 int pop_global_sum(pop_ctx *c, const char *name, int tl, int n, const char *mask_name, double *result) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   double *p, *mk = nullptr; long long cnt;
   if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
   if (mask_name && resolve(c, mask_name, 0, 0, &mk, &cnt)) { c->err = std::string("unknown mask ") + mask_name; return 1; }
@@ -1804,6 +1834,7 @@ int pop_global_sum(pop_ctx *c, const char *name, int tl, int n, const char *mask
 // the redundant half of the top row once
 int pop_global_sum_loc(pop_ctx *c, const char *name, int tl, int n, const char *mask_name, int field_loc, double *result) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   if (c->h.c.ns_boundary != 2 || (field_loc != 1 && field_loc != 2)) return pop_global_sum(c, name, tl, n, mask_name, result);
   double *p, *mk = nullptr; long long cnt;
   if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
@@ -1833,6 +1864,7 @@ static int gather_slots(pop_ctx *c, const double *local, int nv, std::vector<dou
 // (block order, then j, then i) that attains it; mask_name selects cells with a non-zero mask value
 int pop_global_extreme(pop_ctx *c, const char *name, int tl, int n, const char *mask_name, int want_max, double *value, int *iloc, int *jloc) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   double *p, *mk = nullptr; long long cnt;
   if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
   if (mask_name && resolve(c, mask_name, 0, 0, &mk, &cnt)) { c->err = std::string("unknown mask ") + mask_name; return 1; }
@@ -1874,6 +1906,7 @@ int pop_global_extreme(pop_ctx *c, const char *name, int tl, int n, const char *
 // NE-corner fields counted once)
 int pop_global_count(pop_ctx *c, const char *name, int tl, int n, int field_loc, long long *count) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   double *p; long long cnt;
   if (resolve(c, name, tl, n, &p, &cnt)) { c->err = std::string("unknown field ") + name; return 1; }
   const double *dup = (c->h.c.ns_boundary == 2 && (field_loc == 1 || field_loc == 2)) ? c->d2["TRIPOLE_DUP"] : nullptr;
@@ -1888,6 +1921,7 @@ int pop_global_count(pop_ctx *c, const char *name, int tl, int n, int field_loc,
 int pop_global_sum_prod(pop_ctx *c, const char *name_a, int tl_a, int n_a, const char *name_b, int tl_b, int n_b,
                         const char *mask_name, double *result) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   double *pa, *pb, *mk = nullptr; long long cnt;
   if (resolve(c, name_a, tl_a, n_a, &pa, &cnt)) { c->err = std::string("unknown field ") + name_a; return 1; }
   if (resolve(c, name_b, tl_b, n_b, &pb, &cnt)) { c->err = std::string("unknown field ") + name_b; return 1; }
@@ -2071,6 +2105,7 @@ int pop_timer_ms(pop_ctx *c, const char *name, double *ms, int *calls) {
 }
 int pop_device_sync(pop_ctx *c) {
   if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -2085,7 +2120,7 @@ int pop_time_phase(pop_ctx *c, const char *phase, int reps, double *avg_ms) {
   else if (p == "impvmixt") fn = phase_impvmixt_pred;
   else if (p == "state") fn = phase_state_new;
   else if (p == "momentum_rhs") fn = phase_momentum_rhs;
-  else if (p == "impvmixu") fn = phase_impvmixu;
+  else if (p == "impvmixu") fn = [](pop_ctx *x) { return phase_impvmixu(x); };
   else if (p == "correct") fn = phase_correct;
   else if (p == "add_btrop") fn = phase_add_btrop;
   else if (p == "hmix_tracer") fn = [](pop_ctx *x) { return phase_hmix_tracer(x); };
