@@ -560,6 +560,32 @@ def test_operators_are_bitwise_the_oracle(pkg, orclib_built):
     gpu.close(); orc.close()
 
 
+def test_entry_points_fail_loudly(pkg, tmp_path):
+    """Error convention of the C ABI (non-zero return + message, no partial work): bad operator arguments, unknown
+    fields, a missing or truncated restart file."""
+    m = pkg.PopModel(named_config("tiny"))
+    with pytest.raises(pkg.PopError, match="op 0 grad"):
+        m.operator("grad", 0, "PSURF")
+    with pytest.raises(pkg.PopError, match="unknown field"):
+        m.operator("div", 1, "NOPE", "VBTROP")
+    with pytest.raises(pkg.PopError, match="unknown 2-D field"):
+        m.solver_preconditioner("UVEL", "DH")                    # 3-D field where a 2-D one is required
+    with pytest.raises(pkg.PopError, match="cannot open"):
+        m.read_restart(str(tmp_path / "missing.bin"))
+    m.step()
+    path = str(tmp_path / "r.bin")
+    m.write_restart(path)
+    with open(path, "r+b") as f:
+        f.truncate(1000)
+    with pytest.raises(pkg.PopError, match="short read"):
+        m.read_restart(path)
+    hdr = open(path + ".hdr").read().replace("&SALT_OLD", "&SALT_GONE")
+    open(path + ".hdr", "w").write(hdr)
+    with pytest.raises(pkg.PopError, match="could not find field in binary header file: SALT_OLD"):
+        m.read_restart(path)
+    m.close()
+
+
 @pytest.mark.parametrize("solver", [1, 2, 3])
 def test_solver_error_convention(pkg, orclib_built, solver):
     """POP_SolversMod.F90:1492-1497: hitting maxIterations is an error (errorCode set, message) unless
