@@ -101,8 +101,8 @@ k_kpp_buoydiff(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
 // pressure-independent second term of the denominator (mwjf_prep2) of the top KR levels sit in registers
 // (KR >= max kref, checked by the host), every field is read once, and only the pressure-dependent
 // polynomials are re-evaluated.  Same operations in the same order as k_kpp_buoydiff.
-template <int KR>
-__global__ void __launch_bounds__(POP_COL_THREADS)
+template <int KR, int WAVES>
+__global__ void __launch_bounds__(POP_COL_THREADS, WAVES)
 k_kpp_buoydiff_col(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
                    double *__restrict__ DBLOC, double *__restrict__ DBSFC) {
   Col c;
@@ -713,8 +713,13 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
   else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
   if (KH.side) hipEventRecord(KH.ev_join, KH.side);
-  if ((g_kpp_col & 2) && KH.max_kref <= 20) hipLaunchKernelGGL(k_kpp_buoydiff_col<20>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
-  else if (g_kpp_col & 2) hipLaunchKernelGGL(k_kpp_buoydiff_col<24>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  // two waves per SIMD (<= 256 VGPRs, ~80 spilled) beat one wave with everything in registers: the kernel is VALU-bound
+  // and a second wave fills the division / dependency stalls of the first (POP_KPP_BUOY_WAVES=1 keeps one wave)
+  static const int bw = getenv("POP_KPP_BUOY_WAVES") ? atoi(getenv("POP_KPP_BUOY_WAVES")) : 2;
+  if ((g_kpp_col & 2) && KH.max_kref <= 20 && bw == 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<20, 2>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  else if ((g_kpp_col & 2) && KH.max_kref <= 20) hipLaunchKernelGGL((k_kpp_buoydiff_col<20, 1>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  else if ((g_kpp_col & 2) && bw == 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<24, 2>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  else if (g_kpp_col & 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<24, 1>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   static const bool int_reg = !getenv("POP_KPP_INTERIOR_GENERIC");
   if (int_reg && g.km == 60) hipLaunchKernelGGL(k_kpp_interior_reg<60>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
