@@ -14,8 +14,9 @@
 
 namespace pop {
 
+// the corrector form (MODE 1) needs ~260 VGPRs: capped at 256 it runs two waves per SIMD
 template <int KM, int MODE, bool PRE, bool POST>
-__global__ void __launch_bounds__(POP_COL_THREADS)
+__global__ void __launch_bounds__(POP_COL_THREADS, (MODE == 1) ? 2 : 1)
 k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
   Col c;
   if (!col_setup(g, c, true)) return;
@@ -95,8 +96,10 @@ k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
 // one velocity component per thread (blockIdx.z = 0: U, 1: V): the two solves share only the
 // elimination coefficients, which each thread recomputes, so the column fits two register arrays
 // and the launch has twice the waves
-template <int KM>
-__global__ void __launch_bounds__(POP_COL_THREADS)
+// WAVES = 2 caps the kernel at 256 VGPRs (38 - 64 spilled): faster on small, latency-bound grids (gx1v7: 0.111 -> 0.099 ms),
+// slower on bandwidth-bound ones (tx0.1v3: 6.5 -> 6.9 ms), so the launcher picks by grid size
+template <int KM, int WAVES>
+__global__ void __launch_bounds__(POP_COL_THREADS, WAVES)
 k_impvmixu_reg(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   Col c;
   if (!col_setup(g, c, true)) return;
@@ -167,8 +170,11 @@ inline void launch_impvmixt(const DevGrid &g, const StepParams &sp, const Impvmi
 inline void launch_impvmixu(const DevGrid &g, const StepParams &sp, const ImpvmixuArgs &a, dim3 G, hipStream_t st, bool allow_reg) {
   const dim3 B(POP_COL_THREADS);
   const dim3 G2(G.x, G.y, 2);
-  if (allow_reg && g.km == 60) hipLaunchKernelGGL(k_impvmixu_reg<60>, G2, B, 0, st, g, sp, a);
-  else if (allow_reg && g.km == 62) hipLaunchKernelGGL(k_impvmixu_reg<62>, G2, B, 0, st, g, sp, a);
+  const bool small = (long long)g.n2 * g.nblocks <= (1 << 19);
+  if (allow_reg && g.km == 60 && small) hipLaunchKernelGGL((k_impvmixu_reg<60, 2>), G2, B, 0, st, g, sp, a);
+  else if (allow_reg && g.km == 60) hipLaunchKernelGGL((k_impvmixu_reg<60, 1>), G2, B, 0, st, g, sp, a);
+  else if (allow_reg && g.km == 62 && small) hipLaunchKernelGGL((k_impvmixu_reg<62, 2>), G2, B, 0, st, g, sp, a);
+  else if (allow_reg && g.km == 62) hipLaunchKernelGGL((k_impvmixu_reg<62, 1>), G2, B, 0, st, g, sp, a);
   else hipLaunchKernelGGL(k_impvmixu_norm, G, B, 0, st, g, sp, a);
 }
 
