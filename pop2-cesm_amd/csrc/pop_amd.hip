@@ -55,7 +55,7 @@ struct pop_ctx {
   // coefficients (own output buffers d2t / d2u instead of the shared scratch; POP_DEL4_SIDE=0: in line, scratch reused)
   double *d2t[2] = {nullptr, nullptr}, *d2u[2] = {nullptr, nullptr};
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_d2t = nullptr, ev_d2u = nullptr, ev_vmixu = nullptr;
-  bool side_del4 = false, vmixu_pending = false;   // implicit vertical mixing of U,V in flight on the side stream
+  bool side_del4 = false, vmixu_pending = false, btrop_added = false;   // implicit vertical mixing of U,V in flight on the side stream
   double *HBLT = nullptr, *HMXL = nullptr;
   MixDev mix{};
   // solver
@@ -1525,8 +1525,8 @@ static int phase_correct(pop_ctx *c) {
   else launch_impvmixt<0, true, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t);
   return 0;
 }
-static int phase_add_btrop(pop_ctx *c) {
-  hipLaunchKernelGGL(k_add_barotropic, grid_3d(c), dim3(256), 0, c->stream, c->g, c->U[c->newt], c->V[c->newt], c->UB[c->newt], c->VB[c->newt]);
+static int phase_add_btrop(pop_ctx *c, hipStream_t st = nullptr) {
+  hipLaunchKernelGGL(k_add_barotropic, grid_3d(c), dim3(256), 0, st ? st : c->stream, c->g, c->U[c->newt], c->V[c->newt], c->UB[c->newt], c->VB[c->newt]);
   return 0;
 }
 
@@ -1660,6 +1660,15 @@ int pop_barotropic_driver(pop_ctx *c) {
 int pop_baroclinic_correct_adjust(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "CORRECT_ADJUST");
+  // the barotropic velocity is added to U, V(new) (step_mod.F90:572-600) on the side stream while the tracer corrector runs:
+  // same sum at every cell; the halo update of U, V in the step tail then carries it to the ghost cells
+  if (c->side && !getenv("POP_BTROP_INLINE")) {
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if (phase_add_btrop(c, c->side)) return 1;
+    HIPCHK(c, hipEventRecord(c->ev_vmixu, c->side));
+    c->vmixu_pending = true; c->btrop_added = true;
+  }
   if (phase_correct(c)) return 1;
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -1734,7 +1743,8 @@ int pop_step_tail(pop_ctx *c) {
   if (halo_update(c, c->UB[c->newt], 1) || halo_update(c, c->VB[c->newt], 1)) return 1;
   if (halo_update(c, c->U[c->newt], km) || halo_update(c, c->V[c->newt], km) || halo_update(c, c->RHO[c->newt], km)) return 1;
   for (int n = 0; n < c->h.nt; ++n) if (halo_update(c, c->TR[n][c->newt], km)) return 1;
-  if (phase_add_btrop(c)) return 1;
+  if (!c->btrop_added && phase_add_btrop(c)) return 1;
+  c->btrop_added = false;
   const long long a2 = (long long)c->g.n2 * c->g.nblocks;
   hipLaunchKernelGGL(k_pguess, dim3((a2 + 255) / 256), dim3(256), 0, c->stream, a2, c->PGUESS, c->PS[c->newt], c->PS[c->curt], c->PS[c->oldt]);
   if (c->avg_ts) {
@@ -2122,7 +2132,7 @@ int pop_time_phase(pop_ctx *c, const char *phase, int reps, double *avg_ms) {
   else if (p == "momentum_rhs") fn = phase_momentum_rhs;
   else if (p == "impvmixu") fn = [](pop_ctx *x) { return phase_impvmixu(x); };
   else if (p == "correct") fn = phase_correct;
-  else if (p == "add_btrop") fn = phase_add_btrop;
+  else if (p == "add_btrop") fn = [](pop_ctx *x) { return phase_add_btrop(x); };
   else if (p == "hmix_tracer") fn = [](pop_ctx *x) { return phase_hmix_tracer(x); };
   else if (p == "hmix_momentum") fn = [](pop_ctx *x) { return phase_hmix_momentum(x); };
   if (!fn) { c->err = "unknown phase " + p; return 1; }
