@@ -627,12 +627,13 @@ __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__
 // per-context KPP state (MixDev::kpp)
 // col: bit 0 = ushear, bit 1 = buoydiff in column form.  side / ev_*: second HIP stream on which the shear kernel (needs only
 // U, V; consumed by bldepth) runs beside buoydiff + interior (POP_KPP_SIDE_STREAM=0 keeps everything on one stream)
-struct KppHost { KppDev dev; int max_kref = 1; int col = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+struct KppHost { KppDev dev; int max_kref = 1; int col = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bd = nullptr; };
 inline void kpp_destroy(MixDev &m) {
   KppHost *k = (KppHost *)m.kpp;
   if (k) {
     if (k->ev_fork) hipEventDestroy(k->ev_fork);
     if (k->ev_join) hipEventDestroy(k->ev_join);
+    if (k->ev_bd) hipEventDestroy(k->ev_bd);
     if (k->side) hipStreamDestroy(k->side);
   }
   delete k; m.kpp = nullptr;
@@ -665,7 +666,8 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   if (!(getenv("POP_KPP_SIDE_STREAM") && atoi(getenv("POP_KPP_SIDE_STREAM")) == 0)) {
     if (hipStreamCreateWithFlags(&K->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&K->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&K->ev_join, hipEventDisableTiming) != hipSuccess) { err = "kpp: side stream"; return 1; }
+        hipEventCreateWithFlags(&K->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&K->ev_bd, hipEventDisableTiming) != hipSuccess) { err = "kpp: side stream"; return 1; }
   }
   KppDev &k = K->dev;
   void *p;
@@ -712,7 +714,6 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   if (KH.side) { hipEventRecord(KH.ev_fork, st); hipStreamWaitEvent(KH.side, KH.ev_fork, 0); }
   if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
   else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
-  if (KH.side) hipEventRecord(KH.ev_join, KH.side);
   // two waves per SIMD (<= 256 VGPRs, ~80 spilled) beat one wave with everything in registers: the kernel is VALU-bound
   // and a second wave fills the division / dependency stalls of the first (POP_KPP_BUOY_WAVES=1 keeps one wave)
   static const int bw = getenv("POP_KPP_BUOY_WAVES") ? atoi(getenv("POP_KPP_BUOY_WAVES")) : 2;
@@ -721,13 +722,21 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   else if ((g_kpp_col & 2) && bw == 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<24, 2>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if (g_kpp_col & 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<24, 1>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  // the boundary-layer depth (needs buoydiff + shear, writes only the 2-D boundary-layer fields) follows the shear kernel
+  // on the side stream and runs beside the interior coefficients; blmix waits for both
+  if (KH.side) {
+    hipEventRecord(KH.ev_bd, st); hipStreamWaitEvent(KH.side, KH.ev_bd, 0);
+    hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                       (const double *)DBSFC, (const double *)WU);
+    hipEventRecord(KH.ev_join, KH.side);
+  }
   static const bool int_reg = !getenv("POP_KPP_INTERIOR_GENERIC");
   if (int_reg && g.km == 60) hipLaunchKernelGGL(k_kpp_interior_reg<60>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else if (int_reg && g.km == 62) hipLaunchKernelGGL(k_kpp_interior_reg<62>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
   if (KH.side) hipStreamWaitEvent(st, KH.ev_join, 0);
-  hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
-                     (const double *)DBSFC, (const double *)WU);
+  else hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                          (const double *)DBSFC, (const double *)WU);
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                      s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
   hipLaunchKernelGGL(k_kpp_vvc, dim3((g.n2 + 255) / 256, (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(256), 0, st, g, (const double *)VISC, s.VVC);
