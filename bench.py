@@ -7,7 +7,8 @@
 A "step" is one full model time step (step_mod.F90 `step`: dhdt -> baroclinic_driver ->
 barotropic_driver -> baroclinic_correct_adjust -> halo updates / time-level update) on synthetic
 bathymetry and forcing, all state resident in HBM before the timed region.  The headline value is
-simulated years per day (SYPD = 86400 / (t_step * steps_per_day * 365)); ms_per_step
+simulated years per day (SYPD = 86400 / (t_step * step_calls_per_day * 365); step_calls_per_day = steps_per_day
+plus the averaging half-steps of time_mix_opt = 'avgfit': 319 for tx0.1v3, not 300); ms_per_step
 is the step wall time.  N > 1 shards the SAME global domain by blocks (strong scaling) with halo
 exchange and the solver's block-sum all-reduce on RCCL (torch.distributed backend "nccl").
 
@@ -246,7 +247,9 @@ def main():
         # default: the library's own RCCL transport (stream-ordered ncclSend/Recv/AllReduce, no host call per
         # message); POP_BENCH_TRANSPORT=torch keeps the torch.distributed callbacks.  A failed self-test on
         # any rank makes every rank fall back to the callbacks.
-        want_native = backend == "nccl" and os.environ.get("POP_BENCH_TRANSPORT", "rccl") == "rccl"
+        # (POP_BENCH_BACKEND=gloo + POP_RCCL_LIB=tests/rccl_stub/librccl_stub.so rehearses this branch with several
+        # ranks on a one-GPU box: torch's own process group is then gloo, the library binds the stand-in.)
+        want_native = (backend == "nccl" or os.environ.get("POP_RCCL_LIB")) and os.environ.get("POP_BENCH_TRANSPORT", "rccl") == "rccl"
         ok = 0
         if want_native:
             box = [None]
@@ -263,7 +266,7 @@ def main():
                     ok = 1
                 except pkg.PopError as e:
                     print("rank %d: rccl transport failed its self-test: %s" % (rank, e), file=sys.stderr)
-            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = int(t.item())
         if ok:
@@ -294,7 +297,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_step = 1e3 * elapsed / args.steps
-    sypd = 86400.0 / ((elapsed / args.steps) * cfg.steps_per_day * 365.0)
+    # step calls per model day: with time_mix_opt = 'avgfit' a day is `full` leapfrog steps plus `half` averaging
+    # half-steps (time_management.F90:820-860; tx0.1v3: 300 + 19 = 319 calls), every one a full pass of the hot path
+    calls_per_day = model.dim("nsteps_per_interval")
+    sypd = 86400.0 / ((elapsed / args.steps) * calls_per_day * 365.0)
 
     # ---- roofline: every 3-D phase kernel timed with HIP events on its launch stream
     vm = cfg.vmix_choice - 1
@@ -331,7 +337,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "grid": [cfg.nx_global, cfg.ny_global, cfg.km], "nt": cfg.nt,
-                   "block_size": [cfg.block_size_x, cfg.block_size_y], "steps_per_day": cfg.steps_per_day,
+                   "block_size": [cfg.block_size_x, cfg.block_size_y], "steps_per_day": cfg.steps_per_day, "step_calls_per_day": calls_per_day,
                    "hmix": "del%d" % cfg.hmix_momentum, "vmix": ["const", "rich", "kpp"][vm],
                    "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport},
@@ -341,7 +347,7 @@ def main():
         dt, n, scfg, scale, cores = cpu_baseline(cfg)
         what = "%d concurrent %dx%dx%d sub-domains of %s, one per core (same options; together %.4f of the columns, " \
                "step time scaled by that ratio)" % (cores, scfg.nx_global, scfg.ny_global, scfg.km, args.workload, scale)
-        out["cpu_baseline"] = {"value": round(86400.0 / (dt * cfg.steps_per_day * 365.0), 5), "unit": "SYPD",
+        out["cpu_baseline"] = {"value": round(86400.0 / (dt * calls_per_day * 365.0), 5), "unit": "SYPD",
                                "ms_per_step": round(dt * 1e3, 2), "cores": cores, "kind": "port",
                                "sample": "%d leapfrog steps of %s; scalar C oracle (restated reference algorithm, "
                                          "not the upstream binary), no inter-domain messages" % (n, what)}

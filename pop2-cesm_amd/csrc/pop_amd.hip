@@ -177,6 +177,8 @@ struct ScopedPhase {   // optional HIP-event timing of a phase on the launch str
 // halo update of a device-resident field with nz levels (mpi/POP_HaloMod.F90:1732-2071 2-D,
 // :2766-3211 3-D): local ghost copies + fills in one launch, then one packed message per peer
 // ---------------------------------------------------------------------------------------------
+// what the transport said about a failed exchange / all-reduce
+std::string tr_err(const pop_ctx *c) { return c->rccl_tr ? ": " + c->rccl_tr->err : std::string(" in the host callback"); }
 // remote part only: one pack launch, the exchange, one unpack launch
 int halo_remote(pop_ctx *c, double *F, int nz) {
   if (c->peers.empty()) return 0;
@@ -191,7 +193,7 @@ int halo_remote(pop_ctx *c, double *F, int nz) {
   if (so > c->comm_doubles || ro > c->comm_doubles) { c->err = "halo_update: comm buffer too small"; return 1; }
   if (c->nsend_all) hipLaunchKernelGGL(k_halo_pack_all, dim3((c->nsend_all + 255) / 256, nz), dim3(256), 0, c->stream, (const double *)F, c->sa_src, c->sa_start, c->sa_cnt, c->nsend_all, c->sendbuf, nz, n2);
   if (c->xchg(c->comm_user, (int)peer.size(), peer.data(), soff.data(), scnt.data(), roff.data(), rcnt.data())) {
-    c->err = "halo_update: exchange failed" + (c->rccl_tr ? ": " + c->rccl_tr->err : std::string(" in the host callback")); return 1;
+    c->err = "halo_update: exchange failed" + tr_err(c); return 1;
   }
   if (c->nrecv_all) hipLaunchKernelGGL(k_halo_unpack_all, dim3((c->nrecv_all + 255) / 256, nz), dim3(256), 0, c->stream, F, c->ra_dst, c->ra_start, c->ra_cnt, c->nrecv_all, (const double *)c->recvbuf, nz, n2);
   return 0;
@@ -221,7 +223,7 @@ int reduce_finish(pop_ctx *c, int mode) {
     bs = c->redbuf;
     hipLaunchKernelGGL(k_block_sums_global<NF>, dim3(c->h.nblocks_tot), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->loc_of_gid, bs);
   } else hipLaunchKernelGGL(k_block_sums<NF>, dim3(c->g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, c->partial, c->nchunk, c->gid, bs);
-  if (c->h.nranks > 1 && c->allred(c->comm_user, 0, (long long)NF * c->h.nblocks_tot)) { c->err = "global sum: allreduce callback failed"; return 1; }
+  if (c->h.nranks > 1 && c->allred(c->comm_user, 0, (long long)NF * c->h.nblocks_tot)) { c->err = "global sum: allreduce callback failed" + tr_err(c); return 1; }
   hipLaunchKernelGGL(k_finalize<NF>, dim3(1), dim3(1), 0, c->stream, bs, c->h.nblocks_tot, c->sc, mode);
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -471,7 +473,7 @@ int solver_pcg_fused_dist(pop_ctx *c) {
   };
   auto allsum = [&](const double *partial, long long off) -> int {   // ordered block sums of every rank -> all ranks
     hipLaunchKernelGGL(k_block_sums_global<1>, dim3(nbt), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->loc_of_gid, c->redbuf + off);
-    if (c->allred(c->comm_user, off, nbt)) { c->err = "distributed pcg: allreduce failed"; return 1; }
+    if (c->allred(c->comm_user, off, nbt)) { c->err = "distributed pcg: allreduce failed" + tr_err(c); return 1; }
     return 0;
   };
   SolverScalars init{}; init.eta0 = 1.0;
@@ -525,7 +527,7 @@ int solver_pcg_replicated(pop_ctx *c) {
     HIPCHK(c, hipMemcpyAsync(c->redbuf + go, c->RHS + lb * n2, n2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->redbuf + NG + go, PN + lb * n2, n2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   }
-  if (c->allred(c->comm_user, 0, (long long)(2 * NG))) { c->err = "replicated solve: allreduce callback failed"; return 1; }
+  if (c->allred(c->comm_user, 0, (long long)(2 * NG))) { c->err = "replicated solve: allreduce callback failed" + tr_err(c); return 1; }
   HIPCHK(c, hipMemcpyAsync(v.RHS, c->redbuf, NG * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(v.X, c->redbuf + NG, NG * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(k_center_all, dim3((unsigned)((NG + 255) / 256)), dim3(256), 0, c->stream, v.g, step_params(c), c->gTAREA, c->gKMT, v.C, (long long)NG);
@@ -839,7 +841,7 @@ int solver_pcsi_fused_dist(pop_ctx *c) {
     in = 1 - in;
     if (check) {
       hipLaunchKernelGGL(k_block_sums_global<1>, dim3(nbt), dim3(POP_RED_THREADS), 0, c->stream, (const double *)c->partial, c->nchunk, c->loc_of_gid, c->redbuf);
-      if (c->allred(c->comm_user, 0, nbt)) { c->err = "distributed P-CSI: allreduce failed"; return 1; }
+      if (c->allred(c->comm_user, 0, nbt)) { c->err = "distributed P-CSI: allreduce failed" + tr_err(c); return 1; }
       hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, c->redbuf, nbt, c->sc, (int)FIN_RR);
       SolverScalars s;
       if (read_scalars(c, &s)) return 1;
@@ -1865,7 +1867,7 @@ static int gather_slots(pop_ctx *c, const double *local, int nv, std::vector<dou
   if (!c->allred || !c->redbuf || c->red_doubles < (long long)nv * nr) { c->err = "global reduction: multi-rank run without a transport"; return 1; }
   std::copy(local, local + nv, all.begin() + (size_t)nv * c->h.rank);
   HIPCHK(c, hipMemcpyAsync(c->redbuf, all.data(), sizeof(double) * all.size(), hipMemcpyHostToDevice, c->stream));
-  if (c->allred(c->comm_user, 0, (long long)all.size())) { c->err = "global reduction: allreduce failed"; return 1; }
+  if (c->allred(c->comm_user, 0, (long long)all.size())) { c->err = "global reduction: allreduce failed" + tr_err(c); return 1; }
   HIPCHK(c, hipMemcpyAsync(all.data(), c->redbuf, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -1959,7 +1961,7 @@ int pop_global_sum_scalar(pop_ctx *c, double local, double *result) {
   std::vector<double> v(nr, 0.0);
   v[c->h.rank] = local;
   HIPCHK(c, hipMemcpyAsync(c->redbuf, v.data(), sizeof(double) * nr, hipMemcpyHostToDevice, c->stream));
-  if (c->allred(c->comm_user, 0, nr)) { c->err = "pop_global_sum_scalar: allreduce failed"; return 1; }
+  if (c->allred(c->comm_user, 0, nr)) { c->err = "pop_global_sum_scalar: allreduce failed" + tr_err(c); return 1; }
   HIPCHK(c, hipMemcpyAsync(v.data(), c->redbuf, sizeof(double) * nr, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   double t = 0.0;

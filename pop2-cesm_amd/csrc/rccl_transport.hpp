@@ -9,6 +9,7 @@
 // (pop_rccl_unique_id -> pop_comm_init_rccl on every rank); INTEGRATION.md shows the Fortran call.
 #pragma once
 #include <dlfcn.h>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <string>
 
@@ -33,9 +34,17 @@ struct RcclApi {
 
   int load(std::string &err) {
     if (handle) return 0;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) { handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (handle) break; }
-    if (!handle) { err = std::string("rccl transport: cannot open librccl: ") + dlerror(); return 1; }
+    // POP_RCCL_LIB names the library to bind instead of the system librccl (tests: tests/rccl_stub, which lets
+    // several ranks share one GPU; a site build of RCCL).  An override that cannot be opened is an error.
+    const char *over = getenv("POP_RCCL_LIB");
+    if (over && *over) {
+      handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+      if (!handle) { err = std::string("rccl transport: cannot open POP_RCCL_LIB=") + over + ": " + dlerror(); return 1; }
+    } else {
+      const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+      for (const char *n : names) { handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (handle) break; }
+      if (!handle) { err = std::string("rccl transport: cannot open librccl: ") + dlerror(); return 1; }
+    }
     auto sym = [&](const char *n) { void *p = dlsym(handle, n); if (!p) err = std::string("rccl transport: missing symbol ") + n; return p; };
     GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
     CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");

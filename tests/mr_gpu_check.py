@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--config", default="tiny")
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--kw", default="")
+    ap.add_argument("--transport", default="staged", choices=["staged", "native"],
+                    help="staged: callback transport over gloo; native: the library's own RCCL binding "
+                         "(POP_RCCL_LIB = tests/rccl_stub/librccl_stub.so lets several ranks share one GPU)")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
@@ -36,8 +39,19 @@ def main():
     pkg = ge.load_package()
     kw = eval("dict(%s)" % args.kw)
     cfg = named_config(args.config, **kw)
+    keep = []
+
+    def attach(model):
+        """install the transport under test on a multi-rank model"""
+        if args.transport == "native":
+            box = [pkg.PopModel.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            model.comm_init_rccl(box[0])
+        else:
+            keep.append(bench.TorchComm(pkg, model, rank, world, staged=True))
+
     m = pkg.PopModel(cfg, rank=rank, nranks=world)
-    comm = bench.TorchComm(pkg, m, rank, world, staged=True)   # noqa: F841
+    attach(m)
     m.comm_selftest()                                          # all-reduce of known values + a self message
     ref = pkg.PopModel(cfg) if True else None                  # every rank keeps a single-rank twin
     ids = m.local_block_ids()
@@ -62,7 +76,7 @@ def main():
     m.write_restart(path)
     dist.barrier()
     m2 = pkg.PopModel(cfg, rank=rank, nranks=world)
-    comm2 = bench.TorchComm(pkg, m2, rank, world, staged=True)   # noqa: F841
+    attach(m2)
     m2.read_restart(path)
     ref2 = pkg.PopModel(cfg); ref2.read_restart(path)
     for s in range(2):
@@ -79,7 +93,7 @@ def main():
     m2.close(); ref2.close()
     t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print("MR_GPU_CHECK", "OK" if int(t.item()) == 1 else "FAILED", "world", world, "config", args.config, args.kw)
+        print("MR_GPU_CHECK", "OK" if int(t.item()) == 1 else "FAILED", "world", world, "config", args.config, args.kw, "transport", args.transport)
     m.close(); ref.close()
     dist.destroy_process_group()
     sys.exit(0 if int(t.item()) == 1 else 1)

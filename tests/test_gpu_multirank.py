@@ -2,7 +2,6 @@
 paths of libpop_amd (peer halo messages, block-sum all-reduce, replicated barotropic solve) must
 reproduce the single-rank run bit for bit.  See tests/mr_gpu_check.py."""
 import os
-import socket
 import subprocess
 import sys
 
@@ -12,21 +11,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+STUB = os.path.join(ROOT, "tests", "rccl_stub", "librccl_stub.so")
+_RDZV_ERRORS = ("address already in use", "EADDRINUSE", "RendezvousConnectionError", "RendezvousTimeoutError", "DistNetworkError",
+                "failed to bind", "The server socket has failed")
 
 
-def _run_check(args, timeout, env=None):
-    """Launch tests/mr_gpu_check.py under torch.distributed.run.  The harness prints 'MR_GPU_CHECK OK|FAILED' when it
-    ran to the end; if neither appears (rendezvous / port trouble -- the free port is chosen before torchrun binds it)
-    the launch is repeated once on another port.  A FAILED verdict is never retried."""
+def _run_check(args, timeout, env=None, transport="staged"):
+    """Launch tests/mr_gpu_check.py under torch.distributed.run.  torchrun itself binds a free rendezvous port
+    (--standalone), so there is no window between choosing and binding it.  The launch is repeated ONCE, and only
+    when there is no verdict AND stderr names a rendezvous / bind error; a run that ends without a verdict for any
+    other reason (a rank that aborted or faulted) fails with its output, and a FAILED verdict is never retried."""
+    env = dict(os.environ, **(env or {}))
+    if transport == "native":
+        if not os.path.exists(STUB):
+            subprocess.check_call(["make", "-s", "-C", os.path.dirname(STUB)])
+        env["POP_RCCL_LIB"] = STUB
+        args = args + ["--transport", "native"]
     out = None
-    for _ in range(2):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--master-addr", "127.0.0.1", "--master-port", str(_port())] + args
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
-        if "MR_GPU_CHECK" in out.stdout:
+    for attempt in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1"] + args
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        if "MR_GPU_CHECK" in out.stdout or not any(e in out.stderr for e in _RDZV_ERRORS):
             break
-    assert "MR_GPU_CHECK OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "MR_GPU_CHECK OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_gx1v7_two_ranks_equal_single_rank():
@@ -61,3 +68,27 @@ def test_large_grid_two_ranks_equal_single_rank():
 def test_multirank_equals_single_rank(nranks, kw, env):
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
                 "--kw", kw], 300, env)
+
+
+# ---- the library's own RCCL binding (rccl_transport.hpp: ncclSend/ncclRecv groups + ncclAllReduce on the launch
+# stream) with several ranks on the one GPU, through the stand-in librccl of tests/rccl_stub (POP_RCCL_LIB)
+@pytest.mark.parametrize("nranks,kw,env", [
+    (2, "", {}),                                                      # fused distributed pcg
+    (2, "block_size_x=48,block_size_y=20", {}),                       # replicated barotropic solve (one all-reduce gathers RHS + guess)
+    (4, "block_size_x=24,block_size_y=20", {"POP_SOLVER_DISTRIBUTED": "1"}),   # one block per rank: E-W, N-S and corner peers
+    (2, "solver_choice=2", {}),                                       # ChronGear
+    (4, "solver_choice=3,block_size_x=24,block_size_y=20", {}),       # P-CSI
+    (3, "block_size_x=24,block_size_y=20,vmix_choice=3,km=24", {}),   # uneven ownership, KPP
+    (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3
+])
+def test_native_transport_equals_single_rank(nranks, kw, env):
+    _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
+                "--kw", kw], 300, env, transport="native")
+
+
+def test_native_transport_large_grid_two_ranks():
+    """quarter-size tx0.1v3 in two j-bands over the native transport: the large-grid kernel selection with the
+    distributed solver (3-D halo messages of 62 levels through ncclSend/ncclRecv groups)"""
+    _run_check(["--nproc-per-node", "2", os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tx0.1v3", "--steps", "2",
+                "--kw", "nx_global=1800,ny_global=1200,block_size_x=1800,block_size_y=600"], 900,
+               {"POP_RCCL_STUB_BOX_MB": "16", "POP_SOLVER_DISTRIBUTED": "1"}, transport="native")
