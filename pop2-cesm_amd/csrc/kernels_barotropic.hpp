@@ -334,6 +334,17 @@ k_rr_total(const double *__restrict__ partial, int nchunk, int nblocks, SolverSc
   }
 }
 
+// the same check for blocks spread over ranks: the all-reduced block-sum vector added in block-id order
+__global__ void k_rr_blocks(const double *__restrict__ blocksum, int nblocks_tot, SolverScalars *s, double *host_ring, double criterion) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || s->stop) return;
+  double total = 0.0;
+  for (int b = 0; b < nblocks_tot; ++b) total = total + blocksum[b];
+  s->sum0 = total; s->rr = total;
+  host_ring[s->icnt & 7] = total;
+  s->icnt = s->icnt + 1;
+  if (total < criterion) s->stop = 1;
+}
+
 // generic masked product sum over the physical domain: partial of a*b*mask (b, mask optional)
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_dot_partial(DevGrid g, const double *__restrict__ A, const double *__restrict__ Bv, const double *__restrict__ M,
@@ -582,6 +593,45 @@ __global__ void k_halo_unpack_all(double *__restrict__ F, const int *__restrict_
   F[((long long)(d / n2) * nz + k) * n2 + d % n2] = buf[(long long)st * nz + (long long)k * m + (t - st)];
 }
 
+// Several fields in ONE halo update (the seven updates that end a step, step_mod.F90:467-560, travel as one message
+// per neighbour).  blockIdx.y = level within the concatenation of the fields' levels; the message of a peer is
+// [field][level][cell], i.e. level-major over the concatenation.
+struct HaloFields { double *F[8]; int nz[8], lev0[8]; int nf, nztot; };
+__device__ __forceinline__ int halo_field_of(const HaloFields &H, int kk) {
+  int f = 0;
+  while (f + 1 < H.nf && kk >= H.lev0[f + 1]) ++f;
+  return f;
+}
+__global__ void k_halo_pack_many(HaloFields H, const int *__restrict__ src, const int *__restrict__ start, const int *__restrict__ cnt,
+                                 int n, double *__restrict__ buf, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, kk = blockIdx.y;
+  if (t >= n) return;
+  const int f = halo_field_of(H, kk), k = kk - H.lev0[f], nz = H.nz[f];
+  const int s = src[t], st = start[t], m = cnt[t];
+  buf[(long long)st * H.nztot + (long long)kk * m + (t - st)] = H.F[f][((long long)(s / n2) * nz + k) * n2 + s % n2];
+}
+__global__ void k_halo_unpack_many(HaloFields H, const int *__restrict__ dst, const int *__restrict__ start, const int *__restrict__ cnt,
+                                   int n, const double *__restrict__ buf, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, kk = blockIdx.y;
+  if (t >= n) return;
+  const int f = halo_field_of(H, kk), k = kk - H.lev0[f], nz = H.nz[f];
+  const int d = dst[t], st = start[t], m = cnt[t];
+  H.F[f][((long long)(d / n2) * nz + k) * n2 + d % n2] = buf[(long long)st * H.nztot + (long long)kk * m + (t - st)];
+}
+__global__ void k_halo_local_many(HaloFields H, const int *__restrict__ dst, const int *__restrict__ src, int ncopy,
+                                  const int *__restrict__ filld, int nfill, double fill, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, kk = blockIdx.y;
+  const int f = halo_field_of(H, kk), k = kk - H.lev0[f], nz = H.nz[f];
+  double *F = H.F[f];
+  if (t < ncopy) {
+    const int d = dst[t], s = src[t];
+    F[((long long)(d / n2) * nz + k) * n2 + d % n2] = F[((long long)(s / n2) * nz + k) * n2 + s % n2];
+  } else if (t < ncopy + nfill) {
+    const int d = filld[t - ncopy];
+    F[((long long)(d / n2) * nz + k) * n2 + d % n2] = fill;
+  }
+}
+
 }  // namespace pop
 
 // =============================================================================================
@@ -609,7 +659,29 @@ struct FusedArgs {
   // solver kernels (bsA/bsB) instead of being recomputed by every workgroup (O(#workgroups^2) reads)
   const double *bsA, *bsB;
   int presummed;
+  // blocks spread over ranks: the one halo exchange per iteration (z) is packed by the kernel that produces z and
+  // read in place from the receive buffer by the kernel that consumes it -- no pack / unpack launches.
+  //   sendmap[q] >= 0: cell q is entry e of (send_off, send_slot): its value goes to sendbuf[send_slot[send_off[e] .. send_off[e+1])]
+  //   rmap[q]    >= 0: ghost cell q is owned by another rank; its value is rbuf[rmap[q]] (message order of the peer lists)
+  const int *sendmap, *send_off, *send_slot;
+  double *sendbuf;
+  const int *rmap;
+  const double *rbuf;
 };
+// cells within NGHOST of the edge of the physical domain: the only ones a neighbour block's ghosts can copy
+__device__ __forceinline__ bool send_band(const DevGrid &g, int i, int j) {
+  return i + 1 < g.ib + NGHOST || i + 1 > g.ie - NGHOST || j + 1 < g.jb + NGHOST || j + 1 > g.je - NGHOST;
+}
+__device__ __forceinline__ void pack_cell(const FusedArgs &a, long long q, double val) {
+  const int e = a.sendmap[q];
+  if (e < 0) return;
+  for (int n = a.send_off[e]; n < a.send_off[e + 1]; ++n) a.sendbuf[a.send_slot[n]] = val;
+}
+// value of z at stencil source cell m (>= 0): from the receive buffer when m is a ghost owned by another rank
+__device__ __forceinline__ double z_at(const FusedArgs &a, int m) {
+  if (a.rmap) { const int rs = a.rmap[m]; if (rs >= 0) return a.rbuf[rs]; }
+  return a.Z[m];
+}
 
 // ordered total of workgroup partials: per POP block a thread-strided sequential sum + fixed tree,
 // block sums added in block order.  Every thread returns the same value.
@@ -666,7 +738,10 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
     }
     const double z = (cw != 0.0) ? r / cw : 0.0;
     a.Z[q] = z;
-    if (interior(g, i, j)) v[0] = (r * z) * mk;
+    if (interior(g, i, j)) {
+      v[0] = (r * z) * mk;
+      if (a.sendmap && send_band(g, i, j)) pack_cell(a, q, z);
+    }
   }
   wg_reduce_store<1>(v, a.partA, b * gridDim.x + red_chunk(g));
 }
@@ -687,7 +762,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
   // gather operands first (independent loads in flight while the total is formed)
   const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
   double zv[9], sv[9], wv[9];
-  zv[0] = a.Z[q]; sv[0] = a.S0[q];
+  zv[0] = (inner || !live) ? a.Z[q] : z_at(a, (int)q); sv[0] = a.S0[q];
 #pragma unroll
   for (int t = 1; t < 9; ++t) { zv[t] = 0.0; sv[t] = 0.0; }
   if (inner) {
@@ -698,7 +773,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
 #pragma unroll
       for (int t = 1; t < 9; ++t) {
         const int m = a.srcmap[q + off[t]];
-        if (m >= 0) { zv[t] = a.Z[m]; sv[t] = a.S0[m]; }
+        if (m >= 0) { zv[t] = z_at(a, m); sv[t] = a.S0[m]; }
       }
     }
     wv[0] = a.C[q]; wv[1] = g.WNo[q]; wv[2] = g.WNo[q - nxb]; wv[3] = g.WEa[q]; wv[4] = g.WEa[q - 1];
@@ -751,6 +826,11 @@ __device__ __forceinline__ void fused_total2(const double *__restrict__ partial,
     __syncthreads();
   }
 }
+// z = r*A0R at stencil source cell m; a ghost owned by another rank has its owner's z in the receive buffer
+__device__ __forceinline__ double cg_z_at(const FusedArgs &a, int m) {
+  if (a.rmap) { const int rs = a.rmap[m]; if (rs >= 0) return a.rbuf[rs]; }
+  return a.R[m] * a.A0R[m];
+}
 // step A (:2117-2157): z = r*A0R at the nine stencil points (ghost neighbours at their source cell, which is what
 // the halo update of z delivers), az = A z, partial (r,z), (az,z)
 __global__ void __launch_bounds__(POP_RED_THREADS)
@@ -776,7 +856,7 @@ k_fcg_a(DevGrid g, FusedArgs a) {
 #pragma unroll
       for (int t = 1; t < 9; ++t) {
         const int m = a.srcmap[q + off[t]];
-        zv[t] = (m >= 0) ? a.R[m] * a.A0R[m] : 0.0;
+        zv[t] = (m >= 0) ? cg_z_at(a, m) : 0.0;
       }
     }
     wv[0] = a.C[q]; wv[1] = g.WNo[q]; wv[2] = g.WNo[q - nxb]; wv[3] = g.WEa[q]; wv[4] = g.WEa[q - 1];
@@ -845,7 +925,7 @@ k_fcg_a2(DevGrid g, FusedArgs a) {
 #pragma unroll
       for (int n = 1; n < 9; ++n) {
         const int m = a.srcmap[qq + off[n]];
-        az = az + wv[n] * ((m >= 0) ? a.R[m] * a.A0R[m] : 0.0);
+        az = az + wv[n] * ((m >= 0) ? cg_z_at(a, m) : 0.0);
       }
       a.Z[qq] = z0; a.AZ[qq] = az;
       const double mk = (double)g.mMask8[qq];
@@ -891,7 +971,19 @@ k_fcg_b(DevGrid g, FusedArgs a, int par) {
     qq = az + bt * qq;
     a.S0[q] = s; a.Q[q] = qq;
     a.X[q] = x + al * s;
-    a.R[q] = r - al * qq;
+    const double rn = r - al * qq;
+    a.R[q] = rn;
+    if (a.sendmap && send_band(g, i, j)) pack_cell(a, q, rn * a.A0R[q]);   // next iteration's z for the neighbours' ghosts
+  } else if (live && a.rmap) {
+    // ghost owned by another rank: its z of this iteration is in the receive buffer; the search direction and the
+    // solution there are advanced with the owner's arithmetic (needed by r = b - A x at the checks and as the ghost
+    // values of the solution), so they never travel
+    const int rs = a.rmap[q];
+    if (rs >= 0) {
+      const double sg = a.rbuf[rs] + bt * a.S0[q];
+      a.S0[q] = sg;
+      a.X[q] = a.X[q] + al * sg;
+    }
   }
 }
 
@@ -956,15 +1048,16 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
       if (!(e == 0 ? live0 : live1)) continue;
       const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
-      const double s = a.Z[qq] + a.S0[qq] * bt;
+      const bool in_e = interior(g, ii, jj);
+      const double s = (in_e ? a.Z[qq] : z_at(a, (int)qq)) + a.S0[qq] * bt;
       double aq = 0.0, vv = 0.0;
-      if (interior(g, ii, jj)) {
+      if (in_e) {
         const double wv[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};
         aq = wv[0] * s;
 #pragma unroll
         for (int n = 1; n < 9; ++n) {
           const int m = a.srcmap[qq + off[n]];
-          const double sn = (m >= 0) ? a.Z[m] + a.S0[m] * bt : 0.0 + 0.0 * bt;
+          const double sn = (m >= 0) ? z_at(a, m) + a.S0[m] * bt : 0.0 + 0.0 * bt;
           aq = aq + wv[n] * sn;
         }
         vv = (aq * s) * (double)g.mMask8[qq];
@@ -1016,6 +1109,8 @@ k_fresidual(DevGrid g, FusedArgs a) {
       const double r = a.Bv[q] - ax;
       a.R[q] = r;
       if (WITH_RR) v[0] = (r * r) * (double)g.mMask8[q];
+      // distributed ChronGear: the z = r*A0R the next iteration's neighbours need travels from here
+      if (a.sendmap && a.A0R && send_band(g, i, j)) pack_cell(a, q, r * a.A0R[q]);
     }
   }
   if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * gridDim.x + red_chunk(g));
@@ -1058,6 +1153,10 @@ k_fresidual2(DevGrid g, FusedArgs a) {
     const double rA = bv.x - axA, rB = bv.y - axB;
     *reinterpret_cast<double2 *>(a.R + q) = make_double2(rA, rB);
     if (WITH_RR) { v0 = (rA * rA) * (double)g.mMask8[q]; v1 = (rB * rB) * (double)g.mMask8[q + 1]; }
+    if (a.sendmap && a.A0R) {   // the second ring of the send band lies inside the fast region
+      if (send_band(g, i, j)) pack_cell(a, q, rA * a.A0R[q]);
+      if (send_band(g, i + 1, j)) pack_cell(a, q + 1, rB * a.A0R[q + 1]);
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -1071,6 +1170,7 @@ k_fresidual2(DevGrid g, FusedArgs a) {
       const double r = a.Bv[qq] - ax;
       a.R[qq] = r;
       if (WITH_RR) { const double vv = (r * r) * (double)g.mMask8[qq]; if (e == 0) v0 = vv; else v1 = vv; }
+      if (a.sendmap && a.A0R && send_band(g, ii, jj)) pack_cell(a, qq, r * a.A0R[qq]);
     }
   }
   if (WITH_RR) {

@@ -86,6 +86,11 @@ struct pop_ctx {
   // all peers concatenated (one pack / unpack launch per halo update)
   int *sa_src = nullptr, *sa_start = nullptr, *sa_cnt = nullptr, *ra_dst = nullptr, *ra_start = nullptr, *ra_cnt = nullptr;
   int nsend_all = 0, nrecv_all = 0;
+  // fused distributed solvers: per-cell send entries / receive slots (FusedArgs::sendmap, rmap), nz = 1 message order
+  int *sendmap = nullptr, *send_off = nullptr, *send_slot = nullptr, *rmap = nullptr;
+  pop_exchange_fn xchg_side = nullptr;                     // the same exchange on the side stream (own communicator), or null
+  hipEvent_t ev_sa = nullptr, ev_sx = nullptr;            // solver: z packed (launch stream) / z received (side stream)
+  long long solver_ops = 0, solver_enq = 0;               // stream operations / iterations enqueued by the last distributed solve (incl. look-ahead)
   // tripole northern boundary, per field location (single rank)
   int *tp_dst[4] = {}, *tp_a[4] = {}, *tp_b[4] = {}; int tp_n[4] = {}; double *tp_buf = nullptr;
   // comm hooks
@@ -210,6 +215,43 @@ int halo_update(pop_ctx *c, double *F, int nz, double fill = 0.0, int loc = 0, i
                        kind == 0 ? 1.0 : -1.0, nz, n2);
     hipLaunchKernelGGL(k_tripole_store, dim3((n + 255) / 256, nz), dim3(256), 0, c->stream, F, c->tp_dst[loc], n, (const double *)c->tp_buf, nz, n2);
   }
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// Several fields, one halo update: ONE message per neighbour rank carrying all of them (pack, exchange, unpack = three
+// stream operations whatever the number of fields) and one launch for the ghost copies / fills inside the rank.
+// Field by field the result is the one halo_update gives (same cells, same values).  fill value 0.
+struct HaloItem { double *F; int nz; };
+int halo_update_many(pop_ctx *c, const std::vector<HaloItem> &items) {
+  if (items.size() == 1 || items.size() > 8 || c->h.c.ns_boundary == 2 || getenv("POP_HALO_SEPARATE")) {
+    for (const HaloItem &it : items) if (halo_update(c, it.F, it.nz)) return 1;
+    return 0;
+  }
+  HaloFields H{};
+  H.nf = (int)items.size();
+  int tot = 0;
+  for (int f = 0; f < H.nf; ++f) { H.F[f] = items[f].F; H.nz[f] = items[f].nz; H.lev0[f] = tot; tot += items[f].nz; }
+  H.nztot = tot;
+  const int n2 = c->g.n2;
+  if (!c->peers.empty()) {
+    if (!c->xchg || !c->sendbuf) { c->err = "halo_update: multi-rank run without pop_set_comm"; return 1; }
+    std::vector<int> peer; std::vector<long long> soff, scnt, roff, rcnt;
+    long long so = 0, ro = 0;
+    for (auto &p : c->peers) {
+      peer.push_back(p.rank); soff.push_back(so); scnt.push_back((long long)p.nsend * tot); roff.push_back(ro); rcnt.push_back((long long)p.nrecv * tot);
+      so += (long long)p.nsend * tot; ro += (long long)p.nrecv * tot;
+    }
+    if (so > c->comm_doubles || ro > c->comm_doubles) {   // buffers of an older host framework: field by field
+      for (const HaloItem &it : items) if (halo_update(c, it.F, it.nz)) return 1;
+      return 0;
+    }
+    if (c->nsend_all) hipLaunchKernelGGL(k_halo_pack_many, dim3((c->nsend_all + 255) / 256, tot), dim3(256), 0, c->stream, H, c->sa_src, c->sa_start, c->sa_cnt, c->nsend_all, c->sendbuf, n2);
+    if (c->xchg(c->comm_user, (int)peer.size(), peer.data(), soff.data(), scnt.data(), roff.data(), rcnt.data())) { c->err = "halo_update: exchange failed" + tr_err(c); return 1; }
+    if (c->nrecv_all) hipLaunchKernelGGL(k_halo_unpack_many, dim3((c->nrecv_all + 255) / 256, tot), dim3(256), 0, c->stream, H, c->ra_dst, c->ra_start, c->ra_cnt, c->nrecv_all, (const double *)c->recvbuf, n2);
+  }
+  const int nloc = c->ncopy + c->nfill;
+  if (nloc) hipLaunchKernelGGL(k_halo_local_many, dim3((nloc + 255) / 256, tot), dim3(256), 0, c->stream, H, c->copy_dst, c->copy_src, c->ncopy, c->fill_dst, c->nfill, 0.0, n2);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -455,57 +497,114 @@ SolveView local_view(pop_ctx *c) {
 // all-reduce of disjoint contributions, runs the fused solver on the whole 2-D domain with no
 // per-iteration communication, and keeps its own blocks.  Arithmetic and iteration count equal the
 // single-rank run (same blocks, same b4b sums).
-// pcg, fused form for blocks spread over ranks: the same two kernels per iteration as solver_pcg_fused; ghosts
-// with a source on this rank are read there (srcmap), ghosts owned by another rank are read in place after ONE
-// halo exchange per iteration (z; the search direction at those ghosts is then advanced locally with the same
-// arithmetic as on its owner), and the two dot products go through the b4b block-sum vector and an
-// all-reduce.  9 stream operations per iteration instead of 16 in solver_pcg; bitwise the same results.
+// ---- fused solvers for blocks spread over ranks -------------------------------------------------------------------
+// Ghosts with a source on this rank are read there (srcmap); ghosts owned by another rank need ONE exchange per
+// iteration (z: the search direction and the solution at those ghosts are then advanced locally with the owner's
+// arithmetic, so they never travel).  The message is packed by the kernel that produces z (FusedArgs::sendmap) and read
+// in place from the receive buffer by the kernel that consumes it (rmap): no pack / unpack launches.  The dot products
+// go through the b4b block-sum vector (own blocks' ordered sums, zeros elsewhere) and an all-reduce.  Forming the
+// block sums in the producing kernel (last workgroup by atomic ticket) was measured and rejected: the agent-scope
+// release every workgroup needs costs 20 ns per workgroup (profiles/probes/ticket_probe.hip: 77-88 us against 10 us
+// for the two launches at 4 224 workgroups).
+//   pcg       : k_fpcg_a(+pack) | block sums | all-reduce (launch stream)  ||  exchange z (side stream, own communicator)
+//               k_fpcg_b(reads rbuf) | block sums | all-reduce            = 7 operations, 6 on the critical path
+//   ChronGear : exchange z | k_fcg_a(reads rbuf) | block sums<2> | ONE all-reduce | k_fcg_b(+pack)   = 5 operations
+// Convergence checks keep one interval of look-ahead (run_intervals): the residual lands in pinned host memory, the
+// check that converges raises the device stop flag, and -- the all-reduced sums being the same bits on every rank --
+// all ranks stop at the same check.  Bitwise the same results as the single-rank run.
+struct DistSolve {
+  pop_ctx *c; SolveView v; int nbt;
+  FusedArgs args() const {
+    FusedArgs a = fused_args(c, v);
+    a.presummed = 1; a.nblocks = nbt; a.bsA = c->redbuf; a.bsB = c->redbuf + 2 * nbt;
+    a.sendmap = c->sendmap; a.send_off = c->send_off; a.send_slot = c->send_slot; a.sendbuf = c->sendbuf;
+    a.rmap = c->rmap; a.rbuf = c->recvbuf;
+    return a;
+  }
+  // ordered block sums of every rank -> all ranks; NF interleaved fields at redbuf + off
+  template <int NF> int allsum(const double *partial, long long off) {
+    hipLaunchKernelGGL(k_block_sums_global<NF>, dim3(nbt), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->loc_of_gid, c->redbuf + off);
+    if (c->allred(c->comm_user, off, (long long)NF * nbt)) { c->err = "distributed solver: allreduce failed" + tr_err(c); return 1; }
+    c->solver_ops += 2;
+    return 0;
+  }
+  // the one-level exchange of the buffers the kernels packed: on the side stream beside the all-reduce when the
+  // transport has a second communicator, else in line.  fork: the packed data is complete on the launch stream now.
+  bool overlap = true;
+  bool side() const { return overlap && c->xchg_side && c->side && !getenv("POP_SOLVER_OVERLAP_OFF"); }
+  int xchg_begin() {
+    std::vector<int> peer; std::vector<long long> so, sc, ro, rc;
+    long long s0 = 0, r0 = 0;
+    for (auto &p : c->peers) { peer.push_back(p.rank); so.push_back(s0); sc.push_back(p.nsend); ro.push_back(r0); rc.push_back(p.nrecv); s0 += p.nsend; r0 += p.nrecv; }
+    c->solver_ops += 1;
+    if (side()) {
+      if (hipEventRecord(c->ev_sa, c->stream) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_sa, 0) != hipSuccess) { c->err = "distributed solver: event failed"; return 1; }
+      if (c->xchg_side(c->comm_user, (int)peer.size(), peer.data(), so.data(), sc.data(), ro.data(), rc.data())) { c->err = "distributed solver: exchange failed" + tr_err(c); return 1; }
+      if (hipEventRecord(c->ev_sx, c->side) != hipSuccess) { c->err = "distributed solver: event failed"; return 1; }
+      return 0;
+    }
+    if (c->xchg(c->comm_user, (int)peer.size(), peer.data(), so.data(), sc.data(), ro.data(), rc.data())) { c->err = "distributed solver: exchange failed" + tr_err(c); return 1; }
+    return 0;
+  }
+  int xchg_end() {   // the launch stream may read the receive buffer after this
+    if (side() && hipStreamWaitEvent(c->stream, c->ev_sx, 0) != hipSuccess) { c->err = "distributed solver: event failed"; return 1; }
+    return 0;
+  }
+  // residual + (r,r) of all ranks -> device scalars, pinned host ring, stop flag (the check of run_intervals)
+  int check() {
+    launch_fresidual<true>(c, v, args());
+    if (allsum<1>(args().partA, 0)) return 1;
+    hipLaunchKernelGGL(k_rr_blocks, dim3(1), dim3(1), 0, c->stream, (const double *)c->redbuf, nbt, c->sc, c->host_rr, c->h.convergenceCriterion);
+    c->solver_ops += 2;
+    return 0;
+  }
+};
+
 int solver_pcg_fused_dist(pop_ctx *c) {
   const pop_config &cf = c->h.c;
-  SolveView v = local_view(c);
+  DistSolve D{c, local_view(c), c->h.nblocks_tot};
+  SolveView &v = D.v;
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
-  const int nbt = c->h.nblocks_tot;
-  if (!c->allred || !c->redbuf || c->red_doubles < 2LL * nbt) { c->err = "distributed pcg: no transport / reduce buffer"; return 1; }
-  auto args = [&]() {
-    FusedArgs a = fused_args(c, v);
-    a.presummed = 1; a.nblocks = nbt; a.bsA = c->redbuf; a.bsB = c->redbuf + nbt;
-    return a;
-  };
-  auto allsum = [&](const double *partial, long long off) -> int {   // ordered block sums of every rank -> all ranks
-    hipLaunchKernelGGL(k_block_sums_global<1>, dim3(nbt), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->loc_of_gid, c->redbuf + off);
-    if (c->allred(c->comm_user, off, nbt)) { c->err = "distributed pcg: allreduce failed" + tr_err(c); return 1; }
-    return 0;
-  };
+  const int nbt = D.nbt, freq = cf.convergence_check_freq;
+  if (!c->allred || !c->xchg || !c->redbuf || !c->sendbuf || c->red_doubles < 4LL * nbt) { c->err = "distributed pcg: no transport / reduce buffer"; return 1; }
   SolverScalars init{}; init.eta0 = 1.0;
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(v.S0, 0, sizeof(double) * v.g.n2 * v.g.nblocks, c->stream));
-  launch_fresidual<false>(c, v, args());
+  launch_fresidual<false>(c, v, D.args());
   c->numIterations = cf.max_iterations;
-  double rr = 0.0;
-  bool pending = false;
-  for (int m = 1; m <= cf.max_iterations; ++m) {
-    FusedArgs a = args();
-    if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
-    else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
-    if (allsum(a.partA, 0) || halo_remote(c, v.Z, 1)) return 1;
-    launch_fpcg_b(c, v, a);
-    if (allsum(a.partB, nbt)) return 1;
-    std::swap(v.S0, v.S1);
-    pending = true;
-    if (m % cf.convergence_check_freq == 0) {
-      a = args();
-      hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, a);
-      pending = false;
-      launch_fresidual<true>(c, v, a);
-      if (allsum(a.partA, 0)) return 1;
-      hipLaunchKernelGGL(k_finalize<1>, dim3(1), dim3(1), 0, c->stream, c->redbuf, nbt, c->sc, (int)FIN_RR);
-      SolverScalars s;
-      if (read_scalars(c, &s)) return 1;
-      rr = s.rr;
-      if (rr < c->h.convergenceCriterion) { c->numIterations = m; break; }
+  c->solver_ops = 0; c->solver_enq = 0;
+  auto iterations = [&](int n, bool pending) -> int {
+    for (int it = 0; it < n; ++it) {
+      c->solver_enq += 1;
+      FusedArgs a = D.args();
+      if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
+      else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
+      c->solver_ops += 1;
+      if (D.xchg_begin() || D.allsum<1>(a.partA, 0) || D.xchg_end()) return 1;
+      launch_fpcg_b(c, v, a);
+      c->solver_ops += 1;
+      if (D.allsum<1>(a.partB, 2 * nbt)) return 1;
+      std::swap(v.S0, v.S1);
+      pending = true;
     }
+    return 0;
+  };
+  double rr = 0.0;
+  int lerr = 0;
+  const int nint = cf.max_iterations / freq;
+  const int conv = run_intervals(c, nint, [&](int) -> int {
+    if (iterations(freq, false)) return -1;
+    hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, D.args());
+    c->solver_ops += 1;
+    if (D.check()) return -1;
+    return 1;
+  }, rr, lerr);
+  if (lerr) { if (c->err.empty()) c->err = "distributed pcg: interval launch failed"; return 1; }
+  if (conv >= 0) c->numIterations = (conv + 1) * freq;
+  if (c->numIterations == cf.max_iterations && nint * freq < cf.max_iterations) {   // remainder without a check
+    if (iterations(cf.max_iterations - nint * freq, false)) return 1;
+    hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, D.args());
   }
-  if (pending) hipLaunchKernelGGL(k_fpcg_xr, G, B, 0, c->stream, v.g, args());
   // ghosts of the solution as POP_SolversRun leaves them: remote ones were advanced with their owners'
   // arithmetic, the ones with a source on this rank are copied now (srcmap is the identity on remote ghosts)
   const long long ncell = (long long)v.g.n2 * v.g.nblocks;
@@ -655,6 +754,81 @@ int solver_chrongear_fused(pop_ctx *c) {
   if (c->numIterations == cf.max_iterations && m < cf.max_iterations) {   // remainder without a check
     int par = m & 1;
     cg_fused_iterations(c, v, cf.max_iterations - m, par);
+  }
+  hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, v.X, v.srcmap, a2);
+  c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
+  HIPCHK(c, hipGetLastError());
+  if (c->numIterations == cf.max_iterations && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversChronGear: solver not converged"; return 2; }
+  return 0;
+}
+
+// ChronGear for blocks spread over ranks (see DistSolve): start-up pass as in solver_chrongear, then per iteration
+// exchange z | k_fcg_a | block sums of (r,z), (az,z) | ONE all-reduce | k_fcg_b, which also packs the next z
+int solver_chrongear_fused_dist(pop_ctx *c) {
+  const pop_config &cf = c->h.c;
+  DistSolve D{c, local_view(c), c->h.nblocks_tot};
+  D.overlap = false;   // nothing runs beside the exchange here: the next kernel needs it
+  SolveView &v = D.v;
+  const dim3 G = view_grid(v), B(POP_RED_THREADS);
+  const int nbt = D.nbt, freq = cf.convergence_check_freq;
+  const long long a2 = (long long)c->g.n2 * c->g.nblocks;
+  if (!c->allred || !c->xchg || !c->redbuf || !c->sendbuf || c->red_doubles < 4LL * nbt) { c->err = "distributed ChronGear: no transport / reduce buffer"; return 1; }
+  SolverScalars init{};
+  HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  SolverArgs sa = solver_args(c);
+  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, sa);
+  if (halo_update(c, c->R, 1)) return 1;
+  hipLaunchKernelGGL(k_cg_init<false>, G, B, 0, c->stream, c->g, sa);
+  if (halo_update(c, c->Q, 1)) return 1;
+  if (reduce_finish<2>(c, FIN_CG_INIT)) return 1;
+  hipLaunchKernelGGL(k_cg_update<true>, G, B, 0, c->stream, c->g, sa);
+  hipLaunchKernelGGL(k_pcsi_a0r, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->centerWgt, v.S1, a2);
+  // z of the first iteration at the neighbours' ghosts: z = r*A0R on the whole array, packed and exchanged once
+  hipLaunchKernelGGL(k_cg_z, G, B, 0, c->stream, c->g, sa);
+  if (c->nsend_all) hipLaunchKernelGGL(k_halo_pack_all, dim3((c->nsend_all + 255) / 256, 1), dim3(256), 0, c->stream, (const double *)c->Z, c->sa_src, c->sa_start, c->sa_cnt, c->nsend_all, c->sendbuf, 1, c->g.n2);
+  if (D.xchg_begin()) return 1;
+  c->numIterations = cf.max_iterations;
+  c->solver_ops = 0; c->solver_enq = 0;
+  auto args = [&]() { FusedArgs a = D.args(); a.AZ = c->AZ; a.A0R = v.S1; return a; };
+  auto iterations = [&](int n, int &par) -> int {
+    for (int it = 0; it < n; ++it) {
+      c->solver_enq += 1;
+      FusedArgs a = args();
+      if ((v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell && (long long)v.nchunk * v.g.nblocks > 2048) hipLaunchKernelGGL(k_fcg_a2, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
+      else hipLaunchKernelGGL(k_fcg_a, G, B, 0, c->stream, v.g, a);
+      c->solver_ops += 1;
+      if (D.allsum<2>(a.partA, 0)) return 1;
+      hipLaunchKernelGGL(k_fcg_b, G, B, 0, c->stream, v.g, a, par);
+      c->solver_ops += 1;
+      if (D.xchg_begin()) return 1;
+      par = 1 - par;
+    }
+    return 0;
+  };
+  double rr = 0.0;
+  int lerr = 0;
+  const int nint = cf.max_iterations / freq;
+  const int conv = run_intervals(c, nint, [&](int i) -> int {
+    int par = (i * freq) & 1;
+    if (iterations(freq, par)) return -1;
+    // r = b - A x; its z = r*A0R is packed by the residual kernel and exchanged for the next interval
+    {
+      FusedArgs a = args();
+      const dim3 GG = view_grid(v);
+      if ((v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell && (long long)v.nchunk * v.g.nblocks > 2048) hipLaunchKernelGGL(k_fresidual2<true>, GG, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
+      else hipLaunchKernelGGL(k_fresidual<true>, GG, dim3(POP_RED_THREADS), 0, c->stream, v.g, a);
+      if (D.allsum<1>(a.partA, 0)) return -1;
+      hipLaunchKernelGGL(k_rr_blocks, dim3(1), dim3(1), 0, c->stream, (const double *)c->redbuf, nbt, c->sc, c->host_rr, c->h.convergenceCriterion);
+      if (D.xchg_begin()) return -1;
+      c->solver_ops += 2;
+    }
+    return 1;
+  }, rr, lerr);
+  if (lerr) { if (c->err.empty()) c->err = "distributed ChronGear: interval launch failed"; return 1; }
+  if (conv >= 0) c->numIterations = (conv + 1) * freq;
+  if (c->numIterations == cf.max_iterations && nint * freq < cf.max_iterations) {   // remainder without a check
+    int par = (nint * freq) & 1;
+    if (iterations(cf.max_iterations - nint * freq, par)) return 1;
   }
   hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, v.X, v.srcmap, a2);
   c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
@@ -1055,6 +1229,17 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
       for (int v : pp.recv_dst) { rd.push_back(v); rt.push_back(r0); rc.push_back((int)pp.recv_dst.size()); }
     }
     c->nsend_all = (int)ss.size(); c->nrecv_all = (int)rd.size();
+    if (!h.halo.peers.empty()) {   // per-cell maps of the same lists for the kernels that pack / read a one-level message themselves
+      std::vector<int> smap(a2, -1), rmp(a2, -1), off(1, 0), slot;
+      std::map<int, std::vector<int>> by_cell;
+      for (size_t t = 0; t < ss.size(); ++t) by_cell[ss[t]].push_back((int)t);
+      for (auto &kv : by_cell) { smap[kv.first] = (int)off.size() - 1; for (int t : kv.second) slot.push_back(t); off.push_back((int)slot.size()); }
+      for (size_t t = 0; t < rd.size(); ++t) rmp[rd[t]] = (int)t;
+      if (dev_upload(c, &c->sendmap, smap.data(), smap.size()) || dev_upload(c, &c->send_off, off.data(), off.size()) ||
+          dev_upload(c, &c->send_slot, slot.data(), std::max<size_t>(slot.size(), 1)) || dev_upload(c, &c->rmap, rmp.data(), rmp.size())) return 1;
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_sa, hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_sx, hipEventDisableTiming));
+    }
     if (c->nsend_all && (dev_upload(c, &c->sa_src, ss.data(), ss.size()) || dev_upload(c, &c->sa_start, st.data(), st.size()) || dev_upload(c, &c->sa_cnt, sc.data(), sc.size()))) return 1;
     if (c->nrecv_all && (dev_upload(c, &c->ra_dst, rd.data(), rd.size()) || dev_upload(c, &c->ra_start, rt.data(), rt.size()) || dev_upload(c, &c->ra_cnt, rc.data(), rc.size()))) return 1;
   }
@@ -1176,13 +1361,17 @@ int pop_destroy(pop_ctx *c) {
   if (c->ev_d2t) hipEventDestroy(c->ev_d2t);
   if (c->ev_d2u) hipEventDestroy(c->ev_d2u);
   if (c->ev_vmixu) hipEventDestroy(c->ev_vmixu);
-  if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+  if (c->ev_sa) hipEventDestroy(c->ev_sa);
+  if (c->ev_sx) hipEventDestroy(c->ev_sx);
   for (auto &e : c->chk_ev) if (e) hipEventDestroy(e);
   if (c->rccl_tr) {
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->side) hipStreamSynchronize(c->side);
+    if (c->rccl_tr->comm2) rccl().CommDestroy(c->rccl_tr->comm2);
     if (c->rccl_tr->comm) rccl().CommDestroy(c->rccl_tr->comm);
     delete c->rccl_tr;
   }
+  if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
   kpp_destroy(c->mix);
   for (void *p : c->allocs) hipFree(p);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -1209,6 +1398,8 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "avg_ts") return c->avg_ts;
   if (n == "nsteps_total") return c->nsteps_total;
   if (n == "nsteps_per_interval") return c->h.nsteps_per_interval;
+  if (n == "solver_stream_ops") return (int)c->solver_ops;
+  if (n == "solver_iterations_enqueued") return (int)c->solver_enq;
   if (n == "rank") return c->h.rank;
   if (n == "nranks") return c->h.nranks;
   return -1;
@@ -1551,7 +1742,7 @@ int pop_baroclinic_driver(pop_ctx *c) {
   if (phase_tracer_rhs(c)) return 1;
   if (sp.pavg) {
     if (phase_impvmixt_pred(c)) return 1;
-    if (halo_update(c, c->TR[0][c->newt], c->g.km) || halo_update(c, c->TR[1][c->newt], c->g.km)) return 1;
+    if (halo_update_many(c, {{c->TR[0][c->newt], c->g.km}, {c->TR[1][c->newt], c->g.km}})) return 1;
     if (phase_state_new(c)) return 1;
   }
   if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2u, 0));
@@ -1572,7 +1763,11 @@ int pop_baroclinic_driver(pop_ctx *c) {
 
 int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
-  if (c->h.c.solver_choice == 2) return (c->fused_ok && !c->use_evp) ? solver_chrongear_fused(c) : solver_chrongear(c);
+  if (c->h.c.solver_choice == 2) {
+    if (c->fused_ok && !c->use_evp) return solver_chrongear_fused(c);
+    if (c->h.nranks > 1 && c->h.nblocks <= 8 && !c->use_evp && !getenv("POP_SOLVER_UNFUSED")) return solver_chrongear_fused_dist(c);
+    return solver_chrongear(c);
+  }
   if (c->h.c.solver_choice == 3) {
     if (c->use_evp) return solver_pcsi(c);
     if (c->fused_ok) return solver_pcsi_fused(c);
@@ -1636,7 +1831,7 @@ int pop_barotropic_driver(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "BAROTROPIC");
   const StepParams sp = step_params(c);
-  if (halo_update(c, c->ZX, 1) || halo_update(c, c->ZY, 1)) return 1;
+  if (halo_update_many(c, {{c->ZX, 1}, {c->ZY, 1}})) return 1;
   BtropArgs a{};
   a.ZX = c->ZX; a.ZY = c->ZY; a.GXC = c->GX[c->curt]; a.GXO = c->GX[c->oldt]; a.GYC = c->GY[c->curt]; a.GYO = c->GY[c->oldt];
   a.UBO = c->UB[c->oldt]; a.VBO = c->VB[c->oldt]; a.PCUR = c->PS[c->curt]; a.FW = c->FW; a.PGUESS = c->PGUESS;
@@ -1654,7 +1849,7 @@ int pop_barotropic_driver(pop_ctx *c) {
   if (reduce_finish<1>(c, FIN_XCHECK)) return 1;
   hipLaunchKernelGGL(k_btrop_fin1, G, B, 0, c->stream, c->g, a);
   hipLaunchKernelGGL(k_btrop_fin2, G, B, 0, c->stream, c->g, sp, a);
-  if (halo_update(c, c->PS[c->newt], 1) || halo_update(c, c->GX[c->newt], 1) || halo_update(c, c->GY[c->newt], 1)) return 1;
+  if (halo_update_many(c, {{c->PS[c->newt], 1}, {c->GX[c->newt], 1}, {c->GY[c->newt], 1}})) return 1;
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1742,9 +1937,11 @@ int pop_step_tail(pop_ctx *c) {
   ScopedPhase ph(c, "3D-UPDATE");
   const int km = c->g.km;
   if (join_side(c)) return 1;
-  if (halo_update(c, c->UB[c->newt], 1) || halo_update(c, c->VB[c->newt], 1)) return 1;
-  if (halo_update(c, c->U[c->newt], km) || halo_update(c, c->V[c->newt], km) || halo_update(c, c->RHO[c->newt], km)) return 1;
-  for (int n = 0; n < c->h.nt; ++n) if (halo_update(c, c->TR[n][c->newt], km)) return 1;
+  {   // the seven updates of step_mod.F90:467-560 as one message per neighbour
+    std::vector<HaloItem> items = {{c->UB[c->newt], 1}, {c->VB[c->newt], 1}, {c->U[c->newt], km}, {c->V[c->newt], km}, {c->RHO[c->newt], km}};
+    for (int n = 0; n < c->h.nt; ++n) items.push_back({c->TR[n][c->newt], km});
+    if (halo_update_many(c, items)) return 1;
+  }
   if (!c->btrop_added && phase_add_btrop(c)) return 1;
   c->btrop_added = false;
   const long long a2 = (long long)c->g.n2 * c->g.nblocks;
@@ -2027,11 +2224,31 @@ int pop_comm_init_rccl(pop_ctx *c, const unsigned char *id128) {
   if (rc) { c->err = "pop_comm_init_rccl: ncclCommInitRank: " + rccl().what(rc); delete t; return 1; }
   c->rccl_tr = t;
   t->stream = &c->stream;
-  const long long nb = pop_comm_buffer_doubles(c), nr = std::max<long long>(pop_reduce_buffer_doubles(c), 8);
+  const long long nb = pop_comm_buffer_doubles(c), nr = std::max<long long>(pop_reduce_buffer_doubles(c), 128);
   if (dev_alloc(c, &t->send, (size_t)nb) || dev_alloc(c, &t->recv, (size_t)nb) || dev_alloc(c, &t->red, (size_t)nr)) return 1;
   c->sendbuf = t->send; c->recvbuf = t->recv; c->comm_doubles = nb;
   c->redbuf = t->red; c->red_doubles = nr;
   c->xchg = rccl_exchange; c->allred = rccl_allreduce; c->comm_user = t;
+  // second communicator for exchanges on the side stream (beside an all-reduce on the first).  Its id is made by
+  // rank 0 and travels over the first communicator, one byte per double (exact under the sum with the other ranks'
+  // zeros), so the host has nothing more to broadcast.  POP_RCCL_OVERLAP=0 keeps everything on one communicator.
+  if (c->side && c->h.nranks > 1 && !(getenv("POP_RCCL_OVERLAP") && atoi(getenv("POP_RCCL_OVERLAP")) == 0)) {
+    std::vector<double> enc(128, 0.0);
+    RcclApi::UniqueId id2;
+    if (c->h.rank == 0) {
+      if (rccl().GetUniqueId(&id2)) { c->err = "pop_comm_init_rccl: ncclGetUniqueId for the second communicator failed"; return 1; }
+      for (int b = 0; b < 128; ++b) enc[b] = (double)(unsigned char)id2.internal[b];
+    }
+    HIPCHK(c, hipMemcpyAsync(t->red, enc.data(), 128 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (rccl_allreduce(t, 0, 128)) { c->err = "pop_comm_init_rccl: broadcasting the second id failed: " + t->err; return 1; }
+    HIPCHK(c, hipMemcpyAsync(enc.data(), t->red, 128 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int b = 0; b < 128; ++b) id2.internal[b] = (char)(unsigned char)enc[b];
+    const int rc2 = rccl().CommInitRank(&t->comm2, c->h.nranks, id2, c->h.rank);
+    if (rc2) { c->err = "pop_comm_init_rccl: second communicator: " + rccl().what(rc2); return 1; }
+    t->side = &c->side;
+    c->xchg_side = rccl_exchange_side;
+  }
   return 0;
 }
 // transport self-test (also the single-rank check of the RCCL binding): every rank contributes
@@ -2058,6 +2275,19 @@ int pop_comm_selftest(pop_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int r = 0; r < nr; ++r) if (v[r] != r + 1.0) { c->err = "pop_comm_selftest: all-reduce returned a wrong sum"; return 1; }
   if (back != 1000.0 + prv) { c->err = "pop_comm_selftest: ring send/recv returned a wrong value"; return 1; }
+  if (c->xchg_side && c->side) {   // the same ring through the second communicator on the side stream, beside an all-reduce on the first
+    const double probe2 = 2000.0 + c->h.rank;
+    double back2 = 0.0;
+    HIPCHK(c, hipMemcpyAsync(c->sendbuf, &probe2, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    if (c->xchg_side(c->comm_user, nxt == prv ? 1 : 2, peer, z2, sc1, z2, rc1)) { c->err = "pop_comm_selftest: side-stream exchange failed" + tr_err(c); return 1; }
+    if (c->allred(c->comm_user, 0, nr)) { c->err = "pop_comm_selftest: allreduce beside the side-stream exchange failed" + tr_err(c); return 1; }
+    HIPCHK(c, hipStreamSynchronize(c->side));
+    HIPCHK(c, hipMemcpyAsync(&back2, c->recvbuf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (back2 != 2000.0 + prv) { c->err = "pop_comm_selftest: side-stream ring send/recv returned a wrong value"; return 1; }
+  }
   return 0;
 }
 
@@ -2076,7 +2306,8 @@ int pop_set_stream(pop_ctx *c, void *hip_stream) {   // run on the host framewor
 long long pop_comm_buffer_doubles(const pop_ctx *c) {
   long long cells = 0;
   for (auto &p : c->h.halo.peers) cells += (long long)std::max(p.send_src.size(), p.recv_dst.size());
-  return std::max<long long>(cells * std::max(c->h.km, 1), 4LL * c->h.nblocks_tot);
+  // the largest message: the end-of-step update of UBTROP, VBTROP, U, V, RHO and the tracers in one piece
+  return std::max<long long>(cells * (long long)(2 + (3 + c->h.nt) * std::max(c->h.km, 1)), 4LL * c->h.nblocks_tot);
 }
 int pop_halo_plan_counts(const pop_ctx *c, int *nl, int *nf, int *np) {
   if (nl) *nl = (int)c->h.halo.copy_dst.size();

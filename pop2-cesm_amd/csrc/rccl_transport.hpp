@@ -66,25 +66,38 @@ inline RcclApi &rccl() { static RcclApi a; return a; }
 // state of one context's native transport
 struct RcclTransport {
   RcclApi::Comm comm = nullptr;
+  RcclApi::Comm comm2 = nullptr;      // second communicator: exchanges on the side stream beside an all-reduce on `comm`
   hipStream_t *stream = nullptr;      // the context's launch stream (pointer: follows pop_set_stream)
+  hipStream_t *side = nullptr;        // the context's side stream
   double *send = nullptr, *recv = nullptr, *red = nullptr;
   std::string err;
 };
 
 // pop_exchange_fn: offsets/counts are in doubles within the context's send / receive buffers
-inline int rccl_exchange(void *user, int nmsg, const int *peer, const long long *soff, const long long *scnt,
-                         const long long *roff, const long long *rcnt) {
-  RcclTransport *t = (RcclTransport *)user;
+inline int rccl_exchange_on(RcclTransport *t, RcclApi::Comm comm, hipStream_t st, int nmsg, const int *peer, const long long *soff,
+                            const long long *scnt, const long long *roff, const long long *rcnt) {
   RcclApi &a = rccl();
   int rc = a.GroupStart();
   for (int i = 0; i < nmsg && rc == 0; ++i) {
-    if (rcnt[i]) rc = a.Recv(t->recv + roff[i], (size_t)rcnt[i], RcclApi::kDouble, peer[i], t->comm, *t->stream);
-    if (rc == 0 && scnt[i]) rc = a.Send(t->send + soff[i], (size_t)scnt[i], RcclApi::kDouble, peer[i], t->comm, *t->stream);
+    if (rcnt[i]) rc = a.Recv(t->recv + roff[i], (size_t)rcnt[i], RcclApi::kDouble, peer[i], comm, st);
+    if (rc == 0 && scnt[i]) rc = a.Send(t->send + soff[i], (size_t)scnt[i], RcclApi::kDouble, peer[i], comm, st);
   }
   const int rc2 = a.GroupEnd();
   if (rc == 0) rc = rc2;
   if (rc) { t->err = a.what(rc); return 1; }
   return 0;
+}
+inline int rccl_exchange(void *user, int nmsg, const int *peer, const long long *soff, const long long *scnt,
+                         const long long *roff, const long long *rcnt) {
+  RcclTransport *t = (RcclTransport *)user;
+  return rccl_exchange_on(t, t->comm, *t->stream, nmsg, peer, soff, scnt, roff, rcnt);
+}
+// the same exchange on the side stream through the second communicator (operations on one communicator must not
+// run concurrently; two communicators may)
+inline int rccl_exchange_side(void *user, int nmsg, const int *peer, const long long *soff, const long long *scnt,
+                              const long long *roff, const long long *rcnt) {
+  RcclTransport *t = (RcclTransport *)user;
+  return rccl_exchange_on(t, t->comm2, *t->side, nmsg, peer, soff, scnt, roff, rcnt);
 }
 // pop_allreduce_fn: in-place sum over ranks of red[off .. off+cnt)
 inline int rccl_allreduce(void *user, long long off, long long cnt) {

@@ -64,6 +64,8 @@ def main():
             a = m.get(name, 1, 0); b = ref.get(name, 1, 0)[[i - 1 for i in ids]]
             if not np.array_equal(a, b):
                 print("rank %d step %d: %s differs, max %g" % (rank, s, name, np.abs(a - b).max())); ok = False
+    if rank == 0:   # stream operations the distributed solver enqueued per iteration in the last solve (0: replicated / unfused path)
+        print("MR_SOLVER_OPS %.3f" % (m.dim("solver_stream_ops") / max(m.dim("solver_iterations_enqueued"), 1)))
     # global reductions across ranks: same value / location / count as the single-rank twin
     for want_max in (True, False):
         if m.global_extreme("PSURF", 1, 0, want_max=want_max) != ref.global_extreme("PSURF", 1, 0, want_max=want_max):

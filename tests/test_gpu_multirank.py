@@ -34,6 +34,7 @@ def _run_check(args, timeout, env=None, transport="staged"):
         if "MR_GPU_CHECK" in out.stdout or not any(e in out.stderr for e in _RDZV_ERRORS):
             break
     assert "MR_GPU_CHECK OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    return out.stdout
 
 
 def test_gx1v7_two_ranks_equal_single_rank():
@@ -60,7 +61,10 @@ def test_large_grid_two_ranks_equal_single_rank():
     (2, "solver_choice=3", {}),                                       # P-CSI fused: one r' halo + one launch per iteration, no collective
     (2, "solver_choice=3", {"POP_SOLVER_UNFUSED": "1"}),              # P-CSI operation by operation
     (4, "solver_choice=3,block_size_x=24,block_size_y=20", {}),       # P-CSI, one block per rank
-    (2, "solver_choice=2", {}),                                       # ChronGear
+    (2, "solver_choice=2", {}),                                       # ChronGear, fused distributed form (one all-reduce per iteration)
+    (2, "solver_choice=2", {"POP_SOLVER_UNFUSED": "1"}),              # ChronGear operation by operation
+    (4, "solver_choice=2,block_size_x=24,block_size_y=20", {}),       # ChronGear fused, one block per rank: corner cells go to three peers
+    (2, "", {"POP_HALO_SEPARATE": "1"}),                              # one message per field instead of the batched halo updates
     (2, "precond_choice=1", {}),                                      # EVP preconditioner, pcg: extra z halo per iteration
     (3, "precond_choice=1,solver_choice=3,block_size_x=24,block_size_y=20", {}),   # P-CSI + EVP, uneven ownership
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3 across ranks
@@ -77,6 +81,9 @@ def test_multirank_equals_single_rank(nranks, kw, env):
     (2, "block_size_x=48,block_size_y=20", {}),                       # replicated barotropic solve (one all-reduce gathers RHS + guess)
     (4, "block_size_x=24,block_size_y=20", {"POP_SOLVER_DISTRIBUTED": "1"}),   # one block per rank: E-W, N-S and corner peers
     (2, "solver_choice=2", {}),                                       # ChronGear
+    (4, "solver_choice=2,block_size_x=24,block_size_y=20", {}),       # ChronGear, one block per rank
+    (2, "", {"POP_SOLVER_OVERLAP_OFF": "1"}),                         # z exchange in line instead of on the side stream
+    (2, "", {"POP_RCCL_OVERLAP": "0"}),                               # one communicator only
     (4, "solver_choice=3,block_size_x=24,block_size_y=20", {}),       # P-CSI
     (3, "block_size_x=24,block_size_y=20,vmix_choice=3,km=24", {}),   # uneven ownership, KPP
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3
@@ -92,3 +99,18 @@ def test_native_transport_large_grid_two_ranks():
     _run_check(["--nproc-per-node", "2", os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tx0.1v3", "--steps", "2",
                 "--kw", "nx_global=1800,ny_global=1200,block_size_x=1800,block_size_y=600"], 900,
                {"POP_RCCL_STUB_BOX_MB": "16", "POP_SOLVER_DISTRIBUTED": "1"}, transport="native")
+
+
+def _ops(stdout):
+    return float([l for l in stdout.splitlines() if l.startswith("MR_SOLVER_OPS")][0].split()[1])
+
+
+def test_stream_operations_per_distributed_iteration():
+    """What the distributed solvers enqueue per iteration, counted by the library (pop_get_dim solver_stream_ops) and
+    averaged over the last solve including its convergence checks (one per 10 iterations: x update, residual, block
+    sums, all-reduce, check = 5 more).  pcg: k_fpcg_a(+pack) | block sums | all-reduce || exchange z on the side
+    stream, k_fpcg_b(reads the receive buffer) | block sums | all-reduce = 7 enqueued, 6 on the critical path (round 1:
+    9, all serial).  ChronGear: exchange | k_fcg_a | block sums | ONE all-reduce | k_fcg_b(+pack) = 5."""
+    args = ["--nproc-per-node", "2", os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "2", "--kw"]
+    assert _ops(_run_check(args + [""], 300, transport="native")) <= 7.0 + 0.5
+    assert _ops(_run_check(args + ["solver_choice=2"], 300, transport="native")) <= 5.0 + 0.5
