@@ -52,7 +52,9 @@ typedef struct pop_config {
   int lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri; /* vmix_kpp_nml */
   int reserved_i[8];          /* [0] = maxlanczosstep (0 = 20), [1] = convergenceCheckStart (0 = 60) for PCSI
                                * (POP_SolversMod.F90:626-640); [2] = preconditionerChoice: 0 'diagonal', 1 'evp'
-                               * (:124, :252-290, :2434-2696; any solver_choice) */
+                               * (:124, :252-290, :2434-2696; any solver_choice);
+                               * [3] = synthetic topography: 0 the reference's internal flat bottom (grid.F90:880-884,
+                               * 1957-1985), 1 stepped bathymetry KMT = 3 ... km (test extension, not in the reference) */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;
@@ -214,6 +216,14 @@ int pop_timer_ms(pop_ctx *ctx, const char *name, double *total_ms, int *calls);
 /* bench support: time `reps` launches of one named kernel phase with HIP events on the
  * stream it runs on; returns average ms */
 int pop_time_phase(pop_ctx *ctx, const char *phase, int reps, double *avg_ms);
+/* one phase of baroclinic_driver / baroclinic_correct_adjust on its own (the public routines the reference's drivers
+ * call one after the other): "vmix" vmix_coeffs vertical_mix.F90:518, "hmix_tracer" / "hmix_momentum" first Laplacians of
+ * hmix_del4.F90:1021 / :730 (no-ops for del2), "tracer_rhs" tracer_update baroclinic.F90:1902, "impvmixt"
+ * vertical_mix.F90:1164, "state" state_mod.F90:258 on the new tracers, "momentum_rhs" clinic baroclinic.F90:1635,
+ * "impvmixu" vertical_mix.F90:1679 + baroclinic.F90:1077-1129, "correct" impvmixt_correct :1460 with the surface
+ * terms of baroclinic.F90:1261-1475, "add_btrop" step_mod.F90:572-600.  Uses the step parameters of the last
+ * pop_time_manager call. */
+int pop_run_phase(pop_ctx *ctx, const char *phase);
 int pop_device_sync(pop_ctx *ctx);
 /* run all launches on the host framework's HIP stream (e.g. torch.cuda.current_stream().cuda_stream) */
 int pop_set_stream(pop_ctx *ctx, void *hip_stream);

@@ -73,6 +73,8 @@ double  orc_scalar(orc_model *m, const char *name);
 void orc_time_manager(orc_model *m);      /* set step flags for next step */
 void orc_dhdt(orc_model *m);
 int  orc_baroclinic_driver(orc_model *m);
+/* the same in stages (bit mask): 1 vmix_coeffs + tracer_update, 2 impvmixt + halo, 4 state(new), 8 clinic, 16 impvmixu + finish */
+int  orc_baroclinic_stages(orc_model *m, int stages);
 int  orc_barotropic_driver(orc_model *m);
 void orc_baroclinic_correct_adjust(orc_model *m);
 void orc_step_tail(orc_model *m);

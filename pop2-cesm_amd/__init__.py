@@ -78,7 +78,7 @@ def lib():
         "pop_halo_plan_counts": (ci, [vp, pi, pi, pi]), "pop_halo_plan_peer": (ci, [vp, ci, pi, pi, pi]),
         "pop_halo_plan_lists": (ci, [vp, ci, pi, pi]), "pop_halo_plan_local": (ci, [vp, pi, pi, pi]),
         "pop_timers_reset": (ci, [vp]), "pop_timer_ms": (ci, [vp, cs, pd, pi]),
-        "pop_time_phase": (ci, [vp, cs, ci, pd]), "pop_device_sync": (ci, [vp]),
+        "pop_time_phase": (ci, [vp, cs, ci, pd]), "pop_device_sync": (ci, [vp]), "pop_run_phase": (ci, [vp, cs]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)       # AttributeError here = the library does not export the ABI
@@ -318,6 +318,10 @@ class PopModel:
         ms, calls = C.c_double(), C.c_int()
         self.L.pop_timer_ms(self.h, name.encode(), C.byref(ms), C.byref(calls))
         return ms.value, calls.value
+
+    def run_phase(self, phase):
+        """one phase of baroclinic_driver / baroclinic_correct_adjust on its own (include/pop_amd.h pop_run_phase)"""
+        self._chk(self.L.pop_run_phase(self.h, phase.encode()))
 
     def time_phase(self, phase, reps=10):
         ms = C.c_double()

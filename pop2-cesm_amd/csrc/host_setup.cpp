@@ -252,6 +252,10 @@ int host_build(HostModel &h) {
     if (latd > 60.0 && lond > 210.0 && lond < 150.0) k = 0;
     if (latd > -60.0 && lond > 110.0 && lond < 150.0) k = 0;
     if (std::fabs(latd) > 75.0) k = 0;
+    // reserved_i[3] = 1: stepped synthetic bathymetry (an extension for tests; the reference's internal topography is
+    // flat, grid.F90:880-884): ocean columns of 3 ... km levels in stairs 3 cells wide in i and 2 in j, so that every
+    // k > KMT / k > KMU branch and the shallow-column paths of the Thomas solves are exercised.  Integer arithmetic only.
+    if (k > 0 && c.reserved_i[3] == 1) k = std::max(3, h.km - ((ig / 3) * 5 + (jg / 2) * 3) % (h.km / 2 + 1));
     return k;
   };
   auto &ULAT = newf("ULAT"), &ULON = newf("ULON"), &TLAT = newf("TLAT");

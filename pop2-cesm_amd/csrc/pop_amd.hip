@@ -2354,20 +2354,38 @@ int pop_device_sync(pop_ctx *c) {
 }
 // time `reps` launches of one kernel phase with HIP events on the launch stream (state is left as
 // the phase leaves it; callers use it between steps for roofline measurement only)
+typedef int (*phase_fn_t)(pop_ctx *);
+static phase_fn_t phase_by_name(const std::string &p) {
+  if (p == "vmix") return phase_vmix;
+  if (p == "tracer_rhs") return phase_tracer_rhs;
+  if (p == "impvmixt") return phase_impvmixt_pred;
+  if (p == "state") return phase_state_new;
+  if (p == "momentum_rhs") return phase_momentum_rhs;
+  if (p == "impvmixu") return [](pop_ctx *x) { return phase_impvmixu(x); };
+  if (p == "correct") return phase_correct;
+  if (p == "add_btrop") return [](pop_ctx *x) { return phase_add_btrop(x); };
+  if (p == "hmix_tracer") return [](pop_ctx *x) { return phase_hmix_tracer(x); };
+  if (p == "hmix_momentum") return [](pop_ctx *x) { return phase_hmix_momentum(x); };
+  return nullptr;
+}
+// one phase of baroclinic_driver / baroclinic_correct_adjust on its own, once, on the launch stream with the step
+// parameters pop_time_manager set: the public routines the reference's drivers call (vmix_coeffs vertical_mix.F90:518,
+// tracer_update baroclinic.F90:1902 [tracer_rhs; hmix_tracer = the first Laplacian of hdifft_del4], impvmixt
+// vertical_mix.F90:1164, state state_mod.F90:258 on the new tracers, clinic baroclinic.F90:1635 [momentum_rhs;
+// hmix_momentum = first Laplacian of hdiffu_del4], impvmixu vertical_mix.F90:1679 + baroclinic.F90:1077-1129,
+// impvmixt_correct :1460 [correct]).  Lets a caller -- and the parity tests -- drive and check the phases one by one.
+int pop_run_phase(pop_ctx *c, const char *phase) {
+  if (need_device(c) || join_side(c)) return 1;
+  phase_fn_t fn = phase_by_name(phase ? phase : "");
+  if (!fn) { c->err = std::string("unknown phase ") + (phase ? phase : "(null)"); return 1; }
+  if (fn(c)) return 1;
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 int pop_time_phase(pop_ctx *c, const char *phase, int reps, double *avg_ms) {
   if (need_device(c)) return 1;
   const std::string p(phase);
-  int (*fn)(pop_ctx *) = nullptr;
-  if (p == "vmix") fn = phase_vmix;
-  else if (p == "tracer_rhs") fn = phase_tracer_rhs;
-  else if (p == "impvmixt") fn = phase_impvmixt_pred;
-  else if (p == "state") fn = phase_state_new;
-  else if (p == "momentum_rhs") fn = phase_momentum_rhs;
-  else if (p == "impvmixu") fn = [](pop_ctx *x) { return phase_impvmixu(x); };
-  else if (p == "correct") fn = phase_correct;
-  else if (p == "add_btrop") fn = [](pop_ctx *x) { return phase_add_btrop(x); };
-  else if (p == "hmix_tracer") fn = [](pop_ctx *x) { return phase_hmix_tracer(x); };
-  else if (p == "hmix_momentum") fn = [](pop_ctx *x) { return phase_hmix_momentum(x); };
+  phase_fn_t fn = phase_by_name(p);
   if (!fn) { c->err = "unknown phase " + p; return 1; }
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));

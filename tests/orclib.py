@@ -35,6 +35,8 @@ def load():
     for f in ("orc_baroclinic_driver", "orc_barotropic_driver", "orc_step", "orc_solver_iterations"):
         getattr(L, f).argtypes = [C.c_void_p]
         getattr(L, f).restype = C.c_int
+    L.orc_baroclinic_stages.argtypes = [C.c_void_p, C.c_int]
+    L.orc_baroclinic_stages.restype = C.c_int
     L.orc_solver_rms.argtypes = [C.c_void_p]
     L.orc_solver_rms.restype = C.c_double
     L.orc_state_point.restype = C.c_double
@@ -156,6 +158,12 @@ class Oracle:
 
     def evp_info(self, what, idx=0):
         return self.L.orc_evp_info(self.h, what, idx)
+
+    STAGE = {"tracer_rhs": 1, "impvmixt": 2, "state": 4, "momentum_rhs": 8, "impvmixu": 16}
+
+    def run_phase(self, phase):
+        """one stage of baroclinic_driver on its own (the oracle's vmix_coeffs + tracer_update form one stage)"""
+        assert self.L.orc_baroclinic_stages(self.h, self.STAGE[phase]) == 0
 
     def step(self):
         e = self.L.orc_step(self.h)

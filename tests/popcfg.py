@@ -60,10 +60,13 @@ def base_config(**kw):
 
 def _apply(c, kw):
     """Set fields by name; robert_alpha / robert_nu live in reserved_d[1], [2] (tmix_opt = 3),
-    precond_choice (0 diagonal, 1 evp) in reserved_i[2]."""
+    precond_choice (0 diagonal, 1 evp) in reserved_i[2],
+    stepped_bathymetry (test extension: KMT = 3 ... km) in reserved_i[3]."""
     for k, v in kw.items():
         if k == "precond_choice":
             c.reserved_i[2] = v
+        elif k == "stepped_bathymetry":
+            c.reserved_i[3] = v
         elif k == "robert_alpha":
             c.reserved_d[1] = v
         elif k == "robert_nu":

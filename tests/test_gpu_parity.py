@@ -149,6 +149,13 @@ def force_kpp_case(gpu, orc):
     ("test", {"precond_choice": 1, "solver_choice": 3}, 4),
     ("tiny", {"tmix_opt": 3}, 5),                                    # Robert-Asselin-Williams filter (alpha 0.53, nu 0.2)
     ("tiny", {"tmix_opt": 3, "robert_alpha": 1.0, "vmix_choice": 3, "km": 24}, 5),   # classic Robert-Asselin: previous-step averaging
+    # stepped synthetic bathymetry (KMT = 3 ... km in stairs): every k > KMT / k > KMU branch, shallow columns in the Thomas solves
+    ("tiny", {"stepped_bathymetry": 1}, 4),
+    ("tiny", {"stepped_bathymetry": 1, "vmix_choice": 3, "km": 24, "ldbl_diff": 1}, 5),
+    ("tiny", {"stepped_bathymetry": 1, "vmix_choice": 2, "hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1, "am": -1.0e22, "ah": -1.0e21}, 4),
+    ("tiny", {"stepped_bathymetry": 1, "tadvect": 2, "solver_choice": 2}, 4),
+    ("tiny", {"stepped_bathymetry": 1, "km": 60, "vmix_choice": 3}, 3),                  # register Thomas kernels with shallow columns
+    ("gx3v7", {"stepped_bathymetry": 1, "solver_choice": 3}, 3),
 ])
 def test_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
     cfg = named_config(name, **kw)

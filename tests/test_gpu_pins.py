@@ -1,0 +1,68 @@
+"""The independent pins of tests/pins.py against the DEVICE library through the C ABI (pop_run_phase): LAPACK for the
+implicit vertical solves -- generic kernels (km = 16, 20) and the column-in-registers kernels (km = 60, 62), with shallow
+and land columns --, closed forms for the pressure gradient and horizontal diffusion."""
+import numpy as np
+import pytest
+
+import pins
+from popcfg import named_config
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("const-km16-stepped", dict(stepped_bathymetry=1)),
+    ("kpp-km20-stepped", dict(vmix_choice=3, km=20, stepped_bathymetry=1)),
+    ("kpp-km60-stepped", dict(vmix_choice=3, km=60, stepped_bathymetry=1)),      # k_impvmixt_reg<60>, k_impvmixu_reg<60>
+    ("kpp-km62-del4-stepped", dict(vmix_choice=3, km=62, stepped_bathymetry=1, hmix_tracer=4, hmix_momentum=4, am=-1.0e19, ah=-1.0e19)),
+    ("rich-flat", dict(vmix_choice=2)),
+]
+
+
+@pytest.fixture(params=CASES, ids=[c[0] for c in CASES])
+def adapter(request, pkg):
+    A = pins.GpuAdapter(pkg, named_config("tiny", **request.param[1]))
+    yield A
+    A.close()
+
+
+def test_impvmixt_solves_its_tridiagonal_system(adapter):
+    pins.check_impvmixt(adapter, np.random.default_rng(11))
+
+
+def test_impvmixt_correct_solves_its_tridiagonal_system(adapter):
+    pins.check_impvmixt_correct(adapter, np.random.default_rng(12))
+
+
+def test_impvmixu_and_mean_removal_match_lapack(adapter):
+    pins.check_impvmixu(adapter, np.random.default_rng(13))
+
+
+@pytest.mark.parametrize("env", [{}, {"POP_GENERIC_THOMAS": "1"}], ids=["register-kernels", "generic-kernels"])
+def test_thomas_kernel_variants_km60(pkg, env, monkeypatch):
+    """both implementations of the km = 60 solves against LAPACK"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for check, seed in ((pins.check_impvmixt, 21), (pins.check_impvmixt_correct, 22), (pins.check_impvmixu, 23)):
+        A = pins.GpuAdapter(pkg, named_config("tiny", vmix_choice=3, km=60, stepped_bathymetry=1))
+        check(A, np.random.default_rng(seed))
+        A.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stepped_bathymetry=1), dict(impcor=0), dict(hmix_momentum=4, am=-1.0e19), dict(km=60)],
+                         ids=["flat", "stepped", "explicit-coriolis", "del4", "km60"])
+def test_pressure_gradient_closed_forms(kw, pkg, monkeypatch):
+    for lds in ("8", "0"):                       # LDS-tiled and direct-load momentum kernels
+        monkeypatch.setenv("POP_MOMENTUM_LDS", lds)
+        A = pins.GpuAdapter(pkg, named_config("tiny", **kw))
+        pins.check_gradp(A)
+        A.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(hmix_tracer=4, ah=-1.0e19), dict(hmix_tracer=4, ah=-1.0e19, lvariable_hmix=1), dict(vmix_choice=3, km=20)],
+                         ids=["del2", "del4", "del4-variable", "del2-kpp"])
+def test_tracer_diffusion_of_a_quadratic_field(kw, pkg, monkeypatch):
+    for lds in ("8", "0"):                       # LDS-tiled and direct-load tracer kernels
+        monkeypatch.setenv("POP_TRACER_LDS", lds)
+        A = pins.GpuAdapter(pkg, named_config("tiny", block_size_x=48, block_size_y=40, **kw))
+        pins.check_hdifft(A)
+        A.close()

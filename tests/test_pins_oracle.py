@@ -1,0 +1,48 @@
+"""The independent pins of tests/pins.py against the CPU oracle (no GPU): LAPACK for the implicit vertical solves, closed
+forms for the pressure gradient and for horizontal diffusion.  tests/test_gpu_pins.py runs the same checks on the device."""
+import numpy as np
+import pytest
+
+import pins
+from popcfg import named_config
+
+CASES = [
+    ("const-stepped", dict(stepped_bathymetry=1)),                              # shallow columns: KMT = 8 ... 16
+    ("kpp-km20-stepped", dict(vmix_choice=3, km=20, stepped_bathymetry=1)),     # two VDC fields
+    ("rich-flat", dict(vmix_choice=2)),
+]
+
+
+@pytest.fixture(params=CASES, ids=[c[0] for c in CASES])
+def adapter(request, orclib_built):
+    A = pins.OracleAdapter(named_config("tiny", **request.param[1]))
+    yield A
+    A.close()
+
+
+def test_impvmixt_solves_its_tridiagonal_system(adapter):
+    pins.check_impvmixt(adapter, np.random.default_rng(11))
+
+
+def test_impvmixt_correct_solves_its_tridiagonal_system(adapter):
+    pins.check_impvmixt_correct(adapter, np.random.default_rng(12))
+
+
+def test_impvmixu_and_mean_removal_match_lapack(adapter):
+    pins.check_impvmixu(adapter, np.random.default_rng(13))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stepped_bathymetry=1), dict(impcor=0), dict(hmix_momentum=4, am=-1.0e19)],
+                         ids=["flat", "stepped", "explicit-coriolis", "del4"])
+def test_pressure_gradient_closed_forms(kw, orclib_built):
+    A = pins.OracleAdapter(named_config("tiny", **kw))
+    pins.check_gradp(A)
+    A.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(hmix_tracer=4, ah=-1.0e19), dict(hmix_tracer=4, ah=-1.0e19, lvariable_hmix=1), dict(vmix_choice=3, km=20)],
+                         ids=["del2", "del4", "del4-variable", "del2-kpp"])
+def test_tracer_diffusion_of_a_quadratic_field(kw, orclib_built):
+    A = pins.OracleAdapter(named_config("tiny", block_size_x=48, block_size_y=40, **kw))
+    pins.check_hdifft(A)
+    A.close()
