@@ -149,6 +149,219 @@ k_kpp_buoydiff_col(DevGrid g, KppDev kp, const double *__restrict__ T, const dou
   }
 }
 
+// ---- buoydiff, level-parallel form with the surface layer in LDS ---------------------------------------------------
+// The column form above is VALU-bound at one or two waves per SIMD (60 register doubles for the prepared surface-layer
+// levels).  Here a workgroup owns 64 columns and NG waves share them: the prepared top KR levels (clamped T, 1000 S,
+// pressure-independent denominator term) are formed once into LDS (KR * 3 * 512 B = 30 KB for KR = 20), and wave g takes the
+// levels k = 2 + g, 2 + g + NG, ... (interleaved: the work per level grows with kref).  A thread keeps no column state, so
+// five workgroups fit a CU and the divisions of one wave hide behind the others.  Every (i,j,k) value is formed by the same
+// operations in the same order as in k_kpp_buoydiff / k_kpp_buoydiff_col: bitwise equal (tested).
+template <int KR, int NG>
+__global__ void __launch_bounds__(POP_COL_THREADS * NG)
+k_kpp_buoydiff_lds(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
+                   double *__restrict__ DBLOC, double *__restrict__ DBSFC) {
+  __shared__ double top[3][KR][POP_COL_THREADS];
+  const int tx = threadIdx.x, gy = threadIdx.y;
+  // same column order as col_setup (xcd_remap 0 / 1); surplus threads keep running to the barrier with a clamped column
+  const int tile = g.xcd_remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const long long p2raw = (long long)tile * POP_COL_THREADS + tx;
+  const bool live = p2raw < g.n2;
+  const int p2 = live ? (int)p2raw : 0;
+  const int b = blockIdx.y, km = g.km;
+  const long long n2 = g.n2, base3 = (long long)b * g.n3 + p2;
+  for (int t = 1 + gy; t <= KR; t += NG) {
+    const int kk = (t <= km) ? t : km;
+    const long long o = base3 + (long long)(kk - 1) * n2;
+    const MwjfTS2 x = mwjf_prep2(tmask(T[o]), S[o]);
+    top[0][t - 1][tx] = x.TQ; top[1][t - 1][tx] = x.SQ; top[2][t - 1][tx] = x.A2;
+  }
+  __syncthreads();
+  if (!live) return;
+  const int kmt = g.KMT[(long long)b * n2 + p2];
+  if (gy == 0) DBSFC[base3] = 0.0;
+  auto top_at = [&](int t) { MwjfTS2 x; x.TQ = top[0][t - 1][tx]; x.SQ = top[1][t - 1][tx]; x.A2 = top[2][t - 1][tx]; return x; };
+  for (int k = 2 + gy; k <= km; k += NG) {
+    const long long o = base3 + (long long)(k - 1) * n2;
+    const double tk = T[o], sk = S[o], tm = T[o - n2], sm = S[o - n2];
+    const MwjfTS2 xk = mwjf_prep2(tmask(tk), sk), xkm = mwjf_prep2(tmask(tm), sm);
+    const MwjfP P = mwjf_level(g.pressz[k]);
+    const double rhokm = mwjf_eval2(P, xkm);
+    const double rhok = mwjf_eval2(P, xk);
+    const double surfthick = KPP_EPSSFC * g.zt[k];
+    const int kref = kp.kref[k];                 // wave-uniform (k is)
+    double rhoavg = mwjf_eval2(P, top_at(kref));
+    if (kref != 1) {
+      rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
+      for (int kt = 1; kt <= kref - 1; ++kt) rhoavg = rhoavg + g.dz[kt] * mwjf_eval2(P, top_at(kt));
+      rhoavg = rhoavg / surfthick;
+    }
+    double dbs = 0.0, dbl = 0.0;
+    if (rhok != 0.0) { dbs = GRAV * (1.0 - rhoavg / rhok); dbl = GRAV * (1.0 - rhokm / rhok); }
+    if (k - 1 >= kmt) dbl = 0.0;
+    DBSFC[o] = dbs;
+    DBLOC[o - n2] = dbl;
+    if (k == km) DBLOC[o] = 0.0;
+  }
+}
+
+// ---- buoydiff + ri_iwmix + ddmix in one level-parallel launch ------------------------------------------------------
+// k_kpp_buoydiff_lds continued through the interior coefficients: the wave that forms DBLOC(k-1) also forms the local
+// Richardson number of that interface (velocity shear at the four surrounding U points, two levels) into a second LDS
+// array; after a barrier the "carry below the bottom" rule, the 1-2-1 smoothing and the coefficients -- all local in
+// k +- 1 -- are evaluated level-parallel from it.  T, S, U, V are read and DBLOC, DBSFC, VISC, VDC written once; the
+// Richardson scratch field and the second pass over T, S, U, V of the column kernels are gone.  All loops stay rolled (a
+// fully unrolled variant was 153 KB of code and ran at instruction-cache speed: 20 ms instead of 9).  Same operations
+// in the same order per value as k_kpp_buoydiff_col + k_kpp_interior(_reg): bitwise equal (tested).  km <= 64.
+template <int KR, int NG>
+__global__ void __launch_bounds__(POP_COL_THREADS * NG)
+k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
+                        const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ DBLOC,
+                        double *__restrict__ DBSFC, double *__restrict__ VISC, double *__restrict__ VDC1, double *__restrict__ VDC2) {
+  constexpr int KMR = 64, TOPR = (3 * KR > KMR) ? 3 * KR : KMR;
+  __shared__ double shtop[TOPR][POP_COL_THREADS];   // prepared surface-layer levels; later the smoothing ping-pong buffer
+  __shared__ double shri[KMR][POP_COL_THREADS];     // Richardson number of level k at row k - 1
+  const int tx = threadIdx.x, gy = threadIdx.y;
+  const int tile = g.xcd_remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const long long p2raw = (long long)tile * POP_COL_THREADS + tx;
+  const bool live = p2raw < g.n2;
+  const int p2 = live ? (int)p2raw : 0;
+  const int b = blockIdx.y, km = g.km, nxb = g.nxb;
+  const long long n2 = g.n2, base3 = (long long)b * g.n3 + p2;
+  const int ci = p2 % nxb, cj = p2 / nxb;
+  const bool edge = (ci == 0 || cj == 0);          // ugrid_to_tgrid zeroes the first row and column
+  for (int t = 1 + gy; t <= KR; t += NG) {
+    const int kk = (t <= km) ? t : km;
+    const long long o = base3 + (long long)(kk - 1) * n2;
+    const MwjfTS2 x = mwjf_prep2(tmask(T[o]), S[o]);
+    shtop[t - 1][tx] = x.TQ; shtop[KR + t - 1][tx] = x.SQ; shtop[2 * KR + t - 1][tx] = x.A2;
+  }
+  __syncthreads();
+  const int kmt = live ? g.KMT[(long long)b * n2 + p2] : 0;
+  auto top_at = [&](int t) { MwjfTS2 x; x.TQ = shtop[t - 1][tx]; x.SQ = shtop[KR + t - 1][tx]; x.A2 = shtop[2 * KR + t - 1][tx]; return x; };
+  const long long off4[4] = {0, -(long long)nxb, -1, -1 - (long long)nxb};
+  if (live && gy == 0) DBSFC[base3] = 0.0;
+#pragma unroll 1
+  for (int k = 2 + gy; k <= km; k += NG) {
+    double ri = 0.0;
+    if (live) {
+      const long long o = base3 + (long long)(k - 1) * n2;
+      const double tk = T[o], sk = S[o], tm = T[o - n2], sm = S[o - n2];
+      double sh4[4] = {0.0, 0.0, 0.0, 0.0};
+      if (!edge) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const long long q = o + off4[t];
+          const double du = U[q - n2] - U[q], dv = V[q - n2] - V[q];
+          sh4[t] = du * du + dv * dv;
+        }
+      }
+      const MwjfTS2 xk = mwjf_prep2(tmask(tk), sk), xkm = mwjf_prep2(tmask(tm), sm);
+      const MwjfP P = mwjf_level(g.pressz[k]);
+      const double rhokm = mwjf_eval2(P, xkm);
+      const double rhok = mwjf_eval2(P, xk);
+      const double surfthick = KPP_EPSSFC * g.zt[k];
+      const int kref = kp.kref[k];                 // wave-uniform (k is)
+      double rhoavg = mwjf_eval2(P, top_at(kref));
+      if (kref != 1) {
+        rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
+#pragma unroll 1
+        for (int kt = 1; kt <= kref - 1; ++kt) rhoavg = rhoavg + g.dz[kt] * mwjf_eval2(P, top_at(kt));
+        rhoavg = rhoavg / surfthick;
+      }
+      double dbs = 0.0, dbl = 0.0;
+      if (rhok != 0.0) { dbs = GRAV * (1.0 - rhoavg / rhok); dbl = GRAV * (1.0 - rhokm / rhok); }
+      if (k - 1 >= kmt) dbl = 0.0;
+      DBSFC[o] = dbs;
+      DBLOC[o - n2] = dbl;
+      if (k == km) DBLOC[o] = 0.0;
+      double vsh = 0.0;
+      if (!edge) vsh = 0.25 * sh4[0] + 0.25 * sh4[1] + 0.25 * sh4[2] + 0.25 * sh4[3];
+      ri = dbl * (kp.zgrid[k - 1] - kp.zgrid[k]) / (vsh + KPP_EPS);
+    }
+    shri[k - 2][tx] = ri;                           // level k - 1
+  }
+  if (gy == 0) shri[km - 1][tx] = 0.0 * (kp.zgrid[km] - kp.zgrid[km + 1]) / (0.0 + KPP_EPS);   // DBLOC(km) = 0, no shear below
+  __syncthreads();                                  // Richardson column complete; the surface-layer levels are dead
+  // WORK0 of ri_iwmix: below the bottom the last ocean value is carried (0 on land)
+  const double carry = (kmt >= 1) ? shri[kmt - 1][tx] : 0.0;
+  auto w0 = [&](int k) { return (k <= kmt) ? shri[k - 1][tx] : carry; };
+  // smoothing passes that are not the last write a full column into the other buffer (old values are never overwritten)
+  double (*src)[POP_COL_THREADS] = nullptr;          // nullptr: read through w0()
+  double (*dst)[POP_COL_THREADS] = shtop;
+  for (int pass = 0; pass + 1 < kp.nsmooth; ++pass) {
+#pragma unroll 1
+    for (int k = 1 + gy; k <= km; k += NG) {
+      const double cur = src ? src[k - 1][tx] : w0(k);
+      double v = cur;
+      if (kmt >= 3) {
+        const double w1 = 0.25 * ((k > 1) ? (src ? src[k - 2][tx] : w0(k - 1)) : cur);
+        const double nxt = (k < km) ? (src ? src[k][tx] : w0(k + 1)) : cur;
+        v = w1 + 0.5 * cur + 0.25 * nxt;
+      }
+      dst[k - 1][tx] = v;
+    }
+    __syncthreads();
+    src = dst; dst = (dst == shtop) ? shri : shtop;
+  }
+  if (!live) return;
+  // last smoothing pass + coefficients (+ double diffusion), level by level
+  const long long vb = ((long long)b * (km + 2)) * n2 + p2;
+#pragma unroll 1
+  for (int k = 1 + gy; k <= km; k += NG) {
+    const long long o = base3 + (long long)(k - 1) * n2;
+    const double cur = src ? src[k - 1][tx] : w0(k);
+    double riw = cur;
+    if (kp.nsmooth >= 1 && kmt >= 3) {
+      const double w1 = 0.25 * ((k > 1) ? (src ? src[k - 2][tx] : w0(k - 1)) : cur);
+      const double nxt = (k < km) ? (src ? src[k][tx] : w0(k + 1)) : cur;
+      riw = w1 + 0.5 * cur + 0.25 * nxt;
+    }
+    double fri = fmax(riw, 0.0) / KPP_RIINFTY;
+    fri = fmin(fri, 1.0);
+    double visc, vd1 = 0.0, vd2 = 0.0;
+    if (kp.lrich) {
+      const double f = 1.0 - fri * fri;
+      const double f3 = (f * f) * f;
+      visc = kp.bckgrnd_vvc[k] + kp.rich_mix * f3;
+      if (k < km) { vd2 = kp.bckgrnd_vdc[k] + kp.rich_mix * f3; vd1 = vd2; }
+    } else {
+      visc = kp.bckgrnd_vvc[k];
+      if (k < km) { vd2 = kp.bckgrnd_vdc[k]; vd1 = vd2; }
+    }
+    if (k >= kmt) { visc = 0.0; vd1 = 0.0; vd2 = 0.0; }
+    if (kp.ldbl_diff) {
+      const double t_k = T[o], s_k = S[o];
+      double ta_u = 0.0, sb_u = 0.0;
+      { const MwjfP Pk = mwjf_level(g.pressz[k]); (void)mwjf_rho<true>(Pk, tmask(t_k), s_k, &ta_u, &sb_u); }
+      double alphadt = 0.0, betads = 0.0, ta_n = 0.0, sb_n = 0.0, t_n = 0.0, s_n = 0.0;
+      if (k < km) {
+        t_n = T[o + n2]; s_n = S[o + n2];
+        const MwjfP Pn = mwjf_level(g.pressz[k + 1]);
+        (void)mwjf_rho<true>(Pn, tmask(t_n), s_n, &ta_n, &sb_n);
+        alphadt = -0.5 * (ta_u + ta_n) * (t_k - t_n);
+        betads = 0.5 * (sb_u + sb_n) * (s_k - s_n);
+      }
+      if (alphadt > betads && betads > 0.0) {
+        const double rrho = fmin(alphadt / betads, KPP_RRHO0);
+        const double f = 1.0 - (rrho - 1.0) / (KPP_RRHO0 - 1.0);
+        const double diffdd = KPP_DSFMAX * ((f * f) * f);
+        vd1 = vd1 + 0.7 * diffdd; vd2 = vd2 + diffdd;
+      }
+      double rrho = 0.0, diffdd = 0.0, prandtl = 0.0;
+      if (alphadt < 0.0 && betads < 0.0 && alphadt > betads) {
+        rrho = alphadt / betads;
+        diffdd = 1.5e-2 * 0.909 * exp(4.6 * exp(-0.54 * (1.0 / rrho - 1.0)));
+        prandtl = 0.15 * rrho;
+      }
+      if (rrho > 0.5) prandtl = (1.85 - 0.85 / rrho) * rrho;
+      vd1 = vd1 + diffdd; vd2 = vd2 + prandtl * diffdd;
+    }
+    VISC[o] = visc;
+    VDC1[vb + (long long)k * n2] = vd1;
+    VDC2[vb + (long long)k * n2] = vd2;
+  }
+}
+
 // ---- bldepth part 1, column form: U, V of the top KR levels in registers, each level read once ----
 template <int KR>
 __global__ void __launch_bounds__(POP_COL_THREADS)
@@ -694,8 +907,8 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   // the column form halves the instruction count by hoisting the pressure-independent half of the equation of
   // state, but its 3 x 20 register doubles leave one wave per SIMD).  POP_KPP_COL = bit mask (1 ushear,
   // 2 buoydiff) overrides.
-  K->col = (K->max_kref <= 24) ? ((h.n2 * h.nblocks > (1u << 19)) ? 3 : 1) : 0;   // ushear: column form at every size (gx1v7 vmix 0.716 -> 0.692 ms)
-  if (getenv("POP_KPP_COL")) K->col = (K->max_kref <= 24) ? atoi(getenv("POP_KPP_COL")) : 0;
+  K->col = (K->max_kref <= 24) ? ((h.n2 * h.nblocks > (1u << 19)) ? 15 : 1) : 0;   // ushear: column form at every size (gx1v7 vmix 0.716 -> 0.692 ms)
+  if (getenv("POP_KPP_COL")) K->col = (K->max_kref <= 24) ? atoi(getenv("POP_KPP_COL")) : 0;   // bit 0 ushear column form, bit 1 buoydiff column form, bit 2 buoydiff LDS form, bit 3 buoydiff + interior fused
   (void)g; (void)m;
   return 0;
 }
@@ -717,7 +930,14 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   // two waves per SIMD (<= 256 VGPRs, ~80 spilled) beat one wave with everything in registers: the kernel is VALU-bound
   // and a second wave fills the division / dependency stalls of the first (POP_KPP_BUOY_WAVES=1 keeps one wave)
   static const int bw = getenv("POP_KPP_BUOY_WAVES") ? atoi(getenv("POP_KPP_BUOY_WAVES")) : 2;
-  if ((g_kpp_col & 2) && KH.max_kref <= 20 && bw == 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<20, 2>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  // level-parallel LDS form (bit 2 of the mask; the default on bandwidth-bound grids, linear column order only)
+  const dim3 GL(col_grid_x(g.n2, POP_COL_THREADS), g.nblocks), BL(POP_COL_THREADS, 4);
+  // bit 3: buoydiff and the interior coefficients in ONE level-parallel launch
+  const bool fused_bi = (g_kpp_col & 8) && KH.max_kref <= 20 && g.xcd_remap != 2 && g.km <= 64;
+  if (fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
+  else if ((g_kpp_col & 4) && KH.max_kref <= 20 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<20, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  else if ((g_kpp_col & 4) && KH.max_kref <= 28 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<28, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  else if ((g_kpp_col & 2) && KH.max_kref <= 20 && bw == 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<20, 2>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if ((g_kpp_col & 2) && KH.max_kref <= 20) hipLaunchKernelGGL((k_kpp_buoydiff_col<20, 1>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if ((g_kpp_col & 2) && bw == 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<24, 2>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if (g_kpp_col & 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<24, 1>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
@@ -731,7 +951,8 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
     hipEventRecord(KH.ev_join, KH.side);
   }
   static const bool int_reg = !getenv("POP_KPP_INTERIOR_GENERIC");
-  if (int_reg && g.km == 60) hipLaunchKernelGGL(k_kpp_interior_reg<60>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
+  if (fused_bi) {}
+  else if (int_reg && g.km == 60) hipLaunchKernelGGL(k_kpp_interior_reg<60>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else if (int_reg && g.km == 62) hipLaunchKernelGGL(k_kpp_interior_reg<62>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
   if (KH.side) hipStreamWaitEvent(st, KH.ev_join, 0);

@@ -20,7 +20,9 @@ struct MomTile {
   static_assert(NHALO <= POP_COL_THREADS * R, "every halo cell needs a thread");
 };
 
-template <int R>
+// PF: how many levels ahead the cells of the stencil fields are loaded (1: the next level while this one is computed;
+// 2: two levels in flight, 26 more registers)
+template <int R, int PF = 1>
 __global__ void __launch_bounds__(POP_COL_THREADS * R)
 k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a) {
   using T = MomTile<R>;
@@ -103,6 +105,8 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a) {
   };
   Lev cur = load_cell(1);
   Hal hal = load_halo(1);
+  Lev nxt = cur; Hal nhal = hal;
+  if (PF == 2) { nxt = load_cell(km > 1 ? 2 : 1); nhal = load_halo(km > 1 ? 2 : 1); }
   double *__restrict__ const UNp = a.UNEW;
   double *__restrict__ const VNp = a.VNEW;
   for (int k = 1; k <= km; ++k) {
@@ -110,8 +114,9 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a) {
     t.u[buf][lc] = cur.u; t.v[buf][lc] = cur.v; t.f[buf][lc] = cur.f; t.um[buf][lc] = cur.um; t.vm[buf][lc] = cur.vm;
     if (hl >= 0) { t.u[buf][hl] = hal.u; t.v[buf][hl] = hal.v; t.f[buf][hl] = hal.f; t.um[buf][hl] = hal.um; t.vm[buf][hl] = hal.vm; }
     const int kp1 = (k < km) ? k + 1 : km;
-    const Lev nxt = load_cell(kp1);          // in flight while this level is computed
-    const Hal nhal = load_halo(kp1);
+    Lev nx2 = nxt; Hal nh2 = nhal;
+    if (PF == 1) { nxt = load_cell(kp1); nhal = load_halo(kp1); }          // in flight while this level is computed
+    else { const int kp2 = (k + 2 <= km) ? k + 2 : km; nx2 = load_cell(kp2); nh2 = load_halo(kp2); }
     __syncthreads();
     if (act) {
       const long long o = base3 + (long long)(k - 1) * n2;
@@ -208,6 +213,7 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a) {
 #undef VV
     }
     cur = nxt; hal = nhal;
+    if (PF == 2) { nxt = nx2; nhal = nh2; }
   }
   if (act) { a.ZX[q2] = zx * hur; a.ZY[q2] = zy * hur; }
 }
@@ -216,7 +222,9 @@ template <int R>
 inline void launch_momentum_lds(const DevGrid &g, const StepParams &sp, const MomentumRhsArgs &a, hipStream_t st) {
   const int tiles_i = (g.nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
   const int tiles_j = (g.nyb - 2 * NGHOST + R - 1) / R;
-  hipLaunchKernelGGL(k_momentum_rhs_lds<R>, dim3(lds_grid_x(g.lds_order, tiles_i, tiles_j), g.nblocks), dim3(POP_COL_THREADS, R), 0, st, g, sp, a);
+  static const int pf = getenv("POP_MOMENTUM_PF") ? atoi(getenv("POP_MOMENTUM_PF")) : 1;
+  if (pf == 2) hipLaunchKernelGGL((k_momentum_rhs_lds<R, 2>), dim3(lds_grid_x(g.lds_order, tiles_i, tiles_j), g.nblocks), dim3(POP_COL_THREADS, R), 0, st, g, sp, a);
+  else hipLaunchKernelGGL((k_momentum_rhs_lds<R, 1>), dim3(lds_grid_x(g.lds_order, tiles_i, tiles_j), g.nblocks), dim3(POP_COL_THREADS, R), 0, st, g, sp, a);
 }
 
 }  // namespace pop

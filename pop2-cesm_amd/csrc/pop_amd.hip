@@ -58,6 +58,12 @@ struct pop_ctx {
   bool side_del4 = false, vmixu_pending = false, btrop_added = false;   // implicit vertical mixing of U,V in flight on the side stream
   double *HBLT = nullptr, *HMXL = nullptr;
   MixDev mix{};
+  // KPP look-ahead: the vertical-mixing coefficients of the NEXT step depend only on this step's curtime fields (its
+  // mixtime on a leapfrog step), so pop_step computes them on a third stream beside the barotropic solver (VALU-bound
+  // work beside bandwidth-bound work) into a second set of output fields; the next step swaps the sets in.
+  double *VDCa[2] = {nullptr, nullptr}, *VVCa = nullptr, *KPPa[MAXNT] = {}, *HBLTa = nullptr;
+  hipStream_t ahead = nullptr; hipEvent_t ev_ahead_fork = nullptr, ev_ahead = nullptr;
+  bool ahead_enabled = false, ahead_valid = false; int ahead_slot = -1;
   // solver
   double *R = nullptr, *S0 = nullptr, *S1 = nullptr, *Q = nullptr, *Z = nullptr, *AZ = nullptr;
   double *partial = nullptr, *blocksum = nullptr;
@@ -1338,6 +1344,16 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     HIPCHK(c, hipMemcpy(c->VVC, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (mix_create(c->h, c->g, c->mix, c->allocs, c->err)) return 1;
+  // KPP look-ahead (bandwidth-bound grids; POP_KPP_AHEAD=0|1 overrides): second set of KPP outputs, own stream
+  c->ahead_enabled = cfg->vmix_choice == 3 && c->side && (h.n2 * h.nblocks > (1u << 19));
+  if (getenv("POP_KPP_AHEAD")) c->ahead_enabled = cfg->vmix_choice == 3 && c->side && atoi(getenv("POP_KPP_AHEAD")) != 0;
+  if (c->ahead_enabled) {
+    for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->VDCa[n], (size_t)(h.km + 2) * a2) || dev_alloc(c, &c->KPPa[n], a3)) return 1;
+    if (dev_alloc(c, &c->VVCa, a3) || dev_alloc(c, &c->HBLTa, a2)) return 1;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->ahead, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_ahead_fork, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming));
+  }
   // initial state (initial.F90:1389-1427, 1660-1676): T,S on all three levels, RHO(cur), RHO(old)
   c->oldt = 0; c->curt = 1; c->newt = 2; c->mixt = 1;
   for (int t = 0; t < 3; ++t) {
@@ -1361,6 +1377,9 @@ int pop_destroy(pop_ctx *c) {
   if (c->ev_d2t) hipEventDestroy(c->ev_d2t);
   if (c->ev_d2u) hipEventDestroy(c->ev_d2u);
   if (c->ev_vmixu) hipEventDestroy(c->ev_vmixu);
+  if (c->ahead) { hipStreamSynchronize(c->ahead); hipStreamDestroy(c->ahead); }
+  if (c->ev_ahead_fork) hipEventDestroy(c->ev_ahead_fork);
+  if (c->ev_ahead) hipEventDestroy(c->ev_ahead);
   if (c->ev_sa) hipEventDestroy(c->ev_sa);
   if (c->ev_sx) hipEventDestroy(c->ev_sx);
   for (auto &e : c->chk_ev) if (e) hipEventDestroy(e);
@@ -1445,8 +1464,16 @@ long long pop_field_count(const pop_ctx *c, const char *name) {
   return a2;
 }
 // wait for side-stream work whose results the launch stream (or the host) is about to use
-static int join_side(pop_ctx *c) {
+// drop a KPP look-ahead in flight: whatever follows on the launch stream is ordered after it, and the next step computes
+// its coefficients itself.  Every entry point through which a caller may read or change fields (join_side) does this, so
+// only an uninterrupted sequence of pop_step calls uses the look-ahead.
+static int ahead_cancel(pop_ctx *c) {
+  if (c->ahead_valid) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0)); c->ahead_valid = false; }
+  return 0;
+}
+static int join_side(pop_ctx *c, bool keep_ahead = false) {
   if (c->vmixu_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_vmixu, 0)); c->vmixu_pending = false; }
+  if (!keep_ahead && ahead_cancel(c)) return 1;
   return 0;
 }
 int pop_get_field(pop_ctx *c, const char *name, int tl, int n, double *host, long long count) {
@@ -1636,19 +1663,49 @@ int pop_dhdt(pop_ctx *c) {
 }
 
 // launchers of the individual baroclinic phases (also used by pop_time_phase)
+static MixState kpp_mix_state(pop_ctx *c, int slot, bool into_alt) {
+  MixState ms{};
+  for (int n = 0; n < 2; ++n) {
+    ms.TMIX[n] = c->TR[n][slot]; ms.STF[n] = c->STF[n];
+    ms.KPP_SRC[n] = into_alt ? c->KPPa[n] : c->KPP_SRC[n]; ms.VDC[n] = into_alt ? c->VDCa[n] : c->VDC[n];
+  }
+  ms.UMIX = c->U[slot]; ms.VMIX = c->V[slot]; ms.UCUR = c->U[c->curt]; ms.VCUR = c->V[c->curt]; ms.RHOMIX = c->RHO[slot];
+  ms.VVC = into_alt ? c->VVCa : c->VVC; ms.SHF_QSW = c->SHF_QSW; ms.HBLT = into_alt ? c->HBLTa : c->HBLT; ms.HMXL = c->HMXL;
+  ms.S3a = c->S3a; ms.S3b = c->S3b; ms.S3c = c->S3c; ms.S3d = c->S3d; ms.E3 = c->E3; ms.F3 = c->F3;
+  return ms;
+}
 static int phase_vmix(pop_ctx *c) {
   const pop_config &cf = c->h.c;
   const StepParams sp = step_params(c);
   if (cf.vmix_choice == 1)
     hipLaunchKernelGGL(k_vmix_const, grid_3d(c), dim3(256), 0, c->stream, c->g, sp, c->TR[0][c->mixt], c->TR[1][c->mixt], c->VDC[0], c->VVC);
   else {
-    MixState ms{};
-    for (int n = 0; n < 2; ++n) { ms.TMIX[n] = c->TR[n][c->mixt]; ms.KPP_SRC[n] = c->KPP_SRC[n]; ms.STF[n] = c->STF[n]; ms.VDC[n] = c->VDC[n]; }
-    ms.UMIX = c->U[c->mixt]; ms.VMIX = c->V[c->mixt]; ms.UCUR = c->U[c->curt]; ms.VCUR = c->V[c->curt]; ms.RHOMIX = c->RHO[c->mixt];
-    ms.VVC = c->VVC; ms.SHF_QSW = c->SHF_QSW; ms.HBLT = c->HBLT; ms.HMXL = c->HMXL;
-    ms.S3a = c->S3a; ms.S3b = c->S3b; ms.S3c = c->S3c; ms.S3d = c->S3d; ms.E3 = c->E3; ms.F3 = c->F3;
+    if (c->ahead_valid && c->ahead_slot == c->mixt) {   // computed beside the previous step's solver: swap the output sets in
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+      c->ahead_valid = false;
+      for (int n = 0; n < 2; ++n) { std::swap(c->VDC[n], c->VDCa[n]); std::swap(c->KPP_SRC[n], c->KPPa[n]); }
+      std::swap(c->VVC, c->VVCa); std::swap(c->HBLT, c->HBLTa);
+      return 0;
+    }
+    if (ahead_cancel(c)) return 1;
+    const MixState ms = kpp_mix_state(c, c->mixt, false);
     if (mix_vmix_coeffs(c->h, c->g, sp, c->mix, ms, c->stream, c->err)) return 1;
   }
+  return 0;
+}
+// KPP of the next step on the look-ahead stream.  Valid when the next step is a leapfrog step (mixtime = its oldtime = this
+// step's curtime) and nothing rewrites the curtime fields before then (no averaging step, no Robert filter).  Inputs:
+// T, S, U, V at curtime and the surface fluxes; scratch: the 3-D work fields, idle between baroclinic_driver and the
+// next step; outputs: the second set of VDC / VVC / KPP_SRC / HBLT.
+static int kpp_look_ahead(pop_ctx *c) {
+  // an averaging step rewrites oldtime and curtime in its tail and does not rotate; the Robert filter rewrites curtime
+  if (!c->ahead_enabled || c->h.c.vmix_choice != 3 || c->avg_ts || c->h.c.tmix_opt == 3) return 0;
+  HIPCHK(c, hipEventRecord(c->ev_ahead_fork, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->ahead, c->ev_ahead_fork, 0));
+  const MixState ms = kpp_mix_state(c, c->curt, true);
+  if (mix_vmix_coeffs(c->h, c->g, step_params(c), c->mix, ms, c->ahead, c->err)) return 1;
+  HIPCHK(c, hipEventRecord(c->ev_ahead, c->ahead));
+  c->ahead_valid = true; c->ahead_slot = c->curt;
   return 0;
 }
 static int phase_hmix_tracer(pop_ctx *c, hipStream_t st = nullptr) {   // del4 only: first Laplacian of the tracers into d2t
@@ -1936,7 +1993,7 @@ int pop_step_tail(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "3D-UPDATE");
   const int km = c->g.km;
-  if (join_side(c)) return 1;
+  if (join_side(c, true)) return 1;
   {   // the seven updates of step_mod.F90:467-560 as one message per neighbour
     std::vector<HaloItem> items = {{c->UB[c->newt], 1}, {c->VB[c->newt], 1}, {c->U[c->newt], km}, {c->V[c->newt], km}, {c->RHO[c->newt], km}};
     for (int n = 0; n < c->h.nt; ++n) items.push_back({c->TR[n][c->newt], km});
@@ -1974,8 +2031,8 @@ int pop_step(pop_ctx *c) {
   if (c->h.c.ns_boundary == 2) { c->err = "time stepping on a tripole decomposition needs a tripole grid (not built): only halo updates are"; return 1; }
   ScopedPhase ph(c, "STEP");
   int e;
-  if ((e = pop_time_manager(c)) || (e = pop_dhdt(c)) || (e = pop_baroclinic_driver(c)) || (e = pop_barotropic_driver(c)) ||
-      (e = pop_baroclinic_correct_adjust(c)) || (e = pop_step_tail(c))) return e;
+  if ((e = pop_time_manager(c)) || (e = pop_dhdt(c)) || (e = pop_baroclinic_driver(c)) || (e = kpp_look_ahead(c)) ||
+      (e = pop_barotropic_driver(c)) || (e = pop_baroclinic_correct_adjust(c)) || (e = pop_step_tail(c))) return e;
   return 0;
 }
 
@@ -2383,7 +2440,7 @@ int pop_run_phase(pop_ctx *c, const char *phase) {
   return 0;
 }
 int pop_time_phase(pop_ctx *c, const char *phase, int reps, double *avg_ms) {
-  if (need_device(c)) return 1;
+  if (need_device(c) || join_side(c)) return 1;
   const std::string p(phase);
   phase_fn_t fn = phase_by_name(p);
   if (!fn) { c->err = "unknown phase " + p; return 1; }

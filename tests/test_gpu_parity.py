@@ -371,6 +371,13 @@ def test_momentum_kernels_agree_bitwise(pkg, monkeypatch, kw):
     ({"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21},
      {"POP_REG_THOMAS_T": "1", "POP_KPP_COL": "3", "POP_XCD_REMAP": "0"}),   # the tx0.1v3 kernel selection + register tracer solve
     ({"km": 60, "vmix_choice": 3}, {"POP_REG_THOMAS_T": "0", "POP_KPP_COL": "3"}),
+    ({"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "stepped_bathymetry": 1},
+     {"POP_REG_THOMAS_T": "0", "POP_KPP_COL": "7", "POP_XCD_REMAP": "0"}),   # round 2: buoydiff in the level-parallel LDS form
+    ({"km": 60, "vmix_choice": 3, "ldbl_diff": 1}, {"POP_KPP_COL": "7"}),    # the same with the XCD-banded column order
+    ({"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "stepped_bathymetry": 1},
+     {"POP_REG_THOMAS_T": "0", "POP_KPP_COL": "15", "POP_XCD_REMAP": "0"}),  # buoydiff + interior coefficients in one level-parallel launch
+    ({"km": 60, "vmix_choice": 3, "ldbl_diff": 1, "stepped_bathymetry": 1}, {"POP_KPP_COL": "15"}),
+    ({"km": 24, "vmix_choice": 3, "num_v_smooth_Ri": 3}, {"POP_KPP_COL": "15"}),   # several smoothing passes
 ])
 def test_production_level_counts_match_oracle(pkg, orclib_built, monkeypatch, kw, env):
     """Kernels that are compiled for the production level counts (km = 60, 62) or selected by grid size are
@@ -389,14 +396,15 @@ def test_production_level_counts_match_oracle(pkg, orclib_built, monkeypatch, kw
     gpu.close(); orc.close()
 
 
-@pytest.mark.parametrize("kw", [{"vmix_choice": 3, "km": 24}, {"vmix_choice": 3, "km": 24, "ldbl_diff": 1, "block_size_x": 48, "block_size_y": 40}])
+@pytest.mark.parametrize("kw", [{"vmix_choice": 3, "km": 24}, {"vmix_choice": 3, "km": 24, "ldbl_diff": 1, "block_size_x": 48, "block_size_y": 40},
+                                {"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1, "num_v_smooth_Ri": 2, "ldbl_diff": 1}])
 def test_kpp_column_kernels_agree_bitwise(pkg, orclib_built, monkeypatch, kw):
     """buoydiff / ushear exist in a 3-D-parallel form (small grids) and a column form with the top
     reference levels in registers (large grids; POP_KPP_COL is a bit mask that forces either): same operations in the same
     order, so every output of the step must be identical to the last bit."""
     cfg = named_config("tiny", **kw)
     out = {}
-    for mode in ("3", "0"):
+    for mode in ("3", "0", "7", "15"):
         monkeypatch.setenv("POP_KPP_COL", mode)
         m, orc = pkg.PopModel(cfg), Oracle(cfg)
         force_kpp_case(m, orc)
@@ -406,6 +414,10 @@ def test_kpp_column_kernels_agree_bitwise(pkg, orclib_built, monkeypatch, kw):
         out[mode] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "VVC", "HBLT")]
         m.close()
     for a, b in zip(out["3"], out["0"]):
+        assert np.array_equal(a, b)
+    for a, b in zip(out["7"], out["0"]):          # buoydiff level-parallel with the surface layer in LDS
+        assert np.array_equal(a, b)
+    for a, b in zip(out["15"], out["0"]):         # buoydiff + ri_iwmix + ddmix fused, level-parallel
         assert np.array_equal(a, b)
 
 
@@ -661,3 +673,29 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
         assert np.array_equal(a.get(name), d.get(name)), name
         assert np.array_equal(a.get(name), e.get(name)), name
     a.close(); b.close(); c.close(); d.close(); e.close()
+
+
+@pytest.mark.parametrize("kw", [{"vmix_choice": 3, "km": 24}, {"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21},
+                                {"vmix_choice": 3, "km": 24, "tmix_opt": 1, "time_mix_freq": 3}, {"vmix_choice": 3, "km": 24, "tmix_opt": 3}])
+def test_kpp_look_ahead_is_bitwise_neutral(pkg, orclib_built, monkeypatch, kw):
+    """POP_KPP_AHEAD=1: pop_step computes the next step's KPP coefficients on a third stream beside the barotropic solver
+    (inputs: this step's curtime fields) and the next step swaps them in.  Twelve steps -- first (Euler) step, leapfrog
+    steps, averaging steps (no look-ahead: they rewrite curtime) -- must equal the run without look-ahead bit for bit, also
+    when a field is read or set between steps (which drops the look-ahead in flight)."""
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("POP_KPP_AHEAD", mode)
+        m, orc = pkg.PopModel(cfg), Oracle(cfg)
+        force_kpp_case(m, orc)
+        orc.close()
+        for s in range(12):
+            m.step()
+            if s == 5:
+                m.set("STF", m.get("STF", 1, 0) * 1.5, 1, 0)     # a caller changes the forcing between steps
+            if s == 8:
+                m.get("UVEL", 1, 0)
+        out[mode] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "VVC", "HBLT", "KPP_SRC")] + [m.get("VDC", 0, 1).copy()]
+        m.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
