@@ -134,7 +134,8 @@ int pop_halo_update_loc(pop_ctx *ctx, const char *name, int tl, int n, int field
 int pop_halo_update_host_r8_loc(pop_ctx *ctx, double *array, int nz, double fill, int field_loc, int field_kind);
 int pop_halo_update_host_i4_loc(pop_ctx *ctx, int *array, int nz, int fill, int field_loc, int field_kind);
 /* host-array variants used at init time and by the unit-test rule of
- * test/unit/halo/POP.F90Dipole (nz = product of trailing dims) */
+ * test/unit/halo/POP.F90Dipole (nz = product of trailing dims).  pop_halo_update_host_r8_loc also serves decompositions
+ * over several ranks (the array is then staged through a device work field; 1 <= nz <= km) */
 int pop_halo_update_host_r8(pop_ctx *ctx, double *array, int nz, double fill);
 int pop_halo_update_host_i4(pop_ctx *ctx, int *array, int nz, int fill);
 /* POP_GlobalSum(array, dist, fieldLoc, errorCode, mMask) mpi/POP_ReductionsMod.F90:144-389
@@ -152,6 +153,9 @@ int pop_global_sum_loc(pop_ctx *ctx, const char *name, int tl, int n, const char
 int pop_global_count(pop_ctx *ctx, const char *name, int tl, int n, int field_loc, long long *count);
 int pop_global_extreme(pop_ctx *ctx, const char *name, int tl, int n, const char *mask_name, int want_max,
                        double *value, int *iloc, int *jloc);
+/* POP_GlobalSum on HOST arrays of the local blocks, array(nx_block, ny_block, nblocks) and an optional multiplicative mask
+ * of the same shape (NULL: none) -- the reference's own argument list; staged through device work fields, same b4b rule */
+int pop_global_sum_host(pop_ctx *ctx, const double *array, const double *mask, int field_loc, double *result);
 int pop_global_sum_nfields(pop_ctx *ctx, int nfields, const char *const *names, const int *tl, const int *n,
                            const char *mask_name, double *results);
 int pop_global_sum_prod(pop_ctx *ctx, const char *name_a, int tl_a, int n_a, const char *name_b, int tl_b, int n_b,

@@ -61,6 +61,7 @@ def lib():
         "pop_global_count": (ci, [vp, cs, ci, ci, ci, C.POINTER(ll)]),
         "pop_global_extreme": (ci, [vp, cs, ci, ci, cs, ci, pd, pi, pi]),
         "pop_global_sum_loc": (ci, [vp, cs, ci, ci, cs, ci, pd]),
+        "pop_global_sum_host": (ci, [vp, pd, pd, ci, pd]),
         "pop_global_sum_nfields": (ci, [vp, ci, C.POINTER(cs), pi, pi, cs, pd]),
         "pop_global_sum_prod": (ci, [vp, cs, ci, ci, cs, ci, ci, cs, pd]),
         "pop_global_sum_scalar": (ci, [vp, cd, pd]), "pop_global_sum_i4": (ci, [vp, cs, C.POINTER(ll)]),
@@ -243,6 +244,16 @@ class PopModel:
     def global_sum_loc(self, name, tl=1, n=0, mask=None, loc="center"):
         r = C.c_double()
         self._chk(self.L.pop_global_sum_loc(self.h, name.encode(), tl, n, mask.encode() if mask else None, self.LOC[loc], C.byref(r)))
+        return r.value
+
+    def global_sum_host(self, arr, mask=None, loc="center"):
+        """POP_GlobalSum of a host array of the local blocks (optional multiplicative mask of the same shape)"""
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.float64)
+        r = C.c_double()
+        P = C.POINTER(C.c_double)
+        self._chk(self.L.pop_global_sum_host(self.h, a.ctypes.data_as(P), mk.ctypes.data_as(P) if mk is not None else None,
+                                             self.LOC[loc], C.byref(r)))
         return r.value
 
     def global_sum_nfields(self, names, tl=1, n=0, mask=None):

@@ -2060,10 +2060,46 @@ int pop_halo_update_loc(pop_ctx *c, const char *name, int tl, int n, int field_l
   const int nz = (int)(cnt / ((long long)c->g.n2 * c->g.nblocks));
   return halo_update(c, p, nz, 0.0, field_loc, field_kind);
 }
+// host array (nx_block, ny_block, nz, local blocks) staged through a device work field: the update then runs through
+// the same plan, kernels and transport as a device-resident field, so it also serves decompositions over several ranks
+static int halo_host_staged(pop_ctx *c, double *array, int nz, double fill, int field_loc, int field_kind) {
+  if (need_device(c) || join_side(c)) return 1;
+  if (nz < 1 || nz > c->g.km) { c->err = "host halo update over several ranks: 1 <= nz <= km (update a 4-D field tracer by tracer)"; return 1; }
+  const size_t cnt = (size_t)c->g.n2 * nz * c->g.nblocks;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->S3a, array, cnt * sizeof(double), hipMemcpyHostToDevice));
+  if (halo_update(c, c->S3a, nz, fill, field_loc, field_kind)) return 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(array, c->S3a, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
 int pop_halo_update_host_r8_loc(pop_ctx *c, double *array, int nz, double fill, int field_loc, int field_kind) {
-  if (c->h.nranks != 1) { c->err = "host halo update needs all blocks on one rank"; return 1; }
   if (field_loc < 0 || field_loc > 3 || field_kind < 0 || field_kind > 2) { c->err = "unknown field location / kind"; return 1; }
+  if (c->h.nranks != 1) return halo_host_staged(c, array, nz, fill, field_loc, field_kind);
   host_halo_r8_loc(c->h, array, nz, fill, field_loc, field_kind);
+  return 0;
+}
+// POP_GlobalSum(array, dist, fieldLoc, errorCode, mMask) on HOST arrays of the local blocks (mpi/POP_ReductionsMod.F90:144-389):
+// array and the optional multiplicative mask are staged into 2-D device work fields and summed by the same b4b kernels
+// as a device-resident field (field_loc as in pop_global_sum_loc)
+int pop_global_sum_host(pop_ctx *c, const double *array, const double *mask, int field_loc, double *result) {
+  if (need_device(c) || join_side(c)) return 1;
+  if (!array || !result) { c->err = "pop_global_sum_host: null argument"; return 1; }
+  const size_t a2 = (size_t)c->g.n2 * c->g.nblocks;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->W3, array, a2 * sizeof(double), hipMemcpyHostToDevice));
+  if (mask) HIPCHK(c, hipMemcpy(c->W4, mask, a2 * sizeof(double), hipMemcpyHostToDevice));
+  const double *mk = mask ? c->W4 : nullptr;
+  if (c->h.c.ns_boundary == 2 && (field_loc == 1 || field_loc == 2)) {
+    hipLaunchKernelGGL(k_dot_partial_dup, grid_2d(c), dim3(POP_RED_THREADS), 0, c->stream, c->g, (const double *)c->W3, mk, (const double *)c->d2["TRIPOLE_DUP"], c->partial);
+    if (reduce_finish<2>(c, FIN_TRIPOLE)) return 1;
+  } else {
+    hipLaunchKernelGGL(k_dot_partial, grid_2d(c), dim3(POP_RED_THREADS), 0, c->stream, c->g, (const double *)c->W3, (const double *)nullptr, mk, c->partial);
+    if (reduce_finish<1>(c, FIN_PLAIN)) return 1;
+  }
+  SolverScalars sres;
+  if (read_scalars(c, &sres)) return 1;
+  *result = sres.sum0;
   return 0;
 }
 int pop_halo_update_host_i4_loc(pop_ctx *c, int *array, int nz, int fill, int field_loc, int field_kind) {

@@ -149,6 +149,14 @@
          type (c_ptr), value :: mask_name
          real (c_double), intent(out) :: res
       end function
+      integer (c_int) function pop_global_sum_host(ctx, array, mask, field_loc, res) bind(C, name='pop_global_sum_host')
+         import :: c_int, c_ptr, c_double
+         type (c_ptr), value :: ctx
+         real (c_double), intent(in) :: array(*)
+         type (c_ptr), value :: mask                 ! c_loc of a host array of the same shape, or c_null_ptr
+         integer (c_int), value :: field_loc
+         real (c_double), intent(out) :: res
+      end function
       integer (c_int) function pop_solver_run(ctx) bind(C, name='pop_solver_run')
          import :: c_int, c_ptr
          type (c_ptr), value :: ctx
@@ -243,6 +251,12 @@
          real (c_double), value :: fill
       end function
       ! in-library RCCL transport (include/pop_amd.h)
+      integer (c_int) function pop_halo_update_host_i4_loc(ctx, array, nz, fill, loc, kind) bind(C, name='pop_halo_update_host_i4_loc')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+         integer (c_int), intent(inout) :: array(*)
+         integer (c_int), value :: nz, fill, loc, kind
+      end function
       integer (c_int) function pop_rccl_unique_id(id128) bind(C, name='pop_rccl_unique_id')
          import :: c_int, c_signed_char
          integer (c_signed_char), intent(out) :: id128(128)

@@ -1,9 +1,23 @@
 !|||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||
-! Modules with the reference's names and argument lists whose bodies forward
-! to the C ABI of libpop_amd.so.  A maintainer drops these in place of the
-! reference modules of the same name (source/blocks.F90, surface_hgt.F90,
-! baroclinic.F90, barotropic.F90, POP_SolversMod.F90, mpi/POP_HaloMod.F90,
-! mpi/POP_ReductionsMod.F90, step_mod.F90); see INTEGRATION.md.
+! Modules with the reference's names whose bodies forward to the C ABI of
+! libpop_amd.so.  Every routine of the step path exists under the reference's
+! OWN argument list (host arrays, POP_halo / POP_distrb handles, character
+! fieldLoc / fieldKind constants):
+!   dhdt(DH,DHU)                                        surface_hgt.F90:131
+!   baroclinic_driver(ZX,ZY,DH,DHU,errorCode)           baroclinic.F90:578-630
+!   barotropic_driver(ZX,ZY,errorCode)                  barotropic.F90:267
+!   baroclinic_correct_adjust                           baroclinic.F90:1217
+!   POP_HaloUpdate(array,halo,fieldLoc,fieldKind,errorCode,fillValue)   mpi/POP_HaloMod.F90:1732-1773
+!   POP_GlobalSum(array,dist,fieldLoc,errorCode,mMask)  mpi/POP_ReductionsMod.F90:144-187
+!   POP_SolversRun(sfcPressure,rhsClinic,errorCode)     POP_SolversMod.F90:327
+! (host arrays are staged to / from the device-resident state), and -- under the
+! same generic name or a *Field name -- in a form that addresses the
+! device-resident field by the reference's variable name and moves no data.
+! A maintainer drops these in place of the reference modules of the same name
+! (source/blocks.F90, surface_hgt.F90, baroclinic.F90, barotropic.F90,
+! POP_SolversMod.F90, mpi/POP_HaloMod.F90, mpi/POP_ReductionsMod.F90,
+! step_mod.F90); see INTEGRATION.md and pop_driver_ref.F90, a caller written
+! against the reference's argument lists.
 ! Error convention: integer errorCode, POP_Success = 0 on success
 ! (source/POP_ErrorMod.F90:82-250); callers re-tag and return.
 !|||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||
@@ -76,66 +90,165 @@
  end module POP_CommMod
 
 !-----------------------------------------------------------------------
+ module POP_GridHorzMod      ! source/POP_GridHorzMod.F90:51-61 (field locations on the horizontal grid)
+   implicit none
+   character ( 7), parameter, public :: POP_gridHorzLocUnknown  = 'Unknown'
+   character ( 6), parameter, public :: POP_gridHorzLocCenter   = 'Center'
+   character ( 5), parameter, public :: POP_gridHorzLocNface    = 'NFace'
+   character ( 5), parameter, public :: POP_gridHorzLocEface    = 'EFace'
+   character ( 8), parameter, public :: POP_gridHorzLocNEcorner = 'NECorner'
+   character ( 8), parameter, public :: POP_gridHorzLocNoUpdate = 'NoUpdate'
+ contains
+   integer function POP_gridHorzLocCode(fieldLoc)     ! field_loc of the C ABI; -1 unknown
+      character (*), intent(in) :: fieldLoc
+      select case (trim(fieldLoc))
+      case (POP_gridHorzLocCenter);   POP_gridHorzLocCode = 0
+      case (POP_gridHorzLocNEcorner); POP_gridHorzLocCode = 1
+      case (POP_gridHorzLocNface);    POP_gridHorzLocCode = 2
+      case (POP_gridHorzLocEface);    POP_gridHorzLocCode = 3
+      case default;                   POP_gridHorzLocCode = -1
+      end select
+   end function
+ end module POP_GridHorzMod
+
+ module POP_FieldMod         ! source/POP_FieldMod.F90:105-109 (field kinds)
+   implicit none
+   character (7), parameter, public :: POP_fieldKindUnknown  = 'unknown'
+   character (6), parameter, public :: POP_fieldKindScalar   = 'scalar'
+   character (6), parameter, public :: POP_fieldKindVector   = 'vector'
+   character (5), parameter, public :: POP_fieldKindAngle    = 'angle'
+   character (8), parameter, public :: POP_fieldKindNoUpdate = 'noUpdate'
+ contains
+   integer function POP_fieldKindCode(fieldKind)
+      character (*), intent(in) :: fieldKind
+      select case (trim(fieldKind))
+      case (POP_fieldKindScalar); POP_fieldKindCode = 0
+      case (POP_fieldKindVector); POP_fieldKindCode = 1
+      case (POP_fieldKindAngle);  POP_fieldKindCode = 2
+      case default;               POP_fieldKindCode = -1
+      end select
+   end function
+ end module POP_FieldMod
+
+!-----------------------------------------------------------------------
+ module POP_DistributionMod  ! source/POP_DistributionMod.F90:33-46: the distribution lives in the library; this is its handle
+   use kinds_mod
+   implicit none
+   type, public :: POP_distrb
+      integer (POP_i4) :: numProcs = 1, communicator = 0, numLocalBlocks = 0
+   end type
+ end module POP_DistributionMod
+
+!-----------------------------------------------------------------------
  module POP_HaloMod          ! mpi/POP_HaloMod.F90:79-89, 1732-1773
    use kinds_mod
    use pop_amd_c
+   use POP_GridHorzMod
+   use POP_FieldMod
    implicit none
    private
-   public :: POP_HaloUpdate, POP_HaloUpdateField
-   ! fieldLoc / fieldKind constants (POP_GridHorzMod.F90, POP_FieldMod.F90), as integers of the C ABI
-   integer (POP_i4), parameter, public :: POP_gridHorzLocCenter = 0, POP_gridHorzLocNEcorner = 1, &
-      POP_gridHorzLocNface = 2, POP_gridHorzLocEface = 3, &
-      POP_fieldKindScalar = 0, POP_fieldKindVector = 1, POP_fieldKindAngle = 2
-   interface POP_HaloUpdate
-      module procedure POP_HaloUpdate2DR8, POP_HaloUpdate3DR8, POP_HaloUpdate2DI4
+   public :: POP_HaloUpdate, POP_HaloUpdateField, POP_HaloCreate
+   ! mpi/POP_HaloMod.F90:42-70: the message plan is built and kept by the library (halo_plan.cpp); this is its handle
+   type, public :: POP_halo
+      integer (POP_i4) :: communicator = 0, numMsgSend = 0, numMsgRecv = 0, numLocalCopies = 0
+   end type
+   interface POP_HaloUpdate   ! mpi/POP_HaloMod.F90:79-89
+      module procedure POP_HaloUpdate2DR8, POP_HaloUpdate3DR8, POP_HaloUpdate4DR8, POP_HaloUpdate2DI4
    end interface
  contains
-   ! device-resident field, addressed by the reference's variable name
-   subroutine POP_HaloUpdateField(name, timeLevel, n, errorCode, fieldLoc, fieldKind)
-      character (*), intent(in) :: name
+   ! POP_HaloCreate(distrb, nsBoundaryType, ewBoundaryType, nxGlobal, errorCode) :142: the plan exists once the
+   ! context does; the handle reports its sizes
+   function POP_HaloCreate(errorCode) result(halo)
+      integer (POP_i4), intent(out) :: errorCode
+      type (POP_halo) :: halo
+      halo%numLocalCopies = pop_get_dim(pop_ctx, cstr('nblocks'))
+      errorCode = POP_Success
+   end function
+   subroutine loc_kind(fieldLoc, fieldKind, loc, kind, errorCode)
+      character (*), intent(in) :: fieldLoc, fieldKind
+      integer (POP_i4), intent(out) :: loc, kind, errorCode
+      loc = POP_gridHorzLocCode(fieldLoc); kind = POP_fieldKindCode(fieldKind)
+      errorCode = POP_Success
+      if (loc < 0 .or. kind < 0) errorCode = POP_Fail    ! 'POP_HaloUpdate: Unknown field location / kind' :1990-2010
+   end subroutine
+   ! device-resident field, addressed by the reference's variable name (no data moves)
+   subroutine POP_HaloUpdateField(name, timeLevel, n, halo, fieldLoc, fieldKind, errorCode)
+      character (*), intent(in) :: name, fieldLoc, fieldKind
       integer (POP_i4), intent(in) :: timeLevel, n
+      type (POP_halo), intent(in) :: halo
       integer (POP_i4), intent(out) :: errorCode
-      integer (POP_i4), intent(in), optional :: fieldLoc, fieldKind   ! tripole northern boundary only
-      if (present(fieldLoc) .and. present(fieldKind)) then
-         errorCode = pop_halo_update_loc(pop_ctx, cstr(name), timeLevel, n, fieldLoc, fieldKind)
-      else
-         errorCode = pop_halo_update(pop_ctx, cstr(name), timeLevel, n)
-      endif
+      integer (POP_i4) :: loc, kind
+      call loc_kind(fieldLoc, fieldKind, loc, kind, errorCode)
+      if (errorCode /= POP_Success) return
+      errorCode = pop_halo_update_loc(pop_ctx, cstr(name), timeLevel, n, loc, kind)
    end subroutine
-   ! host arrays (init-time fields): array(nx_block,ny_block,nblocks)
-   subroutine POP_HaloUpdate2DR8(array, errorCode, fillValue, fieldLoc, fieldKind)
+   ! host arrays, the reference's argument list: array(nx_block,ny_block,nblocks)
+   subroutine POP_HaloUpdate2DR8(array, halo, fieldLoc, fieldKind, errorCode, fillValue)
       real (POP_r8), dimension(:,:,:), intent(inout) :: array
+      type (POP_halo), intent(in) :: halo
+      character (*), intent(in) :: fieldKind, fieldLoc
       integer (POP_i4), intent(out) :: errorCode
       real (POP_r8), intent(in), optional :: fillValue
-      integer (POP_i4), intent(in), optional :: fieldLoc, fieldKind
       real (POP_r8) :: fill
+      integer (POP_i4) :: loc, kind
       fill = 0.0_POP_r8
       if (present(fillValue)) fill = fillValue
-      if (present(fieldLoc) .and. present(fieldKind)) then
-         errorCode = pop_halo_update_host_r8_loc(pop_ctx, array, 1, fill, fieldLoc, fieldKind)
-      else
-         errorCode = pop_halo_update_host_r8(pop_ctx, array, 1, fill)
-      endif
+      call loc_kind(fieldLoc, fieldKind, loc, kind, errorCode)
+      if (errorCode /= POP_Success) return
+      errorCode = pop_halo_update_host_r8_loc(pop_ctx, array, 1, fill, loc, kind)
    end subroutine
-   subroutine POP_HaloUpdate3DR8(array, errorCode, fillValue)
+   subroutine POP_HaloUpdate3DR8(array, halo, fieldLoc, fieldKind, errorCode, fillValue)   ! :2766-3211
       real (POP_r8), dimension(:,:,:,:), intent(inout) :: array    ! (nx,ny,nz,nblocks)
+      type (POP_halo), intent(in) :: halo
+      character (*), intent(in) :: fieldKind, fieldLoc
       integer (POP_i4), intent(out) :: errorCode
       real (POP_r8), intent(in), optional :: fillValue
       real (POP_r8) :: fill
+      integer (POP_i4) :: loc, kind
       fill = 0.0_POP_r8
       if (present(fillValue)) fill = fillValue
-      errorCode = pop_halo_update_host_r8(pop_ctx, array, size(array,3), fill)
+      call loc_kind(fieldLoc, fieldKind, loc, kind, errorCode)
+      if (errorCode /= POP_Success) return
+      errorCode = pop_halo_update_host_r8_loc(pop_ctx, array, size(array,3), fill, loc, kind)
    end subroutine
-   subroutine POP_HaloUpdate2DI4(array, errorCode, fillValue)
+   subroutine POP_HaloUpdate4DR8(array, halo, fieldLoc, fieldKind, errorCode, fillValue)   ! :4122-4585
+      real (POP_r8), dimension(:,:,:,:,:), intent(inout) :: array  ! (nx,ny,nz,nt,nblocks)
+      type (POP_halo), intent(in) :: halo
+      character (*), intent(in) :: fieldKind, fieldLoc
+      integer (POP_i4), intent(out) :: errorCode
+      real (POP_r8), intent(in), optional :: fillValue
+      real (POP_r8), allocatable :: slab(:,:,:,:)
+      integer (POP_i4) :: n
+      do n = 1, size(array,4)                                     ! one 3-D update per tracer
+         slab = array(:,:,:,n,:)
+         call POP_HaloUpdate3DR8(slab, halo, fieldLoc, fieldKind, errorCode, fillValue)
+         if (errorCode /= POP_Success) return
+         array(:,:,:,n,:) = slab
+      end do
+   end subroutine
+   subroutine POP_HaloUpdate2DI4(array, halo, fieldLoc, fieldKind, errorCode, fillValue)   ! :2420-2760
       integer (POP_i4), dimension(:,:,:), intent(inout) :: array
+      type (POP_halo), intent(in) :: halo
+      character (*), intent(in) :: fieldKind, fieldLoc
       integer (POP_i4), intent(out) :: errorCode
       integer (POP_i4), intent(in), optional :: fillValue
-      integer (POP_i4) :: fill
+      integer (POP_i4) :: fill, loc, kind
       fill = 0
       if (present(fillValue)) fill = fillValue
-      errorCode = pop_halo_update_host_i4(pop_ctx, array, 1, fill)
+      call loc_kind(fieldLoc, fieldKind, loc, kind, errorCode)
+      if (errorCode /= POP_Success) return
+      errorCode = pop_halo_update_host_i4_loc(pop_ctx, array, 1, fill, loc, kind)
    end subroutine
  end module POP_HaloMod
+
+!-----------------------------------------------------------------------
+ module POP_DomainMod        ! source/POP_DomainMod.F90: the handles every caller passes to halo updates and reductions
+   use POP_HaloMod, only: POP_halo
+   use POP_DistributionMod, only: POP_distrb
+   implicit none
+   type (POP_halo), public, save :: POP_haloClinic, POP_haloTropic
+   type (POP_distrb), public, save :: POP_distrbClinic, POP_distrbTropic
+ end module POP_DomainMod
 
 !-----------------------------------------------------------------------
  module POP_ReductionsMod    ! mpi/POP_ReductionsMod.F90:144-389
@@ -145,7 +258,33 @@
    private
    public :: POP_GlobalSum, POP_GlobalSumProd, POP_GlobalSumScalar, POP_GlobalSumI4
    public :: POP_GlobalCount, POP_GlobalMaxval, POP_GlobalMinval, POP_GlobalMaxloc, POP_GlobalMinloc
+   interface POP_GlobalSum     ! the reference's list (host array) and the named device-resident field
+      module procedure POP_GlobalSum2DR8, POP_GlobalSumField
+   end interface
  contains
+   ! POP_GlobalSum2DR8(array, dist, fieldLoc, errorCode, mMask) :144-187: array(nx_block,ny_block,nblocks) on the host
+   function POP_GlobalSum2DR8(array, dist, fieldLoc, errorCode, mMask) result(globalSum)
+      use POP_DistributionMod, only: POP_distrb
+      use POP_GridHorzMod, only: POP_gridHorzLocCode
+      real (POP_r8), dimension(:,:,:), intent(in) :: array
+      type (POP_distrb), intent(in) :: dist
+      character (*), intent(in) :: fieldLoc
+      integer (POP_i4), intent(out) :: errorCode
+      real (POP_r8), dimension(:,:,:), intent(in), target, optional :: mMask
+      real (POP_r8) :: globalSum
+      integer (POP_i4) :: loc
+      globalSum = 0.0_POP_r8
+      loc = POP_gridHorzLocCode(fieldLoc)
+      if (loc < 0) then
+         errorCode = POP_Fail
+         return
+      endif
+      if (present(mMask)) then
+         errorCode = pop_global_sum_host(pop_ctx, array, c_loc(mMask), loc, globalSum)
+      else
+         errorCode = pop_global_sum_host(pop_ctx, array, c_null_ptr, loc, globalSum)
+      endif
+   end function
    ! :2062-2207 (non-zero cells of a device-resident field)
    function POP_GlobalCount(name, timeLevel, n, errorCode) result(globalCount)
       character (*), intent(in) :: name
@@ -211,7 +350,7 @@
       errorCode = pop_global_sum_i4(pop_ctx, cstr(name), globalSum)
    end function
    ! global sum of a device-resident field over the physical domain, optionally times mMask
-   function POP_GlobalSum(name, timeLevel, n, errorCode, mMask) result(globalSum)
+   function POP_GlobalSumField(name, timeLevel, n, errorCode, mMask) result(globalSum)
       character (*), intent(in) :: name
       integer (POP_i4), intent(in) :: timeLevel, n
       integer (POP_i4), intent(out) :: errorCode
@@ -224,7 +363,7 @@
       else
          errorCode = pop_global_sum(pop_ctx, cstr(name), timeLevel, n, c_null_ptr, globalSum)
       endif
-   end function POP_GlobalSum
+   end function POP_GlobalSumField
  end module POP_ReductionsMod
 
 !-----------------------------------------------------------------------
@@ -234,6 +373,9 @@
    implicit none
    private
    public :: POP_SolversRun, POP_SolversGetDiagnostics, POP_SolversDiagonal
+   interface POP_SolversRun
+      module procedure POP_SolversRunHost, POP_SolversRunResident
+   end interface
  contains
    ! POP_SolversMod.F90:1110-1151; diagonalCorrection is a host array (nx_block,ny_block)
    subroutine POP_SolversDiagonal(diagonalCorrection, blockIndx, errorCode)
@@ -243,9 +385,21 @@
       errorCode = pop_solver_diagonal(pop_ctx, blockIndx, diagonalCorrection)
    end subroutine
    ! operates on PSURF(:,:,newtime,:) and the barotropic RHS, both device resident
-   subroutine POP_SolversRun(errorCode)
+   subroutine POP_SolversRunResident(errorCode)
       integer (POP_i4), intent(out) :: errorCode
       errorCode = pop_solver_run(pop_ctx)
+   end subroutine
+   ! POP_SolversRun(sfcPressure, rhsClinic, errorCode) :327: host arrays (nx_block,ny_block,nblocks); on input the
+   ! initial guess, on output the solution (the centre weight is the one the last POP_SolversDiagonal /
+   ! barotropic_driver set)
+   subroutine POP_SolversRunHost(sfcPressure, rhsClinic, errorCode)
+      real (POP_r8), dimension(:,:,:), intent(inout) :: sfcPressure
+      real (POP_r8), dimension(:,:,:), intent(in) :: rhsClinic
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_set_field(pop_ctx, cstr('PSURF'), 2, 0, sfcPressure, int(size(sfcPressure), c_long_long))
+      if (errorCode == POP_Success) errorCode = pop_set_field(pop_ctx, cstr('RHS'), 1, 0, rhsClinic, int(size(rhsClinic), c_long_long))
+      if (errorCode == POP_Success) errorCode = pop_solver_run(pop_ctx)
+      if (errorCode == POP_Success) errorCode = pop_get_field(pop_ctx, cstr('PSURF'), 2, 0, sfcPressure, int(size(sfcPressure), c_long_long))
    end subroutine
    subroutine POP_SolversGetDiagnostics(iterationCount, residual, errorCode)
       integer (POP_i4), intent(out) :: iterationCount, errorCode
@@ -279,8 +433,23 @@
    implicit none
    private
    public :: baroclinic_driver, baroclinic_correct_adjust
+   interface baroclinic_driver
+      module procedure baroclinic_driver_ref, baroclinic_driver_resident
+   end interface
  contains
-   subroutine baroclinic_driver(errorCode, ZX, ZY)
+   ! baroclinic_driver(ZX,ZY,DH,DHU,errorCode) baroclinic.F90:578-630: DH, DHU (from dhdt) in, the vertically integrated
+   ! forcing ZX, ZY out, all (nx_block,ny_block,nblocks) on the host; the prognostic state stays on the device
+   subroutine baroclinic_driver_ref(ZX, ZY, DH, DHU, errorCode)
+      real (r8), dimension(:,:,:), intent(out) :: ZX, ZY
+      real (r8), dimension(:,:,:), intent(in) :: DH, DHU
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_set_field(pop_ctx, cstr('DH'), 1, 0, DH, int(size(DH), c_long_long))
+      if (errorCode == POP_Success) errorCode = pop_set_field(pop_ctx, cstr('DHU'), 1, 0, DHU, int(size(DHU), c_long_long))
+      if (errorCode == POP_Success) errorCode = pop_baroclinic_driver(pop_ctx)
+      if (errorCode == POP_Success) errorCode = pop_get_field(pop_ctx, cstr('ZX'), 1, 0, ZX, int(size(ZX), c_long_long))
+      if (errorCode == POP_Success) errorCode = pop_get_field(pop_ctx, cstr('ZY'), 1, 0, ZY, int(size(ZY), c_long_long))
+   end subroutine
+   subroutine baroclinic_driver_resident(errorCode, ZX, ZY)
       integer (POP_i4), intent(out) :: errorCode
       real (r8), dimension(:,:,:), intent(out), optional :: ZX, ZY   ! host copies on request
       integer (c_int) :: ierr
@@ -302,8 +471,20 @@
    implicit none
    private
    public :: barotropic_driver
+   interface barotropic_driver
+      module procedure barotropic_driver_ref, barotropic_driver_resident
+   end interface
  contains
-   subroutine barotropic_driver(errorCode)
+   ! barotropic_driver(ZX,ZY,errorCode) barotropic.F90:267: the forcing as host arrays (ghost cells included or not: the
+   ! library repeats the halo update of step_mod.F90:405-423, which is idempotent)
+   subroutine barotropic_driver_ref(ZX, ZY, errorCode)
+      real (r8), dimension(:,:,:), intent(in) :: ZX, ZY
+      integer (POP_i4), intent(out) :: errorCode
+      errorCode = pop_set_field(pop_ctx, cstr('ZX'), 1, 0, ZX, int(size(ZX), c_long_long))
+      if (errorCode == POP_Success) errorCode = pop_set_field(pop_ctx, cstr('ZY'), 1, 0, ZY, int(size(ZY), c_long_long))
+      if (errorCode == POP_Success) errorCode = pop_barotropic_driver(pop_ctx)
+   end subroutine
+   subroutine barotropic_driver_resident(errorCode)
       integer (POP_i4), intent(out) :: errorCode
       errorCode = pop_barotropic_driver(pop_ctx)
    end subroutine

@@ -1,0 +1,134 @@
+!|||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||
+! A caller written against the REFERENCE's argument lists (the call style of source/step_mod.F90:361-560 and of
+! the routines it calls), compiled against pop_amd_mods.F90 to show that code written for the reference's
+! module-procedure surface compiles and runs unchanged in shape:
+!    call dhdt(DH, DHU)
+!    call baroclinic_driver(ZX, ZY, DH, DHU, errorCode)
+!    call POP_HaloUpdate(ZX, POP_haloClinic, POP_gridHorzLocNECorner, POP_fieldKindVector, errorCode, fillValue = 0.0_POP_r8)
+!    call barotropic_driver(ZX, ZY, errorCode)
+!    call baroclinic_correct_adjust
+! followed by the library's step tail, a global sum with the reference's POP_GlobalSum(array, dist, fieldLoc,
+! errorCode, mMask) and -- once -- a stand-alone POP_SolversRun(sfcPressure, rhsClinic, errorCode) that must reproduce
+! the pressure the step just computed.  Prints the same checksums as pop_driver.F90 (named-field forms), so the
+! test suite can compare both with the Python-driven run.
+!   pop_driver_ref <nx> <ny> <km> <bx> <by> <vmix> <nsteps>
+!|||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||
+ program pop_driver_ref
+
+   use kinds_mod
+   use pop_amd_c
+   use blocks
+   use POP_GridHorzMod
+   use POP_FieldMod
+   use POP_DomainMod, only: POP_haloClinic, POP_distrbClinic
+   use POP_HaloMod, only: POP_HaloUpdate, POP_HaloCreate
+   use POP_ReductionsMod, only: POP_GlobalSum
+   use POP_SolversMod, only: POP_SolversRun, POP_SolversGetDiagnostics
+   use surface_hgt, only: dhdt
+   use baroclinic, only: baroclinic_driver, baroclinic_correct_adjust
+   use barotropic, only: barotropic_driver
+   implicit none
+
+   type (pop_config) :: cfg
+   integer (POP_i4) :: errorCode, nsteps, n, iters, iters2
+   real (POP_r8), allocatable, dimension(:,:,:) :: DH, DHU, ZX, ZY, PSURF, RHS, GUESS, MASK, T1
+   real (POP_r8) :: rms, tsum, psum, dmax
+   character (char_len) :: arg, msg
+
+   cfg = default_config()
+   call geti(1, cfg%nx_global); call geti(2, cfg%ny_global); call geti(3, cfg%km)
+   call geti(4, cfg%block_size_x); call geti(5, cfg%block_size_y); call geti(6, cfg%vmix_choice)
+   call geti(7, nsteps)
+   errorCode = pop_create(cfg, 0, 1, 0, pop_ctx)
+   if (errorCode /= POP_Success) call die('pop_create')
+   call init_blocks_from_ctx
+   POP_haloClinic = POP_HaloCreate(errorCode)
+
+   allocate(DH(nx_block,ny_block,nblocks_clinic), DHU(nx_block,ny_block,nblocks_clinic), ZX(nx_block,ny_block,nblocks_clinic), &
+            ZY(nx_block,ny_block,nblocks_clinic), PSURF(nx_block,ny_block,nblocks_clinic), RHS(nx_block,ny_block,nblocks_clinic), &
+            GUESS(nx_block,ny_block,nblocks_clinic), MASK(nx_block,ny_block,nblocks_clinic), T1(nx_block,ny_block,nblocks_clinic))
+   errorCode = pop_get_field(pop_ctx, cstr('mMask'), 1, 0, MASK, int(size(MASK), c_long_long))
+
+   do n = 1, nsteps
+      errorCode = pop_time_manager(pop_ctx)                                  ! time_manager / set_switches
+      if (errorCode /= POP_Success) call die('time_manager')
+      call dhdt(DH, DHU)                                                     ! step_mod.F90:361
+      call baroclinic_driver(ZX, ZY, DH, DHU, errorCode)                     ! :369
+      if (errorCode /= POP_Success) call die('baroclinic_driver')
+      call POP_HaloUpdate(ZX, POP_haloClinic, POP_gridHorzLocNECorner, &     ! :405-423
+                          POP_fieldKindVector, errorCode, fillValue = 0.0_POP_r8)
+      if (errorCode /= POP_Success) call die('POP_HaloUpdate(ZX)')
+      call POP_HaloUpdate(ZY, POP_haloClinic, POP_gridHorzLocNECorner, &
+                          POP_fieldKindVector, errorCode, fillValue = 0.0_POP_r8)
+      if (errorCode /= POP_Success) call die('POP_HaloUpdate(ZY)')
+      call barotropic_driver(ZX, ZY, errorCode)                              ! :431
+      if (errorCode /= POP_Success) call die('barotropic_driver')
+      call POP_SolversGetDiagnostics(iters, rms, errorCode)
+      if (n == nsteps) then
+         ! the elliptic solve on its own, reference argument list: same right-hand side, same first guess (PGUESS) -> the
+         ! same iteration count; the pressure barotropic_driver left (null space removed) is put back afterwards
+         errorCode = pop_get_field(pop_ctx, cstr('RHS'), 1, 0, RHS, int(size(RHS), c_long_long))
+         errorCode = pop_get_field(pop_ctx, cstr('PGUESS'), 1, 0, GUESS, int(size(GUESS), c_long_long))
+         errorCode = pop_get_field(pop_ctx, cstr('PSURF'), 2, 0, PSURF, int(size(PSURF), c_long_long))
+         call POP_SolversRun(GUESS, RHS, errorCode)
+         if (errorCode /= POP_Success) call die('POP_SolversRun')
+         call POP_SolversGetDiagnostics(iters2, rms, errorCode)
+         write(*,'(a,i5,a,i5)') 'solver rerun iters ', iters2, ' of ', iters
+         errorCode = pop_set_field(pop_ctx, cstr('PSURF'), 2, 0, PSURF, int(size(PSURF), c_long_long))
+      endif
+      call baroclinic_correct_adjust                                         ! :458
+      errorCode = pop_step_tail(pop_ctx)                                     ! :467-832
+      if (errorCode /= POP_Success) call die('step tail')
+      errorCode = pop_get_field(pop_ctx, cstr('PSURF'), 1, 0, PSURF, int(size(PSURF), c_long_long))
+      errorCode = pop_get_field(pop_ctx, cstr('TRACER'), 1, 0, T1, int(size(T1), c_long_long))   ! first nx*ny*nblocks values only
+      psum = POP_GlobalSum(PSURF, POP_distrbClinic, POP_gridHorzLocCenter, errorCode, mMask = MASK)
+      if (errorCode /= POP_Success) call die('POP_GlobalSum')
+      write(*,'(a,i4,a,i5,a,es23.15)') 'step ', n, ' iters ', iters, ' sumP ', psum
+   end do
+   write(*,'(a,es12.4)') 'halo: max |ZX| ', maxval(abs(ZX))
+   errorCode = pop_destroy(pop_ctx)
+
+ contains
+
+   subroutine die(what)
+      character (*), intent(in) :: what
+      call pop_amd_error_message(msg)
+      write(*,*) trim(what), ' failed: ', trim(msg)
+      stop 2
+   end subroutine
+
+   subroutine geti(i, v)
+      integer, intent(in) :: i
+      integer (c_int), intent(inout) :: v
+      if (command_argument_count() >= i) then
+         call get_command_argument(i, arg)
+         read(arg, *) v
+      endif
+   end subroutine
+
+   function default_config() result(c)
+      type (pop_config) :: c
+      c%nx_global = 48; c%ny_global = 40; c%km = 16; c%nt = 2
+      c%block_size_x = 12; c%block_size_y = 10
+      c%ew_boundary = 1; c%ns_boundary = 0
+      c%hmix_momentum = 2; c%hmix_tracer = 2; c%lvariable_hmix = 0
+      c%vmix_choice = 1; c%tadvect = 1; c%solver_choice = 1
+      c%max_iterations = 1000; c%convergence_check_freq = 10
+      c%tmix_opt = 2; c%time_mix_freq = 17; c%steps_per_day = 24
+      c%lbouss_correct = 0; c%lpressure_avg = 1; c%impcor = 1; c%reset_to_freezing = 1
+      c%lrich = 1; c%ldbl_diff = 0; c%lshort_wave = 0; c%lcheckekmo = 0; c%num_v_smooth_Ri = 1
+      c%reserved_i = 0
+      c%am = 3.0e9_c_double; c%ah = 1.0e7_c_double
+      c%const_vvc = 0.25_c_double; c%const_vdc = 0.25_c_double
+      c%convect_diff = 1000.0_c_double; c%convect_visc = 1000.0_c_double
+      c%bottom_drag = 1.0e-3_c_double; c%aidif = 1.0_c_double
+      c%rich_bckgrnd_vvc = 1.0_c_double; c%rich_bckgrnd_vdc = 0.1_c_double; c%rich_mix = 50.0_c_double
+      c%bckgrnd_vdc1 = 0.1_c_double; c%bckgrnd_vdc2 = 0.0_c_double
+      c%bckgrnd_vdc_dpth = 2500.0e2_c_double; c%bckgrnd_vdc_linv = 4.5e-5_c_double
+      c%Prandtl = 10.0_c_double; c%kpp_rich_mix = 50.0_c_double
+      c%convergence_criterion = 1.0e-12_c_double
+      c%reserved_d = 0.0_c_double
+      c%reserved_d(1) = 1.0e-2_c_double
+   end function default_config
+
+ end program pop_driver_ref

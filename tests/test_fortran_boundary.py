@@ -52,3 +52,29 @@ def test_fortran_step_sequence_matches_python(pkg):
         assert float(st) == pytest.approx(m.global_sum("TRACER", 1, 0), rel=1e-15)
         assert float(sp) == pytest.approx(m.global_sum("PSURF", 1, 0, mask="mMask"), rel=1e-13, abs=1e-9)
     m.close()
+
+
+@pytest.mark.gpu
+def test_reference_argument_lists_match_python(pkg):
+    """pop_driver_ref.F90 is written against the REFERENCE's argument lists -- dhdt(DH,DHU),
+    baroclinic_driver(ZX,ZY,DH,DHU,errorCode), POP_HaloUpdate(array,halo,fieldLoc,fieldKind,errorCode,fillValue),
+    barotropic_driver(ZX,ZY,errorCode), POP_GlobalSum(array,dist,fieldLoc,errorCode,mMask),
+    POP_SolversRun(sfcPressure,rhsClinic,errorCode) on host arrays -- and must reproduce the Python-driven run bit for
+    bit: same iteration counts, same masked global sum of PSURF, and the stand-alone solve repeats the step's count."""
+    _build()
+    exe = os.path.join(FDIR, "pop_driver_ref")
+    assert os.path.exists(exe)
+    nsteps = 5
+    out = subprocess.check_output([exe, "48", "40", "16", "12", "10", "1", str(nsteps)], text=True)
+    rows = re.findall(r"step\s+(\d+)\s+iters\s+(\d+)\s+sumP\s+(\S+)", out)
+    assert len(rows) == nsteps, out
+    m = pkg.PopModel(named_config("tiny"))
+    for n, it, sp in rows:
+        m.step()
+        assert int(it) == m.solver_diagnostics()[0]
+        host = m.get("PSURF", 1, 0)
+        assert float(sp) == pytest.approx(m.global_sum_host(host, mask=m.get("mMask")), rel=1e-13, abs=1e-9)
+        assert m.global_sum_host(host, mask=m.get("mMask")) == m.global_sum("PSURF", 1, 0, mask="mMask")   # host-array form == named form
+    rerun = re.search(r"solver rerun iters\s+(\d+)\s+of\s+(\d+)", out)
+    assert rerun and rerun.group(1) == rerun.group(2)
+    m.close()
