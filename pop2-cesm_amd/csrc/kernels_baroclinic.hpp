@@ -99,6 +99,9 @@ struct TracerRhsArgs {
   double c2dtt;
   int use_kpp_src;
   Upw3Dev up;               // UPW3 only
+  // forward elimination of the implicit vertical mixing fused into the right-hand side (k_tracer_rhs_lds<R, true>): the
+  // elimination coefficients and the reduced right-hand side of tracer n go to E[n], F[n] instead of the RHS to TNEW
+  double *E[2], *F[2];
 };
 
 // UPW3: advt_upwind3 + hupw3 (advection.F90:2313-2481, 2488-2676) in place of advt_centered.  The east
@@ -310,6 +313,31 @@ k_impvmixt(DevGrid g, StepParams sp, ImpvmixtArgs a) {
       const MwjfP P = mwjf_level(g.pressz[k]);
       a.RHO[o] = mwjf_rho<false>(P, a.TNEW[0][o], a.TNEW[1][o], nullptr, nullptr);
     }
+  }
+}
+
+// back substitution of impvmixt (predictor) from elimination coefficients a fused right-hand-side kernel left in
+// E[n], F[n] (k_tracer_rhs_lds<R, true>): T(new) = T(old) + x.  Same operations as the second half of k_impvmixt<0>.
+struct ImpvmixtBackArgs { double *TNEW[2]; const double *TOLD[2], *E[2], *F[2]; };
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_impvmixt_back(DevGrid g, ImpvmixtBackArgs a) {
+  Col c;
+  if (!col_setup(g, c, true)) return;
+  const int km = g.km, n = blockIdx.z;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  double *__restrict__ const TN = a.TNEW[n];
+  const double *__restrict__ const TO = a.TOLD[n];
+  const double *__restrict__ const E = a.E[n];
+  const double *__restrict__ const F = a.F[n];
+  double Fkp1 = 0.0;
+#pragma unroll 4
+  for (int k = km; k >= 1; --k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    double f = F[o];
+    if (k < km && k < kmt) f = f + E[o] * Fkp1;
+    Fkp1 = f;
+    TN[o] = TO[o] + f;
   }
 }
 

@@ -18,7 +18,11 @@ struct TrcTile {
   static_assert(NHALO <= POP_COL_THREADS * R, "every halo cell needs a thread");
 };
 
-template <int R>
+// FWD: the forward elimination of impvmixt (vertical_mix.F90:1263-1340; pressure-averaging predictor, PSFC = PSURF(cur))
+// runs on the right-hand side as it is formed -- level k's value and VDC(k) are in registers anyway -- and E, F are
+// stored instead of the right-hand side: the separate solve then only substitutes back (k_impvmixt_back).  Three field
+// passes per tracer less than right-hand side + k_impvmixt; the same operations in the same order (bitwise equal, tested).
+template <int R, bool FWD = false>
 __global__ void __launch_bounds__(POP_COL_THREADS * R)
 k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
   using T = TrcTile<R>;
@@ -94,6 +98,10 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
   Hal hal = load_halo(1);
   double vtf[2] = {0, 0}, tc_km1[2] = {0.0, 0.0};
   double *__restrict__ const TNp[2] = {a.TNEW[0], a.TNEW[1]};
+  // forward-elimination state per tracer (FWD)
+  const double hfac1 = g.dz[1] / a.c2dtt;
+  const double H1 = hfac1 + (act ? a.PCUR[q2] : 0.0) / (sp.grav * a.c2dtt);
+  double fwA[2] = {0, 0}, fwB[2] = {0, 0}, fwF[2] = {0, 0};
   for (int k = 1; k <= km; ++k) {
     const int buf = k & 1;
     t.u[buf][lc] = cur.u; t.v[buf][lc] = cur.v;
@@ -141,10 +149,38 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
         double src = 0.0;
         if (a.use_kpp_src) src = src + cur.src[n];
         FT = FT + src;
-        if (k == 1 && sp.pavg) {
-          if (kmt > 0) TNp[n][o] = a.c2dtt * FT - 2.0 * tc_k * psfac / (sp.grav * g.dz[1]);
+        if (!FWD) {
+          if (k == 1 && sp.pavg) {
+            if (kmt > 0) TNp[n][o] = a.c2dtt * FT - 2.0 * tc_k * psfac / (sp.grav * g.dz[1]);
+          } else {
+            TNp[n][o] = (k <= kmt) ? a.c2dtt * FT : 0.0;
+          }
         } else {
-          TNp[n][o] = (k <= kmt) ? a.c2dtt * FT : 0.0;
+          // the value the right-hand side would have stored (land columns keep what TNEW(1) held: the reference's don't-care)
+          double rhs;
+          if (k == 1 && sp.pavg) rhs = (kmt > 0) ? a.c2dtt * FT - 2.0 * tc_k * psfac / (sp.grav * g.dz[1]) : TNp[n][o];
+          else rhs = (k <= kmt) ? a.c2dtt * FT : 0.0;
+          if (k == 1) {
+            const double A = g.afac_t[1] * cur.vdc[n];
+            const double D = H1 + A;
+            const double Ek = A / D;
+            fwA[n] = A; fwB[n] = H1 * Ek; fwF[n] = hfac1 * rhs / D;
+            a.E[n][o] = Ek; a.F[n][o] = fwF[n];
+          } else {
+            const double C = fwA[n];
+            const double hf = g.dz[k] / a.c2dtt;
+            const double A = g.afac_t[k] * cur.vdc[n];
+            fwA[n] = A;
+            if (k > kmt) fwF[n] = 0.0;
+            else {
+              const double D = (k == kmt) ? hf + fwB[n] : hf + A + fwB[n];
+              const double Ek = A / D;
+              fwB[n] = (hf + fwB[n]) * Ek;
+              fwF[n] = (hf * rhs + C * fwF[n]) / D;
+              a.E[n][o] = Ek;
+            }
+            a.F[n][o] = fwF[n];
+          }
         }
         tc_km1[n] = tc_k;
       }
@@ -155,10 +191,12 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
 }
 
 template <int R>
-inline void launch_tracer_lds(const DevGrid &g, const StepParams &sp, const TracerRhsArgs &a, hipStream_t st) {
+inline void launch_tracer_lds(const DevGrid &g, const StepParams &sp, const TracerRhsArgs &a, hipStream_t st, bool fwd = false) {
   const int tiles_i = (g.nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
   const int tiles_j = (g.nyb - 2 * NGHOST + R - 1) / R;
-  hipLaunchKernelGGL(k_tracer_rhs_lds<R>, dim3(lds_grid_x(g.lds_order, tiles_i, tiles_j), g.nblocks), dim3(POP_COL_THREADS, R), 0, st, g, sp, a);
+  const dim3 G(lds_grid_x(g.lds_order, tiles_i, tiles_j), g.nblocks), B(POP_COL_THREADS, R);
+  if (fwd) hipLaunchKernelGGL((k_tracer_rhs_lds<R, true>), G, B, 0, st, g, sp, a);
+  else hipLaunchKernelGGL((k_tracer_rhs_lds<R, false>), G, B, 0, st, g, sp, a);
 }
 
 }  // namespace pop

@@ -94,7 +94,8 @@ struct pop_ctx {
   int nsend_all = 0, nrecv_all = 0;
   // fused distributed solvers: per-cell send entries / receive slots (FusedArgs::sendmap, rmap), nz = 1 message order
   int *sendmap = nullptr, *send_off = nullptr, *send_slot = nullptr, *rmap = nullptr;
-  pop_exchange_fn xchg_side = nullptr;                     // the same exchange on the side stream (own communicator), or null
+  pop_exchange_fn xchg_side = nullptr;                     // the same exchange on the communication stream (own communicator), or null
+  hipStream_t comm_side = nullptr;                         // stream of those exchanges (not `side`: impvmixu runs there beside the solver)
   hipEvent_t ev_sa = nullptr, ev_sx = nullptr;            // solver: z packed (launch stream) / z received (side stream)
   long long solver_ops = 0, solver_enq = 0;               // stream operations / iterations enqueued by the last distributed solve (incl. look-ahead)
   // tripole northern boundary, per field location (single rank)
@@ -537,16 +538,16 @@ struct DistSolve {
   // the one-level exchange of the buffers the kernels packed: on the side stream beside the all-reduce when the
   // transport has a second communicator, else in line.  fork: the packed data is complete on the launch stream now.
   bool overlap = true;
-  bool side() const { return overlap && c->xchg_side && c->side && !getenv("POP_SOLVER_OVERLAP_OFF"); }
+  bool side() const { return overlap && c->xchg_side && c->comm_side && !getenv("POP_SOLVER_OVERLAP_OFF"); }
   int xchg_begin() {
     std::vector<int> peer; std::vector<long long> so, sc, ro, rc;
     long long s0 = 0, r0 = 0;
     for (auto &p : c->peers) { peer.push_back(p.rank); so.push_back(s0); sc.push_back(p.nsend); ro.push_back(r0); rc.push_back(p.nrecv); s0 += p.nsend; r0 += p.nrecv; }
     c->solver_ops += 1;
     if (side()) {
-      if (hipEventRecord(c->ev_sa, c->stream) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_sa, 0) != hipSuccess) { c->err = "distributed solver: event failed"; return 1; }
+      if (hipEventRecord(c->ev_sa, c->stream) != hipSuccess || hipStreamWaitEvent(c->comm_side, c->ev_sa, 0) != hipSuccess) { c->err = "distributed solver: event failed"; return 1; }
       if (c->xchg_side(c->comm_user, (int)peer.size(), peer.data(), so.data(), sc.data(), ro.data(), rc.data())) { c->err = "distributed solver: exchange failed" + tr_err(c); return 1; }
-      if (hipEventRecord(c->ev_sx, c->side) != hipSuccess) { c->err = "distributed solver: event failed"; return 1; }
+      if (hipEventRecord(c->ev_sx, c->comm_side) != hipSuccess) { c->err = "distributed solver: event failed"; return 1; }
       return 0;
     }
     if (c->xchg(c->comm_user, (int)peer.size(), peer.data(), so.data(), sc.data(), ro.data(), rc.data())) { c->err = "distributed solver: exchange failed" + tr_err(c); return 1; }
@@ -1385,11 +1386,12 @@ int pop_destroy(pop_ctx *c) {
   for (auto &e : c->chk_ev) if (e) hipEventDestroy(e);
   if (c->rccl_tr) {
     if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->side) hipStreamSynchronize(c->side);
+    if (c->comm_side) hipStreamSynchronize(c->comm_side);
     if (c->rccl_tr->comm2) rccl().CommDestroy(c->rccl_tr->comm2);
     if (c->rccl_tr->comm) rccl().CommDestroy(c->rccl_tr->comm);
     delete c->rccl_tr;
   }
+  if (c->comm_side) hipStreamDestroy(c->comm_side);
   if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
   kpp_destroy(c->mix);
   for (void *p : c->allocs) hipFree(p);
@@ -1712,9 +1714,10 @@ static int phase_hmix_tracer(pop_ctx *c, hipStream_t st = nullptr) {   // del4 o
   if (c->h.c.hmix_tracer != 4) return 0;
   return mix_hdifft_del4(c->h, c->g, step_params(c), c->mix, c->TR[0][c->mixt], c->TR[1][c->mixt], c->d2t[0], c->d2t[1], c->S3c, c->S3d, st ? st : c->stream, c->err);
 }
-static int phase_tracer_rhs(pop_ctx *c) {
+static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   const StepParams sp = step_params(c);
   TracerRhsArgs a{};
+  a.E[0] = c->E3; a.F[0] = c->F3; a.E[1] = c->S3c; a.F[1] = c->S3d;
   for (int n = 0; n < 2; ++n) {
     a.TCUR[n] = c->TR[n][c->curt]; a.TOLD[n] = c->TR[n][c->oldt]; a.TMIX[n] = c->TR[n][c->mixt]; a.TNEW[n] = c->TR[n][c->newt];
     a.VDC[n] = c->VDC[sp.nvdc == 2 ? n : 0]; a.KPP_SRC[n] = c->KPP_SRC[n]; a.STF[n] = c->STF[n]; a.TFW[n] = c->TFW[n];
@@ -1722,8 +1725,9 @@ static int phase_tracer_rhs(pop_ctx *c) {
   if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->d2t[0]; a.TMIX[1] = c->d2t[1]; }   // del4: second Laplacian acts on D2T
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
   a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
-  if (c->h.c.tadvect == 1 && c->trc_lds_rows == 8) { launch_tracer_lds<8>(c->g, sp, a, c->stream); return 0; }
-  if (c->h.c.tadvect == 1 && c->trc_lds_rows == 4) { launch_tracer_lds<4>(c->g, sp, a, c->stream); return 0; }
+  if (c->h.c.tadvect == 1 && c->trc_lds_rows == 8) { launch_tracer_lds<8>(c->g, sp, a, c->stream, fwd); return 0; }
+  if (c->h.c.tadvect == 1 && c->trc_lds_rows == 4) { launch_tracer_lds<4>(c->g, sp, a, c->stream, fwd); return 0; }
+  if (fwd) { c->err = "fused forward elimination needs the LDS tracer kernel"; return 1; }
   if (c->h.c.tadvect == 2) {
     a.up = c->upw3;
     hipLaunchKernelGGL((k_tracer_rhs<false, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
@@ -1737,6 +1741,21 @@ static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {
   a.PSFC = psfc; a.POLD = c->PS[c->oldt]; a.PCUR = c->PS[c->curt]; a.PNEW = c->PS[c->newt]; a.PMIX = c->PS[c->mixt];
   a.E = c->E3; a.F = c->F3; a.RHO = c->RHO[c->newt]; a.c2dtt = c->c2dtt; a.nfirst = 1; a.nlast = 2;
   return a;
+}
+// predictor with the forward elimination inside the right-hand-side kernel: bandwidth-bound grids, centred advection
+// through the LDS kernel, generic (scratch-staged) solve -- POP_TRACER_FWD=0|1 overrides
+static bool tracer_fwd_fused(const pop_ctx *c) {
+  const bool can = c->h.c.tadvect == 1 && (c->trc_lds_rows == 4 || c->trc_lds_rows == 8) && c->h.c.lpressure_avg && c->leapfrogts;
+  if (getenv("POP_TRACER_FWD")) return can && atoi(getenv("POP_TRACER_FWD")) != 0;
+  return can && !c->reg_thomas_t;
+}
+static int phase_impvmixt_back(pop_ctx *c) {
+  ImpvmixtBackArgs b{};
+  for (int n = 0; n < 2; ++n) { b.TNEW[n] = c->TR[n][c->newt]; b.TOLD[n] = c->TR[n][c->oldt]; }
+  b.E[0] = c->E3; b.F[0] = c->F3; b.E[1] = c->S3c; b.F[1] = c->S3d;
+  const dim3 G = grid_cols(c);
+  hipLaunchKernelGGL(k_impvmixt_back, dim3(G.x, G.y, 2), dim3(POP_COL_THREADS), 0, c->stream, c->g, b);
+  return 0;
 }
 static int phase_impvmixt_pred(pop_ctx *c) {
   launch_impvmixt<0, false, false>(c->g, step_params(c), impvmixt_args(c, c->PS[c->curt]), grid_cols(c), c->stream, c->reg_thomas_t);
@@ -1796,9 +1815,10 @@ int pop_baroclinic_driver(pop_ctx *c) {
   if (phase_vmix(c)) return 1;
   if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2t, 0));
   else if (phase_hmix_tracer(c)) return 1;
-  if (phase_tracer_rhs(c)) return 1;
+  const bool fwd = sp.pavg && tracer_fwd_fused(c);
+  if (phase_tracer_rhs(c, fwd)) return 1;
   if (sp.pavg) {
-    if (phase_impvmixt_pred(c)) return 1;
+    if (fwd ? phase_impvmixt_back(c) : phase_impvmixt_pred(c)) return 1;
     if (halo_update_many(c, {{c->TR[0][c->newt], c->g.km}, {c->TR[1][c->newt], c->g.km}})) return 1;
     if (phase_state_new(c)) return 1;
   }
@@ -2325,7 +2345,9 @@ int pop_comm_init_rccl(pop_ctx *c, const unsigned char *id128) {
   // second communicator for exchanges on the side stream (beside an all-reduce on the first).  Its id is made by
   // rank 0 and travels over the first communicator, one byte per double (exact under the sum with the other ranks'
   // zeros), so the host has nothing more to broadcast.  POP_RCCL_OVERLAP=0 keeps everything on one communicator.
-  if (c->side && c->h.nranks > 1 && !(getenv("POP_RCCL_OVERLAP") && atoi(getenv("POP_RCCL_OVERLAP")) == 0)) {
+  // (POP_RCCL_OVERLAP=2 also creates it on a single rank, so that the whole set-up can be checked against the real librccl)
+  const int want2 = getenv("POP_RCCL_OVERLAP") ? atoi(getenv("POP_RCCL_OVERLAP")) : 1;
+  if (c->side && want2 != 0 && (c->h.nranks > 1 || want2 == 2)) {
     std::vector<double> enc(128, 0.0);
     RcclApi::UniqueId id2;
     if (c->h.rank == 0) {
@@ -2339,7 +2361,8 @@ int pop_comm_init_rccl(pop_ctx *c, const unsigned char *id128) {
     for (int b = 0; b < 128; ++b) id2.internal[b] = (char)(unsigned char)enc[b];
     const int rc2 = rccl().CommInitRank(&t->comm2, c->h.nranks, id2, c->h.rank);
     if (rc2) { c->err = "pop_comm_init_rccl: second communicator: " + rccl().what(rc2); return 1; }
-    t->side = &c->side;
+    HIPCHK(c, hipStreamCreateWithFlags(&c->comm_side, hipStreamNonBlocking));
+    t->side = &c->comm_side;
     c->xchg_side = rccl_exchange_side;
   }
   return 0;
@@ -2368,15 +2391,15 @@ int pop_comm_selftest(pop_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int r = 0; r < nr; ++r) if (v[r] != r + 1.0) { c->err = "pop_comm_selftest: all-reduce returned a wrong sum"; return 1; }
   if (back != 1000.0 + prv) { c->err = "pop_comm_selftest: ring send/recv returned a wrong value"; return 1; }
-  if (c->xchg_side && c->side) {   // the same ring through the second communicator on the side stream, beside an all-reduce on the first
+  if (c->xchg_side && c->comm_side) {   // the same ring through the second communicator on its own stream, beside an all-reduce on the first
     const double probe2 = 2000.0 + c->h.rank;
     double back2 = 0.0;
     HIPCHK(c, hipMemcpyAsync(c->sendbuf, &probe2, sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_side, c->ev_fork, 0));
     if (c->xchg_side(c->comm_user, nxt == prv ? 1 : 2, peer, z2, sc1, z2, rc1)) { c->err = "pop_comm_selftest: side-stream exchange failed" + tr_err(c); return 1; }
     if (c->allred(c->comm_user, 0, nr)) { c->err = "pop_comm_selftest: allreduce beside the side-stream exchange failed" + tr_err(c); return 1; }
-    HIPCHK(c, hipStreamSynchronize(c->side));
+    HIPCHK(c, hipStreamSynchronize(c->comm_side));
     HIPCHK(c, hipMemcpyAsync(&back2, c->recvbuf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (back2 != 2000.0 + prv) { c->err = "pop_comm_selftest: side-stream ring send/recv returned a wrong value"; return 1; }
@@ -2450,7 +2473,9 @@ int pop_device_sync(pop_ctx *c) {
 typedef int (*phase_fn_t)(pop_ctx *);
 static phase_fn_t phase_by_name(const std::string &p) {
   if (p == "vmix") return phase_vmix;
-  if (p == "tracer_rhs") return phase_tracer_rhs;
+  if (p == "tracer_rhs") return [](pop_ctx *x) { return phase_tracer_rhs(x); };
+  if (p == "tracer_rhs_fwd") return [](pop_ctx *x) { return phase_tracer_rhs(x, true); };
+  if (p == "impvmixt_back") return phase_impvmixt_back;
   if (p == "impvmixt") return phase_impvmixt_pred;
   if (p == "state") return phase_state_new;
   if (p == "momentum_rhs") return phase_momentum_rhs;

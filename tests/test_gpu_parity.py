@@ -699,3 +699,25 @@ def test_kpp_look_ahead_is_bitwise_neutral(pkg, orclib_built, monkeypatch, kw):
         m.close()
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kw", [{}, {"stepped_bathymetry": 1, "vmix_choice": 3, "km": 24}, {"km": 62, "vmix_choice": 3, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21},
+                                {"lpressure_avg": 0, "tmix_opt": 1, "time_mix_freq": 3}])
+def test_fused_forward_elimination_is_bitwise_neutral(pkg, monkeypatch, kw):
+    """POP_TRACER_FWD=1: the forward elimination of the predictor's implicit vertical mixing runs inside the tracer
+    right-hand-side kernel (k_tracer_rhs_lds<R, true> + k_impvmixt_back) instead of k_impvmixt after it: same operations,
+    same order -- every field equal to the last bit, for both tile heights, land and shallow columns included."""
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for mode, rows in (("0", "8"), ("1", "8"), ("1", "4")):
+        monkeypatch.setenv("POP_TRACER_FWD", mode)
+        monkeypatch.setenv("POP_TRACER_LDS", rows)
+        monkeypatch.setenv("POP_REG_THOMAS_T", "0")
+        m = pkg.PopModel(cfg)
+        for _ in range(5):
+            m.step()
+        out[(mode, rows)] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "PSURF")] + [m.get("TRACER", tl, n).copy() for tl in (0, 1) for n in (0, 1)]
+        m.close()
+    for key in (("1", "8"), ("1", "4")):
+        for a, b in zip(out[("0", "8")], out[key]):
+            assert np.array_equal(a, b), key

@@ -30,6 +30,20 @@ def test_rccl_transport_single_rank(pkg):
     a.close(); b.close()
 
 
+def test_second_communicator_on_real_rccl(pkg, monkeypatch):
+    """POP_RCCL_OVERLAP=2: the second communicator (exchanges on the side stream beside an all-reduce on the first) is
+    created on a single rank too -- its id travels through an all-reduce on the first communicator -- and the self-test
+    runs a send/recv group on it concurrently with an all-reduce: the real librccl accepts the whole set-up."""
+    monkeypatch.setenv("POP_RCCL_OVERLAP", "2")
+    m = pkg.PopModel(named_config("tiny"))
+    m.comm_init_rccl(pkg.PopModel.rccl_unique_id())
+    m.comm_selftest()
+    for _ in range(2):
+        m.step()
+    m.comm_selftest()
+    m.close()
+
+
 def test_selftest_without_transport_fails(pkg):
     m = pkg.PopModel(named_config("tiny"))
     with pytest.raises(pkg.PopError):
