@@ -1096,6 +1096,28 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   pop_ctx *c = new pop_ctx();
   *out = c;
   c->h.c = *cfg; c->h.rank = rank; c->h.nranks = nranks;
+  {   // every option this library does not implement is refused here, before anything is built (the reference aborts
+      // in the init routine of the option's own module, e.g. vertical_mix.F90:280-296, POP_SolversMod.F90:442-472)
+    auto bad = [&](const std::string &m) { c->err = "pop_create: " + m; return 1; };
+    if (cfg->nx_global < 1 || cfg->ny_global < 1 || cfg->km < 2 || cfg->block_size_x < 1 || cfg->block_size_y < 1) return bad("domain / block sizes must be positive (km >= 2)");
+    if (cfg->ew_boundary != 0 && cfg->ew_boundary != 1) return bad("ew_boundary: 0 closed, 1 cyclic");
+    if (cfg->ns_boundary < 0 || cfg->ns_boundary > 2) return bad("ns_boundary: 0 closed, 1 cyclic, 2 tripole");
+    if (cfg->hmix_momentum != 2 && cfg->hmix_momentum != 4) return bad("hmix_momentum: 2 (del2) or 4 (del4); anisotropic / GM are not built");
+    if (cfg->hmix_tracer != 2 && cfg->hmix_tracer != 4) return bad("hmix_tracer: 2 (del2) or 4 (del4); GM is not built");
+    if (cfg->vmix_choice < 1 || cfg->vmix_choice > 3) return bad("vmix_choice: 1 const, 2 rich, 3 kpp");
+    if (cfg->tadvect != 1 && cfg->tadvect != 2) return bad("tadvect: 1 (centered) and 2 (upwind3) are built; lw_lim is not");
+    if (cfg->solver_choice < 1 || cfg->solver_choice > 3) return bad("solver_choice: 1 pcg, 2 ChronGear, 3 PCSI");
+    if (cfg->reserved_i[2] != 0 && cfg->reserved_i[2] != 1) return bad("preconditionerChoice (reserved_i[2]): 0 diagonal, 1 evp");
+    if (cfg->reserved_i[3] != 0 && cfg->reserved_i[3] != 1) return bad("synthetic topography (reserved_i[3]): 0 flat, 1 stepped");
+    if (cfg->max_iterations < 1 || cfg->convergence_check_freq < 1) return bad("max_iterations and convergence_check_freq must be >= 1");
+    if (cfg->tmix_opt < 0 || cfg->tmix_opt > 3) return bad("tmix_opt: 0 none, 1 avg, 2 avgfit, 3 robert");
+    if ((cfg->tmix_opt == 1 || cfg->tmix_opt == 2) && cfg->time_mix_freq < 1) return bad("time_mix_freq must be >= 1");
+    if (cfg->steps_per_day < 1) return bad("steps_per_day must be >= 1");
+    if (cfg->aidif != 1.0) return bad("aidif: only the fully implicit vertical mixing (aidif = 1) is built");
+    if (cfg->vmix_choice == 3 && (cfg->lshort_wave || cfg->lcheckekmo)) return bad("KPP: lshort_wave / lcheckekmo are not built");
+    if (cfg->vmix_choice == 3 && cfg->num_v_smooth_Ri < 1) return bad("KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)");
+    if (!(cfg->convergence_criterion >= 0.0)) return bad("convergence_criterion must be >= 0");
+  }
   if (host_build(c->h)) { c->err = c->h.err; return 1; }
   c->host_only = (flags & POP_CREATE_HOST_ONLY) != 0;
   if (c->host_only) return 0;

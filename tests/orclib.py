@@ -6,7 +6,8 @@ import numpy as np
 from popcfg import PopConfig
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, "oracle", "libpop_oracle.so")
+# POP_ORACLE_LIB: another build of the same source (bench.py's cpu_baseline times the -O3 build; parity uses the default)
+_SO = os.environ.get("POP_ORACLE_LIB") or os.path.join(_ROOT, "oracle", "libpop_oracle.so")
 
 
 def build():

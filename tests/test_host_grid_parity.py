@@ -91,3 +91,15 @@ def test_bad_configs_are_rejected(pkg):
     assert m.L.pop_get_block(m.h, 0, None, None, None) != 0          # get_block: invalid block_id
     assert m.L.pop_get_block(m.h, m.nblocks_tot + 1, None, None, None) != 0
     m.close()
+
+
+@pytest.mark.parametrize("field,value", [("hmix_momentum", 3), ("hmix_tracer", 1), ("vmix_choice", 4), ("solver_choice", 0), ("tadvect", 3),
+                                         ("aidif", 0.5), ("tmix_opt", 7), ("ew_boundary", 2), ("ns_boundary", 5), ("convergence_check_freq", 0),
+                                         ("precond_choice", 2), ("km", 1)])
+def test_unsupported_options_are_refused_at_create(pkg, field, value):
+    """every option value the library does not implement fails loudly in pop_create (host-only contexts included), with a
+    message that names the option"""
+    cfg = named_config("tiny", **{field: value})
+    with pytest.raises(pkg.PopError) as e:
+        pkg.PopModel(cfg, host_only=True)
+    assert "pop_create" in str(e.value)
