@@ -196,9 +196,9 @@ KERNEL_OF_PHASE = {"tracer_rhs": "k_tracer_rhs_lds", "momentum_rhs": "k_momentum
 
 def pmc_traffic(workload, kernel):
     """HBM/fabric bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, separate passes; profiles/r01_pmc_traffic.json).  None when no pass exists for this case."""
+    WRITE_SIZE, separate passes; profiles/r02_pmc_traffic.json).  None when no pass exists for this case."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             t = json.load(f)
         e = t[workload][kernel]
         return e["fetch_bytes"] + e["write_bytes"]
@@ -325,8 +325,14 @@ def main():
     roof = {"bound": "hbm", "kernel": kern, "achieved": phases[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(phases[dom]["GBps"] / HBM_PEAK_GBS, 4),
             "traffic": pmc_traffic(args.workload, kern) if world == 1 else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, profiles/r01_pmc_traffic.json",
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, profiles/r02_pmc_traffic.json",
             "alg_bytes_per_launch": phases[dom]["alg_GB"] * 1e9, "avg_launch_ms": phases[dom]["ms"], "phases": phases}
+    if cfg.hmix_momentum == 4 and dom == "momentum_rhs":
+        # del4: the kernel also reads the two first-Laplacian fields (D2U, D2V), which SURVEY's phase E (written for del2,
+        # where the mix-time fields are the old fields it reads anyway) does not count: 12 words instead of 10.  Reported
+        # beside `frac`, never instead of it.
+        gb12 = 12 * 8.0 * ncell_phys / 1e9
+        roof["frac_with_del4_inputs"] = round(gb12 / (phases[dom]["ms"] * 1e-3) / HBM_PEAK_GBS, 4)
     # both baroclinic stencil kernels together (tracer + momentum right-hand sides): algorithmic bytes / summed time
     pair_gb = phases["tracer_rhs"]["alg_GB"] + phases["momentum_rhs"]["alg_GB"]
     pair_ms = phases["tracer_rhs"]["ms"] + phases["momentum_rhs"]["ms"]
