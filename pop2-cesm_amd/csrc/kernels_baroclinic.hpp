@@ -34,6 +34,16 @@ __global__ void k_dhdt(DevGrid g, StepParams sp, const double *__restrict__ PC, 
 // ------------------------------------------------------------------------------------------
 // state over whole 3-D arrays (state_mod.F90:258-498): RHO = rho(T,S,pressz(k)).  3-D parallel.
 // ------------------------------------------------------------------------------------------
+// the same on the cells p2_first <= p2 < p2_end of every level (a band of rows: rim / interior split around a halo exchange)
+__global__ void k_state3d_rows(DevGrid g, const double *__restrict__ T, const double *__restrict__ S, double *__restrict__ RHO,
+                               int p2_first, int p2_end) {
+  const int p2 = p2_first + blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= p2_end) return;
+  const long long o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
+  const MwjfP P = mwjf_level(g.pressz[k]);
+  RHO[o] = mwjf_rho<false>(P, T[o], S[o], nullptr, nullptr);
+}
 __global__ void k_state3d(DevGrid g, const double *__restrict__ T, const double *__restrict__ S, double *__restrict__ RHO) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y + 1, b = blockIdx.z;

@@ -24,16 +24,17 @@ struct MomTile {
 // 2: two levels in flight, 26 more registers)
 template <int R, int PF = 1>
 __global__ void __launch_bounds__(POP_COL_THREADS * R)
-k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a) {
+k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a, int tj_first, int tj_count) {
   using T = MomTile<R>;
   __shared__ T t;
   const int nxb = g.nxb, nyb = g.nyb, km = g.km;
   const long long n2 = g.n2;
-  // tiles start at the first physical column/row (0-based NGHOST)
+  // tiles start at the first physical column/row (0-based NGHOST); this launch covers the tile rows tj_first .. +tj_count
   const int tiles_i = (nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
-  const int tiles_j = (nyb - 2 * NGHOST + R - 1) / R, b = blockIdx.y;
+  const int b = blockIdx.y;
   int ti, tj;
-  if (!lds_tile(g.lds_order, tiles_i, tiles_j, ti, tj)) return;
+  if (!lds_tile(g.lds_order, tiles_i, tj_count, ti, tj)) return;
+  tj += tj_first;
   const int i0 = NGHOST + ti * POP_COL_THREADS, j0 = NGHOST + tj * R;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * POP_COL_THREADS + tx;
   const int i = i0 + tx, j = j0 + ty;
@@ -218,13 +219,17 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a) {
   if (act) { a.ZX[q2] = zx * hur; a.ZY[q2] = zy * hur; }
 }
 
+// tj_first / tj_count: window of tile rows (default: all) -- the rim / interior split around a halo exchange
 template <int R>
-inline void launch_momentum_lds(const DevGrid &g, const StepParams &sp, const MomentumRhsArgs &a, hipStream_t st) {
+inline void launch_momentum_lds(const DevGrid &g, const StepParams &sp, const MomentumRhsArgs &a, hipStream_t st, int tj_first = 0, int tj_count = -1) {
   const int tiles_i = (g.nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
   const int tiles_j = (g.nyb - 2 * NGHOST + R - 1) / R;
+  if (tj_count < 0) tj_count = tiles_j - tj_first;
+  if (tj_count <= 0) return;
   static const int pf = getenv("POP_MOMENTUM_PF") ? atoi(getenv("POP_MOMENTUM_PF")) : 1;
-  if (pf == 2) hipLaunchKernelGGL((k_momentum_rhs_lds<R, 2>), dim3(lds_grid_x(g.lds_order, tiles_i, tiles_j), g.nblocks), dim3(POP_COL_THREADS, R), 0, st, g, sp, a);
-  else hipLaunchKernelGGL((k_momentum_rhs_lds<R, 1>), dim3(lds_grid_x(g.lds_order, tiles_i, tiles_j), g.nblocks), dim3(POP_COL_THREADS, R), 0, st, g, sp, a);
+  const dim3 G(lds_grid_x(g.lds_order, tiles_i, tj_count), g.nblocks), B(POP_COL_THREADS, R);
+  if (pf == 2) hipLaunchKernelGGL((k_momentum_rhs_lds<R, 2>), G, B, 0, st, g, sp, a, tj_first, tj_count);
+  else hipLaunchKernelGGL((k_momentum_rhs_lds<R, 1>), G, B, 0, st, g, sp, a, tj_first, tj_count);
 }
 
 }  // namespace pop

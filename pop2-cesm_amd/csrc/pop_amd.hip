@@ -94,6 +94,8 @@ struct pop_ctx {
   int nsend_all = 0, nrecv_all = 0;
   // fused distributed solvers: per-cell send entries / receive slots (FusedArgs::sendmap, rmap), nz = 1 message order
   int *sendmap = nullptr, *send_off = nullptr, *send_slot = nullptr, *rmap = nullptr;
+  int max_blocks_per_rank = 0;                             // over all ranks: choices between collective code paths must not depend on the rank
+  bool halo_ns_only = false;                               // every ghost cell owned by another rank lies in a ghost ROW (j-band shards)
   pop_exchange_fn xchg_side = nullptr;                     // the same exchange on the communication stream (own communicator), or null
   hipStream_t comm_side = nullptr;                         // stream of those exchanges (not `side`: impvmixu runs there beside the solver)
   hipEvent_t ev_sa = nullptr, ev_sx = nullptr;            // solver: z packed (launch stream) / z received (side stream)
@@ -259,6 +261,47 @@ int halo_update_many(pop_ctx *c, const std::vector<HaloItem> &items) {
   }
   const int nloc = c->ncopy + c->nfill;
   if (nloc) hipLaunchKernelGGL(k_halo_local_many, dim3((nloc + 255) / 256, tot), dim3(256), 0, c->stream, H, c->copy_dst, c->copy_src, c->ncopy, c->fill_dst, c->nfill, 0.0, n2);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+// The same update in two halves around work that does not need the ghost cells of other ranks (north_star: "halo updates
+// ... overlapped with interior stencil work on a second HIP stream").  begin: ghost copies inside the rank, pack, and the
+// exchange on the communication stream (second communicator); end: unpack and the ghost copies again (corner ghosts
+// take values that just arrived; the others are rewritten with the same values).  Between the two the launch stream
+// may run anything that reads only cells this rank owns or ghosts with a source on this rank.
+bool halo_async_ok(const pop_ctx *c) {
+  return !c->peers.empty() && c->halo_ns_only && c->xchg_side && c->comm_side && c->h.c.ns_boundary != 2 && !getenv("POP_HALO_OVERLAP_OFF");
+}
+struct HaloAsync { HaloFields H; int tot; };
+int halo_many_begin(pop_ctx *c, const std::vector<HaloItem> &items, HaloAsync &A) {
+  HaloFields &H = A.H;
+  H = HaloFields{};
+  H.nf = (int)items.size();
+  int tot = 0;
+  for (int f = 0; f < H.nf; ++f) { H.F[f] = items[f].F; H.nz[f] = items[f].nz; H.lev0[f] = tot; tot += items[f].nz; }
+  H.nztot = tot; A.tot = tot;
+  const int n2 = c->g.n2, nloc = c->ncopy + c->nfill;
+  std::vector<int> peer; std::vector<long long> soff, scnt, roff, rcnt;
+  long long so = 0, ro = 0;
+  for (auto &p : c->peers) {
+    peer.push_back(p.rank); soff.push_back(so); scnt.push_back((long long)p.nsend * tot); roff.push_back(ro); rcnt.push_back((long long)p.nrecv * tot);
+    so += (long long)p.nsend * tot; ro += (long long)p.nrecv * tot;
+  }
+  if (so > c->comm_doubles || ro > c->comm_doubles) { c->err = "halo_update: comm buffer too small"; return 1; }
+  if (nloc) hipLaunchKernelGGL(k_halo_local_many, dim3((nloc + 255) / 256, tot), dim3(256), 0, c->stream, H, c->copy_dst, c->copy_src, c->ncopy, c->fill_dst, c->nfill, 0.0, n2);
+  if (c->nsend_all) hipLaunchKernelGGL(k_halo_pack_many, dim3((c->nsend_all + 255) / 256, tot), dim3(256), 0, c->stream, H, c->sa_src, c->sa_start, c->sa_cnt, c->nsend_all, c->sendbuf, n2);
+  HIPCHK(c, hipEventRecord(c->ev_sa, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->comm_side, c->ev_sa, 0));
+  if (c->xchg_side(c->comm_user, (int)peer.size(), peer.data(), soff.data(), scnt.data(), roff.data(), rcnt.data())) { c->err = "halo_update: exchange failed" + tr_err(c); return 1; }
+  HIPCHK(c, hipEventRecord(c->ev_sx, c->comm_side));
+  return 0;
+}
+int halo_many_end(pop_ctx *c, const HaloAsync &A) {
+  const int n2 = c->g.n2, nloc = c->ncopy + c->nfill;
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sx, 0));
+  if (c->nrecv_all) hipLaunchKernelGGL(k_halo_unpack_many, dim3((c->nrecv_all + 255) / 256, A.tot), dim3(256), 0, c->stream, A.H, c->ra_dst, c->ra_start, c->ra_cnt, c->nrecv_all, (const double *)c->recvbuf, n2);
+  if (nloc) hipLaunchKernelGGL(k_halo_local_many, dim3((nloc + 255) / 256, A.tot), dim3(256), 0, c->stream, A.H, c->copy_dst, c->copy_src, c->ncopy, c->fill_dst, c->nfill, 0.0, n2);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1264,6 +1307,15 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
       for (size_t t = 0; t < ss.size(); ++t) by_cell[ss[t]].push_back((int)t);
       for (auto &kv : by_cell) { smap[kv.first] = (int)off.size() - 1; for (int t : kv.second) slot.push_back(t); off.push_back((int)slot.size()); }
       for (size_t t = 0; t < rd.size(); ++t) rmp[rd[t]] = (int)t;
+      // the same answer on every rank (the overlapped update uses the second communicator: all ranks or none): every
+      // block's east neighbour -- the cyclic one included -- is owned by the block's own rank, i.e. the shards are j-bands
+      c->halo_ns_only = true;
+      for (const BlockInfo &B : h.all_blocks) {
+        int ie = B.iblock + 1;
+        if (ie > h.nbx) { if (h.c.ew_boundary != 1) continue; ie = 1; }
+        for (const BlockInfo &E : h.all_blocks)
+          if (E.jblock == B.jblock && E.iblock == ie && h.block_owner[E.block_id - 1] != h.block_owner[B.block_id - 1]) c->halo_ns_only = false;
+      }
       if (dev_upload(c, &c->sendmap, smap.data(), smap.size()) || dev_upload(c, &c->send_off, off.data(), off.size()) ||
           dev_upload(c, &c->send_slot, slot.data(), std::max<size_t>(slot.size(), 1)) || dev_upload(c, &c->rmap, rmp.data(), rmp.size())) return 1;
       HIPCHK(c, hipEventCreateWithFlags(&c->ev_sa, hipEventDisableTiming));
@@ -1281,6 +1333,11 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     HIPCHK(c, hipHostMalloc((void **)&c->host_sc, sizeof(SolverScalars)));
     HIPCHK(c, hipHostMalloc((void **)&c->host_rr, 8 * sizeof(double)));
     for (auto &e : c->chk_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    {
+      std::vector<int> per(h.nranks, 0);
+      for (int o : h.block_owner) if (o >= 0 && o < h.nranks) per[o]++;
+      c->max_blocks_per_rank = *std::max_element(per.begin(), per.end());
+    }
     c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED");
     if (cfg->solver_choice == 3) {   // omega_k of P-CSI (POP_SolversMod.F90:1617-1620, 1695): a function of the eigenvalue bounds only
       const double csalpha = 2.0 / (h.pcsi_max_eig - h.pcsi_min_eig);
@@ -1787,11 +1844,18 @@ static int phase_state_new(pop_ctx *c) {
   hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->newt], c->TR[1][c->newt], c->RHO[c->newt]);
   return 0;
 }
+// density of the new tracers on the rows j_first <= j < j_end (0-based) of every block
+static void state_new_rows(pop_ctx *c, int j_first, int j_end) {
+  const int p0 = j_first * c->g.nxb, p1 = j_end * c->g.nxb;
+  if (p1 <= p0) return;
+  hipLaunchKernelGGL(k_state3d_rows, dim3((p1 - p0 + 255) / 256, c->g.km, c->g.nblocks), dim3(256), 0, c->stream, c->g,
+                     (const double *)c->TR[0][c->newt], (const double *)c->TR[1][c->newt], c->RHO[c->newt], p0, p1);
+}
 static int phase_hmix_momentum(pop_ctx *c, hipStream_t st = nullptr) {   // del4 only: first Laplacian of the velocity into d2u
   if (c->h.c.hmix_momentum != 4) return 0;
   return mix_hdiffu_del4(c->h, c->g, step_params(c), c->mix, c->U[c->mixt], c->V[c->mixt], c->d2u[0], c->d2u[1], c->S3c, c->S3d, st ? st : c->stream, c->err);
 }
-static int phase_momentum_rhs(pop_ctx *c) {
+static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1) {
   MomentumRhsArgs a{};
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.UOLD = c->U[c->oldt]; a.VOLD = c->V[c->oldt]; a.UMIX = c->U[c->mixt]; a.VMIX = c->V[c->mixt];
   a.RHOOLD = c->RHO[c->oldt]; a.RHOCUR = c->RHO[c->curt]; a.RHONEW = c->RHO[c->newt]; a.VVC = c->VVC; a.DHU = c->DHU;
@@ -1799,8 +1863,8 @@ static int phase_momentum_rhs(pop_ctx *c) {
   a.UNEW = c->U[c->newt]; a.VNEW = c->V[c->newt]; a.ZX = c->ZX; a.ZY = c->ZY;
   // 3x3 stencils staged through LDS (kernels_momentum_lds.hpp): 64x8 tiles measured -11 % (tx0.1v3) / -12 % (gx1v7)
   // against the direct-load kernel, 64x4 +8 %; POP_MOMENTUM_LDS=0|4|8 selects (read at pop_create)
-  if (c->mom_lds_rows == 8) launch_momentum_lds<8>(c->g, step_params(c), a, c->stream);
-  else if (c->mom_lds_rows == 4) launch_momentum_lds<4>(c->g, step_params(c), a, c->stream);
+  if (c->mom_lds_rows == 8) launch_momentum_lds<8>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
+  else if (c->mom_lds_rows == 4) launch_momentum_lds<4>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
   return 0;
 }
@@ -1839,14 +1903,36 @@ int pop_baroclinic_driver(pop_ctx *c) {
   else if (phase_hmix_tracer(c)) return 1;
   const bool fwd = sp.pavg && tracer_fwd_fused(c);
   if (phase_tracer_rhs(c, fwd)) return 1;
+  // several ranks: the exchange of the new tracers' ghost rows runs on the communication stream while the launch stream
+  // forms the density and the momentum right-hand side of every tile that reads no ghost row of another rank; the first
+  // and last tile rows follow once the rows have arrived (same kernels on disjoint tiles: bitwise the serial result)
+  const int mrows = c->mom_lds_rows;
+  const bool overlap = sp.pavg && halo_async_ok(c) && (mrows == 4 || mrows == 8) && !c->h.c.ns_boundary;
+  const int mtiles_j = overlap ? (c->g.nyb - 2 * NGHOST + mrows - 1) / mrows : 0;
   if (sp.pavg) {
     if (fwd ? phase_impvmixt_back(c) : phase_impvmixt_pred(c)) return 1;
-    if (halo_update_many(c, {{c->TR[0][c->newt], c->g.km}, {c->TR[1][c->newt], c->g.km}})) return 1;
-    if (phase_state_new(c)) return 1;
+    if (overlap && mtiles_j >= 3) {
+      HaloAsync HA;
+      if (halo_many_begin(c, {{c->TR[0][c->newt], c->g.km}, {c->TR[1][c->newt], c->g.km}}, HA)) return 1;
+      state_new_rows(c, NGHOST, c->g.nyb - NGHOST);                      // physical rows: own cells + ghosts copied inside the rank
+      if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2u, 0));
+      else if (phase_hmix_momentum(c)) return 1;
+      if (phase_momentum_rhs(c, 1, mtiles_j - 2)) return 1;             // interior tile rows
+      if (halo_many_end(c, HA)) return 1;
+      state_new_rows(c, 0, NGHOST); state_new_rows(c, c->g.nyb - NGHOST, c->g.nyb);   // ghost rows
+      if (phase_momentum_rhs(c, 0, 1) || phase_momentum_rhs(c, mtiles_j - 1, 1)) return 1;   // rim tile rows
+    } else {
+      if (halo_update_many(c, {{c->TR[0][c->newt], c->g.km}, {c->TR[1][c->newt], c->g.km}})) return 1;
+      if (phase_state_new(c)) return 1;
+      if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2u, 0));
+      else if (phase_hmix_momentum(c)) return 1;
+      if (phase_momentum_rhs(c)) return 1;
+    }
+  } else {
+    if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2u, 0));
+    else if (phase_hmix_momentum(c)) return 1;
+    if (phase_momentum_rhs(c)) return 1;
   }
-  if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2u, 0));
-  else if (phase_hmix_momentum(c)) return 1;
-  if (phase_momentum_rhs(c)) return 1;
   // the implicit vertical mixing of U, V is not needed before the step tail: with the register kernel (no shared scratch)
   // it runs on the side stream beside the barotropic solver, whose one-workgroup reduction kernels leave the GPU idle
   if (c->side && c->reg_thomas && (c->g.km == 60 || c->g.km == 62) && !getenv("POP_VMIXU_INLINE")) {
@@ -1864,7 +1950,7 @@ int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
   if (c->h.c.solver_choice == 2) {
     if (c->fused_ok && !c->use_evp) return solver_chrongear_fused(c);
-    if (c->h.nranks > 1 && c->h.nblocks <= 8 && !c->use_evp && !getenv("POP_SOLVER_UNFUSED")) return solver_chrongear_fused_dist(c);
+    if (c->h.nranks > 1 && c->max_blocks_per_rank <= 8 && !c->use_evp && !getenv("POP_SOLVER_UNFUSED")) return solver_chrongear_fused_dist(c);
     return solver_chrongear(c);
   }
   if (c->h.c.solver_choice == 3) {
@@ -1879,7 +1965,7 @@ int pop_solver_run(pop_ctx *c) {
     return solver_pcg_replicated(c);
   }
   if (c->fused_ok) { SolveView v = local_view(c); const int e = solver_pcg_fused(c, v); c->S0 = v.S0; c->S1 = v.S1; return e; }
-  if (c->h.nranks > 1 && c->h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcg_fused_dist(c);
+  if (c->h.nranks > 1 && c->max_blocks_per_rank <= 8 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcg_fused_dist(c);
   return solver_pcg(c);
 }
 int pop_solver_preconditioner(pop_ctx *c, const char *x_name, int x_tl, const char *px_name, int px_tl) {
@@ -2500,7 +2586,7 @@ static phase_fn_t phase_by_name(const std::string &p) {
   if (p == "impvmixt_back") return phase_impvmixt_back;
   if (p == "impvmixt") return phase_impvmixt_pred;
   if (p == "state") return phase_state_new;
-  if (p == "momentum_rhs") return phase_momentum_rhs;
+  if (p == "momentum_rhs") return [](pop_ctx *x) { return phase_momentum_rhs(x); };
   if (p == "impvmixu") return [](pop_ctx *x) { return phase_impvmixu(x); };
   if (p == "correct") return phase_correct;
   if (p == "add_btrop") return [](pop_ctx *x) { return phase_add_btrop(x); };

@@ -84,6 +84,9 @@ def test_multirank_equals_single_rank(nranks, kw, env):
     (4, "solver_choice=2,block_size_x=24,block_size_y=20", {}),       # ChronGear, one block per rank
     (2, "", {"POP_SOLVER_OVERLAP_OFF": "1"}),                         # z exchange in line instead of on the side stream
     (2, "", {"POP_RCCL_OVERLAP": "0"}),                               # one communicator only
+    (2, "ny_global=80,block_size_x=48,block_size_y=40", {"POP_SOLVER_DISTRIBUTED": "1"}),   # two tall j-band blocks: T,S halo beside the interior tiles
+    (2, "ny_global=80,block_size_x=48,block_size_y=40,vmix_choice=3,km=24", {"POP_HALO_OVERLAP_OFF": "1", "POP_SOLVER_DISTRIBUTED": "1"}),
+    (3, "ny_global=120,block_size_x=24,block_size_y=40,vmix_choice=3,km=24", {"POP_SOLVER_DISTRIBUTED": "1"}),   # two blocks per rank side by side, three bands
     (4, "solver_choice=3,block_size_x=24,block_size_y=20", {}),       # P-CSI
     (3, "block_size_x=24,block_size_y=20,vmix_choice=3,km=24", {}),   # uneven ownership, KPP
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3
