@@ -49,6 +49,7 @@ struct orc_model {
   void *kpp;
   void *del4;
   void *upw3;
+  void *lwlim;                /* orc_lwlim.inc (tadvect = 3) */
   void *rf;
   void *pcsi;
   void *evp;

@@ -109,6 +109,7 @@ struct TracerRhsArgs {
   double c2dtt;
   int use_kpp_src;
   Upw3Dev up;               // UPW3 only
+  const double *LTK[2];     // tadvect = 3: L(T) formed beforehand by the lw_lim kernels (kernels_lwlim.hpp); else null
   // forward elimination of the implicit vertical mixing fused into the right-hand side (k_tracer_rhs_lds<R, true>): the
   // elimination coefficients and the reduced right-hand side of tracer n go to E[n], F[n] instead of the RHS to TNEW
   double *E[2], *F[2];
@@ -207,6 +208,8 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
         if (k == 1) L = L - dz2rk * auxb;
         else L = L + dz2rk * (aux[n] - auxb);
         aux[n] = auxb;
+      } else if (a.LTK[0]) {
+        L = a.LTK[n][o];                                   // lw_lim advection (advection.F90:2684-3280), formed beforehand
       } else {
         L = 0.5 * (hdiv * tc_k[n] + VTN * TC[o + nxb] - VTS * TC[o - nxb] + UTE * TC[o + 1] - UTW * TC[o - 1]) * tarear;
         if (k != 1) L = L + dz2rk * wtk * (tc_km1[n] + tc_k[n]);

@@ -14,6 +14,7 @@
 #include "kernels_rf.hpp"
 #include "kernels_pcsi.hpp"
 #include "kernels_evp.hpp"
+#include "kernels_lwlim.hpp"
 #include <fcntl.h>
 #include <unistd.h>
 #include "rccl_transport.hpp"
@@ -113,6 +114,7 @@ struct pop_ctx {
   std::vector<std::pair<std::pair<double *, int>, hipGraphExec_t>> pcsi_graphs;   // keyed by (solution array, variant)
   double rf_S[MAXNT] = {}, rf_S_prev[MAXNT] = {}; bool rf_S_prev_valid[MAXNT] = {};   // Robert filter
   Upw3Dev upw3{};                                          // tadvect = 2
+  LwDev lw{};                                              // tadvect = 3 (lw_lim): flux-velocity and work fields
   RcclTransport *rccl_tr = nullptr;                       // in-library RCCL transport (pop_comm_init_rccl)
   // time stepping
   int oldt = 0, curt = 1, newt = 2, mixt = 1;
@@ -1148,7 +1150,7 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     if (cfg->hmix_momentum != 2 && cfg->hmix_momentum != 4) return bad("hmix_momentum: 2 (del2) or 4 (del4); anisotropic / GM are not built");
     if (cfg->hmix_tracer != 2 && cfg->hmix_tracer != 4) return bad("hmix_tracer: 2 (del2) or 4 (del4); GM is not built");
     if (cfg->vmix_choice < 1 || cfg->vmix_choice > 3) return bad("vmix_choice: 1 const, 2 rich, 3 kpp");
-    if (cfg->tadvect != 1 && cfg->tadvect != 2) return bad("tadvect: 1 (centered) and 2 (upwind3) are built; lw_lim is not");
+    if (cfg->tadvect < 1 || cfg->tadvect > 3) return bad("tadvect: 1 centered, 2 upwind3, 3 lw_lim");
     if (cfg->solver_choice < 1 || cfg->solver_choice > 3) return bad("solver_choice: 1 pcg, 2 ChronGear, 3 PCSI");
     if (cfg->reserved_i[2] != 0 && cfg->reserved_i[2] != 1) return bad("preconditionerChoice (reserved_i[2]): 0 diagonal, 1 evp");
     if (cfg->reserved_i[3] != 0 && cfg->reserved_i[3] != 1) return bad("synthetic topography (reserved_i[3]): 0 flat, 1 stepped");
@@ -1165,7 +1167,6 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
   c->host_only = (flags & POP_CREATE_HOST_ONLY) != 0;
   if (c->host_only) return 0;
   if (cfg->nt != 2) { c->err = "device kernels are built for nt = 2 (T,S) in this round"; return 1; }
-  if (cfg->tadvect != 1 && cfg->tadvect != 2) { c->err = "tadvect: 1 (centered) and 2 (upwind3) are built; lw_lim is not"; return 1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { c->err = "no HIP device available; libpop_amd has no CPU fallback"; return 1; }
   HIPCHK(c, hipStreamCreate(&c->stream));
@@ -1234,6 +1235,13 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
       double *p; if (dev_upload(c, &p, h.upw_z[t].data(), h.upw_z[t].size())) return 1;
       c->upw3.cz[t] = p;
     }
+  }
+  if (cfg->tadvect == 3) {   // lw_lim: three flux-velocity fields, three work fields per tracer
+    const size_t a3l = h.n3 * h.nblocks;
+    if (dev_alloc(c, &c->lw.UTE, a3l) || dev_alloc(c, &c->lw.VTN, a3l) || dev_alloc(c, &c->lw.WTKB, a3l)) return 1;
+    for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->lw.XOUT[n], a3l) || dev_alloc(c, &c->lw.XSTAR[n], a3l) || dev_alloc(c, &c->lw.XSTAR2[n], a3l)) return 1;
+    c->lw.HTE = c->d2["HTE"]; c->lw.HTN = c->d2["HTN"]; c->lw.DXT = c->d2["DXT"]; c->lw.DYT = c->d2["DYT"];
+    if (!c->lw.HTE || !c->lw.HTN || !c->lw.DXT || !c->lw.DYT) { c->err = "lw_lim: grid fields HTE / HTN / DXT / DYT missing"; return 1; }
   }
 #define GI(f) g.f = c->di2[#f]
   GI(KMT); GI(KMU); GI(KMTN); GI(KMTS); GI(KMTE); GI(KMTW); GI(KMTEE); GI(KMTNN);
@@ -1793,9 +1801,26 @@ static int phase_hmix_tracer(pop_ctx *c, hipStream_t st = nullptr) {   // del4 o
   if (c->h.c.hmix_tracer != 4) return 0;
   return mix_hdifft_del4(c->h, c->g, step_params(c), c->mix, c->TR[0][c->mixt], c->TR[1][c->mixt], c->d2t[0], c->d2t[1], c->S3c, c->S3d, st ? st : c->stream, c->err);
 }
+// advt with tadvect = 3 (advection.F90:1667-1708, 2684-3280; comp_flux_vel_ghost :1014-1120): L(T) of both tracers into lw.XOUT
+static int phase_advt_lw_lim(pop_ctx *c) {
+  const int km = c->g.km;
+  const double *X0 = c->TR[0][c->mixt], *X1 = c->TR[1][c->mixt];
+  hipLaunchKernelGGL(k_lw_flux, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, c->lw, (const double *)c->U[c->curt], (const double *)c->V[c->curt], (const double *)c->DH);
+  if (halo_update_many(c, {{c->lw.UTE, km}, {c->lw.VTN, km}, {c->lw.WTKB, km}})) return 1;
+  const dim3 G3((c->g.n2 + 255) / 256, km, c->g.nblocks * 2);
+  hipLaunchKernelGGL(k_lw_z, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+  hipLaunchKernelGGL(k_lw_x, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+  hipLaunchKernelGGL(k_lw_y, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
 static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   const StepParams sp = step_params(c);
   TracerRhsArgs a{};
+  if (c->h.c.tadvect == 3) {
+    if (phase_advt_lw_lim(c)) return 1;
+    a.LTK[0] = c->lw.XOUT[0]; a.LTK[1] = c->lw.XOUT[1];
+  }
   a.E[0] = c->E3; a.F[0] = c->F3; a.E[1] = c->S3c; a.F[1] = c->S3d;
   for (int n = 0; n < 2; ++n) {
     a.TCUR[n] = c->TR[n][c->curt]; a.TOLD[n] = c->TR[n][c->oldt]; a.TMIX[n] = c->TR[n][c->mixt]; a.TNEW[n] = c->TR[n][c->newt];

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from popcfg import named_config  # noqa: E402
 
 FIELDS = [("TRACER", True), ("UVEL", True), ("VVEL", True), ("RHO", True), ("PSURF", False), ("UBTROP", False)]
-NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6, "pcsi_evp": 4}
+NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6, "pcsi_evp": 4, "lw_lim": 5}
 
 
 def config(case):
@@ -29,6 +29,8 @@ def config(case):
                             am=-1.0e23, ah=-1.0e22, solver_choice=2, **small)
     if case == "upwind3":     # third-order upwind tracer advection + Richardson vmix
         return named_config("tiny", tadvect=2, vmix_choice=2, **small)
+    if case == "lw_lim":      # Lax-Wendroff advection with one-dimensional flux limiters + KPP
+        return named_config("tiny", tadvect=3, vmix_choice=3, stepped_bathymetry=1, **small)
     if case == "robert":      # Robert-Asselin-Williams time filter (step_RF) instead of averaging steps
         return named_config("tiny", tmix_opt=3, **small)
     if case == "pcsi_evp":    # CESM's production solver pair: P-CSI with the EVP block preconditioner (one 24x20 block: 8/8/8 x 8/6/6 pieces)

@@ -68,6 +68,7 @@ def test_large_grid_two_ranks_equal_single_rank():
     (2, "precond_choice=1", {}),                                      # EVP preconditioner, pcg: extra z halo per iteration
     (3, "precond_choice=1,solver_choice=3,block_size_x=24,block_size_y=20", {}),   # P-CSI + EVP, uneven ownership
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3 across ranks
+    (2, "tadvect=3", {}),                                             # lw_lim: halo update of the flux-velocity fields across ranks
 ])
 def test_multirank_equals_single_rank(nranks, kw, env):
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
@@ -90,6 +91,7 @@ def test_multirank_equals_single_rank(nranks, kw, env):
     (4, "solver_choice=3,block_size_x=24,block_size_y=20", {}),       # P-CSI
     (3, "block_size_x=24,block_size_y=20,vmix_choice=3,km=24", {}),   # uneven ownership, KPP
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3
+    (4, "tadvect=3,block_size_x=24,block_size_y=20", {}),             # lw_lim, one block per rank
 ])
 def test_native_transport_equals_single_rank(nranks, kw, env):
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",

@@ -156,6 +156,13 @@ def force_kpp_case(gpu, orc):
     ("tiny", {"stepped_bathymetry": 1, "tadvect": 2, "solver_choice": 2}, 4),
     ("tiny", {"stepped_bathymetry": 1, "km": 60, "vmix_choice": 3}, 3),                  # register Thomas kernels with shallow columns
     ("gx3v7", {"stepped_bathymetry": 1, "solver_choice": 3}, 3),
+    # tadvect = 3: Lax-Wendroff advection with one-dimensional flux limiters ('lw_lim', advection.F90:2684-3280)
+    ("tiny", {"tadvect": 3}, 5),
+    ("tiny", {"tadvect": 3, "stepped_bathymetry": 1, "vmix_choice": 3, "km": 24}, 5),
+    ("tiny", {"tadvect": 3, "hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1, "am": -1.0e22, "ah": -1.0e21, "vmix_choice": 2}, 4),
+    ("tiny", {"tadvect": 3, "block_size_x": 48, "block_size_y": 40, "ew_boundary": 0}, 4),       # one block, closed east-west
+    ("gx3v7", {"tadvect": 3}, 3),
+    ("test", {"tadvect": 3, "stepped_bathymetry": 1}, 4),                                         # 96 blocks
 ])
 def test_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
     cfg = named_config(name, **kw)
@@ -504,7 +511,7 @@ def test_evp_preconditioner_is_bitwise_the_oracle(pkg, orclib_built, name, kw):
     gpu.close(); orc.close()
 
 
-@pytest.mark.parametrize("kw", [{}, {"tadvect": 2}, {"hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21},
+@pytest.mark.parametrize("kw", [{}, {"tadvect": 2}, {"tadvect": 3}, {"hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21},
                                 {"block_size_x": 48, "block_size_y": 40}])
 def test_uniform_tracers_stay_uniform_in_the_interior(pkg, kw):
     """The scheme's own invariant on the device (see the oracle twin in tests/test_oracle_fixtures.py): with
