@@ -39,7 +39,7 @@ typedef struct pop_config {
   int hmix_tracer;            /* 2 del2, 4 del4 */
   int lvariable_hmix;         /* hmix_del2.F90:223, hmix_del4.F90:200 */
   int vmix_choice;            /* 1 const, 2 rich, 3 kpp (vertical_mix.F90:280-296) */
-  int tadvect;                /* 1 centered, 2 upwind3  (advection.F90:1667-1729) */
+  int tadvect;                /* 1 centered, 2 upwind3, 3 lw_lim (advection.F90:1667-1729, 2313-2676, 2684-3280) */
   int solver_choice;          /* 1 pcg, 2 ChronGear, 3 PCSI with Lanczos eigenvalue bounds
                                * (POP_SolversMod.F90:442-472, 1510-1835, 2699-2990); preconditioner: reserved_i[2] */
   int max_iterations;

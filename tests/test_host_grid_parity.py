@@ -93,7 +93,7 @@ def test_bad_configs_are_rejected(pkg):
     m.close()
 
 
-@pytest.mark.parametrize("field,value", [("hmix_momentum", 3), ("hmix_tracer", 1), ("vmix_choice", 4), ("solver_choice", 0), ("tadvect", 3),
+@pytest.mark.parametrize("field,value", [("hmix_momentum", 3), ("hmix_tracer", 1), ("vmix_choice", 4), ("solver_choice", 0), ("tadvect", 4),
                                          ("aidif", 0.5), ("tmix_opt", 7), ("ew_boundary", 2), ("ns_boundary", 5), ("convergence_check_freq", 0),
                                          ("precond_choice", 2), ("km", 1)])
 def test_unsupported_options_are_refused_at_create(pkg, field, value):
