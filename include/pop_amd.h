@@ -34,7 +34,7 @@ typedef struct pop_config {
   int nx_global, ny_global, km, nt;   /* domain_size.F90 */
   int block_size_x, block_size_y;     /* domain_size.F90 */
   int ew_boundary;            /* 0 closed, 1 cyclic   (domain.F90 ew_boundary_type) */
-  int ns_boundary;            /* 0 closed, 1 cyclic, 2 tripole (halo updates only: the internal grid is lat-lon) */
+  int ns_boundary;            /* 0 closed, 1 cyclic, 2 tripole (time stepping: with pop_create_with_grid) */
   int hmix_momentum;          /* 2 del2, 4 del4       (horizontal_mix.F90:427-472) */
   int hmix_tracer;            /* 2 del2, 4 del4 */
   int lvariable_hmix;         /* hmix_del2.F90:223, hmix_del4.F90:200 */
@@ -75,6 +75,21 @@ typedef struct pop_ctx pop_ctx;
 /* ---- lifecycle (no reference counterpart: the reference's state is module
  *      global, initial.F90:133-699 builds it) -------------------------------- */
 int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx **out);
+/* horiz_grid_opt = 'file' / topography_opt = 'file' (grid.F90:1314-1542 read_horiz_grid, :2025-2107 read_topography):
+ * the seven records of horiz_grid_file and the KMT record of topography_file as global (nx_global, ny_global)
+ * arrays, i fastest, scattered with the reference's field locations (mpi/gather_scatter.F90:862-1161, tripole ghost
+ * rows mirrored).  KMT = NULL: topography_internal on the supplied ULAT / ULON.  ANGLE is accepted for file-format
+ * parity; nothing on this path reads it (the analytic wind stress is not rotated).  The arrays are read during the
+ * call only.  A tripole decomposition (ns_boundary = 2) steps only on a grid supplied this way: the internal grid is
+ * lat-lon and has no values beyond the fold.  pop_read_grid_files fills the arrays from the reference's direct-access
+ * binary files (records of nx_global*ny_global r8 / one record of i4, native byte order). */
+typedef struct pop_grid_input {
+  const double *ULAT, *ULON, *HTN, *HTE, *HUS, *HUW, *ANGLE;
+  const int *KMT;
+} pop_grid_input;
+int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int rank, int nranks, int flags, pop_ctx **out);
+int pop_read_grid_files(const char *horiz_grid_file, const char *topography_file, int nx_global, int ny_global,
+                        double *seven_records /* 7*nx*ny, or NULL */, int *kmt /* nx*ny, or NULL */);
 int pop_destroy(pop_ctx *ctx);
 const char *pop_last_error(const pop_ctx *ctx);
 
@@ -116,6 +131,8 @@ int pop_dhdt(pop_ctx *ctx);                      /* surface_hgt.F90:131   dhdt(D
 int pop_baroclinic_driver(pop_ctx *ctx);         /* baroclinic.F90:578    baroclinic_driver(ZX,ZY,DH,DHU,err) */
 int pop_barotropic_driver(pop_ctx *ctx);         /* barotropic.F90:267    barotropic_driver(ZX,ZY,err)
                                                     (includes the ZX,ZY halo of step_mod.F90:405-423) */
+int pop_barotropic_driver_updated(pop_ctx *ctx); /* barotropic.F90:267 alone: ZX, ZY already halo-updated by the caller
+                                                    (as step_mod.F90:405-423 does before the call) */
 int pop_baroclinic_correct_adjust(pop_ctx *ctx); /* baroclinic.F90:1217 */
 int pop_step_tail(pop_ctx *ctx);                 /* step_mod.F90:467-832  halos, +barotropic, PGUESS,
                                                     averaging step / time-level rotation */

@@ -9,6 +9,7 @@
 
 struct orc_model {
   orc_config c;
+  const orc_grid_input *gin;  /* only during construction */
   int nxb, nyb, km, nt, nblocks, nbx, nby;
   size_t n2, n3;
   int *i_glob, *j_glob, *blk_ib, *blk_ie, *blk_jb, *blk_je;

@@ -209,6 +209,42 @@ void orc_halo_update_tripole_int(orc_model *m, int *a, int loc, int kind) {
   orc_halo_update_int(m, a);
   ORC_TRIPOLE_BODY(int, abs, ORC_AVG_I4)
 }
+/* POP_HaloUpdate with its fieldLoc / fieldKind arguments (mpi/POP_HaloMod.F90:1732-1773) */
+void orc_halo(orc_model *m, double *a, int nz, int loc, int kind) {
+  if (m->c.ns_boundary == 2) orc_halo_update_tripole(m, a, nz, loc, kind); else orc_halo_update(m, a, nz, 0);
+}
+void orc_halo_int(orc_model *m, int *a, int loc, int kind) {
+  if (m->c.ns_boundary == 2) orc_halo_update_tripole_int(m, a, loc, kind); else orc_halo_update_int(m, a);
+}
+
+/* scatter_global (mpi/gather_scatter.F90:862-1161 r8, int alike): local (ghost cells included) <- global array;
+ * cells with a zero global index keep 0; ghost rows beyond a tripole boundary (j_glob < 0) read the mirrored
+ * address isrc = nx_global + xoffset - i_glob, jsrc = ny_global + yoffset + (j_glob + ny_global) with the
+ * offsets of the field location (:929-945).  No sign factor is applied there (:1036, :1117).           */
+#define ORC_SCATTER_BODY                                                                              \
+  const orc_config *c = &m->c;                                                                        \
+  const int nxb = m->nxb, nyb = m->nyb, nx = c->nx_global, ny = c->ny_global;                         \
+  int xoffset = 1, yoffset = 1;                                                                       \
+  if (loc == ORC_NECORNER) { xoffset = 0; yoffset = 0; }                                              \
+  else if (loc == ORC_EFACE) { xoffset = 0; yoffset = 1; }                                            \
+  else if (loc == ORC_NFACE) { xoffset = 1; yoffset = 0; }                                            \
+  for (int b = 0; b < m->nblocks; b++) {                                                              \
+    const int *ig = m->i_glob + (size_t)b * nxb, *jg = m->j_glob + (size_t)b * nyb;                   \
+    for (int j = 1; j <= nyb; j++) for (int i = 1; i <= nxb; i++) {                                   \
+      size_t p = (size_t)b * m->n2 + (size_t)(j - 1) * nxb + (i - 1);                                 \
+      A[p] = 0;                                                                                       \
+      if (ig[i - 1] == 0 || jg[j - 1] == 0) continue;                                                 \
+      if (jg[j - 1] > 0) A[p] = G[(size_t)(jg[j - 1] - 1) * nx + ig[i - 1] - 1];                      \
+      else {                                                                                          \
+        int jsrc = ny + yoffset + (jg[j - 1] + ny), isrc = nx + xoffset - ig[i - 1];                  \
+        if (isrc < 1) isrc = isrc + nx;                                                               \
+        if (isrc > nx) isrc = isrc - nx;                                                              \
+        A[p] = G[(size_t)(jsrc - 1) * nx + isrc - 1];                                                 \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+static void scatter_global_r8(orc_model *m, double *A, const double *G, int loc) { ORC_SCATTER_BODY }
+static void scatter_global_i4(orc_model *m, int *A, const int *G, int loc) { ORC_SCATTER_BODY }
 
 /* ------------------------------------------------------------------ */
 /* global sum: serial/POP_ReductionsMod.F90:200-300, serial/global_reductions.F90
@@ -322,6 +358,11 @@ static void horiz_grid(orc_model *m) {
   double dlon = 360.0 / (double)nxg, dlat = 180.0 / (double)nyg;
   double *ULAT_G = dalloc((size_t)nxg * nyg), *ULON_G = dalloc((size_t)nxg * nyg);
   int *KMT_G = ialloc((size_t)nxg * nyg);
+  const orc_grid_input *gin = m->gin;
+  if (gin) {
+    memcpy(ULAT_G, gin->ULAT, (size_t)nxg * nyg * sizeof(double));
+    memcpy(ULON_G, gin->ULON, (size_t)nxg * nyg * sizeof(double));
+  } else {
   for (int i = 1; i <= nxg; i++) {
     double xdeg = i * dlon;
     if (xdeg > 180.0) xdeg = xdeg - 360.0;
@@ -329,6 +370,7 @@ static void horiz_grid(orc_model *m) {
   }
   for (int j = 1; j <= nyg; j++)
     for (int i = 1; i <= nxg; i++) ULAT_G[(size_t)(j - 1) * nxg + i - 1] = (-90.0 + j * dlat) / radian;
+  }
   /* topography_internal (kmt_global branch) grid.F90:1957-1985 */
   for (int j = 1; j <= nyg; j++)
     for (int i = 1; i <= nxg; i++) {
@@ -349,6 +391,48 @@ static void horiz_grid(orc_model *m) {
       }
       KMT_G[p] = kmt;
     }
+  if (gin && gin->KMT) memcpy(KMT_G, gin->KMT, (size_t)nxg * nyg * sizeof(int));   /* read_topography :2062-2090 */
+  if (gin) {
+    /* read_horiz_grid grid.F90:1422-1536: records scattered with their field locations, the U/T spacings from
+     * averaged HTN / HTE, non-positive lengths (closed-boundary ghosts) replaced by 1 */
+    size_t ng = (size_t)nxg * nyg;
+    double *W = dalloc(ng);
+#define G2(A, i, j) (A)[(size_t)((j)-1) * nxg + (i)-1]
+    scatter_global_r8(m, m->ULAT, ULAT_G, ORC_NECORNER);
+    scatter_global_r8(m, m->ULON, ULON_G, ORC_NECORNER);
+    scatter_global_r8(m, m->HTN, gin->HTN, ORC_NFACE);
+    for (int j = 1; j <= nyg; j++) for (int i = 1; i <= nxg; i++) {
+      int ip1 = i + 1; if (i == nxg) ip1 = 1;
+      G2(W, i, j) = 0.5 * (G2(gin->HTN, i, j) + G2(gin->HTN, ip1, j));
+    }
+    scatter_global_r8(m, m->DXU, W, ORC_NECORNER);
+    for (int j = 1; j <= nyg; j++) {
+      int jm1 = j - 1; if (j == 1) jm1 = nyg;
+      for (int i = 1; i <= nxg; i++) G2(W, i, j) = 0.5 * (G2(gin->HTN, i, j) + G2(gin->HTN, i, jm1));
+    }
+    scatter_global_r8(m, m->DXT, W, ORC_CENTER);
+    scatter_global_r8(m, m->HTE, gin->HTE, ORC_EFACE);
+    for (int j = 1; j <= nyg; j++) for (int i = 1; i <= nxg; i++) {
+      int im1 = i - 1; if (i == 1) im1 = nxg;
+      G2(W, i, j) = 0.5 * (G2(gin->HTE, i, j) + G2(gin->HTE, im1, j));
+    }
+    scatter_global_r8(m, m->DYT, W, ORC_CENTER);
+    for (int j = 1; j <= nyg; j++) {
+      int jp1 = j + 1; if (j == nyg) jp1 = 1;
+      for (int i = 1; i <= nxg; i++) G2(W, i, j) = 0.5 * (G2(gin->HTE, i, j) + G2(gin->HTE, i, jp1));
+    }
+    if (c->ns_boundary == 2)   /* tripole-grid correction :1495-1500 */
+      for (int i = 1; i <= nxg; i++) G2(W, i, nyg) = G2(gin->HTE, i, nyg);
+    scatter_global_r8(m, m->DYU, W, ORC_NECORNER);
+    scatter_global_r8(m, m->HUS, gin->HUS, ORC_EFACE);
+    scatter_global_r8(m, m->HUW, gin->HUW, ORC_NFACE);
+#undef G2
+    free(W);
+    double *pos[8] = {m->HTN, m->HTE, m->HUS, m->HUW, m->DXU, m->DYU, m->DXT, m->DYT};
+    for (int q = 0; q < 8; q++)
+      for (size_t p = 0; p < m->n2 * m->nblocks; p++) if (pos[q][p] <= 0.0) pos[q][p] = 1.0;
+    scatter_global_i4(m, m->KMT, KMT_G, ORC_CENTER);
+  }
   for (int b = 0; b < m->nblocks; b++) {
     const int *ig = m->i_glob + (size_t)b * nxb, *jgl = m->j_glob + (size_t)b * nyb;
     size_t o = (size_t)b * m->n2;
@@ -356,7 +440,7 @@ static void horiz_grid(orc_model *m) {
     double *DXU = m->DXU + o, *DYU = m->DYU + o, *DXT = m->DXT + o, *DYT = m->DYT + o;
     double *ULAT = m->ULAT + o, *ULON = m->ULON + o;
     int *KMT = m->KMT + o;
-    for (int j = 1; j <= nyb; j++) {
+    for (int j = 1; j <= nyb && !gin; j++) {
       int jg = jgl[j - 1], jm1 = jg - 1;
       if (jm1 < 1) jm1 = nyg;
       for (int i = 1; i <= nxb; i++) {
@@ -445,7 +529,7 @@ static void horiz_grid(orc_model *m) {
     if (jgl[jb - 1] == 1)
       for (int i = ib; i <= ie; i++) TLAT[P2(i, jb)] = 2.0 * TLAT[P2(i, jb + 1)] - TLAT[P2(i, jb + 2)];
   }
-  orc_halo_update(m, m->TLAT, 1, 0);
+  orc_halo(m, m->TLAT, 1, ORC_CENTER, ORC_SCALAR);
   free(ULAT_G); free(ULON_G); free(KMT_G);
 
   /* flat bottom: where (KMT /= 0) KMT = km (grid.F90:880-884) -- already km */
@@ -459,7 +543,7 @@ static void horiz_grid(orc_model *m) {
       KMU[P2(i, j)] = mn;
     }
   }
-  orc_halo_update_int(m, m->KMU);
+  orc_halo_int(m, m->KMU, ORC_NECORNER, ORC_SCALAR);
   for (int b = 0; b < m->nblocks; b++) {
     size_t o = (size_t)b * m->n2;
     int *KMT = m->KMT + o, *KMU = m->KMU + o;
@@ -603,8 +687,8 @@ static void init_del2(orc_model *m) {
       m->AMF[p] = sqrt(m->UAREA[p] / ref);
       m->AHF[p] = sqrt(m->TAREA[p] / ref);
     }
-    orc_halo_update(m, m->AMF, 1, 0);
-    orc_halo_update(m, m->AHF, 1, 0);
+    orc_halo(m, m->AMF, 1, ORC_NECORNER, ORC_SCALAR);
+    orc_halo(m, m->AHF, 1, ORC_CENTER, ORC_SCALAR);
   }
 #define P2(i, j) ((size_t)((j)-1) * nxb + (i)-1)
 #define E(A, i, j) esh(A, nxb, nyb, i, j)

@@ -30,7 +30,7 @@ typedef struct {
   int nx_global, ny_global, km, nt;
   int block_size_x, block_size_y;
   int ew_boundary;            /* 0 closed, 1 cyclic */
-  int ns_boundary;            /* 0 closed, 1 cyclic, 2 tripole (halo updates only) */
+  int ns_boundary;            /* 0 closed, 1 cyclic, 2 tripole (time stepping needs orc_create_with_grid) */
   int hmix_momentum;          /* 2 del2, 4 del4 */
   int hmix_tracer;            /* 2 del2, 4 del4 */
   int lvariable_hmix;         /* variable hmix coefficients */
@@ -57,7 +57,16 @@ typedef struct {
 
 typedef struct orc_model orc_model;
 
+/* horiz_grid_opt = 'file' / topography_opt = 'file' (grid.F90:1314-1542 read_horiz_grid, :2025-2107 read_topography):
+ * the records of horiz_grid_file (ULAT, ULON, HTN, HTE, HUS, HUW, ANGLE) and of topography_file (KMT) as global
+ * (nx_global, ny_global) arrays, i fastest.  KMT = NULL: topography_internal on the supplied ULAT/ULON. */
+typedef struct {
+  const double *ULAT, *ULON, *HTN, *HTE, *HUS, *HUW, *ANGLE;
+  const int *KMT;
+} orc_grid_input;
+
 orc_model *orc_create(const orc_config *cfg);
+orc_model *orc_create_with_grid(const orc_config *cfg, const orc_grid_input *grid);   /* grid = NULL: orc_create */
 void       orc_destroy(orc_model *m);
 
 /* array access by the reference's variable name; tl = 0 old,1 cur,2 new
@@ -86,6 +95,11 @@ void   orc_state(orc_model *m, int k, int kk, const double *T, const double *S,
 double orc_state_point(double T, double S_msu, double p_bar);
 void   orc_halo_update(orc_model *m, double *a, int nz, int fieldloc_unused);
 void   orc_halo_update_int(orc_model *m, int *a);
+/* POP_HaloUpdate(array, halo, fieldLoc, fieldKind): the ordinary update, plus the tripole pass when ns_boundary = 2 */
+enum { ORC_CENTER = 0, ORC_NECORNER = 1, ORC_NFACE = 2, ORC_EFACE = 3 };
+enum { ORC_SCALAR = 0, ORC_VECTOR = 1, ORC_ANGLE = 2 };
+void   orc_halo(orc_model *m, double *a, int nz, int loc, int kind);
+void   orc_halo_int(orc_model *m, int *a, int loc, int kind);
 /* tripole northern boundary (mpi/POP_HaloMod.F90:1936-2050); loc 0 centre, 1 NE corner, 2 N face, 3 E face; kind 0 scalar, 1 vector, 2 angle */
 void   orc_halo_update_tripole(orc_model *m, double *a, int nz, int loc, int kind);
 void   orc_halo_update_tripole_int(orc_model *m, int *a, int loc, int kind);

@@ -45,13 +45,15 @@ def lib():
     pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int)
     sig = {
         "pop_create": (ci, [vp, ci, ci, ci, C.POINTER(vp)]), "pop_destroy": (ci, [vp]),
+        "pop_create_with_grid": (ci, [vp, vp, ci, ci, ci, C.POINTER(vp)]),
+        "pop_read_grid_files": (ci, [cs, cs, ci, ci, pd, pi]),
         "pop_last_error": (cs, [vp]), "pop_get_dim": (ci, [vp, cs]), "pop_get_scalar": (cd, [vp, cs]),
         "pop_get_block": (ci, [vp, ci, pi, pi, pi]), "pop_local_block_ids": (ci, [vp, pi]),
         "pop_get_field": (ci, [vp, cs, ci, ci, pd, ll]), "pop_set_field": (ci, [vp, cs, ci, ci, pd, ll]),
         "pop_get_ifield": (ci, [vp, cs, pi, ll]), "pop_field_count": (ll, [vp, cs]),
         "pop_field_device_ptr": (vp, [vp, cs, ci, ci]),
         "pop_time_manager": (ci, [vp]), "pop_dhdt": (ci, [vp]), "pop_baroclinic_driver": (ci, [vp]),
-        "pop_barotropic_driver": (ci, [vp]), "pop_baroclinic_correct_adjust": (ci, [vp]),
+        "pop_barotropic_driver": (ci, [vp]), "pop_barotropic_driver_updated": (ci, [vp]), "pop_baroclinic_correct_adjust": (ci, [vp]),
         "pop_step_tail": (ci, [vp]), "pop_step": (ci, [vp]),
         "pop_halo_update": (ci, [vp, cs, ci, ci]),
         "pop_halo_update_host_r8": (ci, [vp, pd, ci, cd]), "pop_halo_update_host_i4": (ci, [vp, pi, ci, ci]),
@@ -103,15 +105,62 @@ class PopError(RuntimeError):
     pass
 
 
+class PopGridInput(C.Structure):
+    """include/pop_amd.h pop_grid_input"""
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")] + [("KMT", C.POINTER(C.c_int))]
+
+
+def grid_input(grid, nx, ny):
+    """dict of (ny, nx) arrays -> (PopGridInput, the contiguous arrays it points into)"""
+    gin, keep = PopGridInput(), []
+    for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE"):
+        if grid.get(n) is None:
+            continue
+        a = np.ascontiguousarray(grid[n], dtype=np.float64)
+        if a.shape != (ny, nx):
+            raise ValueError("grid[%s]: shape %s, expected (ny_global, nx_global) = %s" % (n, a.shape, (ny, nx)))
+        keep.append(a)
+        setattr(gin, n, a.ctypes.data_as(C.POINTER(C.c_double)))
+    if grid.get("KMT") is not None:
+        a = np.ascontiguousarray(grid["KMT"], dtype=np.int32)
+        if a.shape != (ny, nx):
+            raise ValueError("grid[KMT]: shape %s, expected %s" % (a.shape, (ny, nx)))
+        keep.append(a)
+        gin.KMT = a.ctypes.data_as(C.POINTER(C.c_int))
+    return gin, keep
+
+
+def read_grid_files(horiz_grid_file, topography_file, nx, ny):
+    """the reference's direct-access binary files -> the dict PopModel(grid=...) takes"""
+    rec = np.empty((7, ny, nx), dtype=np.float64)
+    kmt = np.empty((ny, nx), dtype=np.int32)
+    e = lib().pop_read_grid_files(horiz_grid_file.encode(), topography_file.encode() if topography_file else None, nx, ny,
+                                  rec.ctypes.data_as(C.POINTER(C.c_double)), kmt.ctypes.data_as(C.POINTER(C.c_int)))
+    if e:
+        raise PopError("pop_read_grid_files: cannot read %s" % (horiz_grid_file if e == 1 else topography_file))
+    g = {n: rec[i] for i, n in enumerate(("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE"))}
+    if topography_file:
+        g["KMT"] = kmt
+    return g
+
+
 class PopModel:
     """One rank's model instance.  Array views are numpy arrays shaped
     (nblocks_local, [km,] ny_block, nx_block) = the reference layout read in C order."""
 
-    def __init__(self, cfg, rank=0, nranks=1, host_only=False):
+    def __init__(self, cfg, rank=0, nranks=1, host_only=False, grid=None):
+        """grid: None (the internal lat-lon grid) or a dict of global (ny_global, nx_global) arrays ULAT, ULON, HTN,
+        HTE, HUS, HUW [, ANGLE] [, KMT] -- the records of horiz_grid_file / topography_file (pop_create_with_grid)."""
         self.L = lib()
         self.cfg = cfg
         self.h = C.c_void_p()
-        e = self.L.pop_create(C.byref(cfg), rank, nranks, POP_CREATE_HOST_ONLY if host_only else 0, C.byref(self.h))
+        flags = POP_CREATE_HOST_ONLY if host_only else 0
+        if grid is None:
+            e = self.L.pop_create(C.byref(cfg), rank, nranks, flags, C.byref(self.h))
+        else:
+            gin, keep = grid_input(grid, cfg.nx_global, cfg.ny_global)
+            e = self.L.pop_create_with_grid(C.byref(cfg), C.byref(gin), rank, nranks, flags, C.byref(self.h))
+            del keep
         if e:
             msg = self.L.pop_last_error(self.h).decode() if self.h else "pop_create failed"
             raise PopError(msg)
@@ -182,8 +231,9 @@ class PopModel:
     def baroclinic_driver(self):
         self._chk(self.L.pop_baroclinic_driver(self.h))
 
-    def barotropic_driver(self):
-        self._chk(self.L.pop_barotropic_driver(self.h))
+    def barotropic_driver(self, zx_zy_updated=False):
+        """zx_zy_updated: the caller has already updated the halos of ZX, ZY (step_mod.F90:405-423)"""
+        self._chk((self.L.pop_barotropic_driver_updated if zx_zy_updated else self.L.pop_barotropic_driver)(self.h))
 
     def baroclinic_correct_adjust(self):
         self._chk(self.L.pop_baroclinic_correct_adjust(self.h))

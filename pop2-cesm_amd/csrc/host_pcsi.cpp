@@ -105,18 +105,18 @@ int host_pcsi_prep(HostModel &h, const std::vector<double> &C) {
   double csc = -host_global_sum(h, WORK.data(), mMask.data()), csa, csb = 0.0, u = 0.0, v = 0.0, mineig = 1.0;
   if (!(csc > 0.0)) { h.err = "PcsiLanczos: start vector has zero norm (singular operator)"; return 1; }
   for (size_t p = 0; p < A2; ++p) Q[p] = (1 / std::sqrt(csc)) * R[p];
-  host_halo_r8(h, Q.data(), 1, 0.0);
+  host_halo_r8_loc(h, Q.data(), 1, 0.0, 0, 0);
   std::vector<double> vcsa(maxstep + 2), vcsb(maxstep + 2), mcsa(maxstep + 2), mcsb(maxstep + 2);
   h.pcsi_lanczos_steps = 0;
   for (int m = 1; m <= maxstep; ++m) {
     h.pcsi_lanczos_steps = m;
     precond(P, Q);
-    host_halo_r8(h, P.data(), 1, 0.0);
+    host_halo_r8_loc(h, P.data(), 1, 0.0, 0, 0);
     op(WORK1, P);
     for (size_t p = 0; p < A2; ++p) { R[p] = WORK1[p] - csb * Q1[p]; WORK[p] = P[p] * R[p]; }
     csa = -host_global_sum(h, WORK.data(), mMask.data());
     for (size_t p = 0; p < A2; ++p) R[p] = R[p] - csa * Q[p];
-    host_halo_r8(h, R.data(), 1, 0.0);
+    host_halo_r8_loc(h, R.data(), 1, 0.0, 0, 0);
     precond(S, R);
     for (size_t p = 0; p < A2; ++p) WORK[p] = S[p] * R[p];
     csc = -host_global_sum(h, WORK.data(), mMask.data());

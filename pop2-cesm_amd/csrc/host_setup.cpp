@@ -227,6 +227,7 @@ int host_build(HostModel &h) {
   }
   make_blocks(h);
   if (h.nblocks == 0) { h.err = "rank owns no blocks (more ranks than blocks)"; return 1; }
+  build_halo_plan(h);   // needs the blocks only; the tripole pass of the grid-time halo updates below reads it
   if (make_vertical(h)) return 1;
 
   const int nxb = h.nxb, nyb = h.nyb, NB = h.nblocks_tot;
@@ -242,9 +243,7 @@ int host_build(HostModel &h) {
   const double dlon = 360.0 / (double)nxg, dlat = 180.0 / (double)nyg;
   auto ulat_g = [&](int jg) { return (-90.0 + jg * dlat) / radian; };          // jg 1-based
   auto ulon_g = [&](int ig) { double x = ig * dlon; if (x > 180.0) x = x - 360.0; return x / radian; };
-  auto kmt_g = [&](int ig, int jg) {
-    const double latd = ulat_g(jg) * radian;
-    double lond = ulon_g(ig) * radian;
+  auto kmt_ll = [&](const double latd, double lond, int ig, int jg) {
     if (lond < 0.0) lond = lond + 360.0;
     int k = h.km;
     if (latd > -35.0 && lond > 210.0 && lond < 250.0) k = 0;
@@ -258,14 +257,58 @@ int host_build(HostModel &h) {
     if (k > 0 && c.reserved_i[3] == 1) k = std::max(3, h.km - ((ig / 3) * 5 + (jg / 2) * 3) % (h.km / 2 + 1));
     return k;
   };
+  auto kmt_g = [&](int ig, int jg) { return kmt_ll(ulat_g(jg) * radian, ulon_g(ig) * radian, ig, jg); };
   auto &ULAT = newf("ULAT"), &ULON = newf("ULON"), &TLAT = newf("TLAT");
   auto &HTN = newf("HTN"), &HTE = newf("HTE"), &HUS = newf("HUS"), &HUW = newf("HUW");
   auto &DXU = newf("DXU"), &DYU = newf("DYU"), &DXT = newf("DXT"), &DYT = newf("DYT");
   auto &KMT = newi("KMT"), &KMU = newi("KMU");
   const double cell = dlat * RADIUS / radian, cellx = dlon * RADIUS / radian;
+  const pop_grid_input *gin = h.gin;
+  if (gin) {
+    // horiz_grid_opt = 'file' (grid.F90:1314-1542 read_horiz_grid) and topography_opt = 'file' (:2025-2107) on the
+    // caller's global arrays.  scatter_global (mpi/gather_scatter.F90:862-1161): every local cell, ghosts included,
+    // reads its global address; zero global index -> 0; ghost rows beyond a tripole boundary read the address mirrored
+    // with the offsets of the field location (centre 1,1; NE corner 0,0; E face 0,1; N face 1,0), no sign factor.
+    auto scatter = [&](auto &A, auto G, int loc) {
+      const int xo = (loc == 0 || loc == 2) ? 1 : 0, yo = (loc == 0 || loc == 3) ? 1 : 0;
+      for (int b = 0; b < NB; ++b) {
+        const BlockInfo &B = h.all_blocks[b];
+        for (int j = 0; j < nyb; ++j) for (int i = 0; i < nxb; ++i) {
+          const int ig = B.i_glob[i], jg = B.j_glob[j];
+          auto &dst = A[idx(b, i, j)];
+          dst = 0;
+          if (ig == 0 || jg == 0) continue;
+          if (jg > 0) { dst = G(ig, jg); continue; }
+          const int js = nyg + yo + (jg + nyg);
+          int is = nxg + xo - ig;
+          if (is < 1) is += nxg;
+          if (is > nxg) is -= nxg;
+          dst = G(is, js);
+        }
+      }
+    };
+    auto rec = [&](const double *R) { return [R, nxg](int i, int j) { return R[(size_t)(j - 1) * nxg + (i - 1)]; }; };
+    const auto gHTN = rec(gin->HTN), gHTE = rec(gin->HTE);
+    scatter(ULAT, rec(gin->ULAT), 1); scatter(ULON, rec(gin->ULON), 1);
+    scatter(HTN, gHTN, 2);
+    scatter(DXU, [&](int i, int j) { return 0.5 * (gHTN(i, j) + gHTN(i == nxg ? 1 : i + 1, j)); }, 1);
+    scatter(DXT, [&](int i, int j) { return 0.5 * (gHTN(i, j) + gHTN(i, j == 1 ? nyg : j - 1)); }, 0);
+    scatter(HTE, gHTE, 3);
+    scatter(DYT, [&](int i, int j) { return 0.5 * (gHTE(i, j) + gHTE(i == 1 ? nxg : i - 1, j)); }, 0);
+    scatter(DYU, [&](int i, int j) {
+      if (c.ns_boundary == 2 && j == nyg) return gHTE(i, j);       // tripole-grid correction :1495-1500
+      return 0.5 * (gHTE(i, j) + gHTE(i, j == nyg ? 1 : j + 1)); }, 1);
+    scatter(HUS, rec(gin->HUS), 3); scatter(HUW, rec(gin->HUW), 2);
+    for (auto *F : {&HTN, &HTE, &HUS, &HUW, &DXU, &DYU, &DXT, &DYT}) for (double &v : *F) if (v <= 0.0) v = 1.0;
+    if (gin->KMT) { const int *K = gin->KMT; scatter(KMT, [K, nxg](int i, int j) { return K[(size_t)(j - 1) * nxg + (i - 1)]; }, 0); }
+    else {   // topography_internal on the supplied ULAT / ULON
+      const auto gLAT = rec(gin->ULAT), gLON = rec(gin->ULON);
+      scatter(KMT, [&](int i, int j) { return kmt_ll(gLAT(i, j) * radian, gLON(i, j) * radian, i, j); }, 0);
+    }
+  }
   for (int b = 0; b < NB; ++b) {
     const BlockInfo &B = h.all_blocks[b];
-    for (int j = 0; j < nyb; ++j) {
+    for (int j = 0; j < nyb && !gin; ++j) {
       const int jg = B.j_glob[j];
       int jm1 = jg - 1; if (jm1 < 1) jm1 = nyg;
       for (int i = 0; i < nxb; ++i) {
@@ -330,7 +373,7 @@ int host_build(HostModel &h) {
     if (B.j_glob[B.jb - 1] == 1)
       for (int i = B.ib - 1; i < B.ie; ++i) TLAT[idx(b, i, B.jb - 1)] = 2.0 * TLAT[idx(b, i, B.jb)] - TLAT[idx(b, i, B.jb + 1)];
   }
-  host_halo_r8(h, TLAT.data(), 1, 0.0);
+  host_halo_r8_loc(h, TLAT.data(), 1, 0.0, 0, 0);                  // centre, scalar (grid.F90:3073)
 
   // ---------------- masks and depths ----------------
   for (int b = 0; b < NB; ++b)
@@ -339,7 +382,7 @@ int host_build(HostModel &h) {
       m = std::min(m, KMT[idx(b, i + 1, j)]); m = std::min(m, KMT[idx(b, i, j + 1)]); m = std::min(m, KMT[idx(b, i + 1, j + 1)]);
       KMU[idx(b, i, j)] = m;
     }
-  host_halo_i4(h, KMU.data(), 1, 0);
+  host_halo_i4_loc(h, KMU.data(), 1, 0, 1, 0);                     // NE corner, scalar (grid.F90:987)
   auto &HT = newf("HT"), &HU = newf("HU"), &HUR = newf("HUR"), &RCALCT = newf("RCALCT"), &RCALCU = newf("RCALCU");
   auto &FCOR = newf("FCOR"), &FCORT = newf("FCORT");
   auto &KMTN = newi("KMTN"), &KMTS = newi("KMTS"), &KMTE = newi("KMTE"), &KMTW = newi("KMTW"), &KMTEE = newi("KMTEE"), &KMTNN = newi("KMTNN");
@@ -378,8 +421,8 @@ int host_build(HostModel &h) {
   if (c.lvariable_hmix && (c.hmix_momentum == 2 || c.hmix_tracer == 2)) {
     double ref = 2.0 * pi * RADIUS / nxg; ref = ref * ref;
     for (size_t p = 0; p < A2; ++p) { AMF[p] = std::sqrt(UAREA[p] / ref); AHF[p] = std::sqrt(TAREA[p] / ref); }
-    host_halo_r8(h, AMF.data(), 1, 0.0);
-    host_halo_r8(h, AHF.data(), 1, 0.0);
+    host_halo_r8_loc(h, AMF.data(), 1, 0.0, 1, 0);                 // NE corner (hmix_del2.F90:262)
+    host_halo_r8_loc(h, AHF.data(), 1, 0.0, 0, 0);                 // centre (:583)
   }
   auto &DUC = newf("DUC"), &DUN = newf("DUN"), &DUS = newf("DUS"), &DUE = newf("DUE"), &DUW = newf("DUW");
   auto &DMC = newf("DMC"), &DMN = newf("DMN"), &DMS = newf("DMS"), &DME = newf("DME"), &DMW = newf("DMW"), &DUM = newf("DUM");
@@ -429,8 +472,8 @@ int host_build(HostModel &h) {
     for (size_t p = 0; p < A2; ++p) { A4[p] = 1.0; H4[p] = 1.0; }
     if (c.lvariable_hmix) {
       for (size_t p = 0; p < A2; ++p) { A4[p] = std::pow(UAREA[p] / h.uarea_equator, 1.5); H4[p] = std::pow(TAREA[p] / h.uarea_equator, 1.5); }
-      host_halo_r8(h, A4.data(), 1, 0.0);
-      host_halo_r8(h, H4.data(), 1, 0.0);
+      host_halo_r8_loc(h, A4.data(), 1, 0.0, 1, 0);                // NE corner (hmix_del4.F90:237)
+      host_halo_r8_loc(h, H4.data(), 1, 0.0, 0, 0);                // centre (:536)
     }
     auto &eUC = newf("d4DUC"), &eUN = newf("d4DUN"), &eUS = newf("d4DUS"), &eUE = newf("d4DUE"), &eUW = newf("d4DUW");
     auto &eMC = newf("d4DMC"), &eMN = newf("d4DMN"), &eMS = newf("d4DMS"), &eME = newf("d4DME"), &eMW = newf("d4DMW"), &eUM = newf("d4DUM");
@@ -634,7 +677,8 @@ int host_build(HostModel &h) {
         }
     }
   }
-  build_halo_plan(h);
+  // the test perturbation is a function of the global indices, which ghost rows beyond a tripole boundary do not carry
+  if (c.ns_boundary == 2) host_halo_r8_loc(h, T0.data(), h.km, 0.0, 0, 0);
   // ---------------- tripole: redundant top-row points of N-face / NE-corner fields ----------------
   if (c.ns_boundary == 2) {
     auto &DUP = newf("TRIPOLE_DUP");

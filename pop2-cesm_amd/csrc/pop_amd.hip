@@ -74,7 +74,7 @@ struct pop_ctx {
   double *host_rr = nullptr;                              // pinned ring of (r,r) check results (k_rr_total)
   hipEvent_t chk_ev[4] = {};                              // one event per check interval in flight
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
-  bool no_graph = false, fused_ok = false, replicated = false;
+  bool no_graph = false, fused_ok = false, replicated = false, grid_from_input = false;
   bool fpcg_one_cell = false;   // POP_FPCG_B2=0: one cell per thread in step B of the fused pcg even on large grids
   bool force_presum = false;
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
@@ -233,10 +233,11 @@ int halo_update(pop_ctx *c, double *F, int nz, double fill = 0.0, int loc = 0, i
 // Several fields, one halo update: ONE message per neighbour rank carrying all of them (pack, exchange, unpack = three
 // stream operations whatever the number of fields) and one launch for the ghost copies / fills inside the rank.
 // Field by field the result is the one halo_update gives (same cells, same values).  fill value 0.
-struct HaloItem { double *F; int nz; };
+// loc / kind: POP_HaloUpdate's fieldLoc / fieldKind (0 centre, 1 NE corner, 2 N face, 3 E face; 0 scalar, 1 vector); they matter on a tripole boundary only
+struct HaloItem { double *F; int nz; int loc = 0, kind = 0; };
 int halo_update_many(pop_ctx *c, const std::vector<HaloItem> &items) {
   if (items.size() == 1 || items.size() > 8 || c->h.c.ns_boundary == 2 || getenv("POP_HALO_SEPARATE")) {
-    for (const HaloItem &it : items) if (halo_update(c, it.F, it.nz)) return 1;
+    for (const HaloItem &it : items) if (halo_update(c, it.F, it.nz, 0.0, it.loc, it.kind)) return 1;
     return 0;
   }
   HaloFields H{};
@@ -1136,11 +1137,31 @@ int resolve(pop_ctx *c, const std::string &name, int tl, int n, double **ptr, lo
 // =============================================================================================
 extern "C" {
 
-int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx **out) {
+int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx **out) { return pop_create_with_grid(cfg, nullptr, rank, nranks, flags, out); }
+
+// the reference's direct-access binary grid files (grid.F90:1362-1380, :2066-2085): whole records, native byte order
+int pop_read_grid_files(const char *horiz_grid_file, const char *topography_file, int nx_global, int ny_global, double *seven_records, int *kmt) {
+  const size_t n = (size_t)nx_global * ny_global;
+  auto slurp = [&](const char *path, void *dst, size_t bytes) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return 1;
+    const size_t got = fread(dst, 1, bytes, f);
+    fclose(f);
+    return got == bytes ? 0 : 1;
+  };
+  if (horiz_grid_file && seven_records && slurp(horiz_grid_file, seven_records, 7 * n * sizeof(double))) return 1;
+  if (topography_file && kmt && slurp(topography_file, kmt, n * sizeof(int))) return 2;
+  return 0;
+}
+
+int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int rank, int nranks, int flags, pop_ctx **out) {
   if (!cfg || !out || nranks < 1 || rank < 0 || rank >= nranks) return 1;
   pop_ctx *c = new pop_ctx();
   *out = c;
   c->h.c = *cfg; c->h.rank = rank; c->h.nranks = nranks;
+  c->grid_from_input = grid != nullptr;
+  if (grid && !(grid->ULAT && grid->ULON && grid->HTN && grid->HTE && grid->HUS && grid->HUW)) { c->err = "pop_create_with_grid: ULAT, ULON, HTN, HTE, HUS, HUW are required"; return 1; }
+  c->h.gin = grid;
   {   // every option this library does not implement is refused here, before anything is built (the reference aborts
       // in the init routine of the option's own module, e.g. vertical_mix.F90:280-296, POP_SolversMod.F90:442-472)
     auto bad = [&](const std::string &m) { c->err = "pop_create: " + m; return 1; };
@@ -1162,8 +1183,11 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     if (cfg->vmix_choice == 3 && (cfg->lshort_wave || cfg->lcheckekmo)) return bad("KPP: lshort_wave / lcheckekmo are not built");
     if (cfg->vmix_choice == 3 && cfg->num_v_smooth_Ri < 1) return bad("KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)");
     if (!(cfg->convergence_criterion >= 0.0)) return bad("convergence_criterion must be >= 0");
+    if (cfg->ns_boundary == 2 && cfg->tadvect == 3) return bad("lw_lim advection on a tripole decomposition is not built");
   }
-  if (host_build(c->h)) { c->err = c->h.err; return 1; }
+  const int hb = host_build(c->h);
+  c->h.gin = nullptr;
+  if (hb) { c->err = c->h.err; return 1; }
   c->host_only = (flags & POP_CREATE_HOST_ONLY) != 0;
   if (c->host_only) return 0;
   if (cfg->nt != 2) { c->err = "device kernels are built for nt = 2 (T,S) in this round"; return 1; }
@@ -1337,6 +1361,10 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
     for (size_t p = 0; p < a2; ++p) sm[p] = (int)p;
     for (size_t i = 0; i < h.halo.copy_dst.size(); ++i) sm[h.halo.copy_dst[i]] = h.halo.copy_src[i];
     for (int d : h.halo.fill_dst) sm[d] = -1;
+    if (cfg->ns_boundary == 2) {   // centre scalars beyond the fold are plain mirrored copies of physical cells (TripolePlan loc 0: no symmetrised row)
+      const TripolePlan &T = h.halo.tripole[0];
+      for (size_t e = 0; e < T.dst.size(); ++e) sm[T.dst[e]] = T.a[e];
+    }
     if (dev_upload(c, &c->srcmap, sm.data(), sm.size())) return 1;
     HIPCHK(c, hipHostMalloc((void **)&c->host_sc, sizeof(SolverScalars)));
     HIPCHK(c, hipHostMalloc((void **)&c->host_rr, 8 * sizeof(double)));
@@ -1698,7 +1726,8 @@ int pop_read_restart(pop_ctx *c, const char *path, int flags) {
     double *p; long long n;
     if (resolve(c, f.dev, f.tl, f.n, &p, &n) || (size_t)n != cnt) { c->err = "restart: unknown field " + f.dev; rc = 1; break; }
     if (hipMemcpy(p, buf.data(), cnt * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { c->err = "restart: device copy failed"; rc = 1; break; }
-    if (halo_update(c, p, nz)) { rc = 1; break; }                    // read_restart :960-1040 (fillValue 0)
+    const int uv = (f.mask == 1 || f.mask == 3) ? 1 : 0;             // U-grid fields: NE corner, vector (restart.F90:969-1014)
+    if (halo_update(c, p, nz, 0.0, uv, uv)) { rc = 1; break; }       // read_restart :960-1040 (fillValue 0)
   }
   close(fd);
   if (rc) return rc;
@@ -2037,11 +2066,16 @@ int pop_solver_get_diagnostics(const pop_ctx *c, int *it, double *rms) {
   return 0;
 }
 
-int pop_barotropic_driver(pop_ctx *c) {
+static int barotropic_driver(pop_ctx *c, bool update_zx_zy);
+int pop_barotropic_driver(pop_ctx *c) { return barotropic_driver(c, true); }
+// barotropic.F90:267 on its own: the caller has already updated the halos of ZX, ZY (step_mod.F90:405-423).  Beyond a tripole
+// fold a second update would not be a no-op (the symmetrised top row takes each sign from the partner point).
+int pop_barotropic_driver_updated(pop_ctx *c) { return barotropic_driver(c, false); }
+static int barotropic_driver(pop_ctx *c, bool update_zx_zy) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "BAROTROPIC");
   const StepParams sp = step_params(c);
-  if (halo_update_many(c, {{c->ZX, 1}, {c->ZY, 1}})) return 1;
+  if (update_zx_zy && halo_update_many(c, {{c->ZX, 1, 1, 1}, {c->ZY, 1, 1, 1}})) return 1;   // NE corner, vector (step_mod.F90:405-423)
   BtropArgs a{};
   a.ZX = c->ZX; a.ZY = c->ZY; a.GXC = c->GX[c->curt]; a.GXO = c->GX[c->oldt]; a.GYC = c->GY[c->curt]; a.GYO = c->GY[c->oldt];
   a.UBO = c->UB[c->oldt]; a.VBO = c->VB[c->oldt]; a.PCUR = c->PS[c->curt]; a.FW = c->FW; a.PGUESS = c->PGUESS;
@@ -2059,7 +2093,7 @@ int pop_barotropic_driver(pop_ctx *c) {
   if (reduce_finish<1>(c, FIN_XCHECK)) return 1;
   hipLaunchKernelGGL(k_btrop_fin1, G, B, 0, c->stream, c->g, a);
   hipLaunchKernelGGL(k_btrop_fin2, G, B, 0, c->stream, c->g, sp, a);
-  if (halo_update_many(c, {{c->PS[c->newt], 1}, {c->GX[c->newt], 1}, {c->GY[c->newt], 1}})) return 1;
+  if (halo_update_many(c, {{c->PS[c->newt], 1}, {c->GX[c->newt], 1, 1, 1}, {c->GY[c->newt], 1, 1, 1}})) return 1;   // barotropic.F90:699-729
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -2068,8 +2102,10 @@ int pop_baroclinic_correct_adjust(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "CORRECT_ADJUST");
   // the barotropic velocity is added to U, V(new) (step_mod.F90:572-600) on the side stream while the tracer corrector runs:
-  // same sum at every cell; the halo update of U, V in the step tail then carries it to the ghost cells
-  if (c->side && !getenv("POP_BTROP_INLINE")) {
+  // same sum at every cell; the halo update of U, V in the step tail then carries it to the ghost cells.  Not beyond a
+  // tripole fold: there the update symmetrises |U| of the degenerate top row, which does not commute with the sum, so the
+  // reference's order (halo updates first, step_mod.F90:467-513, then the sum over whole blocks) is kept.
+  if (c->side && !getenv("POP_BTROP_INLINE") && c->h.c.ns_boundary != 2) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     if (phase_add_btrop(c, c->side)) return 1;
@@ -2148,7 +2184,7 @@ int pop_step_tail(pop_ctx *c) {
   const int km = c->g.km;
   if (join_side(c, true)) return 1;
   {   // the seven updates of step_mod.F90:467-560 as one message per neighbour
-    std::vector<HaloItem> items = {{c->UB[c->newt], 1}, {c->VB[c->newt], 1}, {c->U[c->newt], km}, {c->V[c->newt], km}, {c->RHO[c->newt], km}};
+    std::vector<HaloItem> items = {{c->UB[c->newt], 1, 1, 1}, {c->VB[c->newt], 1, 1, 1}, {c->U[c->newt], km, 1, 1}, {c->V[c->newt], km, 1, 1}, {c->RHO[c->newt], km}};
     for (int n = 0; n < c->h.nt; ++n) items.push_back({c->TR[n][c->newt], km});
     if (halo_update_many(c, items)) return 1;
   }
@@ -2181,7 +2217,7 @@ int pop_step_tail(pop_ctx *c) {
 
 int pop_step(pop_ctx *c) {
   if (need_device(c)) return 1;
-  if (c->h.c.ns_boundary == 2) { c->err = "time stepping on a tripole decomposition needs a tripole grid (not built): only halo updates are"; return 1; }
+  if (c->h.c.ns_boundary == 2 && !c->grid_from_input) { c->err = "time stepping on a tripole decomposition needs the caller's grid (pop_create_with_grid): the internal lat-lon grid has no values beyond the fold"; return 1; }
   ScopedPhase ph(c, "STEP");
   int e;
   if ((e = pop_time_manager(c)) || (e = pop_dhdt(c)) || (e = pop_baroclinic_driver(c)) || (e = kpp_look_ahead(c)) ||

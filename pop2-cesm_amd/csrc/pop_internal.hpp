@@ -63,6 +63,7 @@ struct EvpHost {
 //      POP_SolversInit, init_barotropic, init_ts) on the local blocks of this rank
 struct HostModel {
   pop_config c{};
+  const pop_grid_input *gin = nullptr;     // caller's grid (pop_create_with_grid); read during host_build only
   int rank = 0, nranks = 1;
   int nxb = 0, nyb = 0, km = 0, nt = 2;
   int nbx = 0, nby = 0, nblocks_tot = 0, nblocks = 0;   // nblocks = local

@@ -33,6 +33,13 @@
       real (c_double) :: reserved_d(8)
    end type pop_config
 
+   ! mirrors `struct pop_grid_input`: the records of horiz_grid_file / topography_file (grid.F90:1314-1542, 2025-2107)
+   ! as global (nx_global,ny_global) arrays; c_loc of the host arrays, c_null_ptr for an absent ANGLE / KMT
+   type, bind(C) :: pop_grid_input
+      type (c_ptr) :: ULAT, ULON, HTN, HTE, HUS, HUW, ANGLE
+      type (c_ptr) :: KMT
+   end type pop_grid_input
+
    type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task
 
    interface
@@ -41,6 +48,21 @@
          type (pop_config), intent(in) :: cfg
          integer (c_int), value :: rank, nranks, flags
          type (c_ptr), intent(out) :: ctx
+      end function
+      integer (c_int) function pop_create_with_grid(cfg, grid, rank, nranks, flags, ctx) bind(C, name='pop_create_with_grid')
+         import :: c_int, c_ptr, pop_config, pop_grid_input
+         type (pop_config), intent(in) :: cfg
+         type (pop_grid_input), intent(in) :: grid
+         integer (c_int), value :: rank, nranks, flags
+         type (c_ptr), intent(out) :: ctx
+      end function
+      integer (c_int) function pop_read_grid_files(horiz_grid_file, topography_file, nx_global, ny_global, seven_records, kmt) &
+                                bind(C, name='pop_read_grid_files')
+         import :: c_int, c_char, c_double
+         character (kind=c_char), dimension(*), intent(in) :: horiz_grid_file, topography_file
+         integer (c_int), value :: nx_global, ny_global
+         real (c_double), dimension(*), intent(out) :: seven_records
+         integer (c_int), dimension(*), intent(out) :: kmt
       end function
       integer (c_int) function pop_destroy(ctx) bind(C, name='pop_destroy')
          import :: c_int, c_ptr
@@ -107,6 +129,10 @@
          type (c_ptr), value :: ctx
       end function
       integer (c_int) function pop_barotropic_driver(ctx) bind(C, name='pop_barotropic_driver')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+      end function
+      integer (c_int) function pop_barotropic_driver_updated(ctx) bind(C, name='pop_barotropic_driver_updated')
          import :: c_int, c_ptr
          type (c_ptr), value :: ctx
       end function

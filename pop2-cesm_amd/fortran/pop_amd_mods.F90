@@ -482,7 +482,8 @@
       integer (POP_i4), intent(out) :: errorCode
       errorCode = pop_set_field(pop_ctx, cstr('ZX'), 1, 0, ZX, int(size(ZX), c_long_long))
       if (errorCode == POP_Success) errorCode = pop_set_field(pop_ctx, cstr('ZY'), 1, 0, ZY, int(size(ZY), c_long_long))
-      if (errorCode == POP_Success) errorCode = pop_barotropic_driver(pop_ctx)
+      ! ZX, ZY arrive with their halos updated, as in the reference (step_mod.F90:405-423 before :431)
+      if (errorCode == POP_Success) errorCode = pop_barotropic_driver_updated(pop_ctx)
    end subroutine
    subroutine barotropic_driver_resident(errorCode)
       integer (POP_i4), intent(out) :: errorCode

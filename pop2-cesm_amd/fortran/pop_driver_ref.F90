@@ -11,7 +11,7 @@
 ! errorCode, mMask) and -- once -- a stand-alone POP_SolversRun(sfcPressure, rhsClinic, errorCode) that must reproduce
 ! the pressure the step just computed.  Prints the same checksums as pop_driver.F90 (named-field forms), so the
 ! test suite can compare both with the Python-driven run.
-!   pop_driver_ref <nx> <ny> <km> <bx> <by> <vmix> <nsteps>
+!   pop_driver_ref <nx> <ny> <km> <bx> <by> <vmix> <nsteps> [<ns_boundary> <horiz_grid_file> <topography_file>]
 !|||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||||
  program pop_driver_ref
 
@@ -33,13 +33,33 @@
    integer (POP_i4) :: errorCode, nsteps, n, iters, iters2
    real (POP_r8), allocatable, dimension(:,:,:) :: DH, DHU, ZX, ZY, PSURF, RHS, GUESS, MASK, T1
    real (POP_r8) :: rms, tsum, psum, dmax
-   character (char_len) :: arg, msg
+   character (char_len) :: arg, msg, horiz_grid_file, topography_file
+   type (pop_grid_input) :: grid
+   real (POP_r8), allocatable, target, dimension(:,:,:) :: GRID_G
+   integer (POP_i4), allocatable, target, dimension(:,:) :: KMT_G
 
    cfg = default_config()
    call geti(1, cfg%nx_global); call geti(2, cfg%ny_global); call geti(3, cfg%km)
    call geti(4, cfg%block_size_x); call geti(5, cfg%block_size_y); call geti(6, cfg%vmix_choice)
    call geti(7, nsteps)
-   errorCode = pop_create(cfg, 0, 1, 0, pop_ctx)
+   if (command_argument_count() >= 10) then
+      ! horiz_grid_opt = 'file', topography_opt = 'file' (grid.F90:441-445, 467-470): the reference's direct-access
+      ! binary files, read whole and handed over as global arrays; <ns_boundary> 2 = tripole
+      call geti(8, cfg%ns_boundary)
+      call get_command_argument(9, horiz_grid_file)
+      call get_command_argument(10, topography_file)
+      allocate(GRID_G(cfg%nx_global, cfg%ny_global, 7), KMT_G(cfg%nx_global, cfg%ny_global))
+      errorCode = pop_read_grid_files(cstr(trim(horiz_grid_file)), cstr(trim(topography_file)), cfg%nx_global, cfg%ny_global, &
+                                      GRID_G, KMT_G)
+      if (errorCode /= POP_Success) call die('pop_read_grid_files')
+      grid%ULAT = c_loc(GRID_G(1,1,1)); grid%ULON = c_loc(GRID_G(1,1,2)); grid%HTN = c_loc(GRID_G(1,1,3))
+      grid%HTE = c_loc(GRID_G(1,1,4)); grid%HUS = c_loc(GRID_G(1,1,5)); grid%HUW = c_loc(GRID_G(1,1,6))
+      grid%ANGLE = c_loc(GRID_G(1,1,7)); grid%KMT = c_loc(KMT_G)
+      errorCode = pop_create_with_grid(cfg, grid, 0, 1, 0, pop_ctx)
+      deallocate(GRID_G, KMT_G)
+   else
+      errorCode = pop_create(cfg, 0, 1, 0, pop_ctx)
+   endif
    if (errorCode /= POP_Success) call die('pop_create')
    call init_blocks_from_ctx
    POP_haloClinic = POP_HaloCreate(errorCode)

@@ -20,6 +20,9 @@ def load():
     L = C.CDLL(_SO)
     L.orc_create.restype = C.c_void_p
     L.orc_create.argtypes = [C.POINTER(PopConfig)]
+    L.orc_create_with_grid.restype = C.c_void_p
+    L.orc_create_with_grid.argtypes = [C.POINTER(PopConfig), C.c_void_p]
+    L.orc_halo.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int]
     L.orc_destroy.argtypes = [C.c_void_p]
     L.orc_field.restype = C.POINTER(C.c_double)
     L.orc_field.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
@@ -61,14 +64,30 @@ def load():
     return L
 
 
+class OrcGridInput(C.Structure):
+    """oracle/pop_oracle.h orc_grid_input"""
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")] + [("KMT", C.POINTER(C.c_int))]
+
+
 class Oracle:
     """Thin object wrapper; arrays come back as numpy views in Fortran index order
     reversed, i.e. shape (nblocks, [km,] ny_block, nx_block)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, grid=None):
         self.L = load()
         self.cfg = cfg
-        self.h = self.L.orc_create(C.byref(cfg))
+        if grid is None:
+            self.h = self.L.orc_create(C.byref(cfg))
+        else:   # orc_grid_input has pop_grid_input's layout (declared separately on purpose, like the config)
+            gin, keep = OrcGridInput(), []
+            for n, ty, ct in [(n, np.float64, C.c_double) for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")] + [("KMT", np.int32, C.c_int)]:
+                if grid.get(n) is not None:
+                    a = np.ascontiguousarray(grid[n], dtype=ty)
+                    assert a.shape == (cfg.ny_global, cfg.nx_global), n
+                    keep.append(a)
+                    setattr(gin, n, a.ctypes.data_as(C.POINTER(ct)))
+            self.h = self.L.orc_create_with_grid(C.byref(cfg), C.cast(C.byref(gin), C.c_void_p))
+            del keep
         if not self.h:
             raise RuntimeError("orc_create failed")
         d = lambda n: self.L.orc_dim(self.h, n.encode())

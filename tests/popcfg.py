@@ -101,3 +101,40 @@ def named_config(name, **kw):
         raise KeyError(name)
     _apply(c, kw)
     return c
+
+
+def synthetic_grid(c, lat_span=160.0, wobble=0.04, stepped=True, kmt=True):
+    """Global arrays in the layout of the reference's horiz_grid_file / topography_file records (grid.F90:1314-1542,
+    :2025-2107), shape (ny_global, nx_global): a lat-lon grid over +-lat_span/2 degrees whose spacings also vary with
+    longitude (so that the mirrored column of a tripole ghost row is a different number), ocean up to the northern
+    edge (the fold of a tripole decomposition runs through water) and, optionally, stepped bathymetry.  TEST DATA, not
+    a physical tripole grid: the code under test only ever sees arrays."""
+    import numpy as np
+    nx, ny, km = c.nx_global, c.ny_global, c.km
+    radius, radian = 6370.0e5, 180.0 / np.pi
+    i = np.arange(1, nx + 1, dtype=np.float64)[None, :]
+    j = np.arange(1, ny + 1, dtype=np.float64)[:, None]
+    dlat, dlon = lat_span / ny, 360.0 / nx
+    ulat = (-lat_span / 2 + j * dlat) / radian + 0.0 * i
+    lon = i * dlon + 0.0 * j
+    ulon = np.where(lon > 180.0, lon - 360.0, lon) / radian
+    east = 1.0 + wobble * np.cos(2.0 * np.pi * i / nx)            # E faces / NE corners: symmetric under i -> nx - i
+    north = 1.0 + wobble * np.cos(2.0 * np.pi * (i - 0.5) / nx)   # N faces / centres:    symmetric under i -> nx + 1 - i
+    cell, cellx = dlat * radius / radian, dlon * radius / radian
+    g = {"ULAT": ulat, "ULON": ulon,
+         "HTN": cellx * np.cos(ulat) * north, "HTE": cell * east + 0.0 * j,
+         "HUS": cellx * np.cos((-lat_span / 2 + (j - 0.5) * dlat) / radian) * east, "HUW": cell * north + 0.0 * j,
+         "ANGLE": np.zeros((ny, nx))}
+    if kmt:
+        latd, lond = ulat * radian, np.where(ulon < 0, ulon * radian + 360.0, ulon * radian)
+        k = np.full((ny, nx), km, dtype=np.int32)
+        k[(latd > -35.0) & (lond > 210.0) & (lond < 250.0)] = 0
+        k[(latd > 25.0) & (latd < 60.0) & (lond > 210.0) & (lond < 330.0)] = 0
+        k[(latd > -60.0) & (latd < 55.0) & (lond > 110.0) & (lond < 150.0)] = 0
+        k[latd < -70.0] = 0
+        if stepped:
+            ii, jj = np.arange(1, nx + 1)[None, :], np.arange(1, ny + 1)[:, None]
+            cut = ((ii // 3) * 5 + (jj // 2) * 3) % (km // 2 + 1)
+            k = np.where(k > 0, np.maximum(3, km - cut), 0).astype(np.int32)
+        g["KMT"] = k
+    return {n: np.ascontiguousarray(a) for n, a in g.items()}

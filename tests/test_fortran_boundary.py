@@ -78,3 +78,28 @@ def test_reference_argument_lists_match_python(pkg):
     rerun = re.search(r"solver rerun iters\s+(\d+)\s+of\s+(\d+)", out)
     assert rerun and rerun.group(1) == rerun.group(2)
     m.close()
+
+
+@pytest.mark.gpu
+def test_reference_argument_lists_on_a_tripole_grid_from_files(pkg, tmp_path):
+    """horiz_grid_opt = 'file' / topography_opt = 'file' from Fortran: the reference's direct-access binary files read
+    with pop_read_grid_files, handed to pop_create_with_grid, and the reference-argument-list step sequence run on a
+    tripole decomposition (POP_HaloUpdate(ZX, ..., POP_gridHorzLocNECorner, POP_fieldKindVector) does the fold on the host
+    array; barotropic_driver(ZX, ZY) takes them as updated).  Same numbers as the Python-driven run on the same arrays."""
+    _build()
+    from popcfg import synthetic_grid
+    cfg = named_config("tiny", ns_boundary=2)
+    g = synthetic_grid(cfg)
+    hf, tf = str(tmp_path / "horiz_grid.bin"), str(tmp_path / "topography.bin")
+    np.stack([g[n] for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")]).astype(np.float64).tofile(hf)
+    g["KMT"].astype(np.int32).tofile(tf)
+    nsteps = 4
+    out = subprocess.check_output([os.path.join(FDIR, "pop_driver_ref"), "48", "40", "16", "12", "10", "1", str(nsteps), "2", hf, tf], text=True)
+    rows = re.findall(r"step\s+(\d+)\s+iters\s+(\d+)\s+sumP\s+(\S+)", out)
+    assert len(rows) == nsteps, out
+    m = pkg.PopModel(cfg, grid=g)
+    for n, it, sp in rows:
+        m.step()
+        assert int(it) == m.solver_diagnostics()[0]
+        assert float(sp) == pytest.approx(m.global_sum("PSURF", 1, 0, mask="mMask"), rel=1e-13, abs=1e-9)
+    m.close()

@@ -13,7 +13,7 @@ Tolerances (fp64):
 import numpy as np
 import pytest
 
-from popcfg import named_config
+from popcfg import named_config, synthetic_grid
 from orclib import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -178,6 +178,49 @@ def test_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
         run_phases(gpu, orc, s, tol)
         tol = TOL_SOLVE        # later steps inherit the solver's summation-order difference
     gpu.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw,nsteps,env", [
+    # tripole northern boundary (ns_boundary = 2) on a grid supplied by the caller: every halo update of the step carries
+    # the reference's fieldLoc / fieldKind (U-grid vectors change sign beyond the fold and have their top row symmetrised)
+    ({"ns_boundary": 2}, 5, {}),                                                        # 16 blocks, fused pcg (fold inside srcmap)
+    ({"ns_boundary": 2}, 4, {"POP_SOLVER_UNFUSED": "1"}),                               # per-operation solver: tripole halo passes
+    ({"ns_boundary": 2, "block_size_x": 48, "block_size_y": 40, "solver_choice": 2}, 4, {}),   # one block, ChronGear
+    ({"ns_boundary": 2, "vmix_choice": 3, "km": 24, "ldbl_diff": 1}, 5, {}),            # KPP
+    ({"ns_boundary": 2, "hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1, "am": -1.0e22, "ah": -1.0e21, "tadvect": 2}, 4, {}),
+    ({"ns_boundary": 2, "solver_choice": 3}, 4, {}),                                    # P-CSI (Lanczos through the fold)
+    ({"ns_boundary": 2, "precond_choice": 1, "solver_choice": 2}, 4, {}),               # EVP preconditioner
+    ({"ns_boundary": 2, "tmix_opt": 3, "vmix_choice": 2}, 5, {}),                       # Robert filter
+    ({"ns_boundary": 2, "km": 60, "vmix_choice": 3, "block_size_x": 24, "block_size_y": 20}, 3, {}),
+    # the same grid arrays under ordinary boundaries (horiz_grid_opt / topography_opt = 'file' without a fold)
+    ({"ns_boundary": 0}, 3, {}),
+    ({"ns_boundary": 0, "ew_boundary": 0, "vmix_choice": 3, "km": 24}, 3, {}),
+    ({"ns_boundary": 1, "tadvect": 3}, 3, {}),
+])
+def test_grid_input_step_phases_match_oracle(pkg, orclib_built, monkeypatch, kw, nsteps, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = named_config("tiny", **kw)
+    grid = synthetic_grid(cfg)
+    gpu, orc = pkg.PopModel(cfg, grid=grid), Oracle(cfg, grid=grid)
+    for n in (0, 1):
+        assert np.array_equal(gpu.get("TRACER", 1, n), orc.f3("TRACER", 1, n))
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
+    tol = TOL_LOCAL
+    for s in range(1, nsteps + 1):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+    gpu.close(); orc.close()
+
+
+def test_tripole_without_grid_input_refuses_to_step(pkg):
+    m = pkg.PopModel(named_config("tiny", ns_boundary=2))
+    with pytest.raises(pkg.PopError, match="pop_create_with_grid"):
+        m.step()
+    m.close()
+    with pytest.raises(pkg.PopError, match="lw_lim"):
+        pkg.PopModel(named_config("tiny", ns_boundary=2, tadvect=3))
 
 
 @pytest.mark.parametrize("kw,nsteps", [

@@ -4,7 +4,7 @@ KMT/KMU and index maps bit-exact; all init-time fields are pure functions of the
 import numpy as np
 import pytest
 
-from popcfg import named_config
+from popcfg import named_config, synthetic_grid
 from orclib import Oracle
 
 FIELDS = ["ULAT", "ULON", "TLAT", "HTN", "HTE", "HUS", "HUW", "DXU", "DYU", "DXT", "DYT", "DXUR", "DYUR",
@@ -24,8 +24,79 @@ IFIELDS = ["KMT", "KMU", "KMTN", "KMTS", "KMTE", "KMTW", "KMTEE", "KMTNN"]
                                      ("tiny", {"solver_choice": 3}), ("gx3v7", {"solver_choice": 3}), ("test", {"solver_choice": 3})])
 def test_host_fields_bit_exact(pkg, orclib_built, name, kw):
     cfg = named_config(name, **kw)
-    m = pkg.PopModel(cfg, host_only=True)
-    o = Oracle(cfg)
+    _host_fields_bit_exact(pkg, cfg, None)
+
+
+@pytest.mark.parametrize("kw", [{"ns_boundary": 2}, {"ns_boundary": 0}, {"ns_boundary": 1}, {"ns_boundary": 0, "ew_boundary": 0},
+                                {"ns_boundary": 2, "hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1},
+                                {"ns_boundary": 2, "lvariable_hmix": 1, "tadvect": 2, "solver_choice": 3},
+                                {"ns_boundary": 2, "precond_choice": 1, "block_size_x": 48, "block_size_y": 40}])
+def test_host_fields_from_grid_input_bit_exact(pkg, orclib_built, kw):
+    """horiz_grid_opt = 'file' / topography_opt = 'file' (pop_create_with_grid): the caller's global arrays scattered with
+    the reference's field locations (tripole ghost rows mirrored), every derived field equal to the oracle's bit for bit"""
+    cfg = named_config("tiny", **kw)
+    _host_fields_bit_exact(pkg, cfg, synthetic_grid(cfg))
+
+
+def test_grid_input_scatter_rule(pkg):
+    """scatter_global (mpi/gather_scatter.F90:929-945, 1027-1038) stated constructively: a cell with positive global
+    indices holds the global value; a ghost row n beyond the fold holds global row ny + yoffset - n at column
+    nx + xoffset - i (wrapped), offsets (1,1) centre, (0,0) NE corner, (0,1) E face, (1,0) N face"""
+    cfg = named_config("tiny", ns_boundary=2)
+    g = synthetic_grid(cfg)
+    m = pkg.PopModel(cfg, host_only=True, grid=g)
+    nx, ny = cfg.nx_global, cfg.ny_global
+    big = lambda a: np.where(a <= 0.0, 1.0, a)
+    # the mirrored spacings: DXT from HTN averaged in j (centre), DYU from HTE averaged in j with the tripole row (NE corner)
+    dxt = 0.5 * (g["HTN"] + np.roll(g["HTN"], 1, axis=0))
+    dyu = 0.5 * (g["HTE"] + np.roll(g["HTE"], -1, axis=0)); dyu[-1] = g["HTE"][-1]
+    for name, G, xo, yo in (("ULAT", g["ULAT"], 0, 0), ("HTN", g["HTN"], 1, 0), ("HTE", g["HTE"], 0, 1), ("HUS", g["HUS"], 0, 1),
+                            ("HUW", g["HUW"], 1, 0), ("DXT", dxt, 1, 1), ("DYU", dyu, 0, 0), ("KMT", g["KMT"], 1, 1)):
+        A = m.geti(name) if name == "KMT" else m.get(name)
+        seen_fold = 0
+        for bid in range(1, m.nblocks_tot + 1):
+            blk = m.get_block(bid)
+            for j, jg in enumerate(blk["j_glob"]):
+                for i, ig in enumerate(blk["i_glob"]):
+                    if ig == 0 or jg == 0:
+                        if name in ("DXT", "DYU"):
+                            continue          # the closed-boundary extension overwrites those (grid.F90:587-634)
+                        want = 0 if name == "KMT" else (0.0 if name == "ULAT" else 1.0)
+                    elif jg > 0:
+                        want = G[jg - 1, ig - 1]
+                    else:
+                        n = -jg - ny
+                        js, is_ = ny + yo - n, nx + xo - ig
+                        is_ = is_ + nx if is_ < 1 else (is_ - nx if is_ > nx else is_)
+                        want = G[js - 1, is_ - 1]
+                        seen_fold += 1
+                    assert A[bid - 1, j, i] == want, (name, bid, j, i)
+        assert seen_fold == 2 * m.nxb * (nx // cfg.block_size_x)
+    m.close()
+
+
+def test_grid_files_round_trip(pkg, tmp_path):
+    """the reference's direct-access binary files (7 r8 records; one i4 record) read back into the same model"""
+    cfg = named_config("tiny", ns_boundary=2)
+    g = synthetic_grid(cfg)
+    hf, tf = str(tmp_path / "horiz_grid.bin"), str(tmp_path / "topography.bin")
+    np.stack([g[n] for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")]).astype(np.float64).tofile(hf)
+    g["KMT"].astype(np.int32).tofile(tf)
+    g2 = pkg.read_grid_files(hf, tf, cfg.nx_global, cfg.ny_global)
+    for n in g:
+        assert np.array_equal(g[n], g2[n]), n
+    with pytest.raises(pkg.PopError, match="cannot read"):
+        pkg.read_grid_files(hf + ".missing", tf, cfg.nx_global, cfg.ny_global)
+    a, b = pkg.PopModel(cfg, host_only=True, grid=g), pkg.PopModel(cfg, host_only=True, grid=g2)
+    assert np.array_equal(a.get("TAREA"), b.get("TAREA")) and np.array_equal(a.geti("KMU"), b.geti("KMU"))
+    a.close(); b.close()
+    with pytest.raises(pkg.PopError, match="required"):
+        pkg.PopModel(cfg, host_only=True, grid={"ULAT": g["ULAT"]})
+
+
+def _host_fields_bit_exact(pkg, cfg, grid):
+    m = pkg.PopModel(cfg, host_only=True, grid=grid)
+    o = Oracle(cfg, grid=grid)
     assert (m.nxb, m.nyb, m.km, m.nblocks) == (o.nxb, o.nyb, o.km, o.nblocks)
     for f in IFIELDS:
         assert np.array_equal(m.geti(f), o.i2(f)), f
