@@ -24,6 +24,11 @@ struct DevGrid {
   const double *WNE, *WEa, *WNo, *WC0, *mMask, *CHECKER, *CONSTNT;
   const double *SMF1, *SMF2, *SMFT1, *SMFT2;
   const unsigned char *mMask8;                     // mMask (exactly 0 or 1) as bytes: the fused solver kernels read 1 B instead of 8
+  // land elimination at workgroup-tile granularity (the reference drops land BLOCKS from the distribution,
+  // distribution.F90 / domain.F90 'Eliminating land blocks'; here a block is as large as a GPU's share, so the unit is the tile
+  // a workgroup works on).  opre[b*(n2+1) + p] = number of cells with KMT > 0 among the cells < p of block b (ghosts included).
+  const int *opre;
+  int skip;                                        // 1: workgroups whose tile holds no ocean cell return at once
 };
 
 // scalar parameters of the current step (step_mod.F90:302-320)

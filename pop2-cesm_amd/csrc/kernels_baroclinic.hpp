@@ -48,6 +48,7 @@ __global__ void k_state3d(DevGrid g, const double *__restrict__ T, const double 
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
+  if (land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x)) return;
   const long long o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
   const MwjfP P = mwjf_level(g.pressz[k]);
   RHO[o] = mwjf_rho<false>(P, T[o], S[o], nullptr, nullptr);
@@ -62,6 +63,7 @@ __global__ void k_vmix_const(DevGrid g, StepParams sp, const double *__restrict_
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
+  if (land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x)) return;
   const int kp1 = min(k + 1, g.km);
   const long long o = (long long)b * g.n3 + p2;
   const MwjfP P = mwjf_level(g.pressz[kp1]);
@@ -596,6 +598,7 @@ __global__ void k_add_barotropic(DevGrid g, double *__restrict__ UNEW, double *_
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
+  if (land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x)) return;
   const long long q2 = (long long)b * g.n2 + p2;
   if (k <= g.KMU[q2]) {
     const long long o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
@@ -660,6 +663,7 @@ __global__ void k_avg3d(DevGrid g, Avg3dArgs a) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
+  if (land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x)) return;
   const long long o = (long long)b * g.n3 + (long long)(k - 1) * g.n2 + p2;
   const double uc = a.UC[o], vc = a.VC[o];
   a.UO[o] = 0.5 * (a.UO[o] + uc); a.VO[o] = 0.5 * (a.VO[o] + vc);

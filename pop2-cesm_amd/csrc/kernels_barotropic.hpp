@@ -715,6 +715,7 @@ template <bool UPDATE>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_a(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (red_land_out<1>(g, a.partA, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const long long q = (long long)b * g.n2 + (live ? p2 : 0);
@@ -752,6 +753,7 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_b(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (red_land_out<1>(g, a.partB, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const int pp = live ? p2 : 0;
@@ -836,6 +838,7 @@ __device__ __forceinline__ double cg_z_at(const FusedArgs &a, int m) {
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fcg_a(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (red_land_out<2>(g, a.partA, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const int pp = live ? p2 : 0;
@@ -875,6 +878,7 @@ k_fcg_a(DevGrid g, FusedArgs a) {
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fcg_a2(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (red_land_out<2>(g, a.partA, a.sendmap != nullptr)) return;
   __shared__ double sh[2][POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;
@@ -950,6 +954,7 @@ k_fcg_a2(DevGrid g, FusedArgs a) {
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fcg_b(DevGrid g, FusedArgs a, int par) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (red_land(g, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const int pp = live ? p2 : 0;
@@ -994,6 +999,7 @@ k_fcg_b(DevGrid g, FusedArgs a, int par) {
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fpcg_b2(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (red_land_out<1>(g, a.partB, a.sendmap != nullptr)) return;
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;     // first cell of the pair (even)
@@ -1080,6 +1086,7 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_xr(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (red_land(g, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, a.presummed);
   const double rz = a.sc->eta1;
@@ -1097,6 +1104,7 @@ template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fresidual(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (WITH_RR ? red_land_out<1>(g, a.partA, a.sendmap != nullptr) : red_land(g, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   double v[1] = {0.0};
   if (p2 < g.n2) {
@@ -1122,6 +1130,7 @@ template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fresidual2(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (WITH_RR ? red_land_out<1>(g, a.partA, a.sendmap != nullptr) : red_land(g, a.sendmap != nullptr)) return;
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;

@@ -76,6 +76,32 @@ __device__ __forceinline__ bool lds_tile(int lds_order, int ntx, int nty, int &t
   ti = Pi * PW + rr % w; tj = Pj * PH + rr / w;
   return true;
 }
+// ---- land elimination: does the tile of this workgroup hold an ocean cell? -------------------------------------------
+// A tile without one (KMT = 0 everywhere; KMU = min of four KMT is 0 there too) has nothing to compute: what the full
+// kernels write there does not depend on the state (zeros, rho(0,0,p(k)), the vertical-mixing floor values), so it is
+// written during the first steps after set-up (DevGrid::skip = 0) and left alone afterwards.  Arguments are uniform over
+// the workgroup, so the look-ups are scalar loads.
+__device__ __forceinline__ int ocean_cells(const DevGrid &g, int b, int p0, int p1) {   // cells p0 <= p < p1 of block b
+  const int *S = g.opre + (long long)b * (g.n2 + 1);
+  return S[p1] - S[p0];
+}
+__device__ __forceinline__ bool land_tile(const DevGrid &g, int b, int i0, int w, int j0, int h) {   // cells [i0, i0+w) x [j0, j0+h)
+  if (!g.skip) return false;
+  int i1 = i0 + w, j1 = j0 + h;
+  if (i0 < 0) i0 = 0;
+  if (j0 < 0) j0 = 0;
+  if (i1 > g.nxb) i1 = g.nxb;
+  if (j1 > g.nyb) j1 = g.nyb;
+  if (i0 >= i1) return false;
+  int n = 0;
+  for (int j = j0; j < j1; ++j) n += ocean_cells(g, b, j * g.nxb + i0, j * g.nxb + i1);
+  return n == 0;
+}
+__device__ __forceinline__ bool land_run(const DevGrid &g, int b, long long p0, int n) {   // n consecutive cells from p0
+  if (!g.skip || p0 >= g.n2) return false;
+  const int p1 = (p0 + n < g.n2) ? (int)(p0 + n) : g.n2;
+  return ocean_cells(g, b, (int)p0, p1) == 0;
+}
 __host__ __device__ inline int col_grid_x(int n2, int threads) { const int nt = (n2 + threads - 1) / threads; return 8 * ((nt + 7) / 8); }
 // launch grid x for a col_setup kernel with `threads` x 1 workgroups
 __host__ inline int col_grid(const DevGrid &g, int threads) {
@@ -88,11 +114,13 @@ __device__ __forceinline__ bool col_setup(const DevGrid &g, Col &c, bool interio
     c.i = t.ti * blockDim.x + threadIdx.x;
     c.j = t.tj * blockDim.y + threadIdx.y;
     if (!t.valid || c.i >= g.nxb || c.j >= g.nyb) return false;
+    if (land_tile(g, c.b, t.ti * blockDim.x, blockDim.x, t.tj * blockDim.y, blockDim.y)) return false;
     c.p2 = c.j * g.nxb + c.i;
   } else {
     const int tile = g.xcd_remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     c.p2 = tile * blockDim.x + threadIdx.x;
     if (c.p2 >= g.n2) return false;
+    if (land_run(g, c.b, (long long)tile * blockDim.x, blockDim.x)) return false;
     c.i = c.p2 % g.nxb;
     c.j = c.p2 / g.nxb;
   }
@@ -122,6 +150,40 @@ __device__ __forceinline__ int red_cell(const DevGrid &g) {
   }
   const long long p2 = (long long)red_chunk(g) * blockDim.x + threadIdx.x;
   return p2 < g.n2 ? (int)p2 : g.n2;
+}
+
+// 2-D reduction / fused solver kernels: does the chunk (or 64 x 4 tile) of this workgroup hold no ocean cell?  Every solver
+// vector stays exactly 0 there (right-hand side, weights and the first guess are), so the workgroup only writes its zero
+// partial(s).  Workgroup (0,0) never says so: it publishes the scalars of the iteration.
+// deep: the tile must also lie at least NGHOST cells inside the physical domain (blocks spread over ranks: the cells
+// nearer the edge are packed for / advanced on behalf of other ranks by the same kernels, which a skipped workgroup would not do)
+__device__ __forceinline__ bool red_land(const DevGrid &g, bool deep = false) {
+  if (!g.skip || (blockIdx.x == 0 && blockIdx.y == 0)) return false;
+  int i0, i1, j0, j1;   // inclusive, 0-based
+  if (g.red_tiles) {
+    const TileId t = tile_of_block(g.nxb, g.nyb, 64, 4);
+    if (!t.valid) return false;
+    i0 = t.ti * 64; i1 = i0 + 63; j0 = t.tj * 4; j1 = j0 + 3;
+    if (!land_tile(g, blockIdx.y, i0, 64, j0, 4)) return false;
+  } else {
+    const long long p0 = (long long)red_chunk(g) * 256;
+    if (!land_run(g, blockIdx.y, p0, 256)) return false;
+    const long long p1 = (p0 + 255 < g.n2) ? p0 + 255 : g.n2 - 1;
+    j0 = (int)(p0 / g.nxb); j1 = (int)(p1 / g.nxb);
+    i0 = (j0 == j1) ? (int)(p0 % g.nxb) : 0; i1 = (j0 == j1) ? (int)(p1 % g.nxb) : g.nxb - 1;
+  }
+  if (deep && !(i0 >= g.ib - 1 + NGHOST && i1 <= g.ie - 1 - NGHOST && j0 >= g.jb - 1 + NGHOST && j1 <= g.je - 1 - NGHOST)) return false;
+  return true;
+}
+template <int NF>
+__device__ __forceinline__ bool red_land_out(const DevGrid &g, double *__restrict__ partial, bool deep = false) {
+  if (!red_land(g, deep)) return false;
+  if (threadIdx.x == 0) {
+    const long long slot = (long long)blockIdx.y * gridDim.x + red_chunk(g);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) partial[NF * slot + f] = 0.0;
+  }
+  return true;
 }
 
 // ---- McDougall, Wright, Jackett & Feistel (2003) equation of state as used by the

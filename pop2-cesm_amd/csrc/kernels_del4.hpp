@@ -19,6 +19,7 @@ __global__ void k_del4_d2t(DevGrid g, const double *__restrict__ AHF, const doub
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k0 = blockIdx.y * POP_DEL4_KC + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
+  if (land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x)) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
   if (i + 1 < g.ib - 1 || i + 1 > g.ie + 1 || j + 1 < g.jb - 1 || j + 1 > g.je + 1) return;
   const long long q = (long long)b * g.n2 + p2;
@@ -41,6 +42,7 @@ __global__ void k_del4_d2u(DevGrid g, const double *__restrict__ AMF, const doub
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k0 = blockIdx.y * POP_DEL4_KC + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
+  if (land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x)) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
   if (i + 1 < g.ib - 1 || i + 1 > g.ie + 1 || j + 1 < g.jb - 1 || j + 1 > g.je + 1) return;
   const long long q = (long long)b * g.n2 + p2;

@@ -165,6 +165,7 @@ k_kpp_buoydiff_lds(DevGrid g, KppDev kp, const double *__restrict__ T, const dou
   // same column order as col_setup (xcd_remap 0 / 1); surplus threads keep running to the barrier with a clamped column
   const int tile = g.xcd_remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const long long p2raw = (long long)tile * POP_COL_THREADS + tx;
+  if (land_run(g, blockIdx.y, (long long)tile * POP_COL_THREADS, POP_COL_THREADS)) return;   // whole workgroup: before any barrier
   const bool live = p2raw < g.n2;
   const int p2 = live ? (int)p2raw : 0;
   const int b = blockIdx.y, km = g.km;
@@ -223,6 +224,7 @@ k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, cons
   const int tx = threadIdx.x, gy = threadIdx.y;
   const int tile = g.xcd_remap ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const long long p2raw = (long long)tile * POP_COL_THREADS + tx;
+  if (land_run(g, blockIdx.y, (long long)tile * POP_COL_THREADS, POP_COL_THREADS)) return;   // whole workgroup: before any barrier
   const bool live = p2raw < g.n2;
   const int p2 = live ? (int)p2raw : 0;
   const int b = blockIdx.y, km = g.km, nxb = g.nxb;
@@ -821,6 +823,7 @@ __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k0 = blockIdx.y * POP_VVC_KC + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
+  if (land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x)) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
   const long long q2 = (long long)b * g.n2 + p2;
   const bool in = i < g.nxb - 1 && j < g.nyb - 1;

@@ -36,6 +36,7 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a, int tj_first, in
   if (!lds_tile(g.lds_order, tiles_i, tj_count, ti, tj)) return;
   tj += tj_first;
   const int i0 = NGHOST + ti * POP_COL_THREADS, j0 = NGHOST + tj * R;
+  if (land_tile(g, b, i0, POP_COL_THREADS, j0, R)) return;   // no ocean column in the tile: U, V stay 0 there
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * POP_COL_THREADS + tx;
   const int i = i0 + tx, j = j0 + ty;
   const bool inb = i < nxb && j < nyb;                       // cell exists (tiles may overhang the array)

@@ -34,6 +34,7 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
   int ti, tj;
   if (!lds_tile(g.lds_order, tiles_i, tiles_j, ti, tj)) return;
   const int i0 = NGHOST + ti * POP_COL_THREADS, j0 = NGHOST + tj * R;
+  if (land_tile(g, b, i0, POP_COL_THREADS, j0, R)) return;   // no ocean column in the tile
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * POP_COL_THREADS + tx;
   const int i = i0 + tx, j = j0 + ty;
   const bool inb = i < nxb && j < nyb;

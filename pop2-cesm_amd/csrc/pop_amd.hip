@@ -75,6 +75,9 @@ struct pop_ctx {
   hipEvent_t chk_ev[4] = {};                              // one event per check interval in flight
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
   bool no_graph = false, fused_ok = false, replicated = false, grid_from_input = false;
+  // land elimination: the first land_full_steps steps after set-up / a restart / a new state run every workgroup (they write
+  // the state-independent values of the land tiles), later steps skip workgroups without an ocean cell (DevGrid::skip)
+  bool land_skip = true; int land_full_steps = 4, full_left = 4; double land_fraction = 0.0;
   bool fpcg_one_cell = false;   // POP_FPCG_B2=0: one cell per thread in step B of the fused pcg even on large grids
   bool force_presum = false;
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
@@ -1244,6 +1247,46 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   }
   G2(mMask); G2(CHECKER); G2(CONSTNT); G2(SMF1); G2(SMF2); G2(SMFT1); G2(SMFT2);
 #undef G2
+  {   // land elimination (DevGrid::opre): prefix count of the cells that have an ocean T cell within two cells in either
+      // direction.  The margin is what makes the skipped values independent of the state: every field the full kernels write
+      // on a cell further than one stencil from any ocean cell (tgrid_to_ugrid averages, gradients at land U points, ...) is a
+      // constant.  Ghost cells count with the KMT their halo update gave them.
+    const std::vector<int> kmt = local_part(h, h.i2["KMT"]);
+    std::vector<int> pre((size_t)(h.n2 + 1) * h.nblocks);
+    long long tiles = 0, land = 0;
+    for (int b = 0; b < h.nblocks; ++b) {
+      const int *K = kmt.data() + (size_t)b * h.n2;
+      int *P = pre.data() + (size_t)b * (h.n2 + 1);
+      const BlockInfo &B = h.all_blocks[h.local_ids[b] - 1];
+      P[0] = 0;
+      for (int j = 0; j < h.nyb; ++j)
+        for (int i = 0; i < h.nxb; ++i) {
+          // ghost cells beyond a closed boundary are rewritten with the fill value by every halo update and recomputed by the
+          // whole-block kernels of averaging steps: their values do depend on the step, so they count as cells to compute
+          int near = (B.i_glob[i] == 0 || B.j_glob[j] == 0) ? 1 : 0;
+          for (int dj = -2; dj <= 2 && !near; ++dj)
+            for (int di = -2; di <= 2; ++di) {
+              const int ii = i + di, jj = j + dj;
+              if (ii >= 0 && ii < h.nxb && jj >= 0 && jj < h.nyb && K[(size_t)jj * h.nxb + ii] > 0) { near = 1; break; }
+            }
+          P[(size_t)j * h.nxb + i + 1] = P[(size_t)j * h.nxb + i] + near;
+        }
+      for (int j = 0; j < h.nyb; ++j)
+        for (int i0 = 0; i0 < h.nxb; i0 += 64) {
+          const int i1 = std::min(i0 + 64, h.nxb);
+          ++tiles;
+          if (P[(size_t)j * h.nxb + i1] == P[(size_t)j * h.nxb + i0]) ++land;
+        }
+    }
+    int *d;
+    if (dev_upload(c, &d, pre.data(), pre.size())) return 1;
+    g.opre = d;
+    g.skip = 0;
+    c->land_fraction = tiles ? (double)land / (double)tiles : 0.0;
+    c->land_skip = !(getenv("POP_LAND_SKIP") && atoi(getenv("POP_LAND_SKIP")) == 0);
+    c->land_full_steps = getenv("POP_LAND_FULL_STEPS") ? atoi(getenv("POP_LAND_FULL_STEPS")) : 4;
+    c->full_left = c->land_full_steps;
+  }
   g.WNE = c->d2["btropWgtNE"]; g.WEa = c->d2["btropWgtEast"]; g.WNo = c->d2["btropWgtNorth"]; g.WC0 = c->d2["centerWgtIndep"];
   if (cfg->hmix_tracer == 4) { g.DTN = c->d2["d4DTN"]; g.DTS = c->d2["d4DTS"]; g.DTE = c->d2["d4DTE"]; g.DTW = c->d2["d4DTW"]; }
   if (cfg->hmix_momentum == 4) {
@@ -1531,6 +1574,7 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "curtime") return c->curt;
   if (n == "newtime") return c->newt;
   if (n == "leapfrogts") return c->leapfrogts;
+  if (n == "land_skip_active") return c->g.skip;
   if (n == "avg_ts") return c->avg_ts;
   if (n == "nsteps_total") return c->nsteps_total;
   if (n == "nsteps_per_interval") return c->h.nsteps_per_interval;
@@ -1551,6 +1595,7 @@ double pop_get_scalar(const pop_ctx *c, const char *name) {
   if (n == "rconst") return c->h.rconst;
   if (n == "uarea_equator") return c->h.uarea_equator;
   if (n == "rmsResidual") return c->rmsResidual;
+  if (n == "land_tile_fraction") return c->land_fraction;     // 64-column row segments without an ocean cell nearby (land elimination)
   if (n == "PcsiMaxEigs") return c->h.pcsi_max_eig;
   if (n == "PcsiMinEigs") return c->h.pcsi_min_eig;
   if (n == "lanczos_steps") return (double)c->h.pcsi_lanczos_steps;
@@ -1622,6 +1667,9 @@ int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *hos
   if (join_side(c)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(p, host, cnt * sizeof(double), hipMemcpyHostToDevice));
+  // a new prognostic state may carry other values on land: the next steps run every workgroup again (land elimination)
+  for (const char *f : {"TRACER", "UVEL", "VVEL", "RHO", "PSURF", "GRADPX", "GRADPY", "UBTROP", "VBTROP", "PGUESS", "FW_OLD"})
+    if (!strcmp(name, f)) c->full_left = c->land_full_steps;
   return 0;
 }
 int pop_get_ifield(pop_ctx *c, const char *name, int *host, long long count) {
@@ -1731,6 +1779,7 @@ int pop_read_restart(pop_ctx *c, const char *path, int flags) {
   }
   close(fd);
   if (rc) return rc;
+  c->full_left = c->land_full_steps;   // land elimination: the state just read is new
   // init_ts :1665-1681: density of both time levels from the tracers just read
   hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->curt], c->TR[1][c->curt], c->RHO[c->curt]);
   hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->oldt], c->TR[1][c->oldt], c->RHO[c->oldt]);
@@ -1753,8 +1802,20 @@ int pop_read_restart(pop_ctx *c, const char *path, int flags) {
 }
 
 // ---- time_manager + set_switches (time_management.F90:1823-1847, 2139-2234) ----------------
+// DevGrid::skip for the step that starts now; cached solver graphs hold the flag by value
+static void land_skip_for_step(pop_ctx *c) {
+  const int want = (c->land_skip && c->full_left == 0) ? 1 : 0;
+  if (c->full_left > 0) --c->full_left;
+  if (want == c->g.skip) return;
+  c->g.skip = want;
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+  for (auto &g : c->pcsi_graphs) hipGraphExecDestroy(g.second);
+  c->graphs.clear(); c->pcsi_graphs.clear();
+}
 int pop_time_manager(pop_ctx *c) {
   const pop_config &cf = c->h.c;
+  if (!c->host_only) land_skip_for_step(c);
   c->leapfrogts = 1; c->f_euler_ts = 0; c->avg_ts = 0;
   c->nsteps_total += 1;
   if (cf.tmix_opt == 2) { c->nsteps_this_interval += 1; if (c->nsteps_this_interval > c->h.nsteps_per_interval) c->nsteps_this_interval = 1; }
