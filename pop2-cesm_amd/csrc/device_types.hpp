@@ -29,6 +29,16 @@ struct DevGrid {
   // a workgroup works on).  opre[b*(n2+1) + p] = number of cells with KMT > 0 among the cells < p of block b (ghosts included).
   const int *opre;
   int skip;                                        // 1: workgroups whose tile holds no ocean cell return at once
+  // fused solver kernels only (their launches are ~100 us, so even workgroups that return at once cost a quarter of it): the
+  // launch covers red_nact workgroups per block and workgroup w of block b takes chunk red_act[b*red_nact + w] -- the chunks
+  // with an ocean cell first, in increasing order, padded with land chunks of the same block
+  // LDS-tiled stencil kernels (64 x R column tiles): launch order of the tiles with an ocean cell, tj << 16 | ti, -1 = padding.
+  // Without the list the XCDs that draw land tiles idle while the in-order dispatcher waits for the others (measured: the
+  // momentum kernel gained 22% from skipping 35% of its tiles)
+  const int *lds_act4, *lds_act8;
+  int lds_n4, lds_n8;
+  const int *red_act, *red_cnt;                    // red_cnt[b]: how many entries of block b's list are chunks with ocean
+  int red_nact;
 };
 
 // scalar parameters of the current step (step_mod.F90:302-320)

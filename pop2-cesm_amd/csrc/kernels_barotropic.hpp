@@ -714,14 +714,15 @@ __device__ __forceinline__ double fused_total(const double *__restrict__ partial
 template <bool UPDATE>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_a(DevGrid g, FusedArgs a) {
-  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
-  if (red_land_out<1>(g, a.partA, a.sendmap != nullptr)) return;
+  const int stop = a.sc->stop;   // an earlier check has converged: this launch belongs to the look-ahead interval (branch below, after the loads are issued)
+  if (red_land_out<1>(g, a.partA, a.nchunk, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const long long q = (long long)b * g.n2 + (live ? p2 : 0);
   double r = a.R[q], x = 0.0, s0 = 0.0, qq = 0.0;
   if (UPDATE) { x = a.X[q]; s0 = a.S0[q]; qq = a.Q[q]; }
   const double cw = a.C[q], mk = (double)g.mMask8[q];
+  if (stop) return;
   double alpha = 0.0;
   if (UPDATE) {
     const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, a.presummed);
@@ -744,7 +745,7 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
       if (a.sendmap && send_band(g, i, j)) pack_cell(a, q, z);
     }
   }
-  wg_reduce_store<1>(v, a.partA, b * gridDim.x + red_chunk(g));
+  wg_reduce_store<1>(v, a.partA, b * a.nchunk + red_chunk(g));
 }
 
 // step B: s_new = z + s_old*(eta1/eta0) at the 9 stencil points; q = A s_new; partial (q,s).
@@ -753,7 +754,7 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_b(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
-  if (red_land_out<1>(g, a.partB, a.sendmap != nullptr)) return;
+  if (red_land_out<1>(g, a.partB, a.nchunk, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const int pp = live ? p2 : 0;
@@ -798,7 +799,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
     }
     a.Q[q] = aq;
   }
-  wg_reduce_store<1>(v, a.partB, b * gridDim.x + red_chunk(g));
+  wg_reduce_store<1>(v, a.partB, b * a.nchunk + red_chunk(g));
 }
 
 // ---- fused ChronGear (POP_SolversMod.F90:2100-2210): two launches per iteration ----------------------------
@@ -838,7 +839,7 @@ __device__ __forceinline__ double cg_z_at(const FusedArgs &a, int m) {
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fcg_a(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
-  if (red_land_out<2>(g, a.partA, a.sendmap != nullptr)) return;
+  if (red_land_out<2>(g, a.partA, a.nchunk, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const int pp = live ? p2 : 0;
@@ -871,14 +872,14 @@ k_fcg_a(DevGrid g, FusedArgs a) {
     const double mk = (double)g.mMask8[q];
     v[0] = (r * zv[0]) * mk; v[1] = (az * zv[0]) * mk;
   }
-  wg_reduce_store<2>(v, a.partA, b * gridDim.x + red_chunk(g));
+  wg_reduce_store<2>(v, a.partA, b * a.nchunk + red_chunk(g));
 }
 // step A with two horizontally adjacent cells per thread (large grids, even row pitch; see k_fpcg_b2): the pair shares
 // its three stencil rows of r and A0R.  Same operations per cell, same reduction tree: bitwise equal to k_fcg_a.
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fcg_a2(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
-  if (red_land_out<2>(g, a.partA, a.sendmap != nullptr)) return;
+  if (red_land_out<2>(g, a.partA, a.nchunk, a.sendmap != nullptr)) return;
   __shared__ double sh[2][POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;
@@ -945,7 +946,7 @@ k_fcg_a2(DevGrid g, FusedArgs a) {
     __syncthreads();
   }
   if (t == 0) {
-    const long long slot = (long long)b * gridDim.x + red_chunk(g);
+    const long long slot = (long long)b * a.nchunk + red_chunk(g);
     a.partA[2 * slot] = sh[0][0]; a.partA[2 * slot + 1] = sh[1][0];
   }
 }
@@ -998,8 +999,8 @@ k_fcg_b(DevGrid g, FusedArgs a, int par) {
 // in the same order per cell, and the 256 products are reduced by the same tree as in k_fpcg_b: bitwise equal.
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fpcg_b2(DevGrid g, FusedArgs a) {
-  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
-  if (red_land_out<1>(g, a.partB, a.sendmap != nullptr)) return;
+  const int stop = a.sc->stop;   // an earlier check has converged: this launch belongs to the look-ahead interval (branch below, after the loads are issued)
+  if (red_land_out<1>(g, a.partB, a.nchunk, a.sendmap != nullptr)) return;
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;     // first cell of the pair (even)
@@ -1028,6 +1029,7 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
     ne0w = g.WNE[q - 1]; nemw = g.WNE[q - 1 - nxb];
     mk0 = (double)g.mMask8[q]; mk1 = (double)g.mMask8[q + 1];
   }
+  if (stop) return;
   // presummed block sums only (host selects this kernel for large grids): no barrier inside
   const double rz = fused_total(a.partA, a.nchunk, a.nblocks, a.bsA, 1);
   const double bt = rz / a.sc->eta0;
@@ -1079,7 +1081,7 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
     if (t < s) sh[t] = sh[t] + sh[t + s];
     __syncthreads();
   }
-  if (t == 0) a.partB[(long long)b * gridDim.x + red_chunk(g)] = sh[0];
+  if (t == 0) a.partB[(long long)b * a.nchunk + red_chunk(g)] = sh[0];
 }
 
 // pending x,r update before a convergence check
@@ -1104,7 +1106,7 @@ template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fresidual(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
-  if (WITH_RR ? red_land_out<1>(g, a.partA, a.sendmap != nullptr) : red_land(g, a.sendmap != nullptr)) return;
+  if (WITH_RR ? red_land_out<1>(g, a.partA, a.nchunk, a.sendmap != nullptr) : red_land(g, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   double v[1] = {0.0};
   if (p2 < g.n2) {
@@ -1121,7 +1123,7 @@ k_fresidual(DevGrid g, FusedArgs a) {
       if (a.sendmap && a.A0R && send_band(g, i, j)) pack_cell(a, q, r * a.A0R[q]);
     }
   }
-  if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * gridDim.x + red_chunk(g));
+  if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * a.nchunk + red_chunk(g));
 }
 
 // r = b - A x with two horizontally adjacent cells per thread (large grids, even row pitch; see k_fpcg_b2): bitwise
@@ -1130,7 +1132,7 @@ template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fresidual2(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
-  if (WITH_RR ? red_land_out<1>(g, a.partA, a.sendmap != nullptr) : red_land(g, a.sendmap != nullptr)) return;
+  if (WITH_RR ? red_land_out<1>(g, a.partA, a.nchunk, a.sendmap != nullptr) : red_land(g, a.sendmap != nullptr)) return;
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;
@@ -1189,7 +1191,7 @@ k_fresidual2(DevGrid g, FusedArgs a) {
       if (t < s) sh[t] = sh[t] + sh[t + s];
       __syncthreads();
     }
-    if (t == 0) a.partA[(long long)b * gridDim.x + red_chunk(g)] = sh[0];
+    if (t == 0) a.partA[(long long)b * a.nchunk + red_chunk(g)] = sh[0];
   }
 }
 

@@ -59,10 +59,10 @@ __host__ __device__ inline int lds_grid_x(int lds_order, int ntx, int nty) {
   const int nt = ntx * nty;
   return lds_order ? 256 * ((nt + 255) / 256) : nt;
 }
-__device__ __forceinline__ bool lds_tile(int lds_order, int ntx, int nty, int &ti, int &tj) {
-  if (!lds_order) { ti = blockIdx.x % ntx; tj = blockIdx.x / ntx; return true; }
+__host__ __device__ inline bool lds_tile_of(int lds_order, int bx, int ntx, int nty, int &ti, int &tj) {
+  if (!lds_order) { ti = bx % ntx; tj = bx / ntx; return tj < nty; }
   constexpr int PW = 4, PH = 8;
-  const int e = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int e = bx & 7, s = bx >> 3;
   const int gi = ((s >> 5) * 8 + e) * 32 + (s & 31);
   if (gi >= ntx * nty) return false;
   const int row_tiles = PH * ntx, full_rows = nty / PH;
@@ -75,6 +75,27 @@ __device__ __forceinline__ bool lds_tile(int lds_order, int ntx, int nty, int &t
   else { Pi = nfullp; w = ntx - nfullp * PW; rr = r - nfullp * patch_tiles; }
   ti = Pi * PW + rr % w; tj = Pj * PH + rr / w;
   return true;
+}
+__device__ __forceinline__ bool lds_tile(int lds_order, int ntx, int nty, int &ti, int &tj) {
+  return lds_tile_of(lds_order, (int)blockIdx.x, ntx, nty, ti, tj);
+}
+// the same through the list of tiles with an ocean cell (DevGrid::lds_act4/8) when land elimination is on
+template <int R>
+__device__ __forceinline__ bool lds_tile_active(const DevGrid &g, int b, int ntx, int nty, int &ti, int &tj, bool &listed) {
+  const int *L = (R == 8) ? g.lds_act8 : g.lds_act4;
+  const int nL = (R == 8) ? g.lds_n8 : g.lds_n4;
+  listed = g.skip && L != nullptr;
+  if (!listed) return lds_tile(g.lds_order, ntx, nty, ti, tj);
+  const int e = L[(long long)b * nL + blockIdx.x];
+  if (e < 0) return false;
+  ti = e & 0xffff; tj = e >> 16;
+  return true;
+}
+template <int R>
+__host__ inline int lds_launch_x(const DevGrid &g, int ntx, int nty) {
+  const int *L = (R == 8) ? g.lds_act8 : g.lds_act4;
+  if (g.skip && L) return (R == 8) ? g.lds_n8 : g.lds_n4;
+  return lds_grid_x(g.lds_order, ntx, nty);
 }
 // ---- land elimination: does the tile of this workgroup hold an ocean cell? -------------------------------------------
 // A tile without one (KMT = 0 everywhere; KMU = min of four KMT is 0 there too) has nothing to compute: what the full
@@ -132,6 +153,7 @@ __device__ __forceinline__ bool col_setup(const DevGrid &g, Col &c, bool interio
 // 2-D reduction kernels (POP_RED_THREADS = 256 threads, one partial per workgroup): cell of this thread,
 // or g.n2 (not a cell) for surplus threads.  Large grids use 64 x 4 tiles in the XCD-strided column order.
 __host__ inline int red_grid_x(const DevGrid &g) {
+  if (g.red_act) return g.red_nact;
   if (g.red_tiles) return tile_grid_x(g.nxb, g.nyb, 64, 4);
   const int nc = (g.n2 + 255) / 256;
   return g.red_band ? 8 * ((nc + 7) / 8) : nc;
@@ -140,6 +162,7 @@ __host__ inline int red_grid_x(const DevGrid &g) {
 // j+-1 of a 9-point stencil were touched by the same XCD a few workgroups earlier; the chunk -> cells map and the
 // order of the partials are unchanged, only which workgroup computes which chunk.
 __device__ __forceinline__ int red_chunk(const DevGrid &g) {
+  if (g.red_act) return g.red_act[(long long)blockIdx.y * g.red_nact + blockIdx.x];
   return g.red_band ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
 }
 __device__ __forceinline__ int red_cell(const DevGrid &g) {
@@ -159,6 +182,7 @@ __device__ __forceinline__ int red_cell(const DevGrid &g) {
 // nearer the edge are packed for / advanced on behalf of other ranks by the same kernels, which a skipped workgroup would not do)
 __device__ __forceinline__ bool red_land(const DevGrid &g, bool deep = false) {
   if (!g.skip || (blockIdx.x == 0 && blockIdx.y == 0)) return false;
+  if (g.red_act) return (int)blockIdx.x >= g.red_cnt[blockIdx.y];   // compacted launch: the list is sorted, land chunks only pad it
   int i0, i1, j0, j1;   // inclusive, 0-based
   if (g.red_tiles) {
     const TileId t = tile_of_block(g.nxb, g.nyb, 64, 4);
@@ -176,10 +200,10 @@ __device__ __forceinline__ bool red_land(const DevGrid &g, bool deep = false) {
   return true;
 }
 template <int NF>
-__device__ __forceinline__ bool red_land_out(const DevGrid &g, double *__restrict__ partial, bool deep = false) {
+__device__ __forceinline__ bool red_land_out(const DevGrid &g, double *__restrict__ partial, int nchunk, bool deep = false) {
   if (!red_land(g, deep)) return false;
   if (threadIdx.x == 0) {
-    const long long slot = (long long)blockIdx.y * gridDim.x + red_chunk(g);
+    const long long slot = (long long)blockIdx.y * nchunk + red_chunk(g);
 #pragma unroll
     for (int f = 0; f < NF; ++f) partial[NF * slot + f] = 0.0;
   }

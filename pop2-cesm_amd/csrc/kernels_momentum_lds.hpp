@@ -33,10 +33,12 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a, int tj_first, in
   const int tiles_i = (nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
   const int b = blockIdx.y;
   int ti, tj;
-  if (!lds_tile(g.lds_order, tiles_i, tj_count, ti, tj)) return;
+  bool listed = false;
+  if (tj_first == 0 && tj_count == (nyb - 2 * NGHOST + R - 1) / R) { if (!lds_tile_active<R>(g, b, tiles_i, tj_count, ti, tj, listed)) return; }
+  else if (!lds_tile(g.lds_order, tiles_i, tj_count, ti, tj)) return;
   tj += tj_first;
   const int i0 = NGHOST + ti * POP_COL_THREADS, j0 = NGHOST + tj * R;
-  if (land_tile(g, b, i0, POP_COL_THREADS, j0, R)) return;   // no ocean column in the tile: U, V stay 0 there
+  if (!listed && land_tile(g, b, i0, POP_COL_THREADS, j0, R)) return;   // no ocean column in the tile: U, V stay 0 there
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * POP_COL_THREADS + tx;
   const int i = i0 + tx, j = j0 + ty;
   const bool inb = i < nxb && j < nyb;                       // cell exists (tiles may overhang the array)
@@ -228,7 +230,8 @@ inline void launch_momentum_lds(const DevGrid &g, const StepParams &sp, const Mo
   if (tj_count < 0) tj_count = tiles_j - tj_first;
   if (tj_count <= 0) return;
   static const int pf = getenv("POP_MOMENTUM_PF") ? atoi(getenv("POP_MOMENTUM_PF")) : 1;
-  const dim3 G(lds_grid_x(g.lds_order, tiles_i, tj_count), g.nblocks), B(POP_COL_THREADS, R);
+  const bool whole = tj_first == 0 && tj_count == tiles_j;
+  const dim3 G(whole ? lds_launch_x<R>(g, tiles_i, tiles_j) : lds_grid_x(g.lds_order, tiles_i, tj_count), g.nblocks), B(POP_COL_THREADS, R);
   if (pf == 2) hipLaunchKernelGGL((k_momentum_rhs_lds<R, 2>), G, B, 0, st, g, sp, a, tj_first, tj_count);
   else hipLaunchKernelGGL((k_momentum_rhs_lds<R, 1>), G, B, 0, st, g, sp, a, tj_first, tj_count);
 }

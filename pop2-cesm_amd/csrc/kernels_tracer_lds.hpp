@@ -32,9 +32,10 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
   const int tiles_i = (nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
   const int tiles_j = (nyb - 2 * NGHOST + R - 1) / R, b = blockIdx.y;
   int ti, tj;
-  if (!lds_tile(g.lds_order, tiles_i, tiles_j, ti, tj)) return;
+  bool listed = false;
+  if (!lds_tile_active<R>(g, b, tiles_i, tiles_j, ti, tj, listed)) return;
   const int i0 = NGHOST + ti * POP_COL_THREADS, j0 = NGHOST + tj * R;
-  if (land_tile(g, b, i0, POP_COL_THREADS, j0, R)) return;   // no ocean column in the tile
+  if (!listed && land_tile(g, b, i0, POP_COL_THREADS, j0, R)) return;   // no ocean column in the tile
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * POP_COL_THREADS + tx;
   const int i = i0 + tx, j = j0 + ty;
   const bool inb = i < nxb && j < nyb;
@@ -195,7 +196,7 @@ template <int R>
 inline void launch_tracer_lds(const DevGrid &g, const StepParams &sp, const TracerRhsArgs &a, hipStream_t st, bool fwd = false) {
   const int tiles_i = (g.nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS;
   const int tiles_j = (g.nyb - 2 * NGHOST + R - 1) / R;
-  const dim3 G(lds_grid_x(g.lds_order, tiles_i, tiles_j), g.nblocks), B(POP_COL_THREADS, R);
+  const dim3 G(lds_launch_x<R>(g, tiles_i, tiles_j), g.nblocks), B(POP_COL_THREADS, R);
   if (fwd) hipLaunchKernelGGL((k_tracer_rhs_lds<R, true>), G, B, 0, st, g, sp, a);
   else hipLaunchKernelGGL((k_tracer_rhs_lds<R, false>), G, B, 0, st, g, sp, a);
 }

@@ -70,6 +70,8 @@ struct pop_ctx {
   double *partial = nullptr, *blocksum = nullptr;
   SolverScalars *sc = nullptr;
   int *gid = nullptr, *srcmap = nullptr, *iota = nullptr, *loc_of_gid = nullptr;
+  std::vector<int> opre_host;
+  int *red_act = nullptr, *red_cnt = nullptr; int red_nact = 0;                // chunks with an ocean cell (fused solver launches, land elimination)
   SolverScalars *host_sc = nullptr;                       // pinned
   double *host_rr = nullptr;                              // pinned ring of (r,r) check results (k_rr_total)
   hipEvent_t chk_ev[4] = {};                              // one event per check interval in flight
@@ -355,7 +357,7 @@ int solver_pcg(pop_ctx *c) {
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->S0, 0, sizeof(double) * c->g.n2 * c->g.nblocks, c->stream));
   SolverArgs a = solver_args(c);
-  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_residual<false>, grid_2d(c), B, 0, c->stream, c->g, a);
   if (halo_update(c, c->R, 1)) return 1;
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
@@ -379,7 +381,7 @@ int solver_pcg(pop_ctx *c) {
       a = solver_args(c);
       hipLaunchKernelGGL(k_pcg_xr, G, B, 0, c->stream, c->g, a);
       pending = false;
-      hipLaunchKernelGGL(k_residual<true>, G, B, 0, c->stream, c->g, a);
+      hipLaunchKernelGGL(k_residual<true>, grid_2d(c), B, 0, c->stream, c->g, a);
       if (halo_update(c, c->R, 1)) return 1;
       if (reduce_finish<1>(c, FIN_RR)) return 1;
       SolverScalars s;
@@ -547,6 +549,16 @@ SolveView local_view(pop_ctx *c) {
   v.srcmap = c->srcmap; v.gid = c->gid; v.nchunk = c->nchunk; v.nblocks_tot = c->h.nblocks_tot;
   return v;
 }
+// the same view for the fused pcg / ChronGear kernels: with land elimination active their launches cover only the chunks
+// that hold an ocean cell (DevGrid::red_act); the partials of the chunks left out are zeroed once per solve
+SolveView fused_view(pop_ctx *c) {
+  SolveView v = local_view(c);
+  if (c->g.skip && c->red_act) {
+    v.g.red_act = c->red_act; v.g.red_cnt = c->red_cnt; v.g.red_nact = c->red_nact;
+    hipMemsetAsync(v.partial, 0, (size_t)v.nchunk * v.g.nblocks * 2 * sizeof(double), c->stream);
+  }
+  return v;
+}
 // Replicated barotropic mode (small 2-D problems on several GPUs): the tropic distribution of the
 // reference (domain.F90:433-543, POP_RedistributeBlocks around the solve, POP_SolversMod.F90:390-417,
 // 481) taken to its limit -- every rank gathers RHS and the first guess of ALL blocks with one
@@ -618,7 +630,7 @@ struct DistSolve {
 
 int solver_pcg_fused_dist(pop_ctx *c) {
   const pop_config &cf = c->h.c;
-  DistSolve D{c, local_view(c), c->h.nblocks_tot};
+  DistSolve D{c, fused_view(c), c->h.nblocks_tot};
   SolveView &v = D.v;
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
   const int nbt = D.nbt, freq = cf.convergence_check_freq;
@@ -702,15 +714,15 @@ int solver_chrongear(pop_ctx *c) {
   SolverScalars init{};
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   SolverArgs a = solver_args(c);
-  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_residual<false>, grid_2d(c), B, 0, c->stream, c->g, a);
   if (halo_update(c, c->R, 1)) return 1;
   if (c->use_evp) {   // :2009-2032
     if (evp_apply(c, c->R, c->Z) || halo_update(c, c->Z, 1)) return 1;
-    hipLaunchKernelGGL(k_cg_init<true>, G, B, 0, c->stream, c->g, a);
-  } else hipLaunchKernelGGL(k_cg_init<false>, G, B, 0, c->stream, c->g, a);
+    hipLaunchKernelGGL(k_cg_init<true>, grid_2d(c), B, 0, c->stream, c->g, a);
+  } else hipLaunchKernelGGL(k_cg_init<false>, grid_2d(c), B, 0, c->stream, c->g, a);
   if (halo_update(c, c->Q, 1)) return 1;
   if (reduce_finish<2>(c, FIN_CG_INIT)) return 1;
-  hipLaunchKernelGGL(k_cg_update<true>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_cg_update<true>, grid_2d(c), B, 0, c->stream, c->g, a);
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
   for (int m = 1; m <= cf.max_iterations; ++m) {
@@ -719,9 +731,9 @@ int solver_chrongear(pop_ctx *c) {
     if (halo_update(c, c->Z, 1)) return 1;
     hipLaunchKernelGGL(k_cg_az, G, B, 0, c->stream, c->g, a);
     if (reduce_finish<2>(c, FIN_CG_ITER)) return 1;
-    hipLaunchKernelGGL(k_cg_update<false>, G, B, 0, c->stream, c->g, a);
+    hipLaunchKernelGGL(k_cg_update<false>, grid_2d(c), B, 0, c->stream, c->g, a);
     if (m % cf.convergence_check_freq == 0) {
-      hipLaunchKernelGGL(k_residual<true>, G, B, 0, c->stream, c->g, a);
+      hipLaunchKernelGGL(k_residual<true>, grid_2d(c), B, 0, c->stream, c->g, a);
       if (halo_update(c, c->R, 1)) return 1;
       if (reduce_finish<1>(c, FIN_RR)) return 1;
       SolverScalars s;
@@ -740,6 +752,11 @@ int solver_chrongear(pop_ctx *c) {
 // (k_fcg_a, k_fcg_b: the z halo folded into the matvec through srcmap, scalar recurrences recomputed by every
 // workgroup from the ordered totals) and one hipGraph replay per check interval.  Same arithmetic and summation
 // order as solver_chrongear: bitwise the same solution and iteration count.
+// compacted launches (DevGrid::red_act): the iterations store pairs of partials, the checks single ones, in the same slots;
+// chunks that are not launched cannot zero theirs, so the slots are cleared whenever the layout changes
+static void cg_clear_partials(pop_ctx *c, const SolveView &v) {
+  if (v.g.red_act) hipMemsetAsync(v.partial, 0, (size_t)v.nchunk * v.g.nblocks * 2 * sizeof(double), c->stream);
+}
 static int cg_fused_iterations(pop_ctx *c, SolveView &v, int n, int &par) {
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
   for (int it = 0; it < n; ++it) {
@@ -756,25 +773,27 @@ static int cg_fused_iterations(pop_ctx *c, SolveView &v, int n, int &par) {
 static int cg_fused_interval(pop_ctx *c, SolveView &v, int freq) {
   int par = 0;
   cg_fused_iterations(c, v, freq, par);
+  cg_clear_partials(c, v);
   launch_fresidual<true>(c, v, fused_args(c, v));
   hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_rr, c->h.convergenceCriterion);
+  cg_clear_partials(c, v);
   return 0;
 }
 int solver_chrongear_fused(pop_ctx *c) {
   const pop_config &cf = c->h.c;
-  SolveView v = local_view(c);
+  SolveView v = fused_view(c);
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
   const int freq = cf.convergence_check_freq;
   const long long a2 = (long long)c->g.n2 * c->g.nblocks;
   SolverScalars init{};
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   SolverArgs a = solver_args(c);
-  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_residual<false>, grid_2d(c), B, 0, c->stream, c->g, a);
   if (halo_update(c, c->R, 1)) return 1;
-  hipLaunchKernelGGL(k_cg_init<false>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_cg_init<false>, grid_2d(c), B, 0, c->stream, c->g, a);
   if (halo_update(c, c->Q, 1)) return 1;
   if (reduce_finish<2>(c, FIN_CG_INIT)) return 1;
-  hipLaunchKernelGGL(k_cg_update<true>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_cg_update<true>, grid_2d(c), B, 0, c->stream, c->g, a);
   hipLaunchKernelGGL(k_pcsi_a0r, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->centerWgt, v.S1, a2);
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
@@ -799,8 +818,10 @@ int solver_chrongear_fused(pop_ctx *c) {
     } else {
       int par = (i * freq) & 1;   // odd freq: the ping-pong slot carries over between intervals
       cg_fused_iterations(c, v, freq, par);
+      cg_clear_partials(c, v);
       launch_fresidual<true>(c, v, fused_args(c, v));
       hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)v.partial, v.nchunk, v.g.nblocks, c->sc, c->host_rr, c->h.convergenceCriterion);
+      cg_clear_partials(c, v);
     }
     return 1;
   }, rr, lerr);
@@ -822,7 +843,7 @@ int solver_chrongear_fused(pop_ctx *c) {
 // exchange z | k_fcg_a | block sums of (r,z), (az,z) | ONE all-reduce | k_fcg_b, which also packs the next z
 int solver_chrongear_fused_dist(pop_ctx *c) {
   const pop_config &cf = c->h.c;
-  DistSolve D{c, local_view(c), c->h.nblocks_tot};
+  DistSolve D{c, local_view(c), c->h.nblocks_tot};   // whole launches: the (r,r) partials of the checks and the pairs of the iterations share slots
   D.overlap = false;   // nothing runs beside the exchange here: the next kernel needs it
   SolveView &v = D.v;
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
@@ -832,15 +853,15 @@ int solver_chrongear_fused_dist(pop_ctx *c) {
   SolverScalars init{};
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   SolverArgs sa = solver_args(c);
-  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, sa);
+  hipLaunchKernelGGL(k_residual<false>, grid_2d(c), B, 0, c->stream, c->g, sa);
   if (halo_update(c, c->R, 1)) return 1;
-  hipLaunchKernelGGL(k_cg_init<false>, G, B, 0, c->stream, c->g, sa);
+  hipLaunchKernelGGL(k_cg_init<false>, grid_2d(c), B, 0, c->stream, c->g, sa);
   if (halo_update(c, c->Q, 1)) return 1;
   if (reduce_finish<2>(c, FIN_CG_INIT)) return 1;
-  hipLaunchKernelGGL(k_cg_update<true>, G, B, 0, c->stream, c->g, sa);
+  hipLaunchKernelGGL(k_cg_update<true>, grid_2d(c), B, 0, c->stream, c->g, sa);
   hipLaunchKernelGGL(k_pcsi_a0r, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->centerWgt, v.S1, a2);
   // z of the first iteration at the neighbours' ghosts: z = r*A0R on the whole array, packed and exchanged once
-  hipLaunchKernelGGL(k_cg_z, G, B, 0, c->stream, c->g, sa);
+  hipLaunchKernelGGL(k_cg_z, grid_2d(c), B, 0, c->stream, c->g, sa);
   if (c->nsend_all) hipLaunchKernelGGL(k_halo_pack_all, dim3((c->nsend_all + 255) / 256, 1), dim3(256), 0, c->stream, (const double *)c->Z, c->sa_src, c->sa_start, c->sa_cnt, c->nsend_all, c->sendbuf, 1, c->g.n2);
   if (D.xchg_begin()) return 1;
   c->numIterations = cf.max_iterations;
@@ -910,7 +931,7 @@ int solver_pcsi(pop_ctx *c) {
   SolverScalars init{};
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   SolverArgs a = solver_args(c);
-  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_residual<false>, grid_2d(c), B, 0, c->stream, c->g, a);
   auto precond = [&]() -> int {   // r' = M^-1 r in place (:1646-1660, :1738-1752)
     if (c->use_evp) {
       if (evp_apply(c, c->R, c->Z)) return 1;
@@ -922,7 +943,7 @@ int solver_pcsi(pop_ctx *c) {
   if (halo_update(c, c->R, 1)) return 1;
   hipLaunchKernelGGL(k_pcsi_update<true>, G1, B1, 0, c->stream, (const double *)c->R, c->Q, a.X, a2, (const double *)c->pcsi_omega,
                      (const int *)c->pcsi_base, 0, c->pcsi_csy);
-  hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+  hipLaunchKernelGGL(k_residual<false>, grid_2d(c), B, 0, c->stream, c->g, a);
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
   const int start = pcsi_check_start(c);
@@ -933,8 +954,8 @@ int solver_pcsi(pop_ctx *c) {
     hipLaunchKernelGGL(k_pcsi_update<false>, G1, B1, 0, c->stream, (const double *)c->R, c->Q, a.X, a2, (const double *)c->pcsi_omega,
                        (const int *)c->pcsi_base, 1, c->pcsi_csy);
     const bool check = (m % cf.convergence_check_freq == 0) && m >= start;
-    if (check) hipLaunchKernelGGL(k_residual<true>, G, B, 0, c->stream, c->g, a);
-    else hipLaunchKernelGGL(k_residual<false>, G, B, 0, c->stream, c->g, a);
+    if (check) hipLaunchKernelGGL(k_residual<true>, grid_2d(c), B, 0, c->stream, c->g, a);
+    else hipLaunchKernelGGL(k_residual<false>, grid_2d(c), B, 0, c->stream, c->g, a);
     if (check) {
       if (reduce_finish<1>(c, FIN_RR)) return 1;
       SolverScalars s;
@@ -1282,6 +1303,32 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if (dev_upload(c, &d, pre.data(), pre.size())) return 1;
     g.opre = d;
     g.skip = 0;
+    c->opre_host = pre;
+    for (int R : {4, 8}) {   // DevGrid::lds_act4 / lds_act8
+      const int ntx = (h.nxb - 2 * NGHOST + POP_COL_THREADS - 1) / POP_COL_THREADS, nty = (h.nyb - 2 * NGHOST + R - 1) / R;
+      if (ntx > 0xffff || nty > 0x7fff) continue;
+      const int G = lds_grid_x(g.lds_order, ntx, nty);
+      std::vector<std::vector<int>> act(h.nblocks);
+      size_t longest = 0;
+      for (int b = 0; b < h.nblocks; ++b) {
+        const int *P = pre.data() + (size_t)b * (h.n2 + 1);
+        for (int bx = 0; bx < G; ++bx) {
+          int ti, tj;
+          if (!lds_tile_of(g.lds_order, bx, ntx, nty, ti, tj)) continue;
+          const int i0 = NGHOST + ti * POP_COL_THREADS, i1 = std::min(i0 + POP_COL_THREADS, h.nxb);
+          int n = 0;
+          for (int j = NGHOST + tj * R; j < std::min(NGHOST + tj * R + R, h.nyb); ++j) n += P[(size_t)j * h.nxb + i1] - P[(size_t)j * h.nxb + i0];
+          if (n) act[b].push_back(tj << 16 | ti);
+        }
+        longest = std::max(longest, act[b].size());
+      }
+      if (longest == 0 || longest == (size_t)ntx * nty) continue;
+      std::vector<int> list((size_t)longest * h.nblocks, -1);
+      for (int b = 0; b < h.nblocks; ++b) std::copy(act[b].begin(), act[b].end(), list.begin() + (size_t)b * longest);
+      int *dl;
+      if (dev_upload(c, &dl, list.data(), list.size())) return 1;
+      if (R == 4) { g.lds_act4 = dl; g.lds_n4 = (int)longest; } else { g.lds_act8 = dl; g.lds_n8 = (int)longest; }
+    }
     c->land_fraction = tiles ? (double)land / (double)tiles : 0.0;
     c->land_skip = !(getenv("POP_LAND_SKIP") && atoi(getenv("POP_LAND_SKIP")) == 0);
     c->land_full_steps = getenv("POP_LAND_FULL_STEPS") ? atoi(getenv("POP_LAND_FULL_STEPS")) : 4;
@@ -1341,6 +1388,36 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     }
   }
   c->nchunk = red_grid_x(g);
+  if (!g.red_tiles) {   // DevGrid::red_act: the chunks (256 consecutive cells) the fused solver kernels have to visit
+    const int nc = (int)((h.n2 + 255) / 256);
+    const bool multi = h.nranks > 1;
+    std::vector<std::vector<int>> act(h.nblocks), land(h.nblocks);
+    size_t longest = 0;
+    for (int b = 0; b < h.nblocks; ++b) {
+      const int *P = c->opre_host.data() + (size_t)b * (h.n2 + 1);
+      for (int k = 0; k < nc; ++k) {
+        const long long p0 = 256LL * k, p1 = std::min<long long>(p0 + 256, (long long)h.n2);
+        bool is_land = P[p1] == P[p0];
+        if (is_land && multi) {   // as red_land(g, deep): chunks within NGHOST of the edge of the physical domain work for other ranks
+          const int j0 = (int)(p0 / h.nxb), j1 = (int)((p1 - 1) / h.nxb);
+          const int i0 = (j0 == j1) ? (int)(p0 % h.nxb) : 0, i1 = (j0 == j1) ? (int)((p1 - 1) % h.nxb) : h.nxb - 1;
+          is_land = i0 >= g.ib - 1 + NGHOST && i1 <= g.ie - 1 - NGHOST && j0 >= g.jb - 1 + NGHOST && j1 <= g.je - 1 - NGHOST;
+        }
+        (is_land && !(b == 0 && k == 0) ? land[b] : act[b]).push_back(k);
+      }
+      longest = std::max(longest, act[b].size());
+    }
+    std::vector<int> list((size_t)longest * h.nblocks);
+    for (int b = 0; b < h.nblocks; ++b)
+      for (size_t w = 0; w < longest; ++w)
+        list[(size_t)b * longest + w] = w < act[b].size() ? act[b][w] : land[b][w - act[b].size()];   // shorter list => it has land chunks to pad with
+    if (longest < (size_t)nc) {
+      std::vector<int> cnt(h.nblocks);
+      for (int b = 0; b < h.nblocks; ++b) cnt[b] = (int)act[b].size();
+      if (dev_upload(c, &c->red_act, list.data(), list.size()) || dev_upload(c, &c->red_cnt, cnt.data(), cnt.size())) return 1;
+      c->red_nact = (int)longest;
+    }
+  }
   if (dev_alloc(c, &c->partial, (size_t)c->nchunk * h.nblocks * 2) || dev_alloc(c, &c->blocksum, (size_t)h.nblocks_tot * 4)) return 1;
   { std::vector<int> io(h.nblocks_tot); for (int b = 0; b < h.nblocks_tot; ++b) io[b] = b; if (dev_upload(c, &c->iota, io.data(), io.size())) return 1; }
   if (dev_alloc(c, &c->sc, 1)) return 1;
@@ -2079,7 +2156,7 @@ int pop_solver_run(pop_ctx *c) {
     if (!c->allred || !c->redbuf || c->red_doubles < 2LL * c->g.n2 * c->h.nblocks_tot) { c->err = "replicated solve needs pop_set_comm with a reduce buffer of pop_reduce_buffer_doubles()"; return 1; }
     return solver_pcg_replicated(c);
   }
-  if (c->fused_ok) { SolveView v = local_view(c); const int e = solver_pcg_fused(c, v); c->S0 = v.S0; c->S1 = v.S1; return e; }
+  if (c->fused_ok) { SolveView v = fused_view(c); const int e = solver_pcg_fused(c, v); c->S0 = v.S0; c->S1 = v.S1; return e; }
   if (c->h.nranks > 1 && c->max_blocks_per_rank <= 8 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcg_fused_dist(c);
   return solver_pcg(c);
 }

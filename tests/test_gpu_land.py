@@ -19,6 +19,8 @@ CASES = [
     ("wide", {"vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e19, "ah": -1.0e18, "time_mix_freq": 5}, BIG, 14),
     ("wide", {"vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e19, "ah": -1.0e18, "time_mix_freq": 5, "solver_choice": 2}, {}, 12),
     ("wide", {"block_size_x": 1056, "tadvect": 2, "vmix_choice": 2, "tmix_opt": 1, "time_mix_freq": 4}, BIG, 12),
+    ("wide", {"time_mix_freq": 5}, {}, 10),                                                      # fused pcg on the compacted chunk list
+    ("wide", {"block_size_x": 1056, "solver_choice": 2}, {}, 10),                                # two blocks: lists padded to one length
     ("test", {"vmix_choice": 3, "stepped_bathymetry": 1, "time_mix_freq": 6}, {}, 13),          # 96 blocks, many of them land
     ("gx3v7", {"tadvect": 3, "tmix_opt": 3}, {}, 10),
     ("tiny", {"solver_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "lvariable_hmix": 1}, {}, 10),
@@ -59,7 +61,7 @@ def test_land_elimination_is_bitwise_invisible(pkg, monkeypatch, name, kw, env, 
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("name,kw,env,nsteps", [CASES[0], CASES[3]])
+@pytest.mark.parametrize("name,kw,env,nsteps", [CASES[0], CASES[3], CASES[5]])
 def test_phases_match_oracle_with_land_elimination_active(pkg, orclib_built, monkeypatch, name, kw, env, nsteps):
     """the oracle computes every cell; steps 5.. run with land tiles skipped and are compared on every cell, ghosts included"""
     cfg = named_config(name, **kw)
