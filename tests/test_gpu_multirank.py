@@ -119,3 +119,23 @@ def test_stream_operations_per_distributed_iteration():
     args = ["--nproc-per-node", "2", os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "2", "--kw"]
     assert _ops(_run_check(args + [""], 300, transport="native")) <= 7.0 + 0.5
     assert _ops(_run_check(args + ["solver_choice=2"], 300, transport="native")) <= 5.0 + 0.5
+
+
+# ---- land elimination across ranks (POP_LAND_FULL_STEPS=0: tiles without ocean are skipped from the first step, in the
+# multi-rank run and in its single-rank twin alike): the distributed solvers work for their neighbours near the edge of a
+# rank's blocks (packing z, advancing ghost cells), so chunks there are never skipped; the compacted chunk lists of the
+# fused pcg must agree with that.  'wide' has a continent several 64-column tiles wide.
+_SKIP = {"POP_LAND_FULL_STEPS": "0"}
+
+
+@pytest.mark.parametrize("nranks,kw,env,transport", [
+    (2, "block_size_x=528", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "staged"),                   # fused distributed pcg, compacted launches
+    (4, "block_size_x=528,solver_choice=2", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "staged"),    # ChronGear, one block per rank
+    (2, "block_size_x=528,vmix_choice=3,hmix_momentum=4,hmix_tracer=4,am=-1.0e19,ah=-1.0e18", _SKIP, "staged"),   # replicated solve
+    (2, "block_size_x=528", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "native"),
+    (4, "block_size_x=528,vmix_choice=3", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "native"),
+    (2, "block_size_x=1056,solver_choice=2", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "native"),
+])
+def test_land_elimination_across_ranks(nranks, kw, env, transport):
+    _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "wide", "--steps", "4",
+                "--kw", kw], 300, env, transport=transport)
