@@ -43,14 +43,28 @@ PHASE_WORDS = {
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def workload_config(name, nranks):
+def workload_config(name, nranks, block_rows=0):
     from popcfg import named_config
     cfg = named_config(name)
-    if nranks > 1:
-        # shard by j-bands: one block per rank
+    if block_rows:
+        if cfg.ny_global % block_rows:
+            raise SystemExit("ny_global=%d not divisible by --block-rows %d" % (cfg.ny_global, block_rows))
+        cfg.block_size_y = block_rows
+        cfg.reserved_i[4] = 1
+    elif nranks > 1:
+        # shard by j-bands.  Large grids: more bands than ranks (16, or 4 per rank) handed out as contiguous runs of equal
+        # OCEAN columns (reserved_i[4] = 1, the reference's load-balanced distributions): with land elimination a rank's
+        # time follows its ocean columns, and equal bands of tx0.1v3's synthetic topography differ by 1.46 x at 8 ranks
+        # (1.16 x with 75-row bands, 1.06 x at 4 ranks, 1.00 x at 2).  Small grids: one band per rank.
         if cfg.ny_global % nranks:
             raise SystemExit("ny_global=%d not divisible by %d ranks" % (cfg.ny_global, nranks))
         cfg.block_size_y = cfg.ny_global // nranks
+        bands = max(16, 4 * nranks)
+        # (two ranks keep one band each: 1.155 x against 1.00 x balanced, but several blocks per rank cost ~7% themselves --
+        # measured on one GPU, tx0.1v3 as 8 blocks: 124.8 ms against 116.1)
+        if nranks >= 4 and cfg.ny_global % bands == 0 and cfg.ny_global // bands >= 64:
+            cfg.block_size_y = cfg.ny_global // bands
+            cfg.reserved_i[4] = 1
     return cfg
 
 
@@ -210,13 +224,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)   # land elimination starts with the fifth step (four steps write the land values)
     ap.add_argument("--workload", default=os.environ.get("POP_BENCH_WORKLOAD", "tx0.1v3"))
     ap.add_argument("--solver", default=os.environ.get("POP_BENCH_SOLVER", "pcg"), choices=["pcg", "chrongear", "pcsi"],
                     help="barotropic solver (headline = pcg, BASELINE.json north_star)")
     ap.add_argument("--precond", default=os.environ.get("POP_BENCH_PRECOND", "diagonal"), choices=["diagonal", "evp"],
                     help="solver preconditioner (headline = diagonal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--block-rows", type=int, default=0, help="rows per j-band block (default: one band per rank, or balanced bands on large grids)")
     args = ap.parse_args()
 
     import torch
@@ -241,7 +256,7 @@ def main():
 
     import __graft_entry__ as ge
     pkg = ge.load_package()
-    cfg = workload_config(args.workload, world)
+    cfg = workload_config(args.workload, world, args.block_rows)
     cfg.solver_choice = {"pcg": 1, "chrongear": 2, "pcsi": 3}[args.solver]
     cfg.reserved_i[2] = 1 if args.precond == "evp" else 0
     model = pkg.PopModel(cfg, rank=rank, nranks=world)
@@ -351,7 +366,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "grid": [cfg.nx_global, cfg.ny_global, cfg.km], "nt": cfg.nt,
                    "block_size": [cfg.block_size_x, cfg.block_size_y], "steps_per_day": cfg.steps_per_day, "step_calls_per_day": calls_per_day,
-                   "land_tile_fraction": round(land_frac, 4),
+                   "land_tile_fraction": round(land_frac, 4), "distribution": "balanced-ocean-columns" if cfg.reserved_i[4] else "equal-block-counts",
+                   "blocks_local": model.nblocks,
                    "hmix": "del%d" % cfg.hmix_momentum, "vmix": ["const", "rich", "kpp"][vm],
                    "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport},

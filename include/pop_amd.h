@@ -54,7 +54,10 @@ typedef struct pop_config {
                                * (POP_SolversMod.F90:626-640); [2] = preconditionerChoice: 0 'diagonal', 1 'evp'
                                * (:124, :252-290, :2434-2696; any solver_choice);
                                * [3] = synthetic topography: 0 the reference's internal flat bottom (grid.F90:880-884,
-                               * 1957-1985), 1 stepped bathymetry KMT = 3 ... km (test extension, not in the reference) */
+                               * 1957-1985), 1 stepped bathymetry KMT = 3 ... km (test extension, not in the reference);
+                               * [4] = distribution of the blocks over ranks (distribution_type, domain.F90): 0 contiguous runs of
+                               * equal block counts ('cartesian' for one column of blocks), 1 contiguous runs of equal ocean
+                               * columns (load-balanced, in the spirit of 'rake' / 'spacecurve', distribution.F90) */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;

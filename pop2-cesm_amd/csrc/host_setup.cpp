@@ -28,6 +28,34 @@ struct Shift {   // zero-filled neighbour access inside one block (Fortran eoshi
   }
 };
 
+// topography_internal (grid.F90:1957-1985) + the stepped test extension (reserved_i[3]); shared by the block distribution
+// (work per block) and the grid set-up
+static int kmt_rule(const pop_config &c, int km, const double latd, double lond, int ig, int jg) {
+  if (lond < 0.0) lond = lond + 360.0;
+  int k = km;
+  if (latd > -35.0 && lond > 210.0 && lond < 250.0) k = 0;
+  if (latd > 25.0 && lond > 210.0 && lond < 330.0) k = 0;
+  if (latd > 60.0 && lond > 210.0 && lond < 150.0) k = 0;
+  if (latd > -60.0 && lond > 110.0 && lond < 150.0) k = 0;
+  if (std::fabs(latd) > 75.0) k = 0;
+  // reserved_i[3] = 1: stepped synthetic bathymetry (an extension for tests; the reference's internal topography is
+  // flat, grid.F90:880-884): ocean columns of 3 ... km levels in stairs 3 cells wide in i and 2 in j, so that every
+  // k > KMT / k > KMU branch and the shallow-column paths of the Thomas solves are exercised.  Integer arithmetic only.
+  if (k > 0 && c.reserved_i[3] == 1) k = std::max(3, km - ((ig / 3) * 5 + (jg / 2) * 3) % (km / 2 + 1));
+  return k;
+}
+// global KMT at (ig, jg), 1-based: the caller's record, or the internal rule on the caller's / the internal ULAT, ULON
+static int kmt_global(const HostModel &h, int ig, int jg) {
+  const pop_config &c = h.c;
+  const double radian = 180.0 / (4.0 * std::atan(1.0));
+  const size_t p = (size_t)(jg - 1) * c.nx_global + (ig - 1);
+  if (h.gin && h.gin->KMT) return h.gin->KMT[p];
+  if (h.gin) return kmt_rule(c, c.km, h.gin->ULAT[p] * radian, h.gin->ULON[p] * radian, ig, jg);
+  const double dlon = 360.0 / (double)c.nx_global, dlat = 180.0 / (double)c.ny_global;
+  double x = ig * dlon; if (x > 180.0) x = x - 360.0;
+  return kmt_rule(c, c.km, ((-90.0 + jg * dlat) / radian) * radian, (x / radian) * radian, ig, jg);
+}
+
 void make_blocks(HostModel &h) {
   const pop_config &c = h.c;
   h.nbx = (c.nx_global - 1) / c.block_size_x + 1;
@@ -66,6 +94,35 @@ void make_blocks(HostModel &h) {
   for (int n = 0; n < h.nblocks_tot; ++n) {
     int owner = (int)(((long long)n * h.nranks) / h.nblocks_tot);
     h.block_owner[n] = owner;
+  }
+  if (c.reserved_i[4] == 1 && h.nranks > 1 && h.nblocks_tot > h.nranks) {
+    // load-balanced distribution (the reference balances ocean points per task with its 'rake' / 'spacecurve'
+    // distributions, distribution.F90; the global KMT is read first for exactly this, grid.F90:449-456): still contiguous
+    // runs of block ids -- neighbours stay neighbours -- but the cuts equalise the ocean columns per rank instead of the
+    // block counts.  With land elimination a rank's time follows its ocean columns, not its blocks.
+    std::vector<long long> work(h.nblocks_tot, 0), pre(h.nblocks_tot + 1, 0);
+    for (int n = 0; n < h.nblocks_tot; ++n) {
+      const BlockInfo &B = h.all_blocks[n];
+      for (int j = B.jb; j <= B.je; ++j) for (int i = B.ib; i <= B.ie; ++i) {
+        const int ig = B.i_glob[i - 1], jg = B.j_glob[j - 1];
+        if (ig > 0 && jg > 0 && kmt_global(h, ig, jg) > 0) ++work[n];
+      }
+      work[n] += 1;                       // a land block still costs its launches
+      pre[n + 1] = pre[n] + work[n];
+    }
+    int first = 0;
+    for (int r = 0; r < h.nranks; ++r) {
+      int last;                           // rank r owns blocks first .. last
+      if (r == h.nranks - 1) last = h.nblocks_tot - 1;
+      else {
+        const double target = (double)pre[h.nblocks_tot] * (r + 1) / h.nranks;
+        last = first;
+        while (last + 1 < h.nblocks_tot - (h.nranks - 1 - r) &&
+               std::fabs((double)pre[last + 2] - target) <= std::fabs((double)pre[last + 1] - target)) ++last;
+      }
+      for (int n = first; n <= last; ++n) h.block_owner[n] = r;
+      first = last + 1;
+    }
   }
   std::vector<int> cnt(h.nranks, 0);
   for (int n = 0; n < h.nblocks_tot; ++n) {
@@ -243,20 +300,7 @@ int host_build(HostModel &h) {
   const double dlon = 360.0 / (double)nxg, dlat = 180.0 / (double)nyg;
   auto ulat_g = [&](int jg) { return (-90.0 + jg * dlat) / radian; };          // jg 1-based
   auto ulon_g = [&](int ig) { double x = ig * dlon; if (x > 180.0) x = x - 360.0; return x / radian; };
-  auto kmt_ll = [&](const double latd, double lond, int ig, int jg) {
-    if (lond < 0.0) lond = lond + 360.0;
-    int k = h.km;
-    if (latd > -35.0 && lond > 210.0 && lond < 250.0) k = 0;
-    if (latd > 25.0 && lond > 210.0 && lond < 330.0) k = 0;
-    if (latd > 60.0 && lond > 210.0 && lond < 150.0) k = 0;
-    if (latd > -60.0 && lond > 110.0 && lond < 150.0) k = 0;
-    if (std::fabs(latd) > 75.0) k = 0;
-    // reserved_i[3] = 1: stepped synthetic bathymetry (an extension for tests; the reference's internal topography is
-    // flat, grid.F90:880-884): ocean columns of 3 ... km levels in stairs 3 cells wide in i and 2 in j, so that every
-    // k > KMT / k > KMU branch and the shallow-column paths of the Thomas solves are exercised.  Integer arithmetic only.
-    if (k > 0 && c.reserved_i[3] == 1) k = std::max(3, h.km - ((ig / 3) * 5 + (jg / 2) * 3) % (h.km / 2 + 1));
-    return k;
-  };
+  auto kmt_ll = [&](const double latd, double lond, int ig, int jg) { return kmt_rule(c, h.km, latd, lond, ig, jg); };
   auto kmt_g = [&](int ig, int jg) { return kmt_ll(ulat_g(jg) * radian, ulon_g(ig) * radian, ig, jg); };
   auto &ULAT = newf("ULAT"), &ULON = newf("ULON"), &TLAT = newf("TLAT");
   auto &HTN = newf("HTN"), &HTE = newf("HTE"), &HUS = newf("HUS"), &HUW = newf("HUW");

@@ -1199,6 +1199,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if (cfg->solver_choice < 1 || cfg->solver_choice > 3) return bad("solver_choice: 1 pcg, 2 ChronGear, 3 PCSI");
     if (cfg->reserved_i[2] != 0 && cfg->reserved_i[2] != 1) return bad("preconditionerChoice (reserved_i[2]): 0 diagonal, 1 evp");
     if (cfg->reserved_i[3] != 0 && cfg->reserved_i[3] != 1) return bad("synthetic topography (reserved_i[3]): 0 flat, 1 stepped");
+    if (cfg->reserved_i[4] != 0 && cfg->reserved_i[4] != 1) return bad("distribution (reserved_i[4]): 0 equal block counts, 1 balanced by ocean columns");
     if (cfg->max_iterations < 1 || cfg->convergence_check_freq < 1) return bad("max_iterations and convergence_check_freq must be >= 1");
     if (cfg->tmix_opt < 0 || cfg->tmix_opt > 3) return bad("tmix_opt: 0 none, 1 avg, 2 avgfit, 3 robert");
     if ((cfg->tmix_opt == 1 || cfg->tmix_opt == 2) && cfg->time_mix_freq < 1) return bad("time_mix_freq must be >= 1");
@@ -2142,7 +2143,7 @@ int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
   if (c->h.c.solver_choice == 2) {
     if (c->fused_ok && !c->use_evp) return solver_chrongear_fused(c);
-    if (c->h.nranks > 1 && c->max_blocks_per_rank <= 8 && !c->use_evp && !getenv("POP_SOLVER_UNFUSED")) return solver_chrongear_fused_dist(c);
+    if (c->h.nranks > 1 && c->max_blocks_per_rank <= 16 && !c->use_evp && !getenv("POP_SOLVER_UNFUSED")) return solver_chrongear_fused_dist(c);
     return solver_chrongear(c);
   }
   if (c->h.c.solver_choice == 3) {
@@ -2157,7 +2158,7 @@ int pop_solver_run(pop_ctx *c) {
     return solver_pcg_replicated(c);
   }
   if (c->fused_ok) { SolveView v = fused_view(c); const int e = solver_pcg_fused(c, v); c->S0 = v.S0; c->S1 = v.S1; return e; }
-  if (c->h.nranks > 1 && c->max_blocks_per_rank <= 8 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcg_fused_dist(c);
+  if (c->h.nranks > 1 && c->max_blocks_per_rank <= 16 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcg_fused_dist(c);
   return solver_pcg(c);
 }
 int pop_solver_preconditioner(pop_ctx *c, const char *x_name, int x_tl, const char *px_name, int px_tl) {

@@ -137,5 +137,19 @@ _SKIP = {"POP_LAND_FULL_STEPS": "0"}
     (2, "block_size_x=1056,solver_choice=2", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "native"),
 ])
 def test_land_elimination_across_ranks(nranks, kw, env, transport):
+    """(see the comment above the parameter list)"""
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "wide", "--steps", "4",
+                "--kw", kw], 300, env, transport=transport)
+
+
+# ---- load-balanced distribution (reserved_i[4] = 1): contiguous runs of blocks with equal ocean columns, so ranks own
+# different numbers of blocks (the polar ranks more); same numbers as the single-rank run
+@pytest.mark.parametrize("nranks,kw,env,transport", [
+    (3, "distribution=1,block_size_x=48,block_size_y=5", {}, "staged"),                                   # 8 j-bands over 3 ranks
+    (2, "distribution=1,block_size_x=48,block_size_y=4,vmix_choice=3,km=24", {"POP_SOLVER_DISTRIBUTED": "1"}, "staged"),
+    (3, "distribution=1,block_size_x=48,block_size_y=5,solver_choice=2", {"POP_SOLVER_DISTRIBUTED": "1"}, "native"),
+    (4, "distribution=1,block_size_x=48,block_size_y=4", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "native"),
+])
+def test_balanced_distribution_equals_single_rank(nranks, kw, env, transport):
+    _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
                 "--kw", kw], 300, env, transport=transport)

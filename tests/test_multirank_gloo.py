@@ -10,6 +10,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from popcfg import named_config
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -95,7 +97,8 @@ def _worker(rank, world, port, kw, q):
 
 
 @pytest.mark.parametrize("world,kw", [(2, {}), (4, {}), (2, {"block_size_x": 48, "block_size_y": 20}),
-                                      (2, {"ew_boundary": 0})])
+                                      (2, {"ew_boundary": 0}),
+                                      (3, {"distribution": 1}), (2, {"distribution": 1, "block_size_x": 48, "block_size_y": 5})])
 def test_halo_plan_and_block_sums_over_gloo(pkg, world, kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -114,3 +117,28 @@ def test_halo_plan_and_block_sums_over_gloo(pkg, world, kw):
         assert npeers >= 1
         owned += ids
     assert sorted(owned) == list(range(1, max(owned) + 1))
+
+
+def test_balanced_distribution_equalises_ocean_columns(pkg):
+    """reserved_i[4] = 1: contiguous runs of block ids whose cuts equalise the ocean columns per rank (the reference's
+    load-balanced distributions count ocean points per block the same way, distribution.F90); every rank owns a block,
+    every block has one owner, and the heaviest rank carries less than under equal block counts"""
+    import numpy as np
+    kw = dict(block_size_x=48, block_size_y=4)        # 10 j-bands of the tiny grid: the polar ones are land
+    nr = 4
+    loads = {}
+    for dist_kind in (0, 1):
+        cfg = named_config("tiny", distribution=dist_kind, **kw)
+        owned, ocean = [], []
+        for r in range(nr):
+            m = pkg.PopModel(cfg, rank=r, nranks=nr, host_only=True)
+            ids = m.local_block_ids()
+            owned.append(ids)
+            kmt = m.geti("KMT")[:, 2:-2, 2:-2]
+            ocean.append(int((kmt > 0).sum()))
+            m.close()
+        flat = [i for ids in owned for i in ids]
+        assert sorted(flat) == list(range(1, 11)) and all(len(ids) >= 1 for ids in owned)
+        assert all(ids == list(range(ids[0], ids[0] + len(ids))) for ids in owned)      # contiguous runs
+        loads[dist_kind] = max(ocean) / (sum(ocean) / nr)
+    assert loads[1] < loads[0] and loads[1] < 1.2, loads
