@@ -64,16 +64,31 @@ void build_halo_plan(HostModel &h) {
   // ghost row n of a northern block mirrors global row ny+1-n (centre, E face) or ny-n (NE corner, N face) at
   // column nx-ig+1 (centre, N face) or nx-ig (0 -> nx; E face, NE corner); NE-corner and N-face fields also
   // replace their top physical row by the symmetrised value of the two degenerate points.
-  if (c.ns_boundary == 2 && h.nranks == 1) {
+  // Several ranks: the fold only ever pairs cells of the top row of blocks, so it stays a rank-local operation as long as
+  // that row has ONE owner (always true for full-width j-band blocks, the decomposition the multi-GPU runs use); that rank
+  // gets the plan, the others an empty one.  tripole_g is the same plan with global block numbers for the set-up code,
+  // whose host arrays hold every block on every rank.
+  int top_owner = -1; bool top_split = false;
+  if (c.ns_boundary == 2)
+    for (int n = 0; n < h.nblocks_tot; ++n) {
+      const BlockInfo &B = h.all_blocks[n];
+      if (!(B.j_glob[B.je] < 0)) continue;
+      if (top_owner < 0) top_owner = h.block_owner[n];
+      else if (top_owner != h.block_owner[n]) top_split = true;
+    }
+  P.tripole_split = top_split;
+  for (int pass = 0; pass < 2 && c.ns_boundary == 2 && !top_split; ++pass) {
+    const bool global = pass == 1;
+    if (!global && top_owner != h.rank) continue;
     const int nx = c.nx_global, ny = c.ny_global;
-    auto cell_of = [&](int gi, int gj) { int sb, cell; source(gi, gj, sb, cell); return h.block_local[sb] * (int)h.n2 + cell; };
+    auto cell_of = [&](int gi, int gj) { int sb, cell; source(gi, gj, sb, cell); return (global ? sb : h.block_local[sb]) * (int)h.n2 + cell; };
     for (int loc = 0; loc < 4; ++loc) {
-      TripolePlan &T = P.tripole[loc];
+      TripolePlan &T = global ? P.tripole_g[loc] : P.tripole[loc];
       const int ioff = (loc == 1 || loc == 3) ? 1 : 0, joff = (loc == 1 || loc == 2) ? 1 : 0;
       for (int n = 0; n < h.nblocks_tot; ++n) {
         const BlockInfo &B = h.all_blocks[n];
         if (!(B.j_glob[B.je] < 0)) continue;                 // j_glob of local row je+1 (0-based index je)
-        const int dl = h.block_local[n];
+        const int dl = global ? n : h.block_local[n];
         for (int jn = 0; jn <= NGHOST; ++jn) {               // jn = 0: top physical row
           if (jn == 0 && !joff) continue;
           const int gj = ny + 1 - jn - joff;                 // source row
@@ -122,6 +137,8 @@ std::vector<int> global_srcmap(const HostModel &h) {
         sm[cell] = (sby * h.nbx + sbx) * (int)h.n2 + (sj - 1) * h.nxb + (si - 1);
       }
   }
+  const TripolePlan &T = h.halo.tripole_g[0];   // centre scalars beyond the fold: mirrored copies of physical cells
+  for (size_t e = 0; e < T.dst.size(); ++e) sm[T.dst[e]] = T.a[e];
   return sm;
 }
 

@@ -206,7 +206,7 @@ void host_halo_i4(const HostModel &h, int *a, int nz, int fill) { halo_all<int>(
 // tripole pass (HaloPlan::tripole): two phases, because the symmetrised top row reads physical cells it also writes
 template <class T, class Avg>
 static void tripole_all(const HostModel &h, T *a, int nz, int loc, int kind, Avg avg) {
-  const TripolePlan &P = h.halo.tripole[loc];
+  const TripolePlan &P = h.halo.tripole_g[loc];   // host arrays hold every block
   const T isign = (kind == 0) ? (T)1 : (T)-1;
   const size_t n2 = h.n2;
   std::vector<T> tmp(P.dst.size());
@@ -285,6 +285,7 @@ int host_build(HostModel &h) {
   make_blocks(h);
   if (h.nblocks == 0) { h.err = "rank owns no blocks (more ranks than blocks)"; return 1; }
   build_halo_plan(h);   // needs the blocks only; the tripole pass of the grid-time halo updates below reads it
+  if (h.halo.tripole_split) { h.err = "tripole: the top row of blocks must belong to one rank (use full-width blocks, block_size_x = nx_global, or fewer ranks)"; return 1; }
   if (make_vertical(h)) return 1;
 
   const int nxb = h.nxb, nyb = h.nyb, NB = h.nblocks_tot;
@@ -715,14 +716,16 @@ int host_build(HostModel &h) {
       const double tin = (1.0 - w) * tlev[kk] + w * tlev[kk + 1], sin_ = (1.0 - w) * slev[kk] + w * slev[kk + 1];
       for (int j = 0; j < nyb; ++j) for (int i = 0; i < nxb; ++i)
         if (k <= KMT[idx(gb, i, j)]) {
-          const double dT = amp * std::sin(2.0 * pi * B.i_glob[i] / (double)nxg) * std::cos(pi * B.j_glob[j] / (double)nyg);
+          // ghost rows beyond a tripole fold carry no global index of their own (j_glob < 0): the value of the centre cell they
+          // mirror, row ny + 1 - n at column nx + 1 - i -- what a halo update of the physical cells would deliver
+          int ige = B.i_glob[i], jge = B.j_glob[j];
+          if (jge < 0) { jge = 2 * nyg + 1 + jge; ige = nxg + 1 - ige; if (ige < 1) ige += nxg; if (ige > nxg) ige -= nxg; }
+          const double dT = amp * std::sin(2.0 * pi * ige / (double)nxg) * std::cos(pi * jge / (double)nyg);
           const size_t q = lb * h.n3 + (size_t)(k - 1) * n2 + (size_t)j * nxb + i;
           T0[q] = tin + dT; S0[q] = sin_ * 1.e-3;
         }
     }
   }
-  // the test perturbation is a function of the global indices, which ghost rows beyond a tripole boundary do not carry
-  if (c.ns_boundary == 2) host_halo_r8_loc(h, T0.data(), h.km, 0.0, 0, 0);
   // ---------------- tripole: redundant top-row points of N-face / NE-corner fields ----------------
   if (c.ns_boundary == 2) {
     auto &DUP = newf("TRIPOLE_DUP");

@@ -1250,7 +1250,21 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     for (auto &v : V) { double *p; if (dev_upload(c, &p, v.src->data(), v.src->size())) return 1; *v.dst = p; }
   }
   // 2-D fields: upload the local blocks of every host field
-  for (auto &kv : h.f2) { auto loc = local_part(h, kv.second); double *p; if (dev_upload(c, &p, loc.data(), loc.size())) return 1; c->d2[kv.first] = p; }
+  for (auto &kv : h.f2) {
+    std::vector<double> all;
+    const std::vector<double> *src = &kv.second;
+    if (cfg->ns_boundary == 2 && kv.first == "centerWgtIndep") {
+      // Beyond a tripole fold the reference forms z = r / centerWgt in the ghost rows with the ghost cells' OWN centerWgt, whose four
+      // terms were added in the mirrored order: equal to the owner's value up to rounding only.  The fused solver kernels (and
+      // the exchange of z between ranks) give a ghost cell its owner's z instead; so that every solver path of this library
+      // agrees bit for bit, the device copy of the state-independent part of centerWgt takes the owners' values in those rows
+      // (the area and the mask in the other part are mirrored copies already).  The host copy keeps the reference's values.
+      all = kv.second;
+      host_halo_r8_loc(h, all.data(), 1, 0.0, 0, 0);
+      src = &all;
+    }
+    auto loc = local_part(h, *src); double *p; if (dev_upload(c, &p, loc.data(), loc.size())) return 1; c->d2[kv.first] = p;
+  }
   for (auto &kv : h.i2) { auto loc = local_part(h, kv.second); int *p; if (dev_upload(c, &p, loc.data(), loc.size())) return 1; c->di2[kv.first] = p; }
 #define G2(f) g.f = c->d2[#f]
   G2(DXU); G2(DYU); G2(DXUR); G2(DYUR); G2(UAREA_R); G2(TAREA_R); G2(TAREA); G2(FCOR); G2(HU); G2(HUR);
@@ -1434,9 +1448,8 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if (d.nrecv && dev_upload(c, &d.recv_dst, pp.recv_dst.data(), d.nrecv)) return 1;
     c->peers.push_back(d);
   }
-  if (cfg->ns_boundary == 2) {   // tripole plan (single rank) + evaluation buffer
-    if (h.nranks != 1) { c->err = "tripole halo updates are built for single-rank decompositions"; return 1; }
-    size_t nmax = 0;
+  if (cfg->ns_boundary == 2) {   // tripole plan (non-empty on the rank that owns the top row of blocks) + evaluation buffer
+    size_t nmax = 1;
     for (int loc = 0; loc < 4; ++loc) {
       const TripolePlan &T = h.halo.tripole[loc];
       c->tp_n[loc] = (int)T.dst.size();
@@ -2684,20 +2697,27 @@ int pop_comm_selftest(pop_ctx *c) {
   if (c->red_doubles < nr) { c->err = "pop_comm_selftest: reduce buffer too small"; return 1; }
   std::vector<double> v(nr, 0.0);
   v[c->h.rank] = c->h.rank + 1.0;
-  HIPCHK(c, hipMemcpyAsync(c->redbuf, v.data(), sizeof(double) * nr, hipMemcpyHostToDevice, c->stream));
+  // pageable host memory: blocking copies bracketed by stream synchronisation (an asynchronous copy from / to a std::vector is
+  // only ordered with the stream once its staging has happened)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->redbuf, v.data(), sizeof(double) * nr, hipMemcpyHostToDevice));
   if (c->allred(c->comm_user, 0, nr)) { c->err = "pop_comm_selftest: allreduce failed" + (c->rccl_tr ? ": " + c->rccl_tr->err : std::string()); return 1; }
-  HIPCHK(c, hipMemcpyAsync(v.data(), c->redbuf, sizeof(double) * nr, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(v.data(), c->redbuf, sizeof(double) * nr, hipMemcpyDeviceToHost));
   const double probe = 1000.0 + c->h.rank;
   double back = 0.0;
-  HIPCHK(c, hipMemcpyAsync(c->sendbuf, &probe, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy(c->sendbuf, &probe, sizeof(double), hipMemcpyHostToDevice));
   // ring: one value to rank+1, one from rank-1 (a self message on one rank)
   const int nxt = (c->h.rank + 1) % nr, prv = (c->h.rank + nr - 1) % nr;
   const int peer[2] = {nxt, prv};
   const long long z2[2] = {0, 0}, sc1[2] = {1, 0}, rc1[2] = {nxt == prv ? 1 : 0, 1};
   if (c->xchg(c->comm_user, nxt == prv ? 1 : 2, peer, z2, sc1, z2, rc1)) { c->err = "pop_comm_selftest: exchange failed" + (c->rccl_tr ? ": " + c->rccl_tr->err : std::string()); return 1; }
-  HIPCHK(c, hipMemcpyAsync(&back, c->recvbuf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (int r = 0; r < nr; ++r) if (v[r] != r + 1.0) { c->err = "pop_comm_selftest: all-reduce returned a wrong sum"; return 1; }
+  HIPCHK(c, hipMemcpy(&back, c->recvbuf, sizeof(double), hipMemcpyDeviceToHost));
+  for (int r = 0; r < nr; ++r) if (v[r] != r + 1.0) {
+    char msg[160]; snprintf(msg, sizeof msg, "pop_comm_selftest: all-reduce returned a wrong sum (slot %d holds %.17g, expected %d)", r, v[r], r + 1);
+    c->err = msg; return 1;
+  }
   if (back != 1000.0 + prv) { c->err = "pop_comm_selftest: ring send/recv returned a wrong value"; return 1; }
   if (c->xchg_side && c->comm_side) {   // the same ring through the second communicator on its own stream, beside an all-reduce on the first
     const double probe2 = 2000.0 + c->h.rank;

@@ -44,7 +44,9 @@ struct HaloPlan {
   std::vector<int> fill_dst;            // ghosts outside closed boundaries / padding: fill value
   std::vector<PeerPlan> peers;
   long long max_msg_cells = 0;          // sum over peers of max(send, recv) cells
-  TripolePlan tripole[4];               // by location: 0 centre, 1 NE corner, 2 N face, 3 E face (ns_boundary = 2)
+  TripolePlan tripole[4];               // by location: 0 centre, 1 NE corner, 2 N face, 3 E face (ns_boundary = 2); cells numbered over the rank's blocks
+  TripolePlan tripole_g[4];             // the same with cells numbered over ALL blocks (host set-up arrays)
+  bool tripole_split = false;           // the top row of blocks has more than one owner: no plan
 };
 
 // ---- EVP block preconditioner (reserved_i[2] = 1; POP_SolversMod.F90:252-290, 2434-2696): sub-blocks of at most

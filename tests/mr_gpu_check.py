@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--config", default="tiny")
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--kw", default="")
+    ap.add_argument("--grid", type=int, default=0, help="1: the caller-supplied synthetic grid (pop_create_with_grid), e.g. for ns_boundary=2")
     ap.add_argument("--transport", default="staged", choices=["staged", "native"],
                     help="staged: callback transport over gloo; native: the library's own RCCL binding "
                          "(POP_RCCL_LIB = tests/rccl_stub/librccl_stub.so lets several ranks share one GPU)")
@@ -39,6 +40,8 @@ def main():
     pkg = ge.load_package()
     kw = eval("dict(%s)" % args.kw)
     cfg = named_config(args.config, **kw)
+    from popcfg import synthetic_grid
+    grid = synthetic_grid(cfg) if args.grid else None
     keep = []
 
     def attach(model):
@@ -50,10 +53,20 @@ def main():
         else:
             keep.append(bench.TorchComm(pkg, model, rank, world, staged=True))
 
-    m = pkg.PopModel(cfg, rank=rank, nranks=world)
+    def calm(model):
+        """tripole: the analytic zonal wind has the same value at both copies of a point of the degenerate top row, so the
+        symmetrising halo update is not idempotent on what it drives and a restart (which updates halos again) cannot be
+        exact -- see tests/test_gpu_restart.py; these runs go without wind"""
+        if cfg.ns_boundary == 2:
+            z = np.zeros_like(model.get("SMF", n=0))
+            for n in (0, 1):
+                model.set("SMF", z, n=n); model.set("SMFT", z, n=n)
+        return model
+
+    m = calm(pkg.PopModel(cfg, rank=rank, nranks=world, grid=grid))
     attach(m)
     m.comm_selftest()                                          # all-reduce of known values + a self message
-    ref = pkg.PopModel(cfg) if True else None                  # every rank keeps a single-rank twin
+    ref = calm(pkg.PopModel(cfg, grid=grid))                  # every rank keeps a single-rank twin
     ids = m.local_block_ids()
     ok = True
     for s in range(args.steps):
@@ -77,10 +90,10 @@ def main():
     path = os.path.join(tempfile.gettempdir(), "mr_restart_%s.bin" % os.environ.get("MASTER_PORT", "0"))
     m.write_restart(path)
     dist.barrier()
-    m2 = pkg.PopModel(cfg, rank=rank, nranks=world)
+    m2 = calm(pkg.PopModel(cfg, rank=rank, nranks=world, grid=grid))
     attach(m2)
     m2.read_restart(path)
-    ref2 = pkg.PopModel(cfg); ref2.read_restart(path)
+    ref2 = calm(pkg.PopModel(cfg, grid=grid)); ref2.read_restart(path)
     for s in range(2):
         m.step(); m2.step(); ref2.step()
     for name in ("TRACER", "UVEL", "PSURF", "UBTROP"):

@@ -153,3 +153,17 @@ def test_land_elimination_across_ranks(nranks, kw, env, transport):
 def test_balanced_distribution_equals_single_rank(nranks, kw, env, transport):
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
                 "--kw", kw], 300, env, transport=transport)
+
+
+# ---- tripole fold across ranks: the fold pairs cells of the top row of blocks only, so with that row on one rank (full-width
+# or not: here 4 blocks wide, all on the last rank) it is a rank-local pass after the ordinary exchange
+@pytest.mark.parametrize("nranks,kw,env,transport", [
+    (2, "ns_boundary=2", {}, "staged"),                                                   # 16 blocks, replicated / fused paths as chosen
+    (4, "ns_boundary=2,vmix_choice=3,km=24", {"POP_SOLVER_DISTRIBUTED": "1"}, "staged"),  # fused distributed pcg: fold inside srcmap on the top rank
+    (3, "ns_boundary=2,solver_choice=2,hmix_momentum=4,hmix_tracer=4,am=-1.0e22,ah=-1.0e21", {"POP_SOLVER_DISTRIBUTED": "1"}, "native"),
+    (2, "ns_boundary=2,block_size_x=48,block_size_y=10", {"POP_SOLVER_UNFUSED": "1", "POP_SOLVER_DISTRIBUTED": "1"}, "native"),   # full-width j-bands
+    (2, "ns_boundary=2,solver_choice=3", {}, "native"),
+])
+def test_tripole_across_ranks_equals_single_rank(nranks, kw, env, transport):
+    _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
+                "--grid", "1", "--kw", kw], 300, env, transport=transport)
