@@ -72,6 +72,8 @@ template <bool FIRST, bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_pcsi_step(DevGrid g, PcsiArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  // land elimination: x, dx and r' stay exactly 0 where no ocean cell is near, in both halves of the ping-pong buffers
+  if (WITH_RR ? red_land_out<1>(g, a.partial, (int)gridDim.x, a.remote_ghosts != 0) : red_land(g, a.remote_ghosts != 0)) return;
   const int p2 = red_cell(g), b = blockIdx.y, nxb = g.nxb;
   double v[1] = {0.0};
   if (p2 < g.n2) {
@@ -128,6 +130,8 @@ template <bool WITH_RR>
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_pcsi_step2(DevGrid g, PcsiArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  // land elimination: x, dx and r' stay exactly 0 where no ocean cell is near, in both halves of the ping-pong buffers
+  if (WITH_RR ? red_land_out<1>(g, a.partial, (int)gridDim.x, a.remote_ghosts != 0) : red_land(g, a.remote_ghosts != 0)) return;
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;

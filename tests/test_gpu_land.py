@@ -21,6 +21,8 @@ CASES = [
     ("wide", {"block_size_x": 1056, "tadvect": 2, "vmix_choice": 2, "tmix_opt": 1, "time_mix_freq": 4}, BIG, 12),
     ("wide", {"time_mix_freq": 5}, {}, 10),                                                      # fused pcg on the compacted chunk list
     ("wide", {"block_size_x": 1056, "solver_choice": 2}, {}, 10),                                # two blocks: lists padded to one length
+    ("wide", {"solver_choice": 3, "time_mix_freq": 5}, {}, 10),                                 # P-CSI: land chunks of both ping-pong halves stay 0
+    ("wide", {"solver_choice": 3, "precond_choice": 1, "block_size_x": 1056}, BIG, 8),           # P-CSI + EVP, two blocks, tile order
     ("test", {"vmix_choice": 3, "stepped_bathymetry": 1, "time_mix_freq": 6}, {}, 13),          # 96 blocks, many of them land
     ("gx3v7", {"tadvect": 3, "tmix_opt": 3}, {}, 10),
     ("tiny", {"solver_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "lvariable_hmix": 1}, {}, 10),
@@ -61,7 +63,7 @@ def test_land_elimination_is_bitwise_invisible(pkg, monkeypatch, name, kw, env, 
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("name,kw,env,nsteps", [CASES[0], CASES[3], CASES[5]])
+@pytest.mark.parametrize("name,kw,env,nsteps", [CASES[0], CASES[3], CASES[7]])
 def test_phases_match_oracle_with_land_elimination_active(pkg, orclib_built, monkeypatch, name, kw, env, nsteps):
     """the oracle computes every cell; steps 5.. run with land tiles skipped and are compared on every cell, ghosts included"""
     cfg = named_config(name, **kw)

@@ -135,6 +135,7 @@ _SKIP = {"POP_LAND_FULL_STEPS": "0"}
     (2, "block_size_x=528", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "native"),
     (4, "block_size_x=528,vmix_choice=3", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "native"),
     (2, "block_size_x=1056,solver_choice=2", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1"), "native"),
+    (2, "block_size_x=528,solver_choice=3", _SKIP, "native"),                                       # P-CSI: r' of skipped chunks stays 0 in the messages
 ])
 def test_land_elimination_across_ranks(nranks, kw, env, transport):
     """(see the comment above the parameter list)"""
