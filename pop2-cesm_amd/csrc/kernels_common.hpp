@@ -59,11 +59,22 @@ __host__ __device__ inline int lds_grid_x(int lds_order, int ntx, int nty) {
   const int nt = ntx * nty;
   return lds_order ? 256 * ((nt + 255) / 256) : nt;
 }
+// position in the launch (blockIdx.x) of the a-th tile of the patch-major numbering: runs of 32 consecutive numbers go to one
+// XCD (workgroup w runs on XCD w % 8)
+__host__ __device__ inline int lds_slot_of(int a) {
+  const int r = a >> 5, t = a & 31;
+  return (((r >> 3) << 5) + t) * 8 + (r & 7);
+}
+// tile gi of the patch-major numbering
+__host__ __device__ inline bool lds_tile_from_gi(int gi, int ntx, int nty, int &ti, int &tj);
 __host__ __device__ inline bool lds_tile_of(int lds_order, int bx, int ntx, int nty, int &ti, int &tj) {
   if (!lds_order) { ti = bx % ntx; tj = bx / ntx; return tj < nty; }
-  constexpr int PW = 4, PH = 8;
   const int e = bx & 7, s = bx >> 3;
   const int gi = ((s >> 5) * 8 + e) * 32 + (s & 31);
+  return lds_tile_from_gi(gi, ntx, nty, ti, tj);
+}
+__host__ __device__ inline bool lds_tile_from_gi(int gi, int ntx, int nty, int &ti, int &tj) {
+  constexpr int PW = 4, PH = 8;
   if (gi >= ntx * nty) return false;
   const int row_tiles = PH * ntx, full_rows = nty / PH;
   int Pj, r, h;
@@ -182,7 +193,8 @@ __device__ __forceinline__ int red_cell(const DevGrid &g) {
 // nearer the edge are packed for / advanced on behalf of other ranks by the same kernels, which a skipped workgroup would not do)
 __device__ __forceinline__ bool red_land(const DevGrid &g, bool deep = false) {
   if (!g.skip || (blockIdx.x == 0 && blockIdx.y == 0)) return false;
-  if (g.red_act) return (int)blockIdx.x >= g.red_cnt[blockIdx.y];   // compacted launch: the list is sorted, land chunks only pad it
+  if (g.red_act)   // compacted launch: entry w = (x % 8) * (red_nact / 8) + x / 8 of the sorted sequence, which land chunks only pad
+    return (int)((blockIdx.x & 7) * (g.red_nact >> 3) + (blockIdx.x >> 3)) >= g.red_cnt[blockIdx.y];
   int i0, i1, j0, j1;   // inclusive, 0-based
   if (g.red_tiles) {
     const TileId t = tile_of_block(g.nxb, g.nyb, 64, 4);
