@@ -1570,10 +1570,12 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     c->trc_lds_rows = (h.n2 * h.nblocks > (1u << 19)) ? 4 : 8;
     if (getenv("POP_TRACER_LDS")) c->trc_lds_rows = atoi(getenv("POP_TRACER_LDS"));
     c->reg_thomas = getenv("POP_GENERIC_THOMAS") == nullptr;
-    // tracer solve: the register kernel (1 wave/SIMD, deep load batches) wins while the launch is
-    // latency-bound (gx1v7: 0.19 vs 0.30 ms); on bandwidth-bound grids the generic march is faster
-    // (tx0.1v3: 9.9 vs 11.6 ms).  The velocity solve is faster in registers at both sizes.
-    c->reg_thomas_t = c->reg_thomas && (h.n2 * h.nblocks <= (1u << 19));
+    // tracer solve: the register kernel keeps the elimination coefficients of a column in VGPRs instead of writing them to
+    // scratch fields and reading them back (the generic corrector moves 46 GB at the L2 for 19 GB of algorithmic traffic).
+    // gx1v7: 0.19 vs 0.30 ms.  tx0.1v3: round 1 measured the generic march faster for the predictor (9.9 vs 11.6 ms, whole
+    // grid); with land elimination the register form wins for both (same box, A/B twice: corrector 6.3 vs 8.1-8.6 ms,
+    // predictor 7.2 vs 7.5-8.1, step -1.2 .. -1.6 ms).  The velocity solve is faster in registers at both sizes.
+    c->reg_thomas_t = c->reg_thomas;
     if (getenv("POP_REG_THOMAS_T")) c->reg_thomas_t = atoi(getenv("POP_REG_THOMAS_T")) != 0;
     c->force_presum = getenv("POP_SOLVER_PRESUM") != nullptr;
     c->fpcg_one_cell = getenv("POP_FPCG_B2") && atoi(getenv("POP_FPCG_B2")) == 0;
