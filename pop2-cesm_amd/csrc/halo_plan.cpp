@@ -82,15 +82,16 @@ void build_halo_plan(HostModel &h) {
     if (!global && top_owner != h.rank) continue;
     const int nx = c.nx_global, ny = c.ny_global;
     auto cell_of = [&](int gi, int gj) { int sb, cell; source(gi, gj, sb, cell); return (global ? sb : h.block_local[sb]) * (int)h.n2 + cell; };
-    for (int loc = 0; loc < 4; ++loc) {
-      TripolePlan &T = global ? P.tripole_g[loc] : P.tripole[loc];
+    for (int lc = 0; lc < 5; ++lc) {
+      const int loc = lc == 4 ? 2 : lc;          // [4] = N face without the degenerate row
+      TripolePlan &T = global ? P.tripole_g[lc] : P.tripole[lc];
       const int ioff = (loc == 1 || loc == 3) ? 1 : 0, joff = (loc == 1 || loc == 2) ? 1 : 0;
       for (int n = 0; n < h.nblocks_tot; ++n) {
         const BlockInfo &B = h.all_blocks[n];
         if (!(B.j_glob[B.je] < 0)) continue;                 // j_glob of local row je+1 (0-based index je)
         const int dl = global ? n : h.block_local[n];
         for (int jn = 0; jn <= NGHOST; ++jn) {               // jn = 0: top physical row
-          if (jn == 0 && !joff) continue;
+          if (jn == 0 && (!joff || lc == 4)) continue;
           const int gj = ny + 1 - jn - joff;                 // source row
           for (int i = 1; i <= h.nxb; ++i) {
             const int ig = B.i_glob[i - 1];

@@ -107,7 +107,7 @@ struct pop_ctx {
   hipEvent_t ev_sa = nullptr, ev_sx = nullptr;            // solver: z packed (launch stream) / z received (side stream)
   long long solver_ops = 0, solver_enq = 0;               // stream operations / iterations enqueued by the last distributed solve (incl. look-ahead)
   // tripole northern boundary, per field location (single rank)
-  int *tp_dst[4] = {}, *tp_a[4] = {}, *tp_b[4] = {}; int tp_n[4] = {}; double *tp_buf = nullptr;
+  int *tp_dst[5] = {}, *tp_a[5] = {}, *tp_b[5] = {}; int tp_n[5] = {}; double *tp_buf = nullptr;
   // comm hooks
   double *sendbuf = nullptr, *recvbuf = nullptr, *redbuf = nullptr;
   long long comm_doubles = 0, red_doubles = 0;
@@ -1208,7 +1208,6 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if (cfg->vmix_choice == 3 && (cfg->lshort_wave || cfg->lcheckekmo)) return bad("KPP: lshort_wave / lcheckekmo are not built");
     if (cfg->vmix_choice == 3 && cfg->num_v_smooth_Ri < 1) return bad("KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)");
     if (!(cfg->convergence_criterion >= 0.0)) return bad("convergence_criterion must be >= 0");
-    if (cfg->ns_boundary == 2 && cfg->tadvect == 3) return bad("lw_lim advection on a tripole decomposition is not built");
   }
   const int hb = host_build(c->h);
   c->h.gin = nullptr;
@@ -1467,7 +1466,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   }
   if (cfg->ns_boundary == 2) {   // tripole plan (non-empty on the rank that owns the top row of blocks) + evaluation buffer
     size_t nmax = 1;
-    for (int loc = 0; loc < 4; ++loc) {
+    for (int loc = 0; loc < 5; ++loc) {
       const TripolePlan &T = h.halo.tripole[loc];
       c->tp_n[loc] = (int)T.dst.size();
       nmax = std::max(nmax, T.dst.size());
@@ -2006,7 +2005,11 @@ static int phase_advt_lw_lim(pop_ctx *c) {
   const int km = c->g.km;
   const double *X0 = c->TR[0][c->mixt], *X1 = c->TR[1][c->mixt];
   hipLaunchKernelGGL(k_lw_flux, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, c->lw, (const double *)c->U[c->curt], (const double *)c->V[c->curt], (const double *)c->DH);
-  if (halo_update_many(c, {{c->lw.UTE, km}, {c->lw.VTN, km}, {c->lw.WTKB, km}})) return 1;
+  // UTE: E face, vector; WTKB: centre (comp_flux_vel_ghost :1080-1100).  VTN is not exchanged by the reference: it forms it in
+  // the ghost rows from the ghost velocities.  Beyond a tripole fold those are the mirrored velocities with the sign of a
+  // vector, so the N-face mirror of VTN with that sign is the same number (the two products are added in the other order);
+  // the degenerate top row stays as computed (location 4: N face, ghost rows only).
+  if (halo_update_many(c, {{c->lw.UTE, km, 3, 1}, {c->lw.VTN, km, 4, 1}, {c->lw.WTKB, km}})) return 1;
   const dim3 G3((c->g.n2 + 255) / 256, km, c->g.nblocks * 2);
   hipLaunchKernelGGL(k_lw_z, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
   hipLaunchKernelGGL(k_lw_x, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);

@@ -44,8 +44,9 @@ struct HaloPlan {
   std::vector<int> fill_dst;            // ghosts outside closed boundaries / padding: fill value
   std::vector<PeerPlan> peers;
   long long max_msg_cells = 0;          // sum over peers of max(send, recv) cells
-  TripolePlan tripole[4];               // by location: 0 centre, 1 NE corner, 2 N face, 3 E face (ns_boundary = 2); cells numbered over the rank's blocks
-  TripolePlan tripole_g[4];             // the same with cells numbered over ALL blocks (host set-up arrays)
+  TripolePlan tripole[5];               // by location: 0 centre, 1 NE corner, 2 N face, 3 E face (ns_boundary = 2); cells numbered over the rank's blocks.
+                                        // [4]: N face, ghost rows only (no symmetrised top row): fields the reference forms locally in the ghost rows
+  TripolePlan tripole_g[5];             // the same with cells numbered over ALL blocks (host set-up arrays)
   bool tripole_split = false;           // the top row of blocks has more than one owner: no plan
 };
 
