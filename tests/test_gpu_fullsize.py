@@ -70,3 +70,27 @@ def test_tx01v3_full_size_properties(pkg, orclib_built, kw):
     assert it2 == iters
     assert np.array_equal(psurf, m2.get("PSURF", 1))
     m2.close()
+
+
+def test_tx01v3_land_elimination_is_invisible(pkg, monkeypatch):
+    """the benchmark configuration itself: seven steps (four write the land values, three run with the workgroups without ocean
+    left out, the solver and stencil kernels on their compacted lists) against seven steps with every workgroup -- same
+    iteration counts, same surface pressure and surface fields bit for bit, land and ghost cells included"""
+    cfg = named_config("tx0.1v3")
+    out = []
+    for skip in ("0", "1"):
+        monkeypatch.setenv("POP_LAND_SKIP", skip)
+        m = pkg.PopModel(cfg)
+        iters = []
+        for _ in range(7):
+            m.step(); iters.append(m.solver_diagnostics())
+        assert m.dim("land_skip_active") == int(skip)
+        if skip == "1":
+            assert 0.3 < m.scalar("land_tile_fraction") < 0.4
+        out.append((iters, m.get("PSURF", 1).copy(), m.get("UBTROP", 1).copy(), m.get("TRACER", 1, 0)[:, 0].copy(), m.get("UVEL", 1)[:, 3].copy(),
+                    m.get("RHO", 1)[:, cfg.km - 1].copy(), m.get("HBLT").copy()))
+        m.close()
+    a, b = out
+    assert a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
