@@ -57,7 +57,9 @@ typedef struct pop_config {
                                * 1957-1985), 1 stepped bathymetry KMT = 3 ... km (test extension, not in the reference);
                                * [4] = distribution of the blocks over ranks (distribution_type, domain.F90): 0 contiguous runs of
                                * equal block counts ('cartesian' for one column of blocks), 1 contiguous runs of equal ocean
-                               * columns (load-balanced, in the spirit of 'rake' / 'spacecurve', distribution.F90) */
+                               * columns (load-balanced, in the spirit of 'rake' / 'spacecurve', distribution.F90);
+                               * [5] = 1: the diagnostic mixed-layer depths of vmix_coeffs_kpp every step (HMXL, HMXL_DR,
+                               * vmix_kpp.F90:1310-1418; fields "HMXL", "HMXL_DR"); 0: not computed (nothing on the path reads them) */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;

@@ -42,7 +42,7 @@ struct orc_model {
   /* work fields */
   double *DH, *DHU, *ZX, *ZY, *UH, *VH, *RHS;
   double *VDC[2], *VVC, *KPP_SRC[8];   /* VDC: (nx,ny,0:km+1) per tracer class */
-  double *HBLT, *HMXL; int *KBL;
+  double *HBLT, *HMXL, *HMXL_DR; int *KBL;
   /* time stepping */
   double dtt, dtu, dtp, c2dtu, c2dtp, beta;
   int first_step, leapfrogts, f_euler_ts, avg_ts, nsteps_total, nsteps_this_interval, nsteps_per_interval;

@@ -14,7 +14,7 @@
 // Selections: no tidal / near-inertial-wave / Langmuir mixing, no short-wave penetration
 // (lshort_wave=.false.), lcheckekmo=.false., SMFT available, no partial bottom cells.
 // Integer powers use the usual expansion x**3=(x*x)*x, x**4=(x*x)*(x*x).
-// Diagnostic-only outputs of the reference routine (HMXL, HMXL_DR, tavg fields) are not computed.
+// Diagnostic outputs HMXL, HMXL_DR: k_kpp_hmxl, with pop_config reserved_i[5] = 1; tavg fields are not computed.
 #pragma once
 
 namespace pop {
@@ -819,6 +819,51 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
 
 // ---- VVC = tgrid_to_ugrid(VISC) masked by k < KMU; VVC(km) = 0.  3-D parallel ---------------
 #define POP_VVC_KC 8   // levels per thread: the four averaging weights and KMU are loaded once per chunk
+// ---- diagnostic mixed-layer depths (vmix_kpp.F90:1310-1418; pop_config reserved_i[5] = 1): HMXL, the depth of the maximum
+// buoyancy gradient, and HMXL_DR, the depth where the potential density exceeds its surface value by 3e-5 g/cm^3.  Every cell
+// of the block, as the reference's whole-array statements (T, S are 0 below the bottom and on land there too).
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_hmxl(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S, const double *__restrict__ DBSFC,
+           double *__restrict__ HMXL, double *__restrict__ HMXL_DR) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int km = g.km, kmt = g.KMT[c.q2];
+  const long long n2 = g.n2;
+  double ustar = 0.0, hmxl = (kmt == 1) ? g.zt[1] : 0.0;
+  for (int k = 2; k <= km && k <= kmt; ++k) {
+    const double q = DBSFC[c.base3 + (long long)(k - 1) * n2] / g.zt[k];
+    ustar = (q > ustar) ? q : ustar;
+    hmxl = g.zt[k];
+  }
+  double gm1 = 0.0, dbm1 = DBSFC[c.base3];
+  for (int k = 2; k <= km; ++k) {
+    const double db = DBSFC[c.base3 + (long long)(k - 1) * n2];
+    const double v = (ustar > 0.0) ? (db - dbm1) / (g.zt[k] - g.zt[k - 1]) : 0.0;
+    if (v >= ustar && (v - gm1) != 0.0 && ustar > 0.0) {
+      const double bf = (v - ustar) / (v - gm1);
+      hmxl = -0.5 * (kp.zgrid[k] + kp.zgrid[k - 1]) * (1.0 - bf) - 0.5 * (kp.zgrid[k - 1] + kp.zgrid[k - 2]) * bf;
+      ustar = 0.0;
+    }
+    gm1 = v; dbm1 = db;
+  }
+  HMXL[c.q2] = hmxl;
+  const MwjfP P1 = mwjf_level(g.pressz[1]);
+  const double rho1 = mwjf_rho<false>(P1, tmask(T[c.base3]), S[c.base3], nullptr, nullptr);
+  const double target = rho1 + 3.0e-05;
+  double rhok = rho1, hdr = (kmt == 1) ? g.zt[1] : 0.0;
+  bool found = (kmt == 1);
+  for (int k = 1; k <= km - 1; ++k) {
+    const long long o = c.base3 + (long long)k * n2;
+    const double rkp1 = mwjf_rho<false>(P1, tmask(T[o]), S[o], nullptr, nullptr);
+    if (target > rhok && target <= rkp1 && !found) {
+      hdr = g.zt[k] + (target - rhok) * (g.zt[k + 1] - g.zt[k]) / (rkp1 - rhok + KPP_EPS);
+      found = true;
+    }
+    rhok = rkp1;
+  }
+  HMXL_DR[c.q2] = hdr;
+}
+
 __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__restrict__ VVC) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k0 = blockIdx.y * POP_VVC_KC + 1, b = blockIdx.z;
@@ -964,8 +1009,9 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                      s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
   hipLaunchKernelGGL(k_kpp_vvc, dim3((g.n2 + 255) / 256, (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(256), 0, st, g, (const double *)VISC, s.VVC);
+  if (h.c.reserved_i[5] == 1 && s.HMXL && s.HMXL_DR)
+    hipLaunchKernelGGL(k_kpp_hmxl, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], (const double *)DBSFC, s.HMXL, s.HMXL_DR);
   if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }
-  (void)h;
   return 0;
 }
 

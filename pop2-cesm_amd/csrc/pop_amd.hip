@@ -57,7 +57,7 @@ struct pop_ctx {
   double *d2t[2] = {nullptr, nullptr}, *d2u[2] = {nullptr, nullptr};
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_d2t = nullptr, ev_d2u = nullptr, ev_vmixu = nullptr;
   bool side_del4 = false, vmixu_pending = false, btrop_added = false;   // implicit vertical mixing of U,V in flight on the side stream
-  double *HBLT = nullptr, *HMXL = nullptr;
+  double *HBLT = nullptr, *HMXL = nullptr, *HMXL_DR = nullptr;
   MixDev mix{};
   // KPP look-ahead: the vertical-mixing coefficients of the NEXT step depend only on this step's curtime fields (its
   // mixtime on a leapfrog step), so pop_step computes them on a third stream beside the barotropic solver (VALU-bound
@@ -1147,6 +1147,7 @@ int resolve(pop_ctx *c, const std::string &name, int tl, int n, double **ptr, lo
   if (name == "centerWgt") return ok(c->centerWgt, a2);
   if (name == "HBLT") return ok(c->HBLT, a2);
   if (name == "HMXL") return ok(c->HMXL, a2);
+  if (name == "HMXL_DR") return ok(c->HMXL_DR, a2);
   if (name == "SMF") return ok(c->d2[n == 0 ? "SMF1" : "SMF2"], a2);
   if (name == "SMFT") return ok(c->d2[n == 0 ? "SMFT1" : "SMFT2"], a2);
   auto it = c->d2.find(name);
@@ -1200,6 +1201,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if (cfg->reserved_i[2] != 0 && cfg->reserved_i[2] != 1) return bad("preconditionerChoice (reserved_i[2]): 0 diagonal, 1 evp");
     if (cfg->reserved_i[3] != 0 && cfg->reserved_i[3] != 1) return bad("synthetic topography (reserved_i[3]): 0 flat, 1 stepped");
     if (cfg->reserved_i[4] != 0 && cfg->reserved_i[4] != 1) return bad("distribution (reserved_i[4]): 0 equal block counts, 1 balanced by ocean columns");
+    if (cfg->reserved_i[5] != 0 && cfg->reserved_i[5] != 1) return bad("KPP mixed-layer-depth diagnostics (reserved_i[5]): 0 off, 1 HMXL and HMXL_DR every step");
     if (cfg->max_iterations < 1 || cfg->convergence_check_freq < 1) return bad("max_iterations and convergence_check_freq must be >= 1");
     if (cfg->tmix_opt < 0 || cfg->tmix_opt > 3) return bad("tmix_opt: 0 none, 1 avg, 2 avgfit, 3 robert");
     if ((cfg->tmix_opt == 1 || cfg->tmix_opt == 2) && cfg->time_mix_freq < 1) return bad("time_mix_freq must be >= 1");
@@ -1391,7 +1393,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if (dev_alloc(c, &c->STF[n], a2) || dev_alloc(c, &c->TFW[n], a2) || dev_alloc(c, &c->KPP_SRC[n], a3)) return 1;
   for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->VDC[n], (size_t)(h.km + 2) * a2)) return 1;
   double **two[] = {&c->PGUESS, &c->FW, &c->FW_OLD, &c->SHF_QSW, &c->DH, &c->DHU, &c->ZX, &c->ZY, &c->UH, &c->VH, &c->W3, &c->W4, &c->RHS,
-                    &c->R, &c->S0, &c->S1, &c->Q, &c->Z, &c->AZ, &c->HBLT, &c->HMXL};
+                    &c->R, &c->S0, &c->S1, &c->Q, &c->Z, &c->AZ, &c->HBLT, &c->HMXL, &c->HMXL_DR};
   for (auto p : two) if (dev_alloc(c, p, a2)) return 1;
   c->centerWgt = c->d2["centerWgt"];
   double **three[] = {&c->VVC, &c->E3, &c->F3, &c->S3a, &c->S3b, &c->S3c, &c->S3d};
@@ -1958,7 +1960,7 @@ static MixState kpp_mix_state(pop_ctx *c, int slot, bool into_alt) {
     ms.KPP_SRC[n] = into_alt ? c->KPPa[n] : c->KPP_SRC[n]; ms.VDC[n] = into_alt ? c->VDCa[n] : c->VDC[n];
   }
   ms.UMIX = c->U[slot]; ms.VMIX = c->V[slot]; ms.UCUR = c->U[c->curt]; ms.VCUR = c->V[c->curt]; ms.RHOMIX = c->RHO[slot];
-  ms.VVC = into_alt ? c->VVCa : c->VVC; ms.SHF_QSW = c->SHF_QSW; ms.HBLT = into_alt ? c->HBLTa : c->HBLT; ms.HMXL = c->HMXL;
+  ms.VVC = into_alt ? c->VVCa : c->VVC; ms.SHF_QSW = c->SHF_QSW; ms.HBLT = into_alt ? c->HBLTa : c->HBLT; ms.HMXL = c->HMXL; ms.HMXL_DR = c->HMXL_DR;
   ms.S3a = c->S3a; ms.S3b = c->S3b; ms.S3c = c->S3c; ms.S3d = c->S3d; ms.E3 = c->E3; ms.F3 = c->F3;
   return ms;
 }
@@ -1987,7 +1989,8 @@ static int phase_vmix(pop_ctx *c) {
 // next step; outputs: the second set of VDC / VVC / KPP_SRC / HBLT.
 static int kpp_look_ahead(pop_ctx *c) {
   // an averaging step rewrites oldtime and curtime in its tail and does not rotate; the Robert filter rewrites curtime
-  if (!c->ahead_enabled || c->h.c.vmix_choice != 3 || c->avg_ts || c->h.c.tmix_opt == 3) return 0;
+  // (with the mixed-layer-depth diagnostics on, HMXL / HMXL_DR must belong to the step that just ran: no look-ahead)
+  if (!c->ahead_enabled || c->h.c.vmix_choice != 3 || c->avg_ts || c->h.c.tmix_opt == 3 || c->h.c.reserved_i[5] == 1) return 0;
   HIPCHK(c, hipEventRecord(c->ev_ahead_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->ahead, c->ev_ahead_fork, 0));
   const MixState ms = kpp_mix_state(c, c->curt, true);

@@ -69,6 +69,8 @@ def _apply(c, kw):
             c.reserved_i[3] = v
         elif k == "distribution":      # 0 equal block counts per rank, 1 balanced by ocean columns
             c.reserved_i[4] = v
+        elif k == "kpp_diagnostics":   # 1: HMXL, HMXL_DR every step
+            c.reserved_i[5] = v
         elif k == "robert_alpha":
             c.reserved_d[1] = v
         elif k == "robert_nu":

@@ -227,6 +227,28 @@ def test_grid_input_step_phases_match_oracle(pkg, orclib_built, monkeypatch, kw,
     gpu.close(); orc.close()
 
 
+@pytest.mark.parametrize("name,kw", [("tiny", {"km": 24}), ("tiny", {"km": 24, "stepped_bathymetry": 1, "ldbl_diff": 1}), ("gx3v7", {})])
+def test_kpp_mixed_layer_depth_diagnostics(pkg, orclib_built, name, kw):
+    """HMXL (depth of the maximum buoyancy gradient) and HMXL_DR (0.03 kg/m^3 density criterion), vmix_kpp.F90:1310-1418,
+    computed every step when reserved_i[5] = 1: every cell of every block against the oracle"""
+    cfg = named_config(name, vmix_choice=3, kpp_diagnostics=1, **kw)
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    force_kpp_case(gpu, orc)
+    tol = TOL_LOCAL
+    for s in range(1, 4):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+        for f in ("HMXL", "HMXL_DR"):
+            a, b = gpu.get(f), orc.f2(f)
+            assert np.abs(b).max() > 1.0e3 and len(np.unique(np.round(b, 3))) > 20, f + ": trivial field"
+            assert relerr(a, b) <= tol * 100, "%s step %d: %g" % (f, s, relerr(a, b))
+    gpu.close(); orc.close()
+    off = pkg.PopModel(named_config(name, vmix_choice=3, **kw))
+    off.step()
+    assert not off.get("HMXL").any()          # not computed unless asked for
+    off.close()
+
+
 def test_tripole_without_grid_input_refuses_to_step(pkg):
     m = pkg.PopModel(named_config("tiny", ns_boundary=2))
     with pytest.raises(pkg.PopError, match="pop_create_with_grid"):
