@@ -49,7 +49,7 @@ typedef struct pop_config {
   int time_mix_freq;
   int steps_per_day;          /* dt_option='steps_per_day', dt_count */
   int lbouss_correct, lpressure_avg, impcor, reset_to_freezing;
-  int lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri; /* vmix_kpp_nml */
+  int lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri; /* vmix_kpp_nml (lshort_wave reads SHF_QSW: pop_set_field) */
   int reserved_i[8];          /* [0] = maxlanczosstep (0 = 20), [1] = convergenceCheckStart (0 = 60) for PCSI
                                * (POP_SolversMod.F90:626-640); [2] = preconditionerChoice: 0 'diagonal', 1 'evp'
                                * (:124, :252-290, :2434-2696; any solver_choice);
@@ -59,7 +59,9 @@ typedef struct pop_config {
                                * equal block counts ('cartesian' for one column of blocks), 1 contiguous runs of equal ocean
                                * columns (load-balanced, in the spirit of 'rake' / 'spacecurve', distribution.F90);
                                * [5] = 1: the diagnostic mixed-layer depths of vmix_coeffs_kpp every step (HMXL, HMXL_DR,
-                               * vmix_kpp.F90:1310-1418; fields "HMXL", "HMXL_DR"); 0: not computed (nothing on the path reads them) */
+                               * vmix_kpp.F90:1310-1418; fields "HMXL", "HMXL_DR"); 0: not computed (nothing on the path reads them);
+                               * [6] = sw_absorption_type for lshort_wave: 0 'top-layer', 1 'jerlov' (sw_absorption.F90:736-811;
+                               * 'chlorophyll' is not built), [7] = jerlov_water_type 1..5 (0 = 3, the CESM default) */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;

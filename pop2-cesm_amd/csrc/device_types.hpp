@@ -16,7 +16,7 @@ struct DevGrid {
   int n2;                                          // nxb*nyb
   long long n3;                                    // n2*km
   const double *dz, *dzw, *zt, *zw, *c2dz, *dzr, *dz2r, *dzwr, *pressz, *bouss, *afac_t, *afac_u;
-  const double *DXU, *DYU, *DXUR, *DYUR, *UAREA_R, *TAREA_R, *TAREA, *FCOR, *HU, *HUR;
+  const double *DXU, *DYU, *DXUR, *DYUR, *UAREA_R, *TAREA_R, *TAREA, *FCOR, *FCORT, *HU, *HUR;
   const double *AU0, *AUN, *AUE, *AUNE, *RCALCT;
   const int *KMT, *KMU, *KMTN, *KMTS, *KMTE, *KMTW, *KMTEE, *KMTNN;
   const double *DTN, *DTS, *DTE, *DTW;

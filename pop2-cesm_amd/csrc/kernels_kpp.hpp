@@ -26,6 +26,10 @@ struct KppDev {
   int *KBL0, *KBL;
   double Vtc, cg, rich_mix;
   int lrich, ldbl_diff, nsmooth;
+  // vmix_kpp_nml lshort_wave (sw_absorption_type: 0 'top-layer', 1 'jerlov' with water type jerlov = 1..5), lcheckekmo
+  int lshort_wave, sw_type, jerlov, lcheckekmo;
+  const double *FCORT, *SHF_QSW;     // T-point Coriolis parameter (Ekman depth), surface short-wave flux
+  double *BO, *BOSOL;                // surface buoyancy forcing without / from the short-wave flux (lshort_wave: blmix needs both)
 };
 
 constexpr double KPP_EPSSFC = 0.1, KPP_RIINFTY = 0.8, KPP_RRHO0 = 2.55, KPP_DSFMAX = 1.0, KPP_CSTAR = 10.0;
@@ -49,6 +53,21 @@ __device__ __forceinline__ void kpp_wscale(double sigma, double hbl, double usta
 }
 
 __device__ __forceinline__ double tmask(double t) { return (t < -2.0) ? -2.0 : t; }
+constexpr double KPP_CEKMAN = 0.7, KPP_CMONOB = 1.0;
+// sw_absorb_frac (sw_absorption.F90:736-811): share of the surface short-wave flux that reaches `depth` (cm) in Jerlov water
+// type jt = 1..5 (two exponentials, Simpson and Paulson 1977; zero below 200 m)
+__device__ __forceinline__ double kpp_sw_absorb_frac(double depth, int jt) {
+  const double rfac[5] = {0.58, 0.62, 0.67, 0.77, 0.78}, depth1[5] = {0.35, 0.60, 1.00, 1.50, 1.40}, depth2[5] = {23.0, 20.0, 17.0, 14.0, 7.90};
+  const double dm = -depth * 0.01;
+  if (dm < -200.0) return 0.0;
+  return rfac[jt - 1] * exp(dm / depth1[jt - 1]) + (1.0 - rfac[jt - 1]) * exp(dm / depth2[jt - 1]);
+}
+// surface buoyancy forcing with the radiative contribution down to `depth` (vmix_kpp.F90:2236-2256, 2387-2412, 2707-2742)
+__device__ __forceinline__ double kpp_bfsfc(const KppDev &kp, double bo, double bosol, double depth) {
+  if (!kp.lshort_wave) return bo;
+  if (kp.sw_type == 0) return bo + bosol;
+  return bo + bosol * (1.0 - kpp_sw_absorb_frac(depth, kp.jerlov));
+}
 
 // ---- buoydiff: 3-D parallel, one thread per (i,j,k); level k yields DBSFC(k) and DBLOC(k-1) ------
 __global__ void __launch_bounds__(256)
@@ -658,21 +677,43 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
   double talpha, sbeta;
   const MwjfP P1 = mwjf_level(g.pressz[1]);
   const double rho1 = mwjf_rho<true>(P1, tmask(T[c.base3]), S[c.base3], &talpha, &sbeta);
-  double bo = 0.0;
-  if (rho1 != 0.0) bo = GRAV * (-talpha * STF1[c.q2] - sbeta * STF2[c.q2]) / rho1;
+  double bo = 0.0, bosol = 0.0;
+  if (rho1 != 0.0) {
+    bo = GRAV * (-talpha * STF1[c.q2] - sbeta * STF2[c.q2]) / rho1;
+    if (kp.lshort_wave) bosol = -GRAV * talpha * kp.SHF_QSW[c.q2] / rho1;
+  }
   int kbl = (kmt > 1) ? kmt : 1;
   double hblt = -kp.zgrid[kbl];
   double rib_upper = 0.0, rib_up = 0.0, z_upper = 0.0, z_up = kp.zgrid[1];
   double bfsfc = bo;
+  // lcheckekmo (:2231-2265): Ekman and Monin-Obukhov depth limits under stable forcing; hmon_up / hmon_dn rotate like rib_*
+  double hekman = 0.0, hlimit = 0.0, hmon_up = 0.0;
+  if (kp.lcheckekmo) {
+    hekman = -kp.zgrid[km] + KPP_EPS; hlimit = -kp.zgrid[km] + KPP_EPS;
+    double bf = kpp_bfsfc(kp, bo, bosol, -z_up);
+    const double st = (bf >= 0.0) ? 1.0 : 0.0;
+    bf = bf + st * KPP_EPS;
+    const double w = st * KPP_CMONOB * ustar * ustar * ustar / KPP_VONKAR / bf + (st - 1.0) * kp.zgrid[km];
+    hmon_up = (w <= -z_up) ? -z_up + KPP_EPS : w;
+  }
   for (int kl = 2; kl <= km; ++kl) {
     const long long o = c.base3 + (long long)(kl - 1) * n2;
     const double surfthick = KPP_EPSSFC * g.zt[kl];
     const double zkl = -kp.zgrid[kl];
     double vshear = 0.0;
     if (!edge) vshear = fmax(fmax(WU[o], WU[o - 1]), fmax(WU[o - nxb], WU[o - 1 - nxb]));
-    bfsfc = bo;
+    bfsfc = kpp_bfsfc(kp, bo, bosol, zkl);
     const double stable = (bfsfc >= 0.0) ? 1.0 : 0.0;
     bfsfc = bfsfc + stable * KPP_EPS;
+    if (kp.lcheckekmo) {   // :2426-2455
+      if (stable > 0.5 && hekman >= -kp.zgrid[km]) hekman = fmax(zkl, KPP_CEKMAN * ustar / (fabs(kp.FCORT[c.q2]) + KPP_EPS));
+      const double hmon_dn = stable * KPP_CMONOB * ustar * ustar * ustar / KPP_VONKAR / bfsfc + (stable - 1.0) * kp.zgrid[km];
+      if (hmon_dn <= zkl && hmon_up > -z_up) {
+        const double w = (hmon_dn - hmon_up) / (z_up + zkl);
+        hlimit = (hmon_dn - w * zkl) / (1.0 - w);
+      }
+      hmon_up = hmon_dn;
+    }
     double wm_unused = 0.0, ws;
     kpp_wscale<false>(KPP_EPSSFC, zkl, ustar, bfsfc, wm_unused, ws);
     const double db = DBLOC[o];
@@ -696,10 +737,16 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
     rib_upper = rib_up; rib_up = rib_dn;
     z_upper = z_up; z_up = kp.zgrid[kl];
   }
+  if (kp.lcheckekmo) {   // :2676-2690; the reference tests against ZKL of the last pass of the march, -zgrid(km)
+    if (hekman < hlimit) hlimit = hekman;
+    for (int kl = 2; kl <= km; ++kl)
+      if (hlimit < hblt && hlimit > -kp.zgrid[kl - 1] && hlimit <= -kp.zgrid[km]) { hblt = hlimit; kbl = kl; }
+  }
   kp.HBLT0[c.q2] = hblt;
   kp.KBL0[c.q2] = kbl;
   kp.USTAR[c.q2] = ustar;
   kp.BFSFC[c.q2] = bfsfc;    // value of the last kl pass (vmix_kpp.F90: no short-wave branch)
+  if (kp.lshort_wave) { kp.BO[c.q2] = bo; kp.BOSOL[c.q2] = bosol; }
 }
 
 // ---- smooth_hblt + blmix + interior convection + masks + non-local source -------------------
@@ -734,6 +781,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
   kp.KBL[c.q2] = kbl;
   const double ustar = kp.USTAR[c.q2];
   double bfsfc = kp.BFSFC[c.q2];
+  if (kp.lshort_wave) bfsfc = kpp_bfsfc(kp, kp.BO[c.q2], kp.BOSOL[c.q2], hblt);   // forcing down to the boundary layer depth (:2707-2742)
   const double stable = (bfsfc >= 0.0) ? 1.0 : 0.0;
   bfsfc = bfsfc + stable * KPP_EPS;
   // blmix: matching at the boundary-layer base
@@ -902,7 +950,8 @@ inline void kpp_destroy(MixDev &m) {
 
 inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<void *> &allocs, std::string &err) {
   const pop_config &c = h.c;
-  if (c.lshort_wave || c.lcheckekmo) { err = "KPP: lshort_wave / lcheckekmo are not supported"; return 1; }
+  if (c.lshort_wave && c.reserved_i[6] != 0 && c.reserved_i[6] != 1) { err = "KPP: sw_absorption_type (reserved_i[6]): 0 top-layer, 1 jerlov; chlorophyll is not built"; return 1; }
+  if (c.reserved_i[7] < 0 || c.reserved_i[7] > 5) { err = "KPP: jerlov_water_type (reserved_i[7]): 1..5 (0 = 3)"; return 1; }
   if (c.num_v_smooth_Ri < 1) { err = "KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)"; return 1; }
   const int km = h.km;
   std::vector<double> zgrid(km + 3, 0.0), hwide(km + 3, 0.0), bvdc(km + 3, 0.0), bvvc(km + 3, 0.0);
@@ -948,6 +997,11 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   k.Vtc = std::sqrt(0.2 / KPP_C_S / KPP_EPSSFC) / (KPP_VONKAR * KPP_VONKAR);
   k.cg = KPP_CSTAR * KPP_VONKAR * std::pow(KPP_C_S * KPP_VONKAR * KPP_EPSSFC, 1.0 / 3.0);
   k.rich_mix = c.kpp_rich_mix; k.lrich = c.lrich; k.ldbl_diff = c.ldbl_diff; k.nsmooth = c.num_v_smooth_Ri;
+  k.lshort_wave = c.lshort_wave ? 1 : 0; k.sw_type = c.reserved_i[6]; k.jerlov = c.reserved_i[7] ? c.reserved_i[7] : 3; k.lcheckekmo = c.lcheckekmo ? 1 : 0;
+  if (k.lshort_wave) {
+    if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.BO = (double *)p;
+    if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.BOSOL = (double *)p;
+  }
   K->max_kref = 1;
   for (int kk = 1; kk <= km; ++kk) K->max_kref = std::max(K->max_kref, kref[kk]);
   // column (register) forms: bandwidth-bound grids only -- below ~2^19 columns the 3-D-parallel forms win on
@@ -964,7 +1018,8 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
 inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParams &sp, const MixDev &m, const MixState &s,
                            hipStream_t st, std::string &err) {
   const KppHost &KH = *(const KppHost *)m.kpp;
-  const KppDev &g_kpp = KH.dev;
+  KppDev g_kpp = KH.dev;
+  g_kpp.SHF_QSW = s.SHF_QSW; g_kpp.FCORT = g.FCORT;
   const int g_kpp_col = KH.col;
   const dim3 GC(col_grid(g, POP_COL_THREADS), g.nblocks), BC(POP_COL_THREADS);
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);

@@ -1207,7 +1207,8 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if ((cfg->tmix_opt == 1 || cfg->tmix_opt == 2) && cfg->time_mix_freq < 1) return bad("time_mix_freq must be >= 1");
     if (cfg->steps_per_day < 1) return bad("steps_per_day must be >= 1");
     if (cfg->aidif != 1.0) return bad("aidif: only the fully implicit vertical mixing (aidif = 1) is built");
-    if (cfg->vmix_choice == 3 && (cfg->lshort_wave || cfg->lcheckekmo)) return bad("KPP: lshort_wave / lcheckekmo are not built");
+    if (cfg->vmix_choice == 3 && cfg->lshort_wave && cfg->reserved_i[6] != 0 && cfg->reserved_i[6] != 1) return bad("KPP lshort_wave: sw_absorption_type (reserved_i[6]) 0 top-layer, 1 jerlov; chlorophyll is not built");
+    if (cfg->reserved_i[7] < 0 || cfg->reserved_i[7] > 5) return bad("jerlov_water_type (reserved_i[7]): 1..5 (0 = 3)");
     if (cfg->vmix_choice == 3 && cfg->num_v_smooth_Ri < 1) return bad("KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)");
     if (!(cfg->convergence_criterion >= 0.0)) return bad("convergence_criterion must be >= 0");
   }
@@ -1268,7 +1269,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   }
   for (auto &kv : h.i2) { auto loc = local_part(h, kv.second); int *p; if (dev_upload(c, &p, loc.data(), loc.size())) return 1; c->di2[kv.first] = p; }
 #define G2(f) g.f = c->d2[#f]
-  G2(DXU); G2(DYU); G2(DXUR); G2(DYUR); G2(UAREA_R); G2(TAREA_R); G2(TAREA); G2(FCOR); G2(HU); G2(HUR);
+  G2(DXU); G2(DYU); G2(DXUR); G2(DYUR); G2(UAREA_R); G2(TAREA_R); G2(TAREA); G2(FCOR); G2(FCORT); G2(HU); G2(HUR);
   G2(AU0); G2(AUN); G2(AUE); G2(AUNE); G2(RCALCT); G2(DTN); G2(DTS); G2(DTE); G2(DTW);
   G2(DUC); G2(DUN); G2(DUS); G2(DUE); G2(DUW); G2(DMC); G2(DMN); G2(DMS); G2(DME); G2(DMW); G2(DUM); G2(KXU); G2(KYU);
   {   // byte copy of the solver mask (RCALCT: exactly 0 or 1, POP_SolversMod.F90:886)

@@ -71,6 +71,10 @@ def _apply(c, kw):
             c.reserved_i[4] = v
         elif k == "kpp_diagnostics":   # 1: HMXL, HMXL_DR every step
             c.reserved_i[5] = v
+        elif k == "sw_absorption_type":   # lshort_wave: 0 top-layer, 1 jerlov
+            c.reserved_i[6] = v
+        elif k == "jerlov_water_type":
+            c.reserved_i[7] = v
         elif k == "robert_alpha":
             c.reserved_d[1] = v
         elif k == "robert_nu":

@@ -249,6 +249,49 @@ def test_kpp_mixed_layer_depth_diagnostics(pkg, orclib_built, name, kw):
     off.close()
 
 
+@pytest.mark.parametrize("kw", [
+    {"lshort_wave": 1},                                        # sw_absorption_type 'top-layer': BFSFC = BO + BOSOL
+    {"lshort_wave": 1, "sw_absorption_type": 1},                # 'jerlov', water type IB (the CESM default 3)
+    {"lshort_wave": 1, "sw_absorption_type": 1, "jerlov_water_type": 5, "ldbl_diff": 1, "stepped_bathymetry": 1},
+    {"lcheckekmo": 1},                                         # Ekman / Monin-Obukhov depth limits under stable forcing
+    {"lcheckekmo": 1, "lshort_wave": 1, "sw_absorption_type": 1, "block_size_x": 48, "block_size_y": 40},
+])
+def test_kpp_short_wave_and_depth_limits(pkg, orclib_built, kw):
+    """vmix_kpp_nml lshort_wave (bldepth :2236-2256, :2387-2412, :2707-2742 with sw_absorb_frac, sw_absorption.F90:736-811) and
+    lcheckekmo (:2231-2265, :2426-2455, :2676-2690): phase parity with a short-wave flux that varies with latitude; the options
+    must also change the boundary layer depth (so the branches are live)"""
+    cfg = named_config("tiny", vmix_choice=3, km=24, **kw)
+    ref = named_config("tiny", vmix_choice=3, km=24, **{k: v for k, v in kw.items() if k in ("ldbl_diff", "stepped_bathymetry", "block_size_x", "block_size_y")})
+    gpu, orc, plain = pkg.PopModel(cfg), Oracle(cfg), pkg.PopModel(ref)
+    force_kpp_case(gpu, orc)
+    tlat = orc.f2("TLAT")
+    qsw = 5.0e-3 * (1.0 + np.cos(tlat))          # degC cm/s
+    orc.f2("SHF_QSW")[...] = qsw
+    gpu.set("SHF_QSW", qsw); plain.set("SHF_QSW", qsw)
+    for tl in (0, 1, 2):
+        for n in (0, 1):
+            plain.set("TRACER", orc.f3("TRACER", tl, n), tl=tl, n=n)
+    for n in (0, 1):
+        plain.set("STF", orc.f2("STF", 1, n), n=n)
+    for tl in (0, 1):
+        plain.set("RHO", orc.f3("RHO", tl), tl=tl)
+    tol = TOL_LOCAL
+    for s in range(1, 4):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+    plain.step()
+    gpu2 = pkg.PopModel(cfg)     # first step of the option against the first step without it
+    gpu.close(); orc.close()
+    hb_plain = plain.get("HBLT")
+    plain.close()
+    o2 = Oracle(cfg)
+    force_kpp_case(gpu2, o2)
+    o2.f2("SHF_QSW")[...] = qsw; gpu2.set("SHF_QSW", qsw)
+    gpu2.step()
+    assert np.abs(gpu2.get("HBLT") - hb_plain).max() > 1.0, "the option did not change the boundary layer depth"
+    gpu2.close(); o2.close()
+
+
 def test_tripole_without_grid_input_refuses_to_step(pkg):
     m = pkg.PopModel(named_config("tiny", ns_boundary=2))
     with pytest.raises(pkg.PopError, match="pop_create_with_grid"):
