@@ -79,7 +79,7 @@ struct pop_ctx {
   bool no_graph = false, fused_ok = false, replicated = false, grid_from_input = false;
   // land elimination: the first land_full_steps steps after set-up / a restart / a new state run every workgroup (they write
   // the state-independent values of the land tiles), later steps skip workgroups without an ocean cell (DevGrid::skip)
-  bool land_skip = true; int land_full_steps = 4, full_left = 4; double land_fraction = 0.0;
+  bool land_skip = true; int land_full_steps = 4, full_left = 4, full_seen = 0; double land_fraction = 0.0;
   bool fpcg_one_cell = false;   // POP_FPCG_B2=0: one cell per thread in step B of the fused pcg even on large grids
   bool force_presum = false;
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
@@ -1916,7 +1916,11 @@ int pop_read_restart(pop_ctx *c, const char *path, int flags) {
 // ---- time_manager + set_switches (time_management.F90:1823-1847, 2139-2234) ----------------
 // DevGrid::skip for the step that starts now; cached solver graphs hold the flag by value
 static void land_skip_for_step(pop_ctx *c) {
-  const int want = (c->land_skip && c->full_left == 0) ? 1 : 0;
+  // every one of the three rotating time levels must have been the `new` one in a step that ran every workgroup (averaging
+  // steps do not rotate: with a short averaging period four steps may not get round), and POP_LAND_FULL_STEPS steps at least
+  if (c->full_left == c->land_full_steps) c->full_seen = 0;      // a reset (set-up, restart, new state) starts the count again
+  const int want = (c->land_skip && c->full_left == 0 && (c->full_seen == 7 || c->land_full_steps == 0)) ? 1 : 0;
+  if (!want) c->full_seen |= 1 << c->newt;
   if (c->full_left > 0) --c->full_left;
   if (want == c->g.skip) return;
   c->g.skip = want;
