@@ -153,7 +153,7 @@ int pop_halo_update(pop_ctx *ctx, const char *name, int tl, int n);
 /* the same with the reference's fieldLoc / fieldKind arguments (POP_GridHorzMod / POP_FieldMod constants):
  * field_loc 0 centre, 1 NE corner, 2 N face, 3 E face; field_kind 0 scalar, 1 vector, 2 angle.  They matter
  * on a tripole northern boundary only (mpi/POP_HaloMod.F90:1936-2050: mirrored copy with offsets and sign,
- * symmetrised degenerate top row for NE-corner / N-face fields; single-rank decompositions). */
+ * symmetrised degenerate top row for NE-corner / N-face fields; the top row of blocks on one rank). */
 int pop_halo_update_loc(pop_ctx *ctx, const char *name, int tl, int n, int field_loc, int field_kind);
 int pop_halo_update_host_r8_loc(pop_ctx *ctx, double *array, int nz, double fill, int field_loc, int field_kind);
 int pop_halo_update_host_i4_loc(pop_ctx *ctx, int *array, int nz, int fill, int field_loc, int field_kind);
