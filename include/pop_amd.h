@@ -60,8 +60,9 @@ typedef struct pop_config {
                                * columns (load-balanced, in the spirit of 'rake' / 'spacecurve', distribution.F90);
                                * [5] = 1: the diagnostic mixed-layer depths of vmix_coeffs_kpp every step (HMXL, HMXL_DR,
                                * vmix_kpp.F90:1310-1418; fields "HMXL", "HMXL_DR"); 0: not computed (nothing on the path reads them);
-                               * [6] = sw_absorption_type for lshort_wave: 0 'top-layer', 1 'jerlov' (sw_absorption.F90:736-811;
-                               * 'chlorophyll' is not built), [7] = jerlov_water_type 1..5 (0 = 3, the CESM default) */
+                               * [6] = sw_absorption_type for lshort_wave: 0 'top-layer', 1 'jerlov' (sw_absorption.F90:736-811),
+                               * 2 'chlorophyll' (:467-728, 951-1047; the field "CHL", mg/m^3, is 0.25 until set with pop_set_field);
+                               * [7] = jerlov_water_type 1..5 (0 = 3, the CESM default) */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;

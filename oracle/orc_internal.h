@@ -38,7 +38,7 @@ struct orc_model {
   double *PGUESS, *FW, *FW_OLD;
   int oldtime, curtime, newtime, mixtime;
   /* forcing */
-  double *SMF[2], *SMFT[2], *STF[8], *TFW[8], *SHF_QSW;
+  double *SMF[2], *SMFT[2], *STF[8], *TFW[8], *SHF_QSW, *CHL;   /* CHL: chlorophyll, mg/m^3 (sw_absorption_type 'chlorophyll') */
   /* work fields */
   double *DH, *DHU, *ZX, *ZY, *UH, *VH, *RHS;
   double *VDC[2], *VVC, *KPP_SRC[8];   /* VDC: (nx,ny,0:km+1) per tracer class */

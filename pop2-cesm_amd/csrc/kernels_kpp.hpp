@@ -29,6 +29,11 @@ struct KppDev {
   // vmix_kpp_nml lshort_wave (sw_absorption_type: 0 'top-layer', 1 'jerlov' with water type jerlov = 1..5), lcheckekmo
   int lshort_wave, sw_type, jerlov, lcheckekmo;
   const double *FCORT, *SHF_QSW;     // T-point Coriolis parameter (Ekman depth), surface short-wave flux
+  // sw_absorption_type 'chlorophyll' (sw_type 2): transmission table Tr[(2 km + 1) * n + k] over the levels ztr[0 .. 2 km] and 401
+  // chlorophyll amounts (sw_absorption.F90:525-728); CHLI = column of the table per cell (set_chl :500-512, computed on the host)
+  const double *Tr, *ztr;
+  const int *CHLI;
+  int ksol;
   double *BO, *BOSOL;                // surface buoyancy forcing without / from the short-wave flux (lshort_wave: blmix needs both)
 };
 
@@ -62,10 +67,26 @@ __device__ __forceinline__ double kpp_sw_absorb_frac(double depth, int jt) {
   if (dm < -200.0) return 0.0;
   return rfac[jt - 1] * exp(dm / depth1[jt - 1]) + (1.0 - rfac[jt - 1]) * exp(dm / depth2[jt - 1]);
 }
-// surface buoyancy forcing with the radiative contribution down to `depth` (vmix_kpp.F90:2236-2256, 2387-2412, 2707-2742)
-__device__ __forceinline__ double kpp_bfsfc(const KppDev &kp, double bo, double bosol, double depth) {
+// sw_trans_chl (sw_absorption.F90:951-1047): kin > 0: transmission to level kin of ztr; kin = 0: interpolated to depth ztrans
+__device__ __forceinline__ double kpp_sw_trans_chl(const KppDev &kp, int kin, double ztrans, int idx) {
+  const double *Trn = kp.Tr + (long long)idx * (kp.ksol + 1);
+  if (kin > 0) return Trn[kin];
+  int kindx = kp.ksol - 1;
+  double w1 = 0.0, w2 = 0.0;
+  for (int k = 1; k <= kp.ksol; ++k)
+    if (kp.ztr[k - 1] <= ztrans && ztrans < kp.ztr[k]) {
+      w2 = (ztrans - kp.ztr[k - 1]) / (kp.ztr[k] - kp.ztr[k - 1]);
+      w1 = 1.0 - w2;
+      kindx = k - 1;
+    }
+  return w1 * Trn[kindx] + w2 * Trn[kindx + 1];
+}
+// surface buoyancy forcing with the radiative contribution down to `depth` (vmix_kpp.F90:2236-2256, 2387-2412, 2707-2742);
+// kin: the level of ztr that `depth` is (chlorophyll table), 0 = interpolate
+__device__ __forceinline__ double kpp_bfsfc(const KppDev &kp, double bo, double bosol, double depth, int kin, int chlidx) {
   if (!kp.lshort_wave) return bo;
   if (kp.sw_type == 0) return bo + bosol;
+  if (kp.sw_type == 2) return bo + bosol * (1.0 - kpp_sw_trans_chl(kp, kin, depth, chlidx));
   return bo + bosol * (1.0 - kpp_sw_absorb_frac(depth, kp.jerlov));
 }
 
@@ -678,6 +699,7 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
   const MwjfP P1 = mwjf_level(g.pressz[1]);
   const double rho1 = mwjf_rho<true>(P1, tmask(T[c.base3]), S[c.base3], &talpha, &sbeta);
   double bo = 0.0, bosol = 0.0;
+  const int chli = (kp.lshort_wave && kp.sw_type == 2) ? kp.CHLI[c.q2] : 0;
   if (rho1 != 0.0) {
     bo = GRAV * (-talpha * STF1[c.q2] - sbeta * STF2[c.q2]) / rho1;
     if (kp.lshort_wave) bosol = -GRAV * talpha * kp.SHF_QSW[c.q2] / rho1;
@@ -690,7 +712,7 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
   double hekman = 0.0, hlimit = 0.0, hmon_up = 0.0;
   if (kp.lcheckekmo) {
     hekman = -kp.zgrid[km] + KPP_EPS; hlimit = -kp.zgrid[km] + KPP_EPS;
-    double bf = kpp_bfsfc(kp, bo, bosol, -z_up);
+    double bf = kpp_bfsfc(kp, bo, bosol, -z_up, 1, chli);
     const double st = (bf >= 0.0) ? 1.0 : 0.0;
     bf = bf + st * KPP_EPS;
     const double w = st * KPP_CMONOB * ustar * ustar * ustar / KPP_VONKAR / bf + (st - 1.0) * kp.zgrid[km];
@@ -702,7 +724,7 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
     const double zkl = -kp.zgrid[kl];
     double vshear = 0.0;
     if (!edge) vshear = fmax(fmax(WU[o], WU[o - 1]), fmax(WU[o - nxb], WU[o - 1 - nxb]));
-    bfsfc = kpp_bfsfc(kp, bo, bosol, zkl);
+    bfsfc = kpp_bfsfc(kp, bo, bosol, zkl, 2 * kl - 1, chli);
     const double stable = (bfsfc >= 0.0) ? 1.0 : 0.0;
     bfsfc = bfsfc + stable * KPP_EPS;
     if (kp.lcheckekmo) {   // :2426-2455
@@ -781,7 +803,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
   kp.KBL[c.q2] = kbl;
   const double ustar = kp.USTAR[c.q2];
   double bfsfc = kp.BFSFC[c.q2];
-  if (kp.lshort_wave) bfsfc = kpp_bfsfc(kp, kp.BO[c.q2], kp.BOSOL[c.q2], hblt);   // forcing down to the boundary layer depth (:2707-2742)
+  if (kp.lshort_wave) bfsfc = kpp_bfsfc(kp, kp.BO[c.q2], kp.BOSOL[c.q2], hblt, 0, kp.sw_type == 2 ? kp.CHLI[c.q2] : 0);   // forcing down to the boundary layer depth (:2707-2742)
   const double stable = (bfsfc >= 0.0) ? 1.0 : 0.0;
   bfsfc = bfsfc + stable * KPP_EPS;
   // blmix: matching at the boundary-layer base
@@ -936,7 +958,7 @@ __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__
 // per-context KPP state (MixDev::kpp)
 // col: bit 0 = ushear, bit 1 = buoydiff in column form.  side / ev_*: second HIP stream on which the shear kernel (needs only
 // U, V; consumed by bldepth) runs beside buoydiff + interior (POP_KPP_SIDE_STREAM=0 keeps everything on one stream)
-struct KppHost { KppDev dev; int max_kref = 1; int col = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bd = nullptr; };
+struct KppHost { KppDev dev; double chlmin = 0, chlmax = 0, dlogchl = 0; int max_kref = 1; int col = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bd = nullptr; };
 inline void kpp_destroy(MixDev &m) {
   KppHost *k = (KppHost *)m.kpp;
   if (k) {
@@ -948,9 +970,16 @@ inline void kpp_destroy(MixDev &m) {
   delete k; m.kpp = nullptr;
 }
 
+// set_chl (sw_absorption.F90:500-512): column of the transmission table for a chlorophyll amount (mg/m^3); the reference
+// assigns the quotient to an integer array, which truncates
+inline int kpp_chl_index(const KppHost &K, double chl) {
+  chl = std::max(chl, K.chlmin); chl = std::min(chl, K.chlmax);
+  int idx = (int)(std::log10(chl / K.chlmin) / K.dlogchl);
+  return std::min(std::max(idx, 0), 400);
+}
 inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<void *> &allocs, std::string &err) {
   const pop_config &c = h.c;
-  if (c.lshort_wave && c.reserved_i[6] != 0 && c.reserved_i[6] != 1) { err = "KPP: sw_absorption_type (reserved_i[6]): 0 top-layer, 1 jerlov; chlorophyll is not built"; return 1; }
+  if (c.lshort_wave && (c.reserved_i[6] < 0 || c.reserved_i[6] > 2)) { err = "KPP: sw_absorption_type (reserved_i[6]): 0 top-layer, 1 jerlov, 2 chlorophyll"; return 1; }
   if (c.reserved_i[7] < 0 || c.reserved_i[7] > 5) { err = "KPP: jerlov_water_type (reserved_i[7]): 1..5 (0 = 3)"; return 1; }
   if (c.num_v_smooth_Ri < 1) { err = "KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)"; return 1; }
   const int km = h.km;
@@ -1001,6 +1030,47 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   if (k.lshort_wave) {
     if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.BO = (double *)p;
     if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.BOSOL = (double *)p;
+  }
+  if (k.lshort_wave && k.sw_type == 2) {   // set_chl_trn (sw_absorption.F90:650-716) on the table of Ohlmann (2003), :135-216
+    static const double cnc[31] = {.001, .005, .01, .02, .03, .05, .10, .15, .20, .25, .30, .35, .40, .45, .50, .60, .70, .80, .90, 1.00, 1.50,
+      2.00, 2.50, 3.00, 4.00, 5.00, 6.00, 7.00, 8.00, 9.00, 10.00};
+    static const double A1t[31] = {0.4421, 0.4451, 0.4488, 0.4563, 0.4622, 0.4715, 0.4877, 0.4993, 0.5084, 0.5159, 0.5223, 0.5278, 0.5326, 0.5369,
+      0.5408, 0.5474, 0.5529, 0.5576, 0.5615, 0.5649, 0.5757, 0.5802, 0.5808, 0.5788, 0.56965, 0.55638, 0.54091, 0.52442, 0.50766, 0.49110, 0.47505};
+    static const double A2t[31] = {0.2981, 0.2963, 0.2940, 0.2894, 0.2858, 0.2800, 0.2703, 0.2628, 0.2571, 0.2523, 0.2481, 0.2444, 0.2411, 0.2382,
+      0.2356, 0.2309, 0.2269, 0.2235, 0.2206, 0.2181, 0.2106, 0.2089, 0.2113, 0.2167, 0.23357, 0.25504, 0.27829, 0.30274, 0.32698, 0.35056, 0.37303};
+    static const double B1t[31] = {0.0287, 0.0301, 0.0319, 0.0355, 0.0384, 0.0434, 0.0532, 0.0612, 0.0681, 0.0743, 0.0800, 0.0853, 0.0902, 0.0949,
+      0.0993, 0.1077, 0.1154, 0.1227, 0.1294, 0.1359, 0.1640, 0.1876, 0.2082, 0.2264, 0.25808, 0.28498, 0.30844, 0.32932, 0.34817, 0.36540, 0.38132};
+    static const double B2t[31] = {0.3192, 0.3243, 0.3306, 0.3433, 0.3537, 0.3705, 0.4031, 0.4262, 0.4456, 0.4621, 0.4763, 0.4889, 0.4999, 0.5100,
+      0.5191, 0.5347, 0.5477, 0.5588, 0.5682, 0.5764, 0.6042, 0.6206, 0.6324, 0.6425, 0.66172, 0.68144, 0.70086, 0.72144, 0.74178, 0.76190, 0.78155};
+    const int ksol = 2 * km, nsub = 400;
+    std::vector<double> ztr(ksol + 1, 0.0), Tr((size_t)(ksol + 1) * (nsub + 1));
+    for (int kk = 1; kk <= km; ++kk) { ztr[2 * kk - 1] = h.zt[kk]; ztr[2 * kk] = h.zw[kk]; }
+    K->chlmin = cnc[0]; K->chlmax = cnc[30];
+    K->dlogchl = (std::log10(K->chlmax) - std::log10(K->chlmin)) / (double)nsub;
+    double logchl = std::log10(K->chlmin) - K->dlogchl;
+    for (int n = 0; n <= nsub; ++n) {
+      logchl = logchl + K->dlogchl;
+      const double amount = std::pow(10.0, logchl);
+      int mc = -1;
+      for (int q = 0; q < 30; ++q) if (cnc[q] <= amount && amount <= cnc[q + 1]) { mc = q; break; }
+      if (mc < 0) mc = (amount < cnc[0]) ? 0 : 29;
+      const double w2 = (amount - cnc[mc]) / (cnc[mc + 1] - cnc[mc]), w1 = 1.0 - w2;
+      const double A1 = A1t[mc] * w1 + A1t[mc + 1] * w2, A2 = A2t[mc] * w1 + A2t[mc + 1] * w2;
+      const double B1 = B1t[mc] * w1 + B1t[mc + 1] * w2, B2 = B2t[mc] * w1 + B2t[mc + 1] * w2;
+      double *Trn = Tr.data() + (size_t)n * (ksol + 1);
+      Trn[0] = 1.0;
+      for (int kk = 1; kk <= ksol; ++kk) {
+        double arg = std::min(B1 * ztr[kk] * 0.01, 35.0);
+        Trn[kk] = A1 * std::exp(-arg);
+        arg = std::min(B2 * ztr[kk] * 0.01, 35.0);
+        Trn[kk] = Trn[kk] + A2 * std::exp(-arg);
+      }
+    }
+    if (up(ztr.data(), ztr.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.ztr = (double *)p;
+    if (up(Tr.data(), Tr.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.Tr = (double *)p;
+    k.ksol = ksol;
+    std::vector<int> ci(a2, kpp_chl_index(*K, 0.25));   // no chlorophyll forcing file here: 0.25 mg/m^3 until the caller sets "CHL"
+    if (up(ci.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } k.CHLI = (int *)p;
   }
   K->max_kref = 1;
   for (int kk = 1; kk <= km; ++kk) K->max_kref = std::max(K->max_kref, kref[kk]);

@@ -47,7 +47,7 @@ struct pop_ctx {
   // prognostic state, physical slots; logical levels via oldt/curt/newt
   double *TR[MAXNT][3] = {}, *U[3] = {}, *V[3] = {}, *RHO[3] = {};
   double *PS[3] = {}, *GX[3] = {}, *GY[3] = {}, *UB[3] = {}, *VB[3] = {};
-  double *PGUESS = nullptr, *FW = nullptr, *FW_OLD = nullptr, *SHF_QSW = nullptr;
+  double *PGUESS = nullptr, *FW = nullptr, *FW_OLD = nullptr, *SHF_QSW = nullptr, *CHL = nullptr;
   double *STF[MAXNT] = {}, *TFW[MAXNT] = {}, *KPP_SRC[MAXNT] = {}, *VDC[2] = {}, *VVC = nullptr;
   double *DH = nullptr, *DHU = nullptr, *ZX = nullptr, *ZY = nullptr, *UH = nullptr, *VH = nullptr;
   double *W3 = nullptr, *W4 = nullptr, *RHS = nullptr, *centerWgt = nullptr;
@@ -1132,6 +1132,7 @@ int resolve(pop_ctx *c, const std::string &name, int tl, int n, double **ptr, lo
   if (name == "FW") return ok(c->FW, a2);
   if (name == "FW_OLD") return ok(c->FW_OLD, a2);
   if (name == "SHF_QSW") return ok(c->SHF_QSW, a2);
+  if (name == "CHL") return ok(c->CHL, a2);                   // chlorophyll, mg/m^3 (sw_absorption_type 'chlorophyll')
   if (name == "STF") return (n >= 0 && n < c->h.nt) ? ok(c->STF[n], a2) : 1;
   if (name == "TFW") return (n >= 0 && n < c->h.nt) ? ok(c->TFW[n], a2) : 1;
   if (name == "KPP_SRC") return (n >= 0 && n < c->h.nt) ? ok(c->KPP_SRC[n], a3) : 1;
@@ -1207,7 +1208,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if ((cfg->tmix_opt == 1 || cfg->tmix_opt == 2) && cfg->time_mix_freq < 1) return bad("time_mix_freq must be >= 1");
     if (cfg->steps_per_day < 1) return bad("steps_per_day must be >= 1");
     if (cfg->aidif != 1.0) return bad("aidif: only the fully implicit vertical mixing (aidif = 1) is built");
-    if (cfg->vmix_choice == 3 && cfg->lshort_wave && cfg->reserved_i[6] != 0 && cfg->reserved_i[6] != 1) return bad("KPP lshort_wave: sw_absorption_type (reserved_i[6]) 0 top-layer, 1 jerlov; chlorophyll is not built");
+    if (cfg->vmix_choice == 3 && cfg->lshort_wave && (cfg->reserved_i[6] < 0 || cfg->reserved_i[6] > 2)) return bad("KPP lshort_wave: sw_absorption_type (reserved_i[6]) 0 top-layer, 1 jerlov, 2 chlorophyll");
     if (cfg->reserved_i[7] < 0 || cfg->reserved_i[7] > 5) return bad("jerlov_water_type (reserved_i[7]): 1..5 (0 = 3)");
     if (cfg->vmix_choice == 3 && cfg->num_v_smooth_Ri < 1) return bad("KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)");
     if (!(cfg->convergence_criterion >= 0.0)) return bad("convergence_criterion must be >= 0");
@@ -1393,7 +1394,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   for (int n = 0; n < h.nt; ++n)
     if (dev_alloc(c, &c->STF[n], a2) || dev_alloc(c, &c->TFW[n], a2) || dev_alloc(c, &c->KPP_SRC[n], a3)) return 1;
   for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->VDC[n], (size_t)(h.km + 2) * a2)) return 1;
-  double **two[] = {&c->PGUESS, &c->FW, &c->FW_OLD, &c->SHF_QSW, &c->DH, &c->DHU, &c->ZX, &c->ZY, &c->UH, &c->VH, &c->W3, &c->W4, &c->RHS,
+  double **two[] = {&c->PGUESS, &c->FW, &c->FW_OLD, &c->SHF_QSW, &c->CHL, &c->DH, &c->DHU, &c->ZX, &c->ZY, &c->UH, &c->VH, &c->W3, &c->W4, &c->RHS,
                     &c->R, &c->S0, &c->S1, &c->Q, &c->Z, &c->AZ, &c->HBLT, &c->HMXL, &c->HMXL_DR};
   for (auto p : two) if (dev_alloc(c, p, a2)) return 1;
   c->centerWgt = c->d2["centerWgt"];
@@ -1615,6 +1616,10 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     HIPCHK(c, hipMemcpy(c->VVC, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (mix_create(c->h, c->g, c->mix, c->allocs, c->err)) return 1;
+  if (cfg->vmix_choice == 3 && cfg->lshort_wave && cfg->reserved_i[6] == 2) {   // the default chlorophyll amount the table index was built for
+    std::vector<double> chl((size_t)c->g.n2 * c->g.nblocks, 0.25);
+    HIPCHK(c, hipMemcpy(c->CHL, chl.data(), chl.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   // KPP look-ahead (bandwidth-bound grids; POP_KPP_AHEAD=0|1 overrides): second set of KPP outputs, own stream
   c->ahead_enabled = cfg->vmix_choice == 3 && c->side && (h.n2 * h.nblocks > (1u << 19));
   if (getenv("POP_KPP_AHEAD")) c->ahead_enabled = cfg->vmix_choice == 3 && c->side && atoi(getenv("POP_KPP_AHEAD")) != 0;
@@ -1779,6 +1784,14 @@ int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *hos
   if (join_side(c)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(p, host, cnt * sizeof(double), hipMemcpyHostToDevice));
+  if (!strcmp(name, "CHL") && c->mix.kpp) {   // set_chl (sw_absorption.F90:500-512): the column of the transmission table per cell
+    KppHost *K = (KppHost *)c->mix.kpp;
+    if (K->dev.CHLI) {
+      std::vector<int> idx((size_t)cnt);
+      for (long long q = 0; q < cnt; ++q) idx[q] = kpp_chl_index(*K, host[q]);
+      HIPCHK(c, hipMemcpy((void *)K->dev.CHLI, idx.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice));
+    }
+  }
   // a new prognostic state may carry other values on land: the next steps run every workgroup again (land elimination)
   for (const char *f : {"TRACER", "UVEL", "VVEL", "RHO", "PSURF", "GRADPX", "GRADPY", "UBTROP", "VBTROP", "PGUESS", "FW_OLD"})
     if (!strcmp(name, f)) c->full_left = c->land_full_steps;

@@ -253,6 +253,8 @@ def test_kpp_mixed_layer_depth_diagnostics(pkg, orclib_built, name, kw):
     {"lshort_wave": 1},                                        # sw_absorption_type 'top-layer': BFSFC = BO + BOSOL
     {"lshort_wave": 1, "sw_absorption_type": 1},                # 'jerlov', water type IB (the CESM default 3)
     {"lshort_wave": 1, "sw_absorption_type": 1, "jerlov_water_type": 5, "ldbl_diff": 1, "stepped_bathymetry": 1},
+    {"lshort_wave": 1, "sw_absorption_type": 2},                # 'chlorophyll' (the CESM default): transmission table look-up, CHL varies in space
+    {"lshort_wave": 1, "sw_absorption_type": 2, "lcheckekmo": 1, "stepped_bathymetry": 1},
     {"lcheckekmo": 1},                                         # Ekman / Monin-Obukhov depth limits under stable forcing
     {"lcheckekmo": 1, "lshort_wave": 1, "sw_absorption_type": 1, "block_size_x": 48, "block_size_y": 40},
 ])
@@ -268,6 +270,10 @@ def test_kpp_short_wave_and_depth_limits(pkg, orclib_built, kw):
     qsw = 5.0e-3 * (1.0 + np.cos(tlat))          # degC cm/s
     orc.f2("SHF_QSW")[...] = qsw
     gpu.set("SHF_QSW", qsw); plain.set("SHF_QSW", qsw)
+    chl = 0.003 + 4.0 * np.abs(np.sin(3.0 * tlat)) ** 3      # mg/m^3: both ends of the table's range
+    if kw.get("sw_absorption_type") == 2:
+        assert np.all(gpu.get("CHL") == 0.25)                # the default until set
+        orc.f2("CHL")[...] = chl; gpu.set("CHL", chl)
     for tl in (0, 1, 2):
         for n in (0, 1):
             plain.set("TRACER", orc.f3("TRACER", tl, n), tl=tl, n=n)
@@ -287,6 +293,8 @@ def test_kpp_short_wave_and_depth_limits(pkg, orclib_built, kw):
     o2 = Oracle(cfg)
     force_kpp_case(gpu2, o2)
     o2.f2("SHF_QSW")[...] = qsw; gpu2.set("SHF_QSW", qsw)
+    if kw.get("sw_absorption_type") == 2:
+        gpu2.set("CHL", chl)
     gpu2.step()
     assert np.abs(gpu2.get("HBLT") - hb_plain).max() > 1.0, "the option did not change the boundary layer depth"
     gpu2.close(); o2.close()
