@@ -72,7 +72,9 @@ typedef struct pop_config {
   double convergence_criterion;
   double reserved_d[8];       /* [0] = amplitude of the synthetic initial T perturbation;
                                * [1], [2] = robert_alpha, robert_nu for tmix_opt = 3 (0 = defaults 0.53, 0.20,
-                               * time_management.F90:461-462); [3] = LanczosconvergenceCriterion (0 = 0.1) */
+                               * time_management.F90:461-462); [3] = LanczosconvergenceCriterion (0 = 0.1);
+                               * [4] != 0: lsw_absorb -- the penetrating short wave SHF_QSW heats the levels below the first
+                               * (add_sw_absorb, sw_absorption.F90:818-947, in tracer_update) with sw_absorption_type reserved_i[6] */
 } pop_config;
 
 typedef struct pop_ctx pop_ctx;

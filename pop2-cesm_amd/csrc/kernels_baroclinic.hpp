@@ -102,6 +102,10 @@ __device__ __forceinline__ double upw3_face(int k, double flux, int kA, int kB, 
   return (flux > 0.0) ? ap * xp1 + bp * x0 + gp * xm1 : am * xp1 + bm * x0 + dm * xp2;
 }
 
+struct TracerRhsArgs;
+// the source of level k for a column with surface flux qsw = max(SHF_QSW, 0); trans_km1 carries the transmission to the top
+// of the level from level to level (chlorophyll: TRANSKM1)
+__device__ __forceinline__ double sw_source(const TracerRhsArgs &a, double qsw, int k, int kmt, double dzrk, int chli, double &trans_km1);
 struct TracerRhsArgs {
   const double *TCUR[2], *TOLD[2], *TMIX[2];
   double *TNEW[2];
@@ -110,12 +114,27 @@ struct TracerRhsArgs {
   const double *DH, *PCUR, *POLD;
   double c2dtt;
   int use_kpp_src;
+  // add_sw_absorb (sw_absorption.F90:818-947; tracer_update, baroclinic.F90:2176): penetrating short wave as a source of
+  // potential temperature.  sw_on 0: off; type 0 / 1: the per-level table swabs(0:km); 2: the chlorophyll transmission table
+  int sw_on, sw_type, sw_ksol;
+  const double *QSW, *swabs, *swTr;
+  const int *swCHLI;
   Upw3Dev up;               // UPW3 only
   const double *LTK[2];     // tadvect = 3: L(T) formed beforehand by the lw_lim kernels (kernels_lwlim.hpp); else null
   // forward elimination of the implicit vertical mixing fused into the right-hand side (k_tracer_rhs_lds<R, true>): the
   // elimination coefficients and the reduced right-hand side of tracer n go to E[n], F[n] instead of the RHS to TNEW
   double *E[2], *F[2];
 };
+__device__ __forceinline__ double sw_source(const TracerRhsArgs &a, double qsw, int k, int kmt, double dzrk, int chli, double &trans_km1) {
+  double top, bot;
+  if (a.sw_type == 2) {
+    if (k == 1) trans_km1 = 1.0;
+    top = trans_km1;
+    bot = a.swTr[(long long)chli * (a.sw_ksol + 1) + 2 * k];
+    trans_km1 = bot;
+  } else { top = a.swabs[k - 1]; bot = a.swabs[k]; }
+  return (k < kmt) ? qsw * (top - bot) * dzrk : qsw * top * dzrk;
+}
 
 // UPW3: advt_upwind3 + hupw3 (advection.F90:2313-2481, 2488-2676) in place of advt_centered.  The east
 // face value of the west neighbour and the north face value of the south neighbour are recomputed by
@@ -139,6 +158,9 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
   double tc_km1[2] = {0.0, 0.0}, tc_k[2], tc_kp1[2], to_k[2], to_kp1[2];
 #pragma unroll
   for (int n = 0; n < 2; ++n) { tc_k[n] = a.TCUR[n][c.base3]; to_k[n] = a.TOLD[n][c.base3]; }
+  const double sw_q = a.sw_on ? fmax(a.QSW[c.q2], 0.0) : 0.0;
+  const int sw_chli = (a.sw_on && a.sw_type == 2) ? a.swCHLI[c.q2] : 0;
+  double sw_tkm1 = 1.0;
   // upwind3: weights at this cell, its west neighbour (x) and its south neighbour (y)
   double wx0[6], wxw[6], wy0[6], wys[6], aux[2] = {0.0, 0.0};
   int kmtee = 0, kmtnn = 0, kEw = 0, kWw = 0, kEEw = 0, kNs = 0, kSs = 0, kNNs = 0;
@@ -226,6 +248,7 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
       if (k == 1) FT = FT + g.dzr[1] * a.TFW[n][c.q2];
       double src = 0.0;
       if (a.use_kpp_src) src = src + a.KPP_SRC[n][o];
+      if (a.sw_on && n == 0) src = src + sw_source(a, sw_q, k, kmt, dzrk, sw_chli, sw_tkm1);
       FT = FT + src;
       if (k == 1 && sp.pavg) {
         if (kmt > 0) TNp[n][o] = a.c2dtt * FT - 2.0 * tc_k[n] * psfac / (sp.grav * g.dz[1]);

@@ -958,7 +958,7 @@ __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__
 // per-context KPP state (MixDev::kpp)
 // col: bit 0 = ushear, bit 1 = buoydiff in column form.  side / ev_*: second HIP stream on which the shear kernel (needs only
 // U, V; consumed by bldepth) runs beside buoydiff + interior (POP_KPP_SIDE_STREAM=0 keeps everything on one stream)
-struct KppHost { KppDev dev; double chlmin = 0, chlmax = 0, dlogchl = 0; int max_kref = 1; int col = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bd = nullptr; };
+struct KppHost { KppDev dev; int max_kref = 1; int col = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bd = nullptr; };
 inline void kpp_destroy(MixDev &m) {
   KppHost *k = (KppHost *)m.kpp;
   if (k) {
@@ -972,10 +972,78 @@ inline void kpp_destroy(MixDev &m) {
 
 // set_chl (sw_absorption.F90:500-512): column of the transmission table for a chlorophyll amount (mg/m^3); the reference
 // assigns the quotient to an integer array, which truncates
-inline int kpp_chl_index(const KppHost &K, double chl) {
-  chl = std::max(chl, K.chlmin); chl = std::min(chl, K.chlmax);
-  int idx = (int)(std::log10(chl / K.chlmin) / K.dlogchl);
+inline int sw_chl_index(const SwTab &T, double chl) {
+  chl = std::max(chl, T.chlmin); chl = std::min(chl, T.chlmax);
+  int idx = (int)(std::log10(chl / T.chlmin) / T.dlogchl);
   return std::min(std::max(idx, 0), 400);
+}
+// device tables of the short-wave absorption (SwTab): sw_absorb(0:km) for sw_absorption_type 0 / 1, the chlorophyll
+// transmission table for 2 (set_chl_trn, sw_absorption.F90:650-716, on the table of Ohlmann (2003), :135-216)
+inline int sw_tables_create(HostModel &h, std::vector<void *> &allocs, std::string &err) {
+  if (h.sw.swabs) return 0;
+  const pop_config &c = h.c;
+  const int km = h.km, type = c.reserved_i[6], jt = c.reserved_i[7] ? c.reserved_i[7] : 3;
+  const size_t a2 = h.n2 * h.nblocks;
+  void *p;
+  auto up = [&](const void *src, size_t bytes, void **dst) -> int {
+    if (hipMalloc(dst, bytes) != hipSuccess) return 1;
+    allocs.push_back(*dst);
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess ? 1 : 0;
+  };
+  {   // init_sw_absorption :355-370
+    std::vector<double> sa(km + 1, 0.0);
+    sa[0] = 1.0;
+    if (type == 1) {
+      const double rfac[5] = {0.58, 0.62, 0.67, 0.77, 0.78}, depth1[5] = {0.35, 0.60, 1.00, 1.50, 1.40}, depth2[5] = {23.0, 20.0, 17.0, 14.0, 7.90};
+      for (int kk = 1; kk <= km - 1; ++kk) {
+        const double dm = -h.zw[kk] * 0.01;
+        sa[kk] = (dm < -200.0) ? 0.0 : rfac[jt - 1] * std::exp(dm / depth1[jt - 1]) + (1.0 - rfac[jt - 1]) * std::exp(dm / depth2[jt - 1]);
+      }
+    }
+    if (up(sa.data(), sa.size() * 8, &p)) { err = "sw alloc"; return 1; } h.sw.swabs = (double *)p;
+  }
+  if (type == 2) {
+    static const double cnc[31] = {.001, .005, .01, .02, .03, .05, .10, .15, .20, .25, .30, .35, .40, .45, .50, .60, .70, .80, .90, 1.00, 1.50,
+      2.00, 2.50, 3.00, 4.00, 5.00, 6.00, 7.00, 8.00, 9.00, 10.00};
+    static const double A1t[31] = {0.4421, 0.4451, 0.4488, 0.4563, 0.4622, 0.4715, 0.4877, 0.4993, 0.5084, 0.5159, 0.5223, 0.5278, 0.5326, 0.5369,
+      0.5408, 0.5474, 0.5529, 0.5576, 0.5615, 0.5649, 0.5757, 0.5802, 0.5808, 0.5788, 0.56965, 0.55638, 0.54091, 0.52442, 0.50766, 0.49110, 0.47505};
+    static const double A2t[31] = {0.2981, 0.2963, 0.2940, 0.2894, 0.2858, 0.2800, 0.2703, 0.2628, 0.2571, 0.2523, 0.2481, 0.2444, 0.2411, 0.2382,
+      0.2356, 0.2309, 0.2269, 0.2235, 0.2206, 0.2181, 0.2106, 0.2089, 0.2113, 0.2167, 0.23357, 0.25504, 0.27829, 0.30274, 0.32698, 0.35056, 0.37303};
+    static const double B1t[31] = {0.0287, 0.0301, 0.0319, 0.0355, 0.0384, 0.0434, 0.0532, 0.0612, 0.0681, 0.0743, 0.0800, 0.0853, 0.0902, 0.0949,
+      0.0993, 0.1077, 0.1154, 0.1227, 0.1294, 0.1359, 0.1640, 0.1876, 0.2082, 0.2264, 0.25808, 0.28498, 0.30844, 0.32932, 0.34817, 0.36540, 0.38132};
+    static const double B2t[31] = {0.3192, 0.3243, 0.3306, 0.3433, 0.3537, 0.3705, 0.4031, 0.4262, 0.4456, 0.4621, 0.4763, 0.4889, 0.4999, 0.5100,
+      0.5191, 0.5347, 0.5477, 0.5588, 0.5682, 0.5764, 0.6042, 0.6206, 0.6324, 0.6425, 0.66172, 0.68144, 0.70086, 0.72144, 0.74178, 0.76190, 0.78155};
+    const int ksol = 2 * km, nsub = 400;
+    std::vector<double> ztr(ksol + 1, 0.0), Tr((size_t)(ksol + 1) * (nsub + 1));
+    for (int kk = 1; kk <= km; ++kk) { ztr[2 * kk - 1] = h.zt[kk]; ztr[2 * kk] = h.zw[kk]; }
+    h.sw.chlmin = cnc[0]; h.sw.chlmax = cnc[30];
+    h.sw.dlogchl = (std::log10(h.sw.chlmax) - std::log10(h.sw.chlmin)) / (double)nsub;
+    double logchl = std::log10(h.sw.chlmin) - h.sw.dlogchl;
+    for (int n = 0; n <= nsub; ++n) {
+      logchl = logchl + h.sw.dlogchl;
+      const double amount = std::pow(10.0, logchl);
+      int mc = -1;
+      for (int q = 0; q < 30; ++q) if (cnc[q] <= amount && amount <= cnc[q + 1]) { mc = q; break; }
+      if (mc < 0) mc = (amount < cnc[0]) ? 0 : 29;
+      const double w2 = (amount - cnc[mc]) / (cnc[mc + 1] - cnc[mc]), w1 = 1.0 - w2;
+      const double A1 = A1t[mc] * w1 + A1t[mc + 1] * w2, A2 = A2t[mc] * w1 + A2t[mc + 1] * w2;
+      const double B1 = B1t[mc] * w1 + B1t[mc + 1] * w2, B2 = B2t[mc] * w1 + B2t[mc + 1] * w2;
+      double *Trn = Tr.data() + (size_t)n * (ksol + 1);
+      Trn[0] = 1.0;
+      for (int kk = 1; kk <= ksol; ++kk) {
+        double arg = std::min(B1 * ztr[kk] * 0.01, 35.0);
+        Trn[kk] = A1 * std::exp(-arg);
+        arg = std::min(B2 * ztr[kk] * 0.01, 35.0);
+        Trn[kk] = Trn[kk] + A2 * std::exp(-arg);
+      }
+    }
+    if (up(ztr.data(), ztr.size() * 8, &p)) { err = "sw alloc"; return 1; } h.sw.ztr = (double *)p;
+    if (up(Tr.data(), Tr.size() * 8, &p)) { err = "sw alloc"; return 1; } h.sw.Tr = (double *)p;
+    h.sw.ksol = ksol;
+    std::vector<int> ci(a2, sw_chl_index(h.sw, 0.25));   // no chlorophyll forcing file here: 0.25 mg/m^3 until the caller sets "CHL"
+    if (up(ci.data(), a2 * 4, &p)) { err = "sw alloc"; return 1; } h.sw.CHLI = (int *)p;
+  }
+  return 0;
 }
 inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<void *> &allocs, std::string &err) {
   const pop_config &c = h.c;
@@ -1031,46 +1099,9 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
     if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.BO = (double *)p;
     if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.BOSOL = (double *)p;
   }
-  if (k.lshort_wave && k.sw_type == 2) {   // set_chl_trn (sw_absorption.F90:650-716) on the table of Ohlmann (2003), :135-216
-    static const double cnc[31] = {.001, .005, .01, .02, .03, .05, .10, .15, .20, .25, .30, .35, .40, .45, .50, .60, .70, .80, .90, 1.00, 1.50,
-      2.00, 2.50, 3.00, 4.00, 5.00, 6.00, 7.00, 8.00, 9.00, 10.00};
-    static const double A1t[31] = {0.4421, 0.4451, 0.4488, 0.4563, 0.4622, 0.4715, 0.4877, 0.4993, 0.5084, 0.5159, 0.5223, 0.5278, 0.5326, 0.5369,
-      0.5408, 0.5474, 0.5529, 0.5576, 0.5615, 0.5649, 0.5757, 0.5802, 0.5808, 0.5788, 0.56965, 0.55638, 0.54091, 0.52442, 0.50766, 0.49110, 0.47505};
-    static const double A2t[31] = {0.2981, 0.2963, 0.2940, 0.2894, 0.2858, 0.2800, 0.2703, 0.2628, 0.2571, 0.2523, 0.2481, 0.2444, 0.2411, 0.2382,
-      0.2356, 0.2309, 0.2269, 0.2235, 0.2206, 0.2181, 0.2106, 0.2089, 0.2113, 0.2167, 0.23357, 0.25504, 0.27829, 0.30274, 0.32698, 0.35056, 0.37303};
-    static const double B1t[31] = {0.0287, 0.0301, 0.0319, 0.0355, 0.0384, 0.0434, 0.0532, 0.0612, 0.0681, 0.0743, 0.0800, 0.0853, 0.0902, 0.0949,
-      0.0993, 0.1077, 0.1154, 0.1227, 0.1294, 0.1359, 0.1640, 0.1876, 0.2082, 0.2264, 0.25808, 0.28498, 0.30844, 0.32932, 0.34817, 0.36540, 0.38132};
-    static const double B2t[31] = {0.3192, 0.3243, 0.3306, 0.3433, 0.3537, 0.3705, 0.4031, 0.4262, 0.4456, 0.4621, 0.4763, 0.4889, 0.4999, 0.5100,
-      0.5191, 0.5347, 0.5477, 0.5588, 0.5682, 0.5764, 0.6042, 0.6206, 0.6324, 0.6425, 0.66172, 0.68144, 0.70086, 0.72144, 0.74178, 0.76190, 0.78155};
-    const int ksol = 2 * km, nsub = 400;
-    std::vector<double> ztr(ksol + 1, 0.0), Tr((size_t)(ksol + 1) * (nsub + 1));
-    for (int kk = 1; kk <= km; ++kk) { ztr[2 * kk - 1] = h.zt[kk]; ztr[2 * kk] = h.zw[kk]; }
-    K->chlmin = cnc[0]; K->chlmax = cnc[30];
-    K->dlogchl = (std::log10(K->chlmax) - std::log10(K->chlmin)) / (double)nsub;
-    double logchl = std::log10(K->chlmin) - K->dlogchl;
-    for (int n = 0; n <= nsub; ++n) {
-      logchl = logchl + K->dlogchl;
-      const double amount = std::pow(10.0, logchl);
-      int mc = -1;
-      for (int q = 0; q < 30; ++q) if (cnc[q] <= amount && amount <= cnc[q + 1]) { mc = q; break; }
-      if (mc < 0) mc = (amount < cnc[0]) ? 0 : 29;
-      const double w2 = (amount - cnc[mc]) / (cnc[mc + 1] - cnc[mc]), w1 = 1.0 - w2;
-      const double A1 = A1t[mc] * w1 + A1t[mc + 1] * w2, A2 = A2t[mc] * w1 + A2t[mc + 1] * w2;
-      const double B1 = B1t[mc] * w1 + B1t[mc + 1] * w2, B2 = B2t[mc] * w1 + B2t[mc + 1] * w2;
-      double *Trn = Tr.data() + (size_t)n * (ksol + 1);
-      Trn[0] = 1.0;
-      for (int kk = 1; kk <= ksol; ++kk) {
-        double arg = std::min(B1 * ztr[kk] * 0.01, 35.0);
-        Trn[kk] = A1 * std::exp(-arg);
-        arg = std::min(B2 * ztr[kk] * 0.01, 35.0);
-        Trn[kk] = Trn[kk] + A2 * std::exp(-arg);
-      }
-    }
-    if (up(ztr.data(), ztr.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.ztr = (double *)p;
-    if (up(Tr.data(), Tr.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.Tr = (double *)p;
-    k.ksol = ksol;
-    std::vector<int> ci(a2, kpp_chl_index(*K, 0.25));   // no chlorophyll forcing file here: 0.25 mg/m^3 until the caller sets "CHL"
-    if (up(ci.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } k.CHLI = (int *)p;
+  if (k.lshort_wave && k.sw_type == 2) {
+    if (sw_tables_create(h, allocs, err)) return 1;
+    k.ztr = h.sw.ztr; k.Tr = h.sw.Tr; k.ksol = h.sw.ksol; k.CHLI = h.sw.CHLI;
   }
   K->max_kref = 1;
   for (int kk = 1; kk <= km; ++kk) K->max_kref = std::max(K->max_kref, kref[kk]);

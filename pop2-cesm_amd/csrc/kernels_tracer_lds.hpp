@@ -58,6 +58,8 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
   int kmt = 0, kmtn = 0, kmts = 0, kmte = 0, kmtw = 0;
   double dtn = 0, dts = 0, dte = 0, dtw = 0, dyu00 = 0, dyu0m = 0, dyum0 = 0, dyumm = 0, dxu00 = 0, dxu0m = 0, dxum0 = 0, dxumm = 0;
   double tarear = 0, psfac = 0, wtk = 0, stf[2] = {0, 0}, tfw[2] = {0, 0};
+  double sw_q = 0.0, sw_tkm1 = 1.0;
+  int sw_chli = 0;
   if (act) {
     kmt = g.KMT[q2]; kmtn = g.KMTN[q2]; kmts = g.KMTS[q2]; kmte = g.KMTE[q2]; kmtw = g.KMTW[q2];
     dtn = g.DTN[q2]; dts = g.DTS[q2]; dte = g.DTE[q2]; dtw = g.DTW[q2];
@@ -68,6 +70,7 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
     wtk = a.DH[q2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) { stf[n] = a.STF[n][q2]; tfw[n] = a.TFW[n][q2]; }
+    if (a.sw_on) { sw_q = fmax(a.QSW[q2], 0.0); if (a.sw_type == 2) sw_chli = a.swCHLI[q2]; }
   }
   const long long vdcbase = ((long long)b * (km + 2)) * n2 + p2;
   struct Lev { double u, v, tc[2], tm[2], to[2], vdc[2], src[2]; };
@@ -150,6 +153,7 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
         if (k == 1) FT = FT + g.dzr[1] * tfw[n];
         double src = 0.0;
         if (a.use_kpp_src) src = src + cur.src[n];
+        if (a.sw_on && n == 0) src = src + sw_source(a, sw_q, k, kmt, dzrk, sw_chli, sw_tkm1);
         FT = FT + src;
         if (!FWD) {
           if (k == 1 && sp.pavg) {

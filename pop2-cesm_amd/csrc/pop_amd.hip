@@ -1210,6 +1210,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if (cfg->aidif != 1.0) return bad("aidif: only the fully implicit vertical mixing (aidif = 1) is built");
     if (cfg->vmix_choice == 3 && cfg->lshort_wave && (cfg->reserved_i[6] < 0 || cfg->reserved_i[6] > 2)) return bad("KPP lshort_wave: sw_absorption_type (reserved_i[6]) 0 top-layer, 1 jerlov, 2 chlorophyll");
     if (cfg->reserved_i[7] < 0 || cfg->reserved_i[7] > 5) return bad("jerlov_water_type (reserved_i[7]): 1..5 (0 = 3)");
+    if (cfg->reserved_d[4] != 0.0 && (cfg->reserved_i[6] < 0 || cfg->reserved_i[6] > 2)) return bad("lsw_absorb (reserved_d[4]): sw_absorption_type (reserved_i[6]) 0 top-layer, 1 jerlov, 2 chlorophyll");
     if (cfg->vmix_choice == 3 && cfg->num_v_smooth_Ri < 1) return bad("KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)");
     if (!(cfg->convergence_criterion >= 0.0)) return bad("convergence_criterion must be >= 0");
   }
@@ -1616,7 +1617,8 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     HIPCHK(c, hipMemcpy(c->VVC, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (mix_create(c->h, c->g, c->mix, c->allocs, c->err)) return 1;
-  if (cfg->vmix_choice == 3 && cfg->lshort_wave && cfg->reserved_i[6] == 2) {   // the default chlorophyll amount the table index was built for
+  if (cfg->reserved_d[4] != 0.0 && sw_tables_create(c->h, c->allocs, c->err)) return 1;   // lsw_absorb without KPP's lshort_wave
+  if (c->h.sw.CHLI) {   // the default chlorophyll amount the table index was built for
     std::vector<double> chl((size_t)c->g.n2 * c->g.nblocks, 0.25);
     HIPCHK(c, hipMemcpy(c->CHL, chl.data(), chl.size() * sizeof(double), hipMemcpyHostToDevice));
   }
@@ -1784,13 +1786,10 @@ int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *hos
   if (join_side(c)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(p, host, cnt * sizeof(double), hipMemcpyHostToDevice));
-  if (!strcmp(name, "CHL") && c->mix.kpp) {   // set_chl (sw_absorption.F90:500-512): the column of the transmission table per cell
-    KppHost *K = (KppHost *)c->mix.kpp;
-    if (K->dev.CHLI) {
-      std::vector<int> idx((size_t)cnt);
-      for (long long q = 0; q < cnt; ++q) idx[q] = kpp_chl_index(*K, host[q]);
-      HIPCHK(c, hipMemcpy((void *)K->dev.CHLI, idx.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice));
-    }
+  if (!strcmp(name, "CHL") && c->h.sw.CHLI) {   // set_chl (sw_absorption.F90:500-512): the column of the transmission table per cell
+    std::vector<int> idx((size_t)cnt);
+    for (long long q = 0; q < cnt; ++q) idx[q] = sw_chl_index(c->h.sw, host[q]);
+    HIPCHK(c, hipMemcpy(c->h.sw.CHLI, idx.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice));
   }
   // a new prognostic state may carry other values on land: the next steps run every workgroup again (land elimination)
   for (const char *f : {"TRACER", "UVEL", "VVEL", "RHO", "PSURF", "GRADPX", "GRADPY", "UBTROP", "VBTROP", "PGUESS", "FW_OLD"})
@@ -2053,6 +2052,10 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->d2t[0]; a.TMIX[1] = c->d2t[1]; }   // del4: second Laplacian acts on D2T
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
   a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
+  if (c->h.c.reserved_d[4] != 0.0) {   // lsw_absorb: penetrating short wave (add_sw_absorb)
+    a.sw_on = 1; a.sw_type = c->h.c.reserved_i[6]; a.sw_ksol = c->h.sw.ksol;
+    a.QSW = c->SHF_QSW; a.swabs = c->h.sw.swabs; a.swTr = c->h.sw.Tr; a.swCHLI = c->h.sw.CHLI;
+  }
   if (c->h.c.tadvect == 1 && c->trc_lds_rows == 8) { launch_tracer_lds<8>(c->g, sp, a, c->stream, fwd); return 0; }
   if (c->h.c.tadvect == 1 && c->trc_lds_rows == 4) { launch_tracer_lds<4>(c->g, sp, a, c->stream, fwd); return 0; }
   if (fwd) { c->err = "fused forward elimination needs the LDS tracer kernel"; return 1; }

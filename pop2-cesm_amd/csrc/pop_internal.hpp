@@ -64,7 +64,17 @@ struct EvpHost {
 
 // ---- host-side model: everything init-time (restates grid.F90, hmix_del*.F90 init,
 //      POP_SolversInit, init_barotropic, init_ts) on the local blocks of this rank
+// short-wave absorption tables on the device (sw_absorption.F90): sw_absorb(0:km) of 'top-layer' / 'jerlov' (:355-370); for
+// 'chlorophyll' the transmission table Tr over the levels ztr and 401 chlorophyll amounts (:525-728) and the table column of
+// every cell (set_chl :500-512).  Shared by KPP (lshort_wave) and the temperature source add_sw_absorb.
+struct SwTab {
+  double *swabs = nullptr, *Tr = nullptr, *ztr = nullptr;
+  int *CHLI = nullptr;
+  int ksol = 0;
+  double chlmin = 0, chlmax = 0, dlogchl = 0;
+};
 struct HostModel {
+  SwTab sw;
   pop_config c{};
   const pop_grid_input *gin = nullptr;     // caller's grid (pop_create_with_grid); read during host_build only
   int rank = 0, nranks = 1;

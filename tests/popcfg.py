@@ -75,6 +75,8 @@ def _apply(c, kw):
             c.reserved_i[6] = v
         elif k == "jerlov_water_type":
             c.reserved_i[7] = v
+        elif k == "lsw_absorb":        # penetrating short wave as a temperature source (add_sw_absorb)
+            c.reserved_d[4] = float(v)
         elif k == "robert_alpha":
             c.reserved_d[1] = v
         elif k == "robert_nu":

@@ -300,6 +300,44 @@ def test_kpp_short_wave_and_depth_limits(pkg, orclib_built, kw):
     gpu2.close(); o2.close()
 
 
+@pytest.mark.parametrize("kw", [
+    {"lsw_absorb": 1, "sw_absorption_type": 0},                                  # all of it in the top level (const vmix, LDS tracer kernel)
+    {"lsw_absorb": 1, "sw_absorption_type": 1, "jerlov_water_type": 2, "stepped_bathymetry": 1},
+    {"lsw_absorb": 1, "sw_absorption_type": 2, "tadvect": 2},                     # chlorophyll table, direct-load tracer kernel (upwind3)
+    {"lsw_absorb": 1, "sw_absorption_type": 2, "vmix_choice": 3, "km": 24, "lshort_wave": 1, "stepped_bathymetry": 1},   # the CESM combination
+    {"lsw_absorb": 1, "sw_absorption_type": 1, "tadvect": 3, "lpressure_avg": 0},
+])
+def test_penetrating_short_wave_source(pkg, orclib_built, kw):
+    """add_sw_absorb (sw_absorption.F90:818-947, called from tracer_update next to add_kpp_sources): the short-wave flux
+    SHF_QSW heats level k with its absorbed share, everything that reaches the bottom level stays there"""
+    cfg = named_config("tiny", **kw)
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
+    tlat = orc.f2("TLAT")
+    qsw = 6.0e-3 * np.cos(tlat) - 1.0e-3          # degC cm/s, negative near the poles (clipped to 0 by the routine)
+    orc.f2("SHF_QSW")[...] = qsw; gpu.set("SHF_QSW", qsw)
+    if kw["sw_absorption_type"] == 2:
+        chl = 0.003 + 4.0 * np.abs(np.sin(3.0 * tlat)) ** 3
+        orc.f2("CHL")[...] = chl; gpu.set("CHL", chl)
+    t0 = gpu.get("TRACER", 1, 0).copy()
+    tol = TOL_LOCAL
+    for s in range(1, 4):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+    off = pkg.PopModel(named_config("tiny", **{k: v for k, v in kw.items() if k != "lsw_absorb"}))
+    if cfg.vmix_choice == 3:
+        o2 = Oracle(cfg); force_kpp_case(off, o2); o2.close()
+    off.set("SHF_QSW", qsw)
+    for _ in range(3):
+        off.step()
+    d = gpu.get("TRACER", 1, 0)[:, 0] - off.get("TRACER", 1, 0)[:, 0]
+    assert d.max() > 1.0e-3, d.max()                                         # the surface level warms where the sun shines
+    if cfg.vmix_choice != 3:                                                 # (KPP mixes the extra heat down: no sign for every cell)
+        assert d.min() > -1.0e-6, d.min()
+    gpu.close(); orc.close(); off.close()
+
+
 def test_tripole_without_grid_input_refuses_to_step(pkg):
     m = pkg.PopModel(named_config("tiny", ns_boundary=2))
     with pytest.raises(pkg.PopError, match="pop_create_with_grid"):
