@@ -28,6 +28,7 @@ struct PcsiArgs {
   double csy;
   int j;                           // step inside the interval (1-based); j = 0: start-up step
   int remote_ghosts;               // multi-rank: also advance dx, x at ghosts owned by other ranks
+  int nchunk;                      // stride of the partial slots per block (the launch may be compacted: DevGrid::red_act)
 };
 
 // unfused building blocks (multi-rank path and cross-check): whole-array operations as the reference has them
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(POP_RED_THREADS)
 k_pcsi_step(DevGrid g, PcsiArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   // land elimination: x, dx and r' stay exactly 0 where no ocean cell is near, in both halves of the ping-pong buffers
-  if (WITH_RR ? red_land_out<1>(g, a.partial, (int)gridDim.x, a.remote_ghosts != 0) : red_land(g, a.remote_ghosts != 0)) return;
+  if (WITH_RR ? red_land_out<1>(g, a.partial, a.nchunk, a.remote_ghosts != 0) : red_land(g, a.remote_ghosts != 0)) return;
   const int p2 = red_cell(g), b = blockIdx.y, nxb = g.nxb;
   double v[1] = {0.0};
   if (p2 < g.n2) {
@@ -120,7 +121,7 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
       a.Qo[q] = dx; a.Xo[q] = a.Xi[q] + dx;
     }
   }
-  if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + red_chunk(g));
+  if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * a.nchunk + red_chunk(g));
 }
 
 // fused step with two horizontally adjacent cells per thread (large grids with an even row pitch; not the first
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_pcsi_step2(DevGrid g, PcsiArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   // land elimination: x, dx and r' stay exactly 0 where no ocean cell is near, in both halves of the ping-pong buffers
-  if (WITH_RR ? red_land_out<1>(g, a.partial, (int)gridDim.x, a.remote_ghosts != 0) : red_land(g, a.remote_ghosts != 0)) return;
+  if (WITH_RR ? red_land_out<1>(g, a.partial, a.nchunk, a.remote_ghosts != 0) : red_land(g, a.remote_ghosts != 0)) return;
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
   const long long p0 = (long long)red_chunk(g) * POP_RED_THREADS + 2 * t;
@@ -205,7 +206,7 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
       if (t < s) sh[t] = sh[t] + sh[t + s];
       __syncthreads();
     }
-    if (t == 0) a.partial[(long long)b * gridDim.x + red_chunk(g)] = sh[0];
+    if (t == 0) a.partial[(long long)b * a.nchunk + red_chunk(g)] = sh[0];
   }
 }
 

@@ -976,19 +976,26 @@ static PcsiArgs pcsi_args(pop_ctx *c, const PcsiBufs &bf, int in, int j) {
   PcsiArgs a{};
   a.Xi = bf.X[in]; a.Ri = bf.R[in]; a.Qi = bf.Q[in]; a.Xo = bf.X[1 - in]; a.Ro = bf.R[1 - in]; a.Qo = bf.Q[1 - in];
   a.Bv = c->RHS; a.C = c->centerWgt; a.A0R = c->S0; a.omega = c->pcsi_omega; a.base = c->pcsi_base; a.srcmap = c->srcmap; a.partial = c->partial; a.sc = c->sc;
-  a.csy = c->pcsi_csy; a.j = j;
+  a.csy = c->pcsi_csy; a.j = j; a.nchunk = c->nchunk;
   return a;
+}
+// DevGrid of the single-rank fused P-CSI launches: with land elimination active, the compacted chunk list (DevGrid::red_act)
+static DevGrid pcsi_grid(const pop_ctx *c) {
+  DevGrid g = c->g;
+  if (c->g.skip && c->red_act && c->peers.empty()) { g.red_act = c->red_act; g.red_cnt = c->red_cnt; g.red_nact = c->red_nact; }
+  return g;
 }
 // `freq` steps starting from buffer `in`; the last one also forms (r,r) -> host when with_rr
 static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool with_rr) {
-  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  const DevGrid gg = pcsi_grid(c);
+  const dim3 G(red_grid_x(gg), gg.nblocks), B(POP_RED_THREADS);
   for (int j = 1; j <= freq; ++j) {
     const PcsiArgs a = pcsi_args(c, bf, in, j);
     if (c->pcsi_two_cell) {
-      if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step2<true>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, c->g, a);
-      else hipLaunchKernelGGL((k_pcsi_step2<false>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, c->g, a);
-    } else if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step<false, true>), G, B, 0, c->stream, c->g, a);
-    else hipLaunchKernelGGL((k_pcsi_step<false, false>), G, B, 0, c->stream, c->g, a);
+      if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step2<true>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, gg, a);
+      else hipLaunchKernelGGL((k_pcsi_step2<false>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, gg, a);
+    } else if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step<false, true>), G, B, 0, c->stream, gg, a);
+    else hipLaunchKernelGGL((k_pcsi_step<false, false>), G, B, 0, c->stream, gg, a);
     in = 1 - in;
   }
   if (with_rr) {
@@ -1011,6 +1018,8 @@ int solver_pcsi_fused(pop_ctx *c) {
     hipLaunchKernelGGL(k_pcsi_scale, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, c->R, (const double *)c->S0);
   }
   hipLaunchKernelGGL((k_pcsi_step<true, false>), G, B, 0, c->stream, c->g, pcsi_args(c, bf, 0, 0));
+  if (pcsi_grid(c).red_act)   // compacted launches from here on: the partials of the chunks that are left out must read as zero
+    HIPCHK(c, hipMemsetAsync(c->partial, 0, (size_t)c->nchunk * c->g.nblocks * 2 * sizeof(double), c->stream));
   int in = 1;
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
