@@ -169,3 +169,14 @@ def test_balanced_distribution_equals_single_rank(nranks, kw, env, transport):
 def test_tripole_across_ranks_equals_single_rank(nranks, kw, env, transport):
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
                 "--grid", "1", "--kw", kw], 300, env, transport=transport)
+
+
+@pytest.mark.parametrize("nranks,kw,env", [
+    (2, "ny_global=80,block_size_x=48,block_size_y=40", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1")),                    # T,S halo beside the interior tile rows
+    (3, "ny_global=120,block_size_x=24,block_size_y=40,vmix_choice=3,km=24", dict(_SKIP, POP_SOLVER_DISTRIBUTED="1")),
+])
+def test_land_elimination_with_overlapped_halo(nranks, kw, env):
+    """tall j-band blocks: the mid-step exchange of the new tracers runs beside the momentum kernel on a window of tile rows
+    (windows classify their tiles one by one, the whole launch uses the compacted list)"""
+    _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
+                "--kw", kw], 300, env, transport="native")
