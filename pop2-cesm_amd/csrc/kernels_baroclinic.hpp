@@ -548,6 +548,7 @@ k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
 struct ImpvmixuArgs {
   double *UNEW, *VNEW, *E;
   const double *UOLD, *VOLD, *VVC;
+  const double *UB = nullptr, *VB = nullptr;   // register kernel with ADD: the new barotropic velocity, added in the final store
 };
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_impvmixu_norm(DevGrid g, StepParams sp, ImpvmixuArgs a) {

@@ -400,7 +400,7 @@ k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, cons
     }
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
-    VDC2[vb + (long long)k * n2] = vd2;
+    if (VDC2 != VDC1) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
   }
 }
 
@@ -528,7 +528,7 @@ k_kpp_interior(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
     }
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
-    VDC2[vb + (long long)k * n2] = vd2;
+    if (VDC2 != VDC1) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
   }
 }
 
@@ -639,7 +639,7 @@ k_kpp_interior_reg(DevGrid g, KppDev kp, const double *__restrict__ T, const dou
     }
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
-    VDC2[vb + (long long)k * n2] = vd2;
+    if (VDC2 != VDC1) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
   }
 }
 
@@ -823,8 +823,9 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     const double R = 1.0 - dh / hwide[k];
     double fm[3], f0[3], fp[3];
     fm[0] = visc_at(k - 1); f0[0] = visc_at(k); fp[0] = visc_at(k + 1);
-    fm[1] = VDC2[vb + (long long)(k - 1) * n2]; f0[1] = VDC2[vb + (long long)k * n2]; fp[1] = VDC2[vb + (long long)(k + 1) * n2];
     fm[2] = VDC1[vb + (long long)(k - 1) * n2]; f0[2] = VDC1[vb + (long long)k * n2]; fp[2] = VDC1[vb + (long long)(k + 1) * n2];
+    if (VDC2 != VDC1) { fm[1] = VDC2[vb + (long long)(k - 1) * n2]; f0[1] = VDC2[vb + (long long)k * n2]; fp[1] = VDC2[vb + (long long)(k + 1) * n2]; }
+    else { fm[1] = fm[2]; f0[1] = f0[2]; fp[1] = fp[2]; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const double up = (fm[q] - f0[q]) / hwide[k], dn = (f0[q] - fp[q]) / hwide[k + 1];
@@ -851,7 +852,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
   const double stf1 = STF1[c.q2], stf2 = STF2[c.q2];
   for (int k = 1; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
-    double visc = VISC[o], vd1 = VDC1[vb + (long long)k * n2], vd2 = VDC2[vb + (long long)k * n2];
+    double visc = VISC[o], vd1 = VDC1[vb + (long long)k * n2], vd2 = (VDC2 != VDC1) ? VDC2[vb + (long long)k * n2] : vd1;
     double ghat = 0.0;
     if (k < kbl) {
       const double sig = (-zgrid[k] + 0.5 * hwide[k]) / hblt;
@@ -879,7 +880,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     } else { vd1 = 0.0; vd2 = 0.0; }
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
-    VDC2[vb + (long long)k * n2] = vd2;
+    if (VDC2 != VDC1) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
     const double fl1 = vd1 * ghat, fl2 = vd2 * ghat;
     if (k == 1) { SRC1[o] = stf1 / g.dz[1] * (-fl1); SRC2[o] = stf2 / g.dz[1] * (-fl2); }
     else { SRC1[o] = stf1 / g.dz[k] * (flux1_prev - fl1); SRC2[o] = stf2 / g.dz[k] * (flux2_prev - fl2); }

@@ -98,7 +98,10 @@ k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
 // and the launch has twice the waves
 // WAVES = 2 caps the kernel at 256 VGPRs (38 - 64 spilled): faster on small, latency-bound grids (gx1v7: 0.111 -> 0.099 ms),
 // slower on bandwidth-bound ones (tx0.1v3: 6.5 -> 6.9 ms), so the launcher picks by grid size
-template <int KM, int WAVES>
+// ADD: the step tail's "add the barotropic velocity where k <= KMU" (step_mod.F90:572-592, k_add_barotropic) applied to the value
+// on its way out -- the same sum (X - mean) + UBTROP, so U, V(new) are bitwise what the two launches leave, and one read and one
+// write of both 3-D fields are gone.  Only valid once the barotropic solve of the step has finished (pop_amd.hip: deferred form).
+template <int KM, int WAVES, bool ADD = false>
 __global__ void __launch_bounds__(POP_COL_THREADS, WAVES)
 k_impvmixu_reg(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   Col c;
@@ -152,7 +155,14 @@ k_impvmixu_reg(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   for (int k = 1; k <= KM; ++k) w1 = w1 + Xa[k - 1] * g.dz[k];
   w1 = w1 * hur;
 #pragma unroll
-  for (int k = 1; k <= KM; ++k) XN[c.base3 + (long long)(k - 1) * n2] = (k <= kmu) ? Xa[k - 1] - w1 : 0.0;
+  for (int k = 1; k <= KM; ++k) Xa[k - 1] = (k <= kmu) ? Xa[k - 1] - w1 : 0.0;
+  if (ADD) {
+    const double xb = (isv ? a.VB : a.UB)[c.q2];
+#pragma unroll
+    for (int k = 1; k <= KM; ++k) if (k <= kmu) Xa[k - 1] = Xa[k - 1] + xb;
+  }
+#pragma unroll
+  for (int k = 1; k <= KM; ++k) XN[c.base3 + (long long)(k - 1) * n2] = Xa[k - 1];
 }
 
 // dispatch on the level count: register kernels for the production grids, generic otherwise
@@ -176,6 +186,17 @@ inline void launch_impvmixu(const DevGrid &g, const StepParams &sp, const Impvmi
   else if (allow_reg && g.km == 62 && small) hipLaunchKernelGGL((k_impvmixu_reg<62, 2>), G2, B, 0, st, g, sp, a);
   else if (allow_reg && g.km == 62) hipLaunchKernelGGL((k_impvmixu_reg<62, 1>), G2, B, 0, st, g, sp, a);
   else hipLaunchKernelGGL(k_impvmixu_norm, G, B, 0, st, g, sp, a);
+}
+// the register kernel with the barotropic velocity added on the way out (a.UB, a.VB set); km = 60 / 62 only
+inline bool impvmixu_add_available(const DevGrid &g, bool allow_reg) { return allow_reg && (g.km == 60 || g.km == 62); }
+inline void launch_impvmixu_add(const DevGrid &g, const StepParams &sp, const ImpvmixuArgs &a, dim3 G, hipStream_t st) {
+  const dim3 B(POP_COL_THREADS);
+  const dim3 G2(G.x, G.y, 2);
+  const bool small = (long long)g.n2 * g.nblocks <= (1 << 19);
+  if (g.km == 60 && small) hipLaunchKernelGGL((k_impvmixu_reg<60, 2, true>), G2, B, 0, st, g, sp, a);
+  else if (g.km == 60) hipLaunchKernelGGL((k_impvmixu_reg<60, 1, true>), G2, B, 0, st, g, sp, a);
+  else if (small) hipLaunchKernelGGL((k_impvmixu_reg<62, 2, true>), G2, B, 0, st, g, sp, a);
+  else hipLaunchKernelGGL((k_impvmixu_reg<62, 1, true>), G2, B, 0, st, g, sp, a);
 }
 
 }  // namespace pop

@@ -56,12 +56,13 @@ struct pop_ctx {
   // coefficients (own output buffers d2t / d2u instead of the shared scratch; POP_DEL4_SIDE=0: in line, scratch reused)
   double *d2t[2] = {nullptr, nullptr}, *d2u[2] = {nullptr, nullptr};
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_d2t = nullptr, ev_d2u = nullptr, ev_vmixu = nullptr;
-  bool side_del4 = false, vmixu_pending = false, btrop_added = false;   // implicit vertical mixing of U,V in flight on the side stream
+  bool side_del4 = false, vmixu_pending = false, btrop_added = false, vmixu_deferred = false;   // implicit vertical mixing of U,V in flight on the side stream
   double *HBLT = nullptr, *HMXL = nullptr, *HMXL_DR = nullptr;
   MixDev mix{};
   // KPP look-ahead: the vertical-mixing coefficients of the NEXT step depend only on this step's curtime fields (its
   // mixtime on a leapfrog step), so pop_step computes them on a third stream beside the barotropic solver (VALU-bound
   // work beside bandwidth-bound work) into a second set of output fields; the next step swaps the sets in.
+  bool vdc_shared = false;
   double *VDCa[2] = {nullptr, nullptr}, *VVCa = nullptr, *KPPa[MAXNT] = {}, *HBLTa = nullptr;
   hipStream_t ahead = nullptr; hipEvent_t ev_ahead_fork = nullptr, ev_ahead = nullptr;
   bool ahead_enabled = false, ahead_valid = false; int ahead_slot = -1;
@@ -1403,7 +1404,13 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   }
   for (int n = 0; n < h.nt; ++n)
     if (dev_alloc(c, &c->STF[n], a2) || dev_alloc(c, &c->TFW[n], a2) || dev_alloc(c, &c->KPP_SRC[n], a3)) return 1;
-  for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->VDC[n], (size_t)(h.km + 2) * a2)) return 1;
+  // KPP without double diffusion gives both tracer classes the same diffusivity, value for value (vmix_kpp.F90 ri_iwmix: VDC(:,:,k,2) =
+  // VDC(:,:,k,1); blmix applies the same shape function to both): one array then serves both, so the KPP kernels write it once and
+  // the tracer kernels find the second read in cache.  pop_get_field("VDC", n) returns it for n = 0 and 1.
+  c->vdc_shared = cfg->vmix_choice == 3 && !cfg->ldbl_diff && !(getenv("POP_VDC_SHARED") && atoi(getenv("POP_VDC_SHARED")) == 0);
+  if (dev_alloc(c, &c->VDC[0], (size_t)(h.km + 2) * a2)) return 1;
+  if (c->vdc_shared) c->VDC[1] = c->VDC[0];
+  else if (dev_alloc(c, &c->VDC[1], (size_t)(h.km + 2) * a2)) return 1;
   double **two[] = {&c->PGUESS, &c->FW, &c->FW_OLD, &c->SHF_QSW, &c->CHL, &c->DH, &c->DHU, &c->ZX, &c->ZY, &c->UH, &c->VH, &c->W3, &c->W4, &c->RHS,
                     &c->R, &c->S0, &c->S1, &c->Q, &c->Z, &c->AZ, &c->HBLT, &c->HMXL, &c->HMXL_DR};
   for (auto p : two) if (dev_alloc(c, p, a2)) return 1;
@@ -1635,7 +1642,10 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   c->ahead_enabled = cfg->vmix_choice == 3 && c->side && (h.n2 * h.nblocks > (1u << 19));
   if (getenv("POP_KPP_AHEAD")) c->ahead_enabled = cfg->vmix_choice == 3 && c->side && atoi(getenv("POP_KPP_AHEAD")) != 0;
   if (c->ahead_enabled) {
-    for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->VDCa[n], (size_t)(h.km + 2) * a2) || dev_alloc(c, &c->KPPa[n], a3)) return 1;
+    for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->KPPa[n], a3)) return 1;
+    if (dev_alloc(c, &c->VDCa[0], (size_t)(h.km + 2) * a2)) return 1;
+    if (c->vdc_shared) c->VDCa[1] = c->VDCa[0];
+    else if (dev_alloc(c, &c->VDCa[1], (size_t)(h.km + 2) * a2)) return 1;
     if (dev_alloc(c, &c->VVCa, a3) || dev_alloc(c, &c->HBLTa, a2)) return 1;
     HIPCHK(c, hipStreamCreateWithFlags(&c->ahead, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_ahead_fork, hipEventDisableTiming));
@@ -1761,7 +1771,11 @@ static int ahead_cancel(pop_ctx *c) {
   if (c->ahead_valid) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0)); c->ahead_valid = false; }
   return 0;
 }
+static int phase_impvmixu(pop_ctx *c, hipStream_t st);
 static int join_side(pop_ctx *c, bool keep_ahead = false) {
+  // implicit vertical mixing of U, V held back for the fused form of baroclinic_correct_adjust: a caller that looks at (or changes)
+  // fields in between gets the plain kernel now, and the barotropic velocity is added by its own launch later
+  if (c->vmixu_deferred) { c->vmixu_deferred = false; if (phase_impvmixu(c, nullptr)) return 1; }
   if (c->vmixu_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_vmixu, 0)); c->vmixu_pending = false; }
   if (!keep_ahead && ahead_cancel(c)) return 1;
   return 0;
@@ -2129,7 +2143,7 @@ static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1) {
   else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
   return 0;
 }
-static int phase_impvmixu(pop_ctx *c, hipStream_t st = nullptr) {
+static int phase_impvmixu(pop_ctx *c, hipStream_t st) {
   ImpvmixuArgs a{c->U[c->newt], c->V[c->newt], c->E3, c->U[c->oldt], c->V[c->oldt], c->VVC};
   launch_impvmixu(c->g, step_params(c), a, grid_cols(c), st ? st : c->stream, c->reg_thomas);
   return 0;
@@ -2149,6 +2163,7 @@ static int phase_add_btrop(pop_ctx *c, hipStream_t st = nullptr) {
 int pop_baroclinic_driver(pop_ctx *c) {
   if (need_device(c)) return 1;
   ScopedPhase ph(c, "BAROCLINIC");
+  if (c->vmixu_deferred) { c->vmixu_deferred = false; if (phase_impvmixu(c, nullptr)) return 1; }   // a driver call that was never followed by its correct_adjust
   const StepParams sp = step_params(c);
   const bool fork = c->side_del4;
   if (fork) {   // del4 first Laplacians beside the vertical-mixing coefficients
@@ -2196,13 +2211,21 @@ int pop_baroclinic_driver(pop_ctx *c) {
   }
   // the implicit vertical mixing of U, V is not needed before the step tail: with the register kernel (no shared scratch)
   // it runs on the side stream beside the barotropic solver, whose one-workgroup reduction kernels leave the GPU idle
-  if (c->side && c->reg_thomas && (c->g.km == 60 || c->g.km == 62) && !getenv("POP_VMIXU_INLINE")) {
+  // bandwidth-bound grids: held back until the barotropic solve has finished and launched then with the barotropic velocity added on
+  // the way out (k_impvmixu_reg<., ., true>): the separate k_add_barotropic pass over U, V(new) is gone.  Nothing between here and
+  // baroclinic_correct_adjust reads U, V(new); a caller that does (any field access: join_side) gets the plain kernel first.
+  // Not across a tripole fold (the sum follows the halo update there).  POP_VMIXU_DEFER=0|1 overrides the size rule.
+  const int defer_env = getenv("POP_VMIXU_DEFER") ? atoi(getenv("POP_VMIXU_DEFER")) : -1;
+  const bool defer = c->side && impvmixu_add_available(c->g, c->reg_thomas) && c->h.c.ns_boundary != 2 && !getenv("POP_BTROP_INLINE") &&
+                     !getenv("POP_VMIXU_INLINE") && (defer_env >= 0 ? defer_env != 0 : (long long)c->g.n2 * c->g.nblocks > (1 << 19));
+  if (defer) c->vmixu_deferred = true;
+  else if (c->side && c->reg_thomas && (c->g.km == 60 || c->g.km == 62) && !getenv("POP_VMIXU_INLINE")) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     if (phase_impvmixu(c, c->side)) return 1;
     HIPCHK(c, hipEventRecord(c->ev_vmixu, c->side));
     c->vmixu_pending = true;
-  } else if (phase_impvmixu(c)) return 1;
+  } else if (phase_impvmixu(c, nullptr)) return 1;
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -2312,7 +2335,15 @@ int pop_baroclinic_correct_adjust(pop_ctx *c) {
   // same sum at every cell; the halo update of U, V in the step tail then carries it to the ghost cells.  Not beyond a
   // tripole fold: there the update symmetrises |U| of the degenerate top row, which does not commute with the sum, so the
   // reference's order (halo updates first, step_mod.F90:467-513, then the sum over whole blocks) is kept.
-  if (c->side && !getenv("POP_BTROP_INLINE") && c->h.c.ns_boundary != 2) {
+  if (c->vmixu_deferred) {   // implicit vertical mixing of U, V and the sum in one launch (see pop_baroclinic_driver)
+    c->vmixu_deferred = false;
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    ImpvmixuArgs a{c->U[c->newt], c->V[c->newt], c->E3, c->U[c->oldt], c->V[c->oldt], c->VVC, c->UB[c->newt], c->VB[c->newt]};
+    launch_impvmixu_add(c->g, step_params(c), a, grid_cols(c), c->side);
+    HIPCHK(c, hipEventRecord(c->ev_vmixu, c->side));
+    c->vmixu_pending = true; c->btrop_added = true;
+  } else if (c->side && !getenv("POP_BTROP_INLINE") && c->h.c.ns_boundary != 2) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     if (phase_add_btrop(c, c->side)) return 1;
@@ -2862,7 +2893,7 @@ static phase_fn_t phase_by_name(const std::string &p) {
   if (p == "impvmixt") return phase_impvmixt_pred;
   if (p == "state") return phase_state_new;
   if (p == "momentum_rhs") return [](pop_ctx *x) { return phase_momentum_rhs(x); };
-  if (p == "impvmixu") return [](pop_ctx *x) { return phase_impvmixu(x); };
+  if (p == "impvmixu") return [](pop_ctx *x) { return phase_impvmixu(x, nullptr); };
   if (p == "correct") return phase_correct;
   if (p == "add_btrop") return [](pop_ctx *x) { return phase_add_btrop(x); };
   if (p == "hmix_tracer") return [](pop_ctx *x) { return phase_hmix_tracer(x); };

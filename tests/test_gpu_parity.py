@@ -538,6 +538,64 @@ def test_momentum_kernels_agree_bitwise(pkg, monkeypatch, kw):
             assert np.array_equal(a, b), rows
 
 
+@pytest.mark.parametrize("kw", [{"km": 62}, {"km": 60, "vmix_choice": 3, "stepped_bathymetry": 1},
+                                {"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "block_size_x": 48, "block_size_y": 40}])
+def test_deferred_vertical_mixing_with_barotropic_sum_is_bitwise_invisible(pkg, monkeypatch, kw):
+    """Large grids hold the implicit vertical mixing of U, V back until the barotropic solve has finished and add the
+    barotropic velocity in its final store (k_impvmixu_reg<., ., true>).  Forced here on a small grid: equal to the last
+    bit to the two-launch form, over Euler, averaging and leapfrog steps; and a caller that reads a field between the
+    driver calls (which flushes the held-back launch) sees the same fields as the phase-by-phase run."""
+    cfg = named_config("tiny", **kw)
+    names = ("UVEL", "VVEL", "TRACER", "PSURF", "UBTROP", "RHO")
+    out = {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("POP_VMIXU_DEFER", defer)
+        m = pkg.PopModel(cfg)
+        for _ in range(5):
+            m.step()
+        out[defer] = [m.get(n, 1, 0).copy() for n in names] + [m.get(n, 2, 0).copy() for n in names]
+        m.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+    # interrupted sequence: a field read after baroclinic_driver must show the mixed velocity, and the step must end the same
+    monkeypatch.setenv("POP_VMIXU_DEFER", "1")
+    m = pkg.PopModel(cfg)
+    monkeypatch.setenv("POP_VMIXU_DEFER", "0")
+    r = pkg.PopModel(cfg)
+    for s_ in range(3):
+        for x in (m, r):
+            x.time_manager(); x.dhdt(); x.baroclinic_driver()
+        for n in ("UVEL", "VVEL"):          # new time level, between the drivers
+            assert np.array_equal(m.get(n, 2, 0), r.get(n, 2, 0)), (s_, n)
+        for x in (m, r):
+            x.barotropic_driver(); x.baroclinic_correct_adjust(); x.step_tail()
+        for n in names:
+            assert np.array_equal(m.get(n, 1, 0), r.get(n, 1, 0)), (s_, n)
+    m.close(); r.close()
+
+
+@pytest.mark.parametrize("kw,env", [({"vmix_choice": 3, "km": 24}, {}), ({"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1}, {"POP_KPP_COL": "15", "POP_XCD_REMAP": "0"}),
+                                    ({"vmix_choice": 3, "km": 60}, {"POP_KPP_COL": "3"})])
+def test_kpp_shared_diffusivity_array_is_bitwise_invisible(pkg, monkeypatch, kw, env):
+    """KPP without double diffusion gives both tracer classes the same diffusivity value for value, so the library keeps one
+    array for both (POP_VDC_SHARED=0 keeps two).  Two arrays hold identical values, and the runs agree to the last bit."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for shared in ("0", "1"):
+        monkeypatch.setenv("POP_VDC_SHARED", shared)
+        m = pkg.PopModel(cfg)
+        for _ in range(4):
+            m.step()
+        out[shared] = [m.get("VDC", 1, 0).copy(), m.get("VDC", 1, 1).copy()] + [m.get(n, 1, 0).copy() for n in ("UVEL", "TRACER", "PSURF", "VVC", "HBLT")] + [m.get("TRACER", 1, 1).copy(), m.get("KPP_SRC", 1, 1).copy()]
+        m.close()
+    assert np.array_equal(out["0"][0], out["0"][1]), "the two classes differ without double diffusion"
+    assert np.abs(out["0"][0]).max() > 0.0
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("kw,env", [
     ({"km": 62}, {}),                                                    # tx0.1v3 level count: k_impvmixu_reg<62>, generic tracer solve
     ({"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21},
