@@ -92,6 +92,7 @@ def test_multirank_equals_single_rank(nranks, kw, env):
     (3, "block_size_x=24,block_size_y=20,vmix_choice=3,km=24", {}),   # uneven ownership, KPP
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3
     (4, "tadvect=3,block_size_x=24,block_size_y=20", {}),             # lw_lim, one block per rank
+    (2, "km=62,vmix_choice=3,ny_global=80,block_size_x=48,block_size_y=40", {"POP_VMIXU_DEFER": "1", "POP_SOLVER_DISTRIBUTED": "1"}),   # U,V vertical mixing held back past the distributed solve
 ])
 def test_native_transport_equals_single_rank(nranks, kw, env):
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
