@@ -253,7 +253,9 @@ k_kpp_buoydiff_lds(DevGrid g, KppDev kp, const double *__restrict__ T, const dou
 // Richardson scratch field and the second pass over T, S, U, V of the column kernels are gone.  All loops stay rolled (a
 // fully unrolled variant was 153 KB of code and ran at instruction-cache speed: 20 ms instead of 9).  Same operations
 // in the same order per value as k_kpp_buoydiff_col + k_kpp_interior(_reg): bitwise equal (tested).  km <= 64.
-template <int KR, int NG>
+// SFC = false: DBSFC is not formed here (k_kpp_bldepth_lazy evaluates it on demand, level by level, until the boundary-layer
+// depth is found); the surface-layer levels are then not prepared and the rhoavg sums -- most of this kernel's arithmetic -- are gone.
+template <int KR, int NG, bool SFC = true>
 __global__ void __launch_bounds__(POP_COL_THREADS * NG)
 k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
                         const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ DBLOC,
@@ -271,17 +273,19 @@ k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, cons
   const long long n2 = g.n2, base3 = (long long)b * g.n3 + p2;
   const int ci = p2 % nxb, cj = p2 / nxb;
   const bool edge = (ci == 0 || cj == 0);          // ugrid_to_tgrid zeroes the first row and column
-  for (int t = 1 + gy; t <= KR; t += NG) {
-    const int kk = (t <= km) ? t : km;
-    const long long o = base3 + (long long)(kk - 1) * n2;
-    const MwjfTS2 x = mwjf_prep2(tmask(T[o]), S[o]);
-    shtop[t - 1][tx] = x.TQ; shtop[KR + t - 1][tx] = x.SQ; shtop[2 * KR + t - 1][tx] = x.A2;
+  if (SFC) {
+    for (int t = 1 + gy; t <= KR; t += NG) {
+      const int kk = (t <= km) ? t : km;
+      const long long o = base3 + (long long)(kk - 1) * n2;
+      const MwjfTS2 x = mwjf_prep2(tmask(T[o]), S[o]);
+      shtop[t - 1][tx] = x.TQ; shtop[KR + t - 1][tx] = x.SQ; shtop[2 * KR + t - 1][tx] = x.A2;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int kmt = live ? g.KMT[(long long)b * n2 + p2] : 0;
   auto top_at = [&](int t) { MwjfTS2 x; x.TQ = shtop[t - 1][tx]; x.SQ = shtop[KR + t - 1][tx]; x.A2 = shtop[2 * KR + t - 1][tx]; return x; };
   const long long off4[4] = {0, -(long long)nxb, -1, -1 - (long long)nxb};
-  if (live && gy == 0) DBSFC[base3] = 0.0;
+  if (SFC && live && gy == 0) DBSFC[base3] = 0.0;
 #pragma unroll 1
   for (int k = 2 + gy; k <= km; k += NG) {
     double ri = 0.0;
@@ -301,19 +305,23 @@ k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, cons
       const MwjfP P = mwjf_level(g.pressz[k]);
       const double rhokm = mwjf_eval2(P, xkm);
       const double rhok = mwjf_eval2(P, xk);
-      const double surfthick = KPP_EPSSFC * g.zt[k];
-      const int kref = kp.kref[k];                 // wave-uniform (k is)
-      double rhoavg = mwjf_eval2(P, top_at(kref));
-      if (kref != 1) {
-        rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
+      double dbl = 0.0;
+      if (SFC) {
+        const double surfthick = KPP_EPSSFC * g.zt[k];
+        const int kref = kp.kref[k];                 // wave-uniform (k is)
+        double rhoavg = mwjf_eval2(P, top_at(kref));
+        if (kref != 1) {
+          rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
 #pragma unroll 1
-        for (int kt = 1; kt <= kref - 1; ++kt) rhoavg = rhoavg + g.dz[kt] * mwjf_eval2(P, top_at(kt));
-        rhoavg = rhoavg / surfthick;
+          for (int kt = 1; kt <= kref - 1; ++kt) rhoavg = rhoavg + g.dz[kt] * mwjf_eval2(P, top_at(kt));
+          rhoavg = rhoavg / surfthick;
+        }
+        double dbs = 0.0;
+        if (rhok != 0.0) dbs = GRAV * (1.0 - rhoavg / rhok);
+        DBSFC[o] = dbs;
       }
-      double dbs = 0.0, dbl = 0.0;
-      if (rhok != 0.0) { dbs = GRAV * (1.0 - rhoavg / rhok); dbl = GRAV * (1.0 - rhokm / rhok); }
+      if (rhok != 0.0) dbl = GRAV * (1.0 - rhokm / rhok);
       if (k - 1 >= kmt) dbl = 0.0;
-      DBSFC[o] = dbs;
       DBLOC[o - n2] = dbl;
       if (k == km) DBLOC[o] = 0.0;
       double vsh = 0.0;
@@ -682,10 +690,22 @@ k_kpp_ushear(DevGrid g, KppDev kp, const double *__restrict__ U, const double *_
 }
 
 // ---- bldepth, part 2: bulk Richardson number march -> unsmoothed HBLT, KBL ---------------------
+// LAZY: the buoyancy difference against the surface layer (DBSFC of buoydiff: up to 1 + kref equation-of-state evaluations per
+// level, the bulk of KPP's arithmetic) is formed here, on demand, for the level the march is at -- same operations in the same
+// order as k_kpp_buoy_interior_lds, from surface-layer levels prepared into LDS as kref grows -- and the wave leaves the march
+// once none of its 64 columns can change any more: a column's (HBLT, KBL) are final after its first crossing of the critical bulk
+// Richardson number, and no crossing happens below its bottom (wk = 0 there), so the levels that are skipped only rotated
+// rib_* / z_*.  BFSFC ("value of the last pass") is formed for kl = km directly.  Results are bitwise those of the full march
+// (tested); the reference's array form (vmix_kpp.F90 bldepth :2280-2520) has no such exit.  Not with lcheckekmo (its Ekman / Monin-
+// Obukhov limits march every level) and not with the mixed-layer-depth diagnostics (they read DBSFC at every level).
+template <bool LAZY, int KR>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
               const double *__restrict__ STF1, const double *__restrict__ STF2, const double *__restrict__ DBLOC,
               const double *__restrict__ DBSFC, const double *__restrict__ WU) {
+  static_assert(POP_COL_THREADS == 64, "the lazy march votes over one 64-lane wave");
+  __shared__ double shtop[LAZY ? 3 * KR : 1][POP_COL_THREADS];
+  int nprep = 0;                                   // surface-layer levels prepared so far (wave-uniform)
   Col c;
   if (!col_setup(g, c, false)) return;
   const int km = g.km, nxb = g.nxb;
@@ -719,9 +739,33 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
     hmon_up = (w <= -z_up) ? -z_up + KPP_EPS : w;
   }
   for (int kl = 2; kl <= km; ++kl) {
+    if (LAZY && __builtin_amdgcn_ballot_w64(kbl == kmt && kl <= kmt) == 0) break;
     const long long o = c.base3 + (long long)(kl - 1) * n2;
     const double surfthick = KPP_EPSSFC * g.zt[kl];
     const double zkl = -kp.zgrid[kl];
+    double dbsfc;
+    if (LAZY) {
+      const int kref = kp.kref[kl];                // wave-uniform
+      for (; nprep < kref; ++nprep) {
+        const int kk = (nprep + 1 <= km) ? nprep + 1 : km;
+        const long long ot = c.base3 + (long long)(kk - 1) * n2;
+        const MwjfTS2 x = mwjf_prep2(tmask(T[ot]), S[ot]);
+        shtop[nprep][threadIdx.x] = x.TQ; shtop[KR + nprep][threadIdx.x] = x.SQ; shtop[2 * KR + nprep][threadIdx.x] = x.A2;
+      }
+      auto top_at = [&](int t) { MwjfTS2 x; x.TQ = shtop[t - 1][threadIdx.x]; x.SQ = shtop[KR + t - 1][threadIdx.x]; x.A2 = shtop[2 * KR + t - 1][threadIdx.x]; return x; };
+      const MwjfTS2 xk = mwjf_prep2(tmask(T[o]), S[o]);
+      const MwjfP P = mwjf_level(g.pressz[kl]);
+      const double rhok = mwjf_eval2(P, xk);
+      double rhoavg = mwjf_eval2(P, top_at(kref));
+      if (kref != 1) {
+        rhoavg = rhoavg * (surfthick - g.zw[kref - 1]);
+#pragma unroll 1
+        for (int kt = 1; kt <= kref - 1; ++kt) rhoavg = rhoavg + g.dz[kt] * mwjf_eval2(P, top_at(kt));
+        rhoavg = rhoavg / surfthick;
+      }
+      dbsfc = 0.0;
+      if (rhok != 0.0) dbsfc = GRAV * (1.0 - rhoavg / rhok);
+    } else dbsfc = DBSFC[o];
     double vshear = 0.0;
     if (!edge) vshear = fmax(fmax(WU[o], WU[o - 1]), fmax(WU[o - nxb], WU[o - 1 - nxb]));
     bfsfc = kpp_bfsfc(kp, bo, bosol, zkl, 2 * kl - 1, chli);
@@ -742,7 +786,7 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
     const double bfr = sqrt(0.5 * (db + fabs(db) + KPP_EPS2) / (kp.zgrid[kl] - kp.zgrid[kl + 1]));
     const double zref = -surfthick / 2.0;
     const double wmm = zkl * ws * bfr * ((kp.Vtc / KPP_RICR) * fmax(2.1 - 200.0 * bfr, KPP_CONCV));
-    const double wk = (kmt >= kl) ? (zref - kp.zgrid[kl]) * DBSFC[o] : 0.0;
+    const double wk = (kmt >= kl) ? (zref - kp.zgrid[kl]) * dbsfc : 0.0;
     const double rib_dn = wk / (vshear + wmm + KPP_EPS);
     if (kbl == kmt && rib_dn > KPP_RICR) {
       const double slope_up = (rib_upper - rib_up) / (z_up - z_upper);
@@ -763,6 +807,10 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
     if (hekman < hlimit) hlimit = hekman;
     for (int kl = 2; kl <= km; ++kl)
       if (hlimit < hblt && hlimit > -kp.zgrid[kl - 1] && hlimit <= -kp.zgrid[km]) { hblt = hlimit; kbl = kl; }
+  }
+  if (LAZY && km >= 2) {      // what the pass kl = km leaves in bfsfc
+    bfsfc = kpp_bfsfc(kp, bo, bosol, -kp.zgrid[km], 2 * km - 1, chli);
+    bfsfc = bfsfc + ((bfsfc >= 0.0) ? 1.0 : 0.0) * KPP_EPS;
   }
   kp.HBLT0[c.q2] = hblt;
   kp.KBL0[c.q2] = kbl;
@@ -1139,7 +1187,11 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   const dim3 GL(col_grid_x(g.n2, POP_COL_THREADS), g.nblocks), BL(POP_COL_THREADS, 4);
   // bit 3: buoydiff and the interior coefficients in ONE level-parallel launch
   const bool fused_bi = (g_kpp_col & 8) && KH.max_kref <= 20 && g.xcd_remap != 2 && g.km <= 64;
-  if (fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
+  // the surface-layer buoyancy difference on demand inside the boundary-layer-depth march (k_kpp_bldepth<true, .>); POP_KPP_LAZY=0 keeps
+  // the full field
+  const bool lazy = fused_bi && !g_kpp.lcheckekmo && h.c.reserved_i[5] != 1 && !(getenv("POP_KPP_LAZY") && atoi(getenv("POP_KPP_LAZY")) == 0);
+  if (lazy) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8, false>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
+  else if (fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if ((g_kpp_col & 4) && KH.max_kref <= 20 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<20, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if ((g_kpp_col & 4) && KH.max_kref <= 28 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<28, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if ((g_kpp_col & 2) && KH.max_kref <= 20 && bw == 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<20, 2>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
@@ -1151,8 +1203,10 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   // on the side stream and runs beside the interior coefficients; blmix waits for both
   if (KH.side) {
     hipEventRecord(KH.ev_bd, st); hipStreamWaitEvent(KH.side, KH.ev_bd, 0);
-    hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
-                       (const double *)DBSFC, (const double *)WU);
+    if (lazy) hipLaunchKernelGGL((k_kpp_bldepth<true, 20>), GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                                 (const double *)DBSFC, (const double *)WU);
+    else hipLaunchKernelGGL((k_kpp_bldepth<false, 20>), GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                            (const double *)DBSFC, (const double *)WU);
     hipEventRecord(KH.ev_join, KH.side);
   }
   static const bool int_reg = !getenv("POP_KPP_INTERIOR_GENERIC");
@@ -1161,7 +1215,9 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   else if (int_reg && g.km == 62) hipLaunchKernelGGL(k_kpp_interior_reg<62>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
   if (KH.side) hipStreamWaitEvent(st, KH.ev_join, 0);
-  else hipLaunchKernelGGL(k_kpp_bldepth, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+  else if (lazy) hipLaunchKernelGGL((k_kpp_bldepth<true, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                                    (const double *)DBSFC, (const double *)WU);
+  else hipLaunchKernelGGL((k_kpp_bldepth<false, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                           (const double *)DBSFC, (const double *)WU);
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                      s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);

@@ -538,6 +538,38 @@ def test_momentum_kernels_agree_bitwise(pkg, monkeypatch, kw):
             assert np.array_equal(a, b), rows
 
 
+@pytest.mark.parametrize("kw,env", [
+    ({"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21}, {"POP_KPP_COL": "15", "POP_XCD_REMAP": "0"}),
+    ({"vmix_choice": 3, "km": 24, "lshort_wave": 1, "sw_absorption_type": 1}, {"POP_KPP_COL": "15"}),
+    ({"vmix_choice": 3, "km": 60, "block_size_x": 48, "block_size_y": 40}, {"POP_KPP_COL": "15", "POP_KPP_SIDE_STREAM": "0"}),
+])
+def test_kpp_on_demand_surface_buoyancy_is_bitwise_invisible(pkg, orclib_built, monkeypatch, kw, env):
+    """k_kpp_bldepth<true>: the buoyancy difference against the surface layer is evaluated inside the bulk-Richardson march,
+    only down to the level where the last column of a wave has found its boundary-layer depth, instead of at every level by
+    the buoydiff kernel.  Same operations in the same order: every output of the step is equal to the last bit, on a state
+    whose boundary layer spans several levels (and the minimum depth elsewhere)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for lazy in ("0", "1"):
+        monkeypatch.setenv("POP_KPP_LAZY", lazy)
+        m, orc = pkg.PopModel(cfg), Oracle(cfg)
+        force_kpp_case(m, orc)
+        if kw.get("lshort_wave"):
+            m.set("SHF_QSW", 5.0e-3 * (1.0 + np.cos(orc.f2("TLAT"))))
+        orc.close()
+        for _ in range(4):
+            m.step()
+        out[lazy] = [m.get("HBLT").copy(), m.get("VDC", 1, 0).copy(), m.get("VVC").copy()] + [m.get("KPP_SRC", 1, n).copy() for n in (0, 1)] + \
+                    [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "RHO")] + [m.get("TRACER", 1, 1).copy()]
+        m.close()
+    h = out["0"][0]
+    assert h.max() > 3.0 * h[h > 0].min(), "the boundary layer has one depth everywhere: the march exits at once in every wave"
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("kw", [{"km": 62}, {"km": 60, "vmix_choice": 3, "stepped_bathymetry": 1},
                                 {"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "block_size_x": 48, "block_size_y": 40}])
 def test_deferred_vertical_mixing_with_barotropic_sum_is_bitwise_invisible(pkg, monkeypatch, kw):
