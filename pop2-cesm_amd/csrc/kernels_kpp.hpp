@@ -1165,11 +1165,15 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   return 0;
 }
 
+// KBL of the last evaluation (the tracer kernel reads KPP_SRC down to it only)
+inline const int *mix_kpp_kbl(const MixDev &m) { return m.kpp ? ((const KppHost *)m.kpp)->dev.KBL : nullptr; }
+
 inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParams &sp, const MixDev &m, const MixState &s,
                            hipStream_t st, std::string &err) {
   const KppHost &KH = *(const KppHost *)m.kpp;
   KppDev g_kpp = KH.dev;
   g_kpp.SHF_QSW = s.SHF_QSW; g_kpp.FCORT = g.FCORT;
+  if (s.KBL) g_kpp.KBL = s.KBL;
   const int g_kpp_col = KH.col;
   const dim3 GC(col_grid(g, POP_COL_THREADS), g.nblocks), BC(POP_COL_THREADS);
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);

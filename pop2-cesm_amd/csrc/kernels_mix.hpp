@@ -16,6 +16,7 @@ struct MixDev {          // device-resident constants of the mixing schemes
 struct MixState {        // per-step field pointers handed to the mixing kernels
   const double *TMIX[2], *UMIX, *VMIX, *UCUR, *VCUR, *RHOMIX, *STF[2], *SHF_QSW;
   double *VDC[2], *VVC, *KPP_SRC[2], *HBLT, *HMXL, *HMXL_DR;
+  int *KBL = nullptr;        // KPP: level of the boundary-layer depth, paired with KPP_SRC (nullptr: the scheme's own array)
   double *S3a, *S3b, *S3c, *S3d, *E3, *F3;   // 3-D scratch
 };
 

@@ -72,6 +72,9 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
     for (int n = 0; n < 2; ++n) { stf[n] = a.STF[n][q2]; tfw[n] = a.TFW[n][q2]; }
     if (a.sw_on) { sw_q = fmax(a.QSW[q2], 0.0); if (a.sw_type == 2) sw_chli = a.swCHLI[q2]; }
   }
+  // KPP's non-local source is +-0 below level KBL (blmix: ghat = 0 there, so the flux difference is 0 - 0), and the sum below starts
+  // from +0.0, so a level that is not read adds the same +0.0: rows of a level in which every column is past its KBL are not fetched
+  const int ksrc = (act && a.use_kpp_src) ? (a.KBL ? a.KBL[q2] : km) : 0;
   const long long vdcbase = ((long long)b * (km + 2)) * n2 + p2;
   struct Lev { double u, v, tc[2], tm[2], to[2], vdc[2], src[2]; };
   struct Hal { double u, v, tc[2], tm[2]; };
@@ -84,7 +87,7 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
       for (int n = 0; n < 2; ++n) {
         L.tc[n] = a.TCUR[n][o]; L.tm[n] = a.TMIX[n][o]; L.to[n] = a.TOLD[n][o];
         L.vdc[n] = a.VDC[n][vdcbase + (long long)k * n2];
-        L.src[n] = a.use_kpp_src ? a.KPP_SRC[n][o] : 0.0;
+        L.src[n] = (k <= ksrc) ? a.KPP_SRC[n][o] : 0.0;
       }
     }
     return L;

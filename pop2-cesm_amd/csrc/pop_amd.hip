@@ -63,7 +63,9 @@ struct pop_ctx {
   // mixtime on a leapfrog step), so pop_step computes them on a third stream beside the barotropic solver (VALU-bound
   // work beside bandwidth-bound work) into a second set of output fields; the next step swaps the sets in.
   bool vdc_shared = false;
+  bool kpp_src_user = false;   // the caller wrote KPP_SRC (pop_set_field): read it at every level until KPP has run again
   double *VDCa[2] = {nullptr, nullptr}, *VVCa = nullptr, *KPPa[MAXNT] = {}, *HBLTa = nullptr;
+  int *KBL = nullptr, *KBLa = nullptr;   // KBL that belongs to KPP_SRC / KPPa (the tracer kernel reads KPP_SRC down to it)
   hipStream_t ahead = nullptr; hipEvent_t ev_ahead_fork = nullptr, ev_ahead = nullptr;
   bool ahead_enabled = false, ahead_valid = false; int ahead_slot = -1;
   // solver
@@ -1633,6 +1635,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     HIPCHK(c, hipMemcpy(c->VVC, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   if (mix_create(c->h, c->g, c->mix, c->allocs, c->err)) return 1;
+  c->KBL = const_cast<int *>(mix_kpp_kbl(c->mix));
   if (cfg->reserved_d[4] != 0.0 && sw_tables_create(c->h, c->allocs, c->err)) return 1;   // lsw_absorb without KPP's lshort_wave
   if (c->h.sw.CHLI) {   // the default chlorophyll amount the table index was built for
     std::vector<double> chl((size_t)c->g.n2 * c->g.nblocks, 0.25);
@@ -1646,7 +1649,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if (dev_alloc(c, &c->VDCa[0], (size_t)(h.km + 2) * a2)) return 1;
     if (c->vdc_shared) c->VDCa[1] = c->VDCa[0];
     else if (dev_alloc(c, &c->VDCa[1], (size_t)(h.km + 2) * a2)) return 1;
-    if (dev_alloc(c, &c->VVCa, a3) || dev_alloc(c, &c->HBLTa, a2)) return 1;
+    if (dev_alloc(c, &c->VVCa, a3) || dev_alloc(c, &c->HBLTa, a2) || dev_alloc(c, &c->KBLa, a2)) return 1;
     HIPCHK(c, hipStreamCreateWithFlags(&c->ahead, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_ahead_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming));
@@ -1814,6 +1817,7 @@ int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *hos
     for (long long q = 0; q < cnt; ++q) idx[q] = sw_chl_index(c->h.sw, host[q]);
     HIPCHK(c, hipMemcpy(c->h.sw.CHLI, idx.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice));
   }
+  if (!strcmp(name, "KPP_SRC")) c->kpp_src_user = true;
   // a new prognostic state may carry other values on land: the next steps run every workgroup again (land elimination)
   for (const char *f : {"TRACER", "UVEL", "VVEL", "RHO", "PSURF", "GRADPX", "GRADPY", "UBTROP", "VBTROP", "PGUESS", "FW_OLD"})
     if (!strcmp(name, f)) c->full_left = c->land_full_steps;
@@ -2001,6 +2005,7 @@ static MixState kpp_mix_state(pop_ctx *c, int slot, bool into_alt) {
   }
   ms.UMIX = c->U[slot]; ms.VMIX = c->V[slot]; ms.UCUR = c->U[c->curt]; ms.VCUR = c->V[c->curt]; ms.RHOMIX = c->RHO[slot];
   ms.VVC = into_alt ? c->VVCa : c->VVC; ms.SHF_QSW = c->SHF_QSW; ms.HBLT = into_alt ? c->HBLTa : c->HBLT; ms.HMXL = c->HMXL; ms.HMXL_DR = c->HMXL_DR;
+  ms.KBL = into_alt ? c->KBLa : c->KBL;
   ms.S3a = c->S3a; ms.S3b = c->S3b; ms.S3c = c->S3c; ms.S3d = c->S3d; ms.E3 = c->E3; ms.F3 = c->F3;
   return ms;
 }
@@ -2012,14 +2017,15 @@ static int phase_vmix(pop_ctx *c) {
   else {
     if (c->ahead_valid && c->ahead_slot == c->mixt) {   // computed beside the previous step's solver: swap the output sets in
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
-      c->ahead_valid = false;
+      c->ahead_valid = false; c->kpp_src_user = false;
       for (int n = 0; n < 2; ++n) { std::swap(c->VDC[n], c->VDCa[n]); std::swap(c->KPP_SRC[n], c->KPPa[n]); }
-      std::swap(c->VVC, c->VVCa); std::swap(c->HBLT, c->HBLTa);
+      std::swap(c->VVC, c->VVCa); std::swap(c->HBLT, c->HBLTa); std::swap(c->KBL, c->KBLa);
       return 0;
     }
     if (ahead_cancel(c)) return 1;
     const MixState ms = kpp_mix_state(c, c->mixt, false);
     if (mix_vmix_coeffs(c->h, c->g, sp, c->mix, ms, c->stream, c->err)) return 1;
+    c->kpp_src_user = false;
   }
   return 0;
 }
@@ -2075,6 +2081,7 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->d2t[0]; a.TMIX[1] = c->d2t[1]; }   // del4: second Laplacian acts on D2T
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
   a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
+  if (a.use_kpp_src && !c->kpp_src_user && !getenv("POP_KPP_SRC_FULL")) a.KBL = c->KBL;
   if (c->h.c.reserved_d[4] != 0.0) {   // lsw_absorb: penetrating short wave (add_sw_absorb)
     a.sw_on = 1; a.sw_type = c->h.c.reserved_i[6]; a.sw_ksol = c->h.sw.ksol;
     a.QSW = c->SHF_QSW; a.swabs = c->h.sw.swabs; a.swTr = c->h.sw.Tr; a.swCHLI = c->h.sw.CHLI;

@@ -570,6 +570,40 @@ def test_kpp_on_demand_surface_buoyancy_is_bitwise_invisible(pkg, orclib_built, 
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kw,env", [
+    ({"vmix_choice": 3, "km": 24}, {}),
+    ({"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1}, {"POP_KPP_AHEAD": "1", "POP_KPP_COL": "15", "POP_XCD_REMAP": "0"}),   # look-ahead: KBL travels with its KPP_SRC
+    ({"vmix_choice": 3, "km": 60, "tmix_opt": 3}, {"POP_KPP_AHEAD": "1", "POP_TRACER_LDS": "8"}),
+])
+def test_nonlocal_source_read_down_to_kbl_only_is_bitwise_invisible(pkg, orclib_built, monkeypatch, kw, env):
+    """KPP's non-local source is +-0 below level KBL, and the tracer kernel starts its source sum from +0.0: not reading those
+    levels (the default) leaves every field equal to the last bit to reading them all (POP_KPP_SRC_FULL=1) -- also when the
+    coefficients come from the look-ahead evaluation, and after a caller has written KPP_SRC itself."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for full in ("1", ""):
+        if full:
+            monkeypatch.setenv("POP_KPP_SRC_FULL", full)
+        else:
+            monkeypatch.delenv("POP_KPP_SRC_FULL", raising=False)
+        m, orc = pkg.PopModel(cfg), Oracle(cfg)
+        force_kpp_case(m, orc)
+        orc.close()
+        for _ in range(5):
+            m.step()
+        src = m.get("KPP_SRC", 1, 0)
+        assert np.abs(src).max() > 0.0
+        m.set("KPP_SRC", np.full_like(src, 1.0e-7), n=0)     # a caller's own source, non-zero at every level: must be read in full
+        m.time_manager(); m.dhdt()
+        m.run_phase("hmix_tracer"); m.run_phase("tracer_rhs")
+        out[full] = [m.get("TRACER", 2, 0).copy(), m.get("TRACER", 1, 0).copy(), m.get("TRACER", 1, 1).copy(), m.get("UVEL", 1, 0).copy(), src.copy()]
+        m.close()
+    for a, b in zip(out["1"], out[""]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("kw", [{"km": 62}, {"km": 60, "vmix_choice": 3, "stepped_bathymetry": 1},
                                 {"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "block_size_x": 48, "block_size_y": 40}])
 def test_deferred_vertical_mixing_with_barotropic_sum_is_bitwise_invisible(pkg, monkeypatch, kw):
