@@ -116,7 +116,10 @@ int pop_local_block_ids(const pop_ctx *ctx, int *ids /* nblocks local */);
 /* ---- state transfer: host arrays in the reference layout -------------------- */
 /* name = the reference's variable name (TRACER, UVEL, VVEL, RHO, PSURF, GRADPX, GRADPY, UBTROP,
  * VBTROP, PGUESS, FW, FW_OLD, SMF, SMFT, STF, TFW, SHF_QSW, ZX, ZY, DH, DHU, VDC, VVC, RHS, grid
- * fields DXU ... ); tl = logical time level; n = tracer / vector component. */
+ * fields DXU ... ); tl = logical time level; n = tracer / vector component.
+ * VDC (levels 0 .. km+1): n = 0 / 1 are KPP's two tracer classes.  Without double diffusion (ldbl_diff = 0) the reference fills
+ * both with the same values (vmix_kpp.F90 ri_iwmix / blmix) and the library keeps ONE array for them: n = 0 and n = 1 read and
+ * write the same storage.  KPP_SRC: a value written with pop_set_field is used at every level until KPP has run again. */
 int pop_get_field(pop_ctx *ctx, const char *name, int tl, int n, double *host, long long count);
 int pop_set_field(pop_ctx *ctx, const char *name, int tl, int n, const double *host, long long count);
 int pop_get_ifield(pop_ctx *ctx, const char *name, int *host, long long count);

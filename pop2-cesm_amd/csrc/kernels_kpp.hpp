@@ -91,6 +91,8 @@ __device__ __forceinline__ double kpp_bfsfc(const KppDev &kp, double bo, double 
 }
 
 // ---- buoydiff: 3-D parallel, one thread per (i,j,k); level k yields DBSFC(k) and DBLOC(k-1) ------
+// SFC = false: DBLOC only (k_kpp_bldepth<true, .> evaluates DBSFC on demand)
+template <bool SFC>
 __global__ void __launch_bounds__(256)
 k_kpp_buoydiff(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
                double *__restrict__ DBLOC, double *__restrict__ DBSFC) {
@@ -101,11 +103,19 @@ k_kpp_buoydiff(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
   const long long n2 = g.n2;
   const long long base3 = (long long)b * g.n3 + p2;
   const long long o = base3 + (long long)(k - 1) * n2;
-  if (k == 1) { DBSFC[o] = 0.0; return; }
+  if (k == 1) { if (SFC) DBSFC[o] = 0.0; return; }
   const int kmt = g.KMT[(long long)b * n2 + p2];
   const MwjfP P = mwjf_level(g.pressz[k]);
   const double rhokm = mwjf_rho<false>(P, tmask(T[o - n2]), S[o - n2], nullptr, nullptr);
   const double rhok = mwjf_rho<false>(P, tmask(T[o]), S[o], nullptr, nullptr);
+  if (!SFC) {
+    double dbl = 0.0;
+    if (rhok != 0.0) dbl = GRAV * (1.0 - rhokm / rhok);
+    if (k - 1 >= kmt) dbl = 0.0;
+    DBLOC[o - n2] = dbl;
+    if (k == km) DBLOC[o] = 0.0;
+    return;
+  }
   const double surfthick = KPP_EPSSFC * g.zt[k];
   const int kref = kp.kref[k];
   const long long orf = base3 + (long long)(kref - 1) * n2;
@@ -1193,8 +1203,12 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   const bool fused_bi = (g_kpp_col & 8) && KH.max_kref <= 20 && g.xcd_remap != 2 && g.km <= 64;
   // the surface-layer buoyancy difference on demand inside the boundary-layer-depth march (k_kpp_bldepth<true, .>); POP_KPP_LAZY=0 keeps
   // the full field
-  const bool lazy = fused_bi && !g_kpp.lcheckekmo && h.c.reserved_i[5] != 1 && !(getenv("POP_KPP_LAZY") && atoi(getenv("POP_KPP_LAZY")) == 0);
-  if (lazy) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8, false>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
+  // (with the level-parallel fused kernel and with the plain 3-D buoydiff kernel; the column / LDS buoydiff forms keep the full field)
+  const bool plain3d = !fused_bi && !(g_kpp_col & 4 && KH.max_kref <= 28 && g.xcd_remap != 2) && !(g_kpp_col & 2);
+  const bool lazy = (fused_bi || plain3d) && KH.max_kref <= 28 && !g_kpp.lcheckekmo && h.c.reserved_i[5] != 1 &&
+                    !(getenv("POP_KPP_LAZY") && atoi(getenv("POP_KPP_LAZY")) == 0);
+  const bool lazy20 = lazy && KH.max_kref <= 20;
+  if (lazy && fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8, false>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if (fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if ((g_kpp_col & 4) && KH.max_kref <= 20 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<20, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if ((g_kpp_col & 4) && KH.max_kref <= 28 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<28, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
@@ -1202,13 +1216,16 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   else if ((g_kpp_col & 2) && KH.max_kref <= 20) hipLaunchKernelGGL((k_kpp_buoydiff_col<20, 1>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if ((g_kpp_col & 2) && bw == 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<24, 2>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if (g_kpp_col & 2) hipLaunchKernelGGL((k_kpp_buoydiff_col<24, 1>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
-  else hipLaunchKernelGGL(k_kpp_buoydiff, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  else if (lazy) hipLaunchKernelGGL(k_kpp_buoydiff<false>, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+  else hipLaunchKernelGGL(k_kpp_buoydiff<true>, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   // the boundary-layer depth (needs buoydiff + shear, writes only the 2-D boundary-layer fields) follows the shear kernel
   // on the side stream and runs beside the interior coefficients; blmix waits for both
   if (KH.side) {
     hipEventRecord(KH.ev_bd, st); hipStreamWaitEvent(KH.side, KH.ev_bd, 0);
-    if (lazy) hipLaunchKernelGGL((k_kpp_bldepth<true, 20>), GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
-                                 (const double *)DBSFC, (const double *)WU);
+    if (lazy20) hipLaunchKernelGGL((k_kpp_bldepth<true, 20>), GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                                   (const double *)DBSFC, (const double *)WU);
+    else if (lazy) hipLaunchKernelGGL((k_kpp_bldepth<true, 28>), GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                                      (const double *)DBSFC, (const double *)WU);
     else hipLaunchKernelGGL((k_kpp_bldepth<false, 20>), GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                             (const double *)DBSFC, (const double *)WU);
     hipEventRecord(KH.ev_join, KH.side);
@@ -1219,7 +1236,9 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   else if (int_reg && g.km == 62) hipLaunchKernelGGL(k_kpp_interior_reg<62>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
   if (KH.side) hipStreamWaitEvent(st, KH.ev_join, 0);
-  else if (lazy) hipLaunchKernelGGL((k_kpp_bldepth<true, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+  else if (lazy20) hipLaunchKernelGGL((k_kpp_bldepth<true, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                                      (const double *)DBSFC, (const double *)WU);
+  else if (lazy) hipLaunchKernelGGL((k_kpp_bldepth<true, 28>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                                     (const double *)DBSFC, (const double *)WU);
   else hipLaunchKernelGGL((k_kpp_bldepth<false, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                           (const double *)DBSFC, (const double *)WU);

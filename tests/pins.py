@@ -183,13 +183,16 @@ def check_impvmixt(A, rng, tol_res=1e-13, tol_sol=1e-12):
     km = A.km
     dz, afac = A.vert("dz")[1:km + 1], A.vert("afac_t")[1:km + 1]
     kmt = A.geti("KMT")
-    nvdc = 2 if A.cfg.vmix_choice == 3 else 1
+    # KPP keeps one diffusivity per tracer class; without double diffusion the two classes hold the same values (the library then
+    # keeps ONE array for both), so distinct values per class are pinned with ldbl_diff only
+    nset = 2 if A.cfg.vmix_choice == 3 else 1
+    nvdc = 2 if (A.cfg.vmix_choice == 3 and A.cfg.ldbl_diff) else 1
     shp = A.get("TRACER", 2, 0).shape
     ps = 40.0 * GRAV * (rng.random(A.get("PSURF", 1).shape) - 0.5)       # +- 20 cm of sea level
     A.set("PSURF", ps, 1)
     vdc = [0.05 + 50.0 * rng.random(A.get("VDC", 0, n).shape) ** 3 for n in range(2)]
-    for n in range(nvdc):
-        A.set("VDC", vdc[n], 0, n)
+    for n in range(nset):
+        A.set("VDC", vdc[n if nvdc == 2 else 0], 0, n)
     rhs = [10.0 * (rng.random(shp) - 0.5) for _ in range(2)]
     told = [A.get("TRACER", 0, n) for n in range(2)]
     for n in range(2):
@@ -225,14 +228,17 @@ def check_impvmixt_correct(A, rng, tol_res=1e-13, tol_sol=1e-12):
     km = A.km
     dz, afac = A.vert("dz")[1:km + 1], A.vert("afac_t")[1:km + 1]
     kmt = A.geti("KMT")
-    nvdc = 2 if A.cfg.vmix_choice == 3 else 1
+    # KPP keeps one diffusivity per tracer class; without double diffusion the two classes hold the same values (the library then
+    # keeps ONE array for both), so distinct values per class are pinned with ldbl_diff only
+    nset = 2 if A.cfg.vmix_choice == 3 else 1
+    nvdc = 2 if (A.cfg.vmix_choice == 3 and A.cfg.ldbl_diff) else 1
     shp2 = A.get("PSURF", 1).shape
     P = [40.0 * GRAV * (rng.random(shp2) - 0.5) for _ in range(3)]
     for tl in range(3):
         A.set("PSURF", P[tl], tl)
     vdc = [0.05 + 50.0 * rng.random(A.get("VDC", 0, n).shape) ** 3 for n in range(2)]
-    for n in range(nvdc):
-        A.set("VDC", vdc[n], 0, n)
+    for n in range(nset):
+        A.set("VDC", vdc[n if nvdc == 2 else 0], 0, n)
     tn = [A.get("TRACER", 1, n) * (1.0 + 0.05 * (rng.random(A.get("TRACER", 1, n).shape) - 0.5)) for n in range(2)]
     tc = [A.get("TRACER", 1, n) for n in range(2)]
     to = [A.get("TRACER", 0, n) for n in range(2)]

@@ -542,6 +542,8 @@ def test_momentum_kernels_agree_bitwise(pkg, monkeypatch, kw):
     ({"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21}, {"POP_KPP_COL": "15", "POP_XCD_REMAP": "0"}),
     ({"vmix_choice": 3, "km": 24, "lshort_wave": 1, "sw_absorption_type": 1}, {"POP_KPP_COL": "15"}),
     ({"vmix_choice": 3, "km": 60, "block_size_x": 48, "block_size_y": 40}, {"POP_KPP_COL": "15", "POP_KPP_SIDE_STREAM": "0"}),
+    ({"vmix_choice": 3, "km": 24, "stepped_bathymetry": 1}, {}),                      # small grids: the 3-D buoydiff kernel without DBSFC
+    ({"vmix_choice": 3, "km": 60}, {"POP_KPP_COL": "1", "POP_XCD_REMAP": "1"}),       # the gx1v7 kernel selection
 ])
 def test_kpp_on_demand_surface_buoyancy_is_bitwise_invisible(pkg, orclib_built, monkeypatch, kw, env):
     """k_kpp_bldepth<true>: the buoyancy difference against the surface layer is evaluated inside the bulk-Richardson march,

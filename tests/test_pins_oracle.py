@@ -8,7 +8,8 @@ from popcfg import named_config
 
 CASES = [
     ("const-stepped", dict(stepped_bathymetry=1)),                              # shallow columns: KMT = 8 ... 16
-    ("kpp-km20-stepped", dict(vmix_choice=3, km=20, stepped_bathymetry=1)),     # two VDC fields
+    ("kpp-km20-stepped", dict(vmix_choice=3, km=20, stepped_bathymetry=1)),     # two VDC fields holding the same values
+    ("kpp-dd-km20-stepped", dict(vmix_choice=3, km=20, ldbl_diff=1, stepped_bathymetry=1)),   # double diffusion: distinct values per tracer class
     ("rich-flat", dict(vmix_choice=2)),
 ]
 
