@@ -26,6 +26,9 @@ struct KppDev {
   int *KBL0, *KBL;
   double Vtc, cg, rich_mix;
   int lrich, ldbl_diff, nsmooth;
+  int vdc_same;            // the two tracer classes share ONE diffusivity array (VDC1 == VDC2): the kernels touch VDC1 only.  A flag, not a
+                           // pointer comparison: both parameters are __restrict__, which lets the compiler assume they differ
+
   // vmix_kpp_nml lshort_wave (sw_absorption_type: 0 'top-layer', 1 'jerlov' with water type jerlov = 1..5), lcheckekmo
   int lshort_wave, sw_type, jerlov, lcheckekmo;
   const double *FCORT, *SHF_QSW;     // T-point Coriolis parameter (Ekman depth), surface short-wave flux
@@ -418,7 +421,7 @@ k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, cons
     }
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
-    if (VDC2 != VDC1) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
+    if (!kp.vdc_same) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
   }
 }
 
@@ -546,7 +549,7 @@ k_kpp_interior(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
     }
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
-    if (VDC2 != VDC1) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
+    if (!kp.vdc_same) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
   }
 }
 
@@ -657,7 +660,7 @@ k_kpp_interior_reg(DevGrid g, KppDev kp, const double *__restrict__ T, const dou
     }
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
-    if (VDC2 != VDC1) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
+    if (!kp.vdc_same) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
   }
 }
 
@@ -882,7 +885,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     double fm[3], f0[3], fp[3];
     fm[0] = visc_at(k - 1); f0[0] = visc_at(k); fp[0] = visc_at(k + 1);
     fm[2] = VDC1[vb + (long long)(k - 1) * n2]; f0[2] = VDC1[vb + (long long)k * n2]; fp[2] = VDC1[vb + (long long)(k + 1) * n2];
-    if (VDC2 != VDC1) { fm[1] = VDC2[vb + (long long)(k - 1) * n2]; f0[1] = VDC2[vb + (long long)k * n2]; fp[1] = VDC2[vb + (long long)(k + 1) * n2]; }
+    if (!kp.vdc_same) { fm[1] = VDC2[vb + (long long)(k - 1) * n2]; f0[1] = VDC2[vb + (long long)k * n2]; fp[1] = VDC2[vb + (long long)(k + 1) * n2]; }
     else { fm[1] = fm[2]; f0[1] = f0[2]; fp[1] = fp[2]; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -910,7 +913,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
   const double stf1 = STF1[c.q2], stf2 = STF2[c.q2];
   for (int k = 1; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
-    double visc = VISC[o], vd1 = VDC1[vb + (long long)k * n2], vd2 = (VDC2 != VDC1) ? VDC2[vb + (long long)k * n2] : vd1;
+    double visc = VISC[o], vd1 = VDC1[vb + (long long)k * n2], vd2 = (!kp.vdc_same) ? VDC2[vb + (long long)k * n2] : vd1;
     double ghat = 0.0;
     if (k < kbl) {
       const double sig = (-zgrid[k] + 0.5 * hwide[k]) / hblt;
@@ -938,7 +941,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     } else { vd1 = 0.0; vd2 = 0.0; }
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
-    if (VDC2 != VDC1) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
+    if (!kp.vdc_same) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
     const double fl1 = vd1 * ghat, fl2 = vd2 * ghat;
     if (k == 1) { SRC1[o] = stf1 / g.dz[1] * (-fl1); SRC2[o] = stf2 / g.dz[1] * (-fl2); }
     else { SRC1[o] = stf1 / g.dz[k] * (flux1_prev - fl1); SRC2[o] = stf2 / g.dz[k] * (flux2_prev - fl2); }
@@ -1184,6 +1187,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   KppDev g_kpp = KH.dev;
   g_kpp.SHF_QSW = s.SHF_QSW; g_kpp.FCORT = g.FCORT;
   if (s.KBL) g_kpp.KBL = s.KBL;
+  g_kpp.vdc_same = (s.VDC[0] == s.VDC[1]) ? 1 : 0;
   const int g_kpp_col = KH.col;
   const dim3 GC(col_grid(g, POP_COL_THREADS), g.nblocks), BC(POP_COL_THREADS);
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);
