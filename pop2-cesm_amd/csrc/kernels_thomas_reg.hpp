@@ -93,6 +93,89 @@ k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
   }
 }
 
+// Both tracers of a column in one thread, for the case that they share one diffusivity array (KPP without double diffusion,
+// a.VDC[0] == a.VDC[1]): the elimination coefficients E(k) depend on VDC, dz, dt and the surface pressure only, so they are formed
+// once and VDC is read once -- 7 instead of 8 fields through HBM in the predictor, 5 instead of 6 in the corrector, 3 divisions per
+// level instead of 4.  Each tracer's values go through exactly the operations of k_impvmixt_reg (E is the same number in both
+// threads there), so TNEW is bitwise unchanged.  Three register columns (E, F_T, F_S): one wave per SIMD.
+template <int KM, int MODE, bool PRE, bool POST>
+__global__ void __launch_bounds__(POP_COL_THREADS, 1)
+k_impvmixt2_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
+  Col c;
+  if (!col_setup(g, c, true)) return;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  const double hfac1 = g.dz[1] / a.c2dtt;
+  const double H1 = hfac1 + a.PSFC[c.q2] / (sp.grav * a.c2dtt);
+  const long long vdcbase = ((long long)c.b * (KM + 2)) * n2 + c.p2;
+  double Ea[KM], F0[KM], F1[KM];
+  double *__restrict__ const TN0 = a.TNEW[0];
+  double *__restrict__ const TN1 = a.TNEW[1];
+  const double *__restrict__ const VDC = a.VDC[0];
+  const double *__restrict__ const TO0 = a.TOLD[0];
+  const double *__restrict__ const TO1 = a.TOLD[1];
+#pragma unroll
+  for (int k = 1; k <= KM; ++k) {
+    Ea[k - 1] = VDC[vdcbase + (long long)k * n2];
+    F0[k - 1] = TN0[c.base3 + (long long)(k - 1) * n2];
+    F1[k - 1] = TN1[c.base3 + (long long)(k - 1) * n2];
+  }
+  double rhs0 = 0.0, rhs1 = 0.0;
+  if (MODE == 1) {
+    if (kmt > 0) {
+      rhs0 = ((2.0 * a.TCUR[0][c.base3] - TO0[c.base3]) * (a.PCUR[c.q2] - a.POLD[c.q2]) - F0[0] * (a.PNEW[c.q2] - a.PCUR[c.q2])) / (sp.grav * g.dz[1]);
+      rhs1 = ((2.0 * a.TCUR[1][c.base3] - TO1[c.base3]) * (a.PCUR[c.q2] - a.POLD[c.q2]) - F1[0] * (a.PNEW[c.q2] - a.PCUR[c.q2])) / (sp.grav * g.dz[1]);
+    }
+  }
+  double t0 = F0[0], t1 = F1[0];
+  if (PRE) {
+    if (kmt > 0) {
+      t0 = t0 - TO0[c.base3] * (a.PNEW[c.q2] - a.PMIX[c.q2]) / (sp.grav * g.dz[1]);
+      t1 = t1 - TO1[c.base3] * (a.PNEW[c.q2] - a.PMIX[c.q2]) / (sp.grav * g.dz[1]);
+    }
+  }
+  double A = g.afac_t[1] * Ea[0];
+  double D = H1 + A;
+  double Ek = A / D;
+  double B = H1 * Ek;
+  double Fk0 = (MODE == 1) ? hfac1 * rhs0 / D : hfac1 * t0 / D;
+  double Fk1 = (MODE == 1) ? hfac1 * rhs1 / D : hfac1 * t1 / D;
+  Ea[0] = Ek; F0[0] = Fk0; F1[0] = Fk1;
+#pragma unroll
+  for (int k = 2; k <= KM; ++k) {
+    const double C = A;
+    const double hf = g.dz[k] / a.c2dtt;
+    A = g.afac_t[k] * Ea[k - 1];
+    const double tn0 = F0[k - 1], tn1 = F1[k - 1];
+    if (k > kmt) { Fk0 = 0.0; Fk1 = 0.0; }
+    else {
+      D = (k == kmt) ? hf + B : hf + A + B;
+      Ek = A / D;
+      B = (hf + B) * Ek;
+      Fk0 = (MODE == 1) ? C * Fk0 / D : (hf * tn0 + C * Fk0) / D;
+      Fk1 = (MODE == 1) ? C * Fk1 / D : (hf * tn1 + C * Fk1) / D;
+      Ea[k - 1] = Ek;
+    }
+    F0[k - 1] = Fk0; F1[k - 1] = Fk1;
+  }
+  double Fp0 = 0.0, Fp1 = 0.0;
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int k = KM; k >= 1; --k) {
+    double f0 = F0[k - 1], f1 = F1[k - 1];
+    if (k < KM && k < kmt) { f0 = f0 + Ea[k - 1] * Fp0; f1 = f1 + Ea[k - 1] * Fp1; }
+    Fp0 = f0; Fp1 = f1;
+    if ((k & 7) == 0) asm volatile("" ::: "memory");
+    const long long ob = c.base3 + (long long)(k - 1) * n2;
+    double x0 = ((MODE == 1) ? TN0[ob] : TO0[ob]) + f0;
+    const double x1 = ((MODE == 1) ? TN1[ob] : TO1[ob]) + f1;
+    if (POST && k == 1 && sp.reset_to_freezing) x0 = fmax(x0, -2.0);
+    F0[k - 1] = x0; F1[k - 1] = x1;
+  }
+#pragma unroll
+  for (int k = 1; k <= KM; ++k) { TN0[c.base3 + (long long)(k - 1) * n2] = F0[k - 1]; TN1[c.base3 + (long long)(k - 1) * n2] = F1[k - 1]; }
+}
+
 // one velocity component per thread (blockIdx.z = 0: U, 1: V): the two solves share only the
 // elimination coefficients, which each thread recomputes, so the column fits two register arrays
 // and the launch has twice the waves
@@ -170,7 +253,18 @@ template <int MODE, bool PRE, bool POST>
 inline void launch_impvmixt(const DevGrid &g, const StepParams &sp, const ImpvmixtArgs &a, dim3 G, hipStream_t st, bool allow_reg) {
   const dim3 B(POP_COL_THREADS);
   const dim3 G2(G.x, G.y, a.nlast - a.nfirst + 1);
-  if (allow_reg && (g.km == 60 || g.km == 62)) {
+  // both tracers in one thread when they share the diffusivity array (POP_THOMAS_PAIR=0|1 overrides the size rule)
+  const int pair_env = getenv("POP_THOMAS_PAIR") ? atoi(getenv("POP_THOMAS_PAIR")) : -1;
+  // (corrector form only: the predictor's three full register columns + its up-front loads spill ~ 900 B per lane)
+  const bool pair = MODE == 1 && allow_reg && (g.km == 60 || g.km == 62) && a.nfirst == 1 && a.nlast == 2 && a.VDC[0] == a.VDC[1] &&
+                    (pair_env >= 0 ? pair_env != 0 : (long long)g.n2 * g.nblocks > (1 << 19));
+  if (pair) {
+    if constexpr (MODE == 1) {
+      if (g.km == 60) hipLaunchKernelGGL((k_impvmixt2_reg<60, MODE, PRE, POST>), G, B, 0, st, g, sp, a);
+      else hipLaunchKernelGGL((k_impvmixt2_reg<62, MODE, PRE, POST>), G, B, 0, st, g, sp, a);
+    }
+    if (POST) hipLaunchKernelGGL(k_state3d, dim3((g.n2 + 255) / 256, g.km, g.nblocks), dim3(256), 0, st, g, (const double *)a.TNEW[0], (const double *)a.TNEW[1], a.RHO);
+  } else if (allow_reg && (g.km == 60 || g.km == 62)) {
     if (g.km == 60) hipLaunchKernelGGL((k_impvmixt_reg<60, MODE, PRE, POST>), G2, B, 0, st, g, sp, a);
     else hipLaunchKernelGGL((k_impvmixt_reg<62, MODE, PRE, POST>), G2, B, 0, st, g, sp, a);
     // the density of the finished tracers (baroclinic.F90:1468-1475) as its own 3-D-parallel pass

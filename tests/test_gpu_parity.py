@@ -606,6 +606,24 @@ def test_nonlocal_source_read_down_to_kbl_only_is_bitwise_invisible(pkg, orclib_
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kw", [{"km": 62, "vmix_choice": 3, "stepped_bathymetry": 1}, {"km": 60, "vmix_choice": 3, "block_size_x": 48, "block_size_y": 40}])
+def test_two_tracer_corrector_solve_is_bitwise_invisible(pkg, monkeypatch, kw):
+    """k_impvmixt2_reg: with one diffusivity array for both tracer classes the corrector's register Thomas solve takes T and S of a
+    column in one thread (the elimination coefficients are formed once).  Forced on a small grid against one tracer per thread."""
+    monkeypatch.setenv("POP_REG_THOMAS_T", "1")
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for pair in ("0", "1"):
+        monkeypatch.setenv("POP_THOMAS_PAIR", pair)
+        m = pkg.PopModel(cfg)
+        for _ in range(4):
+            m.step()
+        out[pair] = [m.get("TRACER", 1, n).copy() for n in (0, 1)] + [m.get(n, 1, 0).copy() for n in ("RHO", "UVEL", "PSURF")]
+        m.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("kw", [{"km": 62}, {"km": 60, "vmix_choice": 3, "stepped_bathymetry": 1},
                                 {"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "block_size_x": 48, "block_size_y": 40}])
 def test_deferred_vertical_mixing_with_barotropic_sum_is_bitwise_invisible(pkg, monkeypatch, kw):
