@@ -624,6 +624,23 @@ def test_two_tracer_corrector_solve_is_bitwise_invisible(pkg, monkeypatch, kw):
         assert np.array_equal(a, b)
 
 
+def test_del4_first_laplacian_patch_shapes_agree_bitwise(pkg, monkeypatch):
+    """The first Laplacians of del4 (k_del4_d2t / k_del4_d2u) run over 256 consecutive cells or over 64 x R patches (large grids:
+    R = 4); the cell -> thread map is all that changes."""
+    cfg = named_config("tiny", hmix_momentum=4, hmix_tracer=4, am=-1.0e22, ah=-1.0e21, stepped_bathymetry=1, lvariable_hmix=1)
+    out = {}
+    for rows in ("0", "2", "4", "8", "16"):
+        monkeypatch.setenv("POP_DEL4_TILE", rows)
+        m = pkg.PopModel(cfg)
+        for _ in range(3):
+            m.step()
+        out[rows] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF")] + [m.get("TRACER", 1, 1).copy()]
+        m.close()
+    for rows in ("2", "4", "8", "16"):
+        for a, b in zip(out["0"], out[rows]):
+            assert np.array_equal(a, b), rows
+
+
 @pytest.mark.parametrize("kw", [{"km": 62}, {"km": 60, "vmix_choice": 3, "stepped_bathymetry": 1},
                                 {"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "block_size_x": 48, "block_size_y": 40}])
 def test_deferred_vertical_mixing_with_barotropic_sum_is_bitwise_invisible(pkg, monkeypatch, kw):
