@@ -161,6 +161,30 @@ __device__ __forceinline__ bool col_setup(const DevGrid &g, Col &c, bool interio
   c.base3 = (long long)c.b * g.n3 + c.p2;
   return true;
 }
+// Element-wise 3-D kernels that read rows j +- 1 (del4 first Laplacians, k_kpp_vvc): cell of this thread.  tile = 0: 256 consecutive cells of the flattened (i,j) index; tile = R > 0: a 64 x R patch (64 R threads), whose
+// rows j+-1 are mostly read by the same workgroup (R + 2 rows fetched for R written instead of 3 for 1)
+__device__ __forceinline__ bool patch_cell(const DevGrid &g, int tile, int b, int &p2) {
+  if (!tile) {
+    p2 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p2 >= g.n2) return false;
+    return !land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x);
+  }
+  const int tiles_i = (g.nxb + 63) / 64;
+  const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i;
+  const int i = ti * 64 + (threadIdx.x & 63), j = tj * tile + (threadIdx.x >> 6);
+  if (land_tile(g, b, ti * 64, 64, tj * tile, tile)) return false;
+  if (i >= g.nxb || j >= g.nyb) return false;
+  p2 = j * g.nxb + i;
+  return true;
+}
+// bandwidth-bound grids: 64 x 4 patches (tx0.1v3: -0.5 ms per step); POP_DEL4_TILE = 0 | 2 | 4 | 8 | 16 overrides
+__host__ inline int patch_rows(const DevGrid &g) {
+  if (getenv("POP_DEL4_TILE")) { const int r = atoi(getenv("POP_DEL4_TILE")); return (r == 2 || r == 4 || r == 8 || r == 16) ? r : 0; }
+  return ((long long)g.n2 * g.nblocks > (1 << 19)) ? 4 : 0;
+}
+__host__ inline unsigned patch_grid_x(const DevGrid &g, int tile) {
+  return tile ? (unsigned)(((g.nxb + 63) / 64) * ((g.nyb + tile - 1) / tile)) : (unsigned)((g.n2 + 255) / 256);
+}
 // 2-D reduction kernels (POP_RED_THREADS = 256 threads, one partial per workgroup): cell of this thread,
 // or g.n2 (not a cell) for surplus threads.  Large grids use 64 x 4 tiles in the XCD-strided column order.
 __host__ inline int red_grid_x(const DevGrid &g) {

@@ -14,35 +14,11 @@ namespace pop {
 // tracers, 13 for momentum) are loaded once per chunk instead of once per level -- at tx0.1v3 they were 3/4 of
 // the kernel's traffic (55 of 72 GB) in the one-level-per-thread form.
 #define POP_DEL4_KC 8
-// cell of this thread.  tile = 0: 256 consecutive cells of the flattened (i,j) index; tile = R > 0: a 64 x R patch (64 R threads), whose
-// rows j+-1 are mostly read by the same workgroup (R + 2 rows fetched for R written instead of 3 for 1)
-__device__ __forceinline__ bool del4_cell(const DevGrid &g, int tile, int b, int &p2) {
-  if (!tile) {
-    p2 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p2 >= g.n2) return false;
-    return !land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x);
-  }
-  const int tiles_i = (g.nxb + 63) / 64;
-  const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i;
-  const int i = ti * 64 + (threadIdx.x & 63), j = tj * tile + (threadIdx.x >> 6);
-  if (land_tile(g, b, ti * 64, 64, tj * tile, tile)) return false;
-  if (i >= g.nxb || j >= g.nyb) return false;
-  p2 = j * g.nxb + i;
-  return true;
-}
-// bandwidth-bound grids: 64 x 4 patches (tx0.1v3: -0.5 ms per step); POP_DEL4_TILE = 0 | 2 | 4 | 8 | 16 overrides
-__host__ inline int del4_tile_rows(const DevGrid &g) {
-  if (getenv("POP_DEL4_TILE")) { const int r = atoi(getenv("POP_DEL4_TILE")); return (r == 2 || r == 4 || r == 8 || r == 16) ? r : 0; }
-  return ((long long)g.n2 * g.nblocks > (1 << 19)) ? 4 : 0;
-}
-__host__ inline unsigned del4_grid_x(const DevGrid &g, int tile) {
-  return tile ? (unsigned)(((g.nxb + 63) / 64) * ((g.nyb + tile - 1) / tile)) : (unsigned)((g.n2 + 255) / 256);
-}
 __global__ void k_del4_d2t(DevGrid g, const double *__restrict__ AHF, const double *__restrict__ T0, const double *__restrict__ T1,
                            double *__restrict__ D0, double *__restrict__ D1, int tile) {
   int p2;
   const int k0 = blockIdx.y * POP_DEL4_KC + 1, b = blockIdx.z;
-  if (!del4_cell(g, tile, b, p2)) return;
+  if (!patch_cell(g, tile, b, p2)) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
   if (i + 1 < g.ib - 1 || i + 1 > g.ie + 1 || j + 1 < g.jb - 1 || j + 1 > g.je + 1) return;
   const long long q = (long long)b * g.n2 + p2;
@@ -64,7 +40,7 @@ __global__ void k_del4_d2u(DevGrid g, const double *__restrict__ AMF, const doub
                            double *__restrict__ DU, double *__restrict__ DV, int tile) {
   int p2;
   const int k0 = blockIdx.y * POP_DEL4_KC + 1, b = blockIdx.z;
-  if (!del4_cell(g, tile, b, p2)) return;
+  if (!patch_cell(g, tile, b, p2)) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
   if (i + 1 < g.ib - 1 || i + 1 > g.ie + 1 || j + 1 < g.jb - 1 || j + 1 > g.je + 1) return;
   const long long q = (long long)b * g.n2 + p2;
@@ -92,15 +68,15 @@ inline int del4_create(HostModel &, const DevGrid &, MixDev &, std::vector<void 
 
 inline int mix_hdifft_del4(const HostModel &, const DevGrid &g, const StepParams &, const MixDev &m, const double *T0, const double *T1,
                            double *D0, double *D1, double *, double *, hipStream_t st, std::string &err) {
-  const int tile = del4_tile_rows(g);
-  hipLaunchKernelGGL(k_del4_d2t, dim3(del4_grid_x(g, tile), (g.km + POP_DEL4_KC - 1) / POP_DEL4_KC, g.nblocks), dim3(tile ? 64 * tile : 256), 0, st, g, m.D4AHF, T0, T1, D0, D1, tile);
+  const int tile = patch_rows(g);
+  hipLaunchKernelGGL(k_del4_d2t, dim3(patch_grid_x(g, tile), (g.km + POP_DEL4_KC - 1) / POP_DEL4_KC, g.nblocks), dim3(tile ? 64 * tile : 256), 0, st, g, m.D4AHF, T0, T1, D0, D1, tile);
   if (hipGetLastError() != hipSuccess) { err = "del4 tracer kernel launch failed"; return 1; }
   return 0;
 }
 inline int mix_hdiffu_del4(const HostModel &, const DevGrid &g, const StepParams &, const MixDev &m, const double *U, const double *V,
                            double *DU, double *DV, double *, double *, hipStream_t st, std::string &err) {
-  const int tile = del4_tile_rows(g);
-  hipLaunchKernelGGL(k_del4_d2u, dim3(del4_grid_x(g, tile), (g.km + POP_DEL4_KC - 1) / POP_DEL4_KC, g.nblocks), dim3(tile ? 64 * tile : 256), 0, st, g, m.D4AMF, U, V, DU, DV, tile);
+  const int tile = patch_rows(g);
+  hipLaunchKernelGGL(k_del4_d2u, dim3(patch_grid_x(g, tile), (g.km + POP_DEL4_KC - 1) / POP_DEL4_KC, g.nblocks), dim3(tile ? 64 * tile : 256), 0, st, g, m.D4AMF, U, V, DU, DV, tile);
   if (hipGetLastError() != hipSuccess) { err = "del4 momentum kernel launch failed"; return 1; }
   return 0;
 }

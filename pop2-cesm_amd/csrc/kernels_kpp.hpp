@@ -996,11 +996,10 @@ k_kpp_hmxl(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__r
   HMXL_DR[c.q2] = hdr;
 }
 
-__global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__restrict__ VVC) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__restrict__ VVC, int patch) {
+  int p2;
   const int k0 = blockIdx.y * POP_VVC_KC + 1, b = blockIdx.z;
-  if (p2 >= g.n2) return;
-  if (land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x)) return;
+  if (!patch_cell(g, patch, b, p2)) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
   const long long q2 = (long long)b * g.n2 + p2;
   const bool in = i < g.nxb - 1 && j < g.nyb - 1;
@@ -1248,7 +1247,8 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                           (const double *)DBSFC, (const double *)WU);
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                      s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
-  hipLaunchKernelGGL(k_kpp_vvc, dim3((g.n2 + 255) / 256, (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(256), 0, st, g, (const double *)VISC, s.VVC);
+  const int vpatch = patch_rows(g);   // large grids: 64 x 4 patches (the row j + 1 of the four-point average is read by the same workgroup)
+  hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vpatch), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vpatch ? 64 * vpatch : 256), 0, st, g, (const double *)VISC, s.VVC, vpatch);
   if (h.c.reserved_i[5] == 1 && s.HMXL && s.HMXL_DR)
     hipLaunchKernelGGL(k_kpp_hmxl, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], (const double *)DBSFC, s.HMXL, s.HMXL_DR);
   if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }

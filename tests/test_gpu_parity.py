@@ -625,16 +625,16 @@ def test_two_tracer_corrector_solve_is_bitwise_invisible(pkg, monkeypatch, kw):
 
 
 def test_del4_first_laplacian_patch_shapes_agree_bitwise(pkg, monkeypatch):
-    """The first Laplacians of del4 (k_del4_d2t / k_del4_d2u) run over 256 consecutive cells or over 64 x R patches (large grids:
-    R = 4); the cell -> thread map is all that changes."""
-    cfg = named_config("tiny", hmix_momentum=4, hmix_tracer=4, am=-1.0e22, ah=-1.0e21, stepped_bathymetry=1, lvariable_hmix=1)
+    """The first Laplacians of del4 (k_del4_d2t / k_del4_d2u) and KPP's viscosity average to U points (k_kpp_vvc) run over 256
+    consecutive cells or over 64 x R patches (large grids: R = 4); the cell -> thread map is all that changes."""
+    cfg = named_config("tiny", hmix_momentum=4, hmix_tracer=4, am=-1.0e22, ah=-1.0e21, stepped_bathymetry=1, lvariable_hmix=1, vmix_choice=3, km=24)
     out = {}
     for rows in ("0", "2", "4", "8", "16"):
         monkeypatch.setenv("POP_DEL4_TILE", rows)
         m = pkg.PopModel(cfg)
         for _ in range(3):
             m.step()
-        out[rows] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF")] + [m.get("TRACER", 1, 1).copy()]
+        out[rows] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "VVC")] + [m.get("TRACER", 1, 1).copy()]
         m.close()
     for rows in ("2", "4", "8", "16"):
         for a, b in zip(out["0"], out[rows]):
