@@ -26,6 +26,11 @@ struct KppDev {
   int *KBL0, *KBL;
   double Vtc, cg, rich_mix;
   int lrich, ldbl_diff, nsmooth;
+  // shear kernel limited to the levels the boundary-layer march is expected to reach (k_kpp_ushear_col with a hint): WUK[q] = number
+  // of levels of WU that are valid at U point q; the march computes a level beyond it itself (kpp_ushear_point, same operations).
+  // nullptr: every level of WU is valid
+  int *WUK;
+  int wu_margin;
   int vdc_same;            // the two tracer classes share ONE diffusivity array (VDC1 == VDC2): the kernels touch VDC1 only.  A flag, not a
                            // pointer comparison: both parameters are __restrict__, which lets the compiler assume they differ
 
@@ -429,18 +434,38 @@ k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, cons
 template <int KR>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_ushear_col(DevGrid g, KppDev kp, const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ WU) {
+  __shared__ int s_cap;
+  if (kp.WUK && threadIdx.x == 0) s_cap = 0;
   Col c;
   if (!col_setup(g, c, false)) return;
   const int km = g.km;
   const long long n2 = g.n2;
+  // With a hint (kp.WUK): the march of k_kpp_bldepth<true> stops, wave by wave, at the deepest first crossing of its columns, which
+  // moves little from one evaluation to the next.  This wave forms WU down to the deepest KBL the previous evaluation left at the
+  // T cells that use its U points, plus a margin, and records that level per column; the march computes what is missing itself.
+  int kcap = km, krcap = KR;
+  if (kp.WUK) {
+    int h = kp.KBL[c.q2];
+    if (c.i + 1 < g.nxb) h = max(h, kp.KBL[c.q2 + 1]);
+    if (c.j + 1 < g.nyb) { h = max(h, kp.KBL[c.q2 + g.nxb]); if (c.i + 1 < g.nxb) h = max(h, kp.KBL[c.q2 + g.nxb + 1]); }
+    __syncthreads();                               // one wave per workgroup: s_cap = 0 is visible
+    atomicMax(&s_cap, h);
+    __syncthreads();
+    kcap = min(km, max(2, s_cap + kp.wu_margin));
+    kp.WUK[c.q2] = kcap;
+    krcap = kp.kref[kcap];                         // kref is non-decreasing in the level
+  }
   double ur[KR + 1], vr[KR + 1];
 #pragma unroll
   for (int t = 1; t <= KR; ++t) {
-    const int kk = (t <= km) ? t : km;
-    const long long o = c.base3 + (long long)(kk - 1) * n2;
-    ur[t] = U[o]; vr[t] = V[o];
+    ur[t] = 0.0; vr[t] = 0.0;
+    if (t <= krcap) {
+      const int kk = (t <= km) ? t : km;
+      const long long o = c.base3 + (long long)(kk - 1) * n2;
+      ur[t] = U[o]; vr[t] = V[o];
+    }
   }
-  for (int kl = 2; kl <= km; ++kl) {
+  for (int kl = 2; kl <= kcap; ++kl) {
     const long long o = c.base3 + (long long)(kl - 1) * n2;
     const double ukl = U[o], vkl = V[o];
     const double surfthick = KPP_EPSSFC * g.zt[kl];
@@ -702,6 +727,30 @@ k_kpp_ushear(DevGrid g, KppDev kp, const double *__restrict__ U, const double *_
   WU[o] = du * du + dv * dv;
 }
 
+// the same for one U point (column base3) and level: what k_kpp_ushear / k_kpp_ushear_col store in WU
+__device__ __forceinline__ double kpp_ushear_point(const DevGrid &g, const KppDev &kp, const double *__restrict__ U, const double *__restrict__ V,
+                                                   long long base3, int kl) {
+  const long long n2 = g.n2;
+  const long long o = base3 + (long long)(kl - 1) * n2;
+  const double surfthick = KPP_EPSSFC * g.zt[kl];
+  const int kref = kp.kref[kl];
+  double uref, vref;
+  if (kref > 1) {
+    const long long orf = base3 + (long long)(kref - 1) * n2;
+    uref = U[orf] * (surfthick - g.zw[kref - 1]);
+    vref = V[orf] * (surfthick - g.zw[kref - 1]);
+#pragma unroll 1
+    for (int kt = 1; kt <= kref - 1; ++kt) {
+      const long long ot = base3 + (long long)(kt - 1) * n2;
+      uref = uref + g.dz[kt] * U[ot];
+      vref = vref + g.dz[kt] * V[ot];
+    }
+    uref = uref / surfthick; vref = vref / surfthick;
+  } else { uref = U[base3]; vref = V[base3]; }
+  const double du = uref - U[o], dv = vref - V[o];
+  return du * du + dv * dv;
+}
+
 // ---- bldepth, part 2: bulk Richardson number march -> unsmoothed HBLT, KBL ---------------------
 // LAZY: the buoyancy difference against the surface layer (DBSFC of buoydiff: up to 1 + kref equation-of-state evaluations per
 // level, the bulk of KPP's arithmetic) is formed here, on demand, for the level the march is at -- same operations in the same
@@ -715,7 +764,7 @@ template <bool LAZY, int KR>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
               const double *__restrict__ STF1, const double *__restrict__ STF2, const double *__restrict__ DBLOC,
-              const double *__restrict__ DBSFC, const double *__restrict__ WU) {
+              const double *__restrict__ DBSFC, const double *__restrict__ WU, const double *__restrict__ UU, const double *__restrict__ VV) {
   static_assert(POP_COL_THREADS == 64, "the lazy march votes over one 64-lane wave");
   __shared__ double shtop[LAZY ? 3 * KR : 1][POP_COL_THREADS];
   int nprep = 0;                                   // surface-layer levels prepared so far (wave-uniform)
@@ -725,6 +774,8 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
   const long long n2 = g.n2;
   const int kmt = g.KMT[c.q2];
   const bool edge = (c.i == 0 || c.j == 0);
+  int wuk[4] = {km, km, km, km};                  // valid levels of WU at the four U points around this T point
+  if (LAZY && kp.WUK && !edge) { wuk[0] = kp.WUK[c.q2]; wuk[1] = kp.WUK[c.q2 - 1]; wuk[2] = kp.WUK[c.q2 - nxb]; wuk[3] = kp.WUK[c.q2 - 1 - nxb]; }
   const double s1 = g.SMFT1[c.q2], s2 = g.SMFT2[c.q2];
   double ustar = sqrt(sqrt(s1 * s1 + s2 * s2));
   ustar = fmax(ustar, KPP_EPS);
@@ -780,7 +831,15 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
       if (rhok != 0.0) dbsfc = GRAV * (1.0 - rhoavg / rhok);
     } else dbsfc = DBSFC[o];
     double vshear = 0.0;
-    if (!edge) vshear = fmax(fmax(WU[o], WU[o - 1]), fmax(WU[o - nxb], WU[o - 1 - nxb]));
+    if (!edge) {
+      if (LAZY && kp.WUK) {
+        const double w00 = (kl <= wuk[0]) ? WU[o] : kpp_ushear_point(g, kp, UU, VV, c.base3, kl);
+        const double w10 = (kl <= wuk[1]) ? WU[o - 1] : kpp_ushear_point(g, kp, UU, VV, c.base3 - 1, kl);
+        const double w01 = (kl <= wuk[2]) ? WU[o - nxb] : kpp_ushear_point(g, kp, UU, VV, c.base3 - nxb, kl);
+        const double w11 = (kl <= wuk[3]) ? WU[o - 1 - nxb] : kpp_ushear_point(g, kp, UU, VV, c.base3 - 1 - nxb, kl);
+        vshear = fmax(fmax(w00, w10), fmax(w01, w11));
+      } else vshear = fmax(fmax(WU[o], WU[o - 1]), fmax(WU[o - nxb], WU[o - 1 - nxb]));
+    }
     bfsfc = kpp_bfsfc(kp, bo, bosol, zkl, 2 * kl - 1, chli);
     const double stable = (bfsfc >= 0.0) ? 1.0 : 0.0;
     bfsfc = bfsfc + stable * KPP_EPS;
@@ -1019,7 +1078,7 @@ __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__
 // per-context KPP state (MixDev::kpp)
 // col: bit 0 = ushear, bit 1 = buoydiff in column form.  side / ev_*: second HIP stream on which the shear kernel (needs only
 // U, V; consumed by bldepth) runs beside buoydiff + interior (POP_KPP_SIDE_STREAM=0 keeps everything on one stream)
-struct KppHost { KppDev dev; int max_kref = 1; int col = 0; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bd = nullptr; };
+struct KppHost { KppDev dev; int max_kref = 1; int col = 0; int *wuk = nullptr; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bd = nullptr; };
 inline void kpp_destroy(MixDev &m) {
   KppHost *k = (KppHost *)m.kpp;
   if (k) {
@@ -1152,6 +1211,8 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   std::vector<int> zi(a2, 0);
   if (up(zi.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } k.KBL0 = (int *)p;
   if (up(zi.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } k.KBL = (int *)p;
+  if (up(zi.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } K->wuk = (int *)p;
+  k.WUK = nullptr; k.wu_margin = 3;
   k.Vtc = std::sqrt(0.2 / KPP_C_S / KPP_EPSSFC) / (KPP_VONKAR * KPP_VONKAR);
   k.cg = KPP_CSTAR * KPP_VONKAR * std::pow(KPP_C_S * KPP_VONKAR * KPP_EPSSFC, 1.0 / 3.0);
   k.rich_mix = c.kpp_rich_mix; k.lrich = c.lrich; k.ldbl_diff = c.ldbl_diff; k.nsmooth = c.num_v_smooth_Ri;
@@ -1191,15 +1252,6 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   const dim3 GC(col_grid(g, POP_COL_THREADS), g.nblocks), BC(POP_COL_THREADS);
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);
   double *DBLOC = s.S3a, *DBSFC = s.S3b, *WU = s.S3c, *VISC = s.S3d, *RIW = s.E3;
-  // the shear of the velocity against its surface-layer reference needs only U and V: on the side stream it overlaps the
-  // (VALU-bound) buoydiff and the interior kernel; bldepth waits for it
-  const hipStream_t su = KH.side ? KH.side : st;
-  if (KH.side) { hipEventRecord(KH.ev_fork, st); hipStreamWaitEvent(KH.side, KH.ev_fork, 0); }
-  if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
-  else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
-  // two waves per SIMD (<= 256 VGPRs, ~80 spilled) beat one wave with everything in registers: the kernel is VALU-bound
-  // and a second wave fills the division / dependency stalls of the first (POP_KPP_BUOY_WAVES=1 keeps one wave)
-  static const int bw = getenv("POP_KPP_BUOY_WAVES") ? atoi(getenv("POP_KPP_BUOY_WAVES")) : 2;
   // level-parallel LDS form (bit 2 of the mask; the default on bandwidth-bound grids, linear column order only)
   const dim3 GL(col_grid_x(g.n2, POP_COL_THREADS), g.nblocks), BL(POP_COL_THREADS, 4);
   // bit 3: buoydiff and the interior coefficients in ONE level-parallel launch
@@ -1211,6 +1263,21 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   const bool lazy = (fused_bi || plain3d) && KH.max_kref <= 28 && !g_kpp.lcheckekmo && h.c.reserved_i[5] != 1 &&
                     !(getenv("POP_KPP_LAZY") && atoi(getenv("POP_KPP_LAZY")) == 0);
   const bool lazy20 = lazy && KH.max_kref <= 20;
+  // shear kernel limited by the previous evaluation's KBL (k_kpp_ushear_col): only with the on-demand march, which can form a level
+  // that is missing itself (POP_KPP_USHEAR_HINT=0: every level; POP_KPP_USHEAR_MARGIN: levels beyond the hint, default 3)
+  if (lazy && (g_kpp_col & 1) && !(getenv("POP_KPP_USHEAR_HINT") && atoi(getenv("POP_KPP_USHEAR_HINT")) == 0)) {
+    g_kpp.WUK = KH.wuk;
+    if (getenv("POP_KPP_USHEAR_MARGIN")) g_kpp.wu_margin = atoi(getenv("POP_KPP_USHEAR_MARGIN"));
+  }
+  // the shear of the velocity against its surface-layer reference needs only U and V: on the side stream it overlaps the
+  // (VALU-bound) buoydiff and the interior kernel; bldepth waits for it
+  const hipStream_t su = KH.side ? KH.side : st;
+  if (KH.side) { hipEventRecord(KH.ev_fork, st); hipStreamWaitEvent(KH.side, KH.ev_fork, 0); }
+  if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
+  else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
+  // two waves per SIMD (<= 256 VGPRs, ~80 spilled) beat one wave with everything in registers: the kernel is VALU-bound
+  // and a second wave fills the division / dependency stalls of the first (POP_KPP_BUOY_WAVES=1 keeps one wave)
+  static const int bw = getenv("POP_KPP_BUOY_WAVES") ? atoi(getenv("POP_KPP_BUOY_WAVES")) : 2;
   if (lazy && fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8, false>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if (fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if ((g_kpp_col & 4) && KH.max_kref <= 20 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<20, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
@@ -1226,11 +1293,11 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   if (KH.side) {
     hipEventRecord(KH.ev_bd, st); hipStreamWaitEvent(KH.side, KH.ev_bd, 0);
     if (lazy20) hipLaunchKernelGGL((k_kpp_bldepth<true, 20>), GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
-                                   (const double *)DBSFC, (const double *)WU);
+                                   (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
     else if (lazy) hipLaunchKernelGGL((k_kpp_bldepth<true, 28>), GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
-                                      (const double *)DBSFC, (const double *)WU);
+                                      (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
     else hipLaunchKernelGGL((k_kpp_bldepth<false, 20>), GC, BC, 0, KH.side, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
-                            (const double *)DBSFC, (const double *)WU);
+                            (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
     hipEventRecord(KH.ev_join, KH.side);
   }
   static const bool int_reg = !getenv("POP_KPP_INTERIOR_GENERIC");
@@ -1240,11 +1307,11 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   else hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
   if (KH.side) hipStreamWaitEvent(st, KH.ev_join, 0);
   else if (lazy20) hipLaunchKernelGGL((k_kpp_bldepth<true, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
-                                      (const double *)DBSFC, (const double *)WU);
+                                      (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
   else if (lazy) hipLaunchKernelGGL((k_kpp_bldepth<true, 28>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
-                                    (const double *)DBSFC, (const double *)WU);
+                                    (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
   else hipLaunchKernelGGL((k_kpp_bldepth<false, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
-                          (const double *)DBSFC, (const double *)WU);
+                          (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                      s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
   const int vpatch = patch_rows(g);   // large grids: 64 x 4 patches (the row j + 1 of the four-point average is read by the same workgroup)

@@ -554,8 +554,15 @@ def test_kpp_on_demand_surface_buoyancy_is_bitwise_invisible(pkg, orclib_built, 
         monkeypatch.setenv(k, v)
     cfg = named_config("tiny", **kw)
     out = {}
-    for lazy in ("0", "1"):
-        monkeypatch.setenv("POP_KPP_LAZY", lazy)
+    # "0": full fields; "1": on demand, shear kernel limited by the previous KBL + 3 levels (the default); "1h0": on demand with the
+    # full shear field; "1m": the hint undercuts the march everywhere (margin -2), so the march forms the shear itself
+    variants = {"0": {"POP_KPP_LAZY": "0"}, "1": {"POP_KPP_LAZY": "1"}, "1h0": {"POP_KPP_LAZY": "1", "POP_KPP_USHEAR_HINT": "0"},
+                "1m": {"POP_KPP_LAZY": "1", "POP_KPP_USHEAR_MARGIN": "-2"}}
+    for lazy, venv in variants.items():
+        for k in ("POP_KPP_LAZY", "POP_KPP_USHEAR_HINT", "POP_KPP_USHEAR_MARGIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in venv.items():
+            monkeypatch.setenv(k, v)
         m, orc = pkg.PopModel(cfg), Oracle(cfg)
         force_kpp_case(m, orc)
         if kw.get("lshort_wave"):
@@ -568,8 +575,9 @@ def test_kpp_on_demand_surface_buoyancy_is_bitwise_invisible(pkg, orclib_built, 
         m.close()
     h = out["0"][0]
     assert h.max() > 3.0 * h[h > 0].min(), "the boundary layer has one depth everywhere: the march exits at once in every wave"
-    for a, b in zip(out["0"], out["1"]):
-        assert np.array_equal(a, b)
+    for v in ("1", "1h0", "1m"):
+        for a, b in zip(out["0"], out[v]):
+            assert np.array_equal(a, b), v
 
 
 @pytest.mark.parametrize("kw,env", [
