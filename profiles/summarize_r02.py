@@ -21,7 +21,7 @@ def short(name):
 
 
 def kernel_stats(wl):
-    fs = glob.glob(os.path.join(PROF, wl + "_stats", "*", "*kernel_trace.csv"))
+    fs = sorted(glob.glob(os.path.join(PROF, wl + "_stats", "*", "*kernel_trace.csv")), key=os.path.getmtime, reverse=True)   # newest collection first
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(fs[0])):
         a = acc.setdefault(r["Kernel_Name"], [0, 0])
@@ -37,7 +37,7 @@ def kernel_stats(wl):
 
 
 def pmc(wl, ctr):
-    fs = glob.glob(os.path.join(PROF, "%s_%s" % (wl, ctr), "*", "*counter_collection.csv"))
+    fs = sorted(glob.glob(os.path.join(PROF, "%s_%s" % (wl, ctr), "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
     acc = collections.defaultdict(lambda: [0, 0.0, 0])
     if not fs:
         return acc
@@ -57,7 +57,11 @@ def sq_summary():
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     nd = collections.defaultdict(lambda: collections.defaultdict(set))
     meta = {}
-    for f in glob.glob(os.path.join(PROF, "tx0.1v3_SQ*", "*", "*counter_collection.csv")):
+    newest = []                                    # one file per SQ pass: the newest collection
+    for d in sorted(glob.glob(os.path.join(PROF, "tx0.1v3_SQ*"))):
+        fs = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
+        newest += fs[:1]
+    for f in newest:
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if not k.startswith("k_"):
