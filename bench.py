@@ -371,7 +371,7 @@ def main():
                    "hmix": "del%d" % cfg.hmix_momentum, "vmix": ["const", "rich", "kpp"][vm],
                    "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport,
-                   # every output of the step is bitwise what the full evaluation gives (tests/test_gpu_parity.py); DESIGN.md 3b
+                   # every output of the step is bitwise what the full evaluation gives (tests/test_gpu_parity.py); DESIGN.md 3, "KPP's surface-layer buoyancy difference on demand"
                    "kpp_surface_buoyancy": ("on-demand down to the boundary-layer depth" if vm == 2 and os.environ.get("POP_KPP_LAZY", "1") != "0"
                                             and not cfg.lcheckekmo and cfg.reserved_i[5] != 1 else "every level")},
         "roofline": roof,
