@@ -115,6 +115,10 @@ struct TracerRhsArgs {
   double c2dtt;
   int use_kpp_src;
   const int *KBL = nullptr;   // LDS kernel: KPP_SRC is read down to this level only (it is +-0 below)
+  // LDS kernel, del4: the first Laplacian of the CURRENT tracers (k_del4_d2t's formula, from the tile already in LDS) for the next
+  // step, whose mix-time field they are; nullptr: not formed
+  double *D2N[2] = {nullptr, nullptr};
+  const double *AHF = nullptr;
   // add_sw_absorb (sw_absorption.F90:818-947; tracer_update, baroclinic.F90:2176): penetrating short wave as a source of
   // potential temperature.  sw_on 0: off; type 0 / 1: the per-level table swabs(0:km); 2: the chlorophyll transmission table
   int sw_on, sw_type, sw_ksol;

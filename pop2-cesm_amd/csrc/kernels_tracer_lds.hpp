@@ -75,6 +75,7 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
   // KPP's non-local source is +-0 below level KBL (blmix: ghat = 0 there, so the flux difference is 0 - 0), and the sum below starts
   // from +0.0, so a level that is not read adds the same +0.0: rows of a level in which every column is past its KBL are not fetched
   const int ksrc = (act && a.use_kpp_src) ? (a.KBL ? a.KBL[q2] : km) : 0;
+  const double ahf_next = (act && a.D2N[0]) ? a.AHF[q2] : 0.0;
   const long long vdcbase = ((long long)b * (km + 2)) * n2 + p2;
   struct Lev { double u, v, tc[2], tm[2], to[2], vdc[2], src[2]; };
   struct Hal { double u, v, tc[2], tm[2]; };
@@ -144,6 +145,8 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
         const double *TM = t.tm[buf][n], *TC = t.tc[buf][n];
         const double tc_k = cur.tc[n], tc_kp1 = nxt.tc[n], to_k = cur.to[n], to_kp1 = nxt.to[n];
         double FT = sp.ah * (CC * TM[lc] + CN * TM[lc + T::W] + CS * TM[lc - T::W] + CE * TM[lc + 1] + CW * TM[lc - 1]);
+        // hdifft_del4's first Laplacian of the current tracers, for the next step (same expression as k_del4_d2t)
+        if (a.D2N[0]) a.D2N[n][o] = ahf_next * (CC * TC[lc] + CN * TC[lc + T::W] + CS * TC[lc - T::W] + CE * TC[lc + 1] + CW * TC[lc - 1]);
         double L = 0.5 * (hdiv * tc_k + VTN * TC[lc + T::W] - VTS * TC[lc - T::W] + UTE * TC[lc + 1] - UTW * TC[lc - 1]) * tarear;
         if (k != 1) L = L + dz2rk * wtk * (tc_km1[n] + tc_k);
         if (k < km) L = L - dz2rk * wtkb * (tc_k + tc_kp1);

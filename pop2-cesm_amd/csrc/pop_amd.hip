@@ -55,6 +55,14 @@ struct pop_ctx {
   // del4: the first Laplacians need only the mix-time fields, so they run on a side stream beside the vertical-mixing
   // coefficients (own output buffers d2t / d2u instead of the shared scratch; POP_DEL4_SIDE=0: in line, scratch reused)
   double *d2t[2] = {nullptr, nullptr}, *d2u[2] = {nullptr, nullptr};
+  // del4: the tracer kernel of a step also forms the first Laplacian of its CURRENT tracers -- the mix-time field of the next
+  // (leapfrog) step -- from the tile it has in LDS; d2t_next receives it, d2t_next_slot is the time slot it belongs to
+  double *d2t_next[2] = {nullptr, nullptr};
+  bool d2t_next_valid = false; int d2t_next_slot = -1;
+  // the ghost cells of the tracers in a time slot are copies of their source cells (set-up and every halo update leave them so;
+  // a caller's pop_set_field / a restart file may not): only then is the halo update of the field formed ahead the same arithmetic
+  // as k_del4_d2t on the ghost ring
+  bool tr_ghosts_ok[3] = {true, true, true};
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_d2t = nullptr, ev_d2u = nullptr, ev_vmixu = nullptr;
   bool side_del4 = false, vmixu_pending = false, btrop_added = false, vmixu_deferred = false;   // implicit vertical mixing of U,V in flight on the side stream
   double *HBLT = nullptr, *HMXL = nullptr, *HMXL_DR = nullptr;
@@ -1429,6 +1437,12 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if ((cfg->hmix_tracer == 4 || cfg->hmix_momentum == 4) && !(getenv("POP_DEL4_SIDE") && atoi(getenv("POP_DEL4_SIDE")) == 0)) {
       if (dev_alloc(c, &c->d2t[0], a3) || dev_alloc(c, &c->d2t[1], a3) || dev_alloc(c, &c->d2u[0], a3) || dev_alloc(c, &c->d2u[1], a3)) return 1;
       c->side_del4 = true;
+      // one rank, no tripole fold (the ghost ring of the field comes from a halo update, which is the same arithmetic only where ghost
+      // cells are plain copies), centred advection through the LDS kernel, bandwidth-bound grids; POP_D2T_FUSE=0|1 overrides the size rule
+      const int fuse_env = getenv("POP_D2T_FUSE") ? atoi(getenv("POP_D2T_FUSE")) : -1;
+      if (cfg->hmix_tracer == 4 && nranks == 1 && cfg->ns_boundary != 2 && cfg->tadvect == 1 &&
+          (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
+        if (dev_alloc(c, &c->d2t_next[0], a3) || dev_alloc(c, &c->d2t_next[1], a3)) return 1;
     }
   }
   c->nchunk = red_grid_x(g);
@@ -1772,6 +1786,7 @@ long long pop_field_count(const pop_ctx *c, const char *name) {
 // only an uninterrupted sequence of pop_step calls uses the look-ahead.
 static int ahead_cancel(pop_ctx *c) {
   if (c->ahead_valid) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0)); c->ahead_valid = false; }
+  c->d2t_next_valid = false;   // same rule for the first Laplacian the tracer kernel formed for the next step
   return 0;
 }
 static int phase_impvmixu(pop_ctx *c, hipStream_t st);
@@ -1818,6 +1833,7 @@ int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *hos
     HIPCHK(c, hipMemcpy(c->h.sw.CHLI, idx.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice));
   }
   if (!strcmp(name, "KPP_SRC")) c->kpp_src_user = true;
+  if (!strcmp(name, "TRACER")) c->tr_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;
   // a new prognostic state may carry other values on land: the next steps run every workgroup again (land elimination)
   for (const char *f : {"TRACER", "UVEL", "VVEL", "RHO", "PSURF", "GRADPX", "GRADPY", "UBTROP", "VBTROP", "PGUESS", "FW_OLD"})
     if (!strcmp(name, f)) c->full_left = c->land_full_steps;
@@ -1834,6 +1850,7 @@ int pop_get_ifield(pop_ctx *c, const char *name, int *host, long long count) {
 void *pop_field_device_ptr(pop_ctx *c, const char *name, int tl, int n) {
   if (c->host_only) return nullptr;
   join_side(c);   // the caller may read the field on the launch stream
+  if (!strcmp(name, "TRACER")) c->tr_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;   // ... or write it
   double *p; long long cnt;
   return resolve(c, name, tl, n, &p, &cnt) ? nullptr : (void *)p;
 }
@@ -1931,6 +1948,7 @@ int pop_read_restart(pop_ctx *c, const char *path, int flags) {
   close(fd);
   if (rc) return rc;
   c->full_left = c->land_full_steps;   // land elimination: the state just read is new
+  for (bool &b : c->tr_ghosts_ok) b = false;
   // init_ts :1665-1681: density of both time levels from the tracers just read
   hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->curt], c->TR[1][c->curt], c->RHO[c->curt]);
   hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->oldt], c->TR[1][c->oldt], c->RHO[c->oldt]);
@@ -2047,6 +2065,12 @@ static int kpp_look_ahead(pop_ctx *c) {
 }
 static int phase_hmix_tracer(pop_ctx *c, hipStream_t st = nullptr) {   // del4 only: first Laplacian of the tracers into d2t
   if (c->h.c.hmix_tracer != 4) return 0;
+  if (c->d2t_next_valid && c->d2t_next_slot == c->mixt) {   // formed by the previous step's tracer kernel (ghost ring already updated)
+    c->d2t_next_valid = false;
+    std::swap(c->d2t[0], c->d2t_next[0]); std::swap(c->d2t[1], c->d2t_next[1]);
+    return 0;
+  }
+  c->d2t_next_valid = false;
   return mix_hdifft_del4(c->h, c->g, step_params(c), c->mix, c->TR[0][c->mixt], c->TR[1][c->mixt], c->d2t[0], c->d2t[1], c->S3c, c->S3d, st ? st : c->stream, c->err);
 }
 // advt with tadvect = 3 (advection.F90:1667-1708, 2684-3280; comp_flux_vel_ghost :1014-1120): L(T) of both tracers into lw.XOUT
@@ -2086,8 +2110,19 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
     a.sw_on = 1; a.sw_type = c->h.c.reserved_i[6]; a.sw_ksol = c->h.sw.ksol;
     a.QSW = c->SHF_QSW; a.swabs = c->h.sw.swabs; a.swTr = c->h.sw.Tr; a.swCHLI = c->h.sw.CHLI;
   }
-  if (c->h.c.tadvect == 1 && c->trc_lds_rows == 8) { launch_tracer_lds<8>(c->g, sp, a, c->stream, fwd); return 0; }
-  if (c->h.c.tadvect == 1 && c->trc_lds_rows == 4) { launch_tracer_lds<4>(c->g, sp, a, c->stream, fwd); return 0; }
+  // the next step's first Laplacian: valid when that step is a leapfrog step whose mix time is this step's current time and nothing
+  // rewrites the current tracers before then (no averaging step, no Robert filter) -- the rule of the KPP look-ahead
+  const bool lds_kernel = c->h.c.tadvect == 1 && (c->trc_lds_rows == 8 || c->trc_lds_rows == 4);
+  const bool form_next = lds_kernel && c->d2t_next[0] && !c->avg_ts && c->h.c.tmix_opt != 3 && c->tr_ghosts_ok[c->curt];
+  if (form_next) { a.D2N[0] = c->d2t_next[0]; a.D2N[1] = c->d2t_next[1]; a.AHF = c->mix.D4AHF; }
+  if (lds_kernel) {
+    if (c->trc_lds_rows == 8) launch_tracer_lds<8>(c->g, sp, a, c->stream, fwd); else launch_tracer_lds<4>(c->g, sp, a, c->stream, fwd);
+    if (form_next) {
+      if (halo_update_many(c, {{c->d2t_next[0], c->g.km}, {c->d2t_next[1], c->g.km}})) return 1;
+      c->d2t_next_valid = true; c->d2t_next_slot = c->curt;
+    }
+    return 0;
+  }
   if (fwd) { c->err = "fused forward elimination needs the LDS tracer kernel"; return 1; }
   if (c->h.c.tadvect == 2) {
     a.up = c->upw3;
@@ -2432,6 +2467,7 @@ int pop_step_tail(pop_ctx *c) {
     std::vector<HaloItem> items = {{c->UB[c->newt], 1, 1, 1}, {c->VB[c->newt], 1, 1, 1}, {c->U[c->newt], km, 1, 1}, {c->V[c->newt], km, 1, 1}, {c->RHO[c->newt], km}};
     for (int n = 0; n < c->h.nt; ++n) items.push_back({c->TR[n][c->newt], km});
     if (halo_update_many(c, items)) return 1;
+    c->tr_ghosts_ok[c->newt] = true;
   }
   if (!c->btrop_added && phase_add_btrop(c)) return 1;
   c->btrop_added = false;

@@ -649,6 +649,37 @@ def test_del4_first_laplacian_patch_shapes_agree_bitwise(pkg, monkeypatch):
             assert np.array_equal(a, b), rows
 
 
+@pytest.mark.parametrize("kw,env", [
+    ({"hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "lvariable_hmix": 1, "stepped_bathymetry": 1}, {}),   # 16 blocks: the ghost ring crosses blocks
+    ({"hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "vmix_choice": 3, "km": 62, "block_size_x": 48, "block_size_y": 40}, {"POP_TRACER_LDS": "4"}),
+    ({"hmix_tracer": 4, "ah": -1.0e21, "tmix_opt": 1, "time_mix_freq": 3, "lpressure_avg": 0}, {"POP_TRACER_LDS": "8"}),          # frequent averaging steps
+    ({"hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "tmix_opt": 3}, {}),                                      # Robert filter: never formed ahead
+])
+def test_first_laplacian_formed_by_the_previous_tracer_kernel_is_bitwise_invisible(pkg, monkeypatch, kw, env):
+    """del4 on large grids: the tracer kernel also forms the first Laplacian of its current tracers -- the next leapfrog step's
+    mix-time field -- from the tile it holds in LDS, and that step skips k_del4_d2t.  Forced on small grids: every field equal to
+    the last bit over Euler, averaging and leapfrog steps, and after a caller has replaced the tracers between two steps."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("POP_D2T_FUSE", fuse)
+        m = pkg.PopModel(cfg)
+        for s_ in range(7):
+            m.step()
+            if s_ == 3:                                   # a new state between two steps: the field formed ahead must be dropped
+                for n in (0, 1):
+                    t = m.get("TRACER", 1, n)
+                    # ghost cells that are NOT copies of their source cells: the library must then keep forming the first
+                    # Laplacian from them (k_del4_d2t) until a halo update has made the slot consistent again
+                    m.set("TRACER", t * (1.0 + 1.0e-3 * np.cos(np.arange(t.shape[-1]))), 1, n)
+        out[fuse] = [m.get(f, 1, 0).copy() for f in ("TRACER", "UVEL", "VVEL", "PSURF", "RHO")] + [m.get("TRACER", 1, 1).copy(), m.get("TRACER", 0, 0).copy()]
+        m.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("kw", [{"km": 62}, {"km": 60, "vmix_choice": 3, "stepped_bathymetry": 1},
                                 {"km": 62, "vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "block_size_x": 48, "block_size_y": 40}])
 def test_deferred_vertical_mixing_with_barotropic_sum_is_bitwise_invisible(pkg, monkeypatch, kw):
