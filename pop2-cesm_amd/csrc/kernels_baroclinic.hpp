@@ -397,6 +397,9 @@ struct MomentumRhsArgs {
   const double *RHOOLD, *RHOCUR, *RHONEW, *VVC, *DHU;
   const double *HDU, *HDV;   // del4 only: precomputed biharmonic friction
   double *UNEW, *VNEW, *ZX, *ZY;
+  // LDS kernel, del4: the first Laplacian of the CURRENT velocity (k_del4_d2u's formula, from the tile in LDS) for the next step
+  double *D2N[2] = {nullptr, nullptr};
+  const double *AMF = nullptr;
 };
 
 template <bool DEL4>

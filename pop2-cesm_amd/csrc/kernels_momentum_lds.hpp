@@ -80,6 +80,7 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a, int tj_first, in
     smfx = (kmu >= 1) ? g.SMF1[q2] : 0.0; smfy = (kmu >= 1) ? g.SMF2[q2] : 0.0;
     wuk = a.DHU[q2];
   }
+  const double amf_next = (act && a.D2N[0]) ? a.AMF[q2] : 0.0;
   double vuf = smfx, vvf = smfy;
   double rhokmx = 0.0, rhokmy = 0.0, sumx = 0.0, sumy = 0.0, zx = 0.0, zy = 0.0;
   double uc_km1 = 0.0, vc_km1 = 0.0;
@@ -187,6 +188,17 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a, int tj_first, in
                               (dmc * um0 + dmn * umn + dms * ums + dme * ume + dmw * umw));
         if (k > kmu) { hdu = 0.0; hdv = 0.0; }
         FX = FX + hdu; FY = FY + hdv;
+      }
+      if (a.D2N[0]) {   // hdiffu_del4's first Laplacian of the current velocity, for the next step (same expression as k_del4_d2u)
+        double du = 0.0, dv = 0.0;
+        if (k <= kmu) {
+          const double u0 = t.u[buf][lc], un = t.u[buf][lc + T::W], us = t.u[buf][lc - T::W], ue = t.u[buf][lc + 1], uw = t.u[buf][lc - 1];
+          const double v0 = t.v[buf][lc], vn = t.v[buf][lc + T::W], vs = t.v[buf][lc - T::W], ve = t.v[buf][lc + 1], vw = t.v[buf][lc - 1];
+          du = (cc_h * u0 + dun * un + dus * us + due * ue + duw * uw) + (dmc * v0 + dmn * vn + dms * vs + dme * ve + dmw * vw);
+          dv = (cc_h * v0 + dun * vn + dus * vs + due * ve + duw * vw) - (dmc * u0 + dmn * un + dms * us + dme * ue + dmw * uw);
+          du = amf_next * du; dv = amf_next * dv;
+        }
+        a.D2N[0][o] = du; a.D2N[1][o] = dv;
       }
       {
         const double vvc = cur.vvc;

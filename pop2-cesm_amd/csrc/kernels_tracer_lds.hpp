@@ -23,7 +23,7 @@ struct TrcTile {
 // stored instead of the right-hand side: the separate solve then only substitutes back (k_impvmixt_back).  Three field
 // passes per tracer less than right-hand side + k_impvmixt; the same operations in the same order (bitwise equal, tested).
 template <int R, bool FWD = false>
-__global__ void __launch_bounds__(POP_COL_THREADS * R)
+__global__ void __launch_bounds__(POP_COL_THREADS * R, POP_TRC_WAVES)
 k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
   using T = TrcTile<R>;
   __shared__ T t;

@@ -63,6 +63,10 @@ struct pop_ctx {
   // a caller's pop_set_field / a restart file may not): only then is the halo update of the field formed ahead the same arithmetic
   // as k_del4_d2t on the ghost ring
   bool tr_ghosts_ok[3] = {true, true, true};
+  // the same for the velocity (k_momentum_rhs_lds forms k_del4_d2u's field for the next step)
+  double *d2u_next[2] = {nullptr, nullptr};
+  bool d2u_next_valid = false; int d2u_next_slot = -1;
+  bool uv_ghosts_ok[3] = {true, true, true};
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_d2t = nullptr, ev_d2u = nullptr, ev_vmixu = nullptr;
   bool side_del4 = false, vmixu_pending = false, btrop_added = false, vmixu_deferred = false;   // implicit vertical mixing of U,V in flight on the side stream
   double *HBLT = nullptr, *HMXL = nullptr, *HMXL_DR = nullptr;
@@ -1443,6 +1447,9 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
       if (cfg->hmix_tracer == 4 && nranks == 1 && cfg->ns_boundary != 2 && cfg->tadvect == 1 &&
           (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
         if (dev_alloc(c, &c->d2t_next[0], a3) || dev_alloc(c, &c->d2t_next[1], a3)) return 1;
+      if (cfg->hmix_momentum == 4 && nranks == 1 && cfg->ns_boundary != 2 && !(getenv("POP_D2U_FUSE") && atoi(getenv("POP_D2U_FUSE")) == 0) &&
+          (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
+        if (dev_alloc(c, &c->d2u_next[0], a3) || dev_alloc(c, &c->d2u_next[1], a3)) return 1;
     }
   }
   c->nchunk = red_grid_x(g);
@@ -1786,7 +1793,8 @@ long long pop_field_count(const pop_ctx *c, const char *name) {
 // only an uninterrupted sequence of pop_step calls uses the look-ahead.
 static int ahead_cancel(pop_ctx *c) {
   if (c->ahead_valid) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0)); c->ahead_valid = false; }
-  c->d2t_next_valid = false;   // same rule for the first Laplacian the tracer kernel formed for the next step
+  c->d2t_next_valid = false;   // same rule for the first Laplacians the tracer / momentum kernels formed for the next step
+  c->d2u_next_valid = false;
   return 0;
 }
 static int phase_impvmixu(pop_ctx *c, hipStream_t st);
@@ -1834,6 +1842,7 @@ int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *hos
   }
   if (!strcmp(name, "KPP_SRC")) c->kpp_src_user = true;
   if (!strcmp(name, "TRACER")) c->tr_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;
+  if (!strcmp(name, "UVEL") || !strcmp(name, "VVEL")) c->uv_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;
   // a new prognostic state may carry other values on land: the next steps run every workgroup again (land elimination)
   for (const char *f : {"TRACER", "UVEL", "VVEL", "RHO", "PSURF", "GRADPX", "GRADPY", "UBTROP", "VBTROP", "PGUESS", "FW_OLD"})
     if (!strcmp(name, f)) c->full_left = c->land_full_steps;
@@ -1851,6 +1860,7 @@ void *pop_field_device_ptr(pop_ctx *c, const char *name, int tl, int n) {
   if (c->host_only) return nullptr;
   join_side(c);   // the caller may read the field on the launch stream
   if (!strcmp(name, "TRACER")) c->tr_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;   // ... or write it
+  if (!strcmp(name, "UVEL") || !strcmp(name, "VVEL")) c->uv_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;
   double *p; long long cnt;
   return resolve(c, name, tl, n, &p, &cnt) ? nullptr : (void *)p;
 }
@@ -1949,6 +1959,7 @@ int pop_read_restart(pop_ctx *c, const char *path, int flags) {
   if (rc) return rc;
   c->full_left = c->land_full_steps;   // land elimination: the state just read is new
   for (bool &b : c->tr_ghosts_ok) b = false;
+  for (bool &b : c->uv_ghosts_ok) b = false;
   // init_ts :1665-1681: density of both time levels from the tracers just read
   hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->curt], c->TR[1][c->curt], c->RHO[c->curt]);
   hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->oldt], c->TR[1][c->oldt], c->RHO[c->oldt]);
@@ -2170,6 +2181,12 @@ static void state_new_rows(pop_ctx *c, int j_first, int j_end) {
 }
 static int phase_hmix_momentum(pop_ctx *c, hipStream_t st = nullptr) {   // del4 only: first Laplacian of the velocity into d2u
   if (c->h.c.hmix_momentum != 4) return 0;
+  if (c->d2u_next_valid && c->d2u_next_slot == c->mixt) {   // formed by the previous step's momentum kernel (ghost ring already updated)
+    c->d2u_next_valid = false;
+    std::swap(c->d2u[0], c->d2u_next[0]); std::swap(c->d2u[1], c->d2u_next[1]);
+    return 0;
+  }
+  c->d2u_next_valid = false;
   return mix_hdiffu_del4(c->h, c->g, step_params(c), c->mix, c->U[c->mixt], c->V[c->mixt], c->d2u[0], c->d2u[1], c->S3c, c->S3d, st ? st : c->stream, c->err);
 }
 static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1) {
@@ -2180,9 +2197,17 @@ static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1) {
   a.UNEW = c->U[c->newt]; a.VNEW = c->V[c->newt]; a.ZX = c->ZX; a.ZY = c->ZY;
   // 3x3 stencils staged through LDS (kernels_momentum_lds.hpp): 64x8 tiles measured -11 % (tx0.1v3) / -12 % (gx1v7)
   // against the direct-load kernel, 64x4 +8 %; POP_MOMENTUM_LDS=0|4|8 selects (read at pop_create)
+  // the next step's first Laplacian of the velocity (see phase_tracer_rhs; whole-domain launches of the LDS kernel only)
+  const bool form_next = (c->mom_lds_rows == 8 || c->mom_lds_rows == 4) && c->d2u_next[0] && tj_first == 0 && tj_count < 0 && !c->avg_ts &&
+                         c->h.c.tmix_opt != 3 && c->uv_ghosts_ok[c->curt];
+  if (form_next) { a.D2N[0] = c->d2u_next[0]; a.D2N[1] = c->d2u_next[1]; a.AMF = c->mix.D4AMF; }
   if (c->mom_lds_rows == 8) launch_momentum_lds<8>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else if (c->mom_lds_rows == 4) launch_momentum_lds<4>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
+  if (form_next) {
+    if (halo_update_many(c, {{c->d2u_next[0], c->g.km, 1, 1}, {c->d2u_next[1], c->g.km, 1, 1}})) return 1;
+    c->d2u_next_valid = true; c->d2u_next_slot = c->curt;
+  }
   return 0;
 }
 static int phase_impvmixu(pop_ctx *c, hipStream_t st) {
@@ -2467,7 +2492,7 @@ int pop_step_tail(pop_ctx *c) {
     std::vector<HaloItem> items = {{c->UB[c->newt], 1, 1, 1}, {c->VB[c->newt], 1, 1, 1}, {c->U[c->newt], km, 1, 1}, {c->V[c->newt], km, 1, 1}, {c->RHO[c->newt], km}};
     for (int n = 0; n < c->h.nt; ++n) items.push_back({c->TR[n][c->newt], km});
     if (halo_update_many(c, items)) return 1;
-    c->tr_ghosts_ok[c->newt] = true;
+    c->tr_ghosts_ok[c->newt] = true; c->uv_ghosts_ok[c->newt] = true;
   }
   if (!c->btrop_added && phase_add_btrop(c)) return 1;
   c->btrop_added = false;

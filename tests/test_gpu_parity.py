@@ -655,20 +655,22 @@ def test_del4_first_laplacian_patch_shapes_agree_bitwise(pkg, monkeypatch):
     ({"hmix_tracer": 4, "ah": -1.0e21, "tmix_opt": 1, "time_mix_freq": 3, "lpressure_avg": 0}, {"POP_TRACER_LDS": "8"}),          # frequent averaging steps
     ({"hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "tmix_opt": 3}, {}),                                      # Robert filter: never formed ahead
 ])
-def test_first_laplacian_formed_by_the_previous_tracer_kernel_is_bitwise_invisible(pkg, monkeypatch, kw, env):
-    """del4 on large grids: the tracer kernel also forms the first Laplacian of its current tracers -- the next leapfrog step's
-    mix-time field -- from the tile it holds in LDS, and that step skips k_del4_d2t.  Forced on small grids: every field equal to
+def test_first_laplacians_formed_by_the_previous_step_are_bitwise_invisible(pkg, monkeypatch, kw, env):
+    """del4 on large grids: the tracer and momentum kernels also form the first Laplacian of their current fields -- the next
+    leapfrog step's mix-time fields -- from the tiles they hold in LDS, and that step skips k_del4_d2t / k_del4_d2u.  Forced on small grids: every field equal to
     the last bit over Euler, averaging and leapfrog steps, and after a caller has replaced the tracers between two steps."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cfg = named_config("tiny", **kw)
     out = {}
     for fuse in ("0", "1"):
-        monkeypatch.setenv("POP_D2T_FUSE", fuse)
+        monkeypatch.setenv("POP_D2T_FUSE", fuse)           # the velocity's first Laplacian follows the same switch (k_momentum_rhs_lds)
         m = pkg.PopModel(cfg)
         for s_ in range(7):
             m.step()
             if s_ == 3:                                   # a new state between two steps: the field formed ahead must be dropped
+                u = m.get("UVEL", 1, 0)
+                m.set("UVEL", u * (1.0 + 1.0e-3 * np.sin(np.arange(u.shape[-1]))), 1, 0)
                 for n in (0, 1):
                     t = m.get("TRACER", 1, n)
                     # ghost cells that are NOT copies of their source cells: the library must then keep forming the first
