@@ -352,6 +352,11 @@ def main():
         # beside `frac`, never instead of it.
         gb12 = 12 * 8.0 * ncell_phys / 1e9
         roof["frac_with_del4_inputs"] = round(gb12 / (phases[dom]["ms"] * 1e-3) / HBM_PEAK_GBS, 4)
+        if model.dim("d2u_fused"):
+            # large grids: the same launch also WRITES the next step's first Laplacian of the velocity (the output of k_del4_d2u, which
+            # is then not launched: SURVEY's del4 row, 2 of its 4 words): 14 words move through it.  avg_launch_ms is this launch.
+            roof["also_writes"] = "D2U, D2V of the next step (k_del4_d2u's output; that kernel is not launched on leapfrog steps)"
+            roof["frac_with_del4_fields"] = round(14 * 8.0 * ncell_phys / 1e9 / (phases[dom]["ms"] * 1e-3) / HBM_PEAK_GBS, 4)
     # both baroclinic stencil kernels together (tracer + momentum right-hand sides): algorithmic bytes / summed time
     pair_gb = phases["tracer_rhs"]["alg_GB"] + phases["momentum_rhs"]["alg_GB"]
     pair_ms = phases["tracer_rhs"]["ms"] + phases["momentum_rhs"]["ms"]

@@ -1737,6 +1737,8 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "newtime") return c->newt;
   if (n == "leapfrogts") return c->leapfrogts;
   if (n == "land_skip_active") return c->g.skip;
+  if (n == "d2t_fused") return c->d2t_next[0] != nullptr;   // the tracer / momentum kernels also form the next step's del4 first Laplacian
+  if (n == "d2u_fused") return c->d2u_next[0] != nullptr;
   if (n == "avg_ts") return c->avg_ts;
   if (n == "nsteps_total") return c->nsteps_total;
   if (n == "nsteps_per_interval") return c->h.nsteps_per_interval;
