@@ -1441,13 +1441,13 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if ((cfg->hmix_tracer == 4 || cfg->hmix_momentum == 4) && !(getenv("POP_DEL4_SIDE") && atoi(getenv("POP_DEL4_SIDE")) == 0)) {
       if (dev_alloc(c, &c->d2t[0], a3) || dev_alloc(c, &c->d2t[1], a3) || dev_alloc(c, &c->d2u[0], a3) || dev_alloc(c, &c->d2u[1], a3)) return 1;
       c->side_del4 = true;
-      // one rank, no tripole fold (the ghost ring of the field comes from a halo update, which is the same arithmetic only where ghost
-      // cells are plain copies), centred advection through the LDS kernel, bandwidth-bound grids; POP_D2T_FUSE=0|1 overrides the size rule
+      // no tripole fold (the ghost ring of the field comes from a halo update, which is the same arithmetic only where ghost cells are
+      // plain copies), centred advection through the LDS kernel, bandwidth-bound grids; POP_D2T_FUSE=0|1 overrides the size rule
       const int fuse_env = getenv("POP_D2T_FUSE") ? atoi(getenv("POP_D2T_FUSE")) : -1;
-      if (cfg->hmix_tracer == 4 && nranks == 1 && cfg->ns_boundary != 2 && cfg->tadvect == 1 &&
+      if (cfg->hmix_tracer == 4 && cfg->ns_boundary != 2 && cfg->tadvect == 1 &&
           (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
         if (dev_alloc(c, &c->d2t_next[0], a3) || dev_alloc(c, &c->d2t_next[1], a3)) return 1;
-      if (cfg->hmix_momentum == 4 && nranks == 1 && cfg->ns_boundary != 2 && !(getenv("POP_D2U_FUSE") && atoi(getenv("POP_D2U_FUSE")) == 0) &&
+      if (cfg->hmix_momentum == 4 && cfg->ns_boundary != 2 && !(getenv("POP_D2U_FUSE") && atoi(getenv("POP_D2U_FUSE")) == 0) &&
           (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
         if (dev_alloc(c, &c->d2u_next[0], a3) || dev_alloc(c, &c->d2u_next[1], a3)) return 1;
     }
@@ -2191,7 +2191,7 @@ static int phase_hmix_momentum(pop_ctx *c, hipStream_t st = nullptr) {   // del4
   c->d2u_next_valid = false;
   return mix_hdiffu_del4(c->h, c->g, step_params(c), c->mix, c->U[c->mixt], c->V[c->mixt], c->d2u[0], c->d2u[1], c->S3c, c->S3d, st ? st : c->stream, c->err);
 }
-static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1) {
+static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1, bool last_piece = true) {
   MomentumRhsArgs a{};
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.UOLD = c->U[c->oldt]; a.VOLD = c->V[c->oldt]; a.UMIX = c->U[c->mixt]; a.VMIX = c->V[c->mixt];
   a.RHOOLD = c->RHO[c->oldt]; a.RHOCUR = c->RHO[c->curt]; a.RHONEW = c->RHO[c->newt]; a.VVC = c->VVC; a.DHU = c->DHU;
@@ -2200,13 +2200,15 @@ static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1) {
   // 3x3 stencils staged through LDS (kernels_momentum_lds.hpp): 64x8 tiles measured -11 % (tx0.1v3) / -12 % (gx1v7)
   // against the direct-load kernel, 64x4 +8 %; POP_MOMENTUM_LDS=0|4|8 selects (read at pop_create)
   // the next step's first Laplacian of the velocity (see phase_tracer_rhs; whole-domain launches of the LDS kernel only)
-  const bool form_next = (c->mom_lds_rows == 8 || c->mom_lds_rows == 4) && c->d2u_next[0] && tj_first == 0 && tj_count < 0 && !c->avg_ts &&
+  // (several ranks launch the kernel in three pieces -- interior tile rows, then the rim rows: every piece writes its tiles, the halo
+  // update follows the last one)
+  const bool form_next = (c->mom_lds_rows == 8 || c->mom_lds_rows == 4) && c->d2u_next[0] && !c->avg_ts &&
                          c->h.c.tmix_opt != 3 && c->uv_ghosts_ok[c->curt];
   if (form_next) { a.D2N[0] = c->d2u_next[0]; a.D2N[1] = c->d2u_next[1]; a.AMF = c->mix.D4AMF; }
   if (c->mom_lds_rows == 8) launch_momentum_lds<8>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else if (c->mom_lds_rows == 4) launch_momentum_lds<4>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
-  if (form_next) {
+  if (form_next && last_piece) {
     if (halo_update_many(c, {{c->d2u_next[0], c->g.km, 1, 1}, {c->d2u_next[1], c->g.km, 1, 1}})) return 1;
     c->d2u_next_valid = true; c->d2u_next_slot = c->curt;
   }
@@ -2262,10 +2264,10 @@ int pop_baroclinic_driver(pop_ctx *c) {
       state_new_rows(c, NGHOST, c->g.nyb - NGHOST);                      // physical rows: own cells + ghosts copied inside the rank
       if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2u, 0));
       else if (phase_hmix_momentum(c)) return 1;
-      if (phase_momentum_rhs(c, 1, mtiles_j - 2)) return 1;             // interior tile rows
+      if (phase_momentum_rhs(c, 1, mtiles_j - 2, false)) return 1;      // interior tile rows
       if (halo_many_end(c, HA)) return 1;
       state_new_rows(c, 0, NGHOST); state_new_rows(c, c->g.nyb - NGHOST, c->g.nyb);   // ghost rows
-      if (phase_momentum_rhs(c, 0, 1) || phase_momentum_rhs(c, mtiles_j - 1, 1)) return 1;   // rim tile rows
+      if (phase_momentum_rhs(c, 0, 1, false) || phase_momentum_rhs(c, mtiles_j - 1, 1, true)) return 1;   // rim tile rows
     } else {
       if (halo_update_many(c, {{c->TR[0][c->newt], c->g.km}, {c->TR[1][c->newt], c->g.km}})) return 1;
       if (phase_state_new(c)) return 1;

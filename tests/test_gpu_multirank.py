@@ -69,6 +69,7 @@ def test_large_grid_two_ranks_equal_single_rank():
     (3, "precond_choice=1,solver_choice=3,block_size_x=24,block_size_y=20", {}),   # P-CSI + EVP, uneven ownership
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3 across ranks
     (2, "tadvect=3", {}),                                             # lw_lim: halo update of the flux-velocity fields across ranks
+    (2, "hmix_momentum=4,hmix_tracer=4,am=-1.0e22,ah=-1.0e21,lvariable_hmix=1", {"POP_D2T_FUSE": "1"}),   # del4 first Laplacians formed by the previous step's kernels: their ghost ring crosses ranks
 ])
 def test_multirank_equals_single_rank(nranks, kw, env):
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
@@ -93,6 +94,8 @@ def test_multirank_equals_single_rank(nranks, kw, env):
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3
     (4, "tadvect=3,block_size_x=24,block_size_y=20", {}),             # lw_lim, one block per rank
     (2, "km=62,vmix_choice=3,ny_global=80,block_size_x=48,block_size_y=40", {"POP_VMIXU_DEFER": "1", "POP_SOLVER_DISTRIBUTED": "1"}),   # U,V vertical mixing held back past the distributed solve
+    (2, "hmix_momentum=4,hmix_tracer=4,am=-1.0e22,ah=-1.0e21,ny_global=80,block_size_x=48,block_size_y=40", {"POP_D2T_FUSE": "1", "POP_SOLVER_DISTRIBUTED": "1"}),   # del4 first Laplacians formed ahead; the momentum kernel runs in three pieces beside the T,S halo
+    (3, "hmix_momentum=4,hmix_tracer=4,am=-1.0e22,ah=-1.0e21,block_size_x=24,block_size_y=20,vmix_choice=3,km=24", {"POP_D2T_FUSE": "1"}),   # the same with uneven ownership and KPP
 ])
 def test_native_transport_equals_single_rank(nranks, kw, env):
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
