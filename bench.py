@@ -339,7 +339,12 @@ def main():
             continue
         nw = words[vm]
         # del4 on large grids: the tracer / momentum launch also writes the next step's first Laplacian (the output of k_del4_d2t /
-        # k_del4_d2u, which are then not launched): the two written words of SURVEY's del4 row belong to this launch
+        # k_del4_d2u, which are then not launched): the two written words of SURVEY's del4 row belong to this launch -- if the
+        # launches just timed did write them (they do not when the last step was an averaging step)
+        if ph == "tracer_rhs":
+            fused_t = bool(model.dim("d2t_last_formed"))
+        if ph == "momentum_rhs":
+            fused_u = bool(model.dim("d2u_last_formed"))
         if (ph == "tracer_rhs" and fused_t) or (ph == "momentum_rhs" and fused_u):
             nw += 2
         gb = nw * 8.0 * ncell_phys / 1e9

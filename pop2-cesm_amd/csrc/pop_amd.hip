@@ -67,6 +67,7 @@ struct pop_ctx {
   double *d2u_next[2] = {nullptr, nullptr};
   bool d2u_next_valid = false; int d2u_next_slot = -1;
   bool uv_ghosts_ok[3] = {true, true, true};
+  bool d2t_last_formed = false, d2u_last_formed = false;   // did the last tracer / momentum launch write the next step's field (bench accounting)
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_d2t = nullptr, ev_d2u = nullptr, ev_vmixu = nullptr;
   bool side_del4 = false, vmixu_pending = false, btrop_added = false, vmixu_deferred = false;   // implicit vertical mixing of U,V in flight on the side stream
   double *HBLT = nullptr, *HMXL = nullptr, *HMXL_DR = nullptr;
@@ -1739,6 +1740,8 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "land_skip_active") return c->g.skip;
   if (n == "d2t_fused") return c->d2t_next[0] != nullptr;   // the tracer / momentum kernels also form the next step's del4 first Laplacian
   if (n == "d2u_fused") return c->d2u_next[0] != nullptr;
+  if (n == "d2t_last_formed") return c->d2t_last_formed;   // ... and whether the last such launch did (not on averaging steps)
+  if (n == "d2u_last_formed") return c->d2u_last_formed;
   if (n == "avg_ts") return c->avg_ts;
   if (n == "nsteps_total") return c->nsteps_total;
   if (n == "nsteps_per_interval") return c->h.nsteps_per_interval;
@@ -2128,6 +2131,7 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   const bool lds_kernel = c->h.c.tadvect == 1 && (c->trc_lds_rows == 8 || c->trc_lds_rows == 4);
   const bool form_next = lds_kernel && c->d2t_next[0] && !c->avg_ts && c->h.c.tmix_opt != 3 && c->tr_ghosts_ok[c->curt];
   if (form_next) { a.D2N[0] = c->d2t_next[0]; a.D2N[1] = c->d2t_next[1]; a.AHF = c->mix.D4AHF; }
+  c->d2t_last_formed = form_next;
   if (lds_kernel) {
     if (c->trc_lds_rows == 8) launch_tracer_lds<8>(c->g, sp, a, c->stream, fwd); else launch_tracer_lds<4>(c->g, sp, a, c->stream, fwd);
     if (form_next) {
@@ -2205,6 +2209,7 @@ static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1, b
   const bool form_next = (c->mom_lds_rows == 8 || c->mom_lds_rows == 4) && c->d2u_next[0] && !c->avg_ts &&
                          c->h.c.tmix_opt != 3 && c->uv_ghosts_ok[c->curt];
   if (form_next) { a.D2N[0] = c->d2u_next[0]; a.D2N[1] = c->d2u_next[1]; a.AMF = c->mix.D4AMF; }
+  c->d2u_last_formed = form_next;
   if (c->mom_lds_rows == 8) launch_momentum_lds<8>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else if (c->mom_lds_rows == 4) launch_momentum_lds<4>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
