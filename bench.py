@@ -50,10 +50,10 @@ def workload_config(name, nranks, block_rows=0):
         if cfg.ny_global % block_rows:
             raise SystemExit("ny_global=%d not divisible by --block-rows %d" % (cfg.ny_global, block_rows))
         cfg.block_size_y = block_rows
-        cfg.reserved_i[4] = 1
+        cfg.distribution_type = 1
     elif nranks > 1:
         # shard by j-bands.  Large grids: more bands than ranks (16, or 4 per rank) handed out as contiguous runs of equal
-        # OCEAN columns (reserved_i[4] = 1, the reference's load-balanced distributions): with land elimination a rank's
+        # OCEAN columns (distribution_type = 1, the reference's load-balanced distributions): with land elimination a rank's
         # time follows its ocean columns, and equal bands of tx0.1v3's synthetic topography differ by 1.46 x at 8 ranks
         # (1.16 x with 75-row bands, 1.06 x at 4 ranks, 1.00 x at 2).  Small grids: one band per rank.
         if cfg.ny_global % nranks:
@@ -64,7 +64,7 @@ def workload_config(name, nranks, block_rows=0):
         # measured on one GPU, tx0.1v3 as 8 blocks: 124.8 ms against 116.1)
         if nranks >= 4 and cfg.ny_global % bands == 0 and cfg.ny_global // bands >= 64:
             cfg.block_size_y = cfg.ny_global // bands
-            cfg.reserved_i[4] = 1
+            cfg.distribution_type = 1
     return cfg
 
 
@@ -258,7 +258,7 @@ def main():
     pkg = ge.load_package()
     cfg = workload_config(args.workload, world, args.block_rows)
     cfg.solver_choice = {"pcg": 1, "chrongear": 2, "pcsi": 3}[args.solver]
-    cfg.reserved_i[2] = 1 if args.precond == "evp" else 0
+    cfg.preconditioner_choice = 1 if args.precond == "evp" else 0
     model = pkg.PopModel(cfg, rank=rank, nranks=world)
     comm, transport = None, "none"
     if world > 1:
@@ -384,14 +384,14 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "grid": [cfg.nx_global, cfg.ny_global, cfg.km], "nt": cfg.nt,
                    "block_size": [cfg.block_size_x, cfg.block_size_y], "steps_per_day": cfg.steps_per_day, "step_calls_per_day": calls_per_day,
-                   "land_tile_fraction": round(land_frac, 4), "distribution": "balanced-ocean-columns" if cfg.reserved_i[4] else "equal-block-counts",
+                   "land_tile_fraction": round(land_frac, 4), "distribution": "balanced-ocean-columns" if cfg.distribution_type else "equal-block-counts",
                    "blocks_local": model.nblocks,
                    "hmix": "del%d" % cfg.hmix_momentum, "vmix": ["const", "rich", "kpp"][vm],
                    "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport,
                    # every output of the step is bitwise what the full evaluation gives (tests/test_gpu_parity.py); DESIGN.md 3, "KPP's surface-layer buoyancy difference on demand"
                    "kpp_surface_buoyancy": ("on-demand down to the boundary-layer depth" if vm == 2 and os.environ.get("POP_KPP_LAZY", "1") != "0"
-                                            and not cfg.lcheckekmo and cfg.reserved_i[5] != 1 else "every level")},
+                                            and not cfg.lcheckekmo and cfg.kpp_ml_diagnostics != 1 else "every level")},
         "roofline": roof,
     }
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

@@ -30,7 +30,9 @@ extern "C" {
 /* Run-time configuration: the namelist subset this path reads
  * (domain_nml, grid_nml, time_manager_nml, hmix_*_nml, vertical_mix_nml,
  *  vmix_*_nml, advect_nml, pressure_grad_nml, baroclinic_nml, &solvers). */
+#define POP_CONFIG_VERSION 3   /* layout of pop_config below; pop_create refuses any other struct_version */
 typedef struct pop_config {
+  int struct_version;         /* = POP_CONFIG_VERSION (round 3: every option has its own named field) */
   int nx_global, ny_global, km, nt;   /* domain_size.F90 */
   int block_size_x, block_size_y;     /* domain_size.F90 */
   int ew_boundary;            /* 0 closed, 1 cyclic   (domain.F90 ew_boundary_type) */
@@ -41,7 +43,7 @@ typedef struct pop_config {
   int vmix_choice;            /* 1 const, 2 rich, 3 kpp (vertical_mix.F90:280-296) */
   int tadvect;                /* 1 centered, 2 upwind3, 3 lw_lim (advection.F90:1667-1729, 2313-2676, 2684-3280) */
   int solver_choice;          /* 1 pcg, 2 ChronGear, 3 PCSI with Lanczos eigenvalue bounds
-                               * (POP_SolversMod.F90:442-472, 1510-1835, 2699-2990); preconditioner: reserved_i[2] */
+                               * (POP_SolversMod.F90:442-472, 1510-1835, 2699-2990) */
   int max_iterations;
   int convergence_check_freq;
   int tmix_opt;               /* 0 none, 1 avg, 2 avgfit (time_management.F90:2170-2213), 3 robert
@@ -50,19 +52,25 @@ typedef struct pop_config {
   int steps_per_day;          /* dt_option='steps_per_day', dt_count */
   int lbouss_correct, lpressure_avg, impcor, reset_to_freezing;
   int lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri; /* vmix_kpp_nml (lshort_wave reads SHF_QSW: pop_set_field) */
-  int reserved_i[8];          /* [0] = maxlanczosstep (0 = 20), [1] = convergenceCheckStart (0 = 60) for PCSI
-                               * (POP_SolversMod.F90:626-640); [2] = preconditionerChoice: 0 'diagonal', 1 'evp'
-                               * (:124, :252-290, :2434-2696; any solver_choice);
-                               * [3] = synthetic topography: 0 the reference's internal flat bottom (grid.F90:880-884,
-                               * 1957-1985), 1 stepped bathymetry KMT = 3 ... km (test extension, not in the reference);
-                               * [4] = distribution of the blocks over ranks (distribution_type, domain.F90): 0 contiguous runs of
-                               * equal block counts ('cartesian' for one column of blocks), 1 contiguous runs of equal ocean
-                               * columns (load-balanced, in the spirit of 'rake' / 'spacecurve', distribution.F90);
-                               * [5] = 1: the diagnostic mixed-layer depths of vmix_coeffs_kpp every step (HMXL, HMXL_DR,
-                               * vmix_kpp.F90:1310-1418; fields "HMXL", "HMXL_DR"); 0: not computed (nothing on the path reads them);
-                               * [6] = sw_absorption_type for lshort_wave: 0 'top-layer', 1 'jerlov' (sw_absorption.F90:736-811),
-                               * 2 'chlorophyll' (:467-728, 951-1047; the field "CHL", mg/m^3, is 0.25 until set with pop_set_field);
-                               * [7] = jerlov_water_type 1..5 (0 = 3, the CESM default) */
+  int maxlanczosstep;         /* solvers_nml, PCSI (POP_SolversMod.F90:626): 0 = 20 */
+  int convergence_check_start;/* solvers_nml convergenceCheckStart, PCSI (:636): 0 = 60 */
+  int preconditioner_choice;  /* solvers_nml preconditionerChoice (:124, :252-290, :2434-2696): 0 'diagonal', 1 'evp'; any solver_choice */
+  int stepped_bathymetry;     /* synthetic topography: 0 the reference's internal flat bottom (grid.F90:880-884, 1957-1985),
+                               * 1 stepped bathymetry KMT = 3 ... km (TEST EXTENSION, not in the reference) */
+  int distribution_type;      /* domain_nml clinic_distribution_type (domain.F90): 0 contiguous runs of equal block counts
+                               * ('cartesian' for one column of blocks), 1 contiguous runs of equal ocean columns
+                               * (load-balanced, in the spirit of 'rake' / 'spacecurve', distribution.F90) */
+  int kpp_ml_diagnostics;     /* 1: the diagnostic mixed-layer depths of vmix_coeffs_kpp every step (HMXL, HMXL_DR,
+                               * vmix_kpp.F90:1310-1418; fields "HMXL", "HMXL_DR"); 0: not computed (nothing on the path reads them) */
+  int sw_absorption_type;     /* sw_absorption_nml: 0 'top-layer', 1 'jerlov' (sw_absorption.F90:736-811),
+                               * 2 'chlorophyll' (:467-728, 951-1047; the field "CHL", mg/m^3, is 0.25 until set with pop_set_field) */
+  int jerlov_water_type;      /* 1..5 (0 = 3, the CESM default) */
+  int lsw_absorb;             /* != 0: the penetrating short wave SHF_QSW heats the levels below the first
+                               * (add_sw_absorb, sw_absorption.F90:818-947, in tracer_update) with sw_absorption_type */
+  int partial_bottom_cells;   /* grid_nml partial_bottom_cells (grid.F90:916-1020): 1 = the bottom T cell of every column has the
+                               * thickness DZBC (pop_grid_input.DZBC = the record of bottom_cell_file; NULL with the internal
+                               * topography: a synthetic DZBC in (0.25, 1] dz(KMT), TEST EXTENSION), DZT / DZU as the reference forms them */
+  int reserved_i[3];          /* must be 0 */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;
@@ -70,17 +78,66 @@ typedef struct pop_config {
   double bckgrnd_vdc1, bckgrnd_vdc2, bckgrnd_vdc_dpth, bckgrnd_vdc_linv;
   double Prandtl, kpp_rich_mix;
   double convergence_criterion;
-  double reserved_d[8];       /* [0] = amplitude of the synthetic initial T perturbation;
-                               * [1], [2] = robert_alpha, robert_nu for tmix_opt = 3 (0 = defaults 0.53, 0.20,
-                               * time_management.F90:461-462); [3] = LanczosconvergenceCriterion (0 = 0.1);
-                               * [4] != 0: lsw_absorb -- the penetrating short wave SHF_QSW heats the levels below the first
-                               * (add_sw_absorb, sw_absorption.F90:818-947, in tracer_update) with sw_absorption_type reserved_i[6] */
+  double init_ts_perturbation;           /* amplitude of the synthetic initial T perturbation (1e-2) */
+  double robert_alpha, robert_nu;        /* tmix_opt = 3 (0 = defaults 0.53, 0.20, time_management.F90:461-462) */
+  double lanczos_convergence_criterion;  /* PCSI LanczosconvergenceCriterion (0 = 0.1) */
+  double reserved_d[4];                  /* must be 0 */
 } pop_config;
 
 typedef struct pop_ctx pop_ctx;
 
 /* flags for pop_create */
 #define POP_CREATE_HOST_ONLY 1   /* build blocks/grid/plans on the host, touch no GPU */
+
+/* ---- tuning: kernel-form and schedule choices.  NONE changes a result: every alternative is tested bitwise equal to the
+ *      default (tests/test_gpu_parity.py, test_gpu_land.py, test_gpu_multirank.py); they exist for measurement and for those
+ *      tests.  Resolved ONCE, at pop_create*: the library's size rules, overridden by the caller's pop_tuning (fields left at
+ *      POP_TUNING_UNSET keep the rule), overridden by the environment variable POP_<FIELD NAME IN UPPER CASE> (read at create
+ *      only; nothing in the step reads the environment).  pop_get_tuning returns what was resolved. ---------------------- */
+#define POP_TUNING_UNSET (-2147483647 - 1)
+typedef struct pop_tuning {
+  int struct_bytes;        /* sizeof(pop_tuning) of the caller */
+  int land_skip;           /* 0: every workgroup runs (no land elimination at tile granularity) */
+  int land_full_steps;     /* steps after set-up / restart / a new state that run every workgroup (default 4) */
+  int xcd_remap;           /* column kernels: workgroup order 0 linear, 1 XCD bands, 2 XCD-strided 2-D tiles */
+  int red_tiles, red_band; /* 2-D reduction / solver kernels: 64x4 tiles | XCD-banded chunk order */
+  int lds_order;           /* LDS-tiled stencil kernels: 1 = XCD patch order */
+  int momentum_lds;        /* momentum right-hand side: LDS tile rows 8 | 4, 0 = direct-load kernel */
+  int tracer_lds;          /* tracer right-hand side (centred advection): LDS tile rows 8 | 4, 0 = direct-load kernel */
+  int generic_thomas;      /* 1: scratch-staged Thomas kernels for U, V even at km = 60 / 62 */
+  int reg_thomas_t;        /* tracers: 1 register Thomas kernels (km = 60 / 62), 0 generic */
+  int thomas_pair;         /* corrector: both tracers in one thread when they share the diffusivity array */
+  int tracer_fwd;          /* predictor: forward elimination inside the tracer right-hand-side kernel */
+  int vdc_shared;          /* 0: two diffusivity arrays even without double diffusion */
+  int side_stream;         /* 0: no side stream at all (every launch in the reference's order on one stream) */
+  int del4_side;           /* 0: del4 first Laplacians in line instead of beside the vertical-mixing coefficients */
+  int del4_tile;           /* del4 first Laplacians: patch rows 0 | 2 | 4 | 8 | 16 */
+  int d2t_fuse, d2u_fuse;  /* del4: the previous step's tracer / momentum launch forms the first Laplacian */
+  int vmixu_defer;         /* implicit vertical mixing of U, V launched after the solve with the barotropic sum */
+  int vmixu_inline;        /* 1: implicit vertical mixing of U, V on the launch stream */
+  int btrop_inline;        /* 1: barotropic velocity added in the step tail (the reference's order) */
+  int kpp_ahead;           /* KPP of the next step beside the barotropic solver */
+  int kpp_col;             /* KPP kernel forms, bit mask: 1 ushear column, 2 buoydiff column, 4 buoydiff LDS, 8 buoydiff + interior fused */
+  int kpp_lazy;            /* 0: surface-layer buoyancy difference at every level */
+  int kpp_ushear_hint;     /* 0: shear kernel forms every level */
+  int kpp_ushear_margin;   /* levels beyond the previous boundary-layer level (default 3; may be negative) */
+  int kpp_side_stream;     /* 0: KPP kernels on one stream */
+  int kpp_buoy_waves;      /* column buoydiff: waves per SIMD 1 | 2 */
+  int kpp_interior_generic;/* 1: scratch-staged interior kernel even at km = 60 / 62 */
+  int kpp_src_full;        /* 1: the tracer kernel reads KPP_SRC at every level */
+  int solver_unfused;      /* 1: one kernel per solver operation */
+  int solver_nograph;      /* 1: no hipGraph replay of the check intervals */
+  int solver_presum;       /* 1: block sums by their own launch even on small grids */
+  int solver_distributed;  /* 1: never the replicated barotropic solve */
+  int solver_overlap_off;  /* 1: solver halo exchange in line with the all-reduce */
+  int fpcg_b2;             /* 0: one cell per thread in step B of the fused pcg */
+  int pcsi_step2;          /* fused P-CSI step with two cells per thread */
+  int halo_separate;       /* 1: one message per field instead of one per neighbour */
+  int halo_overlap_off;    /* 1: mid-step tracer halo in line instead of beside interior tiles */
+  int rccl_overlap;        /* second communicator: 0 none, 1 (default) own stream, 2 ... */
+} pop_tuning;
+void pop_tuning_init(pop_tuning *t);   /* struct_bytes = sizeof, every field POP_TUNING_UNSET */
+int pop_get_tuning(const pop_ctx *ctx, pop_tuning *resolved);   /* fields still POP_TUNING_UNSET: the size rule applied */
 
 /* ---- lifecycle (no reference counterpart: the reference's state is module
  *      global, initial.F90:133-699 builds it) -------------------------------- */
@@ -96,8 +153,13 @@ int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx *
 typedef struct pop_grid_input {
   const double *ULAT, *ULON, *HTN, *HTE, *HUS, *HUW, *ANGLE;
   const int *KMT;
+  const double *DZBC;   /* partial_bottom_cells: the record of bottom_cell_file (read_bottom_cell, grid.F90:2116-2186): thickness of
+                         * the bottom T cell of every column [cm], global (nx_global, ny_global), scattered as a centre scalar.
+                         * NULL: see pop_config.partial_bottom_cells */
 } pop_grid_input;
 int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int rank, int nranks, int flags, pop_ctx **out);
+/* the same with the caller's tuning (NULL: none); grid may be NULL */
+int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const pop_tuning *tuning, int rank, int nranks, int flags, pop_ctx **out);
 int pop_read_grid_files(const char *horiz_grid_file, const char *topography_file, int nx_global, int ny_global,
                         double *seven_records /* 7*nx*ny, or NULL */, int *kmt /* nx*ny, or NULL */);
 int pop_destroy(pop_ctx *ctx);

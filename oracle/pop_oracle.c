@@ -383,8 +383,8 @@ static void horiz_grid(orc_model *m) {
       if (latd > 60.0 && lond > 210.0 && lond < 150.0) kmt = 0;
       if (latd > -60.0 && lond > 110.0 && lond < 150.0) kmt = 0;
       if (fabs(latd) > 75.0) kmt = 0;
-      /* reserved_i[3] = 1: stepped synthetic bathymetry (test extension; the reference's internal topography is flat) */
-      if (kmt > 0 && m->c.reserved_i[3] == 1) {
+      /* stepped_bathymetry = 1: stepped synthetic bathymetry (test extension; the reference's internal topography is flat) */
+      if (kmt > 0 && m->c.stepped_bathymetry == 1) {
         int cut = ((i / 3) * 5 + (j / 2) * 3) % (m->km / 2 + 1);
         kmt = m->km - cut;
         if (kmt < 3) kmt = 3;

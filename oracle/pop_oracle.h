@@ -27,6 +27,7 @@ extern "C" {
 /* Same field order as include/pop_amd.h's pop_config so one ctypes
  * Structure serves both libraries (declared separately on purpose). */
 typedef struct {
+  int struct_version;         /* = 3, as include/pop_amd.h POP_CONFIG_VERSION */
   int nx_global, ny_global, km, nt;
   int block_size_x, block_size_y;
   int ew_boundary;            /* 0 closed, 1 cyclic */
@@ -35,16 +36,22 @@ typedef struct {
   int hmix_tracer;            /* 2 del2, 4 del4 */
   int lvariable_hmix;         /* variable hmix coefficients */
   int vmix_choice;            /* 1 const, 2 rich, 3 kpp */
-  int tadvect;                /* 1 centered, 2 upwind3 */
-  int solver_choice;          /* 1 pcg, 2 ChronGear */
+  int tadvect;                /* 1 centered, 2 upwind3, 3 lw_lim */
+  int solver_choice;          /* 1 pcg, 2 ChronGear, 3 PCSI */
   int max_iterations;
   int convergence_check_freq;
-  int tmix_opt;               /* 0 none, 1 avg, 2 avgfit */
+  int tmix_opt;               /* 0 none, 1 avg, 2 avgfit, 3 robert */
   int time_mix_freq;
   int steps_per_day;
   int lbouss_correct, lpressure_avg, impcor, reset_to_freezing;
   int lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri; /* kpp */
-  int reserved_i[8];
+  int maxlanczosstep, convergence_check_start, preconditioner_choice;   /* solvers_nml */
+  int stepped_bathymetry;     /* test extension */
+  int distribution_type;
+  int kpp_ml_diagnostics;
+  int sw_absorption_type, jerlov_water_type, lsw_absorb;
+  int partial_bottom_cells;   /* grid.F90:916-1020 */
+  int reserved_i[3];
   double am, ah;              /* del2 or del4 coefficients */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;
@@ -52,7 +59,8 @@ typedef struct {
   double bckgrnd_vdc1, bckgrnd_vdc2, bckgrnd_vdc_dpth, bckgrnd_vdc_linv;
   double Prandtl, kpp_rich_mix;
   double convergence_criterion;
-  double reserved_d[8];
+  double init_ts_perturbation, robert_alpha, robert_nu, lanczos_convergence_criterion;
+  double reserved_d[4];
 } orc_config;
 
 typedef struct orc_model orc_model;
@@ -63,6 +71,7 @@ typedef struct orc_model orc_model;
 typedef struct {
   const double *ULAT, *ULON, *HTN, *HTE, *HUS, *HUW, *ANGLE;
   const int *KMT;
+  const double *DZBC;   /* partial_bottom_cells: record of bottom_cell_file (grid.F90:2116-2186), or NULL */
 } orc_grid_input;
 
 orc_model *orc_create(const orc_config *cfg);
@@ -107,7 +116,7 @@ double orc_global_sum(orc_model *m, const double *a, const double *mask);
 double orc_global_sum_tripole(orc_model *m, const double *a, const double *mask, int loc);
 int    orc_solver_iterations(orc_model *m);
 double orc_solver_rms(orc_model *m);
-/* POP_SolversMod.F90:2268-2369 preconditioner on whole arrays (EVP when reserved_i[2] = 1), :2992 partition */
+/* POP_SolversMod.F90:2268-2369 preconditioner on whole arrays (EVP when preconditioner_choice = 1), :2992 partition */
 void orc_preconditioner(orc_model *m, const double *X, double *PX);
 int orc_evp_info(orc_model *m, int what, int idx);
 void orc_btrop_operator(orc_model *m, const double *X, double *AX);   /* POP_SolversMod.F90:2414-2426 */

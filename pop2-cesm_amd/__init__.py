@@ -46,6 +46,8 @@ def lib():
     sig = {
         "pop_create": (ci, [vp, ci, ci, ci, C.POINTER(vp)]), "pop_destroy": (ci, [vp]),
         "pop_create_with_grid": (ci, [vp, vp, ci, ci, ci, C.POINTER(vp)]),
+        "pop_create_tuned": (ci, [vp, vp, vp, ci, ci, ci, C.POINTER(vp)]),
+        "pop_tuning_init": (None, [vp]), "pop_get_tuning": (ci, [vp, vp]),
         "pop_read_grid_files": (ci, [cs, cs, ci, ci, pd, pi]),
         "pop_last_error": (cs, [vp]), "pop_get_dim": (ci, [vp, cs]), "pop_get_scalar": (cd, [vp, cs]),
         "pop_get_block": (ci, [vp, ci, pi, pi, pi]), "pop_local_block_ids": (ci, [vp, pi]),
@@ -105,15 +107,38 @@ class PopError(RuntimeError):
     pass
 
 
+def tuning_fields():
+    """field names of include/pop_amd.h pop_tuning, in declaration order (all int)"""
+    import re
+    hdr = open(os.path.join(os.path.dirname(_HERE), "include", "pop_amd.h")).read()
+    body = hdr[hdr.index("typedef struct pop_tuning {"):hdr.index("} pop_tuning;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"\bint\s+([^;]+);", body):
+        names += [n.strip() for n in decl.split(",")]
+    return names
+
+
+def make_tuning(**kw):
+    """pop_tuning with every field unset (pop_tuning_init) except the ones given"""
+    names = tuning_fields()
+    t = (C.c_int * len(names))()
+    lib().pop_tuning_init(C.cast(t, C.c_void_p))
+    for k, v in kw.items():
+        t[names.index(k)] = int(v)
+    return t
+
+
 class PopGridInput(C.Structure):
     """include/pop_amd.h pop_grid_input"""
-    _fields_ = [(n, C.POINTER(C.c_double)) for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")] + [("KMT", C.POINTER(C.c_int))]
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")] + [("KMT", C.POINTER(C.c_int)),
+                                                                                                               ("DZBC", C.POINTER(C.c_double))]
 
 
 def grid_input(grid, nx, ny):
     """dict of (ny, nx) arrays -> (PopGridInput, the contiguous arrays it points into)"""
     gin, keep = PopGridInput(), []
-    for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE"):
+    for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE", "DZBC"):
         if grid.get(n) is None:
             continue
         a = np.ascontiguousarray(grid[n], dtype=np.float64)
@@ -148,18 +173,19 @@ class PopModel:
     """One rank's model instance.  Array views are numpy arrays shaped
     (nblocks_local, [km,] ny_block, nx_block) = the reference layout read in C order."""
 
-    def __init__(self, cfg, rank=0, nranks=1, host_only=False, grid=None):
+    def __init__(self, cfg, rank=0, nranks=1, host_only=False, grid=None, tuning=None):
         """grid: None (the internal lat-lon grid) or a dict of global (ny_global, nx_global) arrays ULAT, ULON, HTN,
         HTE, HUS, HUW [, ANGLE] [, KMT] -- the records of horiz_grid_file / topography_file (pop_create_with_grid)."""
         self.L = lib()
         self.cfg = cfg
         self.h = C.c_void_p()
         flags = POP_CREATE_HOST_ONLY if host_only else 0
+        tun = C.cast(make_tuning(**tuning), C.c_void_p) if tuning else None    # dict of pop_tuning fields (pop_create_tuned)
         if grid is None:
-            e = self.L.pop_create(C.byref(cfg), rank, nranks, flags, C.byref(self.h))
+            e = self.L.pop_create_tuned(C.byref(cfg), None, tun, rank, nranks, flags, C.byref(self.h))
         else:
             gin, keep = grid_input(grid, cfg.nx_global, cfg.ny_global)
-            e = self.L.pop_create_with_grid(C.byref(cfg), C.byref(gin), rank, nranks, flags, C.byref(self.h))
+            e = self.L.pop_create_tuned(C.byref(cfg), C.byref(gin), tun, rank, nranks, flags, C.byref(self.h))
             del keep
         if e:
             msg = self.L.pop_last_error(self.h).decode() if self.h else "pop_create failed"
@@ -180,6 +206,13 @@ class PopModel:
 
     def dim(self, name):
         return self.L.pop_get_dim(self.h, name.encode())
+
+    def tuning(self):
+        """the resolved pop_tuning as a dict (None = the library's size rule applied)"""
+        names = tuning_fields()
+        t = (C.c_int * len(names))()
+        self._chk(self.L.pop_get_tuning(self.h, C.cast(t, C.c_void_p)))
+        return {n: (None if t[i] == -2147483648 else t[i]) for i, n in enumerate(names)}
 
     def scalar(self, name):
         return self.L.pop_get_scalar(self.h, name.encode())
@@ -343,7 +376,7 @@ class PopModel:
         self._chk(self.L.pop_read_restart(self.h, os.fsencode(path), 1 if byteswap else 0))
 
     def solver_preconditioner(self, x_name, px_name, x_tl=1, px_tl=1):
-        """PX = M^-1 X on the physical cells (EVP sub-block solves when reserved_i[2] = 1, else the diagonal)"""
+        """PX = M^-1 X on the physical cells (EVP sub-block solves when preconditioner_choice = 1, else the diagonal)"""
         self._chk(self.L.pop_solver_preconditioner(self.h, x_name.encode(), x_tl, px_name.encode(), px_tl))
 
     def operator(self, op, k, a, b=None, o1="DH", o2="DHU", tl=1):

@@ -98,8 +98,8 @@ int host_pcsi_prep(HostModel &h, const std::vector<double> &C) {
               WNE[q] * X[q + nxb + 1] + WNE[q - nxb] * X[q - nxb + 1] + WNE[q - 1] * X[q + nxb - 1] + WNE[q - 1 - nxb] * X[q - nxb - 1];
     }
   };
-  const int maxstep = c.reserved_i[0] > 0 ? c.reserved_i[0] : 20;       // maxlanczosstep :626
-  const double crit = c.reserved_d[3] > 0.0 ? c.reserved_d[3] : 0.1;    // LanczosconvergenceCriterion :616
+  const int maxstep = c.maxlanczosstep > 0 ? c.maxlanczosstep : 20;       // maxlanczosstep :626
+  const double crit = c.lanczos_convergence_criterion > 0.0 ? c.lanczos_convergence_criterion : 0.1;    // LanczosconvergenceCriterion :616
   precond(S, R);
   for (size_t p = 0; p < A2; ++p) WORK[p] = S[p] * R[p];
   double csc = -host_global_sum(h, WORK.data(), mMask.data()), csa, csb = 0.0, u = 0.0, v = 0.0, mineig = 1.0;

@@ -28,7 +28,7 @@ struct Shift {   // zero-filled neighbour access inside one block (Fortran eoshi
   }
 };
 
-// topography_internal (grid.F90:1957-1985) + the stepped test extension (reserved_i[3]); shared by the block distribution
+// topography_internal (grid.F90:1957-1985) + the stepped test extension (stepped_bathymetry); shared by the block distribution
 // (work per block) and the grid set-up
 static int kmt_rule(const pop_config &c, int km, const double latd, double lond, int ig, int jg) {
   if (lond < 0.0) lond = lond + 360.0;
@@ -38,10 +38,10 @@ static int kmt_rule(const pop_config &c, int km, const double latd, double lond,
   if (latd > 60.0 && lond > 210.0 && lond < 150.0) k = 0;
   if (latd > -60.0 && lond > 110.0 && lond < 150.0) k = 0;
   if (std::fabs(latd) > 75.0) k = 0;
-  // reserved_i[3] = 1: stepped synthetic bathymetry (an extension for tests; the reference's internal topography is
+  // stepped_bathymetry = 1: stepped synthetic bathymetry (an extension for tests; the reference's internal topography is
   // flat, grid.F90:880-884): ocean columns of 3 ... km levels in stairs 3 cells wide in i and 2 in j, so that every
   // k > KMT / k > KMU branch and the shallow-column paths of the Thomas solves are exercised.  Integer arithmetic only.
-  if (k > 0 && c.reserved_i[3] == 1) k = std::max(3, km - ((ig / 3) * 5 + (jg / 2) * 3) % (km / 2 + 1));
+  if (k > 0 && c.stepped_bathymetry == 1) k = std::max(3, km - ((ig / 3) * 5 + (jg / 2) * 3) % (km / 2 + 1));
   return k;
 }
 // global KMT at (ig, jg), 1-based: the caller's record, or the internal rule on the caller's / the internal ULAT, ULON
@@ -95,7 +95,7 @@ void make_blocks(HostModel &h) {
     int owner = (int)(((long long)n * h.nranks) / h.nblocks_tot);
     h.block_owner[n] = owner;
   }
-  if (c.reserved_i[4] == 1 && h.nranks > 1 && h.nblocks_tot > h.nranks) {
+  if (c.distribution_type == 1 && h.nranks > 1 && h.nblocks_tot > h.nranks) {
     // load-balanced distribution (the reference balances ocean points per task with its 'rake' / 'spacecurve'
     // distributions, distribution.F90; the global KMT is read first for exactly this, grid.F90:449-456): still contiguous
     // runs of block ids -- neighbours stay neighbours -- but the cuts equalise the ocean columns per rank instead of the
@@ -663,7 +663,7 @@ int host_build(HostModel &h) {
   // time_management.F90:897-945; step_mod.F90:1577-1615 (MASK_TRBUDGET = KMT >= k; without region masks the
   // open-ocean mask is KMT >= k .and. RCALCT > 0, grid.F90:1112-1121)
   if (c.tmix_opt == 3) {
-    double alpha = c.reserved_d[1], nu = c.reserved_d[2];
+    double alpha = c.robert_alpha, nu = c.robert_nu;
     if (alpha == 0.0) alpha = 0.53;
     if (nu == 0.0) nu = 0.20;
     h.robert_curtime = 0.5 * nu * alpha;
@@ -704,7 +704,7 @@ int host_build(HostModel &h) {
     34.74, 34.73, 34.73, 34.72, 34.72};
   auto &T0 = h.f3["TEMP0"], &S0 = h.f3["SALT0"];
   T0.assign(h.n3 * h.nblocks, 0.0); S0.assign(h.n3 * h.nblocks, 0.0);
-  const double amp = c.reserved_d[0];
+  const double amp = c.init_ts_perturbation;
   for (int lb = 0; lb < h.nblocks; ++lb) {
     const int gb = h.local_ids[lb] - 1;
     const BlockInfo &B = h.all_blocks[gb];

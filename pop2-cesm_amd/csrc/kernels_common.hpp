@@ -177,9 +177,9 @@ __device__ __forceinline__ bool patch_cell(const DevGrid &g, int tile, int b, in
   p2 = j * g.nxb + i;
   return true;
 }
-// bandwidth-bound grids: 64 x 4 patches (tx0.1v3: -0.5 ms per step); POP_DEL4_TILE = 0 | 2 | 4 | 8 | 16 overrides
-__host__ inline int patch_rows(const DevGrid &g) {
-  if (getenv("POP_DEL4_TILE")) { const int r = atoi(getenv("POP_DEL4_TILE")); return (r == 2 || r == 4 || r == 8 || r == 16) ? r : 0; }
+// bandwidth-bound grids: 64 x 4 patches (tx0.1v3: -0.5 ms per step); pop_tuning.del4_tile = 0 | 2 | 4 | 8 | 16 overrides
+__host__ inline int patch_rows(const DevGrid &g, int tile_tuning) {
+  if (tun_set(tile_tuning)) { const int r = tile_tuning; return (r == 2 || r == 4 || r == 8 || r == 16) ? r : 0; }
   return ((long long)g.n2 * g.nblocks > (1 << 19)) ? 4 : 0;
 }
 __host__ inline unsigned patch_grid_x(const DevGrid &g, int tile) {

@@ -66,16 +66,16 @@ __global__ void k_del4_d2u(DevGrid g, const double *__restrict__ AMF, const doub
 
 inline int del4_create(HostModel &, const DevGrid &, MixDev &, std::vector<void *> &, std::string &) { return 0; }
 
-inline int mix_hdifft_del4(const HostModel &, const DevGrid &g, const StepParams &, const MixDev &m, const double *T0, const double *T1,
+inline int mix_hdifft_del4(const HostModel &h, const DevGrid &g, const StepParams &, const MixDev &m, const double *T0, const double *T1,
                            double *D0, double *D1, double *, double *, hipStream_t st, std::string &err) {
-  const int tile = patch_rows(g);
+  const int tile = patch_rows(g, h.tun.del4_tile);
   hipLaunchKernelGGL(k_del4_d2t, dim3(patch_grid_x(g, tile), (g.km + POP_DEL4_KC - 1) / POP_DEL4_KC, g.nblocks), dim3(tile ? 64 * tile : 256), 0, st, g, m.D4AHF, T0, T1, D0, D1, tile);
   if (hipGetLastError() != hipSuccess) { err = "del4 tracer kernel launch failed"; return 1; }
   return 0;
 }
-inline int mix_hdiffu_del4(const HostModel &, const DevGrid &g, const StepParams &, const MixDev &m, const double *U, const double *V,
+inline int mix_hdiffu_del4(const HostModel &h, const DevGrid &g, const StepParams &, const MixDev &m, const double *U, const double *V,
                            double *DU, double *DV, double *, double *, hipStream_t st, std::string &err) {
-  const int tile = patch_rows(g);
+  const int tile = patch_rows(g, h.tun.del4_tile);
   hipLaunchKernelGGL(k_del4_d2u, dim3(patch_grid_x(g, tile), (g.km + POP_DEL4_KC - 1) / POP_DEL4_KC, g.nblocks), dim3(tile ? 64 * tile : 256), 0, st, g, m.D4AMF, U, V, DU, DV, tile);
   if (hipGetLastError() != hipSuccess) { err = "del4 momentum kernel launch failed"; return 1; }
   return 0;

@@ -14,7 +14,7 @@
 // Selections: no tidal / near-inertial-wave / Langmuir mixing, no short-wave penetration
 // (lshort_wave=.false.), lcheckekmo=.false., SMFT available, no partial bottom cells.
 // Integer powers use the usual expansion x**3=(x*x)*x, x**4=(x*x)*(x*x).
-// Diagnostic outputs HMXL, HMXL_DR: k_kpp_hmxl, with pop_config reserved_i[5] = 1; tavg fields are not computed.
+// Diagnostic outputs HMXL, HMXL_DR: k_kpp_hmxl, with pop_config kpp_ml_diagnostics = 1; tavg fields are not computed.
 #pragma once
 
 namespace pop {
@@ -1010,7 +1010,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
 
 // ---- VVC = tgrid_to_ugrid(VISC) masked by k < KMU; VVC(km) = 0.  3-D parallel ---------------
 #define POP_VVC_KC 8   // levels per thread: the four averaging weights and KMU are loaded once per chunk
-// ---- diagnostic mixed-layer depths (vmix_kpp.F90:1310-1418; pop_config reserved_i[5] = 1): HMXL, the depth of the maximum
+// ---- diagnostic mixed-layer depths (vmix_kpp.F90:1310-1418; pop_config kpp_ml_diagnostics = 1): HMXL, the depth of the maximum
 // buoyancy gradient, and HMXL_DR, the depth where the potential density exceeds its surface value by 3e-5 g/cm^3.  Every cell
 // of the block, as the reference's whole-array statements (T, S are 0 below the bottom and on land there too).
 __global__ void __launch_bounds__(POP_COL_THREADS)
@@ -1102,7 +1102,7 @@ inline int sw_chl_index(const SwTab &T, double chl) {
 inline int sw_tables_create(HostModel &h, std::vector<void *> &allocs, std::string &err) {
   if (h.sw.swabs) return 0;
   const pop_config &c = h.c;
-  const int km = h.km, type = c.reserved_i[6], jt = c.reserved_i[7] ? c.reserved_i[7] : 3;
+  const int km = h.km, type = c.sw_absorption_type, jt = c.jerlov_water_type ? c.jerlov_water_type : 3;
   const size_t a2 = h.n2 * h.nblocks;
   void *p;
   auto up = [&](const void *src, size_t bytes, void **dst) -> int {
@@ -1167,8 +1167,8 @@ inline int sw_tables_create(HostModel &h, std::vector<void *> &allocs, std::stri
 }
 inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<void *> &allocs, std::string &err) {
   const pop_config &c = h.c;
-  if (c.lshort_wave && (c.reserved_i[6] < 0 || c.reserved_i[6] > 2)) { err = "KPP: sw_absorption_type (reserved_i[6]): 0 top-layer, 1 jerlov, 2 chlorophyll"; return 1; }
-  if (c.reserved_i[7] < 0 || c.reserved_i[7] > 5) { err = "KPP: jerlov_water_type (reserved_i[7]): 1..5 (0 = 3)"; return 1; }
+  if (c.lshort_wave && (c.sw_absorption_type < 0 || c.sw_absorption_type > 2)) { err = "KPP: sw_absorption_type: 0 top-layer, 1 jerlov, 2 chlorophyll"; return 1; }
+  if (c.jerlov_water_type < 0 || c.jerlov_water_type > 5) { err = "KPP: jerlov_water_type: 1..5 (0 = 3)"; return 1; }
   if (c.num_v_smooth_Ri < 1) { err = "KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)"; return 1; }
   const int km = h.km;
   std::vector<double> zgrid(km + 3, 0.0), hwide(km + 3, 0.0), bvdc(km + 3, 0.0), bvvc(km + 3, 0.0);
@@ -1190,7 +1190,7 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   };
   KppHost *K = new KppHost();
   m.kpp = K;
-  if (!(getenv("POP_KPP_SIDE_STREAM") && atoi(getenv("POP_KPP_SIDE_STREAM")) == 0)) {
+  if (!tun_off(h.tun.kpp_side_stream)) {
     if (hipStreamCreateWithFlags(&K->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&K->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&K->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -1216,7 +1216,7 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   k.Vtc = std::sqrt(0.2 / KPP_C_S / KPP_EPSSFC) / (KPP_VONKAR * KPP_VONKAR);
   k.cg = KPP_CSTAR * KPP_VONKAR * std::pow(KPP_C_S * KPP_VONKAR * KPP_EPSSFC, 1.0 / 3.0);
   k.rich_mix = c.kpp_rich_mix; k.lrich = c.lrich; k.ldbl_diff = c.ldbl_diff; k.nsmooth = c.num_v_smooth_Ri;
-  k.lshort_wave = c.lshort_wave ? 1 : 0; k.sw_type = c.reserved_i[6]; k.jerlov = c.reserved_i[7] ? c.reserved_i[7] : 3; k.lcheckekmo = c.lcheckekmo ? 1 : 0;
+  k.lshort_wave = c.lshort_wave ? 1 : 0; k.sw_type = c.sw_absorption_type; k.jerlov = c.jerlov_water_type ? c.jerlov_water_type : 3; k.lcheckekmo = c.lcheckekmo ? 1 : 0;
   if (k.lshort_wave) {
     if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.BO = (double *)p;
     if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.BOSOL = (double *)p;
@@ -1233,7 +1233,7 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   // state, but its 3 x 20 register doubles leave one wave per SIMD).  POP_KPP_COL = bit mask (1 ushear,
   // 2 buoydiff) overrides.
   K->col = (K->max_kref <= 24) ? ((h.n2 * h.nblocks > (1u << 19)) ? 15 : 1) : 0;   // ushear: column form at every size (gx1v7 vmix 0.716 -> 0.692 ms)
-  if (getenv("POP_KPP_COL")) K->col = (K->max_kref <= 24) ? atoi(getenv("POP_KPP_COL")) : 0;   // bit 0 ushear column form, bit 1 buoydiff column form, bit 2 buoydiff LDS form, bit 3 buoydiff + interior fused
+  if (tun_set(h.tun.kpp_col)) K->col = (K->max_kref <= 24) ? h.tun.kpp_col : 0;   // bit 0 ushear column form, bit 1 buoydiff column form, bit 2 buoydiff LDS form, bit 3 buoydiff + interior fused
   (void)g; (void)m;
   return 0;
 }
@@ -1260,14 +1260,14 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   // the full field
   // (with the level-parallel fused kernel and with the plain 3-D buoydiff kernel; the column / LDS buoydiff forms keep the full field)
   const bool plain3d = !fused_bi && !(g_kpp_col & 4 && KH.max_kref <= 28 && g.xcd_remap != 2) && !(g_kpp_col & 2);
-  const bool lazy = (fused_bi || plain3d) && KH.max_kref <= 28 && !g_kpp.lcheckekmo && h.c.reserved_i[5] != 1 &&
-                    !(getenv("POP_KPP_LAZY") && atoi(getenv("POP_KPP_LAZY")) == 0);
+  const bool lazy = (fused_bi || plain3d) && KH.max_kref <= 28 && !g_kpp.lcheckekmo && h.c.kpp_ml_diagnostics != 1 &&
+                    !tun_off(h.tun.kpp_lazy);
   const bool lazy20 = lazy && KH.max_kref <= 20;
   // shear kernel limited by the previous evaluation's KBL (k_kpp_ushear_col): only with the on-demand march, which can form a level
   // that is missing itself (POP_KPP_USHEAR_HINT=0: every level; POP_KPP_USHEAR_MARGIN: levels beyond the hint, default 3)
-  if (lazy && (g_kpp_col & 1) && !(getenv("POP_KPP_USHEAR_HINT") && atoi(getenv("POP_KPP_USHEAR_HINT")) == 0)) {
+  if (lazy && (g_kpp_col & 1) && !tun_off(h.tun.kpp_ushear_hint)) {
     g_kpp.WUK = KH.wuk;
-    if (getenv("POP_KPP_USHEAR_MARGIN")) g_kpp.wu_margin = atoi(getenv("POP_KPP_USHEAR_MARGIN"));
+    if (tun_set(h.tun.kpp_ushear_margin)) g_kpp.wu_margin = h.tun.kpp_ushear_margin;
   }
   // the shear of the velocity against its surface-layer reference needs only U and V: on the side stream it overlaps the
   // (VALU-bound) buoydiff and the interior kernel; bldepth waits for it
@@ -1277,7 +1277,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
   // two waves per SIMD (<= 256 VGPRs, ~80 spilled) beat one wave with everything in registers: the kernel is VALU-bound
   // and a second wave fills the division / dependency stalls of the first (POP_KPP_BUOY_WAVES=1 keeps one wave)
-  static const int bw = getenv("POP_KPP_BUOY_WAVES") ? atoi(getenv("POP_KPP_BUOY_WAVES")) : 2;
+  const int bw = tun_or(h.tun.kpp_buoy_waves, 2);
   if (lazy && fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8, false>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if (fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if ((g_kpp_col & 4) && KH.max_kref <= 20 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<20, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
@@ -1300,7 +1300,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                             (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
     hipEventRecord(KH.ev_join, KH.side);
   }
-  static const bool int_reg = !getenv("POP_KPP_INTERIOR_GENERIC");
+  const bool int_reg = !tun_on(h.tun.kpp_interior_generic);
   if (fused_bi) {}
   else if (int_reg && g.km == 60) hipLaunchKernelGGL(k_kpp_interior_reg<60>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else if (int_reg && g.km == 62) hipLaunchKernelGGL(k_kpp_interior_reg<62>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
@@ -1314,9 +1314,9 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                           (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
   hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                      s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
-  const int vpatch = patch_rows(g);   // large grids: 64 x 4 patches (the row j + 1 of the four-point average is read by the same workgroup)
+  const int vpatch = patch_rows(g, h.tun.del4_tile);   // large grids: 64 x 4 patches (the row j + 1 of the four-point average is read by the same workgroup)
   hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vpatch), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vpatch ? 64 * vpatch : 256), 0, st, g, (const double *)VISC, s.VVC, vpatch);
-  if (h.c.reserved_i[5] == 1 && s.HMXL && s.HMXL_DR)
+  if (h.c.kpp_ml_diagnostics == 1 && s.HMXL && s.HMXL_DR)
     hipLaunchKernelGGL(k_kpp_hmxl, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], (const double *)DBSFC, s.HMXL, s.HMXL_DR);
   if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }
   return 0;

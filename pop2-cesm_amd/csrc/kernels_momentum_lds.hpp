@@ -241,11 +241,9 @@ inline void launch_momentum_lds(const DevGrid &g, const StepParams &sp, const Mo
   const int tiles_j = (g.nyb - 2 * NGHOST + R - 1) / R;
   if (tj_count < 0) tj_count = tiles_j - tj_first;
   if (tj_count <= 0) return;
-  static const int pf = getenv("POP_MOMENTUM_PF") ? atoi(getenv("POP_MOMENTUM_PF")) : 1;
   const bool whole = tj_first == 0 && tj_count == tiles_j;
   const dim3 G(whole ? lds_launch_x<R>(g, tiles_i, tiles_j) : lds_grid_x(g.lds_order, tiles_i, tj_count), g.nblocks), B(POP_COL_THREADS, R);
-  if (pf == 2) hipLaunchKernelGGL((k_momentum_rhs_lds<R, 2>), G, B, 0, st, g, sp, a, tj_first, tj_count);
-  else hipLaunchKernelGGL((k_momentum_rhs_lds<R, 1>), G, B, 0, st, g, sp, a, tj_first, tj_count);
+  hipLaunchKernelGGL((k_momentum_rhs_lds<R, 1>), G, B, 0, st, g, sp, a, tj_first, tj_count);
 }
 
 }  // namespace pop

@@ -250,11 +250,11 @@ k_impvmixu_reg(DevGrid g, StepParams sp, ImpvmixuArgs a) {
 
 // dispatch on the level count: register kernels for the production grids, generic otherwise
 template <int MODE, bool PRE, bool POST>
-inline void launch_impvmixt(const DevGrid &g, const StepParams &sp, const ImpvmixtArgs &a, dim3 G, hipStream_t st, bool allow_reg) {
+inline void launch_impvmixt(const DevGrid &g, const StepParams &sp, const ImpvmixtArgs &a, dim3 G, hipStream_t st, bool allow_reg, int pair_tuning) {
   const dim3 B(POP_COL_THREADS);
   const dim3 G2(G.x, G.y, a.nlast - a.nfirst + 1);
-  // both tracers in one thread when they share the diffusivity array (POP_THOMAS_PAIR=0|1 overrides the size rule)
-  const int pair_env = getenv("POP_THOMAS_PAIR") ? atoi(getenv("POP_THOMAS_PAIR")) : -1;
+  // both tracers in one thread when they share the diffusivity array (pop_tuning.thomas_pair = 0 | 1 overrides the size rule)
+  const int pair_env = tun_or(pair_tuning, -1);
   // (corrector form only: the predictor's three full register columns + its up-front loads spill ~ 900 B per lane)
   const bool pair = MODE == 1 && allow_reg && (g.km == 60 || g.km == 62) && a.nfirst == 1 && a.nlast == 2 && a.VDC[0] == a.VDC[1] &&
                     (pair_env >= 0 ? pair_env != 0 : (long long)g.n2 * g.nblocks > (1 << 19));

@@ -130,7 +130,7 @@ struct pop_ctx {
   pop_exchange_fn xchg = nullptr;
   pop_allreduce_fn allred = nullptr;
   void *comm_user = nullptr;
-  EvpDev evp{}; bool use_evp = false;                                                // EVP block preconditioner (reserved_i[2] = 1)
+  EvpDev evp{}; bool use_evp = false;                                                // EVP block preconditioner (preconditioner_choice = 1)
   double *pcsi_omega = nullptr; int *pcsi_base = nullptr; double pcsi_csy = 0;        // P-CSI: omega_k table, interval base
   std::vector<std::pair<std::pair<double *, int>, hipGraphExec_t>> pcsi_graphs;   // keyed by (solution array, variant)
   double rf_S[MAXNT] = {}, rf_S_prev[MAXNT] = {}; bool rf_S_prev_valid[MAXNT] = {};   // Robert filter
@@ -257,7 +257,7 @@ int halo_update(pop_ctx *c, double *F, int nz, double fill = 0.0, int loc = 0, i
 // loc / kind: POP_HaloUpdate's fieldLoc / fieldKind (0 centre, 1 NE corner, 2 N face, 3 E face; 0 scalar, 1 vector); they matter on a tripole boundary only
 struct HaloItem { double *F; int nz; int loc = 0, kind = 0; };
 int halo_update_many(pop_ctx *c, const std::vector<HaloItem> &items) {
-  if (items.size() == 1 || items.size() > 8 || c->h.c.ns_boundary == 2 || getenv("POP_HALO_SEPARATE")) {
+  if (items.size() == 1 || items.size() > 8 || c->h.c.ns_boundary == 2 || tun_on(c->h.tun.halo_separate)) {
     for (const HaloItem &it : items) if (halo_update(c, it.F, it.nz, 0.0, it.loc, it.kind)) return 1;
     return 0;
   }
@@ -295,7 +295,7 @@ int halo_update_many(pop_ctx *c, const std::vector<HaloItem> &items) {
 // take values that just arrived; the others are rewritten with the same values).  Between the two the launch stream
 // may run anything that reads only cells this rank owns or ghosts with a source on this rank.
 bool halo_async_ok(const pop_ctx *c) {
-  return !c->peers.empty() && c->halo_ns_only && c->xchg_side && c->comm_side && c->h.c.ns_boundary != 2 && !getenv("POP_HALO_OVERLAP_OFF");
+  return !c->peers.empty() && c->halo_ns_only && c->xchg_side && c->comm_side && c->h.c.ns_boundary != 2 && !tun_on(c->h.tun.halo_overlap_off);
 }
 struct HaloAsync { HaloFields H; int tot; };
 int halo_many_begin(pop_ctx *c, const std::vector<HaloItem> &items, HaloAsync &A) {
@@ -615,7 +615,7 @@ struct DistSolve {
   // the one-level exchange of the buffers the kernels packed: on the side stream beside the all-reduce when the
   // transport has a second communicator, else in line.  fork: the packed data is complete on the launch stream now.
   bool overlap = true;
-  bool side() const { return overlap && c->xchg_side && c->comm_side && !getenv("POP_SOLVER_OVERLAP_OFF"); }
+  bool side() const { return overlap && c->xchg_side && c->comm_side && !tun_on(c->h.tun.solver_overlap_off); }
   int xchg_begin() {
     std::vector<int> peer; std::vector<long long> so, sc, ro, rc;
     long long s0 = 0, r0 = 0;
@@ -937,7 +937,7 @@ int solver_chrongear_fused_dist(pop_ctx *c) {
 // ---------------------------------------------------------------------------------------------
 __global__ void k_set_int(int *p, int v) { *p = v; }
 
-int pcsi_check_start(const pop_ctx *c) { return c->h.c.reserved_i[1] > 0 ? c->h.c.reserved_i[1] : 60; }   // convergenceCheckStart :636
+int pcsi_check_start(const pop_ctx *c) { return c->h.c.convergence_check_start > 0 ? c->h.c.convergence_check_start : 60; }   // convergenceCheckStart :636
 
 int solver_pcsi(pop_ctx *c) {
   const pop_config &cf = c->h.c;
@@ -1188,7 +1188,52 @@ int resolve(pop_ctx *c, const std::string &name, int tl, int n, double **ptr, lo
 // =============================================================================================
 extern "C" {
 
-int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx **out) { return pop_create_with_grid(cfg, nullptr, rank, nranks, flags, out); }
+int pop_create(const pop_config *cfg, int rank, int nranks, int flags, pop_ctx **out) { return pop_create_tuned(cfg, nullptr, nullptr, rank, nranks, flags, out); }
+int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int rank, int nranks, int flags, pop_ctx **out) {
+  return pop_create_tuned(cfg, grid, nullptr, rank, nranks, flags, out);
+}
+
+// ---- tuning switches (include/pop_amd.h pop_tuning): one table of (field, environment variable)
+#define POP_TUNING_FIELDS(X)                                                                                                            \
+  X(land_skip, "POP_LAND_SKIP") X(land_full_steps, "POP_LAND_FULL_STEPS") X(xcd_remap, "POP_XCD_REMAP") X(red_tiles, "POP_RED_TILES")   \
+  X(red_band, "POP_RED_BAND") X(lds_order, "POP_LDS_ORDER") X(momentum_lds, "POP_MOMENTUM_LDS") X(tracer_lds, "POP_TRACER_LDS")         \
+  X(generic_thomas, "POP_GENERIC_THOMAS") X(reg_thomas_t, "POP_REG_THOMAS_T") X(thomas_pair, "POP_THOMAS_PAIR")                         \
+  X(tracer_fwd, "POP_TRACER_FWD") X(vdc_shared, "POP_VDC_SHARED") X(side_stream, "POP_SIDE_STREAM") X(del4_side, "POP_DEL4_SIDE")       \
+  X(del4_tile, "POP_DEL4_TILE") X(d2t_fuse, "POP_D2T_FUSE") X(d2u_fuse, "POP_D2U_FUSE") X(vmixu_defer, "POP_VMIXU_DEFER")               \
+  X(vmixu_inline, "POP_VMIXU_INLINE") X(btrop_inline, "POP_BTROP_INLINE") X(kpp_ahead, "POP_KPP_AHEAD") X(kpp_col, "POP_KPP_COL")       \
+  X(kpp_lazy, "POP_KPP_LAZY") X(kpp_ushear_hint, "POP_KPP_USHEAR_HINT") X(kpp_ushear_margin, "POP_KPP_USHEAR_MARGIN")                   \
+  X(kpp_side_stream, "POP_KPP_SIDE_STREAM") X(kpp_buoy_waves, "POP_KPP_BUOY_WAVES") X(kpp_interior_generic, "POP_KPP_INTERIOR_GENERIC") \
+  X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
+  X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
+  X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP")
+void pop_tuning_init(pop_tuning *t) {
+  if (!t) return;
+  t->struct_bytes = (int)sizeof(pop_tuning);
+#define X(f, e) t->f = POP_TUNING_UNSET;
+  POP_TUNING_FIELDS(X)
+#undef X
+}
+// caller's struct, then the environment (a variable that is set but not a number counts as 1, as the older on/off switches did)
+static void tuning_resolve(pop_tuning &t, const pop_tuning *user) {
+  pop_tuning_init(&t);
+  if (user && user->struct_bytes == (int)sizeof(pop_tuning)) t = *user;
+  auto env = [](const char *name, int &v) {
+    const char *e = getenv(name);
+    if (!e) return;
+    char *end = nullptr;
+    const long x = strtol(e, &end, 10);
+    v = (end == e) ? 1 : (int)x;
+  };
+#define X(f, e) env(e, t.f);
+  POP_TUNING_FIELDS(X)
+#undef X
+}
+int pop_get_tuning(const pop_ctx *c, pop_tuning *resolved) {
+  if (!c || !resolved) return 1;
+  *resolved = c->h.tun;
+  return 0;
+}
 
 // the reference's direct-access binary grid files (grid.F90:1362-1380, :2066-2085): whole records, native byte order
 int pop_read_grid_files(const char *horiz_grid_file, const char *topography_file, int nx_global, int ny_global, double *seven_records, int *kmt) {
@@ -1205,17 +1250,24 @@ int pop_read_grid_files(const char *horiz_grid_file, const char *topography_file
   return 0;
 }
 
-int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int rank, int nranks, int flags, pop_ctx **out) {
+int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const pop_tuning *tuning, int rank, int nranks, int flags, pop_ctx **out) {
   if (!cfg || !out || nranks < 1 || rank < 0 || rank >= nranks) return 1;
   pop_ctx *c = new pop_ctx();
   *out = c;
   c->h.c = *cfg; c->h.rank = rank; c->h.nranks = nranks;
+  if (tuning && tuning->struct_bytes != (int)sizeof(pop_tuning)) { c->err = "pop_create_tuned: pop_tuning.struct_bytes does not match this library (use pop_tuning_init)"; return 1; }
+  tuning_resolve(c->h.tun, tuning);
   c->grid_from_input = grid != nullptr;
   if (grid && !(grid->ULAT && grid->ULON && grid->HTN && grid->HTE && grid->HUS && grid->HUW)) { c->err = "pop_create_with_grid: ULAT, ULON, HTN, HTE, HUS, HUW are required"; return 1; }
   c->h.gin = grid;
   {   // every option this library does not implement is refused here, before anything is built (the reference aborts
       // in the init routine of the option's own module, e.g. vertical_mix.F90:280-296, POP_SolversMod.F90:442-472)
     auto bad = [&](const std::string &m) { c->err = "pop_create: " + m; return 1; };
+    if (cfg->struct_version != POP_CONFIG_VERSION) return bad("pop_config.struct_version is " + std::to_string(cfg->struct_version) + ", this library was built for " + std::to_string(POP_CONFIG_VERSION) + " (include/pop_amd.h)");
+    for (int r = 0; r < 3; ++r) if (cfg->reserved_i[r] != 0) return bad("pop_config.reserved_i must be 0");
+    for (int r = 0; r < 4; ++r) if (cfg->reserved_d[r] != 0.0) return bad("pop_config.reserved_d must be 0");
+    if (cfg->partial_bottom_cells != 0 && cfg->partial_bottom_cells != 1) return bad("partial_bottom_cells: 0 or 1");
+    if (cfg->lsw_absorb != 0 && cfg->lsw_absorb != 1) return bad("lsw_absorb: 0 or 1");
     if (cfg->nx_global < 1 || cfg->ny_global < 1 || cfg->km < 2 || cfg->block_size_x < 1 || cfg->block_size_y < 1) return bad("domain / block sizes must be positive (km >= 2)");
     if (cfg->ew_boundary != 0 && cfg->ew_boundary != 1) return bad("ew_boundary: 0 closed, 1 cyclic");
     if (cfg->ns_boundary < 0 || cfg->ns_boundary > 2) return bad("ns_boundary: 0 closed, 1 cyclic, 2 tripole");
@@ -1224,18 +1276,18 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
     if (cfg->vmix_choice < 1 || cfg->vmix_choice > 3) return bad("vmix_choice: 1 const, 2 rich, 3 kpp");
     if (cfg->tadvect < 1 || cfg->tadvect > 3) return bad("tadvect: 1 centered, 2 upwind3, 3 lw_lim");
     if (cfg->solver_choice < 1 || cfg->solver_choice > 3) return bad("solver_choice: 1 pcg, 2 ChronGear, 3 PCSI");
-    if (cfg->reserved_i[2] != 0 && cfg->reserved_i[2] != 1) return bad("preconditionerChoice (reserved_i[2]): 0 diagonal, 1 evp");
-    if (cfg->reserved_i[3] != 0 && cfg->reserved_i[3] != 1) return bad("synthetic topography (reserved_i[3]): 0 flat, 1 stepped");
-    if (cfg->reserved_i[4] != 0 && cfg->reserved_i[4] != 1) return bad("distribution (reserved_i[4]): 0 equal block counts, 1 balanced by ocean columns");
-    if (cfg->reserved_i[5] != 0 && cfg->reserved_i[5] != 1) return bad("KPP mixed-layer-depth diagnostics (reserved_i[5]): 0 off, 1 HMXL and HMXL_DR every step");
+    if (cfg->preconditioner_choice != 0 && cfg->preconditioner_choice != 1) return bad("preconditioner_choice: 0 diagonal, 1 evp");
+    if (cfg->stepped_bathymetry != 0 && cfg->stepped_bathymetry != 1) return bad("stepped_bathymetry: 0 flat, 1 stepped");
+    if (cfg->distribution_type != 0 && cfg->distribution_type != 1) return bad("distribution_type: 0 equal block counts, 1 balanced by ocean columns");
+    if (cfg->kpp_ml_diagnostics != 0 && cfg->kpp_ml_diagnostics != 1) return bad("kpp_ml_diagnostics: 0 off, 1 HMXL and HMXL_DR every step");
     if (cfg->max_iterations < 1 || cfg->convergence_check_freq < 1) return bad("max_iterations and convergence_check_freq must be >= 1");
     if (cfg->tmix_opt < 0 || cfg->tmix_opt > 3) return bad("tmix_opt: 0 none, 1 avg, 2 avgfit, 3 robert");
     if ((cfg->tmix_opt == 1 || cfg->tmix_opt == 2) && cfg->time_mix_freq < 1) return bad("time_mix_freq must be >= 1");
     if (cfg->steps_per_day < 1) return bad("steps_per_day must be >= 1");
     if (cfg->aidif != 1.0) return bad("aidif: only the fully implicit vertical mixing (aidif = 1) is built");
-    if (cfg->vmix_choice == 3 && cfg->lshort_wave && (cfg->reserved_i[6] < 0 || cfg->reserved_i[6] > 2)) return bad("KPP lshort_wave: sw_absorption_type (reserved_i[6]) 0 top-layer, 1 jerlov, 2 chlorophyll");
-    if (cfg->reserved_i[7] < 0 || cfg->reserved_i[7] > 5) return bad("jerlov_water_type (reserved_i[7]): 1..5 (0 = 3)");
-    if (cfg->reserved_d[4] != 0.0 && (cfg->reserved_i[6] < 0 || cfg->reserved_i[6] > 2)) return bad("lsw_absorb (reserved_d[4]): sw_absorption_type (reserved_i[6]) 0 top-layer, 1 jerlov, 2 chlorophyll");
+    if (cfg->vmix_choice == 3 && cfg->lshort_wave && (cfg->sw_absorption_type < 0 || cfg->sw_absorption_type > 2)) return bad("KPP lshort_wave: sw_absorption_type 0 top-layer, 1 jerlov, 2 chlorophyll");
+    if (cfg->jerlov_water_type < 0 || cfg->jerlov_water_type > 5) return bad("jerlov_water_type: 1..5 (0 = 3)");
+    if (cfg->lsw_absorb != 0 && (cfg->sw_absorption_type < 0 || cfg->sw_absorption_type > 2)) return bad("lsw_absorb: sw_absorption_type 0 top-layer, 1 jerlov, 2 chlorophyll");
     if (cfg->vmix_choice == 3 && cfg->num_v_smooth_Ri < 1) return bad("KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)");
     if (!(cfg->convergence_criterion >= 0.0)) return bad("convergence_criterion must be >= 0");
   }
@@ -1260,16 +1312,13 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   // the 256 MB infinity cache already absorbs the re-fetch.  Large grids therefore keep the natural
   // linear order; the other orders stay selectable (POP_XCD_REMAP=0|1|2, POP_RED_TILES=0|1) and tested.
   g.xcd_remap = (h.n2 * h.nblocks <= (1u << 19)) ? 1 : 0;
-  if (getenv("POP_XCD_REMAP")) g.xcd_remap = atoi(getenv("POP_XCD_REMAP"));
-  g.red_tiles = 0;
-  if (getenv("POP_RED_TILES")) g.red_tiles = atoi(getenv("POP_RED_TILES"));
+  g.xcd_remap = tun_or(h.tun.xcd_remap, g.xcd_remap);
+  g.red_tiles = tun_or(h.tun.red_tiles, 0);
   // 2-D solver / reduction kernels: XCD-banded chunk order (same chunks, same partial order, only the workgroup ->
   // chunk assignment changes, so results are bitwise unchanged): gx1v7 4.31 -> 4.01 ms per step (the 9-point
   // matvec finds its j+-1 rows in the XCD's own L2), tx0.1v3 177.1 -> 175.2.  POP_RED_BAND=0 restores the natural order.
-  g.lds_order = 1;
-  if (getenv("POP_LDS_ORDER")) g.lds_order = atoi(getenv("POP_LDS_ORDER"));
-  g.red_band = 1;
-  if (getenv("POP_RED_BAND")) g.red_band = atoi(getenv("POP_RED_BAND"));
+  g.lds_order = tun_or(h.tun.lds_order, 1);
+  g.red_band = tun_or(h.tun.red_band, 1);
   g.ib = NGHOST + 1; g.ie = h.nxb - NGHOST; g.jb = NGHOST + 1; g.je = h.nyb - NGHOST;
   // vertical arrays
   {
@@ -1381,8 +1430,8 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
       if (R == 4) { g.lds_act4 = dl; g.lds_n4 = (int)longest; } else { g.lds_act8 = dl; g.lds_n8 = (int)longest; }
     }
     c->land_fraction = tiles ? (double)land / (double)tiles : 0.0;
-    c->land_skip = !(getenv("POP_LAND_SKIP") && atoi(getenv("POP_LAND_SKIP")) == 0);
-    c->land_full_steps = getenv("POP_LAND_FULL_STEPS") ? atoi(getenv("POP_LAND_FULL_STEPS")) : 4;
+    c->land_skip = !tun_off(h.tun.land_skip);
+    c->land_full_steps = tun_or(h.tun.land_full_steps, 4);
     c->full_left = c->land_full_steps;
   }
   g.WNE = c->d2["btropWgtNE"]; g.WEa = c->d2["btropWgtEast"]; g.WNo = c->d2["btropWgtNorth"]; g.WC0 = c->d2["centerWgtIndep"];
@@ -1422,7 +1471,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   // KPP without double diffusion gives both tracer classes the same diffusivity, value for value (vmix_kpp.F90 ri_iwmix: VDC(:,:,k,2) =
   // VDC(:,:,k,1); blmix applies the same shape function to both): one array then serves both, so the KPP kernels write it once and
   // the tracer kernels find the second read in cache.  pop_get_field("VDC", n) returns it for n = 0 and 1.
-  c->vdc_shared = cfg->vmix_choice == 3 && !cfg->ldbl_diff && !(getenv("POP_VDC_SHARED") && atoi(getenv("POP_VDC_SHARED")) == 0);
+  c->vdc_shared = cfg->vmix_choice == 3 && !cfg->ldbl_diff && !tun_off(h.tun.vdc_shared);
   if (dev_alloc(c, &c->VDC[0], (size_t)(h.km + 2) * a2)) return 1;
   if (c->vdc_shared) c->VDC[1] = c->VDC[0];
   else if (dev_alloc(c, &c->VDC[1], (size_t)(h.km + 2) * a2)) return 1;
@@ -1433,22 +1482,22 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   double **three[] = {&c->VVC, &c->E3, &c->F3, &c->S3a, &c->S3b, &c->S3c, &c->S3d};
   for (auto p : three) if (dev_alloc(c, p, a3)) return 1;
   c->d2t[0] = c->S3a; c->d2t[1] = c->S3b; c->d2u[0] = c->S3a; c->d2u[1] = c->S3b;
-  if (!(getenv("POP_SIDE_STREAM") && atoi(getenv("POP_SIDE_STREAM")) == 0)) {
+  if (!tun_off(h.tun.side_stream)) {
     HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2t, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_d2u, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_vmixu, hipEventDisableTiming));
-    if ((cfg->hmix_tracer == 4 || cfg->hmix_momentum == 4) && !(getenv("POP_DEL4_SIDE") && atoi(getenv("POP_DEL4_SIDE")) == 0)) {
+    if ((cfg->hmix_tracer == 4 || cfg->hmix_momentum == 4) && !tun_off(h.tun.del4_side)) {
       if (dev_alloc(c, &c->d2t[0], a3) || dev_alloc(c, &c->d2t[1], a3) || dev_alloc(c, &c->d2u[0], a3) || dev_alloc(c, &c->d2u[1], a3)) return 1;
       c->side_del4 = true;
       // no tripole fold (the ghost ring of the field comes from a halo update, which is the same arithmetic only where ghost cells are
       // plain copies), centred advection through the LDS kernel, bandwidth-bound grids; POP_D2T_FUSE=0|1 overrides the size rule
-      const int fuse_env = getenv("POP_D2T_FUSE") ? atoi(getenv("POP_D2T_FUSE")) : -1;
+      const int fuse_env = tun_or(h.tun.d2t_fuse, -1);
       if (cfg->hmix_tracer == 4 && cfg->ns_boundary != 2 && cfg->tadvect == 1 &&
           (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
         if (dev_alloc(c, &c->d2t_next[0], a3) || dev_alloc(c, &c->d2t_next[1], a3)) return 1;
-      if (cfg->hmix_momentum == 4 && cfg->ns_boundary != 2 && !(getenv("POP_D2U_FUSE") && atoi(getenv("POP_D2U_FUSE")) == 0) &&
+      if (cfg->hmix_momentum == 4 && cfg->ns_boundary != 2 && !tun_off(h.tun.d2u_fuse) &&
           (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
         if (dev_alloc(c, &c->d2u_next[0], a3) || dev_alloc(c, &c->d2u_next[1], a3)) return 1;
     }
@@ -1569,7 +1618,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
       for (int o : h.block_owner) if (o >= 0 && o < h.nranks) per[o]++;
       c->max_blocks_per_rank = *std::max_element(per.begin(), per.end());
     }
-    c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !getenv("POP_SOLVER_UNFUSED");
+    c->fused_ok = h.halo.peers.empty() && h.nblocks <= 8 && !tun_on(h.tun.solver_unfused);
     if (cfg->solver_choice == 3) {   // omega_k of P-CSI (POP_SolversMod.F90:1617-1620, 1695): a function of the eigenvalue bounds only
       const double csalpha = 2.0 / (h.pcsi_max_eig - h.pcsi_min_eig);
       const double csbeta = (h.pcsi_max_eig + h.pcsi_min_eig) / (h.pcsi_max_eig - h.pcsi_min_eig);
@@ -1607,26 +1656,26 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
       c->use_evp = true;
       c->fused_ok = false;
     }
-    c->no_graph = getenv("POP_SOLVER_NOGRAPH") != nullptr;
-    if (getenv("POP_MOMENTUM_LDS")) c->mom_lds_rows = atoi(getenv("POP_MOMENTUM_LDS"));
+    c->no_graph = tun_on(h.tun.solver_nograph);
+    c->mom_lds_rows = tun_or(h.tun.momentum_lds, c->mom_lds_rows);
     // tracer RHS through LDS tiles (kernels_tracer_lds.hpp).  Measured against the direct-load kernel: tx0.1v3 15.0 ms ->
     // 12.8 (64x4 tiles) / 13.6 (64x8); gx1v7 0.260 ms -> 0.208 (64x4) / 0.192 (64x8).  POP_TRACER_LDS=0|4|8 overrides.
     c->trc_lds_rows = (h.n2 * h.nblocks > (1u << 19)) ? 4 : 8;
-    if (getenv("POP_TRACER_LDS")) c->trc_lds_rows = atoi(getenv("POP_TRACER_LDS"));
-    c->reg_thomas = getenv("POP_GENERIC_THOMAS") == nullptr;
+    c->trc_lds_rows = tun_or(h.tun.tracer_lds, c->trc_lds_rows);
+    c->reg_thomas = !tun_on(h.tun.generic_thomas);
     // tracer solve: the register kernel keeps the elimination coefficients of a column in VGPRs instead of writing them to
     // scratch fields and reading them back (the generic corrector moves 46 GB at the L2 for 19 GB of algorithmic traffic).
     // gx1v7: 0.19 vs 0.30 ms.  tx0.1v3: round 1 measured the generic march faster for the predictor (9.9 vs 11.6 ms, whole
     // grid); with land elimination the register form wins for both (same box, A/B twice: corrector 6.3 vs 8.1-8.6 ms,
     // predictor 7.2 vs 7.5-8.1, step -1.2 .. -1.6 ms).  The velocity solve is faster in registers at both sizes.
     c->reg_thomas_t = c->reg_thomas;
-    if (getenv("POP_REG_THOMAS_T")) c->reg_thomas_t = atoi(getenv("POP_REG_THOMAS_T")) != 0;
-    c->force_presum = getenv("POP_SOLVER_PRESUM") != nullptr;
-    c->fpcg_one_cell = getenv("POP_FPCG_B2") && atoi(getenv("POP_FPCG_B2")) == 0;
+    if (tun_set(h.tun.reg_thomas_t)) c->reg_thomas_t = h.tun.reg_thomas_t != 0;
+    c->force_presum = tun_on(h.tun.solver_presum);
+    c->fpcg_one_cell = tun_off(h.tun.fpcg_b2);
     c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && (long long)c->nchunk * h.nblocks > 2048;
-    if (getenv("POP_PCSI_STEP2")) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && atoi(getenv("POP_PCSI_STEP2")) != 0;
+    if (tun_set(h.tun.pcsi_step2)) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && h.tun.pcsi_step2 != 0;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && !use_evp(*cfg) && h.nblocks_tot <= 8 &&
-                    (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !getenv("POP_SOLVER_DISTRIBUTED");
+                    (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !tun_on(h.tun.solver_distributed);
     if (c->replicated) {
       const size_t NG = h.n2 * h.nblocks_tot;
       SolveView &v = c->gv;
@@ -1658,14 +1707,14 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   }
   if (mix_create(c->h, c->g, c->mix, c->allocs, c->err)) return 1;
   c->KBL = const_cast<int *>(mix_kpp_kbl(c->mix));
-  if (cfg->reserved_d[4] != 0.0 && sw_tables_create(c->h, c->allocs, c->err)) return 1;   // lsw_absorb without KPP's lshort_wave
+  if (cfg->lsw_absorb != 0 && sw_tables_create(c->h, c->allocs, c->err)) return 1;   // lsw_absorb without KPP's lshort_wave
   if (c->h.sw.CHLI) {   // the default chlorophyll amount the table index was built for
     std::vector<double> chl((size_t)c->g.n2 * c->g.nblocks, 0.25);
     HIPCHK(c, hipMemcpy(c->CHL, chl.data(), chl.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   // KPP look-ahead (bandwidth-bound grids; POP_KPP_AHEAD=0|1 overrides): second set of KPP outputs, own stream
   c->ahead_enabled = cfg->vmix_choice == 3 && c->side && (h.n2 * h.nblocks > (1u << 19));
-  if (getenv("POP_KPP_AHEAD")) c->ahead_enabled = cfg->vmix_choice == 3 && c->side && atoi(getenv("POP_KPP_AHEAD")) != 0;
+  if (tun_set(h.tun.kpp_ahead)) c->ahead_enabled = cfg->vmix_choice == 3 && c->side && h.tun.kpp_ahead != 0;
   if (c->ahead_enabled) {
     for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->KPPa[n], a3)) return 1;
     if (dev_alloc(c, &c->VDCa[0], (size_t)(h.km + 2) * a2)) return 1;
@@ -2070,7 +2119,7 @@ static int phase_vmix(pop_ctx *c) {
 static int kpp_look_ahead(pop_ctx *c) {
   // an averaging step rewrites oldtime and curtime in its tail and does not rotate; the Robert filter rewrites curtime
   // (with the mixed-layer-depth diagnostics on, HMXL / HMXL_DR must belong to the step that just ran: no look-ahead)
-  if (!c->ahead_enabled || c->h.c.vmix_choice != 3 || c->avg_ts || c->h.c.tmix_opt == 3 || c->h.c.reserved_i[5] == 1) return 0;
+  if (!c->ahead_enabled || c->h.c.vmix_choice != 3 || c->avg_ts || c->h.c.tmix_opt == 3 || c->h.c.kpp_ml_diagnostics == 1) return 0;
   HIPCHK(c, hipEventRecord(c->ev_ahead_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->ahead, c->ev_ahead_fork, 0));
   const MixState ms = kpp_mix_state(c, c->curt, true);
@@ -2121,9 +2170,9 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   if (c->h.c.hmix_tracer == 4) { a.TMIX[0] = c->d2t[0]; a.TMIX[1] = c->d2t[1]; }   // del4: second Laplacian acts on D2T
   a.UCUR = c->U[c->curt]; a.VCUR = c->V[c->curt]; a.DH = c->DH; a.PCUR = c->PS[c->curt]; a.POLD = c->PS[c->oldt];
   a.c2dtt = c->c2dtt; a.use_kpp_src = (c->h.c.vmix_choice == 3);
-  if (a.use_kpp_src && !c->kpp_src_user && !getenv("POP_KPP_SRC_FULL")) a.KBL = c->KBL;
-  if (c->h.c.reserved_d[4] != 0.0) {   // lsw_absorb: penetrating short wave (add_sw_absorb)
-    a.sw_on = 1; a.sw_type = c->h.c.reserved_i[6]; a.sw_ksol = c->h.sw.ksol;
+  if (a.use_kpp_src && !c->kpp_src_user && !tun_on(c->h.tun.kpp_src_full)) a.KBL = c->KBL;
+  if (c->h.c.lsw_absorb != 0) {   // lsw_absorb: penetrating short wave (add_sw_absorb)
+    a.sw_on = 1; a.sw_type = c->h.c.sw_absorption_type; a.sw_ksol = c->h.sw.ksol;
     a.QSW = c->SHF_QSW; a.swabs = c->h.sw.swabs; a.swTr = c->h.sw.Tr; a.swCHLI = c->h.sw.CHLI;
   }
   // the next step's first Laplacian: valid when that step is a leapfrog step whose mix time is this step's current time and nothing
@@ -2159,7 +2208,7 @@ static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {
 // through the LDS kernel, generic (scratch-staged) solve -- POP_TRACER_FWD=0|1 overrides
 static bool tracer_fwd_fused(const pop_ctx *c) {
   const bool can = c->h.c.tadvect == 1 && (c->trc_lds_rows == 4 || c->trc_lds_rows == 8) && c->h.c.lpressure_avg && c->leapfrogts;
-  if (getenv("POP_TRACER_FWD")) return can && atoi(getenv("POP_TRACER_FWD")) != 0;
+  if (tun_set(c->h.tun.tracer_fwd)) return can && c->h.tun.tracer_fwd != 0;
   return can && !c->reg_thomas_t;
 }
 static int phase_impvmixt_back(pop_ctx *c) {
@@ -2171,7 +2220,7 @@ static int phase_impvmixt_back(pop_ctx *c) {
   return 0;
 }
 static int phase_impvmixt_pred(pop_ctx *c) {
-  launch_impvmixt<0, false, false>(c->g, step_params(c), impvmixt_args(c, c->PS[c->curt]), grid_cols(c), c->stream, c->reg_thomas_t);
+  launch_impvmixt<0, false, false>(c->g, step_params(c), impvmixt_args(c, c->PS[c->curt]), grid_cols(c), c->stream, c->reg_thomas_t, c->h.tun.thomas_pair);
   return 0;
 }
 static int phase_state_new(pop_ctx *c) {
@@ -2227,8 +2276,13 @@ static int phase_impvmixu(pop_ctx *c, hipStream_t st) {
 
 static int phase_correct(pop_ctx *c) {
   const StepParams sp = step_params(c);
-  if (sp.pavg) launch_impvmixt<1, false, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t);
-  else launch_impvmixt<0, true, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t);
+  // the generic Thomas kernel stages E, F through the shared 3-D scratch (E3, F3), which a KPP look-ahead in flight on its own
+  // stream also uses (E3 = the Richardson column of the generic k_kpp_interior): the corrector then follows the look-ahead.
+  // The register kernels (km = 60 / 62) touch no scratch and run beside it.
+  const bool reg_kernel = c->reg_thomas_t && (c->g.km == 60 || c->g.km == 62);
+  if (!reg_kernel && c->ahead_valid) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+  if (sp.pavg) launch_impvmixt<1, false, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t, c->h.tun.thomas_pair);
+  else launch_impvmixt<0, true, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t, c->h.tun.thomas_pair);
   return 0;
 }
 static int phase_add_btrop(pop_ctx *c, hipStream_t st = nullptr) {
@@ -2291,11 +2345,11 @@ int pop_baroclinic_driver(pop_ctx *c) {
   // the way out (k_impvmixu_reg<., ., true>): the separate k_add_barotropic pass over U, V(new) is gone.  Nothing between here and
   // baroclinic_correct_adjust reads U, V(new); a caller that does (any field access: join_side) gets the plain kernel first.
   // Not across a tripole fold (the sum follows the halo update there).  POP_VMIXU_DEFER=0|1 overrides the size rule.
-  const int defer_env = getenv("POP_VMIXU_DEFER") ? atoi(getenv("POP_VMIXU_DEFER")) : -1;
-  const bool defer = c->side && impvmixu_add_available(c->g, c->reg_thomas) && c->h.c.ns_boundary != 2 && !getenv("POP_BTROP_INLINE") &&
-                     !getenv("POP_VMIXU_INLINE") && (defer_env >= 0 ? defer_env != 0 : (long long)c->g.n2 * c->g.nblocks > (1 << 19));
+  const int defer_env = tun_or(c->h.tun.vmixu_defer, -1);
+  const bool defer = c->side && impvmixu_add_available(c->g, c->reg_thomas) && c->h.c.ns_boundary != 2 && !tun_on(c->h.tun.btrop_inline) &&
+                     !tun_on(c->h.tun.vmixu_inline) && (defer_env >= 0 ? defer_env != 0 : (long long)c->g.n2 * c->g.nblocks > (1 << 19));
   if (defer) c->vmixu_deferred = true;
-  else if (c->side && c->reg_thomas && (c->g.km == 60 || c->g.km == 62) && !getenv("POP_VMIXU_INLINE")) {
+  else if (c->side && c->reg_thomas && (c->g.km == 60 || c->g.km == 62) && !tun_on(c->h.tun.vmixu_inline)) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     if (phase_impvmixu(c, c->side)) return 1;
@@ -2310,13 +2364,13 @@ int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
   if (c->h.c.solver_choice == 2) {
     if (c->fused_ok && !c->use_evp) return solver_chrongear_fused(c);
-    if (c->h.nranks > 1 && c->max_blocks_per_rank <= 16 && !c->use_evp && !getenv("POP_SOLVER_UNFUSED")) return solver_chrongear_fused_dist(c);
+    if (c->h.nranks > 1 && c->max_blocks_per_rank <= 16 && !c->use_evp && !tun_on(c->h.tun.solver_unfused)) return solver_chrongear_fused_dist(c);
     return solver_chrongear(c);
   }
   if (c->h.c.solver_choice == 3) {
     if (c->use_evp) return solver_pcsi(c);
     if (c->fused_ok) return solver_pcsi_fused(c);
-    if (c->h.nranks > 1 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcsi_fused_dist(c);
+    if (c->h.nranks > 1 && !tun_on(c->h.tun.solver_unfused)) return solver_pcsi_fused_dist(c);
     return solver_pcsi(c);
   }
   if (c->use_evp) return solver_pcg(c);
@@ -2325,7 +2379,7 @@ int pop_solver_run(pop_ctx *c) {
     return solver_pcg_replicated(c);
   }
   if (c->fused_ok) { SolveView v = fused_view(c); const int e = solver_pcg_fused(c, v); c->S0 = v.S0; c->S1 = v.S1; return e; }
-  if (c->h.nranks > 1 && c->max_blocks_per_rank <= 16 && !getenv("POP_SOLVER_UNFUSED")) return solver_pcg_fused_dist(c);
+  if (c->h.nranks > 1 && c->max_blocks_per_rank <= 16 && !tun_on(c->h.tun.solver_unfused)) return solver_pcg_fused_dist(c);
   return solver_pcg(c);
 }
 int pop_solver_preconditioner(pop_ctx *c, const char *x_name, int x_tl, const char *px_name, int px_tl) {
@@ -2419,7 +2473,7 @@ int pop_baroclinic_correct_adjust(pop_ctx *c) {
     launch_impvmixu_add(c->g, step_params(c), a, grid_cols(c), c->side);
     HIPCHK(c, hipEventRecord(c->ev_vmixu, c->side));
     c->vmixu_pending = true; c->btrop_added = true;
-  } else if (c->side && !getenv("POP_BTROP_INLINE") && c->h.c.ns_boundary != 2) {
+  } else if (c->side && !tun_on(c->h.tun.btrop_inline) && c->h.c.ns_boundary != 2) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     if (phase_add_btrop(c, c->side)) return 1;
@@ -2830,7 +2884,7 @@ int pop_comm_init_rccl(pop_ctx *c, const unsigned char *id128) {
   // rank 0 and travels over the first communicator, one byte per double (exact under the sum with the other ranks'
   // zeros), so the host has nothing more to broadcast.  POP_RCCL_OVERLAP=0 keeps everything on one communicator.
   // (POP_RCCL_OVERLAP=2 also creates it on a single rank, so that the whole set-up can be checked against the real librccl)
-  const int want2 = getenv("POP_RCCL_OVERLAP") ? atoi(getenv("POP_RCCL_OVERLAP")) : 1;
+  const int want2 = tun_or(c->h.tun.rccl_overlap, 1);
   if (c->side && want2 != 0 && (c->h.nranks > 1 || want2 == 2)) {
     std::vector<double> enc(128, 0.0);
     RcclApi::UniqueId id2;

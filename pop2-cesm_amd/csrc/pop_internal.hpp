@@ -50,7 +50,7 @@ struct HaloPlan {
   bool tripole_split = false;           // the top row of blocks has more than one owner: no plan
 };
 
-// ---- EVP block preconditioner (reserved_i[2] = 1; POP_SolversMod.F90:252-290, 2434-2696): sub-blocks of at most
+// ---- EVP block preconditioner (preconditioner_choice = 1; POP_SolversMod.F90:252-290, 2434-2696): sub-blocks of at most
 //      EVP_BS x EVP_BS cells with a one-cell rim, for every block of the decomposition
 constexpr int EVP_BS = 8, EVP_LD = EVP_BS + 2, EVP_LE = 2 * EVP_BS - 1;
 struct EvpHost {
@@ -73,9 +73,15 @@ struct SwTab {
   int ksol = 0;
   double chlmin = 0, chlmax = 0, dlogchl = 0;
 };
+// tuning switches (include/pop_amd.h pop_tuning): resolved once at pop_create -- size rule < caller's struct < POP_* environment
+inline bool tun_set(int v) { return v != POP_TUNING_UNSET; }
+inline bool tun_on(int v) { return v != POP_TUNING_UNSET && v != 0; }
+inline bool tun_off(int v) { return v == 0; }
+inline int tun_or(int v, int dflt) { return v != POP_TUNING_UNSET ? v : dflt; }
 struct HostModel {
   SwTab sw;
   pop_config c{};
+  pop_tuning tun{};
   const pop_grid_input *gin = nullptr;     // caller's grid (pop_create_with_grid); read during host_build only
   int rank = 0, nranks = 1;
   int nxb = 0, nyb = 0, km = 0, nt = 2;
@@ -127,7 +133,7 @@ std::vector<double> host_center_init(HostModel &h);                      // cent
 int host_pcsi_prep(HostModel &h, const std::vector<double> &C);         // host_pcsi.cpp
 int host_evp_prep(HostModel &h, const std::vector<double> &C);          // host_evp.cpp
 void host_evp_apply(const HostModel &h, double *PX, const double *X);   // all blocks
-inline bool use_evp(const pop_config &c) { return c.reserved_i[2] == 1; }
+inline bool use_evp(const pop_config &c) { return c.preconditioner_choice == 1; }
 void build_halo_plan(HostModel &h);      // halo_plan.cpp
 void host_halo_r8(const HostModel &h, double *a, int nz, double fill);   // single-rank host halo
 void host_halo_i4(const HostModel &h, int *a, int nz, int fill);

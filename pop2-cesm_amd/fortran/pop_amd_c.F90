@@ -12,7 +12,10 @@
    integer (c_int), parameter :: POP_CREATE_HOST_ONLY = 1
 
    ! mirrors `struct pop_config` field for field
+   integer (c_int), parameter :: POP_CONFIG_VERSION = 3
+
    type, bind(C) :: pop_config
+      integer (c_int) :: struct_version = POP_CONFIG_VERSION
       integer (c_int) :: nx_global, ny_global, km, nt
       integer (c_int) :: block_size_x, block_size_y
       integer (c_int) :: ew_boundary, ns_boundary
@@ -22,7 +25,14 @@
       integer (c_int) :: tmix_opt, time_mix_freq, steps_per_day
       integer (c_int) :: lbouss_correct, lpressure_avg, impcor, reset_to_freezing
       integer (c_int) :: lrich, ldbl_diff, lshort_wave, lcheckekmo, num_v_smooth_Ri
-      integer (c_int) :: reserved_i(8)
+      integer (c_int) :: maxlanczosstep = 0, convergence_check_start = 0   ! solvers_nml (PCSI); 0 = the reference's defaults
+      integer (c_int) :: preconditioner_choice = 0                         ! solvers_nml preconditionerChoice: 0 'diagonal', 1 'evp'
+      integer (c_int) :: stepped_bathymetry = 0                            ! test extension of the internal topography
+      integer (c_int) :: distribution_type = 0                             ! domain_nml: 0 equal block counts, 1 equal ocean columns
+      integer (c_int) :: kpp_ml_diagnostics = 0                            ! HMXL, HMXL_DR every step
+      integer (c_int) :: sw_absorption_type = 0, jerlov_water_type = 0, lsw_absorb = 0   ! sw_absorption_nml
+      integer (c_int) :: partial_bottom_cells = 0                          ! grid_nml
+      integer (c_int) :: reserved_i(3) = 0
       real (c_double) :: am, ah
       real (c_double) :: const_vvc, const_vdc
       real (c_double) :: convect_diff, convect_visc, bottom_drag, aidif
@@ -30,7 +40,10 @@
       real (c_double) :: bckgrnd_vdc1, bckgrnd_vdc2, bckgrnd_vdc_dpth, bckgrnd_vdc_linv
       real (c_double) :: Prandtl, kpp_rich_mix
       real (c_double) :: convergence_criterion
-      real (c_double) :: reserved_d(8)
+      real (c_double) :: init_ts_perturbation = 0.0_c_double
+      real (c_double) :: robert_alpha = 0.0_c_double, robert_nu = 0.0_c_double
+      real (c_double) :: lanczos_convergence_criterion = 0.0_c_double
+      real (c_double) :: reserved_d(4) = 0.0_c_double
    end type pop_config
 
    ! mirrors `struct pop_grid_input`: the records of horiz_grid_file / topography_file (grid.F90:1314-1542, 2025-2107)
@@ -38,6 +51,7 @@
    type, bind(C) :: pop_grid_input
       type (c_ptr) :: ULAT, ULON, HTN, HTE, HUS, HUW, ANGLE
       type (c_ptr) :: KMT
+      type (c_ptr) :: DZBC = c_null_ptr   ! partial_bottom_cells: record of bottom_cell_file (grid.F90:2116-2186)
    end type pop_grid_input
 
    type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task

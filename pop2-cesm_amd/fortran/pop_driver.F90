@@ -85,7 +85,6 @@
       c%tmix_opt = 2; c%time_mix_freq = 17; c%steps_per_day = 24
       c%lbouss_correct = 0; c%lpressure_avg = 1; c%impcor = 1; c%reset_to_freezing = 1
       c%lrich = 1; c%ldbl_diff = 0; c%lshort_wave = 0; c%lcheckekmo = 0; c%num_v_smooth_Ri = 1
-      c%reserved_i = 0
       c%am = 3.0e9_c_double; c%ah = 1.0e7_c_double
       c%const_vvc = 0.25_c_double; c%const_vdc = 0.25_c_double
       c%convect_diff = 1000.0_c_double; c%convect_visc = 1000.0_c_double
@@ -95,8 +94,7 @@
       c%bckgrnd_vdc_dpth = 2500.0e2_c_double; c%bckgrnd_vdc_linv = 4.5e-5_c_double
       c%Prandtl = 10.0_c_double; c%kpp_rich_mix = 50.0_c_double
       c%convergence_criterion = 1.0e-12_c_double
-      c%reserved_d = 0.0_c_double
-      c%reserved_d(1) = 1.0e-2_c_double
+      c%init_ts_perturbation = 1.0e-2_c_double
    end function default_config
 
  end program pop_driver

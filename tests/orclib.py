@@ -66,7 +66,8 @@ def load():
 
 class OrcGridInput(C.Structure):
     """oracle/pop_oracle.h orc_grid_input"""
-    _fields_ = [(n, C.POINTER(C.c_double)) for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")] + [("KMT", C.POINTER(C.c_int))]
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")] + [("KMT", C.POINTER(C.c_int)),
+                                                                                                               ("DZBC", C.POINTER(C.c_double))]
 
 
 class Oracle:
@@ -80,7 +81,7 @@ class Oracle:
             self.h = self.L.orc_create(C.byref(cfg))
         else:   # orc_grid_input has pop_grid_input's layout (declared separately on purpose, like the config)
             gin, keep = OrcGridInput(), []
-            for n, ty, ct in [(n, np.float64, C.c_double) for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE")] + [("KMT", np.int32, C.c_int)]:
+            for n, ty, ct in [(n, np.float64, C.c_double) for n in ("ULAT", "ULON", "HTN", "HTE", "HUS", "HUW", "ANGLE", "DZBC")] + [("KMT", np.int32, C.c_int)]:
                 if grid.get(n) is not None:
                     a = np.ascontiguousarray(grid[n], dtype=ty)
                     assert a.shape == (cfg.ny_global, cfg.nx_global), n

@@ -8,6 +8,7 @@ import ctypes as C
 
 class PopConfig(C.Structure):
     _fields_ = [
+        ("struct_version", C.c_int),
         ("nx_global", C.c_int), ("ny_global", C.c_int), ("km", C.c_int), ("nt", C.c_int),
         ("block_size_x", C.c_int), ("block_size_y", C.c_int),
         ("ew_boundary", C.c_int), ("ns_boundary", C.c_int),
@@ -19,7 +20,11 @@ class PopConfig(C.Structure):
         ("reset_to_freezing", C.c_int),
         ("lrich", C.c_int), ("ldbl_diff", C.c_int), ("lshort_wave", C.c_int), ("lcheckekmo", C.c_int),
         ("num_v_smooth_Ri", C.c_int),
-        ("reserved_i", C.c_int * 8),
+        ("maxlanczosstep", C.c_int), ("convergence_check_start", C.c_int), ("preconditioner_choice", C.c_int),
+        ("stepped_bathymetry", C.c_int), ("distribution_type", C.c_int), ("kpp_ml_diagnostics", C.c_int),
+        ("sw_absorption_type", C.c_int), ("jerlov_water_type", C.c_int), ("lsw_absorb", C.c_int),
+        ("partial_bottom_cells", C.c_int),
+        ("reserved_i", C.c_int * 3),
         ("am", C.c_double), ("ah", C.c_double),
         ("const_vvc", C.c_double), ("const_vdc", C.c_double),
         ("convect_diff", C.c_double), ("convect_visc", C.c_double), ("bottom_drag", C.c_double),
@@ -28,7 +33,9 @@ class PopConfig(C.Structure):
         ("bckgrnd_vdc1", C.c_double), ("bckgrnd_vdc2", C.c_double), ("bckgrnd_vdc_dpth", C.c_double),
         ("bckgrnd_vdc_linv", C.c_double), ("Prandtl", C.c_double), ("kpp_rich_mix", C.c_double),
         ("convergence_criterion", C.c_double),
-        ("reserved_d", C.c_double * 8),
+        ("init_ts_perturbation", C.c_double), ("robert_alpha", C.c_double), ("robert_nu", C.c_double),
+        ("lanczos_convergence_criterion", C.c_double),
+        ("reserved_d", C.c_double * 4),
     ]
 
 
@@ -37,6 +44,7 @@ def base_config(**kw):
     (vertical_mix.F90:233-240, POP_SolversMod.F90:578-662, pressure_grad.F90:118-119,
     baroclinic.F90:208, vmix_rich.F90:108-110, vmix_const.F90:101-102)."""
     c = PopConfig()
+    c.struct_version = 3
     c.nt = 2
     c.ew_boundary, c.ns_boundary = 1, 0
     c.hmix_momentum = c.hmix_tracer = 2
@@ -53,36 +61,21 @@ def base_config(**kw):
     c.bckgrnd_vdc1, c.bckgrnd_vdc2, c.bckgrnd_vdc_dpth, c.bckgrnd_vdc_linv = 0.1, 0.0, 2500.0e2, 4.5e-5
     c.Prandtl, c.kpp_rich_mix = 10.0, 50.0
     c.convergence_criterion = 1.0e-12
-    c.reserved_d[0] = 1.0e-2          # init T perturbation amplitude
+    c.init_ts_perturbation = 1.0e-2          # init T perturbation amplitude
     _apply(c, kw)
     return c
 
 
 def _apply(c, kw):
-    """Set fields by name; robert_alpha / robert_nu live in reserved_d[1], [2] (tmix_opt = 3),
-    precond_choice (0 diagonal, 1 evp) in reserved_i[2],
-    stepped_bathymetry (test extension: KMT = 3 ... km) in reserved_i[3]."""
+    """Set fields by name (a few historical aliases are kept: precond_choice, distribution, kpp_diagnostics)."""
+    alias = {"precond_choice": "preconditioner_choice", "distribution": "distribution_type", "kpp_diagnostics": "kpp_ml_diagnostics"}
     for k, v in kw.items():
-        if k == "precond_choice":
-            c.reserved_i[2] = v
-        elif k == "stepped_bathymetry":
-            c.reserved_i[3] = v
-        elif k == "distribution":      # 0 equal block counts per rank, 1 balanced by ocean columns
-            c.reserved_i[4] = v
-        elif k == "kpp_diagnostics":   # 1: HMXL, HMXL_DR every step
-            c.reserved_i[5] = v
-        elif k == "sw_absorption_type":   # lshort_wave: 0 top-layer, 1 jerlov
-            c.reserved_i[6] = v
-        elif k == "jerlov_water_type":
-            c.reserved_i[7] = v
-        elif k == "lsw_absorb":        # penetrating short wave as a temperature source (add_sw_absorb)
-            c.reserved_d[4] = float(v)
-        elif k == "robert_alpha":
-            c.reserved_d[1] = v
-        elif k == "robert_nu":
-            c.reserved_d[2] = v
-        else:
-            setattr(c, k, v)
+        k = alias.get(k, k)
+        if k == "lsw_absorb":
+            v = int(bool(v))
+        if not hasattr(c, k):
+            raise AttributeError("pop_config has no field %r" % k)
+        setattr(c, k, v)
 
 
 def named_config(name, **kw):

@@ -147,7 +147,7 @@ def test_land_elimination_across_ranks(nranks, kw, env, transport):
                 "--kw", kw], 300, env, transport=transport)
 
 
-# ---- load-balanced distribution (reserved_i[4] = 1): contiguous runs of blocks with equal ocean columns, so ranks own
+# ---- load-balanced distribution (distribution_type = 1): contiguous runs of blocks with equal ocean columns, so ranks own
 # different numbers of blocks (the polar ranks more); same numbers as the single-rank run
 @pytest.mark.parametrize("nranks,kw,env,transport", [
     (3, "distribution=1,block_size_x=48,block_size_y=5", {}, "staged"),                                   # 8 j-bands over 3 ranks

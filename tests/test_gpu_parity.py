@@ -230,7 +230,7 @@ def test_grid_input_step_phases_match_oracle(pkg, orclib_built, monkeypatch, kw,
 @pytest.mark.parametrize("name,kw", [("tiny", {"km": 24}), ("tiny", {"km": 24, "stepped_bathymetry": 1, "ldbl_diff": 1}), ("gx3v7", {})])
 def test_kpp_mixed_layer_depth_diagnostics(pkg, orclib_built, name, kw):
     """HMXL (depth of the maximum buoyancy gradient) and HMXL_DR (0.03 kg/m^3 density criterion), vmix_kpp.F90:1310-1418,
-    computed every step when reserved_i[5] = 1: every cell of every block against the oracle"""
+    computed every step when kpp_ml_diagnostics = 1: every cell of every block against the oracle"""
     cfg = named_config(name, vmix_choice=3, kpp_diagnostics=1, **kw)
     gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
     force_kpp_case(gpu, orc)
@@ -984,7 +984,7 @@ def test_solver_error_convention(pkg, orclib_built, solver):
     """POP_SolversMod.F90:1492-1497: hitting maxIterations is an error (errorCode set, message) unless
     convergenceCriterion == 0, in which case the solver simply runs maxIterations steps."""
     cfg = named_config("tiny", solver_choice=solver, max_iterations=20, convergence_check_freq=10)
-    cfg.reserved_i[1] = 10                                  # PCSI: start checking early
+    cfg.convergence_check_start = 10                                  # PCSI: start checking early
     cfg.convergence_criterion = 1.0e-30                      # unreachable
     m = pkg.PopModel(cfg)
     with pytest.raises(pkg.PopError, match="not converged"):
@@ -1049,13 +1049,19 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
     a.close(); b.close(); c.close(); d.close(); e.close()
 
 
-@pytest.mark.parametrize("kw", [{"vmix_choice": 3, "km": 24}, {"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21},
-                                {"vmix_choice": 3, "km": 24, "tmix_opt": 1, "time_mix_freq": 3}, {"vmix_choice": 3, "km": 24, "tmix_opt": 3}])
-def test_kpp_look_ahead_is_bitwise_neutral(pkg, orclib_built, monkeypatch, kw):
+@pytest.mark.parametrize("kw,env", [({"vmix_choice": 3, "km": 24}, {}),
+                                    ({"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21}, {}),
+                                    ({"vmix_choice": 3, "km": 24, "tmix_opt": 1, "time_mix_freq": 3}, {}), ({"vmix_choice": 3, "km": 24, "tmix_opt": 3}, {}),
+                                    # the scratch-staged corrector and interior kernels share E3 with the look-ahead: the corrector must follow it
+                                    ({"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1}, {"POP_REG_THOMAS_T": "0", "POP_KPP_INTERIOR_GENERIC": "1", "POP_KPP_COL": "1"}),
+                                    ({"vmix_choice": 3, "km": 20, "ldbl_diff": 1, "block_size_x": 48, "block_size_y": 40}, {"POP_KPP_COL": "0"})])
+def test_kpp_look_ahead_is_bitwise_neutral(pkg, orclib_built, monkeypatch, kw, env):
     """POP_KPP_AHEAD=1: pop_step computes the next step's KPP coefficients on a third stream beside the barotropic solver
     (inputs: this step's curtime fields) and the next step swaps them in.  Twelve steps -- first (Euler) step, leapfrog
     steps, averaging steps (no look-ahead: they rewrite curtime) -- must equal the run without look-ahead bit for bit, also
     when a field is read or set between steps (which drops the look-ahead in flight)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     cfg = named_config("tiny", **kw)
     out = {}
     for mode in ("0", "1"):

@@ -120,7 +120,7 @@ def test_halo_plan_and_block_sums_over_gloo(pkg, world, kw):
 
 
 def test_balanced_distribution_equalises_ocean_columns(pkg):
-    """reserved_i[4] = 1: contiguous runs of block ids whose cuts equalise the ocean columns per rank (the reference's
+    """distribution_type = 1: contiguous runs of block ids whose cuts equalise the ocean columns per rank (the reference's
     load-balanced distributions count ocean points per block the same way, distribution.F90); every rank owns a block,
     every block has one owner, and the heaviest rank carries less than under equal block counts"""
     import numpy as np
