@@ -186,7 +186,12 @@ int pop_get_field(pop_ctx *ctx, const char *name, int tl, int n, double *host, l
 int pop_set_field(pop_ctx *ctx, const char *name, int tl, int n, const double *host, long long count);
 int pop_get_ifield(pop_ctx *ctx, const char *name, int *host, long long count);
 long long pop_field_count(const pop_ctx *ctx, const char *name);
-/* device pointer of a field (for zero-copy host frameworks); 0 if unknown */
+/* device pointer of a field (for zero-copy host frameworks); 0 if unknown.  The call is the library's only notice that the caller
+ * may WRITE the field: it drops work computed ahead from the old values (KPP look-ahead, del4 first Laplacians), marks the ghost
+ * cells as possibly inconsistent and restarts the full (no land elimination) steps, exactly as pop_set_field does -- once.  A
+ * caller that writes through a cached pointer must therefore fetch the pointer again before EVERY write (one call per field per
+ * step; the call is cheap: no copy, no synchronisation beyond joining the library's side streams); the time levels rotate by
+ * index, so the pointer of (name, tl) changes from step to step anyway. */
 void *pop_field_device_ptr(pop_ctx *ctx, const char *name, int tl, int n);
 
 /* ---- restart files: write_restart (restart.F90:1095-1715) / read_restart (:184-1088) in the reference's 'bin'

@@ -434,6 +434,9 @@ k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, cons
 template <int KR>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_ushear_col(DevGrid g, KppDev kp, const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ WU) {
+  // the two barriers below follow an early return of some lanes: defined only because the workgroup is exactly one wavefront
+  // (launched with dim3(POP_COL_THREADS), never as a 2-D tile)
+  static_assert(POP_COL_THREADS == 64, "k_kpp_ushear_col: one wavefront per workgroup");
   __shared__ int s_cap;
   if (kp.WUK && threadIdx.x == 0) s_cap = 0;
   Col c;

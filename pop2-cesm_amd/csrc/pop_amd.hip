@@ -143,6 +143,7 @@ struct pop_ctx {
   double c2dtt = 0, c2dtu = 0, c2dtp = 0, beta = 0;
   std::map<std::string, PhaseTimer> timers;
   bool timing = false;
+  bool phase_timing = false;   // inside pop_time_phase: kernels only
 };
 
 namespace {
@@ -1915,6 +1916,10 @@ void *pop_field_device_ptr(pop_ctx *c, const char *name, int tl, int n) {
   join_side(c);   // the caller may read the field on the launch stream
   if (!strcmp(name, "TRACER")) c->tr_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;   // ... or write it
   if (!strcmp(name, "UVEL") || !strcmp(name, "VVEL")) c->uv_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;
+  if (!strcmp(name, "KPP_SRC")) c->kpp_src_user = true;
+  // ... with other values on land: the next steps run every workgroup again, as after pop_set_field
+  for (const char *f : {"TRACER", "UVEL", "VVEL", "RHO", "PSURF", "GRADPX", "GRADPY", "UBTROP", "VBTROP", "PGUESS", "FW_OLD"})
+    if (!strcmp(name, f)) c->full_left = c->land_full_steps;
   double *p; long long cnt;
   return resolve(c, name, tl, n, &p, &cnt) ? nullptr : (void *)p;
 }
@@ -2183,7 +2188,7 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   c->d2t_last_formed = form_next;
   if (lds_kernel) {
     if (c->trc_lds_rows == 8) launch_tracer_lds<8>(c->g, sp, a, c->stream, fwd); else launch_tracer_lds<4>(c->g, sp, a, c->stream, fwd);
-    if (form_next) {
+    if (form_next && !c->phase_timing) {
       if (halo_update_many(c, {{c->d2t_next[0], c->g.km}, {c->d2t_next[1], c->g.km}})) return 1;
       c->d2t_next_valid = true; c->d2t_next_slot = c->curt;
     }
@@ -2262,7 +2267,7 @@ static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1, b
   if (c->mom_lds_rows == 8) launch_momentum_lds<8>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else if (c->mom_lds_rows == 4) launch_momentum_lds<4>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
-  if (form_next && last_piece) {
+  if (form_next && last_piece && !c->phase_timing) {
     if (halo_update_many(c, {{c->d2u_next[0], c->g.km, 1, 1}, {c->d2u_next[1], c->g.km, 1, 1}})) return 1;
     c->d2u_next_valid = true; c->d2u_next_slot = c->curt;
   }
@@ -3050,15 +3055,21 @@ int pop_time_phase(pop_ctx *c, const char *phase, int reps, double *avg_ms) {
   const std::string p(phase);
   phase_fn_t fn = phase_by_name(p);
   if (!fn) { c->err = "unknown phase " + p; return 1; }
-  hipEvent_t e0, e1;
-  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  struct Events {   // destroyed on every return path
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+  } ev;
+  HIPCHK(c, hipEventCreate(&ev.e0)); HIPCHK(c, hipEventCreate(&ev.e1));
+  // the launches of the phase only: the halo update of a first Laplacian formed for the next step (del4, large grids) belongs to
+  // the step, not to the kernel, and the fields formed here are not kept
+  struct Flag { bool &f; Flag(bool &x) : f(x) { f = true; } ~Flag() { f = false; } } timing(c->phase_timing);
   if (fn(c)) return 1;   // warm
-  HIPCHK(c, hipEventRecord(e0, c->stream));
+  HIPCHK(c, hipEventRecord(ev.e0, c->stream));
   for (int r = 0; r < reps; ++r) if (fn(c)) return 1;
-  HIPCHK(c, hipEventRecord(e1, c->stream));
-  HIPCHK(c, hipEventSynchronize(e1));
-  float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(ev.e1));
+  float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+  c->d2t_next_valid = false; c->d2u_next_valid = false;
   *avg_ms = ms / std::max(reps, 1);
   return 0;
 }

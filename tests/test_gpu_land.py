@@ -26,6 +26,12 @@ CASES = [
     ("test", {"vmix_choice": 3, "stepped_bathymetry": 1, "time_mix_freq": 6}, {}, 13),          # 96 blocks, many of them land
     ("gx3v7", {"tadvect": 3, "tmix_opt": 3}, {}, 10),
     ("tiny", {"solver_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "lvariable_hmix": 1}, {}, 10),
+    # the buffers the fused del4 first Laplacians share with other kernel choices: forward elimination inside the tracer kernel (E, F
+    # of the second tracer in S3c / S3d) and the in-line order (d2t / d2u aliased onto S3a / S3b, which KPP also uses as scratch)
+    ("wide", {"vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e19, "ah": -1.0e18, "time_mix_freq": 5},
+     {"POP_D2T_FUSE": "1", "POP_TRACER_FWD": "1", "POP_REG_THOMAS_T": "0"}, 10),
+    ("wide", {"vmix_choice": 3, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e19, "ah": -1.0e18, "time_mix_freq": 5},
+     {"POP_DEL4_SIDE": "0", "POP_D2T_FUSE": "1"}, 10),
 ]
 
 
