@@ -3,6 +3,7 @@
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...        (no launcher: starts the line above itself as a child process and relays its JSON line)
 
 A "step" is one full model time step (step_mod.F90 `step`: dhdt -> baroclinic_driver ->
 barotropic_driver -> baroclinic_correct_adjust -> halo updates / time-level update) on synthetic
@@ -212,12 +213,88 @@ def pmc_traffic(workload, kernel):
     """HBM/fabric bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, separate passes; profiles/r02_pmc_traffic.json).  None when no pass exists for this case."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            t = json.load(f)
-        e = t[workload][kernel]
-        return e["fetch_bytes"] + e["write_bytes"]
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                with open(path) as f:
+                    t = json.load(f)
+                e = t[workload][kernel]
+                return e["fetch_bytes"] + e["write_bytes"]
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
+
+
+def self_launch(argv, ngpus):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks as a CHILD process
+    (torch.distributed.run, rendezvous on 127.0.0.1) before anything in this process has touched the GPU, relay
+    its output and return its exit code.  Never an exec: this pool forbids replacing a process image."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this image)
+    env["POP_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.run(cmd, env=env).returncode
+
+
+def tensor_view(torch, ptr, shape):
+    """torch tensor over a device pointer of the library (pop_field_device_ptr), float64, C order"""
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2, "strides": None}
+    return torch.as_tensor(h, device="cuda")
+
+
+def kpp_deep_state(pkg, model, cfg, torch, nlev=12, warm=6, steps=8):
+    """Second, separately labelled measurement AFTER the timed region: the same workload on a state whose KPP boundary layer is
+    several levels deep (surface cooling over a weakly stratified upper ocean in latitude bands; profiles/kpp_deep.py), because
+    the headline state (STF = 0) keeps HBLT at its minimum, the best case for the on-demand forms of the KPP kernels.
+    The tracers are edited in place on the GPU through pop_field_device_ptr."""
+    nb, km, ny, nx = model.nblocks, model.km, model.nyb, model.nxb
+    kmt_h = model.geti("KMT")
+    kmt = torch.as_tensor(kmt_h, device="cuda")
+    tlat_h = np.broadcast_to(np.linspace(-1.35, 1.5, ny)[None, :, None], (nb, ny, nx)).copy()
+    band = torch.as_tensor(np.sin(3.0 * tlat_h) > 0.0, device="cuda")
+    z = torch.arange(nlev, device="cuda", dtype=torch.float64)[None, :, None, None]
+    cond = (z < kmt[:, None].to(torch.float64)) & band[:, None]
+    model.sync()
+    for tl in (0, 1, 2):
+        for n, slope in ((0, 2.0e-4), (1, -2.0e-9)):
+            ptr = model.L.pop_field_device_ptr(model.h, b"TRACER", tl, n)
+            T = tensor_view(torch, ptr, (nb, km, ny, nx))
+            top = T[:, :nlev]
+            top.copy_(torch.where(cond, T[:, 0:1] - slope * z, top))
+    torch.cuda.synchronize()
+    del kmt, band, cond
+    model.set("STF", -3.0e-2 * np.sin(tlat_h) - 1.0e-2, n=0)
+    model.set("STF", 2.0e-6 * np.cos(2.0 * tlat_h), n=1)
+    for _ in range(warm):
+        model.step()
+    model.sync()
+    model.scalar("solver_ms_reset")
+    t0 = time.perf_counter()
+    its = []
+    for _ in range(steps):
+        model.step()
+        its.append(model.solver_diagnostics()[0])
+    model.sync()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    oc = kmt_h > 0
+    kbl = model.geti("KBL")[oc]
+    H = model.get("HBLT")[oc]
+    sol_ms = model.scalar("solver_ms_total") / max(model.scalar("solver_calls_total"), 1.0)
+    return {"what": "same workload, KPP boundary layer several levels deep (surface cooling over a weakly stratified upper %d levels in "
+                    "latitude bands, profiles/kpp_deep.py); measured AFTER the timed region, not the headline" % nlev,
+            "ms_per_step": round(ms, 3), "steps": steps, "warmup": warm, "pcg_iters_per_step": float(np.mean(its)),
+            "solver_ms_per_step": round(sol_ms, 3), "ms_per_step_without_solver": round(ms - sol_ms, 3),
+            "hblt_level_p50": int(np.percentile(kbl, 50)), "hblt_level_p90": int(np.percentile(kbl, 90)), "hblt_level_max": int(kbl.max()),
+            "hblt_m_p50": round(float(np.median(H)) / 100, 1), "hblt_m_p90": round(float(np.percentile(H, 90)) / 100, 1)}
 
 
 def main():
@@ -232,14 +309,19 @@ def main():
                     help="solver preconditioner (headline = diagonal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-rows", type=int, default=0, help="rows per j-band block (default: one band per rank, or balanced bands on large grids)")
+    ap.add_argument("--no-deep-state", action="store_true", help="skip the second (deep KPP boundary layer) measurement after the timed region")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # no launcher around us: become one (child process; nothing here has touched the GPU yet, torch is not even imported)
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run, or with no launcher at all)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libpop_amd has no CPU fallback")
     # POP_BENCH_BACKEND=gloo: CPU-staged transport so the N>1 path can be rehearsed on a 1-GPU box
@@ -260,7 +342,7 @@ def main():
     cfg.solver_choice = {"pcg": 1, "chrongear": 2, "pcsi": 3}[args.solver]
     cfg.preconditioner_choice = 1 if args.precond == "evp" else 0
     model = pkg.PopModel(cfg, rank=rank, nranks=world)
-    comm, transport = None, "none"
+    comm, transport, transport_note = None, "none", ""
     if world > 1:
         # default: the library's own RCCL transport (stream-ordered ncclSend/Recv/AllReduce, no host call per
         # message); POP_BENCH_TRANSPORT=torch keeps the torch.distributed callbacks.  A failed self-test on
@@ -275,7 +357,8 @@ def main():
                 try:
                     box[0] = pkg.PopModel.rccl_unique_id()
                 except pkg.PopError as e:
-                    print("rccl transport unavailable:", e, file=sys.stderr)
+                    transport_note = "rccl transport unavailable: %s" % e
+                    print(transport_note, file=sys.stderr)
             dist.broadcast_object_list(box, src=0)
             if box[0] is not None:
                 try:
@@ -283,7 +366,8 @@ def main():
                     model.comm_selftest()
                     ok = 1
                 except pkg.PopError as e:
-                    print("rank %d: rccl transport failed its self-test: %s" % (rank, e), file=sys.stderr)
+                    transport_note = "rank %d: rccl transport failed its self-test: %s" % (rank, e)
+                    print(transport_note, file=sys.stderr)
             t = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = int(t.item())
@@ -292,6 +376,11 @@ def main():
         else:
             comm = TorchComm(pkg, model, rank, world, staged=(backend != "nccl"))  # noqa: F841
             transport = "torch.distributed/" + backend
+            if not want_native:
+                transport_note = "native transport not requested (POP_BENCH_TRANSPORT / POP_BENCH_BACKEND)"
+            notes = [None] * world
+            dist.all_gather_object(notes, transport_note)
+            transport_note = "; ".join(n for n in notes if n) or "native self-test failed on another rank"
 
     def barrier():
         model.sync()
@@ -304,23 +393,40 @@ def main():
     for _ in range(args.warmup):
         model.step()
     barrier()
+    model.scalar("solver_ms_reset")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.step()
         iters.append(model.solver_diagnostics()[0])
+    model.sync()
+    busy = time.perf_counter() - t0          # this rank's own work done (before it waits for the others)
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [1e3 * busy / args.steps]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        rank_ms = [None] * world
+        dist.all_gather_object(rank_ms, 1e3 * busy / args.steps)
+    # per-rank evidence for the record: ocean columns owned, what the transport reports about itself
+    kmt_phys = model.geti("KMT")[:, 2:-2, 2:-2]
+    ocean_cols = [int((kmt_phys > 0).sum())]
+    cinfo = [model.comm_info()]
+    if dist is not None:
+        ocean_cols, cinfo = [None] * world, [None] * world
+        dist.all_gather_object(ocean_cols, int((kmt_phys > 0).sum()))
+        dist.all_gather_object(cinfo, model.comm_info())
+    solver_ms = model.scalar("solver_ms_total")
+    solver_iters = model.scalar("solver_iterations_total")
+    solver_calls = model.scalar("solver_calls_total")
     ms_step = 1e3 * elapsed / args.steps
     # step calls per model day: with time_mix_opt = 'avgfit' a day is `full` leapfrog steps plus `half` averaging
     # half-steps (time_management.F90:820-860; tx0.1v3: 300 + 19 = 319 calls), every one a full pass of the hot path
     calls_per_day = model.dim("nsteps_per_interval")
     sypd = 86400.0 / ((elapsed / args.steps) * calls_per_day * 365.0)
 
-    # ---- roofline: every 3-D phase kernel timed with HIP events on its launch stream
+    # ---- roofline: every 3-D phase kernel timed with HIP events on its launch stream (pop_time_phase: the kernel launches only)
     vm = cfg.vmix_choice - 1
     ncell_local = model.nxb * model.nyb * model.km * model.nblocks
     ncell_phys = cfg.nx_global * cfg.ny_global * cfg.km // world
@@ -328,8 +434,14 @@ def main():
     # do not run, so the algorithmic bytes are counted over the segments that do -- the units the launches process
     land_frac = model.scalar("land_tile_fraction") if model.dim("land_skip_active") else 0.0
     ncell_phys = int(round(ncell_phys * (1.0 - land_frac)))
+    # headline state: where the KPP boundary layer sits (decides how much the on-demand KPP forms save)
+    hblt_levels = None
+    if vm == 2:
+        kbl = model.geti("KBL")[model.geti("KMT") > 0]
+        if kbl.size:
+            hblt_levels = [int(np.percentile(kbl, q)) for q in (50, 90, 100)]
     phases = {}
-    fused_t, fused_u = bool(model.dim("d2t_fused")), bool(model.dim("d2u_fused"))
+    extra_words = {}
     for ph, words in PHASE_WORDS.items():
         if ph == "impvmixt" and not cfg.lpressure_avg:
             continue
@@ -337,47 +449,56 @@ def main():
             ms = model.time_phase(ph, reps=10)
         except pkg.PopError:
             continue
-        nw = words[vm]
-        # del4 on large grids: the tracer / momentum launch also writes the next step's first Laplacian (the output of k_del4_d2t /
-        # k_del4_d2u, which are then not launched): the two written words of SURVEY's del4 row belong to this launch -- if the
-        # launches just timed did write them (they do not when the last step was an averaging step)
-        if ph == "tracer_rhs":
-            fused_t = bool(model.dim("d2t_last_formed"))
-        if ph == "momentum_rhs":
-            fused_u = bool(model.dim("d2u_last_formed"))
-        if (ph == "tracer_rhs" and fused_t) or (ph == "momentum_rhs" and fused_u):
-            nw += 2
+        nw = words[vm]        # SURVEY.md 8(d) words of the phase -- the only count `frac` uses
         gb = nw * 8.0 * ncell_phys / 1e9
         phases[ph] = {"ms": round(ms, 4), "alg_GB": round(gb, 4), "GBps": round(gb / (ms * 1e-3), 1), "alg_words": nw}
+        # del4 on large grids: the tracer / momentum launch also READS the two first-Laplacian fields and WRITES the next step's
+        # (the output of k_del4_d2t / k_del4_d2u, which are then not launched).  SURVEY 8(d) has no del4 row, so these words are
+        # reported beside the phase, never inside `frac`.
+        if ph == "tracer_rhs" and cfg.hmix_tracer == 4:
+            extra_words[ph] = 2 + (2 if model.dim("d2t_last_formed") else 0)
+        if ph == "momentum_rhs" and cfg.hmix_momentum == 4:
+            extra_words[ph] = 2 + (2 if model.dim("d2u_last_formed") else 0)
+        if ph in extra_words:
+            phases[ph]["del4_extra_words_moved"] = extra_words[ph]
     # dominant single baroclinic stencil kernel (north_star: "fraction of HBM roofline for the baroclinic stencil")
     dom = max((k for k in phases if k in ("tracer_rhs", "momentum_rhs")), key=lambda k: phases[k]["ms"])
     kern = KERNEL_OF_PHASE[dom]
     roof = {"bound": "hbm", "kernel": kern, "achieved": phases[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(phases[dom]["GBps"] / HBM_PEAK_GBS, 4),
+            "frac_definition": "SURVEY.md 8(d) words of the phase (E = 10, B = 12) x 8 B x computed cells / HIP-event launch time / 8 TB/s",
             "traffic": pmc_traffic(args.workload, kern) if world == 1 else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, profiles/r02_pmc_traffic.json",
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, profiles/r03_pmc_traffic.json (r02 if absent)",
             "alg_bytes_per_launch": phases[dom]["alg_GB"] * 1e9, "avg_launch_ms": phases[dom]["ms"], "phases": phases}
-    if cfg.hmix_momentum == 4 and dom == "momentum_rhs":
-        # del4: the kernel also reads the two first-Laplacian fields (D2U, D2V), which SURVEY's phase E (written for del2,
-        # where the mix-time fields are the old fields it reads anyway) does not count: 12 words instead of 10.  Reported
-        # beside `frac`, never instead of it.
-        gb12 = 12 * 8.0 * ncell_phys / 1e9
-        roof["frac_with_del4_inputs"] = round(gb12 / (phases[dom]["ms"] * 1e-3) / HBM_PEAK_GBS, 4)
-        if fused_u:
-            # large grids: the same launch also WRITES the next step's first Laplacian of the velocity (the output of k_del4_d2u, which
-            # is then not launched).  `frac` counts SURVEY's phase E (10 words) + the two written words of SURVEY's del4 row = 12; with
-            # the two del4 input fields 14 words move through the launch.  avg_launch_ms is this launch.
-            roof["also_writes"] = "D2U, D2V of the next step (k_del4_d2u's output; that kernel is not launched on leapfrog steps)"
-            roof["frac_phase_E_words_only"] = round(10 * 8.0 * ncell_phys / 1e9 / (phases[dom]["ms"] * 1e-3) / HBM_PEAK_GBS, 4)
-            roof["frac_with_del4_inputs"] = round(14 * 8.0 * ncell_phys / 1e9 / (phases[dom]["ms"] * 1e-3) / HBM_PEAK_GBS, 4)
-    # both baroclinic stencil kernels together (tracer + momentum right-hand sides): algorithmic bytes / summed time
+    if dom in extra_words:
+        w = phases[dom]["alg_words"] + extra_words[dom]
+        roof["frac_all_words_moved"] = round(w * 8.0 * ncell_phys / 1e9 / (phases[dom]["ms"] * 1e-3) / HBM_PEAK_GBS, 4)
+        roof["all_words_moved"] = w
+    # both baroclinic stencil kernels together (tracer + momentum right-hand sides): 8(d) bytes / summed time
     pair_gb = phases["tracer_rhs"]["alg_GB"] + phases["momentum_rhs"]["alg_GB"]
     pair_ms = phases["tracer_rhs"]["ms"] + phases["momentum_rhs"]["ms"]
     roof["baroclinic_stencils"] = {"kernels": [KERNEL_OF_PHASE["tracer_rhs"], KERNEL_OF_PHASE["momentum_rhs"]],
                                    "achieved": round(pair_gb / (pair_ms * 1e-3), 1), "frac": round(pair_gb / (pair_ms * 1e-3) / HBM_PEAK_GBS, 4)}
     step_words = sum(v[vm] for k, v in PHASE_WORDS.items() if k in phases)
     roof["step_alg_GBps"] = round(step_words * 8.0 * ncell_phys * world / 1e9 / (elapsed / args.steps), 1)
+    # the barotropic solver ("iterations x per-iteration time separately"; 14 words = 112 B per 2-D point per iteration)
+    if solver_calls > 0 and solver_iters > 0:
+        pts = int(round(cfg.nx_global * cfg.ny_global // world * (1.0 - land_frac)))
+        us_it = 1e3 * solver_ms / solver_iters
+        sol = {"solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "iterations_per_step": round(solver_iters / solver_calls, 2),
+               "ms_per_step": round(solver_ms / solver_calls, 4), "us_per_iteration": round(us_it, 2),
+               "timing": "HIP events around POP_SolversRun on the launch stream inside the timed steps (start-up, checks and the final halo included)",
+               "alg_bytes_per_iteration": 112 * pts, "active_points": pts,
+               "achieved": round(112 * pts / 1e9 / (us_it * 1e-6), 1), "unit": "GB/s",
+               "frac": round(112 * pts / 1e9 / (us_it * 1e-6) / HBM_PEAK_GBS, 4), "share_of_step": round(solver_ms / solver_calls / ms_step, 4)}
+        try:
+            sol["k_block_sums_us_isolated"] = round(1e3 * model.time_phase("block_sums", reps=50), 2)
+            sol["k_block_sums_launches_per_iteration"] = 2 if cfg.solver_choice == 1 else (1 if cfg.solver_choice == 2 else 0)
+        except pkg.PopError:
+            pass
+        roof["solver"] = sol
 
+    tun = {k: v for k, v in model.tuning().items() if v is not None and k != "struct_bytes"}
     out = {
         "metric": "simulated_years_per_day", "value": round(sypd, 3), "unit": "SYPD",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
@@ -390,10 +511,28 @@ def main():
                    "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport,
                    # every output of the step is bitwise what the full evaluation gives (tests/test_gpu_parity.py); DESIGN.md 3, "KPP's surface-layer buoyancy difference on demand"
-                   "kpp_surface_buoyancy": ("on-demand down to the boundary-layer depth" if vm == 2 and os.environ.get("POP_KPP_LAZY", "1") != "0"
-                                            and not cfg.lcheckekmo and cfg.kpp_ml_diagnostics != 1 else "every level")},
+                   "kpp_surface_buoyancy": ("on-demand down to the boundary-layer depth" if vm == 2 and tun.get("kpp_lazy", 1) != 0
+                                            and not cfg.lcheckekmo and cfg.kpp_ml_diagnostics != 1 else "every level"),
+                   "tuning_overrides": tun},
         "roofline": roof,
     }
+    if hblt_levels is not None:
+        out["config"]["hblt_level_p50"], out["config"]["hblt_level_p90"], out["config"]["hblt_level_max"] = hblt_levels
+        out["config"]["hblt_note"] = "STF = 0 (SURVEY 8d) keeps the KPP boundary layer at its minimum: the best case for the on-demand KPP forms; see kpp_deep_state"
+    if world > 1:
+        out["multi_gpu"] = {"transport": transport, "transport_note": transport_note, "launcher": "self (child torch.distributed.run)" if os.environ.get("POP_BENCH_SELF_LAUNCHED") else "external",
+                            "ranks": world, "ncclCommCount": [ci["ncclCommCount"] for ci in cinfo],
+                            "ncclCommCount_second_communicator": [ci["ncclCommCount_second_communicator"] for ci in cinfo],
+                            "librccl": cinfo[0]["librccl"], "halo_neighbour_ranks": [ci["halo_neighbour_ranks"] for ci in cinfo],
+                            "midstep_halo_overlap": [ci["midstep_halo_overlap"] for ci in cinfo],
+                            "ocean_columns_per_rank": ocean_cols, "rank_ms_per_step": [round(x, 3) for x in rank_ms],
+                            "rank_ms_max_over_min": round(max(rank_ms) / max(min(rank_ms), 1e-9), 3),
+                            "devices_visible": torch.cuda.device_count()}
+    if world == 1 and rank == 0 and vm == 2 and not args.no_deep_state and args.workload == "tx0.1v3":
+        try:
+            out["kpp_deep_state"] = kpp_deep_state(pkg, model, cfg, torch)
+        except Exception as e:  # noqa: BLE001  (a second measurement must never lose the headline line)
+            out["kpp_deep_state"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         try:
             dt, n, scfg, scale, cores = cpu_baseline(cfg)

@@ -303,6 +303,11 @@ int pop_set_reduce_buffer(pop_ctx *ctx, void *dev_redbuf, long long doubles);
  * context's stream with no host round trip.  librccl is opened at run time. */
 int pop_rccl_unique_id(unsigned char *id128);
 int pop_comm_init_rccl(pop_ctx *ctx, const unsigned char *id128);
+/* what the installed transport is, for a run's record: out6 = {kind (0 none, 1 host callbacks of pop_set_comm, 2 in-library RCCL),
+ * ncclCommCount of the first communicator, its ncclCommUserRank, ncclCommCount of the second communicator (0: none),
+ * number of neighbour ranks in the halo plan, 1 if the mid-step halo runs beside interior tiles}; -1 where RCCL does not say.
+ * lib_path (may be NULL) receives the name of the librccl that was bound. */
+int pop_comm_info(const pop_ctx *ctx, int *out6, char *lib_path, int lib_path_bytes);
 /* checks the installed transport (either kind): an all-reduce of known values + a self message */
 int pop_comm_selftest(pop_ctx *ctx);
 /* halo plan introspection (host logic, testable without a GPU) */

@@ -79,7 +79,7 @@ def lib():
         "pop_comm_buffer_doubles": (ll, [vp]), "pop_set_stream": (ci, [vp, vp]),
         "pop_reduce_buffer_doubles": (ll, [vp]), "pop_set_reduce_buffer": (ci, [vp, vp, ll]),
         "pop_rccl_unique_id": (ci, [C.c_char_p]), "pop_comm_init_rccl": (ci, [vp, C.c_char_p]),
-        "pop_comm_selftest": (ci, [vp]),
+        "pop_comm_selftest": (ci, [vp]), "pop_comm_info": (ci, [vp, pi, C.c_char_p, ci]),
         "pop_halo_plan_counts": (ci, [vp, pi, pi, pi]), "pop_halo_plan_peer": (ci, [vp, ci, pi, pi, pi]),
         "pop_halo_plan_lists": (ci, [vp, ci, pi, pi]), "pop_halo_plan_local": (ci, [vp, pi, pi, pi]),
         "pop_timers_reset": (ci, [vp]), "pop_timer_ms": (ci, [vp, cs, pd, pi]),
@@ -438,6 +438,14 @@ class PopModel:
 
     def comm_selftest(self):
         self._chk(self.L.pop_comm_selftest(self.h))
+
+    def comm_info(self):
+        """what the installed transport is (pop_comm_info), as a dict for a run's record"""
+        out, path = (C.c_int * 6)(), C.create_string_buffer(256)
+        self._chk(self.L.pop_comm_info(self.h, out, path, 256))
+        return {"kind": ["none", "host-callbacks", "rccl-native"][out[0]], "ncclCommCount": out[1], "ncclCommUserRank": out[2],
+                "ncclCommCount_second_communicator": out[3], "halo_neighbour_ranks": out[4], "midstep_halo_overlap": bool(out[5]),
+                "librccl": path.value.decode()}
 
     def halo_plan(self):
         nl, nf, npeer = C.c_int(), C.c_int(), C.c_int()

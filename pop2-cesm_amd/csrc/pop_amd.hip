@@ -142,6 +142,10 @@ struct pop_ctx {
   int first_step = 1, leapfrogts = 1, f_euler_ts = 0, avg_ts = 0, nsteps_total = 0, nsteps_this_interval = 0;
   double c2dtt = 0, c2dtu = 0, c2dtp = 0, beta = 0;
   std::map<std::string, PhaseTimer> timers;
+  // the barotropic solve bracketed by two events on the launch stream, read back one step later (no synchronisation inside the
+  // step): totals since the last pop_timers_reset / "solver_ms_reset" for the bench's per-iteration figure
+  hipEvent_t ev_solve[2] = {nullptr, nullptr}; bool solve_pending = false; int solve_iters_pending = 0;
+  double solver_ms_total = 0.0; long long solver_iters_total = 0, solver_calls_total = 0;
   bool timing = false;
   bool phase_timing = false;   // inside pop_time_phase: kernels only
 };
@@ -1134,6 +1138,15 @@ int solver_pcsi_fused_dist(pop_ctx *c) {
   return 0;
 }
 
+// elapsed time of the last bracketed solve into the totals (waits for its closing event: at the next solve that is long past)
+void solve_collect(pop_ctx *c) {
+  if (!c->solve_pending) return;
+  c->solve_pending = false;
+  float ms = 0;
+  if (hipEventSynchronize(c->ev_solve[1]) == hipSuccess && hipEventElapsedTime(&ms, c->ev_solve[0], c->ev_solve[1]) == hipSuccess) {
+    c->solver_ms_total += ms; c->solver_iters_total += c->solve_iters_pending; c->solver_calls_total += 1;
+  }
+}
 int need_device(pop_ctx *c) {
   if (!c) return 1;
   if (c->host_only) { c->err = "context was created host-only: no GPU path available (there is no CPU fallback)"; return 1; }
@@ -1740,6 +1753,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
 }
 
 int pop_destroy(pop_ctx *c) {
+  if (c) for (hipEvent_t &e : c->ev_solve) if (e) { hipEventDestroy(e); e = nullptr; }
   if (!c) return 0;
   for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
   for (auto &g : c->pcsi_graphs) hipGraphExecDestroy(g.second);
@@ -1823,6 +1837,11 @@ double pop_get_scalar(const pop_ctx *c, const char *name) {
   if (n == "bgtarea_t_1") return c->h.bgtarea_t_1;
   if (n == "rf_S1") return c->rf_S[0];
   if (n == "rf_S2") return c->rf_S[1];
+  // HIP-event time of the barotropic solves (POP_SolversRun) since "solver_ms_reset", the iterations they took and their number
+  if (n == "solver_ms_total") { solve_collect(const_cast<pop_ctx *>(c)); return c->solver_ms_total; }
+  if (n == "solver_iterations_total") { solve_collect(const_cast<pop_ctx *>(c)); return (double)c->solver_iters_total; }
+  if (n == "solver_calls_total") { solve_collect(const_cast<pop_ctx *>(c)); return (double)c->solver_calls_total; }
+  if (n == "solver_ms_reset") { pop_ctx *m = const_cast<pop_ctx *>(c); solve_collect(m); m->solver_ms_total = 0; m->solver_iters_total = 0; m->solver_calls_total = 0; return 0.0; }
   return NAN;
 }
 int pop_get_block(const pop_ctx *c, int block_id, int *out8, int *i_glob, int *j_glob) {
@@ -1904,6 +1923,14 @@ int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *hos
   return 0;
 }
 int pop_get_ifield(pop_ctx *c, const char *name, int *host, long long count) {
+  if (!strcmp(name, "KBL")) {   // KPP: level of the boundary-layer depth that belongs to the current KPP_SRC (device-resident)
+    if (need_device(c) || join_side(c)) return 1;
+    if (!c->KBL) { c->err = "KBL exists with vmix_choice = 3 only"; return 1; }
+    if (count != (long long)c->g.n2 * c->g.nblocks) { c->err = "count mismatch"; return 1; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host, c->KBL, (size_t)count * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+  }
   auto it = c->h.i2.find(name);
   if (it == c->h.i2.end()) { c->err = std::string("unknown integer field ") + name; return 1; }
   auto loc = local_part(c->h, it->second);
@@ -2452,8 +2479,13 @@ static int barotropic_driver(pop_ctx *c, bool update_zx_zy) {
   hipLaunchKernelGGL(k_btrop_rhs1, G, B, 0, c->stream, c->g, sp, a);
   hipLaunchKernelGGL(k_btrop_rhs2, G, B, 0, c->stream, c->g, sp, a);
   if (halo_update(c, c->RHS, 1)) return 1;
+  solve_collect(c);
+  if (!c->ev_solve[0]) { HIPCHK(c, hipEventCreate(&c->ev_solve[0])); HIPCHK(c, hipEventCreate(&c->ev_solve[1])); }
+  HIPCHK(c, hipEventRecord(c->ev_solve[0], c->stream));
   const int e = pop_solver_run(c);
   if (e) return e;
+  HIPCHK(c, hipEventRecord(c->ev_solve[1], c->stream));
+  c->solve_pending = true; c->solve_iters_pending = c->numIterations;
   hipLaunchKernelGGL(k_dot_partial, grid_2d(c), dim3(POP_RED_THREADS), 0, c->stream, c->g, c->PS[c->newt], c->g.CHECKER, (const double *)nullptr, c->partial);
   if (reduce_finish<1>(c, FIN_XCHECK)) return 1;
   hipLaunchKernelGGL(k_btrop_fin1, G, B, 0, c->stream, c->g, a);
@@ -2910,6 +2942,21 @@ int pop_comm_init_rccl(pop_ctx *c, const unsigned char *id128) {
   }
   return 0;
 }
+int pop_comm_info(const pop_ctx *c, int *out6, char *lib_path, int lib_path_bytes) {
+  if (!c || !out6) return 1;
+  for (int i = 0; i < 6; ++i) out6[i] = 0;
+  if (lib_path && lib_path_bytes > 0) lib_path[0] = 0;
+  out6[4] = (int)c->peers.size();
+  out6[5] = halo_async_ok(c) ? 1 : 0;
+  if (c->rccl_tr) {
+    out6[0] = 2; out6[1] = out6[2] = -1; out6[3] = c->rccl_tr->comm2 ? -1 : 0;
+    RcclApi &a = rccl();
+    if (a.CommCount) { a.CommCount(c->rccl_tr->comm, &out6[1]); if (c->rccl_tr->comm2) a.CommCount(c->rccl_tr->comm2, &out6[3]); }
+    if (a.CommUserRank) a.CommUserRank(c->rccl_tr->comm, &out6[2]);
+    if (lib_path && lib_path_bytes > 0) snprintf(lib_path, (size_t)lib_path_bytes, "%s", a.path.c_str());
+  } else if (c->xchg) out6[0] = 1;
+  return 0;
+}
 // transport self-test (also the single-rank check of the RCCL binding): every rank contributes
 // rank+1 in slot `rank` of the reduce buffer and passes one value round the ring of ranks
 int pop_comm_selftest(pop_ctx *c) {
@@ -3034,6 +3081,9 @@ static phase_fn_t phase_by_name(const std::string &p) {
   if (p == "add_btrop") return [](pop_ctx *x) { return phase_add_btrop(x); };
   if (p == "hmix_tracer") return [](pop_ctx *x) { return phase_hmix_tracer(x); };
   if (p == "hmix_momentum") return [](pop_ctx *x) { return phase_hmix_momentum(x); };
+  // the ordered block sums between the two kernels of a fused pcg iteration (k_block_sums<1>, one workgroup per block), as the
+  // solver launches it: timing only (the partial array holds whatever the last solve left)
+  if (p == "block_sums") return [](pop_ctx *x) { SolveView v = local_view(x); presum(x, v, v.partial, v.blocksum + 2 * v.nblocks_tot); return 0; };
   return nullptr;
 }
 // one phase of baroclinic_driver / baroclinic_correct_adjust on its own, once, on the launch stream with the step

@@ -23,6 +23,8 @@ struct RcclApi {
   int (*GetUniqueId)(UniqueId *) = nullptr;
   int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(Comm) = nullptr;
+  int (*CommCount)(const Comm, int *) = nullptr;       // optional (evidence for the bench line: how many ranks the communicator spans)
+  int (*CommUserRank)(const Comm, int *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
   int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
   int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
@@ -30,6 +32,7 @@ struct RcclApi {
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   void *handle = nullptr;
+  std::string path;                                      // what dlopen bound
   static constexpr int kDouble = 8, kSum = 0;
 
   int load(std::string &err) {
@@ -40,9 +43,10 @@ struct RcclApi {
     if (over && *over) {
       handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
       if (!handle) { err = std::string("rccl transport: cannot open POP_RCCL_LIB=") + over + ": " + dlerror(); return 1; }
+      path = over;
     } else {
       const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-      for (const char *n : names) { handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (handle) break; }
+      for (const char *n : names) { handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (handle) { path = n; break; } }
       if (!handle) { err = std::string("rccl transport: cannot open librccl: ") + dlerror(); return 1; }
     }
     auto sym = [&](const char *n) { void *p = dlsym(handle, n); if (!p) err = std::string("rccl transport: missing symbol ") + n; return p; };
@@ -55,6 +59,8 @@ struct RcclApi {
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    CommCount = (decltype(CommCount))dlsym(handle, "ncclCommCount");
+    CommUserRank = (decltype(CommUserRank))dlsym(handle, "ncclCommUserRank");
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !Send || !Recv || !GroupStart || !GroupEnd) return 1;
     return 0;
   }

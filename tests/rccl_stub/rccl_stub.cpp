@@ -162,6 +162,17 @@ int ncclCommInitRank(void **comm, int nranks, ncclUniqueId id, int rank) {
   return barrier(c);     // communicator creation is collective
 }
 
+int ncclCommCount(const void *comm, int *count) {
+  if (!comm || !count) return kInvalidArgument;
+  *count = ((const Comm *)comm)->nranks;
+  return kOk;
+}
+int ncclCommUserRank(const void *comm, int *rank) {
+  if (!comm || !rank) return kInvalidArgument;
+  *rank = ((const Comm *)comm)->rank;
+  return kOk;
+}
+
 int ncclCommDestroy(void *comm) {
   Comm *c = (Comm *)comm;
   if (!c) return kOk;

@@ -184,3 +184,29 @@ def test_land_elimination_with_overlapped_halo(nranks, kw, env):
     (windows classify their tiles one by one, the whole launch uses the compacted list)"""
     _run_check(["--nproc-per-node", str(nranks), os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tiny", "--steps", "3",
                 "--kw", kw], 300, env, transport="native")
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_bench_starts_its_own_ranks(nranks):
+    """`python bench.py --gpus N` with NO launcher around it (the shape of the driver's N = 1 command): bench.py starts the N ranks
+    itself as a child process before touching the GPU and relays the one JSON line.  Rehearsed on the one GPU through the stand-in
+    librccl (torch's own group is gloo, the library binds the stub): the line must carry the evidence that the library's RCCL
+    transport spanned N ranks on both communicators."""
+    import json
+    if not os.path.exists(STUB):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(STUB)])
+    env = dict(os.environ, POP_BENCH_BACKEND="gloo", POP_RCCL_LIB=STUB)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "2", "--warmup", "1", "--workload", "gx1v7"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == nranks and rec["value"] > 0 and rec["config"]["workload"] == "gx1v7"
+    mg = rec["multi_gpu"]
+    assert mg["transport"] == "rccl-native" and mg["launcher"].startswith("self")
+    assert mg["ncclCommCount"] == [nranks] * nranks and mg["ncclCommCount_second_communicator"] == [nranks] * nranks
+    assert len(mg["ocean_columns_per_rank"]) == nranks and len(mg["rank_ms_per_step"]) == nranks
+    assert rec["roofline"]["phases"]["momentum_rhs"]["alg_words"] == 10 and rec["roofline"]["phases"]["tracer_rhs"]["alg_words"] == 12

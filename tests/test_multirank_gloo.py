@@ -142,3 +142,19 @@ def test_balanced_distribution_equalises_ocean_columns(pkg):
         assert all(ids == list(range(ids[0], ids[0] + len(ids))) for ids in owned)      # contiguous runs
         loads[dist_kind] = max(ocean) / (sum(ocean) / nr)
     assert loads[1] < loads[0] and loads[1] < 1.2, loads
+
+
+def test_bench_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it must start the two ranks itself (a child process) and
+    relay their exit code.  On this GPU-less box every rank stops at "needs a GPU": seeing that message from the ranks -- and not
+    the old "launch with torch.distributed.run" refusal -- shows the launch happened."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_multirank.py::test_bench_starts_its_own_ranks")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert "bench.py needs a GPU" in out.stderr and "launch with torch.distributed.run" not in out.stderr, out.stderr[-2000:]
