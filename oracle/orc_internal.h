@@ -21,6 +21,9 @@ struct orc_model {
   double *DXUR, *DYUR, *DXTR, *DYTR, *UAREA, *TAREA, *UAREA_R, *TAREA_R;
   double *AU0, *AUN, *AUE, *AUNE, *FCOR, *FCORT, *HU, *HUR, *HT, *RCALCT, *RCALCU;
   int *KMT, *KMU, *KMTN, *KMTS, *KMTE, *KMTW, *KMTEE, *KMTNN;
+  /* partial bottom cells (grid.F90:916-1020): DZBC(nx,ny,blk) bottom T-cell thickness; DZT, DZU (nx,ny,0:km+1,blk), levels 0 and
+   * km+1 stay 0 as in the reference; NULL without partial_bottom_cells */
+  double *DZBC, *DZT, *DZU;
   double uarea_equator;
   /* hmix */
   double *AMF, *AHF, *DTN, *DTS, *DTE, *DTW;

@@ -530,7 +530,56 @@ static void horiz_grid(orc_model *m) {
       for (int i = ib; i <= ie; i++) TLAT[P2(i, jb)] = 2.0 * TLAT[P2(i, jb + 1)] - TLAT[P2(i, jb + 2)];
   }
   orc_halo(m, m->TLAT, 1, ORC_CENTER, ORC_SCALAR);
+  /* partial bottom cells: read_bottom_cell (grid.F90:2116-2186) = the caller's record scattered as a centre scalar.  Without a
+   * record (the reference always reads a file): a synthetic thickness in (0.25, 1] dz(KMT) -- TEST EXTENSION, same integer rule
+   * as the library (host_setup.cpp) */
+  if (c->partial_bottom_cells) {
+    double *DZBC_G = dalloc((size_t)nxg * nyg);
+    for (int j = 1; j <= nyg; j++)
+      for (int i = 1; i <= nxg; i++) {
+        size_t p = (size_t)(j - 1) * nxg + i - 1;
+        if (gin && gin->DZBC) DZBC_G[p] = gin->DZBC[p];
+        else DZBC_G[p] = KMT_G[p] > 0 ? (0.25 + 0.75 * (double)((i * 7 + j * 13) % 16 + 1) / 16.0) * m->dz[KMT_G[p]] : 0.0;
+      }
+    m->DZBC = dalloc(m->n2 * m->nblocks);
+    scatter_global_r8(m, m->DZBC, DZBC_G, ORC_CENTER);
+    free(DZBC_G);
+  }
   free(ULAT_G); free(ULON_G); free(KMT_G);
+
+  /* DZT, DZU (grid.F90:926-965) */
+  if (c->partial_bottom_cells) {
+    const int km = m->km;
+    const size_t n2 = m->n2;
+    m->DZT = dalloc((size_t)(km + 2) * n2 * m->nblocks);
+    m->DZU = dalloc((size_t)(km + 2) * n2 * m->nblocks);
+    for (int b = 0; b < m->nblocks; b++) {
+      const int *KMT = m->KMT + (size_t)b * n2;
+      const double *DZBC = m->DZBC + (size_t)b * n2;
+      double *DZT = m->DZT + (size_t)b * (km + 2) * n2, *DZU = m->DZU + (size_t)b * (km + 2) * n2;
+      for (int k = 1; k <= km; k++) {
+        for (int j = 1; j <= nyb; j++) for (int i = 1; i <= nxb; i++) {
+          size_t p = (size_t)(j - 1) * nxb + i - 1;
+          DZT[(size_t)k * n2 + p] = (KMT[p] == k) ? DZBC[p] : m->dz[k];
+        }
+        for (int j = 1; j <= nyb - 1; j++) for (int i = 1; i <= nxb - 1; i++) {
+          size_t p = (size_t)(j - 1) * nxb + i - 1;
+          const double *D = DZT + (size_t)k * n2;
+          double v = D[p];
+          if (D[p + 1] < v) v = D[p + 1];
+          if (D[p + nxb] < v) v = D[p + nxb];
+          if (D[p + nxb + 1] < v) v = D[p + nxb + 1];
+          DZU[(size_t)k * n2 + p] = v;
+        }
+      }
+    }
+    /* POP_HaloUpdate(DZU, ..., NECorner, scalar, fillValue = 0): all km+2 levels of every block (levels 0, km+1 are 0) */
+    for (int b = 0; b < m->nblocks; b++) (void)b;
+    {
+      /* the halo routine works on (nx,ny,nz,blk) arrays with nz levels contiguous per block */
+      orc_halo(m, m->DZU, km + 2, ORC_NECORNER, ORC_SCALAR);
+    }
+  }
 
   /* flat bottom: where (KMT /= 0) KMT = km (grid.F90:880-884) -- already km */
   /* KMU grid.F90:978-995 */
@@ -547,7 +596,18 @@ static void horiz_grid(orc_model *m) {
   for (int b = 0; b < m->nblocks; b++) {
     size_t o = (size_t)b * m->n2;
     int *KMT = m->KMT + o, *KMU = m->KMU + o;
-    /* HT, HU, HUR grid.F90:1024-1043 */
+    /* HT, HU, HUR grid.F90:1024-1043; with partial bottom cells :1001-1020 */
+    if (c->partial_bottom_cells) {
+      const size_t n2 = m->n2;
+      const double *DZT = m->DZT + (size_t)b * (m->km + 2) * n2;
+      double *DZU = m->DZU + (size_t)b * (m->km + 2) * n2;
+      for (int k = 1; k <= m->km; k++)
+        for (size_t p = 0; p < n2; p++) {
+          if (k == KMT[p]) m->HT[o + p] = m->zw[k - 1] + DZT[(size_t)k * n2 + p];
+          if (k == KMU[p]) { m->HU[o + p] = m->zw[k - 1] + DZU[(size_t)k * n2 + p]; m->HUR[o + p] = 1.0 / m->HU[o + p]; }
+          else if (k > KMU[p]) DZU[(size_t)k * n2 + p] = m->dz[k];   /* to prevent divide by zero */
+        }
+    } else
     for (int k = 1; k <= m->km; k++)
       for (size_t p = 0; p < m->n2; p++) {
         if (k == KMT[p]) m->HT[o + p] = m->zw[k];

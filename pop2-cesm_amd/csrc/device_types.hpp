@@ -5,6 +5,23 @@
 
 namespace pop {
 
+// Init-time constant arrays that kernels index with WAVE-UNIFORM indices (the level k of a column march): dz(k), dzr(k), afac_t(k),
+// zgrid(k) ...  Read through a plain `const double *` inside a kernel that also stores to global memory, the compiler cannot prove
+// the array is not clobbered, emits a VECTOR load with a uniform address and -- the load sitting in the middle of the level's
+// arithmetic -- an `s_waitcnt vmcnt(0)` behind it, which also drains every prefetch load in flight (seen in the ISA of the
+// LDS-tiled stencil kernels: three such round trips per level).  Loads through the constant address space are selected as scalar
+// (SMEM) loads into SGPRs: no VGPRs, no vmcnt.  Same bytes, same values; the arrays are written once at pop_create.
+// A divergent index still works (the load is then an ordinary vector load).
+template <class T>
+struct ConstArr {
+  const T *p = nullptr;
+  __device__ __forceinline__ T operator[](int k) const { return ((const __attribute__((address_space(4))) T *)p)[k]; }
+  __host__ __device__ ConstArr &operator=(const T *q) { p = q; return *this; }
+  __host__ __device__ operator const T *() const { return p; }
+};
+using CArr = ConstArr<double>;
+using CArrI = ConstArr<int>;
+
 // Time-invariant data resident in HBM.  2-D fields are (nxb,nyb,nblocks) i-fastest; vertical
 // arrays are 1-based with slot 0 (index k is wave-uniform, so they are read by scalar loads).
 struct DevGrid {
@@ -15,11 +32,16 @@ struct DevGrid {
   int lds_order;                                   // LDS-tiled stencil kernels: 1 = XCD patch order (kernels_common.hpp lds_tile)
   int n2;                                          // nxb*nyb
   long long n3;                                    // n2*km
-  const double *dz, *dzw, *zt, *zw, *c2dz, *dzr, *dz2r, *dzwr, *pressz, *bouss, *afac_t, *afac_u;
+  CArr dz, dzw, zt, zw, c2dz, dzr, dz2r, dzwr, pressz, bouss, afac_t, afac_u;   // vertical arrays: scalar loads (ConstArr)
   const double *DXU, *DYU, *DXUR, *DYUR, *UAREA_R, *TAREA_R, *TAREA, *FCOR, *FCORT, *HU, *HUR;
   const double *AU0, *AUN, *AUE, *AUNE, *RCALCT;
   const int *KMT, *KMU, *KMTN, *KMTS, *KMTE, *KMTW, *KMTEE, *KMTNN;
   const double *DTN, *DTS, *DTE, *DTW;
+  // partial bottom cells (grid.F90:916-1020): thickness of the bottom T cell (DZBC) and of the bottom U cell (DZUB = DZU at level
+  // KMU) of every column; every other level has dz(k).  pbc = 0: both null
+  const double *DZBC, *DZUB;
+  int pbc;
+  double *dump;                                    // scratch words that inactive lanes of branch-free kernels store to
   const double *DUC, *DUN, *DUS, *DUE, *DUW, *DMC, *DMN, *DMS, *DME, *DMW, *DUM, *KXU, *KYU;
   const double *WNE, *WEa, *WNo, *WC0, *mMask, *CHECKER, *CONSTNT;
   const double *SMF1, *SMF2, *SMFT1, *SMFT2;
@@ -45,7 +67,7 @@ struct DevGrid {
 struct StepParams {
   double c2dtu, c2dtp, beta, gamma, dtp, grav;
   double am, ah, bottom_drag, const_vvc, const_vdc, convect_diff, convect_visc;
-  double rich_bckgrnd_vvc, rich_bckgrnd_vdc, rich_mix;
+  double rich_bckgrnd_vvc, rich_bckgrnd_vdc, rich_mix, aidif;
   int leapfrogts, pavg, impcor, reset_to_freezing, nvdc;
 };
 

@@ -428,14 +428,54 @@ int host_build(HostModel &h) {
       KMU[idx(b, i, j)] = m;
     }
   host_halo_i4_loc(h, KMU.data(), 1, 0, 1, 0);                     // NE corner, scalar (grid.F90:987)
+  // ---------------- partial bottom cells (grid.F90:916-1020) ----------------
+  // DZT(i,j,k) = DZBC(i,j) where k = KMT(i,j), dz(k) elsewhere; DZU = min of the four surrounding DZT, halo-updated (NE corner,
+  // fill 0), dz(k) below the bottom.  Below KMU = min(KMT) every surrounding DZT is dz(k), so DZU differs from dz(k) at level KMU
+  // only: the device keeps the two 2-D fields DZBC and DZUB = DZU(:,:,KMU) and forms DZT / DZU where it needs them
+  // (levels 0 and km+1 are 0 as in the reference's arrays).
+  if (c.partial_bottom_cells) {
+    auto &DZBC = newf("DZBC"), &DZUB = newf("DZUB");
+    for (int b = 0; b < NB; ++b) {
+      const BlockInfo &B = h.all_blocks[b];
+      for (int j = 0; j < nyb; ++j) for (int i = 0; i < nxb; ++i) {
+        // read_bottom_cell :2116-2186: scatter_global as a centre scalar (ghosts beyond a tripole fold read the mirrored address)
+        const int ig = B.i_glob[i], jg = B.j_glob[j];
+        int is = ig, js = jg;
+        if (ig == 0 || jg == 0) continue;
+        if (jg < 0) { js = nyg + 1 + (jg + nyg); is = nxg + 1 - ig; if (is < 1) is += nxg; if (is > nxg) is -= nxg; }
+        const size_t p = idx(b, i, j);
+        if (gin && gin->DZBC) DZBC[p] = gin->DZBC[(size_t)(js - 1) * nxg + (is - 1)];
+        else if (KMT[p] > 0)   // no record: synthetic thickness in (0.25, 1] dz(KMT) (TEST EXTENSION; the oracle uses the same integer rule)
+          DZBC[p] = (0.25 + 0.75 * (double)((is * 7 + js * 13) % 16 + 1) / 16.0) * h.dz[KMT[p]];
+      }
+    }
+    for (int b = 0; b < NB; ++b)
+      for (int j = 0; j < nyb - 1; ++j) for (int i = 0; i < nxb - 1; ++i) {
+        const size_t q[4] = {idx(b, i, j), idx(b, i + 1, j), idx(b, i, j + 1), idx(b, i + 1, j + 1)};
+        int kmu = KMT[q[0]];
+        for (int t = 1; t < 4; ++t) kmu = std::min(kmu, KMT[q[t]]);
+        if (kmu < 1) continue;
+        double v = (KMT[q[0]] == kmu) ? DZBC[q[0]] : h.dz[kmu];
+        for (int t = 1; t < 4; ++t) v = std::min(v, (KMT[q[t]] == kmu) ? DZBC[q[t]] : h.dz[kmu]);
+        DZUB[q[0]] = v;
+      }
+    host_halo_r8_loc(h, DZUB.data(), 1, 0.0, 1, 0);                 // NE corner, scalar, fillValue 0 (:958-960)
+    for (size_t p = 0; p < A2; ++p) if (KMU[p] < 1) DZUB[p] = 0.0;
+  }
   auto &HT = newf("HT"), &HU = newf("HU"), &HUR = newf("HUR"), &RCALCT = newf("RCALCT"), &RCALCU = newf("RCALCU");
   auto &FCOR = newf("FCOR"), &FCORT = newf("FCORT");
+  const std::vector<double> *pDZBC = c.partial_bottom_cells ? &h.f2["DZBC"] : nullptr, *pDZUB = c.partial_bottom_cells ? &h.f2["DZUB"] : nullptr;
   auto &KMTN = newi("KMTN"), &KMTS = newi("KMTS"), &KMTE = newi("KMTE"), &KMTW = newi("KMTW"), &KMTEE = newi("KMTEE"), &KMTNN = newi("KMTNN");
   for (int b = 0; b < NB; ++b)
     for (int j = 0; j < nyb; ++j) for (int i = 0; i < nxb; ++i) {
       const size_t p = idx(b, i, j);
+      if (c.partial_bottom_cells) {   // :1001-1020
+        if (KMT[p] >= 1) HT[p] = h.zw[KMT[p] - 1] + (*pDZBC)[p];
+        if (KMU[p] >= 1) { HU[p] = h.zw[KMU[p] - 1] + (*pDZUB)[p]; HUR[p] = 1.0 / HU[p]; }
+      } else {
       if (KMT[p] >= 1) HT[p] = h.zw[KMT[p]];
       if (KMU[p] >= 1) { HU[p] = h.zw[KMU[p]]; HUR[p] = 1.0 / h.zw[KMU[p]]; }
+      }
       RCALCT[p] = KMT[p] >= 1 ? 1.0 : 0.0;
       RCALCU[p] = KMU[p] >= 1 ? 1.0 : 0.0;
       KMTN[p] = S(KMT, b, i, j + 1); KMTS[p] = S(KMT, b, i, j - 1);

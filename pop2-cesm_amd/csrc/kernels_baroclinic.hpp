@@ -105,7 +105,8 @@ __device__ __forceinline__ double upw3_face(int k, double flux, int kA, int kB, 
 struct TracerRhsArgs;
 // the source of level k for a column with surface flux qsw = max(SHF_QSW, 0); trans_km1 carries the transmission to the top
 // of the level from level to level (chlorophyll: TRANSKM1)
-__device__ __forceinline__ double sw_source(const TracerRhsArgs &a, double qsw, int k, int kmt, double dzrk, int chli, double &trans_km1);
+// dzt_pbc > 0: partial bottom cells -- the ground term divides by the cell's own thickness (sw_absorption.F90:880-889, 913-921)
+__device__ __forceinline__ double sw_source(const TracerRhsArgs &a, double qsw, int k, int kmt, double dzrk, int chli, double &trans_km1, double dzt_pbc = 0.0);
 struct TracerRhsArgs {
   const double *TCUR[2], *TOLD[2], *TMIX[2];
   double *TNEW[2];
@@ -130,7 +131,7 @@ struct TracerRhsArgs {
   // elimination coefficients and the reduced right-hand side of tracer n go to E[n], F[n] instead of the RHS to TNEW
   double *E[2], *F[2];
 };
-__device__ __forceinline__ double sw_source(const TracerRhsArgs &a, double qsw, int k, int kmt, double dzrk, int chli, double &trans_km1) {
+__device__ __forceinline__ double sw_source(const TracerRhsArgs &a, double qsw, int k, int kmt, double dzrk, int chli, double &trans_km1, double dzt_pbc) {
   double top, bot;
   if (a.sw_type == 2) {
     if (k == 1) trans_km1 = 1.0;
@@ -138,6 +139,7 @@ __device__ __forceinline__ double sw_source(const TracerRhsArgs &a, double qsw, 
     bot = a.swTr[(long long)chli * (a.sw_ksol + 1) + 2 * k];
     trans_km1 = bot;
   } else { top = a.swabs[k - 1]; bot = a.swabs[k]; }
+  if (dzt_pbc > 0.0) return (k < kmt) ? qsw * (top - bot) * dzrk : qsw * top / dzt_pbc;
   return (k < kmt) ? qsw * (top - bot) * dzrk : qsw * top * dzrk;
 }
 
@@ -145,7 +147,9 @@ __device__ __forceinline__ double sw_source(const TracerRhsArgs &a, double qsw, 
 // face value of the west neighbour and the north face value of the south neighbour are recomputed by
 // this thread (same operands, same order as the neighbour's own evaluation), the flux through the
 // top face (AUX) is carried in a register, and four tracer levels k-1..k+2 are kept in registers.
-template <bool DEL4, bool UPW3>
+// PBC: partial bottom cells (the branches of advection.F90:2040-2062, 2110, 2223-2294, 2380-2385, 2461-2465; hmix_del2.F90:1034-1051;
+// vertical_mix.F90:790-807; sw_absorption.F90:880-921) with DZT / DZU formed from DZBC / DZUB (pbc_dz)
+template <bool DEL4, bool UPW3, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS, POP_TRC_WAVES)
 k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
   Col c;
@@ -159,6 +163,14 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
   const double tarear = g.TAREA_R[c.q2];
   const double psfac = (a.PCUR[c.q2] - a.POLD[c.q2]);
   double wtk = a.DH[c.q2];
+  // partial bottom cells: bottom level / thickness of the four U cells around the T cell and of the T cell and its neighbours
+  int kmu00 = 0, kmu0m = 0, kmum0 = 0, kmumm = 0;
+  double dzub00 = 0, dzub0m = 0, dzubm0 = 0, dzubmm = 0, dzbc = 0, dzbcn = 0, dzbcs = 0, dzbce = 0, dzbcw = 0;
+  if (PBC) {
+    kmu00 = g.KMU[c.q2]; kmu0m = g.KMU[c.q2 - nxb]; kmum0 = g.KMU[c.q2 - 1]; kmumm = g.KMU[c.q2 - 1 - nxb];
+    dzub00 = g.DZUB[c.q2]; dzub0m = g.DZUB[c.q2 - nxb]; dzubm0 = g.DZUB[c.q2 - 1]; dzubmm = g.DZUB[c.q2 - 1 - nxb];
+    dzbc = g.DZBC[c.q2]; dzbcn = g.DZBC[c.q2 + nxb]; dzbcs = g.DZBC[c.q2 - nxb]; dzbce = g.DZBC[c.q2 + 1]; dzbcw = g.DZBC[c.q2 - 1];
+  }
   double vtf[2];
   double tc_km1[2] = {0.0, 0.0}, tc_k[2], tc_kp1[2], to_k[2], to_kp1[2];
 #pragma unroll
@@ -190,15 +202,31 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
     // face flux velocities
     const double u00 = a.UCUR[o], u0m = a.UCUR[o - nxb], um0 = a.UCUR[o - 1], umm = a.UCUR[o - 1 - nxb];
     const double v00 = a.VCUR[o], v0m = a.VCUR[o - nxb], vm0 = a.VCUR[o - 1], vmm = a.VCUR[o - 1 - nxb];
-    const double UTE = 0.5 * (u00 * dyu00 + u0m * dyu0m);
-    const double UTW = 0.5 * (um0 * dyum0 + umm * dyumm);
-    const double VTN = 0.5 * (v00 * dxu00 + vm0 * dxum0);
-    const double VTS = 0.5 * (v0m * dxu0m + vmm * dxumm);
+    double UTE = 0.5 * (u00 * dyu00 + u0m * dyu0m);
+    double UTW = 0.5 * (um0 * dyum0 + umm * dyumm);
+    double VTN = 0.5 * (v00 * dxu00 + vm0 * dxum0);
+    double VTS = 0.5 * (v0m * dxu0m + vmm * dxumm);
+    double dzt = 0.0, dzt_kp1 = 0.0;
+    if (PBC) {
+      const double z00 = pbc_dz(g, k, kmu00, dzub00), z0m = pbc_dz(g, k, kmu0m, dzub0m), zm0 = pbc_dz(g, k, kmum0, dzubm0), zmm = pbc_dz(g, k, kmumm, dzubmm);
+      UTE = 0.5 * (u00 * dyu00 * z00 + u0m * dyu0m * z0m);
+      UTW = 0.5 * (um0 * dyum0 * zm0 + umm * dyumm * zmm);
+      VTN = 0.5 * (v00 * dxu00 * z00 + vm0 * dxum0 * zm0);
+      VTS = 0.5 * (v0m * dxu0m * z0m + vmm * dxumm * zmm);
+      dzt = pbc_dz(g, k, kmt, dzbc); dzt_kp1 = pbc_dz(g, kp1, kmt, dzbc);
+    }
     const double hdiv = VTN - VTS + UTE - UTW;
     double wtkb = 0.0;
-    if (k < km) { const double FC = hdiv * tarear; wtkb = (k < kmt) ? wtk + g.dz[k] * FC : 0.0; }
-    const double CN = (k <= kmtn && k <= kmt) ? dtn : 0.0, CS = (k <= kmts && k <= kmt) ? dts : 0.0;
-    const double CE = (k <= kmte && k <= kmt) ? dte : 0.0, CW = (k <= kmtw && k <= kmt) ? dtw : 0.0;
+    if (k < km) { const double FC = hdiv * tarear; wtkb = (k < kmt) ? (PBC ? wtk + FC : wtk + g.dz[k] * FC) : 0.0; }
+    double CN = dtn, CS = dts, CE = dte, CW = dtw;
+    if (PBC) {
+      CN = dtn * fmin(dzt, pbc_dz(g, k, kmtn, dzbcn)) / dzt; CS = dts * fmin(dzt, pbc_dz(g, k, kmts, dzbcs)) / dzt;
+      CE = dte * fmin(dzt, pbc_dz(g, k, kmte, dzbce)) / dzt; CW = dtw * fmin(dzt, pbc_dz(g, k, kmtw, dzbcw)) / dzt;
+    }
+    if (!(k <= kmtn && k <= kmt)) CN = 0.0;
+    if (!(k <= kmts && k <= kmt)) CS = 0.0;
+    if (!(k <= kmte && k <= kmt)) CE = 0.0;
+    if (!(k <= kmtw && k <= kmt)) CW = 0.0;
     const double CC = -(CN + CS + CE + CW);
     const double dz2rk = g.dz2r[k], dzrk = g.dzr[k], dzwrk = g.dzwr[k];
 #pragma unroll
@@ -214,14 +242,15 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
       const double *TC = a.TCUR[n];
       double L;
       if (UPW3) {
-        const double FVN = VTN * tarear, FVS = -VTS * tarear, FUE = UTE * tarear, FUW = -UTW * tarear;
+        const double w1 = PBC ? tarear / dzt : tarear;   // WORK1 = TAREA_R / DZT (advection.F90:2380-2385)
+        const double FVN = VTN * w1, FVS = -VTS * w1, FUE = UTE * w1, FUW = -UTW * w1;
         const double xw2 = TC[o - 2], xw1 = TC[o - 1], xe1 = TC[o + 1], xe2 = TC[o + 2];
         const double xs2 = TC[o - 2 * (long long)nxb], xs1 = TC[o - nxb], xn1 = TC[o + nxb], xn2 = TC[o + 2 * (long long)nxb];
         const double te = upw3_face(k, FUE, kmte, kmtw, kmtee, wx0, xw1, tc_k[n], xe1, xe2);
-        const double tew = upw3_face(k, UTW * tarear_w, kEw, kWw, kEEw, wxw, xw2, xw1, tc_k[n], xe1);
+        const double tew = upw3_face(k, PBC ? UTW * (tarear_w / pbc_dz(g, k, kmtw, dzbcw)) : UTW * tarear_w, kEw, kWw, kEEw, wxw, xw2, xw1, tc_k[n], xe1);
         L = FUE * te + FUW * tew;
         const double tn = upw3_face(k, FVN, kmtn, kmts, kmtnn, wy0, xs1, tc_k[n], xn1, xn2);
-        const double tns = upw3_face(k, VTS * tarear_s, kNs, kSs, kNNs, wys, xs2, xs1, tc_k[n], xn1);
+        const double tns = upw3_face(k, PBC ? VTS * (tarear_s / pbc_dz(g, k, kmts, dzbcs)) : VTS * tarear_s, kNs, kSs, kNNs, wys, xs2, xs1, tc_k[n], xn1);
         L = L + FVN * tn + FVS * tns;
         // vertical: flux through the bottom face (:2397-2432)
         double azminus, dzminus;
@@ -235,25 +264,38 @@ k_tracer_rhs(DevGrid g, StepParams sp, TracerRhsArgs a) {
           auxb = (wtkb - fabs(wtkb)) * tplus + (wtkb + fabs(wtkb)) * tminus;
         }
         if (k == 1) L = L - dz2rk * auxb;
+        else if (PBC) L = L + 0.5 / dzt * (aux[n] - auxb);
         else L = L + dz2rk * (aux[n] - auxb);
         aux[n] = auxb;
       } else if (a.LTK[0]) {
         L = a.LTK[n][o];                                   // lw_lim advection (advection.F90:2684-3280), formed beforehand
       } else {
         L = 0.5 * (hdiv * tc_k[n] + VTN * TC[o + nxb] - VTS * TC[o - nxb] + UTE * TC[o + 1] - UTW * TC[o - 1]) * tarear;
+        if (PBC) {
+          L = L / dzt;
+          if (k != 1) L = L + 0.5 / dzt * wtk * (tc_km1[n] + tc_k[n]);
+          if (k < km) L = L - 0.5 / dzt * wtkb * (tc_k[n] + tc_kp1[n]);
+        } else {
         if (k != 1) L = L + dz2rk * wtk * (tc_km1[n] + tc_k[n]);
         if (k < km) L = L - dz2rk * wtkb * (tc_k[n] + tc_kp1[n]);
+        }
       }
       FT = FT - L;
       if (k == 1) vtf[n] = (kmt >= 1) ? a.STF[n][c.q2] : 0.0;
-      const double vtfb = (kmt > k) ? a.VDC[n][vdcbase + (long long)k * n2] * (to_k[n] - to_kp1[n]) * dzwrk : 0.0;
-      const double vd = (k <= kmt) ? (vtf[n] - vtfb) * dzrk : 0.0;
+      double vtfb, vd;
+      if (PBC) {
+        vtfb = (kmt > k) ? a.VDC[n][vdcbase + (long long)k * n2] * (to_k[n] - to_kp1[n]) / (0.5 * (dzt + dzt_kp1)) : 0.0;
+        vd = (k <= kmt) ? (vtf[n] - vtfb) / dzt : 0.0;
+      } else {
+        vtfb = (kmt > k) ? a.VDC[n][vdcbase + (long long)k * n2] * (to_k[n] - to_kp1[n]) * dzwrk : 0.0;
+        vd = (k <= kmt) ? (vtf[n] - vtfb) * dzrk : 0.0;
+      }
       vtf[n] = vtfb;
       FT = FT + vd;
       if (k == 1) FT = FT + g.dzr[1] * a.TFW[n][c.q2];
       double src = 0.0;
       if (a.use_kpp_src) src = src + a.KPP_SRC[n][o];
-      if (a.sw_on && n == 0) src = src + sw_source(a, sw_q, k, kmt, dzrk, sw_chli, sw_tkm1);
+      if (a.sw_on && n == 0) src = src + sw_source(a, sw_q, k, kmt, dzrk, sw_chli, sw_tkm1, PBC ? dzt : 0.0);
       FT = FT + src;
       if (k == 1 && sp.pavg) {
         if (kmt > 0) TNp[n][o] = a.c2dtt * FT - 2.0 * tc_k[n] * psfac / (sp.grav * g.dz[1]);
@@ -286,7 +328,8 @@ struct ImpvmixtArgs {
   int nfirst, nlast;                  // 1-based tracer range
 };
 
-template <int MODE, bool PRE, bool POST>
+// PBC: partial bottom cells (vertical_mix.F90:1279-1287, 1577-1585): from level 2 on the column's own thicknesses
+template <int MODE, bool PRE, bool POST, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_impvmixt(DevGrid g, StepParams sp, ImpvmixtArgs a) {
   Col c;
@@ -294,6 +337,7 @@ k_impvmixt(DevGrid g, StepParams sp, ImpvmixtArgs a) {
   const int km = g.km;
   const long long n2 = g.n2;
   const int kmt = g.KMT[c.q2];
+  const double dzbc = PBC ? g.DZBC[c.q2] : 0.0;
   const double hfac1 = g.dz[1] / a.c2dtt;
   const double H1 = hfac1 + a.PSFC[c.q2] / (sp.grav * a.c2dtt);
   const long long vdcbase = ((long long)c.b * (km + 2)) * n2 + c.p2;
@@ -324,8 +368,13 @@ k_impvmixt(DevGrid g, StepParams sp, ImpvmixtArgs a) {
     for (int k = 2; k <= km; ++k) {
       const long long o = c.base3 + (long long)(k - 1) * n2;
       const double C = A;
-      const double hf = g.dz[k] / a.c2dtt;
+      double hf = g.dz[k] / a.c2dtt;
       A = g.afac_t[k] * VDC[vdcbase + (long long)k * n2];
+      if (PBC) {
+        const double dzt = pbc_dz(g, k, kmt, dzbc);
+        A = sp.aidif * VDC[vdcbase + (long long)k * n2] / (0.5 * (dzt + pbc_dz(g, k + 1, kmt, dzbc)));
+        hf = dzt / a.c2dtt;
+      }
       const double tnk = (MODE == 1) ? 0.0 : TN[o];
       if (k > kmt) { Fk = 0.0; }
       else {
@@ -402,7 +451,9 @@ struct MomentumRhsArgs {
   const double *AMF = nullptr;
 };
 
-template <bool DEL4>
+// PBC: partial bottom cells (advection.F90:1245-1300, 1352, 1381-1467; hmix_del2.F90:852-886; vertical_mix.F90:946-995;
+// baroclinic.F90:1037-1039) with DZU formed from KMU / DZUB (pbc_dz)
+template <bool DEL4, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS, POP_MOM_WAVES)
 k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
   Col c;
@@ -411,12 +462,14 @@ k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
   const long long n2 = g.n2;
   const int kmu = g.KMU[c.q2];
   double dyu[3][3], dxu[3][3];
+  int kmu9[3][3] = {}; double dzub9[3][3] = {};   // PBC: bottom level / thickness of the nine U cells
 #pragma unroll
   for (int dj = -1; dj <= 1; ++dj)
 #pragma unroll
     for (int di = -1; di <= 1; ++di) {
       dyu[dj + 1][di + 1] = g.DYU[c.q2 + dj * nxb + di];
       dxu[dj + 1][di + 1] = g.DXU[c.q2 + dj * nxb + di];
+      if (PBC) { kmu9[dj + 1][di + 1] = g.KMU[c.q2 + dj * nxb + di]; dzub9[dj + 1][di + 1] = g.DZUB[c.q2 + dj * nxb + di]; }
     }
   const double uar = g.UAREA_R[c.q2], fcor = g.FCOR[c.q2], kxu = g.KXU[c.q2], kyu = g.KYU[c.q2];
   const double dxur = g.DXUR[c.q2], dyur = g.DYUR[c.q2], hur = g.HUR[c.q2];
@@ -446,7 +499,13 @@ k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
         u[dj + 1][di + 1] = uu; v[dj + 1][di + 1] = vv;
         ud[dj + 1][di + 1] = uu * dyu[dj + 1][di + 1];
         vd[dj + 1][di + 1] = vv * dxu[dj + 1][di + 1];
+        if (PBC) {
+          const double z = pbc_dz(g, k, kmu9[dj + 1][di + 1], dzub9[dj + 1][di + 1]);
+          ud[dj + 1][di + 1] = ud[dj + 1][di + 1] * z; vd[dj + 1][di + 1] = vd[dj + 1][di + 1] * z;
+        }
       }
+    // PBC: thickness of this U cell at level k and k + 1, of its four neighbours at level k
+    const double dzu = PBC ? pbc_dz(g, k, kmu, dzub9[1][1]) : 0.0, dzu_kp1 = PBC ? pbc_dz(g, kp1, kmu, dzub9[1][1]) : 0.0;
 #define UD(di, dj) ud[(dj) + 1][(di) + 1]
 #define VD(di, dj) vd[(dj) + 1][(di) + 1]
 #define UU(di, dj) u[(dj) + 1][(di) + 1]
@@ -455,13 +514,18 @@ k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
     const double UUE = 0.25 * (UD(1, 0) + UD(0, 0)) + 0.125 * (UD(1, -1) + UD(0, -1) + UD(1, 1) + UD(0, 1));   // = UUW(i+1,j)
     const double VUS = 0.25 * (VD(0, 0) + VD(0, -1)) + 0.125 * (VD(-1, 0) + VD(-1, -1) + VD(1, 0) + VD(1, -1));
     const double VUN = 0.25 * (VD(0, 1) + VD(0, 0)) + 0.125 * (VD(-1, 1) + VD(-1, 0) + VD(1, 1) + VD(1, 0));   // = VUS(i,j+1)
-    const double wukb = wuk + g.c2dz[k] * 0.5 * (VUN - VUS + UUE - UUW) * uar;
+    const double wukb = PBC ? wuk + (VUN - VUS + UUE - UUW) * uar : wuk + g.c2dz[k] * 0.5 * (VUN - VUS + UUE - UUW) * uar;
     const double cc = VUN - VUS + UUE - UUW;
     double LU = 0.5 * (cc * UU(0, 0) + VUN * UU(0, 1) - VUS * UU(0, -1) + UUE * UU(1, 0) - UUW * UU(-1, 0)) * uar;
     double LV = 0.5 * (cc * VV(0, 0) + VUN * VV(0, 1) - VUS * VV(0, -1) + UUE * VV(1, 0) - UUW * VV(-1, 0)) * uar;
+    if (PBC) { LU = LU / dzu; LV = LV / dzu; }
     if (k == 1) { LU = LU + g.dzr[k] * wuk * uc_k; LV = LV + g.dzr[k] * wuk * vc_k; }
+    else if (PBC) { LU = LU + 0.5 / dzu * wuk * (uc_km1 + uc_k); LV = LV + 0.5 / dzu * wuk * (vc_km1 + vc_k); }
     else { LU = LU + g.dz2r[k] * wuk * (uc_km1 + uc_k); LV = LV + g.dz2r[k] * wuk * (vc_km1 + vc_k); }
-    if (k < km) { LU = LU - g.dz2r[k] * wukb * (uc_k + uc_kp1); LV = LV - g.dz2r[k] * wukb * (vc_k + vc_kp1); }
+    if (k < km) {
+      if (PBC) { LU = LU - 0.5 / dzu * wukb * (uc_k + uc_kp1); LV = LV - 0.5 / dzu * wukb * (vc_k + vc_kp1); }
+      else { LU = LU - g.dz2r[k] * wukb * (uc_k + uc_kp1); LV = LV - g.dz2r[k] * wukb * (vc_k + vc_kp1); }
+    }
     if (k <= kmu) {
       LU = LU + uc_k * vc_k * kyu - vc_k * vc_k * kxu;
       LV = LV + uc_k * vc_k * kxu - uc_k * uc_k * kyu;
@@ -508,9 +572,14 @@ k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
         const double *UM = a.UMIX, *VM = a.VMIX;
         const double um0 = UM[o], umn = UM[o + nxb], ums = UM[o - nxb], ume = UM[o + 1], umw = UM[o - 1];
         const double vm0 = VM[o], vmn = VM[o + nxb], vms = VM[o - nxb], vme = VM[o + 1], vmw = VM[o - 1];
-        hdu = sp.am * ((cc_h * um0 + dun * umn + dus * ums + due * ume + duw * umw) +
+        double cn = dun, cs = dus, ce = due, cw = duw;
+        if (PBC) {   // the four neighbour weights scaled by min(DZU) / DZU; the central one unchanged
+          cn = dun * fmin(pbc_dz(g, k, kmu9[2][1], dzub9[2][1]), dzu) / dzu; cs = dus * fmin(pbc_dz(g, k, kmu9[0][1], dzub9[0][1]), dzu) / dzu;
+          ce = due * fmin(pbc_dz(g, k, kmu9[1][2], dzub9[1][2]), dzu) / dzu; cw = duw * fmin(pbc_dz(g, k, kmu9[1][0], dzub9[1][0]), dzu) / dzu;
+        }
+        hdu = sp.am * ((cc_h * um0 + cn * umn + cs * ums + ce * ume + cw * umw) +
                        (dmc * vm0 + dmn * vmn + dms * vms + dme * vme + dmw * vmw));
-        hdv = sp.am * ((cc_h * vm0 + dun * vmn + dus * vms + due * vme + duw * vmw) -
+        hdv = sp.am * ((cc_h * vm0 + cn * vmn + cs * vms + ce * vme + cw * vmw) -
                        (dmc * um0 + dmn * umn + dms * ums + dme * ume + dmw * umw));
         if (k > kmu) { hdu = 0.0; hdv = 0.0; }
       }
@@ -521,12 +590,17 @@ k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
       const double vvc = a.VVC[o];
       double vufb = vvc * (uo_k - uo_kp1) * g.dzwr[k];
       double vvfb = vvc * (vo_k - vo_kp1) * g.dzwr[k];
+      if (PBC) {
+        const double W = (k < km) ? 0.5 * (dzu + dzu_kp1) : 0.5 * dzu_kp1;
+        vufb = vvc * (uo_k - uo_kp1) / W; vvfb = vvc * (vo_k - vo_kp1) / W;
+      }
       if (k == kmu) {
         const double vmag = sp.bottom_drag * sqrt(uo_k * uo_k + vo_k * vo_k);
         vufb = vmag * uo_k; vvfb = vmag * vo_k;
       }
-      const double vdu = (k <= kmu) ? (vuf - vufb) * g.dzr[k] : 0.0;
-      const double vdv = (k <= kmu) ? (vvf - vvfb) * g.dzr[k] : 0.0;
+      double vdu = (k <= kmu) ? (vuf - vufb) * g.dzr[k] : 0.0;
+      double vdv = (k <= kmu) ? (vvf - vvfb) * g.dzr[k] : 0.0;
+      if (PBC) { vdu = (k <= kmu) ? (vuf - vufb) / dzu : 0.0; vdv = (k <= kmu) ? (vvf - vvfb) / dzu : 0.0; }
       vuf = vufb; vvf = vvfb;
       FX = FX + vdu; FY = FY + vdv;
     }
@@ -537,7 +611,8 @@ k_momentum_rhs(DevGrid g, StepParams sp, MomentumRhsArgs a) {
       UNp[o] = (FX + W1 * FY) * W2;
       VNp[o] = (FY - W1 * FX) * W2;
     } else { UNp[o] = sp.c2dtu * FX; VNp[o] = sp.c2dtu * FY; }
-    zx = zx + FX * g.dz[k]; zy = zy + FY * g.dz[k];
+    if (PBC) { zx = zx + FX * dzu; zy = zy + FY * dzu; }
+    else { zx = zx + FX * g.dz[k]; zy = zy + FY * g.dz[k]; }
     wuk = wukb;
     uc_km1 = uc_k; vc_km1 = vc_k; uc_k = uc_kp1; vc_k = vc_kp1; uo_k = uo_kp1; vo_k = vo_kp1;
 #undef UD
@@ -558,6 +633,8 @@ struct ImpvmixuArgs {
   const double *UOLD, *VOLD, *VVC;
   const double *UB = nullptr, *VB = nullptr;   // register kernel with ADD: the new barotropic velocity, added in the final store
 };
+// PBC: partial bottom cells (vertical_mix.F90:1777-1785; baroclinic.F90:1097-1106)
+template <bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_impvmixu_norm(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   Col c;
@@ -566,6 +643,7 @@ k_impvmixu_norm(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   const long long n2 = g.n2;
   const int kmu = g.KMU[c.q2];
   const double hur = g.HUR[c.q2];
+  const double dzub = PBC ? g.DZUB[c.q2] : 0.0;
   const double hf1 = g.dz[1] / sp.c2dtu;
   double *__restrict__ const UN = a.UNEW;
   double *__restrict__ const VN = a.VNEW;
@@ -583,8 +661,13 @@ k_impvmixu_norm(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   for (int k = 2; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
     const double C = A;
-    const double hf = g.dz[k] / sp.c2dtu;
+    double hf = g.dz[k] / sp.c2dtu;
     A = g.afac_u[k] * VVC[o];
+    if (PBC) {
+      const double dzu = pbc_dz(g, k, kmu, dzub);
+      hf = dzu / sp.c2dtu;
+      A = sp.aidif * VVC[o] / (0.5 * (dzu + pbc_dz(g, k + 1, kmu, dzub)));
+    }
     const double un = UN[o], vn = VN[o];
     if (k <= kmu) {
       D = (k < kmu) ? hf + A + B : hf + B;
@@ -610,8 +693,9 @@ k_impvmixu_norm(DevGrid g, StepParams sp, ImpvmixuArgs a) {
 #pragma unroll 4
   for (int k = 1; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
-    w1 = w1 + UN[o] * g.dz[k];
-    w2 = w2 + VN[o] * g.dz[k];
+    const double dzk = PBC ? pbc_dz(g, k, kmu, dzub) : g.dz[k];
+    w1 = w1 + UN[o] * dzk;
+    w2 = w2 + VN[o] * dzk;
   }
   w1 = w1 * hur; w2 = w2 * hur;
 #pragma unroll 4

@@ -13,6 +13,13 @@ namespace pop {
 #define POP_MOM_WAVES 2
 #endif
 
+// Partial bottom cells: DZT(i,j,k) / DZU(i,j,k) of the reference (grid.F90:926-1016) from the column's bottom level and bottom
+// thickness -- the bottom cell's own thickness at k = kbot, dz(k) at every other level 1..km, 0 at the levels 0 and km+1 the
+// reference's arrays carry.
+__device__ __forceinline__ double pbc_dz(const DevGrid &g, int k, int kbot, double dzbot) {
+  return (k < 1 || k > g.km) ? 0.0 : ((k == kbot) ? dzbot : g.dz[k]);
+}
+
 // Column-kernel prologue: one thread per (i,j) of local block b; returns false for threads
 // outside the physical domain ib..ie, jb..je (or outside the block).
 struct Col {

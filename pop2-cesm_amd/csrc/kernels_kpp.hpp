@@ -20,8 +20,8 @@
 namespace pop {
 
 struct KppDev {
-  const double *zgrid, *hwide, *bckgrnd_vdc, *bckgrnd_vvc;   // zgrid/hwide: 0..km+1
-  const int *kref;                                          // 1..km: surface-layer reference level
+  CArr zgrid, hwide, bckgrnd_vdc, bckgrnd_vvc;             // zgrid/hwide: 0..km+1 (ConstArr: wave-uniform level index -> scalar loads)
+  CArrI kref;                                               // 1..km: surface-layer reference level
   double *HBLT0, *USTAR, *BFSFC;                              // 2-D scratch
   int *KBL0, *KBL;
   double Vtc, cg, rich_mix;
@@ -493,6 +493,8 @@ k_kpp_ushear_col(DevGrid g, KppDev kp, const double *__restrict__ U, const doubl
 // ---- ri_iwmix + ddmix: interior coefficients -----------------------------------------------
 // VISC: (nxb,nyb,km,block) scratch; VDC1/VDC2: (nxb,nyb,0:km+1,block), levels 0 and km+1 stay 0.
 // RIW: scratch for the (smoothed) Richardson number.
+// PBC: partial bottom cells (vmix_kpp.F90:1531-1533, 1553-1563)
+template <bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_interior(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
                const double *__restrict__ U, const double *__restrict__ V, const double *__restrict__ DBLOC,
@@ -503,16 +505,31 @@ k_kpp_interior(DevGrid g, KppDev kp, const double *__restrict__ T, const double 
   const long long n2 = g.n2;
   const int kmt = g.KMT[c.q2];
   const bool edge = (c.i == 0 || c.j == 0);   // ugrid_to_tgrid zeroes the first row and column
+  // PBC: bottom level / thickness of the four U cells around the T cell (offsets 0, -nxb, -1, -1-nxb) and of the T cell
+  int kmu4[4] = {0, 0, 0, 0}; double dzub4[4] = {0, 0, 0, 0}; const double dzbc = PBC ? g.DZBC[c.q2] : 0.0;
+  if (PBC && !edge) {
+    const long long off[4] = {0, -nxb, -1, -1 - nxb};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { kmu4[t] = g.KMU[c.q2 + off[t]]; dzub4[t] = g.DZUB[c.q2 + off[t]]; }
+  }
   // pass 1: local Richardson number
   double prev = 0.0;   // WORK0(k-1)
   for (int k = 1; k <= km; ++k) {
     const long long o = c.base3 + (long long)(k - 1) * n2;
     double vsh = 0.0;
     if (k < km && !edge) {
-      auto sh = [&](long long q) { const double du = U[q] - U[q + n2], dv = V[q] - V[q + n2]; return du * du + dv * dv; };
-      vsh = 0.25 * sh(o) + 0.25 * sh(o - nxb) + 0.25 * sh(o - 1) + 0.25 * sh(o - 1 - nxb);
+      auto sh = [&](long long q, int t) {
+        const double du = U[q] - U[q + n2], dv = V[q] - V[q + n2];
+        if (PBC) { const double h = 0.5 * (pbc_dz(g, k, kmu4[t], dzub4[t]) + pbc_dz(g, k + 1, kmu4[t], dzub4[t])); return (du * du + dv * dv) / (h * h); }
+        return du * du + dv * dv;
+      };
+      vsh = 0.25 * sh(o, 0) + 0.25 * sh(o - nxb, 1) + 0.25 * sh(o - 1, 2) + 0.25 * sh(o - 1 - nxb, 3);
     }
-    const double ri = DBLOC[o] * (kp.zgrid[k] - kp.zgrid[k + 1]) / (vsh + KPP_EPS);
+    double ri = DBLOC[o] * (kp.zgrid[k] - kp.zgrid[k + 1]) / (vsh + KPP_EPS);
+    if (PBC) {
+      const double h = (k < km) ? 0.5 * (pbc_dz(g, k, kmt, dzbc) + pbc_dz(g, k + 1, kmt, dzbc)) : 0.5 * pbc_dz(g, k, kmt, dzbc);
+      ri = DBLOC[o] / (vsh + KPP_EPS / (h * h)) / h;
+    }
     const double w0 = (k <= kmt) ? ri : prev;
     RIW[o] = w0;
     prev = w0;
@@ -694,6 +711,8 @@ k_kpp_interior_reg(DevGrid g, KppDev kp, const double *__restrict__ T, const dou
 
 // ---- bldepth, part 1: shear^2 between the surface-layer reference velocity and level kl at U
 // points; 3-D parallel, one thread per (i,j,kl)
+// PBC: partial bottom cells (vmix_kpp.F90:2359-2362): divided by the squared distance to the reference level
+template <bool PBC = false>
 __global__ void __launch_bounds__(256)
 k_kpp_ushear(DevGrid g, KppDev kp, const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ WU) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -727,6 +746,12 @@ k_kpp_ushear(DevGrid g, KppDev kp, const double *__restrict__ U, const double *_
     uref = uref / surfthick; vref = vref / surfthick;
   } else { uref = U[base3]; vref = V[base3]; }
   const double du = uref - U[o], dv = vref - V[o];
+  if (PBC) {
+    const long long q2 = (long long)b * n2 + p2;
+    const int kmu = g.KMU[q2]; const double dzub = g.DZUB[q2];
+    const double h = -kp.zgrid[kl - 1] + 0.5 * (pbc_dz(g, kl, kmu, dzub) + pbc_dz(g, kl - 1, kmu, dzub) - pbc_dz(g, 1, kmu, dzub));
+    WU[o] = (du * du + dv * dv) / (h * h);
+  } else
   WU[o] = du * du + dv * dv;
 }
 
@@ -763,7 +788,8 @@ __device__ __forceinline__ double kpp_ushear_point(const DevGrid &g, const KppDe
 // rib_* / z_*.  BFSFC ("value of the last pass") is formed for kl = km directly.  Results are bitwise those of the full march
 // (tested); the reference's array form (vmix_kpp.F90 bldepth :2280-2520) has no such exit.  Not with lcheckekmo (its Ekman / Monin-
 // Obukhov limits march every level) and not with the mixed-layer-depth diagnostics (they read DBSFC at every level).
-template <bool LAZY, int KR>
+// PBC (with LAZY = false): partial bottom cells (vmix_kpp.F90:2212-2220, 2363-2366, 2486-2496, 2561-2575)
+template <bool LAZY, int KR, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
               const double *__restrict__ STF1, const double *__restrict__ STF2, const double *__restrict__ DBLOC,
@@ -793,6 +819,11 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
   }
   int kbl = (kmt > 1) ? kmt : 1;
   double hblt = -kp.zgrid[kbl];
+  const double dzbc = PBC ? g.DZBC[c.q2] : 0.0, dzub = PBC ? g.DZUB[c.q2] : 0.0;
+  const int kmu_c = PBC ? g.KMU[c.q2] : 0;
+  // ZKL of level kl: -zgrid(kl), or with partial bottom cells -zgrid(kl-1) + p5*(DZT(kl) + DZT(kl-1)) for kl > 1
+  auto zkl_of = [&](int kl) { return (PBC && kl > 1) ? -kp.zgrid[kl - 1] + 0.5 * (pbc_dz(g, kl, kmt, dzbc) + pbc_dz(g, kl - 1, kmt, dzbc)) : -kp.zgrid[kl]; };
+  if (PBC) hblt = zkl_of(kbl);
   double rib_upper = 0.0, rib_up = 0.0, z_upper = 0.0, z_up = kp.zgrid[1];
   double bfsfc = bo;
   // lcheckekmo (:2231-2265): Ekman and Monin-Obukhov depth limits under stable forcing; hmon_up / hmon_dn rotate like rib_*
@@ -809,7 +840,7 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
     if (LAZY && __builtin_amdgcn_ballot_w64(kbl == kmt && kl <= kmt) == 0) break;
     const long long o = c.base3 + (long long)(kl - 1) * n2;
     const double surfthick = KPP_EPSSFC * g.zt[kl];
-    const double zkl = -kp.zgrid[kl];
+    const double zkl = zkl_of(kl);
     double dbsfc;
     if (LAZY) {
       const int kref = kp.kref[kl];                // wave-uniform
@@ -858,11 +889,20 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
     double wm_unused = 0.0, ws;
     kpp_wscale<false>(KPP_EPSSFC, zkl, ustar, bfsfc, wm_unused, ws);
     const double db = DBLOC[o];
-    const double bfr = sqrt(0.5 * (db + fabs(db) + KPP_EPS2) / (kp.zgrid[kl] - kp.zgrid[kl + 1]));
+    double bfr = sqrt(0.5 * (db + fabs(db) + KPP_EPS2) / (kp.zgrid[kl] - kp.zgrid[kl + 1]));
+    if (PBC) bfr = (kl < km) ? sqrt(0.5 * (db + fabs(db) + KPP_EPS2) / (0.5 * (pbc_dz(g, kl, kmt, dzbc) + pbc_dz(g, kl + 1, kmt, dzbc))))
+                             : sqrt(0.5 * (db + fabs(db) + KPP_EPS2) / pbc_dz(g, kl, kmt, dzbc));
     const double zref = -surfthick / 2.0;
-    const double wmm = zkl * ws * bfr * ((kp.Vtc / KPP_RICR) * fmax(2.1 - 200.0 * bfr, KPP_CONCV));
-    const double wk = (kmt >= kl) ? (zref - kp.zgrid[kl]) * dbsfc : 0.0;
-    const double rib_dn = wk / (vshear + wmm + KPP_EPS);
+    double wmm = zkl * ws * bfr * ((kp.Vtc / KPP_RICR) * fmax(2.1 - 200.0 * bfr, KPP_CONCV));
+    double wk = (kmt >= kl) ? (zref - kp.zgrid[kl]) * dbsfc : 0.0;
+    double rib_dn;
+    if (PBC) {
+      const double ht = -kp.zgrid[kl - 1] + 0.5 * (pbc_dz(g, kl - 1, kmt, dzbc) + pbc_dz(g, kl, kmt, dzbc) - pbc_dz(g, 1, kmt, dzbc));
+      const double hu = -kp.zgrid[kl - 1] + 0.5 * (pbc_dz(g, kl, kmu_c, dzub) + pbc_dz(g, kl - 1, kmu_c, dzub) - pbc_dz(g, 1, kmu_c, dzub));
+      wk = (kmt >= kl) ? dbsfc / ht : 0.0;
+      wmm = wmm / (ht * ht);
+      rib_dn = wk / (vshear + wmm + KPP_EPS / (hu * hu));
+    } else rib_dn = wk / (vshear + wmm + KPP_EPS);
     if (kbl == kmt && rib_dn > KPP_RICR) {
       const double slope_up = (rib_upper - rib_up) / (z_up - z_upper);
       const double d = z_up + zkl;
@@ -881,7 +921,7 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
   if (kp.lcheckekmo) {   // :2676-2690; the reference tests against ZKL of the last pass of the march, -zgrid(km)
     if (hekman < hlimit) hlimit = hekman;
     for (int kl = 2; kl <= km; ++kl)
-      if (hlimit < hblt && hlimit > -kp.zgrid[kl - 1] && hlimit <= -kp.zgrid[km]) { hblt = hlimit; kbl = kl; }
+      if (hlimit < hblt && hlimit > -kp.zgrid[kl - 1] && hlimit <= zkl_of(km)) { hblt = hlimit; kbl = kl; }
   }
   if (LAZY && km >= 2) {      // what the pass kl = km leaves in bfsfc
     bfsfc = kpp_bfsfc(kp, bo, bosol, -kp.zgrid[km], 2 * km - 1, chli);
@@ -895,6 +935,8 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
 }
 
 // ---- smooth_hblt + blmix + interior convection + masks + non-local source -------------------
+// PBC: partial bottom cells (vmix_kpp.F90:3835-3864, 2911-2923, 2948-2973, 3075-3083, 3155-3165, 1220-1222, 1296-1302)
+template <bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLOC, const double *__restrict__ STF1,
             const double *__restrict__ STF2, double *__restrict__ VISC, double *__restrict__ VDC1, double *__restrict__ VDC2,
@@ -904,7 +946,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
   const int km = g.km, nxb = g.nxb;
   const long long n2 = g.n2;
   const int kmt = g.KMT[c.q2];
-  const double *zgrid = kp.zgrid, *hwide = kp.hwide;
+  const CArr zgrid = kp.zgrid, hwide = kp.hwide;
   // smooth_hblt(overwrite_hblt=.true., use_hmxl=.false.)
   double w2 = kp.HBLT0[c.q2];
   int kbl = kp.KBL0[c.q2];
@@ -917,11 +959,15 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     if (g.KMT[c.q2 + nxb] == 0) { cc = cc + cn; cn = 0.0; }
     w2 = cw * kp.HBLT0[c.q2 - 1] + ce * kp.HBLT0[c.q2 + 1] + cs * kp.HBLT0[c.q2 - nxb] + cn * kp.HBLT0[c.q2 + nxb] + cc * kp.HBLT0[c.q2];
   }
-  if (inner && kmt >= 1 && w2 > -zgrid[kmt]) w2 = -zgrid[kmt];
+  const double dzbc = PBC ? g.DZBC[c.q2] : 0.0;
+  auto dzt_at = [&](int k) { return pbc_dz(g, k, kmt, dzbc); };
+  // ztmp(k) = -zgrid(k), or with partial bottom cells -zgrid(k-1) + p5*(DZT(k-1) + DZT(k))
+  auto ztmp = [&](int k) { return PBC ? -zgrid[k - 1] + 0.5 * (dzt_at(k - 1) + dzt_at(k)) : -zgrid[k]; };
+  if (inner && kmt >= 1 && w2 > ztmp(kmt)) w2 = ztmp(kmt);
   const double hblt = fmax(w2, -zgrid[1]);
   if (inner && kmt != 0)
     for (int k = 1; k <= km; ++k)
-      if (hblt > -zgrid[k - 1] && hblt <= -zgrid[k]) kbl = max(k, 2);
+      if (hblt > -zgrid[k - 1] && hblt <= ztmp(k)) kbl = max(k, 2);
   HBLT_OUT[c.q2] = hblt;
   kp.KBL[c.q2] = kbl;
   const double ustar = kp.USTAR[c.q2];
@@ -932,7 +978,9 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
   // blmix: matching at the boundary-layer base
   double wm, ws;
   kpp_wscale<true>(KPP_EPSSFC, hblt, ustar, bfsfc, wm, ws);
-  const double casea = 0.5 + ((-zgrid[kbl] - 0.5 * hwide[kbl] - hblt) >= 0.0 ? 0.5 : -0.5);
+  double casea_x = -zgrid[kbl] - 0.5 * hwide[kbl] - hblt;
+  if (PBC) casea_x = (kbl == 1) ? -zgrid[0] - hblt : -zgrid[kbl - 1] + 0.5 * dzt_at(kbl - 1) - hblt;
+  const double casea = 0.5 + (casea_x >= 0.0 ? 0.5 : -0.5);
   const int nc = (casea > 0.5) ? 1 : 0;
   const int kn = nc * (kbl - 1) + (1 - nc) * kbl;
   const double u2 = ustar * ustar;
@@ -942,8 +990,16 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
   double gat1[3] = {0.0, 0.0, 0.0}, dat1[3] = {0.0, 0.0, 0.0};
   if (kn >= 1 && kn <= km) {
     const int k = kn;
-    const double dh = 0.5 * hwide[k] - zgrid[k] - hblt;
-    const double R = 1.0 - dh / hwide[k];
+    double dh = 0.5 * hwide[k] - zgrid[k] - hblt;
+    double R = 1.0 - dh / hwide[k];
+    double hup = hwide[k], hdn = hwide[k + 1];
+    if (PBC) {
+      const double w1 = (k == 1) ? 0.0 : dzt_at(k - 1);
+      hdn = (k == km) ? KPP_EPS : dzt_at(k + 1);
+      hup = dzt_at(k);
+      dh = -zgrid[k - 1] + dzt_at(k) + 0.5 * w1 - hblt;
+      R = 1.0 - dh / dzt_at(k);
+    }
     double fm[3], f0[3], fp[3];
     fm[0] = visc_at(k - 1); f0[0] = visc_at(k); fp[0] = visc_at(k + 1);
     fm[2] = VDC1[vb + (long long)(k - 1) * n2]; f0[2] = VDC1[vb + (long long)k * n2]; fp[2] = VDC1[vb + (long long)(k + 1) * n2];
@@ -951,7 +1007,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     else { fm[1] = fm[2]; f0[1] = f0[2]; fp[1] = fp[2]; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const double up = (fm[q] - f0[q]) / hwide[k], dn = (f0[q] - fp[q]) / hwide[k + 1];
+      const double up = (fm[q] - f0[q]) / hup, dn = (f0[q] - fp[q]) / hdn;
       const double Pq = 0.5 * ((1.0 - R) * (up + fabs(up)) + R * (dn + fabs(dn)));
       const double Hq = f0[q] + Pq * dh;
       const double wv = (q == 0) ? wm : ws;
@@ -978,13 +1034,18 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     double visc = VISC[o], vd1 = VDC1[vb + (long long)k * n2], vd2 = (!kp.vdc_same) ? VDC2[vb + (long long)k * n2] : vd1;
     double ghat = 0.0;
     if (k < kbl) {
-      const double sig = (-zgrid[k] + 0.5 * hwide[k]) / hblt;
+      double sig = (-zgrid[k] + 0.5 * hwide[k]) / hblt;
+      if (PBC && k > 1) sig = (-zgrid[k - 1] + 0.5 * dzt_at(k - 1) + dzt_at(k)) / hblt;
       double wmk, wsk;
       kpp_wscale<true>(fmin(sig, KPP_EPSSFC), hblt, ustar, bfsfc, wmk, wsk);
       double b0 = shape(sig, wmk, 0), b1 = shape(sig, wsk, 1), b2 = shape(sig, wsk, 2);
       ghat = (1.0 - stable) * kp.cg / (wsk * hblt + KPP_EPS);
       if (k == kbl - 1 && k <= km - 1) {
-        const double dh = (hblt + zgrid[k]) / (zgrid[k] - zgrid[k + 1]);
+        double dh = (hblt + zgrid[k]) / (zgrid[k] - zgrid[k + 1]);
+        if (PBC) {
+          const double w1 = (k == 1) ? -0.5 * dzt_at(k) : zgrid[k - 1] - 0.5 * (dzt_at(k - 1) + dzt_at(k));
+          dh = (hblt + w1) / (0.5 * (dzt_at(k) + dzt_at(k + 1)));
+        }
         const double omd = 1.0 - dh;
         b0 = omd * visc + dh * ((omd * omd) * dkm1[0] + (dh * dh) * (casea * visc + (1.0 - casea) * b0));
         b1 = omd * vd2 + dh * ((omd * omd) * dkm1[1] + (dh * dh) * (casea * vd2 + (1.0 - casea) * b1));
@@ -994,7 +1055,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
       visc = b0; vd2 = b1; vd1 = b2;
     }
     if (k <= km - 1) {
-      const double N2 = DBLOC[o] / (zgrid[k] - zgrid[k + 1]);
+      const double N2 = PBC ? DBLOC[o] / (0.5 * (dzt_at(k) + dzt_at(k + 1))) : DBLOC[o] / (zgrid[k] - zgrid[k + 1]);
       const double fcon = (N2 > 0.0) ? 0.0 : 1.0;
       double cvv = 0.0, cvd = 0.0;
       if (k >= kbl) { cvv = sp.convect_visc * fcon; cvd = sp.convect_diff * fcon; }
@@ -1006,6 +1067,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     if (!kp.vdc_same) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
     const double fl1 = vd1 * ghat, fl2 = vd2 * ghat;
     if (k == 1) { SRC1[o] = stf1 / g.dz[1] * (-fl1); SRC2[o] = stf2 / g.dz[1] * (-fl2); }
+    else if (PBC) { SRC1[o] = stf1 / dzt_at(k) * (flux1_prev - fl1); SRC2[o] = stf2 / dzt_at(k) * (flux2_prev - fl2); }
     else { SRC1[o] = stf1 / g.dz[k] * (flux1_prev - fl1); SRC2[o] = stf2 / g.dz[k] * (flux2_prev - fl2); }
     flux1_prev = fl1; flux2_prev = fl2;
   }
@@ -1275,9 +1337,25 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   // the shear of the velocity against its surface-layer reference needs only U and V: on the side stream it overlaps the
   // (VALU-bound) buoydiff and the interior kernel; bldepth waits for it
   const hipStream_t su = KH.side ? KH.side : st;
+  if (g.pbc) {
+    // partial bottom cells (round 3): the 3-D-parallel / scratch-staged kernel forms carry the PBC branches; every level of the
+    // surface-layer buoyancy difference and of the shear is formed (no on-demand march)
+    g_kpp.WUK = nullptr;
+    hipLaunchKernelGGL(k_kpp_ushear<true>, G3, dim3(256), 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
+    hipLaunchKernelGGL(k_kpp_buoydiff<true>, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
+    hipLaunchKernelGGL(k_kpp_interior<true>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
+    hipLaunchKernelGGL((k_kpp_bldepth<false, 20, true>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                       (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
+    hipLaunchKernelGGL(k_kpp_blmix<true>, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+                       s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+    const int vp = patch_rows(g, h.tun.del4_tile);
+    hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vp), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vp ? 64 * vp : 256), 0, st, g, (const double *)VISC, s.VVC, vp);
+    if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }
+    return 0;
+  }
   if (KH.side) { hipEventRecord(KH.ev_fork, st); hipStreamWaitEvent(KH.side, KH.ev_fork, 0); }
   if (g_kpp_col & 1) hipLaunchKernelGGL(k_kpp_ushear_col<24>, GC, BC, 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
-  else hipLaunchKernelGGL(k_kpp_ushear, G3, dim3(256), 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
+  else hipLaunchKernelGGL(k_kpp_ushear<false>, G3, dim3(256), 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
   // two waves per SIMD (<= 256 VGPRs, ~80 spilled) beat one wave with everything in registers: the kernel is VALU-bound
   // and a second wave fills the division / dependency stalls of the first (POP_KPP_BUOY_WAVES=1 keeps one wave)
   const int bw = tun_or(h.tun.kpp_buoy_waves, 2);
@@ -1307,7 +1385,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   if (fused_bi) {}
   else if (int_reg && g.km == 60) hipLaunchKernelGGL(k_kpp_interior_reg<60>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else if (int_reg && g.km == 62) hipLaunchKernelGGL(k_kpp_interior_reg<62>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, VISC, s.VDC[0], s.VDC[1]);
-  else hipLaunchKernelGGL(k_kpp_interior, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
+  else hipLaunchKernelGGL(k_kpp_interior<false>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
   if (KH.side) hipStreamWaitEvent(st, KH.ev_join, 0);
   else if (lazy20) hipLaunchKernelGGL((k_kpp_bldepth<true, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                                       (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
@@ -1315,7 +1393,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                                     (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
   else hipLaunchKernelGGL((k_kpp_bldepth<false, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                           (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
-  hipLaunchKernelGGL(k_kpp_blmix, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+  hipLaunchKernelGGL(k_kpp_blmix<false>, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                      s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
   const int vpatch = patch_rows(g, h.tun.del4_tile);   // large grids: 64 x 4 patches (the row j + 1 of the four-point average is read by the same workgroup)
   hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vpatch), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vpatch ? 64 * vpatch : 256), 0, st, g, (const double *)VISC, s.VVC, vpatch);

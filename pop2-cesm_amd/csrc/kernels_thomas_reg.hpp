@@ -256,6 +256,10 @@ inline void launch_impvmixt(const DevGrid &g, const StepParams &sp, const Impvmi
   // both tracers in one thread when they share the diffusivity array (pop_tuning.thomas_pair = 0 | 1 overrides the size rule)
   const int pair_env = tun_or(pair_tuning, -1);
   // (corrector form only: the predictor's three full register columns + its up-front loads spill ~ 900 B per lane)
+  if (g.pbc) {   // partial bottom cells: the scratch-staged kernel with the column's own thicknesses
+    hipLaunchKernelGGL((k_impvmixt<MODE, PRE, POST, true>), G, B, 0, st, g, sp, a);
+    return;
+  }
   const bool pair = MODE == 1 && allow_reg && (g.km == 60 || g.km == 62) && a.nfirst == 1 && a.nlast == 2 && a.VDC[0] == a.VDC[1] &&
                     (pair_env >= 0 ? pair_env != 0 : (long long)g.n2 * g.nblocks > (1 << 19));
   if (pair) {
@@ -275,14 +279,15 @@ inline void launch_impvmixu(const DevGrid &g, const StepParams &sp, const Impvmi
   const dim3 B(POP_COL_THREADS);
   const dim3 G2(G.x, G.y, 2);
   const bool small = (long long)g.n2 * g.nblocks <= (1 << 19);
+  if (g.pbc) { hipLaunchKernelGGL(k_impvmixu_norm<true>, G, B, 0, st, g, sp, a); return; }
   if (allow_reg && g.km == 60 && small) hipLaunchKernelGGL((k_impvmixu_reg<60, 2>), G2, B, 0, st, g, sp, a);
   else if (allow_reg && g.km == 60) hipLaunchKernelGGL((k_impvmixu_reg<60, 1>), G2, B, 0, st, g, sp, a);
   else if (allow_reg && g.km == 62 && small) hipLaunchKernelGGL((k_impvmixu_reg<62, 2>), G2, B, 0, st, g, sp, a);
   else if (allow_reg && g.km == 62) hipLaunchKernelGGL((k_impvmixu_reg<62, 1>), G2, B, 0, st, g, sp, a);
-  else hipLaunchKernelGGL(k_impvmixu_norm, G, B, 0, st, g, sp, a);
+  else hipLaunchKernelGGL(k_impvmixu_norm<false>, G, B, 0, st, g, sp, a);
 }
 // the register kernel with the barotropic velocity added on the way out (a.UB, a.VB set); km = 60 / 62 only
-inline bool impvmixu_add_available(const DevGrid &g, bool allow_reg) { return allow_reg && (g.km == 60 || g.km == 62); }
+inline bool impvmixu_add_available(const DevGrid &g, bool allow_reg) { return allow_reg && !g.pbc && (g.km == 60 || g.km == 62); }
 inline void launch_impvmixu_add(const DevGrid &g, const StepParams &sp, const ImpvmixuArgs &a, dim3 G, hipStream_t st) {
   const dim3 B(POP_COL_THREADS);
   const dim3 G2(G.x, G.y, 2);

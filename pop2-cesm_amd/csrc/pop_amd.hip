@@ -193,6 +193,7 @@ StepParams step_params(const pop_ctx *c) {
   s.dtp = c->h.dtp; s.grav = GRAV;
   s.am = cf.am; s.ah = cf.ah; s.bottom_drag = cf.bottom_drag;
   s.const_vvc = cf.const_vvc; s.const_vdc = cf.const_vdc; s.convect_diff = cf.convect_diff; s.convect_visc = cf.convect_visc;
+  s.aidif = cf.aidif;
   s.rich_bckgrnd_vvc = cf.rich_bckgrnd_vvc; s.rich_bckgrnd_vdc = cf.rich_bckgrnd_vdc; s.rich_mix = cf.rich_mix;
   s.leapfrogts = c->leapfrogts; s.pavg = (cf.lpressure_avg && c->leapfrogts) ? 1 : 0;
   s.impcor = cf.impcor; s.reset_to_freezing = cf.reset_to_freezing;
@@ -1281,6 +1282,10 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     for (int r = 0; r < 3; ++r) if (cfg->reserved_i[r] != 0) return bad("pop_config.reserved_i must be 0");
     for (int r = 0; r < 4; ++r) if (cfg->reserved_d[r] != 0.0) return bad("pop_config.reserved_d must be 0");
     if (cfg->partial_bottom_cells != 0 && cfg->partial_bottom_cells != 1) return bad("partial_bottom_cells: 0 or 1");
+    if (cfg->partial_bottom_cells && cfg->vmix_choice == 2) return bad("partial_bottom_cells with Richardson vertical mixing (vmix_rich.F90:266-330) is not built: vmix_choice 1 (const) or 3 (kpp)");
+    if (cfg->partial_bottom_cells && cfg->tadvect == 3) return bad("partial_bottom_cells with lw_lim advection (advection.F90:582-690, 2757-3140) is not built: tadvect 1 (centered) or 2 (upwind3)");
+    if (cfg->partial_bottom_cells && cfg->kpp_ml_diagnostics) return bad("partial_bottom_cells with the HMXL diagnostic (vmix_kpp.F90:1326-1350) is not built");
+    if (cfg->partial_bottom_cells && grid && grid->DZBC == nullptr && grid->KMT != nullptr) return bad("partial_bottom_cells with a topography record needs pop_grid_input.DZBC (the record of bottom_cell_file)");
     if (cfg->lsw_absorb != 0 && cfg->lsw_absorb != 1) return bad("lsw_absorb: 0 or 1");
     if (cfg->nx_global < 1 || cfg->ny_global < 1 || cfg->km < 2 || cfg->block_size_x < 1 || cfg->block_size_y < 1) return bad("domain / block sizes must be positive (km >= 2)");
     if (cfg->ew_boundary != 0 && cfg->ew_boundary != 1) return bad("ew_boundary: 0 closed, 1 cyclic");
@@ -1336,7 +1341,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
   g.ib = NGHOST + 1; g.ie = h.nxb - NGHOST; g.jb = NGHOST + 1; g.je = h.nyb - NGHOST;
   // vertical arrays
   {
-    struct { const double **dst; std::vector<double> *src; } V[] = {
+    struct { CArr *dst; std::vector<double> *src; } V[] = {
       {&g.dz, &h.dz}, {&g.dzw, &h.dzw}, {&g.zt, &h.zt}, {&g.zw, &h.zw}, {&g.c2dz, &h.c2dz}, {&g.dzr, &h.dzr}, {&g.dz2r, &h.dz2r},
       {&g.dzwr, &h.dzwr}, {&g.pressz, &h.pressz}, {&g.bouss, &h.bouss}, {&g.afac_t, &h.afac_t}, {&g.afac_u, &h.afac_u}};
     for (auto &v : V) { double *p; if (dev_upload(c, &p, v.src->data(), v.src->size())) return 1; *v.dst = p; }
@@ -1374,7 +1379,10 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     g.mMask8 = d8;
   }
   G2(mMask); G2(CHECKER); G2(CONSTNT); G2(SMF1); G2(SMF2); G2(SMFT1); G2(SMFT2);
+  g.pbc = cfg->partial_bottom_cells ? 1 : 0;
+  if (g.pbc) { G2(DZBC); G2(DZUB); }
 #undef G2
+  if (dev_alloc(c, &g.dump, 8192)) return 1;
   {   // land elimination (DevGrid::opre): prefix count of the cells that have an ocean T cell within two cells in either
       // direction.  The margin is what makes the skipped values independent of the state: every field the full kernels write
       // on a cell further than one stencil from any ocean cell (tgrid_to_ugrid averages, gradients at land U points, ...) is a
@@ -1508,10 +1516,10 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       // no tripole fold (the ghost ring of the field comes from a halo update, which is the same arithmetic only where ghost cells are
       // plain copies), centred advection through the LDS kernel, bandwidth-bound grids; POP_D2T_FUSE=0|1 overrides the size rule
       const int fuse_env = tun_or(h.tun.d2t_fuse, -1);
-      if (cfg->hmix_tracer == 4 && cfg->ns_boundary != 2 && cfg->tadvect == 1 &&
+      if (cfg->hmix_tracer == 4 && cfg->ns_boundary != 2 && cfg->tadvect == 1 && !cfg->partial_bottom_cells &&
           (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
         if (dev_alloc(c, &c->d2t_next[0], a3) || dev_alloc(c, &c->d2t_next[1], a3)) return 1;
-      if (cfg->hmix_momentum == 4 && cfg->ns_boundary != 2 && !tun_off(h.tun.d2u_fuse) &&
+      if (cfg->hmix_momentum == 4 && cfg->ns_boundary != 2 && !tun_off(h.tun.d2u_fuse) && !cfg->partial_bottom_cells &&
           (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
         if (dev_alloc(c, &c->d2u_next[0], a3) || dev_alloc(c, &c->d2u_next[1], a3)) return 1;
     }
@@ -1684,6 +1692,11 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     // predictor 7.2 vs 7.5-8.1, step -1.2 .. -1.6 ms).  The velocity solve is faster in registers at both sizes.
     c->reg_thomas_t = c->reg_thomas;
     if (tun_set(h.tun.reg_thomas_t)) c->reg_thomas_t = h.tun.reg_thomas_t != 0;
+    if (cfg->partial_bottom_cells) {
+      // partial bottom cells (round 3): the direct-load right-hand-side kernels and the scratch-staged Thomas kernels carry the
+      // PBC branches; the LDS-tiled / register forms are flat-bottom only
+      c->mom_lds_rows = 0; c->trc_lds_rows = 0; c->reg_thomas = false; c->reg_thomas_t = false;
+    }
     c->force_presum = tun_on(h.tun.solver_presum);
     c->fpcg_one_cell = tun_off(h.tun.fpcg_b2);
     c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && (long long)c->nchunk * h.nblocks > 2048;
@@ -2224,8 +2237,10 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   if (fwd) { c->err = "fused forward elimination needs the LDS tracer kernel"; return 1; }
   if (c->h.c.tadvect == 2) {
     a.up = c->upw3;
-    hipLaunchKernelGGL((k_tracer_rhs<false, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
-  } else hipLaunchKernelGGL((k_tracer_rhs<false, false>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+    if (c->g.pbc) hipLaunchKernelGGL((k_tracer_rhs<false, true, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+    else hipLaunchKernelGGL((k_tracer_rhs<false, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+  } else if (c->g.pbc) hipLaunchKernelGGL((k_tracer_rhs<false, false, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+  else hipLaunchKernelGGL((k_tracer_rhs<false, false>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
   return 0;
 }
 static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {
@@ -2293,7 +2308,8 @@ static int phase_momentum_rhs(pop_ctx *c, int tj_first = 0, int tj_count = -1, b
   c->d2u_last_formed = form_next;
   if (c->mom_lds_rows == 8) launch_momentum_lds<8>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
   else if (c->mom_lds_rows == 4) launch_momentum_lds<4>(c->g, step_params(c), a, c->stream, tj_first, tj_count);
-  else hipLaunchKernelGGL(k_momentum_rhs<false>, grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
+  else if (c->g.pbc) hipLaunchKernelGGL((k_momentum_rhs<false, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
+  else hipLaunchKernelGGL((k_momentum_rhs<false, false>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, step_params(c), a);
   if (form_next && last_piece && !c->phase_timing) {
     if (halo_update_many(c, {{c->d2u_next[0], c->g.km, 1, 1}, {c->d2u_next[1], c->g.km, 1, 1}})) return 1;
     c->d2u_next_valid = true; c->d2u_next_slot = c->curt;
@@ -2311,7 +2327,7 @@ static int phase_correct(pop_ctx *c) {
   // the generic Thomas kernel stages E, F through the shared 3-D scratch (E3, F3), which a KPP look-ahead in flight on its own
   // stream also uses (E3 = the Richardson column of the generic k_kpp_interior): the corrector then follows the look-ahead.
   // The register kernels (km = 60 / 62) touch no scratch and run beside it.
-  const bool reg_kernel = c->reg_thomas_t && (c->g.km == 60 || c->g.km == 62);
+  const bool reg_kernel = c->reg_thomas_t && !c->g.pbc && (c->g.km == 60 || c->g.km == 62);
   if (!reg_kernel && c->ahead_valid) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
   if (sp.pavg) launch_impvmixt<1, false, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t, c->h.tun.thomas_pair);
   else launch_impvmixt<0, true, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t, c->h.tun.thomas_pair);
@@ -2381,7 +2397,7 @@ int pop_baroclinic_driver(pop_ctx *c) {
   const bool defer = c->side && impvmixu_add_available(c->g, c->reg_thomas) && c->h.c.ns_boundary != 2 && !tun_on(c->h.tun.btrop_inline) &&
                      !tun_on(c->h.tun.vmixu_inline) && (defer_env >= 0 ? defer_env != 0 : (long long)c->g.n2 * c->g.nblocks > (1 << 19));
   if (defer) c->vmixu_deferred = true;
-  else if (c->side && c->reg_thomas && (c->g.km == 60 || c->g.km == 62) && !tun_on(c->h.tun.vmixu_inline)) {
+  else if (c->side && c->reg_thomas && !c->g.pbc && (c->g.km == 60 || c->g.km == 62) && !tun_on(c->h.tun.vmixu_inline)) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     if (phase_impvmixu(c, c->side)) return 1;

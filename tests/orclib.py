@@ -122,6 +122,13 @@ class Oracle:
         p = self.L.orc_field(self.h, b"VDC", 0, n)
         return np.ctypeslib.as_array(p, shape=(self.nblocks, self.km + 2, self.nyb, self.nxb))
 
+    def f3p(self, name):
+        """(nblocks, km + 2, ny, nx) arrays with levels 0 .. km+1 (DZT, DZU)"""
+        p = self.L.orc_field(self.h, name.encode(), 0, 0)
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(self.nblocks, self.km + 2, self.nyb, self.nxb))
+
     def i2(self, name):
         p = self.L.orc_ifield(self.h, name.encode())
         if not p:

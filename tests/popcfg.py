@@ -141,3 +141,32 @@ def synthetic_grid(c, lat_span=160.0, wobble=0.04, stepped=True, kmt=True):
             k = np.where(k > 0, np.maximum(3, km - cut), 0).astype(np.int32)
         g["KMT"] = k
     return {n: np.ascontiguousarray(a) for n, a in g.items()}
+
+
+def synthetic_dzbc(c, kmt, seed=11):
+    """A bottom_cell_file record (grid.F90:2116-2186) for the KMT record `kmt` (ny_global, nx_global): the thickness of the bottom T
+    cell of every ocean column, a random fraction in [0.2, 1] of dz(KMT) [cm]; 0 on land.  TEST DATA.  dz restates the
+    reference's internal vertical grid (grid.F90:1565-1640) only to scale the numbers; any positive thickness would do."""
+    import numpy as np
+    km, zmax, dz_sfc, dz_deep, eps = c.km, 5500.0, 25.0, 400.0, 1.0e-10
+
+    def profile(zl):
+        dz, depth = [], 0.0
+        for _ in range(km):
+            r = depth / zl
+            dz.append(dz_deep - (dz_deep - dz_sfc) * np.exp(-(r * r))); depth += dz[-1]
+        return depth, dz
+    zl0, zl1 = eps, zmax
+    d0 = profile(zl0)[0]
+    dzv = profile(zl1)[1]
+    while (zl1 - zl0) / zmax > eps:
+        zl = zl0 + 0.5 * (zl1 - zl0)
+        d, dzv = profile(zl)
+        if (d0 - zmax) * (d - zmax) < 0.0:
+            zl1 = zl
+        else:
+            d0, zl0 = d, zl
+    dz = np.concatenate([[0.0], np.array(dzv) * 100.0])
+    rng = np.random.default_rng(seed)
+    frac = 0.2 + 0.8 * rng.random(kmt.shape)
+    return np.ascontiguousarray(np.where(kmt > 0, frac * dz[np.clip(kmt, 0, km)], 0.0))

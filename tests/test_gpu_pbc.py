@@ -1,0 +1,100 @@
+"""Partial bottom cells (grid.F90:916-1020 and the `partial_bottom_cells` branches of advection.F90,
+hmix_del2.F90, hmix_del4.F90, vertical_mix.F90, baroclinic.F90, vmix_kpp.F90, sw_absorption.F90): every phase of the step
+through the C ABI against the CPU oracle, phase by phase, on stepped bathymetry with a bottom-cell thickness that differs from
+column to column."""
+import numpy as np
+import pytest
+
+from popcfg import named_config, synthetic_grid, synthetic_dzbc
+from orclib import Oracle
+from test_gpu_parity import run_phases, force_kpp_case, relerr, TOL_LOCAL, TOL_SOLVE
+
+pytestmark = pytest.mark.gpu
+
+DEL4 = {"hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1, "am": -1.0e22, "ah": -1.0e21}
+
+
+def _run(pkg, cfg, grid, nsteps):
+    gpu, orc = pkg.PopModel(cfg, grid=grid), Oracle(cfg, grid=grid)
+    for n in (0, 1):
+        assert np.array_equal(gpu.get("TRACER", 1, n), orc.f3("TRACER", 1, n))
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
+    tol = TOL_LOCAL
+    for s in range(1, nsteps + 1):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+    out = [gpu.get(n, 1, 0).copy() for n in ("TRACER", "UVEL", "PSURF")]
+    gpu.close(); orc.close()
+    return out
+
+
+@pytest.mark.parametrize("name,kw,nsteps", [
+    ("tiny", {"stepped_bathymetry": 1}, 5),                                         # const vmix, del2, centred advection, 16 blocks
+    ("tiny", {"stepped_bathymetry": 1, "block_size_x": 48, "block_size_y": 40, "solver_choice": 2}, 4),   # one block, ChronGear
+    ("tiny", dict(DEL4, stepped_bathymetry=1), 5),                                  # del4 + variable mixing
+    ("tiny", {"stepped_bathymetry": 1, "vmix_choice": 3, "km": 24}, 5),             # KPP
+    ("tiny", dict(DEL4, stepped_bathymetry=1, vmix_choice=3, km=24, ldbl_diff=1), 5),   # the tx0.1v3 physics: del4 + KPP + double diffusion
+    ("tiny", {"stepped_bathymetry": 1, "vmix_choice": 3, "km": 20, "lshort_wave": 1, "sw_absorption_type": 1, "lsw_absorb": 1, "lcheckekmo": 1}, 4),
+    ("tiny", {"stepped_bathymetry": 1, "tadvect": 2}, 5),                            # upwind3
+    ("tiny", {"stepped_bathymetry": 1, "lpressure_avg": 0, "tmix_opt": 1, "time_mix_freq": 3, "impcor": 0}, 4),
+    ("tiny", {"stepped_bathymetry": 1, "tmix_opt": 3, "solver_choice": 3}, 4),       # Robert filter, P-CSI
+    ("tiny", {"stepped_bathymetry": 1, "km": 60, "vmix_choice": 3}, 3),              # production level count
+    ("tiny", {}, 3),                                                                 # flat bottom with a partial bottom level
+    ("test", {"stepped_bathymetry": 1, "vmix_choice": 1}, 4),                        # 96 blocks
+    ("gx3v7", {"stepped_bathymetry": 1}, 3),
+])
+def test_partial_bottom_cells_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
+    cfg = named_config(name, partial_bottom_cells=1, **kw)
+    a = _run(pkg, cfg, None, nsteps)
+    if name == "tiny" and not kw.get("tmix_opt"):
+        # ... and the bottom thickness matters: the same run on full cells ends somewhere else
+        b = pkg.PopModel(named_config(name, **kw))
+        if cfg.vmix_choice == 3:
+            o = Oracle(named_config(name, **kw)); force_kpp_case(b, o); o.close()
+        for _ in range(nsteps):
+            b.step()
+        assert np.abs(a[0] - b.get("TRACER", 1, 0)).max() > 1.0e-6
+        b.close()
+
+
+@pytest.mark.parametrize("kw,nsteps", [
+    ({"ns_boundary": 2}, 5),                                                         # through a tripole fold
+    ({"ns_boundary": 2, "vmix_choice": 3, "km": 24, "ldbl_diff": 1, "hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1, "am": -1.0e22, "ah": -1.0e21}, 4),
+    ({"ns_boundary": 2, "block_size_x": 48, "block_size_y": 40, "tadvect": 2}, 4),
+    ({"ns_boundary": 0, "ew_boundary": 0, "vmix_choice": 3, "km": 24}, 3),           # closed boundaries
+    ({"ns_boundary": 1}, 3),
+])
+def test_partial_bottom_cells_on_a_caller_grid(pkg, orclib_built, kw, nsteps):
+    """the production route: horiz_grid_file / topography_file / bottom_cell_file records (pop_create_with_grid), stepped KMT and a
+    random bottom thickness in [0.2, 1] dz(KMT)"""
+    cfg = named_config("tiny", partial_bottom_cells=1, **kw)
+    grid = synthetic_grid(cfg)
+    grid["DZBC"] = synthetic_dzbc(cfg, grid["KMT"])
+    _run(pkg, cfg, grid, nsteps)
+
+
+def test_bottom_cells_of_full_thickness_change_nothing_physical(pkg, orclib_built):
+    """DZBC = dz(KMT) everywhere is the full-cell geometry written through the partial-bottom-cell formulas: the two runs agree
+    to rounding (the formulas divide by thicknesses where the full-cell ones multiply by reciprocals), not bitwise."""
+    kw = {"stepped_bathymetry": 1, "vmix_choice": 3, "km": 24}
+    cfg = named_config("tiny", partial_bottom_cells=1, ns_boundary=1, **kw)
+    ref = named_config("tiny", ns_boundary=1, **kw)
+    grid = synthetic_grid(cfg)
+    o = Oracle(ref, grid=grid)
+    dz = o.v1("dz")
+    o.close()
+    grid["DZBC"] = np.where(grid["KMT"] > 0, dz[np.clip(grid["KMT"], 0, cfg.km)], 0.0)
+    a, b = pkg.PopModel(cfg, grid=grid), pkg.PopModel(ref, grid=grid)
+    for _ in range(5):
+        a.step(); b.step()
+    for f in ("TRACER", "UVEL", "VVEL", "PSURF"):
+        e = relerr(a.get(f, 1, 0), b.get(f, 1, 0))
+        assert e < 1.0e-9, (f, e)
+    a.close(); b.close()
+
+
+def test_partial_bottom_cells_refusals(pkg):
+    for kw, word in (({"vmix_choice": 2}, "Richardson"), ({"tadvect": 3}, "lw_lim"), ({"vmix_choice": 3, "kpp_diagnostics": 1}, "HMXL")):
+        with pytest.raises(pkg.PopError, match=word):
+            pkg.PopModel(named_config("tiny", partial_bottom_cells=1, **kw), host_only=True)

@@ -4,7 +4,7 @@ KMT/KMU and index maps bit-exact; all init-time fields are pure functions of the
 import numpy as np
 import pytest
 
-from popcfg import named_config, synthetic_grid
+from popcfg import named_config, synthetic_grid, synthetic_dzbc
 from orclib import Oracle
 
 FIELDS = ["ULAT", "ULON", "TLAT", "HTN", "HTE", "HUS", "HUW", "DXU", "DYU", "DXT", "DYT", "DXUR", "DYUR",
@@ -36,6 +36,25 @@ def test_host_fields_from_grid_input_bit_exact(pkg, orclib_built, kw):
     the reference's field locations (tripole ghost rows mirrored), every derived field equal to the oracle's bit for bit"""
     cfg = named_config("tiny", **kw)
     _host_fields_bit_exact(pkg, cfg, synthetic_grid(cfg))
+
+
+@pytest.mark.parametrize("name,kw,grid_kw", [
+    ("tiny", {"stepped_bathymetry": 1}, None),                                    # internal grid: synthetic bottom thickness
+    ("test", {"stepped_bathymetry": 1, "vmix_choice": 1}, None),
+    ("tiny", {"ns_boundary": 2}, {"dzbc": True}),                                 # caller's DZBC record, through a tripole fold
+    ("tiny", {"ns_boundary": 2, "block_size_x": 48, "block_size_y": 40}, {"dzbc": True}),
+    ("tiny", {"ns_boundary": 0, "ew_boundary": 0}, {"dzbc": True}),
+    ("tiny", {"ns_boundary": 1, "hmix_momentum": 4, "hmix_tracer": 4}, {"dzbc": False}),   # grid records without DZBC: synthetic
+])
+def test_partial_bottom_cells_host_fields_bit_exact(pkg, orclib_built, name, kw, grid_kw):
+    """partial_bottom_cells = 1 (grid.F90:916-1020): DZBC, the thicknesses DZT / DZU and the depths HT, HU, HUR they change"""
+    cfg = named_config(name, partial_bottom_cells=1, **kw)
+    grid = None
+    if grid_kw is not None:
+        grid = synthetic_grid(cfg, kmt=grid_kw["dzbc"])
+        if grid_kw["dzbc"]:
+            grid["DZBC"] = synthetic_dzbc(cfg, grid["KMT"])
+    _host_fields_bit_exact(pkg, cfg, grid)
 
 
 def test_grid_input_scatter_rule(pkg):
@@ -110,6 +129,17 @@ def _host_fields_bit_exact(pkg, cfg, grid):
     if cfg.tadvect == 2:     # third-order upwind weights (advection.F90:420-562)
         for f in ("TALFXP", "TBETXP", "TGAMXP", "TALFXM", "TBETXM", "TDELXM", "TALFYP", "TBETYP", "TGAMYP", "TALFYM", "TBETYM", "TDELYM"):
             assert np.array_equal(m.get(f), o.f2(f)), f
+    if cfg.partial_bottom_cells:
+        # the library keeps two 2-D fields (DZBC, DZUB = DZU at level KMU); the thicknesses it forms from them must be the
+        # reference's 3-D DZT / DZU (grid.F90:926-1016, levels 0 and km+1 zero) on EVERY cell, ghosts included
+        assert np.array_equal(m.get("DZBC"), o.f2("DZBC"))
+        dz = o.v1("dz")
+        k = np.arange(cfg.km + 2)[None, :, None, None]
+        dzk = np.where((k >= 1) & (k <= cfg.km), dz[np.clip(k, 0, cfg.km)], 0.0)
+        for name2, kb, bot in (("DZT", m.geti("KMT"), m.get("DZBC")), ("DZU", m.geti("KMU"), m.get("DZUB"))):
+            mine = np.where((k == kb[:, None]) & (k >= 1), bot[:, None], dzk)
+            ref = o.f3p(name2)
+            assert np.array_equal(mine, ref), "%s: %d cells differ" % (name2, int((mine != ref).sum()))
     for n in (0, 1):
         assert np.array_equal(m.get("SMF", 1, n), o.f2("SMF", 1, n))
         assert np.array_equal(m.get("SMFT", 1, n), o.f2("SMFT", 1, n))
