@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from popcfg import named_config  # noqa: E402
 
 FIELDS = [("TRACER", True), ("UVEL", True), ("VVEL", True), ("RHO", True), ("PSURF", False), ("UBTROP", False)]
-NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6, "pcsi_evp": 4, "lw_lim": 5}
+NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6, "pcsi_evp": 4, "lw_lim": 5, "pbc_kpp_del4": 5}
 
 
 def config(case):
@@ -27,6 +27,9 @@ def config(case):
     if case == "kpp_del4":
         return named_config("tiny", vmix_choice=3, ldbl_diff=1, hmix_momentum=4, hmix_tracer=4, lvariable_hmix=1,
                             am=-1.0e23, ah=-1.0e22, solver_choice=2, **small)
+    if case == "pbc_kpp_del4":   # partial bottom cells on stepped bathymetry with the tx0.1v3 physics (del4 + variable mixing + KPP + double diffusion)
+        return named_config("tiny", vmix_choice=3, ldbl_diff=1, hmix_momentum=4, hmix_tracer=4, lvariable_hmix=1,
+                            am=-1.0e23, ah=-1.0e22, stepped_bathymetry=1, partial_bottom_cells=1, **small)
     if case == "upwind3":     # third-order upwind tracer advection + Richardson vmix
         return named_config("tiny", tadvect=2, vmix_choice=2, **small)
     if case == "lw_lim":      # Lax-Wendroff advection with one-dimensional flux limiters + KPP
@@ -45,7 +48,7 @@ def surface_fluxes(tlat):
 def prepare(model, case):
     """Set the surface tracer fluxes (the KPP case needs buoyancy forcing).  `model` is an Oracle or a
     PopModel-like object with f2()/set()."""
-    if case != "kpp_del4":
+    if case not in ("kpp_del4", "pbc_kpp_del4"):
         return
     tlat = model.f2("TLAT") if hasattr(model, "f2") else model.get("TLAT")
     st, ss = surface_fluxes(tlat)

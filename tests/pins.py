@@ -170,6 +170,32 @@ def _tridiag_residual(h, a_face, kbot, rhs_h, x):
     return np.where(kbot[None, :] > 0, r, 0.0)              # land columns: the reference leaves don't-care values at k = 1
 
 
+def _thickness(A, kind):
+    """level thicknesses per interior column, (km, ncol): dz(k), or with partial bottom cells (grid.F90:926-951) DZT = DZBC at
+    the bottom level of a T column, and DZU = the minimum of the four surrounding DZT at a U column -- formed here from KMT and
+    DZBC alone, independently of what either implementation stores"""
+    km = A.km
+    dz = A.vert("dz")[1:km + 1]
+    kmt = A.geti("KMT")
+    if not A.cfg.partial_bottom_cells:
+        ncol = interior(kmt).size
+        return np.repeat(dz[:, None], ncol, axis=1)
+    dzbc = A.get("DZBC")
+    k = np.arange(1, km + 1)[None, :, None, None]
+    dzt = np.where(k == kmt[:, None], dzbc[:, None], dz[None, :, None, None])          # (nblocks, km, ny, nx), ghosts included
+    if kind == "T":
+        return _cols(dzt)
+    dzu = dzt.copy()
+    dzu[..., :-1, :-1] = np.minimum(np.minimum(dzt[..., :-1, :-1], dzt[..., :-1, 1:]), np.minimum(dzt[..., 1:, :-1], dzt[..., 1:, 1:]))
+    return _cols(dzu)
+
+
+def _faces(dzc, coef):
+    """A(k) = coefficient(k) / (distance between the centres of levels k and k + 1) for per-column thicknesses dzc (km, ncol)"""
+    below = np.vstack([dzc[1:], np.zeros((1, dzc.shape[1]))])
+    return coef / (0.5 * (dzc + below))
+
+
 def _cols(a3):
     """(nblocks, km, ny, nx) interior -> (km, ncol)"""
     b = interior(a3)
@@ -204,6 +230,9 @@ def check_impvmixt(A, rng, tol_res=1e-13, tol_sol=1e-12):
         v = vdc[n if nvdc == 2 else 0]
         a_face = afac[:, None] * _cols(v[:, 1:km + 1])
         h = np.repeat((dz / c2dt)[:, None], a_face.shape[1], axis=1)
+        if A.cfg.partial_bottom_cells:      # the same system on the columns' own thicknesses
+            dzc = _thickness(A, "T")
+            a_face, h = _faces(dzc, _cols(v[:, 1:km + 1])), dzc / c2dt
         rhs_h = h * _cols(rhs[n])
         h[0] = h[0] + interior(ps).reshape(-1) / (GRAV * c2dt)
         kb = interior(kmt).reshape(-1)
@@ -251,6 +280,9 @@ def check_impvmixt_correct(A, rng, tol_res=1e-13, tol_sol=1e-12):
         v = vdc[n if nvdc == 2 else 0]
         a_face = afac[:, None] * _cols(v[:, 1:km + 1])
         h = np.repeat((dz / c2dt)[:, None], a_face.shape[1], axis=1)
+        if A.cfg.partial_bottom_cells:
+            dzc = _thickness(A, "T")
+            a_face, h = _faces(dzc, _cols(v[:, 1:km + 1])), dzc / c2dt
         kb = interior(kmt).reshape(-1)
         rhs1 = ((2.0 * tc[n][:, 0] - to[n][:, 0]) * (P[1] - P[0]) - tn[n][:, 0] * (P[2] - P[1])) / (GRAV * dz[0])
         rhs_h = np.zeros_like(h)
@@ -292,9 +324,16 @@ def check_impvmixu(A, rng, tol_sol=1e-12):
         out = _cols(A.get(f, 2))
         a_face = afac[:, None] * _cols(vvc)
         h = np.repeat((dz / c2dt)[:, None], a_face.shape[1], axis=1)
+        dzc = np.repeat(dz[:, None], a_face.shape[1], axis=1)
+        if A.cfg.partial_bottom_cells:
+            dzc = _thickness(A, "U")
+            a_face, h = _faces(dzc, _cols(vvc)), dzc / c2dt
+            # the depth the mean divides by is the sum of the column's thicknesses (grid.F90:1011-1014)
+            hu = np.where(klev <= kb[None, :], dzc, 0.0).sum(axis=0)
+            assert np.allclose(np.where(kb > 0, hu * interior(hur).reshape(-1), 1.0), 1.0, rtol=1e-13)
         x = _tridiag_solve(h, a_face, kb, h * _cols(r))
         unew = _cols(o) + x
-        mean = (unew * dz[:, None]).sum(axis=0) * interior(hur).reshape(-1)
+        mean = (unew * dzc).sum(axis=0) * interior(hur).reshape(-1)
         expect = np.where(klev <= kb[None, :], unew - mean[None, :], 0.0)
         err = np.abs(out - expect).max() / np.abs(expect).max()
         assert err <= tol_sol, "%s after impvmixu: differs from the LAPACK-based value by %.3e" % (f, err)

@@ -76,8 +76,10 @@ def test_partial_bottom_cells_on_a_caller_grid(pkg, orclib_built, kw, nsteps):
 
 def test_bottom_cells_of_full_thickness_change_nothing_physical(pkg, orclib_built):
     """DZBC = dz(KMT) everywhere is the full-cell geometry written through the partial-bottom-cell formulas: the two runs agree
-    to rounding (the formulas divide by thicknesses where the full-cell ones multiply by reciprocals), not bitwise."""
-    kw = {"stepped_bathymetry": 1, "vmix_choice": 3, "km": 24}
+    to rounding (the formulas divide by thicknesses where the full-cell ones multiply by reciprocals), not bitwise.  Constant
+    vertical mixing: the partial-bottom-cell branches of KPP are not a generalisation of the full-cell ones (e.g. the bulk
+    Richardson number measures depth from zt(1) instead of from half the surface-layer thickness, vmix_kpp.F90:2561-2575)."""
+    kw = {"stepped_bathymetry": 1, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21}
     cfg = named_config("tiny", partial_bottom_cells=1, ns_boundary=1, **kw)
     ref = named_config("tiny", ns_boundary=1, **kw)
     grid = synthetic_grid(cfg)
@@ -98,3 +100,36 @@ def test_partial_bottom_cells_refusals(pkg):
     for kw, word in (({"vmix_choice": 2}, "Richardson"), ({"tadvect": 3}, "lw_lim"), ({"vmix_choice": 3, "kpp_diagnostics": 1}, "HMXL")):
         with pytest.raises(pkg.PopError, match=word):
             pkg.PopModel(named_config("tiny", partial_bottom_cells=1, **kw), host_only=True)
+
+
+@pytest.mark.parametrize("kw", [{"tadvect": 1}, {"tadvect": 2, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21}, {"vmix_choice": 3, "km": 20}])
+def test_tracer_content_is_conserved_with_partial_bottom_cells(pkg, kw):
+    """What the flux form must do on the device, whatever the thicknesses: with no surface flux the volume integral of a tracer --
+    the bottom cell of every column counted with ITS thickness DZBC, the surface layer with dz(1) + eta -- is unchanged to
+    rounding (the oracle twin: tests/test_oracle_fixtures.py::test_advection_conserves_tracer_volume)."""
+    cfg = named_config("tiny", stepped_bathymetry=1, partial_bottom_cells=1, **kw)
+    m = pkg.PopModel(cfg)
+    o = Oracle(cfg)
+    dz = o.v1("dz")[1:cfg.km + 1].copy()
+    o.close()
+    tarea, kmt, dzbc = m.get("TAREA"), m.geti("KMT"), m.get("DZBC")
+    k = np.arange(1, cfg.km + 1)[None, :, None, None]
+    wet = (k <= kmt[:, None])[..., 2:-2, 2:-2]
+
+    def content(n):
+        T = m.get("TRACER", 1, n)[..., 2:-2, 2:-2]
+        eta = m.get("PSURF", 1)[..., 2:-2, 2:-2] / 980.6
+        thick = np.broadcast_to(dz[None, :, None, None], T.shape).copy()
+        thick = np.where((k == kmt[:, None])[..., 2:-2, 2:-2], dzbc[:, None, 2:-2, 2:-2], thick)
+        thick[:, 0] = thick[:, 0] + eta
+        return float((np.where(wet, T * thick, 0.0) * tarea[:, None, 2:-2, 2:-2]).sum())
+
+    for _ in range(3):
+        m.step()
+    c0 = [content(n) for n in (0, 1)]
+    for _ in range(4):
+        m.step()
+    assert np.abs(m.get("UVEL", 1)).max() > 1.0
+    for n in (0, 1):
+        assert abs(content(n) - c0[n]) <= 2e-9 * abs(c0[n]), (kw, n, content(n), c0[n])
+    m.close()

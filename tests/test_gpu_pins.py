@@ -16,6 +16,9 @@ CASES = [
     ("kpp-dd-km60-stepped", dict(vmix_choice=3, km=60, ldbl_diff=1, stepped_bathymetry=1)),   # double diffusion: a diffusivity array per tracer class
     ("kpp-km62-del4-stepped", dict(vmix_choice=3, km=62, stepped_bathymetry=1, hmix_tracer=4, hmix_momentum=4, am=-1.0e19, ah=-1.0e19)),
     ("rich-flat", dict(vmix_choice=2)),
+    ("pbc-const-km16-stepped", dict(stepped_bathymetry=1, partial_bottom_cells=1)),
+    ("pbc-kpp-dd-km20-stepped", dict(vmix_choice=3, km=20, ldbl_diff=1, stepped_bathymetry=1, partial_bottom_cells=1)),
+    ("pbc-kpp-km62-del4-stepped", dict(vmix_choice=3, km=62, stepped_bathymetry=1, partial_bottom_cells=1, hmix_tracer=4, hmix_momentum=4, am=-1.0e19, ah=-1.0e19)),
 ]
 
 

@@ -11,6 +11,9 @@ CASES = [
     ("kpp-km20-stepped", dict(vmix_choice=3, km=20, stepped_bathymetry=1)),     # two VDC fields holding the same values
     ("kpp-dd-km20-stepped", dict(vmix_choice=3, km=20, ldbl_diff=1, stepped_bathymetry=1)),   # double diffusion: distinct values per tracer class
     ("rich-flat", dict(vmix_choice=2)),
+    # partial bottom cells: the systems on the columns' own thicknesses (DZT / DZU formed in the pin from KMT and DZBC)
+    ("pbc-const-stepped", dict(stepped_bathymetry=1, partial_bottom_cells=1)),
+    ("pbc-kpp-dd-km20-stepped", dict(vmix_choice=3, km=20, ldbl_diff=1, stepped_bathymetry=1, partial_bottom_cells=1)),
 ]
 
 
