@@ -42,6 +42,7 @@ struct DevGrid {
   const double *DZBC, *DZUB;
   int pbc;
   double *dump;                                    // scratch words that inactive lanes of branch-free kernels store to
+  const double *zero;                              // a few words of +0.0 that no kernel writes (loads that must yield zero without a branch)
   const double *DUC, *DUN, *DUS, *DUE, *DUW, *DMC, *DMN, *DMS, *DME, *DMW, *DUM, *KXU, *KYU;
   const double *WNE, *WEa, *WNo, *WC0, *mMask, *CHECKER, *CONSTNT;
   const double *SMF1, *SMF2, *SMFT1, *SMFT2;

@@ -146,27 +146,41 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NF], double *partial
 // (local block); threads take strided subsets sequentially, then a fixed tree.
 // ordered sum of the nchunk partials of one block (all NF fields) by one workgroup: thread-strided
 // left-to-right sums, then a fixed tree; result valid in thread 0
-template <int NF>
+template <int NF, int DEPTH = 16>
 __device__ __forceinline__ void block_sum_ordered(const double *__restrict__ pb, int nchunk, double (&out)[NF]) {
   __shared__ double sh[NF][POP_RED_THREADS];
   const int t = threadIdx.x;
   double v[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) v[f] = 0.0;
-  // same left-to-right order as a plain strided loop; the loads of 16 terms are issued before their
-  // adds so the chain costs one memory latency per 16 terms instead of one per term
+  // same left-to-right order as a plain strided loop; the loads of DEPTH terms are issued before their
+  // adds so the chain costs one memory latency per DEPTH terms instead of one per term (16 inside the solver kernels that
+  // recompute the total themselves; 64 in the one-workgroup k_block_sums launches of large grids, whose 130 terms per thread
+  // then take three round trips instead of nine)
   int cidx = t;
-  for (; cidx + 15 * POP_RED_THREADS < nchunk; cidx += 16 * POP_RED_THREADS) {
-    double w[16][NF];
+  for (; cidx + (DEPTH - 1) * POP_RED_THREADS < nchunk; cidx += DEPTH * POP_RED_THREADS) {
+    double w[DEPTH][NF];
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
+    for (int u = 0; u < DEPTH; ++u)
 #pragma unroll
       for (int f = 0; f < NF; ++f) w[u][f] = pb[((long long)cidx + u * POP_RED_THREADS) * NF + f];
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
+    for (int u = 0; u < DEPTH; ++u)
 #pragma unroll
       for (int f = 0; f < NF; ++f) v[f] = v[f] + w[u][f];
   }
+  if (DEPTH > 16)   // remainder in batches of 16
+    for (; cidx + 15 * POP_RED_THREADS < nchunk; cidx += 16 * POP_RED_THREADS) {
+      double w[16][NF];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) w[u][f] = pb[((long long)cidx + u * POP_RED_THREADS) * NF + f];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f] = v[f] + w[u][f];
+    }
   for (; cidx < nchunk; cidx += POP_RED_THREADS)
 #pragma unroll
     for (int f = 0; f < NF; ++f) v[f] = v[f] + pb[(long long)cidx * NF + f];
@@ -184,11 +198,11 @@ __device__ __forceinline__ void block_sum_ordered(const double *__restrict__ pb,
   for (int f = 0; f < NF; ++f) out[f] = sh[f][0];
 }
 template <int NF>
-__global__ void k_block_sums(const double *__restrict__ partial, int nchunk, const int *__restrict__ gid,
+__global__ void __launch_bounds__(POP_RED_THREADS) k_block_sums(const double *__restrict__ partial, int nchunk, const int *__restrict__ gid,
                              double *__restrict__ blocksum) {
   const int b = blockIdx.x;
   double r[NF];
-  block_sum_ordered<NF>(partial + (long long)b * nchunk * NF, nchunk, r);
+  block_sum_ordered<NF, (NF == 1 ? 64 : 32)>(partial + (long long)b * nchunk * NF, nchunk, r);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) blocksum[(long long)gid[b] * NF + f] = r[f];
@@ -197,13 +211,13 @@ __global__ void k_block_sums(const double *__restrict__ partial, int nchunk, con
 // the whole block-sum vector of the decomposition in one launch (grid = nblocks_tot): own blocks get their
 // ordered sum, the others 0, ready for the all-reduce (replaces memset + k_block_sums)
 template <int NF>
-__global__ void k_block_sums_global(const double *__restrict__ partial, int nchunk, const int *__restrict__ local_of_gid,
+__global__ void __launch_bounds__(POP_RED_THREADS) k_block_sums_global(const double *__restrict__ partial, int nchunk, const int *__restrict__ local_of_gid,
                                     double *__restrict__ blocksum) {
   const int bg = blockIdx.x, lb = local_of_gid[bg];
   double r[NF];
 #pragma unroll
   for (int f = 0; f < NF; ++f) r[f] = 0.0;
-  if (lb >= 0) block_sum_ordered<NF>(partial + (long long)lb * nchunk * NF, nchunk, r);
+  if (lb >= 0) block_sum_ordered<NF, (NF == 1 ? 64 : 32)>(partial + (long long)lb * nchunk * NF, nchunk, r);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) blocksum[(long long)bg * NF + f] = r[f];

@@ -7,7 +7,7 @@ namespace pop {
 #define POP_COL_THREADS 64   // one wavefront per workgroup for column-march kernels
 // waves per SIMD the stencil column kernels are compiled for (second __launch_bounds__ argument)
 #ifndef POP_TRC_WAVES
-#define POP_TRC_WAVES 3
+#define POP_TRC_WAVES 2
 #endif
 #ifndef POP_MOM_WAVES
 #define POP_MOM_WAVES 2

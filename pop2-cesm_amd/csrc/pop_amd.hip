@@ -100,8 +100,8 @@ struct pop_ctx {
   bool force_presum = false;
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
   bool reg_thomas_t = true;
-  int trc_lds_rows = 8;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
-  int mom_lds_rows = 8;                                    // momentum RHS: LDS tile rows (0 = direct-load kernel)
+  int trc_lds_rows = 4;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
+  int mom_lds_rows = 4;                                    // momentum RHS: LDS tile rows (0 = direct-load kernel)
   bool reg_thomas = true;                                  // column-in-registers Thomas kernels (km = 60, 62)
   SolveView gv{};                                         // replicated barotropic mode: all blocks
   double *gTAREA = nullptr; int *gKMT = nullptr;
@@ -1383,6 +1383,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
   if (g.pbc) { G2(DZBC); G2(DZUB); }
 #undef G2
   if (dev_alloc(c, &g.dump, 8192)) return 1;
+  { double *z; if (dev_alloc(c, &z, 64)) return 1; g.zero = z; }
   {   // land elimination (DevGrid::opre): prefix count of the cells that have an ocean T cell within two cells in either
       // direction.  The margin is what makes the skipped values independent of the state: every field the full kernels write
       // on a cell further than one stencil from any ocean cell (tgrid_to_ugrid averages, gradients at land U points, ...) is a
@@ -1682,7 +1683,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->mom_lds_rows = tun_or(h.tun.momentum_lds, c->mom_lds_rows);
     // tracer RHS through LDS tiles (kernels_tracer_lds.hpp).  Measured against the direct-load kernel: tx0.1v3 15.0 ms ->
     // 12.8 (64x4 tiles) / 13.6 (64x8); gx1v7 0.260 ms -> 0.208 (64x4) / 0.192 (64x8).  POP_TRACER_LDS=0|4|8 overrides.
-    c->trc_lds_rows = (h.n2 * h.nblocks > (1u << 19)) ? 4 : 8;
+    c->trc_lds_rows = 4;   // round 3 (branch-free kernels, two waves per SIMD): 64 x 4 tiles at every size (gx1v7 0.149 vs 0.156 ms, tx0.1v3 7.6 vs 8.0)
     c->trc_lds_rows = tun_or(h.tun.tracer_lds, c->trc_lds_rows);
     c->reg_thomas = !tun_on(h.tun.generic_thomas);
     // tracer solve: the register kernel keeps the elimination coefficients of a column in VGPRs instead of writing them to
@@ -1693,9 +1694,9 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->reg_thomas_t = c->reg_thomas;
     if (tun_set(h.tun.reg_thomas_t)) c->reg_thomas_t = h.tun.reg_thomas_t != 0;
     if (cfg->partial_bottom_cells) {
-      // partial bottom cells (round 3): the direct-load right-hand-side kernels and the scratch-staged Thomas kernels carry the
-      // PBC branches; the LDS-tiled / register forms are flat-bottom only
-      c->mom_lds_rows = 0; c->trc_lds_rows = 0; c->reg_thomas = false; c->reg_thomas_t = false;
+      // partial bottom cells (round 3): the right-hand-side kernels (LDS-tiled and direct-load) and the scratch-staged Thomas
+      // kernels carry the PBC branches; the register Thomas forms are flat-bottom only
+      c->reg_thomas = false; c->reg_thomas_t = false;
     }
     c->force_presum = tun_on(h.tun.solver_presum);
     c->fpcg_one_cell = tun_off(h.tun.fpcg_b2);
