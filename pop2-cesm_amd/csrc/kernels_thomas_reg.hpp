@@ -26,6 +26,12 @@ k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
   const double H1 = hfac1 + a.PSFC[c.q2] / (sp.grav * a.c2dtt);
   const long long vdcbase = ((long long)c.b * (KM + 2)) * n2 + c.p2;
   double Ea[KM], Fa[KM];   // VDC -> E and TNEW -> F, in registers
+  // the value the increment is added to -- TOLD (MODE 0) or the incoming TNEW (MODE 1) -- in a third register column, loaded with
+  // the others: read inside the back substitution (round 2) the compiler issued these loads one by one behind the recurrence, each
+  // with its own s_waitcnt vmcnt(0): 40 exposed memory latencies per column (ISA of k_impvmixt_reg<62,0>); one wave per SIMD has
+  // 512 registers, the three columns take 372.  (The corrector form, capped at 256 registers for two waves per SIMD, keeps reading
+  // its base value -- the incoming TNEW -- in the back substitution.)
+  double Ba[MODE == 0 ? KM : 1];
   {
     const int n = a.nfirst - 1 + blockIdx.z;            // one tracer per thread (launch z = tracer count)
     double *__restrict__ const TN = a.TNEW[n];
@@ -36,6 +42,7 @@ k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
     for (int k = 1; k <= KM; ++k) {
       Ea[k - 1] = VDC[vdcbase + (long long)k * n2];
       Fa[k - 1] = TN[c.base3 + (long long)(k - 1) * n2];
+      if (MODE == 0) Ba[k - 1] = TO[c.base3 + (long long)(k - 1) * n2];
     }
     double rhs1 = 0.0;
     if (MODE == 1) {
@@ -78,11 +85,13 @@ k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
       double f = Fa[k - 1];
       if (k < KM && k < kmt) f = f + Ea[k - 1] * Fkp1;
       Fkp1 = f;
-      // base value: TOLD (MODE 0) or the incoming TNEW (MODE 1), read here; a compiler barrier every
-      // 8 levels bounds how many of these loads are in flight (register budget)
-      if ((k & 7) == 0) asm volatile("" ::: "memory");
-      const long long ob = c.base3 + (long long)(k - 1) * n2;
-      double tn = ((MODE == 1) ? TN[ob] : TO[ob]) + f;
+      double tn;
+      if (MODE == 0) tn = Ba[k - 1] + f;                  // base value TOLD: in registers
+      else {
+        // the incoming TNEW, read here; a compiler barrier every 8 levels bounds how many of these loads are in flight
+        if ((k & 7) == 0) asm volatile("" ::: "memory");
+        tn = TN[c.base3 + (long long)(k - 1) * n2] + f;
+      }
       if (POST && n == 0 && k == 1 && sp.reset_to_freezing) tn = fmax(tn, -2.0);
       Fa[k - 1] = tn;
     }
