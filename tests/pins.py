@@ -82,7 +82,7 @@ class GpuAdapter:
         self.cfg = cfg
         self.km, self.nblocks = self.m.km, self.m.nblocks
         o = Oracle(cfg)
-        self._vert = {k: o.v1(k).copy() for k in ("dz", "dzw", "dzwr", "bouss", "afac_t", "afac_u")}
+        self._vert = {k: o.v1(k).copy() for k in ("dz", "dzw", "dzwr", "bouss", "afac_t", "afac_u", "zt", "zw")}
         o.close()
 
     def get(self, name, tl=1, n=0):
@@ -456,3 +456,299 @@ def check_hdifft(A, tol=None):
             worst = max(worst, e)
     assert worst <= tol, "hdifft of a quadratic field differs from the closed form by %.3e" % worst
     return worst
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# KPP (vmix_kpp.F90) against Large, McWilliams & Doney (1994): the published similarity functions, the boundary-layer
+# shape function and the bulk-Richardson-number depth on a two-layer column.  Nothing below evaluates the model's own
+# formulas: the expected values are written from the paper (appendix B for phi_m, phi_s and their constants) and from the
+# geometry of the column.
+# ------------------------------------------------------------------------------------------------------------------
+VONKAR, EPSSFC, RICR = 0.4, 0.1, 0.3           # von Karman constant, surface-layer extent, critical bulk Ri (LMD94 2, 21)
+ZETA_M, ZETA_S, A_M, C_M, A_S, C_S = -0.2, -1.0, 1.26, 8.38, -28.86, 98.96    # LMD94 (B1), (B2)
+CSTAR = 10.0                                   # non-local transport, LMD94 (20)
+KPP_EPS = 1.0e-10                              # vmix_kpp.F90:104
+
+
+def phi_m(zeta):
+    """LMD94 (B1): 1 + 5 zeta | (1 - 16 zeta)^-1/4 | (a_m - c_m zeta)^-1/3"""
+    z = np.asarray(zeta, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        return np.where(z >= 0.0, 1.0 + 5.0 * z, np.where(z >= ZETA_M, (1.0 - 16.0 * z) ** -0.25, (A_M - C_M * z) ** (-1.0 / 3.0)))
+
+
+def phi_s(zeta):
+    """LMD94 (B1): 1 + 5 zeta | (1 - 16 zeta)^-1/2 | (a_s - c_s zeta)^-1/3"""
+    z = np.asarray(zeta, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        return np.where(z >= 0.0, 1.0 + 5.0 * z, np.where(z >= ZETA_S, (1.0 - 16.0 * z) ** -0.5, (A_S - C_S * z) ** (-1.0 / 3.0)))
+
+
+def _patch(kmt, km, r=3):
+    """columns whose neighbourhood of radius r is full-depth ocean inside one block"""
+    full = (kmt == km)
+    ok = full.copy()
+    for dj in range(-r, r + 1):
+        for di in range(-r, r + 1):
+            ok &= np.roll(np.roll(full, dj, axis=1), di, axis=2)
+    ok[:, :r + 2, :] = False; ok[:, -(r + 2):, :] = False; ok[:, :, :r + 2] = False; ok[:, :, -(r + 2):] = False
+    assert ok.any(), "no open-ocean patch in this configuration"
+    return ok
+
+
+def _two_layer(A, kstar, t1, t2, salt=35.0, u1=0.0, u2=0.0):
+    """levels 1 .. kstar-1: temperature t1, velocity (u1, 0); levels kstar .. km: t2, (u2, 0); uniform salinity (model units)"""
+    shp = A.get("TRACER", 1, 0).shape
+    km = A.km
+    lev = np.arange(1, km + 1)[None, :, None, None]
+    T = np.where(lev < kstar, t1, t2) + np.zeros(shp)
+    U = np.where(lev < kstar, u1, u2) + np.zeros(shp)
+    for tl in range(3):
+        A.set("TRACER", T, tl, 0)
+        A.set("TRACER", np.full(shp, salt), tl, 1)
+        A.set("UVEL", U, tl)
+        A.set("VVEL", np.zeros(shp), tl)
+    return T
+
+
+def _rho_of_uniform_column(A, temp, salt):
+    """in-situ density of (temp, salt) at the pressure of every level: the model's own `state` phase on a uniform column.
+    (The equation of state is compared with the oracle level by level in the phase-parity tests; here it only supplies
+    the buoyancy jump and the surface expansion coefficient the closed forms need.)"""
+    shp = A.get("TRACER", 1, 0).shape
+    keep = [(A.get("TRACER", tl, n), tl, n) for tl in range(3) for n in range(2)]
+    for tl in range(3):
+        A.set("TRACER", np.full(shp, temp), tl, 0)
+        A.set("TRACER", np.full(shp, salt), tl, 1)
+    A.run_phase("state")
+    tl_new = 2
+    rho = A.get("RHO", tl_new)
+    for arr, tl, n in keep:
+        A.set("TRACER", arr, tl, n)
+    return rho
+
+
+def _surface_buoyancy_flux(A, t1, salt, stf_t, ok):
+    """Bo = -g (d rho / d T) STF_T / rho at the surface level (LMD94 (A3b), no salt flux): the derivative by central differences
+    of the density the model's `state` phase returns"""
+    d = 2.0 ** -6
+    rp, rm, r0 = (_rho_of_uniform_column(A, t, salt)[:, 0][ok] for t in (t1 + d, t1 - d, t1))
+    drdt = (rp - rm) / (2.0 * d)
+    return float(np.median(-GRAV * drdt * stf_t / r0)), float(np.abs(drdt - np.median(drdt)).max())
+
+
+def _kpp_setup(A, kstar, t1, t2, ustar, stf_t, u1=0.0, u2=0.0, salt=35.0):
+    _prepare(A)
+    for tl in range(3):
+        A.set("PSURF", np.zeros(A.get("PSURF", 1).shape), tl)
+    _two_layer(A, kstar, t1, t2, salt, u1, u2)
+    kmt = A.geti("KMT")
+    z2 = np.zeros(kmt.shape)
+    for name in ("SMF", "SMFT"):                 # |tau| / rho_0 = ustar^2 (vmix_kpp.F90:2177: USTAR = sqrt(|SMFT|); the stress at U and at T points
+        A.set(name, z2 + ustar * ustar, 1, 0)    # are separate forcing fields, forcing_ws.F90:307)
+        A.set(name, z2, 1, 1)
+    A.set("STF", z2 + stf_t, 1, 0)
+    A.set("STF", z2, 1, 1)
+    return kmt
+
+
+def _kpp_run(A):
+    A.dhdt()
+    A.run_phase("vmix")
+    A.run_phase("hmix_tracer")
+    A.run_phase("tracer_rhs")
+
+
+def check_kpp_scales_and_shape(A, regime, nu0=0.0, tol=1e-7):
+    """Inside the boundary layer the diffusivity at the interface of depth d = zw(k) is K_x = h w_x(sigma) G(sigma), sigma = d / h
+    (LMD94 (10)), w_x = kappa ustar / phi_x(zeta), zeta = min(sigma, eps) h kappa Bf / ustar^3 (LMD94 (13); the reference clips
+    sigma at eps in every regime, vmix_kpp.F90:3085), G(sigma) = sigma (1 + a2 sigma + a3 sigma^2) with G(1) = nu(h) / (h w_x(1)),
+    dG(1) = 0 for a depth-independent interior nu (LMD94 (17), (18), (D5)): a2 = -2 + 3 G(1), a3 = 1 - 2 G(1).
+    Non-local term of the tracer equation (LMD94 (20)): K_s gamma_s = C* kappa (c_s kappa eps)^1/3 G(sigma) * surface flux in
+    unstable forcing, none in stable forcing.  `regime`: 'stable' | 'weak' | 'strong' picks the forcing; the similarity regime
+    reached (the branch of phi) is asserted.  Interior: no shear-instability term (lrich = 0), uniform background nu0."""
+    km = A.km
+    kstar = 9
+    ustar, stf = {"stable": (0.5, 1.0e-4), "weak": (2.0, -1.0e-3), "strong": (0.6, -6.0e-3)}[regime]
+    t1, t2, salt = 18.0, 8.0, 0.035
+    kmt = _kpp_setup(A, kstar, t1, t2, ustar, stf, salt=salt)
+    ok = _patch(kmt, km)
+    bo, spread = _surface_buoyancy_flux(A, t1, salt, stf, ok)
+    assert spread <= 1e-12
+    if bo >= 0.0:
+        bo = bo + 2.0 * KPP_EPS                             # the reference's regularisation of stable forcing, applied in the level march of
+                                                            # bldepth and again after it (vmix_kpp.F90:2418, 2755; no short wave)
+    u3 = ustar ** 3 + KPP_EPS                               # and of zeta (:3297)
+    _kpp_run(A)
+    hblt, kbl = A.get("HBLT"), A.geti("KBL")
+    zw, zt, dz = A.vert("zw"), A.vert("zt"), A.vert("dz")
+    h = hblt[ok]                                            # every column of the patch with its own depth
+    assert np.abs(h - np.median(h)).max() <= 1e-6 * np.median(h) and (kbl[ok] == kbl[ok].flat[0]).all()
+    KB = int(kbl[ok].flat[0])
+    assert KB >= 5, "boundary layer too shallow for the check (KBL = %d)" % KB
+    zeta_sl = EPSSFC * h * VONKAR * bo / u3
+    if regime == "stable":
+        assert zeta_sl.min() > 0.0
+    elif regime == "weak":
+        assert ZETA_M < zeta_sl.min() and zeta_sl.max() < 0.0     # both phi on their (1 - 16 zeta) branch
+    else:
+        assert zeta_sl.max() < ZETA_S                       # both phi on their convective (a - c zeta)^1/3 branch
+    worst = 0.0
+    cg = CSTAR * VONKAR * (C_S * VONKAR * EPSSFC) ** (1.0 / 3.0)
+    vdc = [A.get("VDC", 1, n) for n in range(2)]
+    vvc = A.get("VVC")
+    src = A.get("KPP_SRC", 1, 0)
+    w1 = {"m": VONKAR * ustar / phi_m(zeta_sl), "s": VONKAR * ustar / phi_s(zeta_sl)}
+    nu = {"m": nu0 * A.cfg.Prandtl, "s": nu0}
+    # the viscosity reaches U points as the area-weighted mean of the four surrounding T cells (grid.F90 tgrid_to_ugrid):
+    # a horizontally uniform value is multiplied by the sum of the weights
+    ta, ua = A.get("TAREA"), A.get("UAREA")
+    t2u = (0.25 * (ta + np.roll(ta, -1, axis=2) + np.roll(ta, -1, axis=1) + np.roll(np.roll(ta, -1, axis=1), -1, axis=2)) / ua)[ok]
+    g_prev = 0.0
+    for k in range(1, KB - 1):                              # interfaces 1 .. KBL-2: pure boundary-layer values (LMD94 appendix D changes KBL-1)
+        sig = zw[k] / h
+        zeta = np.minimum(sig, EPSSFC) * h * VONKAR * bo / u3
+        G = {}
+        for x, phi in (("m", phi_m), ("s", phi_s)):
+            wx = VONKAR * ustar / phi(zeta)
+            g1 = nu[x] / (h * w1[x])
+            G[x] = sig * (1.0 + sig * ((-2.0 + 3.0 * g1) + (1.0 - 2.0 * g1) * sig))
+            expect = h * wx * G[x] * (t2u if x == "m" else 1.0)
+            got = (vvc[:, k - 1] if x == "m" else vdc[0][:, k])[ok]          # VDC carries the levels 0 .. km+1, VVC 1 .. km
+            worst = max(worst, float((np.abs(got - expect) / expect).max()))
+        assert np.array_equal(vdc[0][:, k][ok], vdc[1][:, k][ok])
+        # non-local source of level k: STF / dz(k) * (K gamma (top) - K gamma (bottom)), K gamma = cg G_s(sigma) when unstable
+        gam = cg * G["s"] if bo < 0.0 else 0.0
+        expect = stf / dz[k] * (g_prev - gam)
+        got = src[:, k - 1][ok]
+        if bo < 0.0:
+            worst = max(worst, float(np.abs(got - expect).max() / abs(stf / dz[k] * cg)))
+        else:
+            assert np.abs(got).max() == 0.0
+        g_prev = gam
+    assert worst <= tol, "KPP boundary-layer coefficients differ from the published forms by %.3e (%s, nu0 = %g)" % (worst, regime, nu0)
+    return worst
+
+
+def check_kpp_hblt_two_layer(A, tol=2e-7):
+    """Boundary-layer depth of a two-layer column (LMD94 (21)): the bulk Richardson number is 0 at every level of the upper
+    layer and Ri* = (d - eps d / 2) db / |dV|^2 at the first level of the lower layer (d = zt(k*), db the buoyancy jump at that
+    level's pressure, dV the velocity jump; no local stratification below the jump, so no unresolved-shear term).  The
+    reference interpolates Ri_b(z) by the parabola through the last three levels (vmix_kpp.F90:2600-2640): with Ri_b = 0
+    at the two upper ones its root is  h = zt(k*-1) + (zt(k*) - zt(k*-1)) sqrt(Ri_c / Ri*)."""
+    km = A.km
+    kstar, t1, t2, salt = 8, 16.0, 15.0, 0.035
+    du = 14.0
+    kmt = _kpp_setup(A, kstar, t1, t2, 1.0, -1.0e-4, u1=du, u2=0.0, salt=salt)
+    ok = _patch(kmt, km)
+    ra = _rho_of_uniform_column(A, t1, salt)[:, kstar - 1][ok]
+    rb = _rho_of_uniform_column(A, t2, salt)[:, kstar - 1][ok]
+    db = float(np.median(GRAV * (1.0 - ra / rb)))
+    _kpp_run(A)
+    zt = A.vert("zt")
+    d = zt[kstar]
+    ri = (d - 0.5 * EPSSFC * d) * db / (du * du)
+    assert ri > RICR
+    expect = zt[kstar - 1] + (zt[kstar] - zt[kstar - 1]) * np.sqrt(RICR / ri)
+    hblt, kbl = A.get("HBLT")[ok], A.geti("KBL")[ok]
+    err = float(np.abs(hblt - expect).max() / expect)
+    assert err <= tol, "HBLT of the two-layer column differs from the closed form by %.3e (%.6f vs %.6f cm)" % (err, hblt.flat[0], expect)
+    assert (kbl == kstar).all()
+    return err
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# advection of tracers (advection.F90): exact flux divergence of a linear field, monotonicity of the limited scheme
+# ------------------------------------------------------------------------------------------------------------------
+def _adv_setup(A, u0):
+    c2dt = _prepare(A)
+    _quiet(A)
+    shp = A.get("UVEL", 1).shape
+    for tl in range(3):
+        A.set("UVEL", np.full(shp, u0), tl)
+    kmt = A.geti("KMT")
+    for n in range(2):
+        A.set("STF", np.zeros(kmt.shape), 1, n)
+    if A.cfg.vmix_choice == 3:
+        for n in range(2):
+            A.set("KPP_SRC", np.zeros(shp), 1, n)
+    return c2dt, kmt, shp
+
+
+def check_advt_linear(A, tol=1e-12):
+    """Uniform zonal velocity u0 at every U point, V = 0, T = a i + b j (indices within the block), no diffusion (ah = 0):
+    the east-face transport is u0 (DYU(i,j) + DYU(i,j-1)) / 2 (advection.F90:1555-1566), independent of i on the lat-lon
+    grid, there is no vertical velocity, and the flux divergence is exactly  u0 a HTE_eff(j) / TAREA(j)  for the centred
+    scheme (advection.F90:1667-1729) and for the third-order upwind scheme (a linear profile is interpolated exactly on a
+    grid uniform in i, :2313-2676)."""
+    assert A.cfg.ah == 0.0
+    u0, a, b = 3.0, 2.0 ** -5, 2.0 ** -4
+    c2dt, kmt, shp = _adv_setup(A, u0)
+    km = A.km
+    ii = np.arange(shp[-1], dtype=np.float64)[None, None, None, :]
+    jj = np.arange(shp[-2], dtype=np.float64)[None, None, :, None]
+    field = [a * ii + b * jj + np.zeros(shp), 0.5 * a * ii - 0.25 * b * jj + 1.0 + np.zeros(shp)]
+    for n in range(2):
+        for tl in range(3):
+            A.set("TRACER", field[n], tl, n)
+    A.dhdt()
+    A.run_phase("vmix")
+    A.run_phase("hmix_tracer")
+    A.run_phase("tracer_rhs")
+    ok = _patch(kmt, km, r=4)
+    dyu, tarea = A.get("DYU"), A.get("TAREA")
+    ute = u0 * 0.5 * (dyu + np.roll(dyu, 1, axis=1))
+    worst = 0.0
+    for n, amp in ((0, a), (1, 0.5 * a)):
+        expect = -(ute * amp / tarea)
+        out = A.get("TRACER", 2, n) / c2dt
+        for k in range(km):
+            worst = max(worst, float(np.abs(out[:, k] - expect)[ok].max() / np.abs(expect)[ok].max()))
+    assert worst <= tol, "advection of a linear field differs from the exact flux divergence by %.3e" % worst
+    return worst
+
+
+def check_lw_lim_monotone(A):
+    """One-dimensional limited Lax-Wendroff advection (advection.F90:2684-3280) of a step in i by a uniform zonal flow at
+    Courant number ~0.4: the advected profile X - dt div(F) has no new extremum (stays inside [lo, hi] and monotone in i across
+    the step), and what the rows lose is what the flow carried across the step: sum_i TAREA div(F) = UTE (X_right - X_left)."""
+    assert A.cfg.tadvect == 3 and A.cfg.ah == 0.0
+    c2dt0 = 2.0 * A.scalar("dtt")
+    dxt = A.get("DXT")
+    u0 = 0.4 * float(np.median(dxt)) / c2dt0
+    c2dt, kmt, shp = _adv_setup(A, u0)
+    km = A.km
+    ok = _patch(kmt, km, r=4)
+    # the longest run of patch columns in a row of block 0
+    b, j = 0, int(np.argmax(ok[0].sum(axis=1)))
+    cols = np.flatnonzero(ok[b, j])
+    runs = np.split(cols, np.flatnonzero(np.diff(cols) > 1) + 1)
+    run = max(runs, key=len)
+    assert len(run) >= 12
+    i0, i1 = int(run[0]), int(run[-1])
+    istep = (i0 + i1) // 2
+    lo, hi = 2.0, 3.0
+    ii = np.arange(shp[-1])[None, None, None, :]
+    step = np.where(ii <= istep, lo, hi) + np.zeros(shp)
+    for n, f in ((0, step), (1, 5.0 - step)):
+        for tl in range(3):
+            A.set("TRACER", f, tl, n)
+    A.dhdt()
+    A.run_phase("vmix")
+    A.run_phase("hmix_tracer")
+    A.run_phase("tracer_rhs")
+    dyu, tarea = A.get("DYU"), A.get("TAREA")
+    ute = u0 * 0.5 * (dyu + np.roll(dyu, 1, axis=1))
+    sel = slice(i0 + 2, i1 - 1)
+    for n, f, jump in ((0, step, hi - lo), (1, 5.0 - step, lo - hi)):
+        ft = A.get("TRACER", 2, n) / c2dt                    # = -div(F)
+        for k in (0, km // 2, km - 1):
+            new = (f[b, k, j] + c2dt * ft[b, k, j])[sel]
+            assert new.min() >= lo - 1e-12 and new.max() <= hi + 1e-12, "limited advection created a new extremum: [%r, %r]" % (new.min(), new.max())
+            d = np.diff(new) * np.sign(jump)
+            assert d.min() >= -1e-12, "limited advection is not monotone across the step"
+            assert np.abs(new - f[b, k, j][sel]).max() > 0.05            # the step did move
+            lost = float((tarea[b, j][sel] * -ft[b, k, j][sel]).sum())
+            expect = float(ute[b, j, istep] * jump)
+            assert abs(lost - expect) <= 1e-11 * abs(expect), "transport across the step: %r vs %r" % (lost, expect)
+    return True

@@ -70,3 +70,39 @@ def test_tracer_diffusion_of_a_quadratic_field(kw, pkg, monkeypatch):
         A = pins.GpuAdapter(pkg, named_config("tiny", block_size_x=48, block_size_y=40, **kw))
         pins.check_hdifft(A)
         A.close()
+
+
+# ---- KPP against Large, McWilliams & Doney (1994) and advection against exact flux divergences (tests/pins.py) ----------
+KPP_PIN = dict(vmix_choice=3, lrich=0, bckgrnd_vdc2=0.0, block_size_x=48, block_size_y=40)
+
+
+@pytest.mark.parametrize("km", [20, 60], ids=["km20-generic-kernels", "km60-register-kernels"])
+@pytest.mark.parametrize("nu0", [0.0, 2000.0], ids=["no-interior-mixing", "uniform-interior-nu"])
+@pytest.mark.parametrize("regime", ["stable", "weak", "strong"])
+def test_kpp_velocity_scales_and_shape_function(regime, nu0, km, pkg):
+    A = pins.GpuAdapter(pkg, named_config("tiny", km=km, bckgrnd_vdc1=nu0, **KPP_PIN))
+    pins.check_kpp_scales_and_shape(A, regime, nu0)
+    A.close()
+
+
+@pytest.mark.parametrize("km", [20, 60])
+def test_kpp_boundary_layer_depth_of_a_two_layer_column(km, pkg):
+    A = pins.GpuAdapter(pkg, named_config("tiny", vmix_choice=3, km=km, block_size_x=48, block_size_y=40))
+    pins.check_kpp_hblt_two_layer(A)
+    A.close()
+
+
+@pytest.mark.parametrize("kw", [dict(tadvect=1), dict(tadvect=2), dict(tadvect=1, vmix_choice=3, km=60), dict(tadvect=2, hmix_tracer=4)],
+                         ids=["centred", "upwind3", "centred-kpp-km60", "upwind3-del4"])
+def test_advection_of_a_linear_field_is_the_exact_flux_divergence(kw, pkg, monkeypatch):
+    for lds in ("4", "0"):                       # LDS-tiled and direct-load tracer kernels
+        monkeypatch.setenv("POP_TRACER_LDS", lds)
+        A = pins.GpuAdapter(pkg, named_config("tiny", ah=0.0, block_size_x=48, block_size_y=40, **kw))
+        pins.check_advt_linear(A)
+        A.close()
+
+
+def test_limited_advection_creates_no_new_extremum(pkg):
+    A = pins.GpuAdapter(pkg, named_config("tiny", ah=0.0, tadvect=3, block_size_x=48, block_size_y=40))
+    pins.check_lw_lim_monotone(A)
+    A.close()
