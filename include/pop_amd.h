@@ -117,7 +117,7 @@ typedef struct pop_tuning {
   int vmixu_inline;        /* 1: implicit vertical mixing of U, V on the launch stream */
   int btrop_inline;        /* 1: barotropic velocity added in the step tail (the reference's order) */
   int kpp_ahead;           /* KPP of the next step beside the barotropic solver */
-  int kpp_col;             /* KPP kernel forms, bit mask: 1 ushear column, 2 buoydiff column, 4 buoydiff LDS, 8 buoydiff + interior fused */
+  int kpp_col;             /* KPP kernel forms, bit mask: 1 ushear column, 2 buoydiff column, 4 buoydiff LDS, 8 buoydiff + interior fused, 16 the two as one column march */
   int kpp_lazy;            /* 0: surface-layer buoyancy difference at every level */
   int kpp_ushear_hint;     /* 0: shear kernel forms every level */
   int kpp_ushear_margin;   /* levels beyond the previous boundary-layer level (default 3; may be negative) */

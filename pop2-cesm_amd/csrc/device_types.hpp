@@ -16,6 +16,15 @@ template <class T>
 struct ConstArr {
   const T *p = nullptr;
   __device__ __forceinline__ T operator[](int k) const { return ((const __attribute__((address_space(4))) T *)p)[k]; }
+  // the caller asserts that k is the same in every lane: pointer and index pass through v_readfirstlane, so the load is a scalar
+  // load wherever it stands (inside a loop whose induction variable the compiler moved into vector registers, operator[]
+  // becomes a vector load followed by a full wait)
+  __device__ __forceinline__ T u(int k) const {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const unsigned ku = __builtin_amdgcn_readfirstlane((unsigned)k);
+    return ((const __attribute__((address_space(4))) T *)(((unsigned long long)hi << 32) | lo))[(int)ku];
+  }
   __host__ __device__ ConstArr &operator=(const T *q) { p = q; return *this; }
   __host__ __device__ operator const T *() const { return p; }
 };

@@ -22,6 +22,7 @@ namespace pop {
 struct KppDev {
   CArr zgrid, hwide, bckgrnd_vdc, bckgrnd_vvc;             // zgrid/hwide: 0..km+1 (ConstArr: wave-uniform level index -> scalar loads)
   CArrI kref;                                               // 1..km: surface-layer reference level
+  CArr eosP;                                                // 6 (km + 2): mwjf_level of every level (k_kpp_level_table)
   double *HBLT0, *USTAR, *BFSFC;                              // 2-D scratch
   int *KBL0, *KBL;
   double Vtc, cg, rich_mix;
@@ -427,6 +428,119 @@ k_kpp_buoy_interior_lds(DevGrid g, KppDev kp, const double *__restrict__ T, cons
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
     if (!kp.vdc_same) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
+  }
+}
+
+// ---- buoydiff (DBLOC) + ri_iwmix as ONE column march, no LDS, no barrier (round 3) ------------------------------------
+// With the surface-layer buoyancy difference formed on demand by the boundary-layer march (SFC = false above) every level
+// costs the same, and nothing is left that needs the level-parallel split of k_kpp_buoy_interior_lds: a thread owns a column
+// and walks down it once.  What it carries between levels is what the level-parallel form recomputes or re-reads -- the
+// prepared (T, S) of the level above (one square root and half an equation of state per cell), U and V of the level above at the
+// four surrounding U points (8 of the 16 velocity loads), and a three-value window of the local Richardson number for
+// the 1-2-1 smoothing (the LDS column and its three barriers per workgroup).  The pressure polynomials of the equation of state
+// come from a per-level table (KppDev::eosP, formed on the device by k_kpp_level_table with mwjf_level itself) through scalar
+// loads instead of 14 vector operations per level.  The raw operands of level k + 2 are in flight while level k + 1 is
+// evaluated.  One smoothing pass (num_v_smooth_Ri = 1, the reference's default), no double diffusion, no partial bottom
+// cells: every other configuration keeps the kernels above.  Same operations in the same order per value: bitwise equal
+// to k_kpp_buoy_interior_lds (tested).
+__global__ void k_kpp_level_table(DevGrid g, double *__restrict__ tab) {
+  const int k = threadIdx.x;
+  if (k < 1 || k > g.km) return;
+  const MwjfP P = mwjf_level(g.pressz[k]);
+  double *t = tab + 6 * k;
+  t[0] = P.n0; t[1] = P.n2; t[2] = P.ns1t0; t[3] = P.d0; t[4] = P.d1; t[5] = P.d3;
+}
+struct KppRaw { double t, s, u[4], v[4]; };
+__global__ void __launch_bounds__(POP_COL_THREADS)
+k_kpp_buoy_interior_march(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
+                          const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ DBLOC,
+                          double *__restrict__ VISC, double *__restrict__ VDC1, double *__restrict__ VDC2) {
+  Col c;
+  if (!col_setup(g, c, false)) return;
+  const int km = g.km, nxb = g.nxb;
+  const long long n2 = g.n2;
+  const int kmt = g.KMT[c.q2];
+  const bool edge = (c.i == 0 || c.j == 0);          // ugrid_to_tgrid zeroes the first row and column (their loads go to the own cell)
+  const long long off4[4] = {0, edge ? 0 : -(long long)nxb, edge ? 0 : -1, edge ? 0 : -1 - (long long)nxb};
+  const long long vb = ((long long)c.b * (km + 2)) * n2 + c.p2;
+  auto load = [&](int k) {                            // level k = 1 .. km
+    KppRaw r;
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    r.t = T[o]; r.s = S[o];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { r.u[t] = U[o + off4[t]]; r.v[t] = V[o + off4[t]]; }
+    return r;
+  };
+  // coefficients of level k from the window (w0(k-1), w0(k), w0(k+1))
+  auto emit = [&](int k, double wprev, double cur, double wnext) {
+    double riw = cur;
+    if (kmt >= 3) {
+      const double w1 = 0.25 * ((k > 1) ? wprev : cur);
+      const double nxt = (k < km) ? wnext : cur;
+      riw = w1 + 0.5 * cur + 0.25 * nxt;
+    }
+    double fri = fmax(riw, 0.0) / KPP_RIINFTY;
+    fri = fmin(fri, 1.0);
+    double visc, vd1 = 0.0, vd2 = 0.0;
+    if (kp.lrich) {
+      const double f = 1.0 - fri * fri;
+      const double f3 = (f * f) * f;
+      visc = kp.bckgrnd_vvc[k] + kp.rich_mix * f3;
+      if (k < km) { vd2 = kp.bckgrnd_vdc[k] + kp.rich_mix * f3; vd1 = vd2; }
+    } else {
+      visc = kp.bckgrnd_vvc[k];
+      if (k < km) { vd2 = kp.bckgrnd_vdc[k]; vd1 = vd2; }
+    }
+    if (k >= kmt) { visc = 0.0; vd1 = 0.0; vd2 = 0.0; }
+    VISC[c.base3 + (long long)(k - 1) * n2] = visc;
+    VDC1[vb + (long long)k * n2] = vd1;
+    if (!kp.vdc_same) VDC2[vb + (long long)k * n2] = vd2;
+  };
+  KppRaw up = load(1), A = load(2 <= km ? 2 : km), B;
+  MwjfTS2 xkm = mwjf_prep2(tmask(up.t), up.s);
+  double wpp = 0.0, wp = 0.0, carry = 0.0;            // w0(k-3), w0(k-2); the value carried below the bottom
+  // level k: forms DBLOC(k-1), Ri(k-1) and the coefficients of level k-2.  cu holds the operands of level k; those of level k+1
+  // are requested into nx first and are in flight while this level is evaluated.  The loop below alternates two operand sets
+  // (a rotation by register moves would have to wait for the loads it moves)
+  auto level = [&](int k, const KppRaw &cu, KppRaw &nx) {
+    nx = load(k + 1 <= km ? k + 1 : km);
+    const MwjfTS2 xk = mwjf_prep2(tmask(cu.t), cu.s);
+    MwjfP P;
+    { const int e = 6 * k; P.n0 = kp.eosP[e]; P.n2 = kp.eosP[e + 1]; P.ns1t0 = kp.eosP[e + 2]; P.d0 = kp.eosP[e + 3]; P.d1 = kp.eosP[e + 4]; P.d3 = kp.eosP[e + 5]; }
+    const double rhokm = mwjf_eval2(P, xkm);
+    const double rhok = mwjf_eval2(P, xk);
+    double dbl = 0.0;
+    if (rhok != 0.0) dbl = GRAV * (1.0 - rhokm / rhok);
+    if (k - 1 >= kmt) dbl = 0.0;
+    DBLOC[c.base3 + (long long)(k - 2) * n2] = dbl;
+    double sh4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double du = up.u[t] - cu.u[t], dv = up.v[t] - cu.v[t];
+      sh4[t] = du * du + dv * dv;
+    }
+    double vsh = 0.25 * sh4[0] + 0.25 * sh4[1] + 0.25 * sh4[2] + 0.25 * sh4[3];
+    if (edge) vsh = 0.0;
+    const double ri = dbl * (kp.zgrid[k - 1] - kp.zgrid[k]) / (vsh + KPP_EPS);
+    const int m = k - 1;                              // the level ri belongs to
+    const double w = (m <= kmt) ? ri : carry;
+    if (m == kmt) carry = ri;
+    if (m >= 2) emit(m - 1, wpp, wp, w);
+    wpp = wp; wp = w;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { up.u[t] = cu.u[t]; up.v[t] = cu.v[t]; }
+    xkm = xk;
+  };
+  int k = 2;
+#pragma unroll 1
+  for (; k + 1 <= km; k += 2) { level(k, A, B); level(k + 1, B, A); }
+  if (k <= km) level(k, A, B);
+  DBLOC[c.base3 + (long long)(km - 1) * n2] = 0.0;
+  {
+    const double ri = 0.0 * (kp.zgrid[km] - kp.zgrid[km + 1]) / (0.0 + KPP_EPS);   // DBLOC(km) = 0, no shear below
+    const double w = (km <= kmt) ? ri : carry;
+    emit(km - 1, wpp, wp, w);
+    emit(km, wp, w, w);
   }
 }
 
@@ -936,7 +1050,10 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
 
 // ---- smooth_hblt + blmix + interior convection + masks + non-local source -------------------
 // PBC: partial bottom cells (vmix_kpp.F90:3835-3864, 2911-2923, 2948-2973, 3075-3083, 3155-3165, 1220-1222, 1296-1302)
-template <bool PBC = false>
+// SAME: the two tracer classes share one diffusivity array (KppDev::vdc_same; a template flag so that the level march below holds no
+// branch around a load or a store).  The march keeps the operands of the next level in flight (two operand sets used in turn).
+struct KppBlRaw { double visc, vd1, vd2, db; };
+template <bool PBC = false, bool SAME = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLOC, const double *__restrict__ STF1,
             const double *__restrict__ STF2, double *__restrict__ VISC, double *__restrict__ VDC1, double *__restrict__ VDC2,
@@ -1003,7 +1120,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     double fm[3], f0[3], fp[3];
     fm[0] = visc_at(k - 1); f0[0] = visc_at(k); fp[0] = visc_at(k + 1);
     fm[2] = VDC1[vb + (long long)(k - 1) * n2]; f0[2] = VDC1[vb + (long long)k * n2]; fp[2] = VDC1[vb + (long long)(k + 1) * n2];
-    if (!kp.vdc_same) { fm[1] = VDC2[vb + (long long)(k - 1) * n2]; f0[1] = VDC2[vb + (long long)k * n2]; fp[1] = VDC2[vb + (long long)(k + 1) * n2]; }
+    if (!SAME) { fm[1] = VDC2[vb + (long long)(k - 1) * n2]; f0[1] = VDC2[vb + (long long)k * n2]; fp[1] = VDC2[vb + (long long)(k + 1) * n2]; }
     else { fm[1] = fm[2]; f0[1] = f0[2]; fp[1] = fp[2]; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -1026,36 +1143,32 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     kpp_wscale<true>(fmin(sig, KPP_EPSSFC), hblt, ustar, bfsfc, wm1, ws1);
     dkm1[0] = shape(sig, wm1, 0); dkm1[1] = shape(sig, ws1, 1); dkm1[2] = shape(sig, ws1, 2);
   }
-  // level march: boundary-layer coefficients above KBL, convection + masks, non-local source
-  double flux1_prev = 0.0, flux2_prev = 0.0;   // VDC(k-1)*GHAT(k-1) per tracer class
+  // The level march in two parts (round 3).
+  // (1) Every level as an INTERIOR level -- convection + masks, and the non-local source of a level below the boundary layer
+  //     (ghat = 0) -- in one branch-free streaming loop with the next level's operands in flight: 3 loads, 4 stores and three
+  //     divisions per level, no divergent block around a memory operation.
+  // (2) The levels k < KBL again, now with the boundary-layer coefficients (similarity functions, shape function, the blending at
+  //     KBL - 1, which needs the interior values of that level: read before (1) overwrites them) and the non-local source down to
+  //     level KBL.  This is the divergent, arithmetic-heavy part; it touches KBL levels only.
+  // Every value is formed by the operations of the single loop it replaces (the reference's order): a level k < KBL takes its
+  // coefficients from (2), where the convective terms are +0.0 exactly as before, a level k >= KBL from (1).
   const double stf1 = STF1[c.q2], stf2 = STF2[c.q2];
-  for (int k = 1; k <= km; ++k) {
+  const int kb1 = (kbl - 1 >= 1) ? kbl - 1 : 1;                 // the level of the blending (clamped: KBL = 1 on land has none)
+  const double visc_b = VISC[c.base3 + (long long)(kb1 - 1) * n2], vd1_b = VDC1[vb + (long long)kb1 * n2];
+  const double vd2_b = SAME ? vd1_b : VDC2[vb + (long long)kb1 * n2];
+  auto load = [&](int k) {
+    KppBlRaw r;
     const long long o = c.base3 + (long long)(k - 1) * n2;
-    double visc = VISC[o], vd1 = VDC1[vb + (long long)k * n2], vd2 = (!kp.vdc_same) ? VDC2[vb + (long long)k * n2] : vd1;
-    double ghat = 0.0;
-    if (k < kbl) {
-      double sig = (-zgrid[k] + 0.5 * hwide[k]) / hblt;
-      if (PBC && k > 1) sig = (-zgrid[k - 1] + 0.5 * dzt_at(k - 1) + dzt_at(k)) / hblt;
-      double wmk, wsk;
-      kpp_wscale<true>(fmin(sig, KPP_EPSSFC), hblt, ustar, bfsfc, wmk, wsk);
-      double b0 = shape(sig, wmk, 0), b1 = shape(sig, wsk, 1), b2 = shape(sig, wsk, 2);
-      ghat = (1.0 - stable) * kp.cg / (wsk * hblt + KPP_EPS);
-      if (k == kbl - 1 && k <= km - 1) {
-        double dh = (hblt + zgrid[k]) / (zgrid[k] - zgrid[k + 1]);
-        if (PBC) {
-          const double w1 = (k == 1) ? -0.5 * dzt_at(k) : zgrid[k - 1] - 0.5 * (dzt_at(k - 1) + dzt_at(k));
-          dh = (hblt + w1) / (0.5 * (dzt_at(k) + dzt_at(k + 1)));
-        }
-        const double omd = 1.0 - dh;
-        b0 = omd * visc + dh * ((omd * omd) * dkm1[0] + (dh * dh) * (casea * visc + (1.0 - casea) * b0));
-        b1 = omd * vd2 + dh * ((omd * omd) * dkm1[1] + (dh * dh) * (casea * vd2 + (1.0 - casea) * b1));
-        b2 = omd * vd1 + dh * ((omd * omd) * dkm1[2] + (dh * dh) * (casea * vd1 + (1.0 - casea) * b2));
-        ghat = (1.0 - casea) * ghat;
-      }
-      visc = b0; vd2 = b1; vd1 = b2;
-    }
+    r.visc = VISC[o]; r.vd1 = VDC1[vb + (long long)k * n2]; r.vd2 = SAME ? 0.0 : VDC2[vb + (long long)k * n2]; r.db = DBLOC[o];
+    return r;
+  };
+  auto level = [&](int k, const KppBlRaw &cu, KppBlRaw &nx) {
+    nx = load(k + 1 <= km ? k + 1 : km);
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    const double zk = zgrid.u(k), zk1 = zgrid.u(k + 1), dz_k = g.dz.u(k);
+    double visc = cu.visc, vd1 = cu.vd1, vd2 = SAME ? cu.vd1 : cu.vd2;
     if (k <= km - 1) {
-      const double N2 = PBC ? DBLOC[o] / (0.5 * (dzt_at(k) + dzt_at(k + 1))) : DBLOC[o] / (zgrid[k] - zgrid[k + 1]);
+      const double N2 = PBC ? cu.db / (0.5 * (dzt_at(k) + dzt_at(k + 1))) : cu.db / (zk - zk1);
       const double fcon = (N2 > 0.0) ? 0.0 : 1.0;
       double cvv = 0.0, cvd = 0.0;
       if (k >= kbl) { cvv = sp.convect_visc * fcon; cvd = sp.convect_diff * fcon; }
@@ -1064,11 +1177,58 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     } else { vd1 = 0.0; vd2 = 0.0; }
     VISC[o] = visc;
     VDC1[vb + (long long)k * n2] = vd1;
-    if (!kp.vdc_same) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
+    if (!SAME) VDC2[vb + (long long)k * n2] = vd2;   // one array when the two classes share their values (no double diffusion)
+    const double fl1 = vd1 * 0.0, fl2 = vd2 * 0.0;  // ghat = 0 below the boundary layer
+    const double dzk = (PBC && k > 1) ? dzt_at(k) : dz_k;
+    const double p1 = (k == 1) ? -fl1 : 0.0 - fl1, p2 = (k == 1) ? -fl2 : 0.0 - fl2;
+    SRC1[o] = stf1 / dzk * p1; SRC2[o] = stf2 / dzk * p2;
+  };
+  {
+    KppBlRaw A = load(1), B;
+    int k = 1;
+#pragma unroll 1
+    for (; k + 1 <= km; k += 2) { level(k, A, B); level(k + 1, B, A); }
+    if (k <= km) level(k, A, B);
+  }
+  // (2) the boundary layer
+  double flux1_prev = 0.0, flux2_prev = 0.0;   // VDC(k-1)*GHAT(k-1) per tracer class
+#pragma unroll 1
+  for (int k = 1; k <= kbl && k <= km; ++k) {
+    const long long o = c.base3 + (long long)(k - 1) * n2;
+    const double dzk = (PBC && k > 1) ? dzt_at(k) : g.dz[k];
+    if (k == kbl) {     // first level below: its source still feels the flux through its upper face
+      if (k > 1) { SRC1[o] = stf1 / dzk * (flux1_prev - 0.0); SRC2[o] = stf2 / dzk * (flux2_prev - 0.0); }
+      break;
+    }
+    double sig = (-zgrid[k] + 0.5 * hwide[k]) / hblt;
+    if (PBC && k > 1) sig = (-zgrid[k - 1] + 0.5 * dzt_at(k - 1) + dzt_at(k)) / hblt;
+    double wmk, wsk;
+    kpp_wscale<true>(fmin(sig, KPP_EPSSFC), hblt, ustar, bfsfc, wmk, wsk);
+    double b0 = shape(sig, wmk, 0), b1 = shape(sig, wsk, 1), b2 = shape(sig, wsk, 2);
+    double ghat = (1.0 - stable) * kp.cg / (wsk * hblt + KPP_EPS);
+    if (k == kbl - 1 && k <= km - 1) {
+      double dh = (hblt + zgrid[k]) / (zgrid[k] - zgrid[k + 1]);
+      if (PBC) {
+        const double w1 = (k == 1) ? -0.5 * dzt_at(k) : zgrid[k - 1] - 0.5 * (dzt_at(k - 1) + dzt_at(k));
+        dh = (hblt + w1) / (0.5 * (dzt_at(k) + dzt_at(k + 1)));
+      }
+      const double omd = 1.0 - dh;
+      b0 = omd * visc_b + dh * ((omd * omd) * dkm1[0] + (dh * dh) * (casea * visc_b + (1.0 - casea) * b0));
+      b1 = omd * vd2_b + dh * ((omd * omd) * dkm1[1] + (dh * dh) * (casea * vd2_b + (1.0 - casea) * b1));
+      b2 = omd * vd1_b + dh * ((omd * omd) * dkm1[2] + (dh * dh) * (casea * vd1_b + (1.0 - casea) * b2));
+      ghat = (1.0 - casea) * ghat;
+    }
+    double visc = b0, vd2 = b1, vd1 = b2;
+    if (k <= km - 1) {
+      if (k < kmt) { visc = visc + 0.0; vd1 = vd1 + 0.0; vd2 = vd2 + 0.0; }   // the convective terms of a level above KBL
+      else { visc = 0.0; vd1 = 0.0; vd2 = 0.0; }
+    } else { vd1 = 0.0; vd2 = 0.0; }
+    VISC[o] = visc;
+    VDC1[vb + (long long)k * n2] = vd1;
+    if (!SAME) VDC2[vb + (long long)k * n2] = vd2;
     const double fl1 = vd1 * ghat, fl2 = vd2 * ghat;
-    if (k == 1) { SRC1[o] = stf1 / g.dz[1] * (-fl1); SRC2[o] = stf2 / g.dz[1] * (-fl2); }
-    else if (PBC) { SRC1[o] = stf1 / dzt_at(k) * (flux1_prev - fl1); SRC2[o] = stf2 / dzt_at(k) * (flux2_prev - fl2); }
-    else { SRC1[o] = stf1 / g.dz[k] * (flux1_prev - fl1); SRC2[o] = stf2 / g.dz[k] * (flux2_prev - fl2); }
+    if (k == 1) { SRC1[o] = stf1 / dzk * (-fl1); SRC2[o] = stf2 / dzk * (-fl2); }
+    else { SRC1[o] = stf1 / dzk * (flux1_prev - fl1); SRC2[o] = stf2 / dzk * (flux2_prev - fl2); }
     flux1_prev = fl1; flux2_prev = fl2;
   }
 }
@@ -1268,6 +1428,13 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   if (up(bvdc.data(), bvdc.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.bckgrnd_vdc = (double *)p;
   if (up(bvvc.data(), bvvc.size() * 8, &p)) { err = "kpp alloc"; return 1; } k.bckgrnd_vvc = (double *)p;
   if (up(kref.data(), kref.size() * 4, &p)) { err = "kpp alloc"; return 1; } k.kref = (int *)p;
+  {
+    std::vector<double> z6(6 * (km + 3), 0.0);
+    if (up(z6.data(), z6.size() * 8, &p)) { err = "kpp alloc"; return 1; }
+    if (km + 1 <= 1024) hipLaunchKernelGGL(k_kpp_level_table, dim3(1), dim3(km + 1), 0, 0, g, (double *)p);
+    if (hipDeviceSynchronize() != hipSuccess) { err = "kpp: level table"; return 1; }
+    k.eosP = (double *)p;
+  }
   const size_t a2 = h.n2 * h.nblocks;
   std::vector<double> z(a2, 0.0);
   if (up(z.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } k.HBLT0 = (double *)p;
@@ -1297,9 +1464,9 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   // the column form halves the instruction count by hoisting the pressure-independent half of the equation of
   // state, but its 3 x 20 register doubles leave one wave per SIMD).  POP_KPP_COL = bit mask (1 ushear,
   // 2 buoydiff) overrides.
-  K->col = (K->max_kref <= 24) ? ((h.n2 * h.nblocks > (1u << 19)) ? 15 : 1) : 0;   // ushear: column form at every size (gx1v7 vmix 0.716 -> 0.692 ms)
-  if (tun_set(h.tun.kpp_col)) K->col = (K->max_kref <= 24) ? h.tun.kpp_col : 0;   // bit 0 ushear column form, bit 1 buoydiff column form, bit 2 buoydiff LDS form, bit 3 buoydiff + interior fused
-  (void)g; (void)m;
+  K->col = (K->max_kref <= 24) ? ((h.n2 * h.nblocks > (1u << 19)) ? 31 : 1) : 0;   // ushear: column form at every size (gx1v7 vmix 0.716 -> 0.692 ms)
+  if (tun_set(h.tun.kpp_col)) K->col = (K->max_kref <= 24) ? h.tun.kpp_col : 0;   // bit 0 ushear column form, bit 1 buoydiff column form, bit 2 buoydiff LDS form, bit 3 buoydiff + interior fused, bit 4 as one column march
+  (void)m;
   return 0;
 }
 
@@ -1346,8 +1513,10 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
     hipLaunchKernelGGL(k_kpp_interior<true>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
     hipLaunchKernelGGL((k_kpp_bldepth<false, 20, true>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                        (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
-    hipLaunchKernelGGL(k_kpp_blmix<true>, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
-                       s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+    if (g_kpp.vdc_same) hipLaunchKernelGGL((k_kpp_blmix<true, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+                                            s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+    else hipLaunchKernelGGL((k_kpp_blmix<true, false>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+                            s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
     const int vp = patch_rows(g, h.tun.del4_tile);
     hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vp), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vp ? 64 * vp : 256), 0, st, g, (const double *)VISC, s.VVC, vp);
     if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }
@@ -1359,7 +1528,10 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   // two waves per SIMD (<= 256 VGPRs, ~80 spilled) beat one wave with everything in registers: the kernel is VALU-bound
   // and a second wave fills the division / dependency stalls of the first (POP_KPP_BUOY_WAVES=1 keeps one wave)
   const int bw = tun_or(h.tun.kpp_buoy_waves, 2);
-  if (lazy && fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8, false>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
+  // bit 4: the two as one column march (one smoothing pass, no double diffusion)
+  const bool march = lazy && fused_bi && (g_kpp_col & 16) && g_kpp.nsmooth == 1 && !g_kpp.ldbl_diff && g.km >= 3;
+  if (march) hipLaunchKernelGGL(k_kpp_buoy_interior_march, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, VISC, s.VDC[0], s.VDC[1]);
+  else if (lazy && fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8, false>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if (fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if ((g_kpp_col & 4) && KH.max_kref <= 20 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<20, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
   else if ((g_kpp_col & 4) && KH.max_kref <= 28 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<28, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
@@ -1393,8 +1565,10 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                                     (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
   else hipLaunchKernelGGL((k_kpp_bldepth<false, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                           (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
-  hipLaunchKernelGGL(k_kpp_blmix<false>, GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
-                     s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+  if (g_kpp.vdc_same) hipLaunchKernelGGL((k_kpp_blmix<false, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+                                          s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+  else hipLaunchKernelGGL((k_kpp_blmix<false, false>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+                          s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
   const int vpatch = patch_rows(g, h.tun.del4_tile);   // large grids: 64 x 4 patches (the row j + 1 of the four-point average is read by the same workgroup)
   hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vpatch), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vpatch ? 64 * vpatch : 256), 0, st, g, (const double *)VISC, s.VVC, vpatch);
   if (h.c.kpp_ml_diagnostics == 1 && s.HMXL && s.HMXL_DR)

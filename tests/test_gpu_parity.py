@@ -580,6 +580,35 @@ def test_kpp_on_demand_surface_buoyancy_is_bitwise_invisible(pkg, orclib_built, 
             assert np.array_equal(a, b), v
 
 
+@pytest.mark.parametrize("kw", [
+    {"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21},
+    {"vmix_choice": 3, "km": 60, "block_size_x": 48, "block_size_y": 40},
+    {"vmix_choice": 3, "km": 24, "stepped_bathymetry": 1, "lrich": 0},
+    {"vmix_choice": 3, "km": 21, "ns_boundary": 1},                                   # odd level count: the two-level loop ends on its tail
+], ids=["km62-stepped-del4", "km60-blocks", "km24-no-shear-term", "km21-cyclic"])
+def test_kpp_interior_column_march_is_bitwise_the_level_parallel_kernel(pkg, orclib_built, monkeypatch, kw):
+    """k_kpp_buoy_interior_march (buoydiff + ri_iwmix as one column walk, POP_KPP_COL bit 4) against the level-parallel LDS
+    kernel (bits 0-3) and against the separate buoydiff / interior kernels (bits 0-1): every output of four steps equal to
+    the last bit, shallow and land columns included."""
+    monkeypatch.setenv("POP_XCD_REMAP", "0")
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for col in ("31", "15", "3"):
+        monkeypatch.setenv("POP_KPP_COL", col)
+        m, orc = pkg.PopModel(cfg), Oracle(cfg)
+        force_kpp_case(m, orc)
+        orc.close()
+        assert m.tuning()["kpp_col"] == int(col)
+        for _ in range(4):
+            m.step()
+        out[col] = [m.get("HBLT").copy(), m.get("VDC", 1, 0).copy(), m.get("VVC").copy()] + [m.get("KPP_SRC", 1, n).copy() for n in (0, 1)] + \
+                   [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "RHO")] + [m.get("TRACER", 1, 1).copy()]
+        m.close()
+    for col in ("15", "3"):
+        for a, b in zip(out["31"], out[col]):
+            assert np.array_equal(a, b), col
+
+
 @pytest.mark.parametrize("kw,env", [
     ({"vmix_choice": 3, "km": 24}, {}),
     ({"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1}, {"POP_KPP_AHEAD": "1", "POP_KPP_COL": "15", "POP_XCD_REMAP": "0"}),   # look-ahead: KBL travels with its KPP_SRC
