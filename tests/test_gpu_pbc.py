@@ -133,3 +133,68 @@ def test_tracer_content_is_conserved_with_partial_bottom_cells(pkg, kw):
     for n in (0, 1):
         assert abs(content(n) - c0[n]) <= 2e-9 * abs(c0[n]), (kw, n, content(n), c0[n])
     m.close()
+
+
+def test_partial_bottom_cells_at_a_quarter_of_tx01v3(pkg, orclib_built):
+    """Size-independent properties at 1800 x 1200 x 62 (a quarter of the tx0.1v3 columns; KPP + biharmonic mixing + stepped
+    bathymetry, the production kernel selection for large grids), where the oracle is out of reach:
+      * geometry: DZUB is the minimum over the four surrounding T columns of DZT at level KMU (grid.F90:1003-1020);
+      * with no surface flux the volume integral of each tracer, every bottom cell counted with ITS thickness, is unchanged
+        to rounding over leapfrog steps;
+      * the boundary layer never reaches below the column's own depth zw(KMT-1) + DZBC (vmix_kpp.F90:3835-3864);
+      * land stays land: velocities below KMU and tracers below KMT are exactly zero."""
+    cfg = named_config("tx0.1v3", nx_global=1800, ny_global=1200, block_size_x=1800, block_size_y=1200,
+                       stepped_bathymetry=1, partial_bottom_cells=1)
+    o = Oracle(named_config("tiny", km=cfg.km))            # the vertical grid depends on km only (bit-compared in test_host_grid_parity)
+    dz, zw = o.v1("dz")[1:cfg.km + 1].copy(), o.v1("zw")[0:cfg.km + 1].copy()
+    o.close()
+    m = pkg.PopModel(cfg)
+    km = cfg.km
+    tarea, kmt, kmu, dzbc, dzub = m.get("TAREA"), m.geti("KMT"), m.geti("KMU"), m.get("DZBC"), m.get("DZUB")
+    # geometry (every U point whose four T columns lie inside the block array)
+    lev = kmu[:, :-1, :-1]
+    quad = [q for q in (
+        np.where(lev == kmt[:, :-1, :-1], dzbc[:, :-1, :-1], dz[np.clip(lev, 1, km) - 1]),
+        np.where(lev == kmt[:, :-1, 1:], dzbc[:, :-1, 1:], dz[np.clip(lev, 1, km) - 1]),
+        np.where(lev == kmt[:, 1:, :-1], dzbc[:, 1:, :-1], dz[np.clip(lev, 1, km) - 1]),
+        np.where(lev == kmt[:, 1:, 1:], dzbc[:, 1:, 1:], dz[np.clip(lev, 1, km) - 1]))]
+    expect = np.minimum(np.minimum(quad[0], quad[1]), np.minimum(quad[2], quad[3]))
+    ocean_u = lev > 0
+    assert ocean_u.sum() > 1000000
+    assert np.array_equal(dzub[:, :-1, :-1][ocean_u], expect[ocean_u])
+    assert (dzbc[kmt > 0] > 0.2 * dz[kmt[kmt > 0] - 1]).all() and (dzbc[kmt > 0] <= dz[kmt[kmt > 0] - 1]).all()
+    assert (dzbc[kmt > 0] < dz[kmt[kmt > 0] - 1]).mean() > 0.5          # most bottom cells are partial
+    k = np.arange(1, km + 1)[None, :, None, None]
+    inner = (slice(None), slice(None), slice(2, -2), slice(2, -2))
+    wet = (k <= kmt[:, None])[inner]
+    bottom = (k == kmt[:, None])[inner]
+
+    def content(n):
+        T = m.get("TRACER", 1, n)[inner]
+        thick = np.where(bottom, dzbc[:, None, 2:-2, 2:-2], dz[None, :, None, None])
+        thick[:, 0] = thick[:, 0] + m.get("PSURF", 1)[:, 2:-2, 2:-2] / 980.6
+        return float((np.where(wet, T * thick, 0.0) * tarea[:, None, 2:-2, 2:-2]).sum(dtype=np.longdouble))
+
+    for _ in range(3):
+        m.step()
+    c0 = [content(n) for n in (0, 1)]
+    for _ in range(4):
+        m.step()
+    for n in (0, 1):
+        c1 = content(n)
+        assert abs(c1 - c0[n]) <= 2e-9 * abs(c0[n]), (n, c1, c0[n])
+    u = m.get("UVEL", 1)
+    assert np.abs(u).max() > 0.1
+    assert np.abs(np.where(k <= kmu[:, None], 0.0, u)).max() == 0.0
+    del u
+    t = m.get("TRACER", 1, 0)
+    assert np.abs(np.where(k <= kmt[:, None], 0.0, t)).max() == 0.0
+    del t
+    depth = zw[np.clip(kmt, 1, km) - 1] + dzbc             # zw(KMT-1) + DZBC
+    hblt = m.get("HBLT")
+    sel = (kmt > 0)
+    sel[:, :2, :] = False; sel[:, -2:, :] = False; sel[:, :, :2] = False; sel[:, :, -2:] = False
+    assert (hblt[sel] <= depth[sel] * (1.0 + 1e-14)).all() and (hblt[sel] > 0.0).all()
+    its = m.solver_diagnostics()[0]
+    assert 0 < its < cfg.max_iterations
+    m.close()
