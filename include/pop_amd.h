@@ -276,6 +276,11 @@ int pop_solver_preconditioner(pop_ctx *ctx, const char *x_name, int x_tl, const 
  * op 2  zcurl(k, CURL, UX, UY)     :199-272   a, b at U points -> o1 at T points, times the cell area
  * A 3-D field name selects its level-k slab; tl applies to names with time levels. */
 int pop_operator(pop_ctx *ctx, int op, int k, const char *a_name, const char *b_name, int tl, const char *o1_name, const char *o2_name);
+/* The same three operators with the reference's own argument lists -- div(k, DIV_OUT, UX, UY, this_block) operators.F90:49,
+ * grad(k, GRADX, GRADY, F, this_block) :126, zcurl(k, CURL, UX, UY, this_block) :199 --: host arrays (nx_block, ny_block) of ONE
+ * block, block_local = this_block%local_id (1-based).  a (and b for div / zcurl) in, o1 (and o2 for grad) out; the arrays are
+ * staged through the GPU (the kernel is the one pop_operator launches). */
+int pop_operator_host(pop_ctx *ctx, int op, int k, int block_local, const double *a, const double *b, double *o1, double *o2);
 /* POP_SolversGetDiagnostics(iterationCount, residual, errorCode) :1158 */
 int pop_solver_get_diagnostics(const pop_ctx *ctx, int *iterations, double *rms_residual);
 /* state(k,kk,TEMPK,SALTK,this_block,RHOOUT,...) state_mod.F90:258 on n device-resident or

@@ -73,6 +73,7 @@ def lib():
         "pop_solver_diagonal": (ci, [vp, ci, pd]),
         "pop_solver_preconditioner": (ci, [vp, cs, ci, cs, ci]),
         "pop_operator": (ci, [vp, ci, ci, cs, cs, ci, cs, cs]),
+        "pop_operator_host": (ci, [vp, ci, ci, ci, vp, vp, vp, vp]),
         "pop_solver_get_diagnostics": (ci, [vp, pi, pd]),
         "pop_state_host": (ci, [vp, ci, pd, pd, pd, pd, pd, ll]),
         "pop_set_comm": (ci, [vp, vp, vp, vp, ll, XCHG_FN, ALLRED_FN, vp]),
@@ -383,6 +384,18 @@ class PopModel:
         """operators.F90 grad / div / zcurl at level k on named device fields (results in o1 [, o2])"""
         self._chk(self.L.pop_operator(self.h, {"grad": 0, "div": 1, "zcurl": 2}[op], k, a.encode(), (b or a).encode(), tl,
                                       o1.encode(), o2.encode()))
+
+    def operator_host(self, op, k, block_local, a, b=None):
+        """the reference's argument lists (operators.F90:49, 126, 199) on host arrays (ny_block, nx_block) of ONE local block,
+        block_local = this_block%local_id (1-based): grad -> (GRADX, GRADY), div / zcurl -> one array"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.shape == (self.nyb, self.nxb)
+        bb = np.ascontiguousarray(b if b is not None else a, dtype=np.float64)
+        o1, o2 = np.empty_like(a), np.empty_like(a)
+        code = {"grad": 0, "div": 1, "zcurl": 2}[op]
+        self._chk(self.L.pop_operator_host(self.h, code, k, block_local, a.ctypes.data, bb.ctypes.data if code else None,
+                                           o1.ctypes.data, o2.ctypes.data if code == 0 else None))
+        return (o1, o2) if code == 0 else o1
 
     def solver_run(self):
         self._chk(self.L.pop_solver_run(self.h))

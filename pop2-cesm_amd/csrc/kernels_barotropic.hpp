@@ -89,8 +89,9 @@ __global__ void k_btrop_fin2(DevGrid g, StepParams sp, BtropArgs a) {
 // ---- operators.F90 as stand-alone entry points (pop_operator): grad :126-192, div :49-119, zcurl :199-272 on one
 // horizontal slab at level k (the time step itself has them inlined in its kernels)
 __global__ void k_operator(DevGrid g, int op, int k, const double *__restrict__ A, const double *__restrict__ Bf,
-                           double *__restrict__ O1, double *__restrict__ O2, long long blk_stride_in, long long blk_stride_out) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+                           double *__restrict__ O1, double *__restrict__ O2, long long blk_stride_in, long long blk_stride_out, int b0) {
+  // b0: first block of the launch (pop_operator_host works on one block: grid y = 1, strides 0, b0 = that block)
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y + b0;
   if (p2 >= g.n2) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
   const long long q = (long long)b * g.n2 + p2, qi = (long long)b * blk_stride_in + p2, qo = (long long)b * blk_stride_out + p2;

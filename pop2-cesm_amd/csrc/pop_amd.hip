@@ -148,6 +148,7 @@ struct pop_ctx {
   double solver_ms_total = 0.0; long long solver_iters_total = 0, solver_calls_total = 0;
   bool timing = false;
   bool phase_timing = false;   // inside pop_time_phase: kernels only
+  double *op_scratch = nullptr;   // pop_operator_host: four block-sized 2-D arrays
 };
 
 namespace {
@@ -2465,8 +2466,27 @@ int pop_operator(pop_ctx *c, int op, int k, const char *a_name, const char *b_na
   if (op == 0 && slab(o2_name, tl, &O2, &so2)) return 1;
   if (sb != sa || (op == 0 && so2 != so1)) { c->err = "pop_operator: the two inputs (outputs) must have the same rank"; return 1; }
   hipLaunchKernelGGL(k_operator, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, op, k,
-                     (const double *)A, (const double *)B, O1, O2 ? O2 : O1, sa, so1);
+                     (const double *)A, (const double *)B, O1, O2 ? O2 : O1, sa, so1, 0);
   HIPCHK(c, hipGetLastError());
+  return 0;
+}
+int pop_operator_host(pop_ctx *c, int op, int k, int block_local, const double *a, const double *b, double *o1, double *o2) {
+  if (need_device(c)) return 1;
+  if (join_side(c)) return 1;
+  if (op < 0 || op > 2 || k < 1 || k > c->g.km) { c->err = "pop_operator_host: op 0 grad, 1 div, 2 zcurl; 1 <= k <= km"; return 1; }
+  if (block_local < 1 || block_local > c->g.nblocks) { c->err = "pop_operator_host: block_local is this_block%local_id, 1 .. nblocks"; return 1; }
+  if (!a || !o1 || (op != 0 && !b) || (op == 0 && !o2)) { c->err = "pop_operator_host: grad(F -> GRADX, GRADY), div / zcurl(UX, UY -> one field)"; return 1; }
+  const size_t n2 = (size_t)c->g.n2;
+  if (!c->op_scratch && dev_alloc(c, &c->op_scratch, 4 * n2)) return 1;
+  double *A = c->op_scratch, *B = A + n2, *O1 = B + n2, *O2 = O1 + n2;
+  HIPCHK(c, hipMemcpyAsync(A, a, n2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (op != 0) HIPCHK(c, hipMemcpyAsync(B, b, n2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_operator, dim3((c->g.n2 + 255) / 256, 1), dim3(256), 0, c->stream, c->g, op, k,
+                     (const double *)A, (const double *)(op != 0 ? B : A), O1, O2, 0LL, 0LL, block_local - 1);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(o1, O1, n2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (op == 0) HIPCHK(c, hipMemcpyAsync(o2, O2, n2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 int pop_solver_get_diagnostics(const pop_ctx *c, int *it, double *rms) {

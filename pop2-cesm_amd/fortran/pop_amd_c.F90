@@ -271,6 +271,12 @@
          integer (c_int), value :: op, k, tl
          character (kind=c_char), intent(in) :: aname(*), bname(*), o1name(*), o2name(*)
       end function
+      integer (c_int) function pop_operator_host(ctx, op, k, block_local, a, b, o1, o2) bind(C, name='pop_operator_host')
+         import :: c_int, c_ptr
+         type (c_ptr), value :: ctx
+         integer (c_int), value :: op, k, block_local
+         type (c_ptr), value :: a, b, o1, o2
+      end function
       integer (c_int) function pop_solver_preconditioner(ctx, xname, xtl, pxname, pxtl) bind(C, name='pop_solver_preconditioner')
          import :: c_int, c_ptr, c_char
          type (c_ptr), value :: ctx

@@ -262,8 +262,10 @@
       module procedure POP_GlobalSum2DR8, POP_GlobalSumField
    end interface
  contains
-   ! POP_GlobalSum2DR8(array, dist, fieldLoc, errorCode, mMask) :144-187: array(nx_block,ny_block,nblocks) on the host
-   function POP_GlobalSum2DR8(array, dist, fieldLoc, errorCode, mMask) result(globalSum)
+   ! POP_GlobalSum2DR8(array, dist, fieldLoc, errorCode, mMask, lMask) :144-187: array(nx_block,ny_block,nblocks) on the host.
+   ! lMask (:281-306): only the cells where it is true are added; they are passed on as the array with +0 elsewhere
+   ! (adding +0 leaves a sum as it is), so that a masked-out Inf or NaN does not reach the sum either
+   function POP_GlobalSum2DR8(array, dist, fieldLoc, errorCode, mMask, lMask) result(globalSum)
       use POP_DistributionMod, only: POP_distrb
       use POP_GridHorzMod, only: POP_gridHorzLocCode
       real (POP_r8), dimension(:,:,:), intent(in) :: array
@@ -271,7 +273,9 @@
       character (*), intent(in) :: fieldLoc
       integer (POP_i4), intent(out) :: errorCode
       real (POP_r8), dimension(:,:,:), intent(in), target, optional :: mMask
+      logical (log_kind), dimension(:,:,:), intent(in), optional :: lMask
       real (POP_r8) :: globalSum
+      real (POP_r8), dimension(:,:,:), allocatable :: picked
       integer (POP_i4) :: loc
       globalSum = 0.0_POP_r8
       loc = POP_gridHorzLocCode(fieldLoc)
@@ -281,6 +285,11 @@
       endif
       if (present(mMask)) then
          errorCode = pop_global_sum_host(pop_ctx, array, c_loc(mMask), loc, globalSum)
+      else if (present(lMask)) then
+         allocate(picked(size(array,1), size(array,2), size(array,3)))
+         picked = merge(array, 0.0_POP_r8, lMask)
+         errorCode = pop_global_sum_host(pop_ctx, picked, c_null_ptr, loc, globalSum)
+         deallocate(picked)
       else
          errorCode = pop_global_sum_host(pop_ctx, array, c_null_ptr, loc, globalSum)
       endif
@@ -547,8 +556,32 @@
    implicit none
    private
    public :: global_sum, global_sum_prod, global_count, global_maxval, global_minval
+   ! pop_constants.F90:77-83
+   integer (int_kind), parameter, public :: field_loc_unknown = 0, field_loc_noupdate = -1, field_loc_center = 1, &
+                                            field_loc_NEcorner = 2, field_loc_Nface = 3, field_loc_Eface = 4
+   interface global_sum          ! the reference's list (host array, :383) and the named device-resident field
+      module procedure global_sum_dbl, global_sum_named
+   end interface
  contains
-   function global_sum(name, timeLevel, n, mMask) result(s)        ! :383-614
+   ! global_sum_dbl(X, dist, field_loc, MASK) :383-614: X(nx_block,ny_block,nblocks) on the host, integer field_loc
+   function global_sum_dbl(X, dist, field_loc, MASK) result(s)
+      use POP_DistributionMod, only: POP_distrb
+      real (r8), dimension(:,:,:), intent(in) :: X
+      type (POP_distrb), intent(in) :: dist
+      integer (int_kind), intent(in) :: field_loc
+      real (r8), dimension(:,:,:), intent(in), target, optional :: MASK
+      real (r8) :: s
+      integer (POP_i4) :: errorCode
+      s = 0.0_r8
+      if (field_loc < field_loc_center .or. field_loc > field_loc_Eface) stop 'global_sum: field_loc'
+      if (present(MASK)) then
+         errorCode = pop_global_sum_host(pop_ctx, X, c_loc(MASK), field_loc - 1, s)
+      else
+         errorCode = pop_global_sum_host(pop_ctx, X, c_null_ptr, field_loc - 1, s)
+      endif
+      if (errorCode /= 0) stop 'global_sum failed'
+   end function
+   function global_sum_named(name, timeLevel, n, mMask) result(s)
       character (*), intent(in) :: name
       integer (POP_i4), intent(in) :: timeLevel, n
       character (*), intent(in), optional :: mMask
@@ -597,20 +630,53 @@
    implicit none
    private
    public :: grad, div, zcurl
+   interface grad                ! the reference's list (host arrays of one block) and named device fields
+      module procedure grad_ref, grad_named
+   end interface
+   interface div
+      module procedure div_ref, div_named
+   end interface
+   interface zcurl
+      module procedure zcurl_ref, zcurl_named
+   end interface
  contains
-   subroutine grad(k, gradxName, gradyName, fName, timeLevel, errorCode)      ! :126-192
+   subroutine grad_ref(k, GRADX, GRADY, F, this_block)                        ! operators.F90:126
+      use blocks, only: block
+      integer (int_kind), intent(in) :: k
+      real (r8), dimension(:,:), intent(in), target :: F
+      real (r8), dimension(:,:), intent(out), target :: GRADX, GRADY
+      type (block), intent(in) :: this_block
+      if (pop_operator_host(pop_ctx, 0, k, this_block%local_id, c_loc(F), c_null_ptr, c_loc(GRADX), c_loc(GRADY)) /= 0) stop 'grad failed'
+   end subroutine
+   subroutine div_ref(k, DIV_OUT, UX, UY, this_block)                         ! operators.F90:49
+      use blocks, only: block
+      integer (int_kind), intent(in) :: k
+      real (r8), dimension(:,:), intent(in), target :: UX, UY
+      real (r8), dimension(:,:), intent(out), target :: DIV_OUT
+      type (block), intent(in) :: this_block
+      if (pop_operator_host(pop_ctx, 1, k, this_block%local_id, c_loc(UX), c_loc(UY), c_loc(DIV_OUT), c_null_ptr) /= 0) stop 'div failed'
+   end subroutine
+   subroutine zcurl_ref(k, CURL, UX, UY, this_block)                          ! operators.F90:199
+      use blocks, only: block
+      integer (int_kind), intent(in) :: k
+      real (r8), dimension(:,:), intent(in), target :: UX, UY
+      real (r8), dimension(:,:), intent(out), target :: CURL
+      type (block), intent(in) :: this_block
+      if (pop_operator_host(pop_ctx, 2, k, this_block%local_id, c_loc(UX), c_loc(UY), c_loc(CURL), c_null_ptr) /= 0) stop 'zcurl failed'
+   end subroutine
+   subroutine grad_named(k, gradxName, gradyName, fName, timeLevel, errorCode)      ! :126-192
       integer (POP_i4), intent(in) :: k, timeLevel
       character (*), intent(in) :: gradxName, gradyName, fName
       integer (POP_i4), intent(out) :: errorCode
       errorCode = pop_operator(pop_ctx, 0, k, cstr(fName), cstr(fName), timeLevel, cstr(gradxName), cstr(gradyName))
    end subroutine
-   subroutine div(k, divName, uxName, uyName, timeLevel, errorCode)           ! :49-119
+   subroutine div_named(k, divName, uxName, uyName, timeLevel, errorCode)           ! :49-119
       integer (POP_i4), intent(in) :: k, timeLevel
       character (*), intent(in) :: divName, uxName, uyName
       integer (POP_i4), intent(out) :: errorCode
       errorCode = pop_operator(pop_ctx, 1, k, cstr(uxName), cstr(uyName), timeLevel, cstr(divName), cstr(divName))
    end subroutine
-   subroutine zcurl(k, curlName, uxName, uyName, timeLevel, errorCode)        ! :199-272
+   subroutine zcurl_named(k, curlName, uxName, uyName, timeLevel, errorCode)        ! :199-272
       integer (POP_i4), intent(in) :: k, timeLevel
       character (*), intent(in) :: curlName, uxName, uyName
       integer (POP_i4), intent(out) :: errorCode

@@ -8,7 +8,7 @@
 !    call barotropic_driver(ZX, ZY, errorCode)
 !    call baroclinic_correct_adjust
 ! followed by the library's step tail, a global sum with the reference's POP_GlobalSum(array, dist, fieldLoc,
-! errorCode, mMask) and -- once -- a stand-alone POP_SolversRun(sfcPressure, rhsClinic, errorCode) that must reproduce
+! errorCode, mMask | lMask), the legacy global_sum(X, dist, field_loc, MASK), grad / div / zcurl(k, ..., this_block) and -- once -- a stand-alone POP_SolversRun(sfcPressure, rhsClinic, errorCode) that must reproduce
 ! the pressure the step just computed.  Prints the same checksums as pop_driver.F90 (named-field forms), so the
 ! test suite can compare both with the Python-driven run.
 !   pop_driver_ref <nx> <ny> <km> <bx> <by> <vmix> <nsteps> [<ns_boundary> <horiz_grid_file> <topography_file>]
@@ -23,6 +23,8 @@
    use POP_DomainMod, only: POP_haloClinic, POP_distrbClinic
    use POP_HaloMod, only: POP_HaloUpdate, POP_HaloCreate
    use POP_ReductionsMod, only: POP_GlobalSum
+   use global_reductions, only: global_sum, field_loc_center
+   use operators, only: grad, div, zcurl
    use POP_SolversMod, only: POP_SolversRun, POP_SolversGetDiagnostics
    use surface_hgt, only: dhdt
    use baroclinic, only: baroclinic_driver, baroclinic_correct_adjust
@@ -33,6 +35,10 @@
    integer (POP_i4) :: errorCode, nsteps, n, iters, iters2
    real (POP_r8), allocatable, dimension(:,:,:) :: DH, DHU, ZX, ZY, PSURF, RHS, GUESS, MASK, T1
    real (POP_r8) :: rms, tsum, psum, dmax
+   real (POP_r8), allocatable, dimension(:,:) :: GX, GY, DV, CU
+   integer (c_int), allocatable :: ids(:)
+   type (block) :: this_block
+   integer (POP_i4) :: iblock
    character (char_len) :: arg, msg, horiz_grid_file, topography_file
    type (pop_grid_input) :: grid
    real (POP_r8), allocatable, target, dimension(:,:,:) :: GRID_G
@@ -106,6 +112,19 @@
       write(*,'(a,i4,a,i5,a,es23.15)') 'step ', n, ' iters ', iters, ' sumP ', psum
    end do
    write(*,'(a,es12.4)') 'halo: max |ZX| ', maxval(abs(ZX))
+   ! the legacy reduction and the logical mask, reference lists (global_reductions.F90:383, POP_ReductionsMod.F90:144)
+   write(*,'(a,es23.15)') 'legacy sumP ', global_sum(PSURF, POP_distrbClinic, field_loc_center, MASK)
+   write(*,'(a,es23.15)') 'lmask sumP ', POP_GlobalSum(PSURF, POP_distrbClinic, POP_gridHorzLocCenter, errorCode, lMask = (MASK > 0.5_POP_r8))
+   ! operators.F90 with its own lists, block by block: grad of the surface pressure, then div and zcurl of that gradient
+   allocate(ids(nblocks_clinic), GX(nx_block,ny_block), GY(nx_block,ny_block), DV(nx_block,ny_block), CU(nx_block,ny_block))
+   errorCode = pop_local_block_ids(pop_ctx, ids)
+   do iblock = 1, nblocks_clinic
+      this_block = get_block(ids(iblock), iblock)
+      call grad(1, GX, GY, PSURF(:,:,iblock), this_block)
+      call div(1, DV, GX, GY, this_block)
+      call zcurl(1, CU, GX, GY, this_block)
+      write(*,'(a,i4,4es23.15)') 'ops block ', iblock, sum(abs(GX)), sum(abs(GY)), sum(abs(DV)), sum(abs(CU))
+   end do
    errorCode = pop_destroy(pop_ctx)
 
  contains

@@ -77,6 +77,22 @@ def test_reference_argument_lists_match_python(pkg):
         assert m.global_sum_host(host, mask=m.get("mMask")) == m.global_sum("PSURF", 1, 0, mask="mMask")   # host-array form == named form
     rerun = re.search(r"solver rerun iters\s+(\d+)\s+of\s+(\d+)", out)
     assert rerun and rerun.group(1) == rerun.group(2)
+    # global_sum(X, dist, field_loc, MASK) and POP_GlobalSum(..., lMask): the same sum as the multiplicative 0 / 1 mask
+    want = m.global_sum("PSURF", 1, 0, mask="mMask")
+    for tag in ("legacy", "lmask"):
+        got = re.search(tag + r" sumP\s+(\S+)", out)
+        assert got and float(got.group(1)) == pytest.approx(want, rel=1e-13, abs=1e-9), tag
+    # grad / div / zcurl(k, ..., this_block) on host arrays of one block against the same entry points from Python
+    ops = re.findall(r"ops block\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", out)
+    assert len(ops) == m.nblocks
+    ps = m.get("PSURF", 1, 0)
+    for row in ops:
+        ib = int(row[0])
+        gx, gy = m.operator_host("grad", 1, ib, ps[ib - 1])
+        dv, cu = m.operator_host("div", 1, ib, gx, gy), m.operator_host("zcurl", 1, ib, gx, gy)
+        for val, arr in zip(row[1:], (gx, gy, dv, cu)):
+            assert float(val) == pytest.approx(np.abs(arr).sum(), rel=1e-12), row
+        assert np.abs(gx).sum() > 0.0 and np.abs(dv).sum() > 0.0
     m.close()
 
 

@@ -979,6 +979,17 @@ def test_operators_are_bitwise_the_oracle(pkg, orclib_built):
     assert np.array_equal(gpu.get("DH"), orc.operator("zcurl", k, u3[:, k - 1], v3[:, k - 1]))
     gpu.operator("div", k, "UVEL", "VVEL", o1="VVC")             # 3-D output: its level-k slab
     assert np.array_equal(gpu.get("VVC")[:, k - 1], orc.operator("div", k, u3[:, k - 1], v3[:, k - 1]))
+    # the reference's own argument lists, grad / div / zcurl(k, ..., this_block): host arrays of one block (pop_operator_host)
+    for kk, (fu, fv) in ((1, (u, v)), (k, (u3[:, k - 1], v3[:, k - 1]))):
+        gx, gy = orc.operator("grad", kk, f)
+        dv, cu = orc.operator("div", kk, fu, fv), orc.operator("zcurl", kk, fu, fv)
+        for ib in range(1, gpu.nblocks + 1):
+            hx, hy = gpu.operator_host("grad", kk, ib, f[ib - 1])
+            assert np.array_equal(hx, gx[ib - 1]) and np.array_equal(hy, gy[ib - 1])
+            assert np.array_equal(gpu.operator_host("div", kk, ib, fu[ib - 1], fv[ib - 1]), dv[ib - 1])
+            assert np.array_equal(gpu.operator_host("zcurl", kk, ib, fu[ib - 1], fv[ib - 1]), cu[ib - 1])
+    with pytest.raises(pkg.PopError, match="local_id"):
+        gpu.operator_host("div", 1, gpu.nblocks + 1, u[0], v[0])
     gpu.close(); orc.close()
 
 
