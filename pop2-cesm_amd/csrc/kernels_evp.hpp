@@ -62,4 +62,96 @@ k_evp_apply(EvpDev e, int nxb, const double *__restrict__ X, double *__restrict_
   for (int c = 2; c <= m - 1; ++c) for (int a = 2; a <= n - 1; ++a) PX[cell(a, c)] = y(a, c);
 }
 
+
+// ---- the same solve with the marching sweeps as anti-diagonal wavefronts (round 3) ------------------------------------------
+// y(i+1,j+1) is formed from y(i,j), y(i+1,j-1), y(i-1,j+1) (all on the anti-diagonal i + j) and y(i-1,j-1) (two diagonals
+// back): every cell of an anti-diagonal can be formed at once, 2 (n - 2) - 1 <= 15 steps per sweep instead of (n - 2)^2 <= 64.
+// Eight lanes own a sub-block (one per cell of the diagonal; a diagonal holds at most eight), eight sub-blocks share a
+// wave; the coefficients (cc, ne, 1/ne), X and y of the sub-block sit in LDS, loaded with the eight sub-blocks side by side
+// (64-byte segments), and the 13 x 13 correction between the sweeps is spread over the lanes row by row, each row summed in
+// the reference's order.  Every value is formed by the expression of k_evp_apply with the same operands: bitwise equal
+// (tests/test_gpu_parity.py).  A workgroup is exactly one wavefront; its barriers only order the LDS traffic.
+#define POP_EVP_SB 8
+constexpr int EVP_CELLS = EVP_LD * EVP_LD, EVP_PAD = EVP_CELLS + 5;
+__global__ void __launch_bounds__(64)
+k_evp_apply_wave(EvpDev e, int nxb, const double *__restrict__ X, double *__restrict__ PX) {
+  __shared__ double ys[POP_EVP_SB][EVP_PAD], xs[POP_EVP_SB][EVP_PAD];
+  __shared__ double ccs[POP_EVP_SB][EVP_PAD], nes[POP_EVP_SB][EVP_PAD], ins[POP_EVP_SB][EVP_PAD];
+  __shared__ double rs[POP_EVP_SB][EVP_LE + 1];
+  const int t = threadIdx.x, w = t >> 3, l = t & 7;
+  const long long s0 = (long long)blockIdx.x * POP_EVP_SB, s = s0 + w;
+  const bool live = s < e.S;
+  int4 mt = make_int4(0, 3 | (3 << 8), 1, 0);
+  if (live) mt = e.meta[s];
+  const int n = mt.y & 255, m = mt.y >> 8;
+  const bool solve = live && !mt.z;
+  auto cell = [&](int a, int c) { return (long long)mt.x + (long long)(c - 1) * nxb + (a - 1); };
+  auto at = [](int a, int c) { return (a - 1) + EVP_LD * (c - 1); };
+  // coefficients: cell q of the eight sub-blocks of this workgroup lies at q * S + s0 .. + 7: lane (q8, sb) = (t >> 3, t & 7)
+  {
+    const int sb = t & 7, q8 = t >> 3;
+    const bool ok = s0 + sb < e.S;
+    for (int q = q8; q < EVP_CELLS; q += 8) {
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+      if (ok) { const long long o = (long long)q * e.S + s0 + sb; c0 = e.cc[o]; c1 = e.ne[o]; c2 = e.ine[o]; }
+      ccs[sb][q] = c0; nes[sb][q] = c1; ins[sb][q] = c2; ys[sb][q] = 0.0;
+    }
+  }
+  // X of the interior, row by row (lane = column); sub-blocks with land are scaled by the diagonal at once (:2344-2348)
+  const int a0 = 2 + l;
+  for (int c = 2; c <= EVP_LD - 1; ++c) {
+    if (live && c <= m - 1 && a0 <= n - 1) {
+      const double x = X[cell(a0, c)];
+      xs[w][at(a0, c)] = x;
+      if (mt.z) PX[cell(a0, c)] = x * e.icc[(long long)at(a0, c) * e.S + s];
+    }
+  }
+  // rows of the correction this lane sums (row index jj = 1 .. n + m - 5; see below), requested before the first sweep
+  const int nm = n + m - 5;
+  double rv0[EVP_LE], rv1[EVP_LE];
+  const int row0 = 1 + l, row1 = 9 + l;
+#pragma unroll
+  for (int k = 1; k <= EVP_LE; ++k) {
+    rv0[k - 1] = (solve && row0 <= nm && k <= nm) ? e.rinv[(long long)((k - 1) + EVP_LE * (row0 - 1)) * e.S + s] : 0.0;
+    rv1[k - 1] = (solve && row1 <= nm && k <= nm) ? e.rinv[(long long)((k - 1) + EVP_LE * (row1 - 1)) * e.S + s] : 0.0;
+  }
+  __syncthreads();
+  auto sweep = [&](int imax, int jmax) {
+    for (int d = 4; d <= 2 * (EVP_LD - 1); ++d) {
+      const int ilo = (d - jmax > 2) ? d - jmax : 2, ihi = (d - 2 < imax) ? d - 2 : imax;
+      const int i = ilo + l, j = d - i;
+      const bool on = solve && d <= imax + jmax && i <= ihi;
+      double v = 0.0;
+      if (on)
+        v = (xs[w][at(i, j)] - ccs[w][at(i, j)] * ys[w][at(i, j)] - nes[w][at(i, j - 1)] * ys[w][at(i + 1, j - 1)] -
+             nes[w][at(i - 1, j)] * ys[w][at(i - 1, j + 1)] - nes[w][at(i - 1, j - 1)] * ys[w][at(i - 1, j - 1)]) * ins[w][at(i, j)];
+      if (on) ys[w][at(i + 1, j + 1)] = v;
+      __syncthreads();
+    }
+  };
+  sweep(n - 1, m - 1);
+  // what reached the north / east rim (:2667-2680)
+  for (int k = 1 + l; k <= EVP_LE; k += 8)
+    if (solve && k <= nm) rs[w][k] = (k <= n - 2) ? ys[w][at(k + 2, m)] : ys[w][at(n, m - (k - (n - 2)))];
+  __syncthreads();
+  // corrected values on the west column (rows jj = 1 .. m-2 -> y(2, m-jj)) and the south row (jj = m-2+ii -> y(ii+2, 2))
+  auto target = [&](int jj) { return (jj <= m - 2) ? at(2, m - jj) : at(jj - (m - 2) + 2, 2); };
+  if (solve && row0 <= nm) {
+    double acc = ys[w][target(row0)];
+#pragma unroll
+    for (int k = 1; k <= EVP_LE; ++k) if (k <= nm) acc = acc + rv0[k - 1] * rs[w][k];
+    ys[w][target(row0)] = acc;
+  }
+  if (solve && row1 <= nm) {
+    double acc = ys[w][target(row1)];
+#pragma unroll
+    for (int k = 1; k <= EVP_LE; ++k) if (k <= nm) acc = acc + rv1[k - 1] * rs[w][k];
+    ys[w][target(row1)] = acc;
+  }
+  __syncthreads();
+  sweep(n - 2, m - 2);
+  for (int c = 2; c <= EVP_LD - 1; ++c)
+    if (solve && c <= m - 1 && a0 <= n - 1) PX[cell(a0, c)] = ys[w][at(a0, c)];
+}
+
 }  // namespace pop

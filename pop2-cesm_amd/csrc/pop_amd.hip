@@ -366,8 +366,11 @@ SolverArgs solver_args(pop_ctx *c) {
 
 // preconditioner() with preconditionerChoice = 'evp' (:2331-2366): PX <- sub-block solves of X on the physical cells
 int evp_apply(pop_ctx *c, const double *X, double *PX) {
-  hipLaunchKernelGGL(k_evp_apply, dim3((unsigned)((c->evp.S + POP_EVP_THREADS - 1) / POP_EVP_THREADS)), dim3(POP_EVP_THREADS), 0, c->stream,
-                     c->evp, c->g.nxb, X, PX);
+  if (!tun_off(c->h.tun.evp_wave))   // anti-diagonal wavefronts: eight lanes per sub-block, eight sub-blocks per wave
+    hipLaunchKernelGGL(k_evp_apply_wave, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
+  else
+    hipLaunchKernelGGL(k_evp_apply, dim3((unsigned)((c->evp.S + POP_EVP_THREADS - 1) / POP_EVP_THREADS)), dim3(POP_EVP_THREADS), 0, c->stream,
+                       c->evp, c->g.nxb, X, PX);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
@@ -1222,7 +1225,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);

@@ -53,6 +53,16 @@
       type (c_ptr) :: KMT
       type (c_ptr) :: DZBC = c_null_ptr   ! partial_bottom_cells: record of bottom_cell_file (grid.F90:2116-2186)
    end type pop_grid_input
+   ! pop_tuning (include/pop_amd.h): kernel-form and schedule choices, none changes a result; fill with pop_tuning_init, then set fields
+   type, bind(C) :: pop_tuning
+      integer (c_int) :: struct_bytes, land_skip, land_full_steps, xcd_remap, red_tiles, red_band
+      integer (c_int) :: lds_order, momentum_lds, tracer_lds, generic_thomas, reg_thomas_t, thomas_pair
+      integer (c_int) :: tracer_fwd, vdc_shared, side_stream, del4_side, del4_tile, d2t_fuse
+      integer (c_int) :: d2u_fuse, vmixu_defer, vmixu_inline, btrop_inline, kpp_ahead, kpp_col
+      integer (c_int) :: kpp_lazy, kpp_ushear_hint, kpp_ushear_margin, kpp_side_stream, kpp_buoy_waves, kpp_interior_generic
+      integer (c_int) :: kpp_src_full, solver_unfused, solver_nograph, solver_presum, solver_distributed, solver_overlap_off
+      integer (c_int) :: fpcg_b2, pcsi_step2, halo_separate, halo_overlap_off, rccl_overlap, evp_wave
+   end type pop_tuning
 
    type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task
 
@@ -270,6 +280,23 @@
          type (c_ptr), value :: ctx
          integer (c_int), value :: op, k, tl
          character (kind=c_char), intent(in) :: aname(*), bname(*), o1name(*), o2name(*)
+      end function
+      subroutine pop_tuning_init(t) bind(C, name='pop_tuning_init')
+         import :: pop_tuning
+         type (pop_tuning), intent(out) :: t
+      end subroutine
+      integer (c_int) function pop_get_tuning(ctx, resolved) bind(C, name='pop_get_tuning')
+         import :: c_int, c_ptr, pop_tuning
+         type (c_ptr), value :: ctx
+         type (pop_tuning), intent(out) :: resolved
+      end function
+      integer (c_int) function pop_create_tuned(cfg, grid, tuning, rank, nranks, flags, ctx) bind(C, name='pop_create_tuned')
+         import :: c_int, c_ptr, pop_config, pop_tuning
+         type (pop_config), intent(in) :: cfg
+         type (c_ptr), value :: grid             ! c_loc of a pop_grid_input, or c_null_ptr
+         type (pop_tuning), intent(in) :: tuning
+         integer (c_int), value :: rank, nranks, flags
+         type (c_ptr), intent(out) :: ctx
       end function
       integer (c_int) function pop_operator_host(ctx, op, k, block_local, a, b, o1, o2) bind(C, name='pop_operator_host')
          import :: c_int, c_ptr

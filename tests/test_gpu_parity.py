@@ -883,11 +883,15 @@ def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
     gpu.close(); orc.close()
 
 
-@pytest.mark.parametrize("name,kw", [("tiny", {}), ("tiny", {"block_size_x": 16, "block_size_y": 20}), ("gx3v7", {})])
-def test_evp_preconditioner_is_bitwise_the_oracle(pkg, orclib_built, name, kw):
-    """preconditioner() on its own (POP_SolversMod.F90:2268-2369, 2618-2696): the sub-block marches are sequential
-    and written in the reference's operation order on both sides, so PX agrees bit for bit; the eigenvalue bounds
-    P-CSI derives through it (Lanczos on the host) are identical too."""
+@pytest.mark.parametrize("wave", ["1", "0"], ids=["wavefront-kernel", "thread-per-sub-block"])
+@pytest.mark.parametrize("name,kw", [("tiny", {}), ("tiny", {"block_size_x": 16, "block_size_y": 20}), ("gx3v7", {}),
+                                     ("tiny", {"nx_global": 66, "ny_global": 52, "block_size_x": 33, "block_size_y": 26, "stepped_bathymetry": 1})])
+def test_evp_preconditioner_is_bitwise_the_oracle(pkg, orclib_built, monkeypatch, name, kw, wave):
+    """preconditioner() on its own (POP_SolversMod.F90:2268-2369, 2618-2696): every value of the sub-block marches is formed by
+    the reference's expression on both sides -- one thread per sub-block in the reference's loop order, or the anti-diagonal
+    wavefront form (eight lanes per sub-block; sub-blocks of every size from 1 x 1 to 8 x 8, land sub-blocks) --, so PX agrees
+    bit for bit; the eigenvalue bounds P-CSI derives through it (Lanczos on the host) are identical too."""
+    monkeypatch.setenv("POP_EVP_WAVE", wave)
     cfg = named_config(name, precond_choice=1, solver_choice=3, **kw)
     gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
     assert gpu.scalar("PcsiMaxEigs") == orc.scalar("PcsiMaxEigs") and gpu.scalar("PcsiMinEigs") == orc.scalar("PcsiMinEigs")
