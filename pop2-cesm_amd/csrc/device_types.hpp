@@ -54,6 +54,7 @@ struct DevGrid {
   const double *zero;                              // a few words of +0.0 that no kernel writes (loads that must yield zero without a branch)
   const double *DUC, *DUN, *DUS, *DUE, *DUW, *DMC, *DMN, *DMS, *DME, *DMW, *DUM, *KXU, *KYU;
   const double *WNE, *WEa, *WNo, *WC0, *mMask, *CHECKER, *CONSTNT;
+  const double *XW, *YW;                           // U-point terms of the barotropic operator: WNE = XW + YW, WEa = XW + XW(j-1) - YW - YW(j-1), WNo = YW + YW(i-1) - XW - XW(i-1)
   const double *SMF1, *SMF2, *SMFT1, *SMFT2;
   const unsigned char *mMask8;                     // mMask (exactly 0 or 1) as bytes: the fused solver kernels read 1 B instead of 8
   // land elimination at workgroup-tile granularity (the reference drops land BLOCKS from the distribution,

@@ -651,6 +651,10 @@ int host_build(HostModel &h) {
   auto &WNE = newf("btropWgtNE"), &WEa = newf("btropWgtEast"), &WNo = newf("btropWgtNorth"), &WC0 = newf("centerWgtIndep");
   auto &mMask = newf("mMask"), &CHECKER = newf("CHECKER"), &CONSTNT = newf("CONSTNT");
   newf("centerWgt");
+  // the two U-point terms every off-centre weight is made of (r3: the two-cell step B of the fused pcg reads these two fields and
+  // forms WNE, WEa, WNo of its stencil from them -- the additions below, same operands, same order -- instead of reading three)
+  auto &XW = newf("btropXW"), &YW = newf("btropYW");
+  for (size_t p = 0; p < A2; ++p) { XW[p] = 0.25 * HU[p] * DXUR[p] * DYU[p]; YW[p] = 0.25 * HU[p] * DYUR[p] * DXU[p]; }
   {
     std::vector<double> area2(A2, 0.0), CA(A2, 0.0), KA(A2, 0.0);
     for (int b = 0; b < NB; ++b) {

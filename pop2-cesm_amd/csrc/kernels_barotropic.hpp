@@ -724,8 +724,11 @@ __device__ __forceinline__ double fused_total(const double *__restrict__ partial
   return total;
 }
 
-// step A: [x += alpha s; r -= alpha q]; z = r/diag; partial (r,z).  The cell's operands are loaded
-// before the ordered total of the previous partials is formed, so memory latency overlaps it.
+// step A: [r -= alpha q]; z = r/diag; partial (r,z).  The cell's operands are loaded before the ordered total of the
+// previous partials is formed, so memory latency overlaps it.  The other half of the pending update, x += alpha s, is
+// done by step B of the same iteration (round 3): B holds s of the previous iteration in registers anyway, so x costs it one
+// load and one store, and A no longer reads x and s -- one word per point and iteration less, the same operations on the
+// same operands (alpha is published by workgroup (0,0) of A and read by B after the launch boundary).
 template <bool UPDATE>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_a(DevGrid g, FusedArgs a) {
@@ -734,8 +737,8 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
   const long long q = (long long)b * g.n2 + (live ? p2 : 0);
-  double r = a.R[q], x = 0.0, s0 = 0.0, qq = 0.0;
-  if (UPDATE) { x = a.X[q]; s0 = a.S0[q]; qq = a.Q[q]; }
+  double r = a.R[q], qq = 0.0;
+  if (UPDATE) qq = a.Q[q];
   const double cw = a.C[q], mk = (double)g.mMask8[q];
   if (stop) return;
   double alpha = 0.0;
@@ -749,7 +752,6 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
   if (live) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
     if (UPDATE) {
-      a.X[q] = x + alpha * s0;
       r = r - alpha * qq;
       a.R[q] = r;
     }
@@ -763,9 +765,72 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
   wg_reduce_store<1>(v, a.partA, b * a.nchunk + red_chunk(g));
 }
 
+// step A with TWO chunks per workgroup (compacted launches on large grids, round 3): the kernel is bound by the length of a
+// workgroup's dependency chain -- list entry -> operands -> total of the previous partials -> reduction tree -> partial -- times the
+// number of workgroups a CU has to run one after the other (85 of them at tx0.1v3), not by bytes (3 words per point take 45 us, 6 take
+// 68).  A thread takes the same cell of two chunks that are neighbours in the launch order of the same XCD band (list entries e
+// and e + 8); both sets of operands are requested together and the two reduction trees share their barriers.  Each chunk's
+// 256 products are reduced by the tree of wg_reduce_store into the chunk's own slot: bitwise the one-chunk kernel.
+template <bool UPDATE>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_fpcg_a_pair(DevGrid g, FusedArgs a) {
+  __shared__ double sh[2][POP_RED_THREADS];
+  const int stop = a.sc->stop;
+  const int b = blockIdx.y, t = threadIdx.x;
+  const int e0 = ((int)blockIdx.x >> 3) * 16 + ((int)blockIdx.x & 7);
+  int ch[2]; bool land[2]; long long q[2]; bool live[2];
+  double r[2], qq[2] = {0.0, 0.0}, cw[2], mk[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = e0 + 8 * u;
+    ch[u] = g.red_act[(long long)b * g.red_nact + e];
+    // position of entry e in the sorted sequence (ocean chunks first); workgroup (0,0) publishes the scalars and never skips
+    land[u] = g.skip && !(e == 0 && b == 0) && ((e & 7) * (g.red_nact >> 3) + (e >> 3)) >= g.red_cnt[b];
+    const long long p2 = (long long)ch[u] * POP_RED_THREADS + t;
+    live[u] = p2 < g.n2;
+    q[u] = (long long)b * g.n2 + (live[u] ? p2 : 0);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    r[u] = a.R[q[u]];
+    if (UPDATE) qq[u] = a.Q[q[u]];
+    cw[u] = a.C[q[u]]; mk[u] = (double)g.mMask8[q[u]];
+  }
+  if (stop) return;
+  double alpha = 0.0;
+  if (UPDATE) {
+    const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, 1);
+    const double rz = a.sc->eta1;
+    alpha = rz / sq;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { a.sc->eta0 = rz; a.sc->alpha = alpha; }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    double v = 0.0;
+    if (live[u] && !land[u]) {
+      const int p2 = (int)(q[u] - (long long)b * g.n2);
+      const int i = p2 % g.nxb, j = p2 / g.nxb;
+      double rr = r[u];
+      if (UPDATE) { rr = rr - alpha * qq[u]; a.R[q[u]] = rr; }
+      const double z = (cw[u] != 0.0) ? rr / cw[u] : 0.0;
+      a.Z[q[u]] = z;
+      if (interior(g, i, j)) v = (rr * z) * mk[u];
+    }
+    sh[u][t] = v;
+  }
+  __syncthreads();
+  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+    if (t < s) { sh[0][t] = sh[0][t] + sh[0][t + s]; sh[1][t] = sh[1][t] + sh[1][t + s]; }
+    __syncthreads();
+  }
+  if (t < 2) a.partA[(long long)b * a.nchunk + ch[t]] = sh[t][0];
+}
+
 // step B: s_new = z + s_old*(eta1/eta0) at the 9 stencil points; q = A s_new; partial (q,s).
 // Only cells on the rim of the physical domain can have ghost neighbours: they read them through
 // srcmap (bit-identical to reading the ghost after a halo update); all other cells index directly.
+// XUPD: the pending x += alpha s of the previous iteration (see step A), on every cell step A updated it on
+template <bool XUPD>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_b(DevGrid g, FusedArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
@@ -781,6 +846,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
   const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
   double zv[9], sv[9], wv[9];
   zv[0] = (inner || !live) ? a.Z[q] : z_at(a, (int)q); sv[0] = a.S0[q];
+  const double xold = XUPD ? a.X[q] : 0.0;
 #pragma unroll
   for (int t = 1; t < 9; ++t) { zv[t] = 0.0; sv[t] = 0.0; }
   if (inner) {
@@ -803,6 +869,7 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta1 = rz; a.sc->beta_cg = bt; }
   double v[1] = {0.0};
   if (live) {
+    if (XUPD) a.X[q] = xold + a.sc->alpha * sv[0];
     const double s = zv[0] + sv[0] * bt;
     a.S1[q] = s;
     double aq = 0.0;
@@ -1012,6 +1079,7 @@ k_fcg_b(DevGrid g, FusedArgs a, int par) {
 // consecutive cells is handled by 128 threads, the pair (q, q+1) shares its three stencil rows of z and s, which are
 // read as (q-1), (q, q+1) as one 16-byte load, (q+2): 14 load instructions per cell instead of 28.  Same operations
 // in the same order per cell, and the 256 products are reduced by the same tree as in k_fpcg_b: bitwise equal.
+template <bool XUPD>
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fpcg_b2(DevGrid g, FusedArgs a) {
   const int stop = a.sc->stop;   // an earlier check has converged: this launch belongs to the look-ahead interval (branch below, after the loads are issued)
@@ -1027,8 +1095,8 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
   const bool fast = live1 && i + 1 > g.ib && i + 2 < g.ie && j + 1 > g.jb && j + 1 < g.je;
   double v0 = 0.0, v1 = 0.0;
   double zr[3][4], sr[3][4];
-  double2 cc, no0, nom, ea0, ne0, nem;
-  double eaw = 0.0, ne0w = 0.0, nemw = 0.0, mk0 = 0.0, mk1 = 0.0;
+  double2 cc, xx, x0, xm, y0, ym;
+  double x0w = 0.0, xmw = 0.0, y0w = 0.0, ymw = 0.0, mk0 = 0.0, mk1 = 0.0;
   if (fast) {   // operands first: the loads are in flight while the total is formed
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -1038,19 +1106,30 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
       sr[r][0] = a.S0[o - 1]; sr[r][1] = sc.x; sr[r][2] = sc.y; sr[r][3] = a.S0[o + 2];
     }
     cc = *reinterpret_cast<const double2 *>(a.C + q);
-    no0 = *reinterpret_cast<const double2 *>(g.WNo + q); nom = *reinterpret_cast<const double2 *>(g.WNo + q - nxb);
-    ea0 = *reinterpret_cast<const double2 *>(g.WEa + q); eaw = g.WEa[q - 1];
-    ne0 = *reinterpret_cast<const double2 *>(g.WNE + q); nem = *reinterpret_cast<const double2 *>(g.WNE + q - nxb);
-    ne0w = g.WNE[q - 1]; nemw = g.WNE[q - 1 - nxb];
+    // the off-centre weights from their two U-point terms (rows j and j-1, columns q-1 .. q+1): two fields instead of three
+    x0 = *reinterpret_cast<const double2 *>(g.XW + q); xm = *reinterpret_cast<const double2 *>(g.XW + q - nxb);
+    y0 = *reinterpret_cast<const double2 *>(g.YW + q); ym = *reinterpret_cast<const double2 *>(g.YW + q - nxb);
+    x0w = g.XW[q - 1]; xmw = g.XW[q - 1 - nxb]; y0w = g.YW[q - 1]; ymw = g.YW[q - 1 - nxb];
     mk0 = (double)g.mMask8[q]; mk1 = (double)g.mMask8[q + 1];
+    if (XUPD) xx = *reinterpret_cast<const double2 *>(a.X + q);
   }
   if (stop) return;
+  const double alpha = XUPD ? a.sc->alpha : 0.0;
   // presummed block sums only (host selects this kernel for large grids): no barrier inside
   const double rz = fused_total(a.partA, a.nchunk, a.nblocks, a.bsA, 1);
   const double bt = rz / a.sc->eta0;
   if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { a.sc->eta1 = rz; a.sc->beta_cg = bt; }
   if (fast) {
     // rows: 0 = j-1, 1 = j, 2 = j+1; columns: 0 = q-1, 1 = q, 2 = q+1, 3 = q+2
+    if (XUPD) *reinterpret_cast<double2 *>(a.X + q) = make_double2(xx.x + alpha * sr[1][1], xx.y + alpha * sr[1][2]);
+    // WNE = xne + yne, WEa = xne + xse - yne - yse, WNo = yne + ynw - xne - xnw (host_setup.cpp, the same additions in the same order)
+    double2 no0, nom, ea0, ne0, nem;
+    const double ne0w = x0w + y0w, nemw = xmw + ymw;
+    ne0.x = x0.x + y0.x; ne0.y = x0.y + y0.y; nem.x = xm.x + ym.x; nem.y = xm.y + ym.y;
+    const double eaw = x0w + xmw - y0w - ymw;
+    ea0.x = x0.x + xm.x - y0.x - ym.x; ea0.y = x0.y + xm.y - y0.y - ym.y;
+    no0.x = y0.x + y0w - x0.x - x0w; no0.y = y0.y + y0.x - x0.y - x0.x;
+    nom.x = ym.x + ymw - xm.x - xmw; nom.y = ym.y + ym.x - xm.y - xm.x;
 #define SN(r, c) (zr[r][c] + sr[r][c] * bt)
     const double sA = SN(1, 1), sB = SN(1, 2);
     double aqA = cc.x * sA;
@@ -1072,7 +1151,9 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
       const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
       const bool in_e = interior(g, ii, jj);
-      const double s = (in_e ? a.Z[qq] : z_at(a, (int)qq)) + a.S0[qq] * bt;
+      const double sold = a.S0[qq];
+      if (XUPD) a.X[qq] = a.X[qq] + alpha * sold;
+      const double s = (in_e ? a.Z[qq] : z_at(a, (int)qq)) + sold * bt;
       double aq = 0.0, vv = 0.0;
       if (in_e) {
         const double wv[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};

@@ -450,12 +450,26 @@ void launch_fresidual(pop_ctx *c, const SolveView &v, const FusedArgs &a) {
     hipLaunchKernelGGL(k_fresidual2<WITH_RR>, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
   else hipLaunchKernelGGL(k_fresidual<WITH_RR>, G, dim3(POP_RED_THREADS), 0, c->stream, v.g, a);
 }
+// step A of the fused pcg: two chunks per workgroup on compacted launches (single rank), else one
+void launch_fpcg_a(pop_ctx *c, const SolveView &v, const FusedArgs &a, bool update) {
+  const dim3 G = view_grid(v), B(POP_RED_THREADS);
+  const bool pair = v.g.red_act && a.presummed && !a.sendmap && (v.g.red_nact % 16) == 0 && !c->fpcg_one_cell && !tun_off(c->h.tun.fpcg_a_pair);
+  if (pair) {
+    const dim3 GP(G.x / 2, G.y);
+    if (update) hipLaunchKernelGGL(k_fpcg_a_pair<true>, GP, B, 0, c->stream, v.g, a);
+    else hipLaunchKernelGGL(k_fpcg_a_pair<false>, GP, B, 0, c->stream, v.g, a);
+  } else if (update) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
+  else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
+}
 // step B of the fused pcg: two cells per thread on large grids (presummed block sums, even row pitch), else one
-void launch_fpcg_b(pop_ctx *c, const SolveView &v, const FusedArgs &a) {
+// xupd: the pending x += alpha s of the previous iteration is applied here (k_fpcg_a<true> ran before and published alpha)
+void launch_fpcg_b(pop_ctx *c, const SolveView &v, const FusedArgs &a, bool xupd) {
   const dim3 G = view_grid(v);
-  if (a.presummed && (v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell)
-    hipLaunchKernelGGL(k_fpcg_b2, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
-  else hipLaunchKernelGGL(k_fpcg_b, G, dim3(POP_RED_THREADS), 0, c->stream, v.g, a);
+  const bool two = a.presummed && (v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell;
+  if (two && xupd) hipLaunchKernelGGL(k_fpcg_b2<true>, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
+  else if (two) hipLaunchKernelGGL(k_fpcg_b2<false>, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
+  else if (xupd) hipLaunchKernelGGL(k_fpcg_b<true>, G, dim3(POP_RED_THREADS), 0, c->stream, v.g, a);
+  else hipLaunchKernelGGL(k_fpcg_b<false>, G, dim3(POP_RED_THREADS), 0, c->stream, v.g, a);
 }
 // one check interval: freq iterations, pending update, residual + (r,r) -> host
 int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
@@ -463,10 +477,9 @@ int fused_interval(pop_ctx *c, SolveView &v, int freq, bool first_has_pending) {
   bool pending = first_has_pending;
   for (int it = 0; it < freq; ++it) {
     FusedArgs a = fused_args(c, v);
-    if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
-    else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
+    launch_fpcg_a(c, v, a, pending);
     if (a.presummed) presum(c, v, a.partA, (double *)a.bsA);
-    launch_fpcg_b(c, v, a);
+    launch_fpcg_b(c, v, a, pending);
     if (a.presummed) presum(c, v, a.partB, (double *)a.bsB);
     std::swap(v.S0, v.S1);
     pending = true;
@@ -550,10 +563,9 @@ int solver_pcg_fused(pop_ctx *c, SolveView &v) {
     bool pending = false;
     for (; m < cf.max_iterations; ++m) {
       FusedArgs a = fused_args(c, v);
-      if (pending) hipLaunchKernelGGL(k_fpcg_a<true>, G, B, 0, c->stream, v.g, a);
-      else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
+      launch_fpcg_a(c, v, a, pending);
       if (a.presummed) presum(c, v, a.partA, (double *)a.bsA);
-      launch_fpcg_b(c, v, a);
+      launch_fpcg_b(c, v, a, pending);
       if (a.presummed) presum(c, v, a.partB, (double *)a.bsB);
       std::swap(v.S0, v.S1);
       pending = true;
@@ -675,7 +687,7 @@ int solver_pcg_fused_dist(pop_ctx *c) {
       else hipLaunchKernelGGL(k_fpcg_a<false>, G, B, 0, c->stream, v.g, a);
       c->solver_ops += 1;
       if (D.xchg_begin() || D.allsum<1>(a.partA, 0) || D.xchg_end()) return 1;
-      launch_fpcg_b(c, v, a);
+      launch_fpcg_b(c, v, a, pending);
       c->solver_ops += 1;
       if (D.allsum<1>(a.partB, 2 * nbt)) return 1;
       std::swap(v.S0, v.S1);
@@ -1225,7 +1237,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -1462,6 +1474,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->full_left = c->land_full_steps;
   }
   g.WNE = c->d2["btropWgtNE"]; g.WEa = c->d2["btropWgtEast"]; g.WNo = c->d2["btropWgtNorth"]; g.WC0 = c->d2["centerWgtIndep"];
+  g.XW = c->d2["btropXW"]; g.YW = c->d2["btropYW"];
   if (cfg->hmix_tracer == 4) { g.DTN = c->d2["d4DTN"]; g.DTS = c->d2["d4DTS"]; g.DTE = c->d2["d4DTE"]; g.DTW = c->d2["d4DTW"]; }
   if (cfg->hmix_momentum == 4) {
     g.DUC = c->d2["d4DUC"]; g.DUN = c->d2["d4DUN"]; g.DUS = c->d2["d4DUS"]; g.DUE = c->d2["d4DUE"]; g.DUW = c->d2["d4DUW"];
@@ -1552,7 +1565,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     // launch order: workgroup w runs on XCD w % 8; XCD x takes one contiguous band of the chunks with ocean (as red_band does
     // for the full launch), so the rows j +- 1 of the 9-point matvec are in the L2 that fetched row j.  The publishing workgroup
     // (0,0) stays chunk 0.  Padding (land chunks) fills each band up to the common length.
-    longest = 8 * ((longest + 7) / 8);
+    longest = 16 * ((longest + 15) / 16);   // multiple of 16: k_fpcg_a_pair takes entries e and e + 8
     std::vector<int> list((size_t)longest * h.nblocks), cnt_pad(h.nblocks);
     bool can_pad = true;
     for (int b = 0; b < h.nblocks; ++b) if (act[b].size() + land[b].size() < longest) can_pad = false;
@@ -1716,6 +1729,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       if (dev_upload(c, &p, h.f2["btropWgtNE"].data(), NG)) return 1; v.g.WNE = p;
       if (dev_upload(c, &p, h.f2["btropWgtEast"].data(), NG)) return 1; v.g.WEa = p;
       if (dev_upload(c, &p, h.f2["btropWgtNorth"].data(), NG)) return 1; v.g.WNo = p;
+      if (dev_upload(c, &p, h.f2["btropXW"].data(), NG)) return 1; v.g.XW = p;
+      if (dev_upload(c, &p, h.f2["btropYW"].data(), NG)) return 1; v.g.YW = p;
       if (dev_upload(c, &p, h.f2["centerWgtIndep"].data(), NG)) return 1; v.g.WC0 = p;
       if (dev_upload(c, &p, h.f2["mMask"].data(), NG)) return 1; v.g.mMask = p;
       { std::vector<unsigned char> m8(NG); for (size_t q = 0; q < NG; ++q) m8[q] = h.f2["mMask"][q] != 0.0;

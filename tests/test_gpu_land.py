@@ -21,6 +21,11 @@ CASES = [
     ("wide", {"block_size_x": 1056, "tadvect": 2, "vmix_choice": 2, "tmix_opt": 1, "time_mix_freq": 4}, BIG, 12),
     ("wide", {"time_mix_freq": 5}, {}, 10),                                                      # fused pcg on the compacted chunk list
     ("wide", {"block_size_x": 1056, "solver_choice": 2}, {}, 10),                                # two blocks: lists padded to one length
+    # the large-grid forms of the fused pcg on the compacted list: block sums by their own launch, two chunks per workgroup in step A
+    # (k_fpcg_a_pair), two cells per thread in step B; one block and two
+    ("wide", {"time_mix_freq": 5}, {"POP_SOLVER_PRESUM": "1"}, 10),
+    ("wide", {"block_size_x": 1056}, {"POP_SOLVER_PRESUM": "1"}, 8),
+    ("wide", {"time_mix_freq": 5}, {"POP_SOLVER_PRESUM": "1", "POP_FPCG_A_PAIR": "0"}, 8),
     ("wide", {"solver_choice": 3, "time_mix_freq": 5}, {}, 10),                                 # P-CSI: land chunks of both ping-pong halves stay 0
     ("wide", {"solver_choice": 3, "precond_choice": 1, "block_size_x": 1056}, BIG, 8),           # P-CSI + EVP, two blocks, tile order
     ("test", {"vmix_choice": 3, "stepped_bathymetry": 1, "time_mix_freq": 6}, {}, 13),          # 96 blocks, many of them land
