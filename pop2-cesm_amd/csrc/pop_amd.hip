@@ -149,6 +149,7 @@ struct pop_ctx {
   bool timing = false;
   bool phase_timing = false;   // inside pop_time_phase: kernels only
   double *op_scratch = nullptr;   // pop_operator_host: four block-sized 2-D arrays
+  bool prio_on = false; int prio_least = 0;   // stream priorities in use; the lowest one
 };
 
 namespace {
@@ -1237,7 +1238,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -1334,7 +1335,14 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
   if (cfg->nt != 2) { c->err = "device kernels are built for nt = 2 (T,S) in this round"; return 1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { c->err = "no HIP device available; libpop_amd has no CPU fallback"; return 1; }
-  HIPCHK(c, hipStreamCreate(&c->stream));
+  // stream priorities (r3, measured and left OFF: 84.7 ms against 83.2 without, profiles/r03_ab_stream_priority.txt): the launch stream above
+  // the streams that only fill its gaps (KPP of the next step), so that the
+  // one-workgroup block sums between the solver's kernels are dispatched ahead of KPP workgroups waiting in the other queues
+  int prio_least = 0, prio_greatest = 0;
+  const bool prio = tun_on(c->h.tun.stream_priority) && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) == hipSuccess && prio_least != prio_greatest;
+  if (prio) HIPCHK(c, hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest));
+  else HIPCHK(c, hipStreamCreate(&c->stream));
+  c->prio_least = prio ? prio_least : 0; c->prio_on = prio;
   c->own_stream = true;
   HostModel &h = c->h;
   DevGrid &g = c->g;
@@ -1768,7 +1776,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     if (c->vdc_shared) c->VDCa[1] = c->VDCa[0];
     else if (dev_alloc(c, &c->VDCa[1], (size_t)(h.km + 2) * a2)) return 1;
     if (dev_alloc(c, &c->VVCa, a3) || dev_alloc(c, &c->HBLTa, a2) || dev_alloc(c, &c->KBLa, a2)) return 1;
-    HIPCHK(c, hipStreamCreateWithFlags(&c->ahead, hipStreamNonBlocking));
+    if (c->prio_on) HIPCHK(c, hipStreamCreateWithPriority(&c->ahead, hipStreamNonBlocking, c->prio_least));
+    else HIPCHK(c, hipStreamCreateWithFlags(&c->ahead, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_ahead_fork, hipEventDisableTiming));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming));
   }
