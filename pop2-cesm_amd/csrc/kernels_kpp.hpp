@@ -23,6 +23,11 @@ struct KppDev {
   CArr zgrid, hwide, bckgrnd_vdc, bckgrnd_vvc;             // zgrid/hwide: 0..km+1 (ConstArr: wave-uniform level index -> scalar loads)
   CArrI kref;                                               // 1..km: surface-layer reference level
   CArr eosP;                                                // 6 (km + 2): mwjf_level of every level (k_kpp_level_table)
+  // r3: bit k-1 of CONVB[column] = the interface below level k is not stably stratified (DBLOC(k) <= 0: the reference's N2 > 0 test,
+  // vmix_kpp.F90:1218-1225, divides by a positive thickness).  Written by k_kpp_buoy_interior_march, read by the sparse form of
+  // k_kpp_blmix instead of the DBLOC column; nullptr when the interior kernel of this evaluation does not form it
+  unsigned long long *CONVB;
+  int src_clear_all;                                        // the non-local source may hold non-zeros below the KBL stored with it (a caller wrote it)
   double *HBLT0, *USTAR, *BFSFC;                              // 2-D scratch
   int *KBL0, *KBL;
   double Vtc, cg, rich_mix;
@@ -499,6 +504,7 @@ k_kpp_buoy_interior_march(DevGrid g, KppDev kp, const double *__restrict__ T, co
   KppRaw up = load(1), A = load(2 <= km ? 2 : km), B;
   MwjfTS2 xkm = mwjf_prep2(tmask(up.t), up.s);
   double wpp = 0.0, wp = 0.0, carry = 0.0;            // w0(k-3), w0(k-2); the value carried below the bottom
+  unsigned long long convb = 0ull;                    // KppDev::CONVB of this column
   // level k: forms DBLOC(k-1), Ri(k-1) and the coefficients of level k-2.  cu holds the operands of level k; those of level k+1
   // are requested into nx first and are in flight while this level is evaluated.  The loop below alternates two operand sets
   // (a rotation by register moves would have to wait for the loads it moves)
@@ -513,6 +519,7 @@ k_kpp_buoy_interior_march(DevGrid g, KppDev kp, const double *__restrict__ T, co
     if (rhok != 0.0) dbl = GRAV * (1.0 - rhokm / rhok);
     if (k - 1 >= kmt) dbl = 0.0;
     DBLOC[c.base3 + (long long)(k - 2) * n2] = dbl;
+    if (!(dbl > 0.0)) convb |= 1ull << (k - 2);
     double sh4[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -536,6 +543,7 @@ k_kpp_buoy_interior_march(DevGrid g, KppDev kp, const double *__restrict__ T, co
   for (; k + 1 <= km; k += 2) { level(k, A, B); level(k + 1, B, A); }
   if (k <= km) level(k, A, B);
   DBLOC[c.base3 + (long long)(km - 1) * n2] = 0.0;
+  if (kp.CONVB) kp.CONVB[c.q2] = convb;
   {
     const double ri = 0.0 * (kp.zgrid[km] - kp.zgrid[km + 1]) / (0.0 + KPP_EPS);   // DBLOC(km) = 0, no shear below
     const double w = (km <= kmt) ? ri : carry;
@@ -1052,8 +1060,14 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
 // PBC: partial bottom cells (vmix_kpp.F90:3835-3864, 2911-2923, 2948-2973, 3075-3083, 3155-3165, 1220-1222, 1296-1302)
 // SAME: the two tracer classes share one diffusivity array (KppDev::vdc_same; a template flag so that the level march below holds no
 // branch around a load or a store).  The march keeps the operands of the next level in flight (two operand sets used in turn).
+// SPARSE (r3; with KppDev::CONVB from the column-march interior kernel, flat bottom): part (1) of the level march touches only what
+// changes.  Below the boundary layer a level is rewritten only where it is convectively unstable (visc + 0.0 is visc, and the
+// zeros below the bottom are already there), found from the 64-bit mask of the column instead of its DBLOC values; the non-local
+// source is written down to KBL and cleared only as deep as the previous evaluation into the same buffers left it non-zero
+// (the KBL stored with them; every level after a caller wrote KPP_SRC).  A level no lane of the wave has to touch is skipped
+// by the whole wave.  Same values as the streaming form (tests/test_gpu_parity.py).
 struct KppBlRaw { double visc, vd1, vd2, db; };
-template <bool PBC = false, bool SAME = false>
+template <bool PBC = false, bool SAME = false, bool SPARSE = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLOC, const double *__restrict__ STF1,
             const double *__restrict__ STF2, double *__restrict__ VISC, double *__restrict__ VDC1, double *__restrict__ VDC2,
@@ -1086,6 +1100,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     for (int k = 1; k <= km; ++k)
       if (hblt > -zgrid[k - 1] && hblt <= ztmp(k)) kbl = max(k, 2);
   HBLT_OUT[c.q2] = hblt;
+  const int kbl_prev = SPARSE ? kp.KBL[c.q2] : 0;   // KBL of the previous evaluation into this set of output buffers
   kp.KBL[c.q2] = kbl;
   const double ustar = kp.USTAR[c.q2];
   double bfsfc = kp.BFSFC[c.q2];
@@ -1156,6 +1171,28 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
   const int kb1 = (kbl - 1 >= 1) ? kbl - 1 : 1;                 // the level of the blending (clamped: KBL = 1 on land has none)
   const double visc_b = VISC[c.base3 + (long long)(kb1 - 1) * n2], vd1_b = VDC1[vb + (long long)kb1 * n2];
   const double vd2_b = SAME ? vd1_b : VDC2[vb + (long long)kb1 * n2];
+  if (SPARSE) {
+    const unsigned long long bits = kp.CONVB[c.q2];
+    const int kdeep = kp.src_clear_all ? km : kbl_prev;
+    const int ktop = (kbl > 1) ? kbl : 1;
+#pragma unroll 1
+    for (int k = 1; k <= km; ++k) {
+      const long long o = c.base3 + (long long)(k - 1) * n2;
+      const bool conv = k >= ktop && k >= kbl && k <= km - 1 && k < kmt && ((bits >> (k - 1)) & 1ull);
+      if (__any(conv)) {      // convection (vmix_kpp.F90:1218-1240) where the column is unstable; the other lanes rewrite their value
+        const double visc = VISC[o], vd1 = VDC1[vb + (long long)k * n2];
+        const double cvv = conv ? sp.convect_visc * 1.0 : 0.0, cvd = conv ? sp.convect_diff * 1.0 : 0.0;
+        VISC[o] = conv ? visc + cvv : visc;
+        VDC1[vb + (long long)k * n2] = conv ? vd1 + cvd : vd1;
+        if (!SAME) { const double vd2 = VDC2[vb + (long long)k * n2]; VDC2[vb + (long long)k * n2] = conv ? vd2 + cvd : vd2; }
+      }
+      const bool clr = k > kbl && k <= kdeep;
+      if (__any(clr)) {       // +-0 below the boundary layer: stf / dz * (0 - 0); lanes above it are rewritten by part (2)
+        const double dzk = g.dz.u(k);
+        SRC1[o] = stf1 / dzk * (0.0 - 0.0); SRC2[o] = stf2 / dzk * (0.0 - 0.0);
+      }
+    }
+  } else {
   auto load = [&](int k) {
     KppBlRaw r;
     const long long o = c.base3 + (long long)(k - 1) * n2;
@@ -1190,6 +1227,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     for (; k + 1 <= km; k += 2) { level(k, A, B); level(k + 1, B, A); }
     if (k <= km) level(k, A, B);
   }
+  }
   // (2) the boundary layer
   double flux1_prev = 0.0, flux2_prev = 0.0;   // VDC(k-1)*GHAT(k-1) per tracer class
 #pragma unroll 1
@@ -1198,6 +1236,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
     const double dzk = (PBC && k > 1) ? dzt_at(k) : g.dz[k];
     if (k == kbl) {     // first level below: its source still feels the flux through its upper face
       if (k > 1) { SRC1[o] = stf1 / dzk * (flux1_prev - 0.0); SRC2[o] = stf2 / dzk * (flux2_prev - 0.0); }
+      else if (SPARSE) { SRC1[o] = stf1 / dzk * (-(0.0)); SRC2[o] = stf2 / dzk * (-(0.0)); }   // KBL = 1 (land): -(vd * ghat), ghat = 0
       break;
     }
     double sig = (-zgrid[k] + 0.5 * hwide[k]) / hblt;
@@ -1303,7 +1342,7 @@ __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__
 // per-context KPP state (MixDev::kpp)
 // col: bit 0 = ushear, bit 1 = buoydiff in column form.  side / ev_*: second HIP stream on which the shear kernel (needs only
 // U, V; consumed by bldepth) runs beside buoydiff + interior (POP_KPP_SIDE_STREAM=0 keeps everything on one stream)
-struct KppHost { KppDev dev; int max_kref = 1; int col = 0; int *wuk = nullptr; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bd = nullptr; };
+struct KppHost { KppDev dev; int max_kref = 1; int col = 0; int *wuk = nullptr; unsigned long long *convb = nullptr; hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bd = nullptr; };
 inline void kpp_destroy(MixDev &m) {
   KppHost *k = (KppHost *)m.kpp;
   if (k) {
@@ -1444,6 +1483,8 @@ inline int kpp_create(HostModel &h, const DevGrid &g, MixDev &m, std::vector<voi
   if (up(zi.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } k.KBL0 = (int *)p;
   if (up(zi.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } k.KBL = (int *)p;
   if (up(zi.data(), a2 * 4, &p)) { err = "kpp alloc"; return 1; } K->wuk = (int *)p;
+  { std::vector<unsigned long long> zb(a2, 0ull); if (up(zb.data(), a2 * 8, &p)) { err = "kpp alloc"; return 1; } K->convb = (unsigned long long *)p; }
+  k.CONVB = nullptr; k.src_clear_all = 0;
   k.WUK = nullptr; k.wu_margin = 3;
   k.Vtc = std::sqrt(0.2 / KPP_C_S / KPP_EPSSFC) / (KPP_VONKAR * KPP_VONKAR);
   k.cg = KPP_CSTAR * KPP_VONKAR * std::pow(KPP_C_S * KPP_VONKAR * KPP_EPSSFC, 1.0 / 3.0);
@@ -1530,6 +1571,8 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   const int bw = tun_or(h.tun.kpp_buoy_waves, 2);
   // bit 4: the two as one column march (one smoothing pass, no double diffusion)
   const bool march = lazy && fused_bi && (g_kpp_col & 16) && g_kpp.nsmooth == 1 && !g_kpp.ldbl_diff && g.km >= 3;
+  g_kpp.CONVB = (march && g.km <= 64 && !tun_off(h.tun.kpp_sparse)) ? KH.convb : nullptr;
+  g_kpp.src_clear_all = s.src_clear_all;
   if (march) hipLaunchKernelGGL(k_kpp_buoy_interior_march, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else if (lazy && fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8, false>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if (fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
@@ -1565,7 +1608,12 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                                     (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
   else hipLaunchKernelGGL((k_kpp_bldepth<false, 20>), GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
                           (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
-  if (g_kpp.vdc_same) hipLaunchKernelGGL((k_kpp_blmix<false, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+  const bool sparse = g_kpp.CONVB != nullptr;
+  if (sparse && g_kpp.vdc_same) hipLaunchKernelGGL((k_kpp_blmix<false, true, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+                                                   s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+  else if (sparse) hipLaunchKernelGGL((k_kpp_blmix<false, false, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
+                                      s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+  else if (g_kpp.vdc_same) hipLaunchKernelGGL((k_kpp_blmix<false, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                                           s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
   else hipLaunchKernelGGL((k_kpp_blmix<false, false>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                           s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);

@@ -17,6 +17,7 @@ struct MixState {        // per-step field pointers handed to the mixing kernels
   const double *TMIX[2], *UMIX, *VMIX, *UCUR, *VCUR, *RHOMIX, *STF[2], *SHF_QSW;
   double *VDC[2], *VVC, *KPP_SRC[2], *HBLT, *HMXL, *HMXL_DR;
   int *KBL = nullptr;        // KPP: level of the boundary-layer depth, paired with KPP_SRC (nullptr: the scheme's own array)
+  int src_clear_all = 0;     // KPP: this set's KPP_SRC may hold non-zeros below its KBL (a caller wrote it): clear every level
   double *S3a, *S3b, *S3c, *S3d, *E3, *F3;   // 3-D scratch
 };
 

@@ -77,6 +77,7 @@ struct pop_ctx {
   // work beside bandwidth-bound work) into a second set of output fields; the next step swaps the sets in.
   bool vdc_shared = false;
   bool kpp_src_user = false;   // the caller wrote KPP_SRC (pop_set_field): read it at every level until KPP has run again
+  bool src_dirty = true, src_dirty_alt = true;   // KPP_SRC / KPPa may hold non-zeros below the KBL stored with them: the next evaluation into that set clears every level
   double *VDCa[2] = {nullptr, nullptr}, *VVCa = nullptr, *KPPa[MAXNT] = {}, *HBLTa = nullptr;
   int *KBL = nullptr, *KBLa = nullptr;   // KBL that belongs to KPP_SRC / KPPa (the tracer kernel reads KPP_SRC down to it)
   hipStream_t ahead = nullptr; hipEvent_t ev_ahead_fork = nullptr, ev_ahead = nullptr;
@@ -1238,7 +1239,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -1956,7 +1957,7 @@ int pop_set_field(pop_ctx *c, const char *name, int tl, int n, const double *hos
     for (long long q = 0; q < cnt; ++q) idx[q] = sw_chl_index(c->h.sw, host[q]);
     HIPCHK(c, hipMemcpy(c->h.sw.CHLI, idx.data(), (size_t)cnt * sizeof(int), hipMemcpyHostToDevice));
   }
-  if (!strcmp(name, "KPP_SRC")) c->kpp_src_user = true;
+  if (!strcmp(name, "KPP_SRC")) { c->kpp_src_user = true; c->src_dirty = true; c->src_dirty_alt = true; }
   if (!strcmp(name, "TRACER")) c->tr_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;
   if (!strcmp(name, "UVEL") || !strcmp(name, "VVEL")) c->uv_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;
   // a new prognostic state may carry other values on land: the next steps run every workgroup again (land elimination)
@@ -1985,7 +1986,7 @@ void *pop_field_device_ptr(pop_ctx *c, const char *name, int tl, int n) {
   join_side(c);   // the caller may read the field on the launch stream
   if (!strcmp(name, "TRACER")) c->tr_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;   // ... or write it
   if (!strcmp(name, "UVEL") || !strcmp(name, "VVEL")) c->uv_ghosts_ok[tl == 0 ? c->oldt : tl == 1 ? c->curt : c->newt] = false;
-  if (!strcmp(name, "KPP_SRC")) c->kpp_src_user = true;
+  if (!strcmp(name, "KPP_SRC")) { c->kpp_src_user = true; c->src_dirty = true; c->src_dirty_alt = true; }
   // ... with other values on land: the next steps run every workgroup again, as after pop_set_field
   for (const char *f : {"TRACER", "UVEL", "VVEL", "RHO", "PSURF", "GRADPX", "GRADPY", "UBTROP", "VBTROP", "PGUESS", "FW_OLD"})
     if (!strcmp(name, f)) c->full_left = c->land_full_steps;
@@ -2163,6 +2164,8 @@ static MixState kpp_mix_state(pop_ctx *c, int slot, bool into_alt) {
   ms.UMIX = c->U[slot]; ms.VMIX = c->V[slot]; ms.UCUR = c->U[c->curt]; ms.VCUR = c->V[c->curt]; ms.RHOMIX = c->RHO[slot];
   ms.VVC = into_alt ? c->VVCa : c->VVC; ms.SHF_QSW = c->SHF_QSW; ms.HBLT = into_alt ? c->HBLTa : c->HBLT; ms.HMXL = c->HMXL; ms.HMXL_DR = c->HMXL_DR;
   ms.KBL = into_alt ? c->KBLa : c->KBL;
+  ms.src_clear_all = (into_alt ? c->src_dirty_alt : c->src_dirty) ? 1 : 0;
+  (into_alt ? c->src_dirty_alt : c->src_dirty) = false;   // the evaluation that follows clears the set
   ms.S3a = c->S3a; ms.S3b = c->S3b; ms.S3c = c->S3c; ms.S3d = c->S3d; ms.E3 = c->E3; ms.F3 = c->F3;
   return ms;
 }
@@ -2176,7 +2179,7 @@ static int phase_vmix(pop_ctx *c) {
       HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
       c->ahead_valid = false; c->kpp_src_user = false;
       for (int n = 0; n < 2; ++n) { std::swap(c->VDC[n], c->VDCa[n]); std::swap(c->KPP_SRC[n], c->KPPa[n]); }
-      std::swap(c->VVC, c->VVCa); std::swap(c->HBLT, c->HBLTa); std::swap(c->KBL, c->KBLa);
+      std::swap(c->VVC, c->VVCa); std::swap(c->HBLT, c->HBLTa); std::swap(c->KBL, c->KBLa); std::swap(c->src_dirty, c->src_dirty_alt);
       return 0;
     }
     if (ahead_cancel(c)) return 1;

@@ -593,18 +593,29 @@ def test_kpp_interior_column_march_is_bitwise_the_level_parallel_kernel(pkg, orc
     monkeypatch.setenv("POP_XCD_REMAP", "0")
     cfg = named_config("tiny", **kw)
     out = {}
-    for col in ("31", "15", "3"):
-        monkeypatch.setenv("POP_KPP_COL", col)
+    # "31": column march + the sparse boundary-layer kernel (convection mask, source cleared only as deep as it was written);
+    # "31s": column march + the streaming boundary-layer kernel; "15" / "3": the level-parallel / separate interior kernels
+    for col in ("31", "31s", "15", "3"):
+        monkeypatch.setenv("POP_KPP_COL", col[:2])
+        monkeypatch.setenv("POP_KPP_SPARSE", "0" if col == "31s" else "1")
         m, orc = pkg.PopModel(cfg), Oracle(cfg)
         force_kpp_case(m, orc)
         orc.close()
-        assert m.tuning()["kpp_col"] == int(col)
-        for _ in range(4):
+        assert m.tuning()["kpp_col"] == int(col[:2])
+        res = []
+        for step in range(7):
+            if step == 4:       # a caller writes the non-local source: honoured by the next step, then cleared at every level again
+                junk = np.random.default_rng(3).standard_normal(m.get("KPP_SRC", 1, 0).shape) * 1.0e-7
+                m.set("KPP_SRC", junk, 1, 0)
+            if step == 5:       # the boundary layer shoals: what the deeper one left in KPP_SRC must go
+                m.set("STF", np.abs(m.get("STF", 1, 0)) * 4.0, 1, 0)
             m.step()
-        out[col] = [m.get("HBLT").copy(), m.get("VDC", 1, 0).copy(), m.get("VVC").copy()] + [m.get("KPP_SRC", 1, n).copy() for n in (0, 1)] + \
-                   [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "RHO")] + [m.get("TRACER", 1, 1).copy()]
+            if step in (3, 4, 6):
+                res += [m.get("HBLT").copy(), m.get("VDC", 1, 0).copy(), m.get("VVC").copy()] + [m.get("KPP_SRC", 1, n).copy() for n in (0, 1)] + \
+                       [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "RHO")] + [m.get("TRACER", 1, 1).copy()]
+        out[col] = res
         m.close()
-    for col in ("15", "3"):
+    for col in ("31s", "15", "3"):
         for a, b in zip(out["31"], out[col]):
             assert np.array_equal(a, b), col
 
