@@ -124,6 +124,13 @@ __global__ void k_operator(DevGrid g, int op, int k, const double *__restrict__ 
 // fixed LDS tree and writes partial[(blk*nchunk + chunk)*nfields + f].  Stage 2 (one workgroup)
 // adds the partials of every POP block in fixed order -> block sums (the b4b block-sum vector of
 // mpi/POP_ReductionsMod.F90:348-383), then the block sums in global block-id order.
+// levels 32 .. 1 of the fixed tree inside the first wavefront (r3): lane t < s adds the value of lane t + s -- the operands and the
+// order of sh[t] = sh[t] + sh[t + s] -- through the cross-lane network instead of six LDS round trips with a barrier each
+__device__ __forceinline__ double tree_tail64(double x) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) x = x + __shfl_down(x, s, 64);
+  return x;
+}
 template <int NF>
 __device__ __forceinline__ void wg_reduce_store(double (&v)[NF], double *partial, int slot) {
   __shared__ double sh[NF][POP_RED_THREADS];
@@ -131,16 +138,19 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NF], double *partial
 #pragma unroll
   for (int f = 0; f < NF; ++f) sh[f][t] = v[f];
   __syncthreads();
-  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+  for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
     if (t < s) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) sh[f][t] = sh[f][t] + sh[f][t + s];
     }
     __syncthreads();
   }
-  if (t == 0) {
+  if (t < 64) {
 #pragma unroll
-    for (int f = 0; f < NF; ++f) partial[(long long)slot * NF + f] = sh[f][0];
+    for (int f = 0; f < NF; ++f) {
+      const double x = tree_tail64(sh[f][t]);
+      if (t == 0) partial[(long long)slot * NF + f] = x;
+    }
   }
 }
 // Stage 2: blocksum[gid[b]*NF+f] = ordered sum of partials of local block b.  One workgroup per
@@ -188,15 +198,16 @@ __device__ __forceinline__ void block_sum_ordered(const double *__restrict__ pb,
 #pragma unroll
   for (int f = 0; f < NF; ++f) sh[f][t] = v[f];
   __syncthreads();
-  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+  for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
     if (t < s) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) sh[f][t] = sh[f][t] + sh[f][t + s];
     }
     __syncthreads();
   }
+  // out is used by thread 0 only (every caller stores from threadIdx.x == 0)
 #pragma unroll
-  for (int f = 0; f < NF; ++f) out[f] = sh[f][0];
+  for (int f = 0; f < NF; ++f) out[f] = (t < 64) ? tree_tail64(sh[f][t]) : 0.0;
 }
 template <int NF>
 __global__ void __launch_bounds__(POP_RED_THREADS) k_block_sums(const double *__restrict__ partial, int nchunk, const int *__restrict__ gid,
@@ -819,11 +830,14 @@ k_fpcg_a_pair(DevGrid g, FusedArgs a) {
     sh[u][t] = v;
   }
   __syncthreads();
-  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+  for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
     if (t < s) { sh[0][t] = sh[0][t] + sh[0][t + s]; sh[1][t] = sh[1][t] + sh[1][t + s]; }
     __syncthreads();
   }
-  if (t < 2) a.partA[(long long)b * a.nchunk + ch[t]] = sh[t][0];
+  if (t < 64) {
+    const double x0 = tree_tail64(sh[0][t]), x1 = tree_tail64(sh[1][t]);
+    if (t == 0) { a.partA[(long long)b * a.nchunk + ch[0]] = x0; a.partA[(long long)b * a.nchunk + ch[1]] = x1; }
+  }
 }
 
 // step B: s_new = z + s_old*(eta1/eta0) at the 9 stencil points; q = A s_new; partial (q,s).
@@ -1173,11 +1187,14 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
   // the tree of wg_reduce_store<1> over the 256 cells of the chunk
   sh[2 * t] = v0; sh[2 * t + 1] = v1;
   __syncthreads();
-  for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+  for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
     if (t < s) sh[t] = sh[t] + sh[t + s];
     __syncthreads();
   }
-  if (t == 0) a.partB[(long long)b * a.nchunk + red_chunk(g)] = sh[0];
+  if (t < 64) {
+    const double x = tree_tail64(sh[t]);
+    if (t == 0) a.partB[(long long)b * a.nchunk + red_chunk(g)] = x;
+  }
 }
 
 // pending x,r update before a convergence check
