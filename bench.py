@@ -310,6 +310,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-rows", type=int, default=0, help="rows per j-band block (default: one band per rank, or balanced bands on large grids)")
     ap.add_argument("--no-deep-state", action="store_true", help="skip the second (deep KPP boundary layer) measurement after the timed region")
+    ap.add_argument("--pbc", action="store_true", help="NOT the headline: partial bottom cells on stepped bathymetry (grid_nml partial_bottom_cells, SURVEY 8 f3); "
+                                                       "config.partial_bottom_cells says so in the line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -341,6 +343,8 @@ def main():
     cfg = workload_config(args.workload, world, args.block_rows)
     cfg.solver_choice = {"pcg": 1, "chrongear": 2, "pcsi": 3}[args.solver]
     cfg.preconditioner_choice = 1 if args.precond == "evp" else 0
+    if args.pbc:
+        cfg.partial_bottom_cells = 1
     model = pkg.PopModel(cfg, rank=rank, nranks=world)
     comm, transport, transport_note = None, "none", ""
     if world > 1:
@@ -508,7 +512,7 @@ def main():
                    "land_tile_fraction": round(land_frac, 4), "distribution": "balanced-ocean-columns" if cfg.distribution_type else "equal-block-counts",
                    "blocks_local": model.nblocks,
                    "hmix": "del%d" % cfg.hmix_momentum, "vmix": ["const", "rich", "kpp"][vm],
-                   "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
+                   "partial_bottom_cells": bool(cfg.partial_bottom_cells), "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport,
                    # every output of the step is bitwise what the full evaluation gives (tests/test_gpu_parity.py); DESIGN.md 3, "KPP's surface-layer buoyancy difference on demand"
                    "kpp_surface_buoyancy": ("on-demand down to the boundary-layer depth" if vm == 2 and tun.get("kpp_lazy", 1) != 0

@@ -15,13 +15,16 @@
 namespace pop {
 
 // the corrector form (MODE 1) needs ~260 VGPRs: capped at 256 it runs two waves per SIMD
-template <int KM, int MODE, bool PRE, bool POST>
+// PBC (r3): partial bottom cells -- from level 2 on the column's own thicknesses (vertical_mix.F90:1279-1287, 1577-1585), which
+// differ from dz(k) at level KMT only: two selects per level on top of the flat-bottom kernel, same expressions as k_impvmixt<.,.,.,true>
+template <int KM, int MODE, bool PRE, bool POST, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS, (MODE == 1) ? 2 : 1)
 k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
   Col c;
   if (!col_setup(g, c, true)) return;
   const long long n2 = g.n2;
   const int kmt = g.KMT[c.q2];
+  const double dzbc = PBC ? g.DZBC[c.q2] : 0.0;
   const double hfac1 = g.dz[1] / a.c2dtt;
   const double H1 = hfac1 + a.PSFC[c.q2] / (sp.grav * a.c2dtt);
   const long long vdcbase = ((long long)c.b * (KM + 2)) * n2 + c.p2;
@@ -65,8 +68,12 @@ k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
 #pragma unroll
     for (int k = 2; k <= KM; ++k) {
       const double C = A;
-      const double hf = g.dz[k] / a.c2dtt;
-      A = g.afac_t[k] * Ea[k - 1];
+      double hf = g.dz[k] / a.c2dtt;
+      if (PBC) {
+        const double dzt = pbc_dz(g, k, kmt, dzbc);
+        A = sp.aidif * Ea[k - 1] / (0.5 * (dzt + pbc_dz(g, k + 1, kmt, dzbc)));
+        hf = dzt / a.c2dtt;
+      } else A = g.afac_t[k] * Ea[k - 1];
       const double tn = Fa[k - 1];
       if (k > kmt) { Fk = 0.0; }
       else {
@@ -107,13 +114,14 @@ k_impvmixt_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
 // once and VDC is read once -- 7 instead of 8 fields through HBM in the predictor, 5 instead of 6 in the corrector, 3 divisions per
 // level instead of 4.  Each tracer's values go through exactly the operations of k_impvmixt_reg (E is the same number in both
 // threads there), so TNEW is bitwise unchanged.  Three register columns (E, F_T, F_S): one wave per SIMD.
-template <int KM, int MODE, bool PRE, bool POST>
+template <int KM, int MODE, bool PRE, bool POST, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS, 1)
 k_impvmixt2_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
   Col c;
   if (!col_setup(g, c, true)) return;
   const long long n2 = g.n2;
   const int kmt = g.KMT[c.q2];
+  const double dzbc = PBC ? g.DZBC[c.q2] : 0.0;
   const double hfac1 = g.dz[1] / a.c2dtt;
   const double H1 = hfac1 + a.PSFC[c.q2] / (sp.grav * a.c2dtt);
   const long long vdcbase = ((long long)c.b * (KM + 2)) * n2 + c.p2;
@@ -153,8 +161,12 @@ k_impvmixt2_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
 #pragma unroll
   for (int k = 2; k <= KM; ++k) {
     const double C = A;
-    const double hf = g.dz[k] / a.c2dtt;
-    A = g.afac_t[k] * Ea[k - 1];
+    double hf = g.dz[k] / a.c2dtt;
+    if (PBC) {
+      const double dzt = pbc_dz(g, k, kmt, dzbc);
+      A = sp.aidif * Ea[k - 1] / (0.5 * (dzt + pbc_dz(g, k + 1, kmt, dzbc)));
+      hf = dzt / a.c2dtt;
+    } else A = g.afac_t[k] * Ea[k - 1];
     const double tn0 = F0[k - 1], tn1 = F1[k - 1];
     if (k > kmt) { Fk0 = 0.0; Fk1 = 0.0; }
     else {
@@ -193,7 +205,8 @@ k_impvmixt2_reg(DevGrid g, StepParams sp, ImpvmixtArgs a) {
 // ADD: the step tail's "add the barotropic velocity where k <= KMU" (step_mod.F90:572-592, k_add_barotropic) applied to the value
 // on its way out -- the same sum (X - mean) + UBTROP, so U, V(new) are bitwise what the two launches leave, and one read and one
 // write of both 3-D fields are gone.  Only valid once the barotropic solve of the step has finished (pop_amd.hip: deferred form).
-template <int KM, int WAVES, bool ADD = false>
+// PBC (r3): the U cells' own thicknesses, DZU = dz except DZUB at level KMU (vertical_mix.F90:1777-1785; baroclinic.F90:1097-1106)
+template <int KM, int WAVES, bool ADD = false, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS, WAVES)
 k_impvmixu_reg(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   Col c;
@@ -201,6 +214,7 @@ k_impvmixu_reg(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   const long long n2 = g.n2;
   const int kmu = g.KMU[c.q2];
   const double hur = g.HUR[c.q2];
+  const double dzub = PBC ? g.DZUB[c.q2] : 0.0;
   const bool isv = (blockIdx.z == 1);
   double *__restrict__ const XN = isv ? a.VNEW : a.UNEW;
   const double *__restrict__ const XO = isv ? a.VOLD : a.UOLD;
@@ -221,8 +235,16 @@ k_impvmixu_reg(DevGrid g, StepParams sp, ImpvmixuArgs a) {
 #pragma unroll
   for (int k = 2; k <= KM; ++k) {
     const double C = A;
-    const double hf = g.dz[k] / sp.c2dtu;
-    A = g.afac_u[k] * Ea[k - 1];
+    double hf = g.dz[k] / sp.c2dtu;
+    if (PBC) {
+      // the thicknesses depend on (kmu, dzub) only, so the scheduler would form all 62 selections at the top of the unrolled
+      // column and keep them alive (460 B of scratch): tied to the recurrence, each is formed where it is used
+      double dzub_k = dzub;
+      asm volatile("" : "+v"(dzub_k) : "v"(B));
+      const double dzu = pbc_dz(g, k, kmu, dzub_k);
+      hf = dzu / sp.c2dtu;
+      A = sp.aidif * Ea[k - 1] / (0.5 * (dzu + pbc_dz(g, k + 1, kmu, dzub_k)));
+    } else A = g.afac_u[k] * Ea[k - 1];
     if (k <= kmu) {
       D = (k < kmu) ? hf + A + B : hf + B;
       Ek = A / D;
@@ -244,7 +266,13 @@ k_impvmixu_reg(DevGrid g, StepParams sp, ImpvmixuArgs a) {
   }
   double w1 = 0.0;
 #pragma unroll
-  for (int k = 1; k <= KM; ++k) w1 = w1 + Xa[k - 1] * g.dz[k];
+  for (int k = 1; k <= KM; ++k) {
+    if (PBC) {
+      double dzub_k = dzub;
+      asm volatile("" : "+v"(dzub_k) : "v"(w1));       // as above: the selection formed where it is used
+      w1 = w1 + Xa[k - 1] * pbc_dz(g, k, kmu, dzub_k);
+    } else w1 = w1 + Xa[k - 1] * g.dz[k];
+  }
   w1 = w1 * hur;
 #pragma unroll
   for (int k = 1; k <= KM; ++k) Xa[k - 1] = (k <= kmu) ? Xa[k - 1] - w1 : 0.0;
@@ -265,8 +293,19 @@ inline void launch_impvmixt(const DevGrid &g, const StepParams &sp, const Impvmi
   // both tracers in one thread when they share the diffusivity array (pop_tuning.thomas_pair = 0 | 1 overrides the size rule)
   const int pair_env = tun_or(pair_tuning, -1);
   // (corrector form only: the predictor's three full register columns + its up-front loads spill ~ 900 B per lane)
-  if (g.pbc) {   // partial bottom cells: the scratch-staged kernel with the column's own thicknesses
-    hipLaunchKernelGGL((k_impvmixt<MODE, PRE, POST, true>), G, B, 0, st, g, sp, a);
+  if (g.pbc) {   // partial bottom cells: the register kernels' PBC instantiations at km = 60 / 62, else the scratch-staged kernel
+    const bool reg = allow_reg && (g.km == 60 || g.km == 62);
+    const bool pairp = MODE == 1 && reg && a.nfirst == 1 && a.nlast == 2 && a.VDC[0] == a.VDC[1] &&
+                       (pair_env >= 0 ? pair_env != 0 : (long long)g.n2 * g.nblocks > (1 << 19));
+    if (!reg) { hipLaunchKernelGGL((k_impvmixt<MODE, PRE, POST, true>), G, B, 0, st, g, sp, a); return; }
+    if (pairp) {
+      if constexpr (MODE == 1) {
+        if (g.km == 60) hipLaunchKernelGGL((k_impvmixt2_reg<60, MODE, PRE, POST, true>), G, B, 0, st, g, sp, a);
+        else hipLaunchKernelGGL((k_impvmixt2_reg<62, MODE, PRE, POST, true>), G, B, 0, st, g, sp, a);
+      }
+    } else if (g.km == 60) hipLaunchKernelGGL((k_impvmixt_reg<60, MODE, PRE, POST, true>), G2, B, 0, st, g, sp, a);
+    else hipLaunchKernelGGL((k_impvmixt_reg<62, MODE, PRE, POST, true>), G2, B, 0, st, g, sp, a);
+    if (POST) hipLaunchKernelGGL(k_state3d, dim3((g.n2 + 255) / 256, g.km, g.nblocks), dim3(256), 0, st, g, (const double *)a.TNEW[0], (const double *)a.TNEW[1], a.RHO);
     return;
   }
   const bool pair = MODE == 1 && allow_reg && (g.km == 60 || g.km == 62) && a.nfirst == 1 && a.nlast == 2 && a.VDC[0] == a.VDC[1] &&
@@ -288,7 +327,12 @@ inline void launch_impvmixu(const DevGrid &g, const StepParams &sp, const Impvmi
   const dim3 B(POP_COL_THREADS);
   const dim3 G2(G.x, G.y, 2);
   const bool small = (long long)g.n2 * g.nblocks <= (1 << 19);
-  if (g.pbc) { hipLaunchKernelGGL(k_impvmixu_norm<true>, G, B, 0, st, g, sp, a); return; }
+  if (g.pbc) {
+    if (allow_reg && g.km == 60) hipLaunchKernelGGL((k_impvmixu_reg<60, 1, false, true>), G2, B, 0, st, g, sp, a);
+    else if (allow_reg && g.km == 62) hipLaunchKernelGGL((k_impvmixu_reg<62, 1, false, true>), G2, B, 0, st, g, sp, a);
+    else hipLaunchKernelGGL(k_impvmixu_norm<true>, G, B, 0, st, g, sp, a);
+    return;
+  }
   if (allow_reg && g.km == 60 && small) hipLaunchKernelGGL((k_impvmixu_reg<60, 2>), G2, B, 0, st, g, sp, a);
   else if (allow_reg && g.km == 60) hipLaunchKernelGGL((k_impvmixu_reg<60, 1>), G2, B, 0, st, g, sp, a);
   else if (allow_reg && g.km == 62 && small) hipLaunchKernelGGL((k_impvmixu_reg<62, 2>), G2, B, 0, st, g, sp, a);
@@ -296,11 +340,16 @@ inline void launch_impvmixu(const DevGrid &g, const StepParams &sp, const Impvmi
   else hipLaunchKernelGGL(k_impvmixu_norm<false>, G, B, 0, st, g, sp, a);
 }
 // the register kernel with the barotropic velocity added on the way out (a.UB, a.VB set); km = 60 / 62 only
-inline bool impvmixu_add_available(const DevGrid &g, bool allow_reg) { return allow_reg && !g.pbc && (g.km == 60 || g.km == 62); }
+inline bool impvmixu_add_available(const DevGrid &g, bool allow_reg) { return allow_reg && (g.km == 60 || g.km == 62); }
 inline void launch_impvmixu_add(const DevGrid &g, const StepParams &sp, const ImpvmixuArgs &a, dim3 G, hipStream_t st) {
   const dim3 B(POP_COL_THREADS);
   const dim3 G2(G.x, G.y, 2);
   const bool small = (long long)g.n2 * g.nblocks <= (1 << 19);
+  if (g.pbc) {
+    if (g.km == 60) hipLaunchKernelGGL((k_impvmixu_reg<60, 1, true, true>), G2, B, 0, st, g, sp, a);
+    else hipLaunchKernelGGL((k_impvmixu_reg<62, 1, true, true>), G2, B, 0, st, g, sp, a);
+    return;
+  }
   if (g.km == 60 && small) hipLaunchKernelGGL((k_impvmixu_reg<60, 2, true>), G2, B, 0, st, g, sp, a);
   else if (g.km == 60) hipLaunchKernelGGL((k_impvmixu_reg<60, 1, true>), G2, B, 0, st, g, sp, a);
   else if (small) hipLaunchKernelGGL((k_impvmixu_reg<62, 2, true>), G2, B, 0, st, g, sp, a);

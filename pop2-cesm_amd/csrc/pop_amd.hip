@@ -1239,7 +1239,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -1719,9 +1719,9 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     // predictor 7.2 vs 7.5-8.1, step -1.2 .. -1.6 ms).  The velocity solve is faster in registers at both sizes.
     c->reg_thomas_t = c->reg_thomas;
     if (tun_set(h.tun.reg_thomas_t)) c->reg_thomas_t = h.tun.reg_thomas_t != 0;
-    if (cfg->partial_bottom_cells) {
-      // partial bottom cells (round 3): the right-hand-side kernels (LDS-tiled and direct-load) and the scratch-staged Thomas
-      // kernels carry the PBC branches; the register Thomas forms are flat-bottom only
+    if (cfg->partial_bottom_cells && tun_on(h.tun.pbc_generic_thomas)) {
+      // partial bottom cells (round 3): every Thomas kernel form carries the PBC branches; pop_tuning.pbc_generic_thomas = 1 keeps
+      // the scratch-staged ones (the cross-check of the register instantiations)
       c->reg_thomas = false; c->reg_thomas_t = false;
     }
     c->force_presum = tun_on(h.tun.solver_presum);
@@ -2359,7 +2359,7 @@ static int phase_correct(pop_ctx *c) {
   // the generic Thomas kernel stages E, F through the shared 3-D scratch (E3, F3), which a KPP look-ahead in flight on its own
   // stream also uses (E3 = the Richardson column of the generic k_kpp_interior): the corrector then follows the look-ahead.
   // The register kernels (km = 60 / 62) touch no scratch and run beside it.
-  const bool reg_kernel = c->reg_thomas_t && !c->g.pbc && (c->g.km == 60 || c->g.km == 62);
+  const bool reg_kernel = c->reg_thomas_t && (c->g.km == 60 || c->g.km == 62);
   if (!reg_kernel && c->ahead_valid) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
   if (sp.pavg) launch_impvmixt<1, false, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t, c->h.tun.thomas_pair);
   else launch_impvmixt<0, true, true>(c->g, sp, impvmixt_args(c, c->PS[c->newt]), grid_cols(c), c->stream, c->reg_thomas_t, c->h.tun.thomas_pair);
@@ -2429,7 +2429,7 @@ int pop_baroclinic_driver(pop_ctx *c) {
   const bool defer = c->side && impvmixu_add_available(c->g, c->reg_thomas) && c->h.c.ns_boundary != 2 && !tun_on(c->h.tun.btrop_inline) &&
                      !tun_on(c->h.tun.vmixu_inline) && (defer_env >= 0 ? defer_env != 0 : (long long)c->g.n2 * c->g.nblocks > (1 << 19));
   if (defer) c->vmixu_deferred = true;
-  else if (c->side && c->reg_thomas && !c->g.pbc && (c->g.km == 60 || c->g.km == 62) && !tun_on(c->h.tun.vmixu_inline)) {
+  else if (c->side && c->reg_thomas && (c->g.km == 60 || c->g.km == 62) && !tun_on(c->h.tun.vmixu_inline)) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     if (phase_impvmixu(c, c->side)) return 1;

@@ -198,3 +198,27 @@ def test_partial_bottom_cells_at_a_quarter_of_tx01v3(pkg, orclib_built):
     its = m.solver_diagnostics()[0]
     assert 0 < its < cfg.max_iterations
     m.close()
+
+
+@pytest.mark.parametrize("kw", [{"vmix_choice": 3, "km": 62, **DEL4}, {"vmix_choice": 1, "km": 60}, {"vmix_choice": 3, "km": 60, "ldbl_diff": 1}],
+                         ids=["kpp-km62-del4", "const-km60", "kpp-dd-km60"])
+def test_register_thomas_kernels_with_partial_bottom_cells_are_bitwise_the_generic_ones(pkg, monkeypatch, kw):
+    """km = 60 / 62: the column-in-registers instantiations k_impvmixt_reg / k_impvmixt2_reg / k_impvmixu_reg<..., PBC> against the
+    scratch-staged kernels (POP_PBC_GENERIC_THOMAS=1), six steps on stepped bathymetry, every prognostic field to the last bit;
+    with the barotropic sum fused into the velocity solve (POP_VMIXU_DEFER=1) and without."""
+    cfg = named_config("tiny", stepped_bathymetry=1, partial_bottom_cells=1, **kw)
+    out = {}
+    for tag, env in (("reg", {}), ("reg-defer", {"POP_VMIXU_DEFER": "1"}), ("pair", {"POP_THOMAS_PAIR": "1"}), ("generic", {"POP_PBC_GENERIC_THOMAS": "1"})):
+        for k in ("POP_VMIXU_DEFER", "POP_THOMAS_PAIR", "POP_PBC_GENERIC_THOMAS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = pkg.PopModel(cfg)
+        for _ in range(6):
+            m.step()
+        out[tag] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "RHO")] + [m.get("TRACER", 1, 1).copy(), m.get("TRACER", 2, 0).copy()]
+        m.close()
+    assert np.abs(out["reg"][0]).max() > 1.0
+    for tag in ("reg-defer", "pair", "generic"):
+        for a, b in zip(out["reg"], out[tag]):
+            assert np.array_equal(a, b), tag
