@@ -139,6 +139,7 @@ typedef struct pop_tuning {
   int fpcg_a_pair;         /* 0: one chunk per workgroup in step A of the fused pcg even on compacted launches */
   int kpp_sparse;          /* 0: KPP boundary-layer kernel streams every level even when the interior kernel formed the convection mask */
   int pbc_generic_thomas;  /* 1: partial bottom cells with the scratch-staged Thomas kernels even at km = 60 / 62 */
+  int pbc_generic_kpp;     /* 1: partial bottom cells with the 3-D-parallel / scratch-staged KPP kernels on large grids too */
   int stream_priority;     /* 1: the launch stream above the gap-filling side streams (default 0: measured slower) */
 } pop_tuning;
 void pop_tuning_init(pop_tuning *t);   /* struct_bytes = sizeof, every field POP_TUNING_UNSET */

@@ -456,6 +456,9 @@ __global__ void k_kpp_level_table(DevGrid g, double *__restrict__ tab) {
   t[0] = P.n0; t[1] = P.n2; t[2] = P.ns1t0; t[3] = P.d0; t[4] = P.d1; t[5] = P.d3;
 }
 struct KppRaw { double t, s, u[4], v[4]; };
+// PBC: partial bottom cells (vmix_kpp.F90:1531-1533, 1553-1563): the shear of each U corner over its own thickness, the Richardson
+// number over the T column's own thickness
+template <bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_buoy_interior_march(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
                           const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ DBLOC,
@@ -468,6 +471,12 @@ k_kpp_buoy_interior_march(DevGrid g, KppDev kp, const double *__restrict__ T, co
   const bool edge = (c.i == 0 || c.j == 0);          // ugrid_to_tgrid zeroes the first row and column (their loads go to the own cell)
   const long long off4[4] = {0, edge ? 0 : -(long long)nxb, edge ? 0 : -1, edge ? 0 : -1 - (long long)nxb};
   const long long vb = ((long long)c.b * (km + 2)) * n2 + c.p2;
+  int kmu4[4] = {0, 0, 0, 0}; double dzub4[4] = {0.0, 0.0, 0.0, 0.0}; const double dzbc = PBC ? g.DZBC[c.q2] : 0.0;
+  if (PBC) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { kmu4[t] = g.KMU[c.q2 + off4[t]]; dzub4[t] = g.DZUB[c.q2 + off4[t]]; }
+  }
+  auto dzq = [&](int k, int kbot, double dzbot) { return (k < 1 || k > km) ? 0.0 : ((k == kbot) ? dzbot : g.dz.u(k)); };   // pbc_dz, scalar loads
   auto load = [&](int k) {                            // level k = 1 .. km
     KppRaw r;
     const long long o = c.base3 + (long long)(k - 1) * n2;
@@ -525,10 +534,12 @@ k_kpp_buoy_interior_march(DevGrid g, KppDev kp, const double *__restrict__ T, co
     for (int t = 0; t < 4; ++t) {
       const double du = up.u[t] - cu.u[t], dv = up.v[t] - cu.v[t];
       sh4[t] = du * du + dv * dv;
+      if (PBC) { const double h = 0.5 * (dzq(k - 1, kmu4[t], dzub4[t]) + dzq(k, kmu4[t], dzub4[t])); sh4[t] = sh4[t] / (h * h); }
     }
     double vsh = 0.25 * sh4[0] + 0.25 * sh4[1] + 0.25 * sh4[2] + 0.25 * sh4[3];
     if (edge) vsh = 0.0;
-    const double ri = dbl * (kp.zgrid[k - 1] - kp.zgrid[k]) / (vsh + KPP_EPS);
+    double ri = dbl * (kp.zgrid[k - 1] - kp.zgrid[k]) / (vsh + KPP_EPS);
+    if (PBC) { const double h = 0.5 * (dzq(k - 1, kmt, dzbc) + dzq(k, kmt, dzbc)); ri = dbl / (vsh + KPP_EPS / (h * h)) / h; }
     const int m = k - 1;                              // the level ri belongs to
     const double w = (m <= kmt) ? ri : carry;
     if (m == kmt) carry = ri;
@@ -545,7 +556,8 @@ k_kpp_buoy_interior_march(DevGrid g, KppDev kp, const double *__restrict__ T, co
   DBLOC[c.base3 + (long long)(km - 1) * n2] = 0.0;
   if (kp.CONVB) kp.CONVB[c.q2] = convb;
   {
-    const double ri = 0.0 * (kp.zgrid[km] - kp.zgrid[km + 1]) / (0.0 + KPP_EPS);   // DBLOC(km) = 0, no shear below
+    double ri = 0.0 * (kp.zgrid[km] - kp.zgrid[km + 1]) / (0.0 + KPP_EPS);   // DBLOC(km) = 0, no shear below
+    if (PBC) { const double h = 0.5 * dzq(km, kmt, dzbc); ri = 0.0 / (0.0 + KPP_EPS / (h * h)) / h; }
     const double w = (km <= kmt) ? ri : carry;
     emit(km - 1, wpp, wp, w);
     emit(km, wp, w, w);
@@ -553,7 +565,7 @@ k_kpp_buoy_interior_march(DevGrid g, KppDev kp, const double *__restrict__ T, co
 }
 
 // ---- bldepth part 1, column form: U, V of the top KR levels in registers, each level read once ----
-template <int KR>
+template <int KR, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_ushear_col(DevGrid g, KppDev kp, const double *__restrict__ U, const double *__restrict__ V, double *__restrict__ WU) {
   // the two barriers below follow an early return of some lanes: defined only because the workgroup is exactly one wavefront
@@ -580,6 +592,7 @@ k_kpp_ushear_col(DevGrid g, KppDev kp, const double *__restrict__ U, const doubl
     kp.WUK[c.q2] = kcap;
     krcap = kp.kref[kcap];                         // kref is non-decreasing in the level
   }
+  const int kmu_c = PBC ? g.KMU[c.q2] : 0; const double dzub_c = PBC ? g.DZUB[c.q2] : 0.0;
   double ur[KR + 1], vr[KR + 1];
 #pragma unroll
   for (int t = 1; t <= KR; ++t) {
@@ -608,7 +621,10 @@ k_kpp_ushear_col(DevGrid g, KppDev kp, const double *__restrict__ U, const doubl
       uref = uref / surfthick; vref = vref / surfthick;
     } else { uref = ur[1]; vref = vr[1]; }
     const double du = uref - ukl, dv = vref - vkl;
-    WU[o] = du * du + dv * dv;
+    if (PBC) {   // vmix_kpp.F90:2359-2362
+      const double h = -kp.zgrid[kl - 1] + 0.5 * (pbc_dz(g, kl, kmu_c, dzub_c) + pbc_dz(g, kl - 1, kmu_c, dzub_c) - pbc_dz(g, 1, kmu_c, dzub_c));
+      WU[o] = (du * du + dv * dv) / (h * h);
+    } else WU[o] = du * du + dv * dv;
   }
 }
 
@@ -878,8 +894,11 @@ k_kpp_ushear(DevGrid g, KppDev kp, const double *__restrict__ U, const double *_
 }
 
 // the same for one U point (column base3) and level: what k_kpp_ushear / k_kpp_ushear_col store in WU
+// PBC: divided by the squared distance to the reference level with the U column's own thicknesses (vmix_kpp.F90:2359-2362); q2 = the
+// U point's 2-D index
+template <bool PBC = false>
 __device__ __forceinline__ double kpp_ushear_point(const DevGrid &g, const KppDev &kp, const double *__restrict__ U, const double *__restrict__ V,
-                                                   long long base3, int kl) {
+                                                   long long base3, int kl, long long q2 = 0) {
   const long long n2 = g.n2;
   const long long o = base3 + (long long)(kl - 1) * n2;
   const double surfthick = KPP_EPSSFC * g.zt[kl];
@@ -898,6 +917,11 @@ __device__ __forceinline__ double kpp_ushear_point(const DevGrid &g, const KppDe
     uref = uref / surfthick; vref = vref / surfthick;
   } else { uref = U[base3]; vref = V[base3]; }
   const double du = uref - U[o], dv = vref - V[o];
+  if (PBC) {
+    const int kmu = g.KMU[q2]; const double dzub = g.DZUB[q2];
+    const double h = -kp.zgrid[kl - 1] + 0.5 * (pbc_dz(g, kl, kmu, dzub) + pbc_dz(g, kl - 1, kmu, dzub) - pbc_dz(g, 1, kmu, dzub));
+    return (du * du + dv * dv) / (h * h);
+  }
   return du * du + dv * dv;
 }
 
@@ -910,7 +934,7 @@ __device__ __forceinline__ double kpp_ushear_point(const DevGrid &g, const KppDe
 // rib_* / z_*.  BFSFC ("value of the last pass") is formed for kl = km directly.  Results are bitwise those of the full march
 // (tested); the reference's array form (vmix_kpp.F90 bldepth :2280-2520) has no such exit.  Not with lcheckekmo (its Ekman / Monin-
 // Obukhov limits march every level) and not with the mixed-layer-depth diagnostics (they read DBSFC at every level).
-// PBC (with LAZY = false): partial bottom cells (vmix_kpp.F90:2212-2220, 2363-2366, 2486-2496, 2561-2575)
+// PBC: partial bottom cells (vmix_kpp.F90:2212-2220, 2363-2366, 2486-2496, 2561-2575), with either form of the march (r3)
 template <bool LAZY, int KR, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS)
 k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__restrict__ S,
@@ -989,10 +1013,10 @@ k_kpp_bldepth(DevGrid g, KppDev kp, const double *__restrict__ T, const double *
     double vshear = 0.0;
     if (!edge) {
       if (LAZY && kp.WUK) {
-        const double w00 = (kl <= wuk[0]) ? WU[o] : kpp_ushear_point(g, kp, UU, VV, c.base3, kl);
-        const double w10 = (kl <= wuk[1]) ? WU[o - 1] : kpp_ushear_point(g, kp, UU, VV, c.base3 - 1, kl);
-        const double w01 = (kl <= wuk[2]) ? WU[o - nxb] : kpp_ushear_point(g, kp, UU, VV, c.base3 - nxb, kl);
-        const double w11 = (kl <= wuk[3]) ? WU[o - 1 - nxb] : kpp_ushear_point(g, kp, UU, VV, c.base3 - 1 - nxb, kl);
+        const double w00 = (kl <= wuk[0]) ? WU[o] : kpp_ushear_point<PBC>(g, kp, UU, VV, c.base3, kl, c.q2);
+        const double w10 = (kl <= wuk[1]) ? WU[o - 1] : kpp_ushear_point<PBC>(g, kp, UU, VV, c.base3 - 1, kl, c.q2 - 1);
+        const double w01 = (kl <= wuk[2]) ? WU[o - nxb] : kpp_ushear_point<PBC>(g, kp, UU, VV, c.base3 - nxb, kl, c.q2 - nxb);
+        const double w11 = (kl <= wuk[3]) ? WU[o - 1 - nxb] : kpp_ushear_point<PBC>(g, kp, UU, VV, c.base3 - 1 - nxb, kl, c.q2 - 1 - nxb);
         vshear = fmax(fmax(w00, w10), fmax(w01, w11));
       } else vshear = fmax(fmax(WU[o], WU[o - 1]), fmax(WU[o - nxb], WU[o - 1 - nxb]));
     }
@@ -1188,7 +1212,7 @@ k_kpp_blmix(DevGrid g, StepParams sp, KppDev kp, const double *__restrict__ DBLO
       }
       const bool clr = k > kbl && k <= kdeep;
       if (__any(clr)) {       // +-0 below the boundary layer: stf / dz * (0 - 0); lanes above it are rewritten by part (2)
-        const double dzk = g.dz.u(k);
+        const double dzk = (PBC && k > 1) ? dzt_at(k) : g.dz.u(k);
         SRC1[o] = stf1 / dzk * (0.0 - 0.0); SRC2[o] = stf2 / dzk * (0.0 - 0.0);
       }
     }
@@ -1545,10 +1569,33 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   // the shear of the velocity against its surface-layer reference needs only U and V: on the side stream it overlaps the
   // (VALU-bound) buoydiff and the interior kernel; bldepth waits for it
   const hipStream_t su = KH.side ? KH.side : st;
+  // bit 4: buoydiff + interior coefficients as one column march (one smoothing pass, no double diffusion)
+  const bool march = lazy && fused_bi && (g_kpp_col & 16) && g_kpp.nsmooth == 1 && !g_kpp.ldbl_diff && g.km >= 3;
+  g_kpp.src_clear_all = s.src_clear_all;
+  if (g.pbc && march && lazy20 && (g_kpp_col & 1) && !tun_on(h.tun.pbc_generic_kpp)) {
+    // partial bottom cells on the production kernel selection (r3): the PBC instantiations of the column-march kernels
+    g_kpp.CONVB = (g.km <= 64 && !tun_off(h.tun.kpp_sparse)) ? KH.convb : nullptr;
+    if (KH.side) { hipEventRecord(KH.ev_fork, st); hipStreamWaitEvent(KH.side, KH.ev_fork, 0); }
+    hipLaunchKernelGGL((k_kpp_ushear_col<24, true>), GC, BC, 0, su, g, g_kpp, s.UMIX, s.VMIX, WU);
+    hipLaunchKernelGGL(k_kpp_buoy_interior_march<true>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, VISC, s.VDC[0], s.VDC[1]);
+    if (KH.side) { hipEventRecord(KH.ev_bd, st); hipStreamWaitEvent(KH.side, KH.ev_bd, 0); }
+    hipLaunchKernelGGL((k_kpp_bldepth<true, 20, true>), GC, BC, 0, su, g, g_kpp, s.TMIX[0], s.TMIX[1], s.STF[0], s.STF[1], (const double *)DBLOC,
+                       (const double *)DBSFC, (const double *)WU, s.UMIX, s.VMIX);
+    if (KH.side) { hipEventRecord(KH.ev_join, KH.side); hipStreamWaitEvent(st, KH.ev_join, 0); }
+    const bool sp_ = g_kpp.CONVB != nullptr;
+    if (sp_ && g_kpp.vdc_same) hipLaunchKernelGGL((k_kpp_blmix<true, true, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1], s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+    else if (sp_) hipLaunchKernelGGL((k_kpp_blmix<true, false, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1], s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+    else if (g_kpp.vdc_same) hipLaunchKernelGGL((k_kpp_blmix<true, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1], s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+    else hipLaunchKernelGGL((k_kpp_blmix<true, false>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1], s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+    const int vp = patch_rows(g, h.tun.del4_tile);
+    hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vp), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vp ? 64 * vp : 256), 0, st, g, (const double *)VISC, s.VVC, vp);
+    if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }
+    return 0;
+  }
   if (g.pbc) {
     // partial bottom cells (round 3): the 3-D-parallel / scratch-staged kernel forms carry the PBC branches; every level of the
     // surface-layer buoyancy difference and of the shear is formed (no on-demand march)
-    g_kpp.WUK = nullptr;
+    g_kpp.WUK = nullptr; g_kpp.CONVB = nullptr;
     hipLaunchKernelGGL(k_kpp_ushear<true>, G3, dim3(256), 0, st, g, g_kpp, s.UMIX, s.VMIX, WU);
     hipLaunchKernelGGL(k_kpp_buoydiff<true>, G3, dim3(256), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);
     hipLaunchKernelGGL(k_kpp_interior<true>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, (const double *)DBLOC, RIW, VISC, s.VDC[0], s.VDC[1]);
@@ -1569,11 +1616,8 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   // two waves per SIMD (<= 256 VGPRs, ~80 spilled) beat one wave with everything in registers: the kernel is VALU-bound
   // and a second wave fills the division / dependency stalls of the first (POP_KPP_BUOY_WAVES=1 keeps one wave)
   const int bw = tun_or(h.tun.kpp_buoy_waves, 2);
-  // bit 4: the two as one column march (one smoothing pass, no double diffusion)
-  const bool march = lazy && fused_bi && (g_kpp_col & 16) && g_kpp.nsmooth == 1 && !g_kpp.ldbl_diff && g.km >= 3;
   g_kpp.CONVB = (march && g.km <= 64 && !tun_off(h.tun.kpp_sparse)) ? KH.convb : nullptr;
-  g_kpp.src_clear_all = s.src_clear_all;
-  if (march) hipLaunchKernelGGL(k_kpp_buoy_interior_march, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, VISC, s.VDC[0], s.VDC[1]);
+  if (march) hipLaunchKernelGGL(k_kpp_buoy_interior_march<false>, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, VISC, s.VDC[0], s.VDC[1]);
   else if (lazy && fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8, false>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if (fused_bi) hipLaunchKernelGGL((k_kpp_buoy_interior_lds<20, 8>), GL, dim3(POP_COL_THREADS, 8), 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], s.UMIX, s.VMIX, DBLOC, DBSFC, VISC, s.VDC[0], s.VDC[1]);
   else if ((g_kpp_col & 4) && KH.max_kref <= 20 && g.xcd_remap != 2) hipLaunchKernelGGL((k_kpp_buoydiff_lds<20, 4>), GL, BL, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], DBLOC, DBSFC);

@@ -222,3 +222,35 @@ def test_register_thomas_kernels_with_partial_bottom_cells_are_bitwise_the_gener
     for tag in ("reg-defer", "pair", "generic"):
         for a, b in zip(out["reg"], out[tag]):
             assert np.array_equal(a, b), tag
+
+
+@pytest.mark.parametrize("kw", [{"km": 62, **DEL4}, {"km": 60, "block_size_x": 48, "block_size_y": 40}, {"km": 24, "lrich": 0}],
+                         ids=["km62-del4", "km60-one-block", "km24"])
+def test_kpp_column_march_kernels_with_partial_bottom_cells_are_bitwise_the_generic_ones(pkg, orclib_built, monkeypatch, kw):
+    """The production KPP kernel selection for large grids (shear column kernel with the level hint, buoydiff + interior as one
+    column march, boundary-layer depth with the on-demand surface-layer buoyancy, sparse boundary-layer kernel) in their PBC
+    instantiations against the 3-D-parallel / scratch-staged PBC kernels (POP_PBC_GENERIC_KPP=1), on stepped bathymetry with
+    a bottom thickness that differs from column to column and a boundary layer several levels deep: every KPP output and the
+    prognostic fields after five steps, to the last bit."""
+    monkeypatch.setenv("POP_XCD_REMAP", "0")
+    monkeypatch.setenv("POP_KPP_COL", "31")
+    cfg = named_config("tiny", vmix_choice=3, stepped_bathymetry=1, partial_bottom_cells=1, **kw)
+    out = {}
+    for tag, env in (("march", {}), ("march-streaming", {"POP_KPP_SPARSE": "0"}), ("generic", {"POP_PBC_GENERIC_KPP": "1"})):
+        for k in ("POP_KPP_SPARSE", "POP_PBC_GENERIC_KPP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m, orc = pkg.PopModel(cfg), Oracle(cfg)
+        force_kpp_case(m, orc)
+        orc.close()
+        for _ in range(5):
+            m.step()
+        out[tag] = [m.get("HBLT").copy(), m.get("VDC", 1, 0).copy(), m.get("VVC").copy()] + [m.get("KPP_SRC", 1, n).copy() for n in (0, 1)] + \
+                   [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "RHO")] + [m.get("TRACER", 1, 1).copy(), m.geti("KBL").copy()]
+        m.close()
+    h = out["march"][0]
+    assert h.max() > 3.0 * h[h > 0].min()
+    for tag in ("march-streaming", "generic"):
+        for a, b in zip(out["march"], out[tag]):
+            assert np.array_equal(a, b), tag
