@@ -1543,10 +1543,10 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       // no tripole fold (the ghost ring of the field comes from a halo update, which is the same arithmetic only where ghost cells are
       // plain copies), centred advection through the LDS kernel, bandwidth-bound grids; POP_D2T_FUSE=0|1 overrides the size rule
       const int fuse_env = tun_or(h.tun.d2t_fuse, -1);
-      if (cfg->hmix_tracer == 4 && cfg->ns_boundary != 2 && cfg->tadvect == 1 && !cfg->partial_bottom_cells &&
+      if (cfg->hmix_tracer == 4 && cfg->ns_boundary != 2 && cfg->tadvect == 1 &&
           (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
         if (dev_alloc(c, &c->d2t_next[0], a3) || dev_alloc(c, &c->d2t_next[1], a3)) return 1;
-      if (cfg->hmix_momentum == 4 && cfg->ns_boundary != 2 && !tun_off(h.tun.d2u_fuse) && !cfg->partial_bottom_cells &&
+      if (cfg->hmix_momentum == 4 && cfg->ns_boundary != 2 && !tun_off(h.tun.d2u_fuse) &&
           (fuse_env >= 0 ? fuse_env != 0 : (long long)h.n2 * h.nblocks > (1 << 19)))
         if (dev_alloc(c, &c->d2u_next[0], a3) || dev_alloc(c, &c->d2u_next[1], a3)) return 1;
     }

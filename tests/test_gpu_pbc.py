@@ -254,3 +254,23 @@ def test_kpp_column_march_kernels_with_partial_bottom_cells_are_bitwise_the_gene
     for tag in ("march-streaming", "generic"):
         for a, b in zip(out["march"], out[tag]):
             assert np.array_equal(a, b), tag
+
+
+@pytest.mark.parametrize("kw", [{"vmix_choice": 3, "km": 62}, {"vmix_choice": 1, "km": 16, "time_mix_freq": 4}], ids=["kpp-km62", "const-km16-averaging-steps"])
+def test_fused_del4_first_laplacians_with_partial_bottom_cells_are_bitwise_the_separate_kernels(pkg, monkeypatch, kw):
+    """POP_D2T_FUSE=1 (the large-grid default): the tracer / momentum kernels of step n also form the first Laplacians step n + 1
+    needs, with the thickness-scaled neighbour weights of hmix_del4.F90:683-697, 964-984, against k_del4_d2t / k_del4_d2u<PBC> as
+    launches of their own: eight steps (Euler, leapfrog and averaging steps), every prognostic field to the last bit."""
+    cfg = named_config("tiny", stepped_bathymetry=1, partial_bottom_cells=1, **DEL4, **kw)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("POP_D2T_FUSE", fuse)
+        m = pkg.PopModel(cfg)
+        assert m.dim("d2t_fused") == int(fuse) and m.dim("d2u_fused") == int(fuse)
+        for _ in range(8):
+            m.step()
+        out[fuse] = [m.get(n, tl, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF") for tl in (0, 1)] + [m.get("TRACER", 1, 1).copy()]
+        m.close()
+    assert np.abs(out["1"][0]).max() > 1.0
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
