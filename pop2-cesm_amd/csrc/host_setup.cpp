@@ -782,6 +782,7 @@ int host_build(HostModel &h) {
   // ---------------- P-CSI preprocessing (POP_SolversPrep) ----------------
   if (use_evp(c) || c.solver_choice == 3) {   // POP_SolversPrep (POP_SolversMod.F90:181-320): EVP first, then Lanczos
     const std::vector<double> C0 = host_center_init(h);
+    if (use_evp(c)) h.f2["evpC0"] = C0;       // the centre weight the EVP coefficients are made of: k_evp_apply_wave2 reads it as a 2-D field
     if (use_evp(c) && host_evp_prep(h, C0)) return 1;
     if (c.solver_choice == 3 && host_pcsi_prep(h, C0)) return 1;
   }

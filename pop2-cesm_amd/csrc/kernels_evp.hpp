@@ -19,6 +19,7 @@ struct EvpDev {
   const int4 *meta;               // x: cell index of (1,1) of the sub-block with rim; y: n | m << 8; z: land
   const double *cc, *ne, *icc, *ine;   // [EVP_LD*EVP_LD][S]
   const double *rinv;             // [EVP_LE*EVP_LE][S]
+  const double *C0, *WNE;         // r3: the 2-D fields cc and ne are copies of (centre weight at set-up, NE weight), for k_evp_apply_wave2
 };
 
 __global__ void __launch_bounds__(POP_EVP_THREADS)
@@ -135,6 +136,112 @@ k_evp_apply_wave(EvpDev e, int nxb, const double *__restrict__ X, double *__rest
     if (solve && k <= nm) rs[w][k] = (k <= n - 2) ? ys[w][at(k + 2, m)] : ys[w][at(n, m - (k - (n - 2)))];
   __syncthreads();
   // corrected values on the west column (rows jj = 1 .. m-2 -> y(2, m-jj)) and the south row (jj = m-2+ii -> y(ii+2, 2))
+  auto target = [&](int jj) { return (jj <= m - 2) ? at(2, m - jj) : at(jj - (m - 2) + 2, 2); };
+  if (solve && row0 <= nm) {
+    double acc = ys[w][target(row0)];
+#pragma unroll
+    for (int k = 1; k <= EVP_LE; ++k) if (k <= nm) acc = acc + rv0[k - 1] * rs[w][k];
+    ys[w][target(row0)] = acc;
+  }
+  if (solve && row1 <= nm) {
+    double acc = ys[w][target(row1)];
+#pragma unroll
+    for (int k = 1; k <= EVP_LE; ++k) if (k <= nm) acc = acc + rv1[k - 1] * rs[w][k];
+    ys[w][target(row1)] = acc;
+  }
+  __syncthreads();
+  sweep(n - 2, m - 2);
+  for (int c = 2; c <= EVP_LD - 1; ++c)
+    if (solve && c <= m - 1 && a0 <= n - 1) PX[cell(a0, c)] = ys[w][at(a0, c)];
+}
+
+
+// ---- wavefront form, second version (r3): more waves per CU, fewer bytes ---------------------------------------------------
+// k_evp_apply_wave keeps five coefficient / operand arrays of the eight sub-blocks in LDS (34.6 KB): four one-wave workgroups per
+// CU, i.e. one wave per SIMD on a kernel that is a chain of ~80 dependent LDS steps -- 352 us per application at tx0.1v3 for
+// ~130 us of bytes.  Here a lane owns one COLUMN of the marching index (i = 2 + lane) and meets the anti-diagonal d = i + j at
+// step d: what it needs at that step -- cc(i,j), X(i,j), 1/ne(i,j) -- depends on the lane only through d, so it sits in
+// registers indexed by the step (15 slots each), loaded up front; only y and ne (read at three neighbours) stay in LDS (14 KB: eleven
+// workgroups per CU).  cc and ne are read from the 2-D fields they were copied from (C0, WNE: 64 cells + rim through the cache
+// instead of 2 x 100 duplicated words per sub-block) and 1/ne is formed here (IEEE division: the bits of the host's table), so a
+// sub-block costs 169 (correction matrix) + ~130 coefficient words instead of 469.  Same expressions, same operands: bitwise
+// k_evp_apply (tests/test_gpu_parity.py).
+constexpr int EVP_STEPS = 2 * (EVP_LD - 1) - 3;   // anti-diagonals d = 4 .. 2 (EVP_LD - 1)
+__global__ void __launch_bounds__(64)
+k_evp_apply_wave2(EvpDev e, int nxb, const double *__restrict__ X, double *__restrict__ PX) {
+  __shared__ double ys[POP_EVP_SB][EVP_PAD], nes[POP_EVP_SB][EVP_PAD];
+  __shared__ double rs[POP_EVP_SB][EVP_LE + 1];
+  const int t = threadIdx.x, w = t >> 3, l = t & 7;
+  const long long s = (long long)blockIdx.x * POP_EVP_SB + w;
+  const bool live = s < e.S;
+  int4 mt = make_int4(0, 3 | (3 << 8), 1, 0);
+  if (live) mt = e.meta[s];
+  const int n = mt.y & 255, m = mt.y >> 8;
+  const bool solve = live && !mt.z;
+  auto cell = [&](int a, int c) { return (long long)mt.x + (long long)(c - 1) * nxb + (a - 1); };
+  auto at = [](int a, int c) { return (a - 1) + EVP_LD * (c - 1); };
+  // ne of the sub-block with its rim (rows c = 1 .. m; lane = column, lanes 0 and 1 also take columns 9 and 10), y = 0
+  for (int c = 1; c <= EVP_LD; ++c) {
+    const int a1 = 1 + l, a2 = 9 + l;
+    double v1 = 0.0, v2 = 0.0;
+    if (live && c <= m && a1 <= n) v1 = e.WNE[cell(a1, c)];
+    if (live && c <= m && l < 2 && a2 <= n) v2 = e.WNE[cell(a2, c)];
+    nes[w][at(a1, c)] = v1; ys[w][at(a1, c)] = 0.0;
+    if (l < 2) { nes[w][at(a2, c)] = v2; ys[w][at(a2, c)] = 0.0; }
+  }
+  // sub-blocks with land: diagonal scaling (:2344-2348), row by row
+  const int a0 = 2 + l;
+  if (live && mt.z) {
+    for (int c = 2; c <= EVP_LD - 1; ++c)
+      if (c <= m - 1 && a0 <= n - 1) {
+        const double cc = e.C0[cell(a0, c)];
+        PX[cell(a0, c)] = X[cell(a0, c)] * ((cc != 0.0) ? 1.0 / cc : 0.0);
+      }
+  }
+  // the operands this lane (column i = 2 + l) meets at step d = i + j: X(i,j), cc(i,j) in registers indexed by the step
+  const int i = 2 + l;
+  double xx[EVP_STEPS], cs[EVP_STEPS];
+#pragma unroll
+  for (int q = 0; q < EVP_STEPS; ++q) {
+    const int j = q + 4 - i;
+    const bool ok = solve && j >= 2 && j <= m - 1 && i <= n - 1;
+    xx[q] = ok ? X[cell(i, j)] : 0.0;
+    cs[q] = ok ? e.C0[cell(i, j)] : 0.0;
+  }
+  const int nm = n + m - 5;
+  double rv0[EVP_LE], rv1[EVP_LE];
+  const int row0 = 1 + l, row1 = 9 + l;
+#pragma unroll
+  for (int k = 1; k <= EVP_LE; ++k) {
+    rv0[k - 1] = (solve && row0 <= nm && k <= nm) ? e.rinv[(long long)((k - 1) + EVP_LE * (row0 - 1)) * e.S + s] : 0.0;
+    rv1[k - 1] = (solve && row1 <= nm && k <= nm) ? e.rinv[(long long)((k - 1) + EVP_LE * (row1 - 1)) * e.S + s] : 0.0;
+  }
+  __syncthreads();
+  double in[EVP_STEPS];         // 1 / ne(i, j) of the step (host: ine = 1 / ne where ne != 0, else 0)
+#pragma unroll
+  for (int q = 0; q < EVP_STEPS; ++q) {
+    const int j = q + 4 - i;
+    const bool ok = solve && j >= 2 && j <= m - 1 && i <= n - 1;
+    const double nv = ok ? nes[w][at(i, j)] : 0.0;
+    in[q] = (nv != 0.0) ? 1.0 / nv : 0.0;
+  }
+  auto sweep = [&](int imax, int jmax) {
+#pragma unroll
+    for (int q = 0; q < EVP_STEPS; ++q) {
+      const int j = q + 4 - i;
+      const bool on = solve && j >= 2 && j <= jmax && i <= imax;
+      double v = 0.0;
+      if (on)
+        v = (xx[q] - cs[q] * ys[w][at(i, j)] - nes[w][at(i, j - 1)] * ys[w][at(i + 1, j - 1)] -
+             nes[w][at(i - 1, j)] * ys[w][at(i - 1, j + 1)] - nes[w][at(i - 1, j - 1)] * ys[w][at(i - 1, j - 1)]) * in[q];
+      if (on) ys[w][at(i + 1, j + 1)] = v;
+      __syncthreads();
+    }
+  };
+  sweep(n - 1, m - 1);
+  for (int k = 1 + l; k <= EVP_LE; k += 8)
+    if (solve && k <= nm) rs[w][k] = (k <= n - 2) ? ys[w][at(k + 2, m)] : ys[w][at(n, m - (k - (n - 2)))];
+  __syncthreads();
   auto target = [&](int jj) { return (jj <= m - 2) ? at(2, m - jj) : at(jj - (m - 2) + 2, 2); };
   if (solve && row0 <= nm) {
     double acc = ys[w][target(row0)];

@@ -29,6 +29,7 @@ struct PcsiArgs {
   int j;                           // step inside the interval (1-based); j = 0: start-up step
   int remote_ghosts;               // multi-rank: also advance dx, x at ghosts owned by other ranks
   int nchunk;                      // stride of the partial slots per block (the launch may be compacted: DevGrid::red_act)
+  int raw_r;                       // EVP preconditioner (r3): Ro receives the residual itself; k_evp_apply_wave2 turns it into r' for the next step
 };
 
 // unfused building blocks (multi-rank path and cross-check): whole-array operations as the reference has them
@@ -110,7 +111,7 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
       // btropOperator :2414-2426, same order as btrop_op
       const double ax = w[0] * xn[0] + w[1] * xn[1] + w[2] * xn[2] + w[3] * xn[3] + w[4] * xn[4] + w[5] * xn[5] + w[6] * xn[6] + w[7] * xn[7] + w[8] * xn[8];
       const double r = bq - ax;
-      a.Qo[q] = dx0; a.Xo[q] = xn[0]; a.Ro[q] = r * a0r;
+      a.Qo[q] = dx0; a.Xo[q] = xn[0]; a.Ro[q] = a.raw_r ? r : r * a0r;
       if (WITH_RR) v[0] = (r * r) * (double)g.mMask8[q];
     } else if (a.remote_ghosts && a.srcmap[q] == q) {
       // ghost owned by another rank (multi-rank fused form): its r' arrived by the halo exchange; dx and x
@@ -170,7 +171,7 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
     const double rA = bq.x - axA, rB = bq.y - axB;
     *reinterpret_cast<double2 *>(a.Qo + q) = make_double2(dxc[0], dxc[1]);
     *reinterpret_cast<double2 *>(a.Xo + q) = make_double2(xn[1][1], xn[1][2]);
-    *reinterpret_cast<double2 *>(a.Ro + q) = make_double2(rA * a0r.x, rB * a0r.y);
+    *reinterpret_cast<double2 *>(a.Ro + q) = a.raw_r ? make_double2(rA, rB) : make_double2(rA * a0r.x, rB * a0r.y);
     if (WITH_RR) { v0 = (rA * rA) * (double)g.mMask8[q]; v1 = (rB * rB) * (double)g.mMask8[q + 1]; }
   } else {
     const int off[8] = {nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
@@ -191,7 +192,7 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
         const double w[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};
         const double ax = w[0] * xn[0] + w[1] * xn[1] + w[2] * xn[2] + w[3] * xn[3] + w[4] * xn[4] + w[5] * xn[5] + w[6] * xn[6] + w[7] * xn[7] + w[8] * xn[8];
         const double r = a.Bv[qq] - ax;
-        a.Qo[qq] = dx0; a.Xo[qq] = xn[0]; a.Ro[qq] = r * a.A0R[qq];
+        a.Qo[qq] = dx0; a.Xo[qq] = xn[0]; a.Ro[qq] = a.raw_r ? r : r * a.A0R[qq];
         if (WITH_RR) { const double vv = (r * r) * (double)g.mMask8[qq]; if (e == 0) v0 = vv; else v1 = vv; }
       } else if (a.remote_ghosts && a.srcmap[qq] == qq) {
         const double dx = om * a.Ri[qq] + cq * a.Qi[qq];

@@ -93,7 +93,7 @@ struct pop_ctx {
   double *host_rr = nullptr;                              // pinned ring of (r,r) check results (k_rr_total)
   hipEvent_t chk_ev[4] = {};                              // one event per check interval in flight
   std::vector<std::pair<double *, hipGraphExec_t>> graphs;  // fused-solver interval graphs, keyed by solution array
-  bool no_graph = false, fused_ok = false, replicated = false, grid_from_input = false;
+  bool no_graph = false, fused_ok = false, evp_fused_ok = false, replicated = false, grid_from_input = false;
   // land elimination: the first land_full_steps steps after set-up / a restart / a new state run every workgroup (they write
   // the state-independent values of the land tiles), later steps skip workgroups without an ocean cell (DevGrid::skip)
   bool land_skip = true; int land_full_steps = 4, full_left = 4, full_seen = 0; double land_fraction = 0.0;
@@ -368,7 +368,10 @@ SolverArgs solver_args(pop_ctx *c) {
 
 // preconditioner() with preconditionerChoice = 'evp' (:2331-2366): PX <- sub-block solves of X on the physical cells
 int evp_apply(pop_ctx *c, const double *X, double *PX) {
-  if (!tun_off(c->h.tun.evp_wave))   // anti-diagonal wavefronts: eight lanes per sub-block, eight sub-blocks per wave
+  const int wave = tun_or(c->h.tun.evp_wave, 2);   // 2 (default): wavefronts, operands in registers; 1: wavefronts, operands in LDS; 0: a thread per sub-block
+  if (wave == 2 && c->evp.C0)
+    hipLaunchKernelGGL(k_evp_apply_wave2, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
+  else if (wave != 0)   // anti-diagonal wavefronts: eight lanes per sub-block, eight sub-blocks per wave
     hipLaunchKernelGGL(k_evp_apply_wave, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
   else
     hipLaunchKernelGGL(k_evp_apply, dim3((unsigned)((c->evp.S + POP_EVP_THREADS - 1) / POP_EVP_THREADS)), dim3(POP_EVP_THREADS), 0, c->stream,
@@ -1017,6 +1020,7 @@ static PcsiArgs pcsi_args(pop_ctx *c, const PcsiBufs &bf, int in, int j) {
   a.Xi = bf.X[in]; a.Ri = bf.R[in]; a.Qi = bf.Q[in]; a.Xo = bf.X[1 - in]; a.Ro = bf.R[1 - in]; a.Qo = bf.Q[1 - in];
   a.Bv = c->RHS; a.C = c->centerWgt; a.A0R = c->S0; a.omega = c->pcsi_omega; a.base = c->pcsi_base; a.srcmap = c->srcmap; a.partial = c->partial; a.sc = c->sc;
   a.csy = c->pcsi_csy; a.j = j; a.nchunk = c->nchunk;
+  if (c->use_evp) { a.raw_r = 1; a.Ri = c->R; a.Ro = c->AZ; }   // r' = M^-1 r in R (read), the residual itself to AZ (written): evp_apply(AZ -> R) follows every step
   return a;
 }
 // DevGrid of the single-rank fused P-CSI launches: with land elimination active, the compacted chunk list (DevGrid::red_act)
@@ -1036,6 +1040,7 @@ static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool
       else hipLaunchKernelGGL((k_pcsi_step2<false>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, gg, a);
     } else if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step<false, true>), G, B, 0, c->stream, gg, a);
     else hipLaunchKernelGGL((k_pcsi_step<false, false>), G, B, 0, c->stream, gg, a);
+    if (c->use_evp) evp_apply(c, c->AZ, c->R);
     in = 1 - in;
   }
   if (with_rr) {
@@ -1046,7 +1051,7 @@ int solver_pcsi_fused(pop_ctx *c) {
   const pop_config &cf = c->h.c;
   const dim3 G = grid_2d(c), B(POP_RED_THREADS);
   const int freq = cf.convergence_check_freq, start = pcsi_check_start(c);
-  PcsiBufs bf{{c->PS[c->newt], c->Z}, {c->R, c->AZ}, {c->Q, c->S1}};
+  PcsiBufs bf{{c->PS[c->newt], c->Z}, {c->R, c->AZ}, {c->Q, c->S1}};   // (with EVP the residual pair is fixed: pcsi_args)
   SolverScalars init{};
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   // r0 = b - A x0 (ghosts of x0 read at their sources), then the start-up step x1 = x0 + r0'/gamma, r1 = b - A x1
@@ -1054,10 +1059,19 @@ int solver_pcsi_fused(pop_ctx *c) {
     SolveView v = local_view(c);
     const long long a2 = (long long)c->g.n2 * c->g.nblocks;
     hipLaunchKernelGGL(k_pcsi_a0r, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->centerWgt, c->S0, a2);
-    hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, c->g, fused_args(c, v));
-    hipLaunchKernelGGL(k_pcsi_scale, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, c->R, (const double *)c->S0);
+    if (c->use_evp) {   // r0 into AZ, r0' = M^-1 r0 by the sub-block solves into R; both start from zero (cells no kernel writes are never read)
+      HIPCHK(c, hipMemsetAsync(c->AZ, 0, sizeof(double) * a2, c->stream));
+      HIPCHK(c, hipMemsetAsync(c->R, 0, sizeof(double) * a2, c->stream));
+      v.R = c->AZ;
+      hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, c->g, fused_args(c, v));
+      if (evp_apply(c, c->AZ, c->R)) return 1;
+    } else {
+      hipLaunchKernelGGL(k_fresidual<false>, G, B, 0, c->stream, c->g, fused_args(c, v));
+      hipLaunchKernelGGL(k_pcsi_scale, dim3((c->g.n2 + 255) / 256, c->g.nblocks), dim3(256), 0, c->stream, c->g, c->R, (const double *)c->S0);
+    }
   }
   hipLaunchKernelGGL((k_pcsi_step<true, false>), G, B, 0, c->stream, c->g, pcsi_args(c, bf, 0, 0));
+  if (c->use_evp && evp_apply(c, c->AZ, c->R)) return 1;
   if (pcsi_grid(c).red_act)   // compacted launches from here on: the partials of the chunks that are left out must read as zero
     HIPCHK(c, hipMemsetAsync(c->partial, 0, (size_t)c->nchunk * c->g.nblocks * 2 * sizeof(double), c->stream));
   int in = 1;
@@ -1701,8 +1715,9 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       int4 *dm; double *d0, *d1, *d2, *d3, *d4;
       if (dev_upload(c, &dm, meta.data(), S) || dev_upload(c, &d0, cc.data(), cc.size()) || dev_upload(c, &d1, ne.data(), ne.size()) ||
           dev_upload(c, &d2, icc.data(), icc.size()) || dev_upload(c, &d3, ine.data(), ine.size()) || dev_upload(c, &d4, rinv.data(), rinv.size())) return 1;
-      c->evp = EvpDev{(long long)S, dm, d0, d1, d2, d3, d4};
+      c->evp = EvpDev{(long long)S, dm, d0, d1, d2, d3, d4, c->d2["evpC0"], c->d2["btropWgtNE"]};
       c->use_evp = true;
+      c->evp_fused_ok = c->fused_ok && cfg->solver_choice == 3;   // P-CSI + EVP: step kernel + sub-block solves, two launches per iteration (r3)
       c->fused_ok = false;
     }
     c->no_graph = tun_on(h.tun.solver_nograph);
@@ -2448,6 +2463,7 @@ int pop_solver_run(pop_ctx *c) {
     return solver_chrongear(c);
   }
   if (c->h.c.solver_choice == 3) {
+    if (c->use_evp && c->evp_fused_ok) return solver_pcsi_fused(c);
     if (c->use_evp) return solver_pcsi(c);
     if (c->fused_ok) return solver_pcsi_fused(c);
     if (c->h.nranks > 1 && !tun_on(c->h.tun.solver_unfused)) return solver_pcsi_fused_dist(c);

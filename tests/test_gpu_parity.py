@@ -894,7 +894,7 @@ def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
     gpu.close(); orc.close()
 
 
-@pytest.mark.parametrize("wave", ["1", "0"], ids=["wavefront-kernel", "thread-per-sub-block"])
+@pytest.mark.parametrize("wave", ["2", "1", "0"], ids=["wavefront-registers", "wavefront-lds", "thread-per-sub-block"])
 @pytest.mark.parametrize("name,kw", [("tiny", {}), ("tiny", {"block_size_x": 16, "block_size_y": 20}), ("gx3v7", {}),
                                      ("tiny", {"nx_global": 66, "ny_global": 52, "block_size_x": 33, "block_size_y": 26, "stepped_bathymetry": 1})])
 def test_evp_preconditioner_is_bitwise_the_oracle(pkg, orclib_built, monkeypatch, name, kw, wave):
@@ -1053,10 +1053,13 @@ def test_solver_error_convention(pkg, orclib_built, solver):
     m.close(); o.close()
 
 
-def test_fused_pcsi_is_bitwise_the_unfused_pcsi(pkg, monkeypatch):
+@pytest.mark.parametrize("precond", [0, 1], ids=["diagonal", "evp"])
+def test_fused_pcsi_is_bitwise_the_unfused_pcsi(pkg, monkeypatch, precond):
     """P-CSI: the one-launch-per-iteration form (neighbour updates recomputed in the matvec, ping-pong state,
-    hipGraph per check interval) against the operation-by-operation form with explicit halo updates."""
-    cfg = named_config("tiny", block_size_x=24, block_size_y=20, solver_choice=3)
+    hipGraph per check interval) against the operation-by-operation form with explicit halo updates.  With the EVP block
+    preconditioner the fused form is two launches per iteration: the step kernel leaves the residual itself, the sub-block solves
+    (k_evp_apply_wave2) turn it into r' for the next step -- no halo update, no copy."""
+    cfg = named_config("tiny", block_size_x=24, block_size_y=20, solver_choice=3, precond_choice=precond)
     a = pkg.PopModel(cfg)
     monkeypatch.setenv("POP_SOLVER_UNFUSED", "1")
     b = pkg.PopModel(cfg)
