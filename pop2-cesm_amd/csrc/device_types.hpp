@@ -35,6 +35,9 @@ using CArrI = ConstArr<int>;
 // arrays are 1-based with slot 0 (index k is wave-uniform, so they are read by scalar loads).
 struct DevGrid {
   int nxb, nyb, km, nt, nblocks, ib, ie, jb, je;   // ib..je are 1-based like the reference
+  // padded blocks (blocks.F90:174-265): when the block size does not divide the domain the last column / row of blocks ends
+  // early; ieb[b], jeb[b] = last physical i, j of local block b.  nullptr: every block ends at ie, je (kernels_common.hpp blk_ie / blk_je)
+  const int *ieb, *jeb;
   int xcd_remap;                                   // column kernels: workgroup order (kernels_common.hpp col_setup)
   int red_band;                                    // 2-D reduction kernels: XCD-banded chunk order
   int red_tiles;                                   // 2-D reduction kernels: 64x4 tiles in XCD-strided columns

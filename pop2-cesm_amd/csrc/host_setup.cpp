@@ -275,8 +275,11 @@ int host_build(HostModel &h) {
   h.km = c.km; h.nt = c.nt;
   if (c.nt < 2 || c.nt > MAXNT) { h.err = "nt must be in [2,8]"; return 1; }
   if (c.km < 2) { h.err = "km must be >= 2"; return 1; }
-  if (c.nx_global % c.block_size_x || c.ny_global % c.block_size_y) {
-    h.err = "block size must divide the global domain (padded blocks not supported)"; return 1;
+  // block sizes that do not divide the domain: the last column / row of blocks is padded (blocks.F90:174-265; make_blocks)
+  const bool padded = c.nx_global % c.block_size_x != 0 || c.ny_global % c.block_size_y != 0;
+  if (padded && (c.ns_boundary == 2 || c.solver_choice == 3 || use_evp(c))) {
+    h.err = "padded blocks (block size not dividing the domain) are built for dipole grids with pcg / ChronGear and the diagonal preconditioner; "
+            "tripole grids, P-CSI and EVP need block sizes that divide the domain"; return 1;
   }
   if (c.ns_boundary < 0 || c.ns_boundary > 2) { h.err = "ns_boundary: 0 closed, 1 cyclic, 2 tripole"; return 1; }
   if (c.ns_boundary == 2 && (c.ew_boundary != 1 || c.nx_global % 2 || c.block_size_y < NGHOST + 1)) {
@@ -381,6 +384,10 @@ int host_build(HostModel &h) {
     if (B.i_glob[B.ie] == 0) for (int j = 0; j < nyb; ++j) for (int i = B.ie; i < nxb; ++i) extend(i, j, B.ie - 1, j);
     if (B.j_glob[0] == 0) for (int j = 0; j < B.jb - 1; ++j) for (int i = 0; i < nxb; ++i) extend(i, j, i, B.jb - 1);
     if (B.j_glob[B.je] == 0) for (int j = B.je; j < nyb; ++j) for (int i = 0; i < nxb; ++i) extend(i, j, i, B.je - 1);
+    // padded blocks: the cells beyond the ghost cells of a short block (global index 0) take the metrics of their neighbour towards
+    // the block, so that reciprocals stay finite; they are land (KMT = 0) and nothing reads them
+    for (int i = B.ie; i < nxb; ++i) if (B.i_glob[i] == 0 && B.i_glob[B.ie] != 0) for (int j = 0; j < nyb; ++j) extend(i, j, i - 1, j);
+    for (int j = B.je; j < nyb; ++j) if (B.j_glob[j] == 0 && B.j_glob[B.je] != 0) for (int i = 0; i < nxb; ++i) extend(i, j, i, j - 1);
   }
   auto &DXUR = newf("DXUR"), &DYUR = newf("DYUR"), &DXTR = newf("DXTR"), &DYTR = newf("DYTR");
   auto &UAREA = newf("UAREA"), &TAREA = newf("TAREA"), &UAREA_R = newf("UAREA_R"), &TAREA_R = newf("TAREA_R");
@@ -622,8 +629,9 @@ int host_build(HostModel &h) {
     azm[km] = 0.0; bzm[km] = 0.0; dzm[km] = 0.0;
     auto &AXP = newf("TALFXP"), &BXP = newf("TBETXP"), &GXP = newf("TGAMXP"), &AXM = newf("TALFXM"), &BXM = newf("TBETXM"), &DXM = newf("TDELXM");
     auto &AYP = newf("TALFYP"), &BYP = newf("TBETYP"), &GYP = newf("TGAMYP"), &AYM = newf("TALFYM"), &BYM = newf("TBETYM"), &DYM = newf("TDELYM");
-    const int ib = NGHOST, ie = nxb - NGHOST - 1, jb = NGHOST, je = nyb - NGHOST - 1;   // 0-based physical domain
     for (int b = 0; b < NB; ++b) {
+      const BlockInfo &Bk = h.all_blocks[b];
+      const int ib = Bk.ib - 1, ie = Bk.ie - 1, jb = Bk.jb - 1, je = Bk.je - 1;   // 0-based physical domain of the block
       for (int j = jb; j <= je; ++j) for (int i = ib - 1; i <= ie; ++i) {
         const size_t p = idx(b, i, j);
         const double dxc = DXT[p], dxcw = DXT[p - 1], dxce = DXT[p + 1], dxce2 = DXT[p + 2];

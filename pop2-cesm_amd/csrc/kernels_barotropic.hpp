@@ -294,7 +294,7 @@ k_extreme_partial(DevGrid g, const double *__restrict__ A, const double *__restr
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
     const long long q = (long long)b * g.n2 + p2;
-    if (i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je && (!M || M[q] != 0.0)) { v = A[q]; idx = (double)q; }
+    if (i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b) && (!M || M[q] != 0.0)) { v = A[q]; idx = (double)q; }
   }
   sv[t] = v; si[t] = idx;
   __syncthreads();
@@ -316,7 +316,7 @@ k_count_partial(DevGrid g, const double *__restrict__ A, const double *__restric
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
     const long long q = (long long)b * g.n2 + p2;
-    if (i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je && A[q] != 0.0 && !(DUP && DUP[q] != 0.0)) v[0] = 1.0;
+    if (i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b) && A[q] != 0.0 && !(DUP && DUP[q] != 0.0)) v[0] = 1.0;
   }
   wg_reduce_store<1>(v, partial, b * gridDim.x + red_chunk(g));
 }
@@ -329,7 +329,7 @@ k_dot_partial_dup(DevGrid g, const double *__restrict__ A, const double *__restr
   double v[2] = {0.0, 0.0};
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
-    if (i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je) {
+    if (i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b)) {
       const long long q = (long long)b * g.n2 + p2;
       double x = A[q];
       if (M) x = x * M[q];
@@ -379,7 +379,7 @@ k_dot_partial(DevGrid g, const double *__restrict__ A, const double *__restrict_
   double v[1] = {0.0};
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb;
-    if (i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je) {
+    if (i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b)) {
       const long long q = (long long)b * g.n2 + p2;
       double x = A[q];
       if (Bv) x = x * Bv[q];
@@ -405,8 +405,8 @@ __device__ __forceinline__ double btrop_op(const DevGrid &g, const double *__res
 __device__ __forceinline__ bool op_range(const DevGrid &g, int i, int j) {   // i,j = 2..n-1 (1-based)
   return i >= 1 && i <= g.nxb - 2 && j >= 1 && j <= g.nyb - 2;
 }
-__device__ __forceinline__ bool interior(const DevGrid &g, int i, int j) {
-  return i + 1 >= g.ib && i + 1 <= g.ie && j + 1 >= g.jb && j + 1 <= g.je;
+__device__ __forceinline__ bool interior(const DevGrid &g, int b, int i, int j) {
+  return i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b);
 }
 
 struct SolverArgs {
@@ -427,7 +427,7 @@ k_residual(DevGrid g, SolverArgs a) {
     const double ax = op_range(g, i, j) ? btrop_op(g, a.C, a.X, q, g.nxb) : 0.0;
     const double r = a.Bv[q] - ax;
     a.R[q] = r;
-    if (WITH_RR && interior(g, i, j)) v[0] = (r * r) * g.mMask[q];
+    if (WITH_RR && interior(g, b, i, j)) v[0] = (r * r) * g.mMask[q];
   }
   if (WITH_RR) wg_reduce_store<1>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
@@ -451,7 +451,7 @@ k_pcg_a(DevGrid g, SolverArgs a) {
     const double cw = a.C[q];
     const double z = (cw != 0.0) ? r / cw : 0.0;
     a.Z[q] = z;
-    if (interior(g, i, j)) v[0] = (r * z) * g.mMask[q];
+    if (interior(g, b, i, j)) v[0] = (r * z) * g.mMask[q];
   }
   wg_reduce_store<1>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
@@ -483,7 +483,7 @@ k_pcg_b(DevGrid g, SolverArgs a) {
            g.WNE[q] * sn(q + nxb + 1) + g.WNE[q - nxb] * sn(q - nxb + 1) + g.WNE[q - 1] * sn(q + nxb - 1) + g.WNE[q - 1 - nxb] * sn(q - nxb - 1);
     }
     a.Q[q] = aq;
-    if (interior(g, i, j)) v[0] = (aq * s) * g.mMask[q];
+    if (interior(g, b, i, j)) v[0] = (aq * s) * g.mMask[q];
   }
   wg_reduce_store<1>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
@@ -507,7 +507,7 @@ k_cg_init(DevGrid g, SolverArgs a) {
       aq = a.C[q] * z + g.WNo[q] * zf(q + nxb) + g.WNo[q - nxb] * zf(q - nxb) + g.WEa[q] * zf(q + 1) + g.WEa[q - 1] * zf(q - 1) +
            g.WNE[q] * zf(q + nxb + 1) + g.WNE[q - nxb] * zf(q - nxb + 1) + g.WNE[q - 1] * zf(q + nxb - 1) + g.WNE[q - 1 - nxb] * zf(q - nxb - 1);
     a.Q[q] = aq;
-    if (interior(g, i, j)) { v[0] = (a.R[q] * z) * g.mMask[q]; v[1] = (z * aq) * g.mMask[q]; }
+    if (interior(g, b, i, j)) { v[0] = (a.R[q] * z) * g.mMask[q]; v[1] = (z * aq) * g.mMask[q]; }
   }
   wg_reduce_store<2>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
@@ -529,7 +529,7 @@ k_cg_az(DevGrid g, SolverArgs a) {
     const long long q = (long long)b * g.n2 + p2;
     const double az = op_range(g, i, j) ? btrop_op(g, a.C, a.Z, q, g.nxb) : 0.0;
     a.AZ[q] = az;
-    if (interior(g, i, j)) { const double z = a.Z[q]; v[0] = (a.R[q] * z) * g.mMask[q]; v[1] = (az * z) * g.mMask[q]; }
+    if (interior(g, b, i, j)) { const double z = a.Z[q]; v[0] = (a.R[q] * z) * g.mMask[q]; v[1] = (az * z) * g.mMask[q]; }
   }
   wg_reduce_store<2>(v, a.partial, b * gridDim.x + red_chunk(g));
 }
@@ -695,8 +695,8 @@ struct FusedArgs {
   const double *rbuf;
 };
 // cells within NGHOST of the edge of the physical domain: the only ones a neighbour block's ghosts can copy
-__device__ __forceinline__ bool send_band(const DevGrid &g, int i, int j) {
-  return i + 1 < g.ib + NGHOST || i + 1 > g.ie - NGHOST || j + 1 < g.jb + NGHOST || j + 1 > g.je - NGHOST;
+__device__ __forceinline__ bool send_band(const DevGrid &g, int b, int i, int j) {
+  return i + 1 < g.ib + NGHOST || i + 1 > blk_ie(g, b) - NGHOST || j + 1 < g.jb + NGHOST || j + 1 > blk_je(g, b) - NGHOST;
 }
 __device__ __forceinline__ void pack_cell(const FusedArgs &a, long long q, double val) {
   const int e = a.sendmap[q];
@@ -768,9 +768,9 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
     }
     const double z = (cw != 0.0) ? r / cw : 0.0;
     a.Z[q] = z;
-    if (interior(g, i, j)) {
+    if (interior(g, b, i, j)) {
       v[0] = (r * z) * mk;
-      if (a.sendmap && send_band(g, i, j)) pack_cell(a, q, z);
+      if (a.sendmap && send_band(g, b, i, j)) pack_cell(a, q, z);
     }
   }
   wg_reduce_store<1>(v, a.partA, b * a.nchunk + red_chunk(g));
@@ -825,7 +825,7 @@ k_fpcg_a_pair(DevGrid g, FusedArgs a) {
       if (UPDATE) { rr = rr - alpha * qq[u]; a.R[q[u]] = rr; }
       const double z = (cw[u] != 0.0) ? rr / cw[u] : 0.0;
       a.Z[q[u]] = z;
-      if (interior(g, i, j)) v = (rr * z) * mk[u];
+      if (interior(g, b, i, j)) v = (rr * z) * mk[u];
     }
     sh[u][t] = v;
   }
@@ -854,8 +854,8 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
   const int pp = live ? p2 : 0;
   const int i = pp % g.nxb, j = pp / g.nxb, nxb = g.nxb;
   const long long q = (long long)b * g.n2 + pp;
-  const bool inner = live && interior(g, i, j);
-  const bool rim = inner && (i + 1 == g.ib || i + 1 == g.ie || j + 1 == g.jb || j + 1 == g.je);
+  const bool inner = live && interior(g, b, i, j);
+  const bool rim = inner && (i + 1 == g.ib || i + 1 == blk_ie(g, b) || j + 1 == g.jb || j + 1 == blk_je(g, b));
   // gather operands first (independent loads in flight while the total is formed)
   const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
   double zv[9], sv[9], wv[9];
@@ -941,10 +941,10 @@ k_fcg_a(DevGrid g, FusedArgs a) {
   const int pp = live ? p2 : 0;
   const int i = pp % g.nxb, j = pp / g.nxb, nxb = g.nxb;
   const long long q = (long long)b * g.n2 + pp;
-  const bool inner = live && interior(g, i, j);
+  const bool inner = live && interior(g, b, i, j);
   double v[2] = {0.0, 0.0};
   if (inner) {
-    const bool rim = (i + 1 == g.ib || i + 1 == g.ie || j + 1 == g.jb || j + 1 == g.je);
+    const bool rim = (i + 1 == g.ib || i + 1 == blk_ie(g, b) || j + 1 == g.jb || j + 1 == blk_je(g, b));
     const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
     double zv[9], wv[9];
     const double r = a.R[q];
@@ -983,7 +983,7 @@ k_fcg_a2(DevGrid g, FusedArgs a) {
   const int pp = live0 ? (int)p0 : 0;
   const int i = pp % nxb, j = pp / nxb;
   const long long q = (long long)b * g.n2 + pp;
-  const bool fast = live1 && i + 1 > g.ib && i + 2 < g.ie && j + 1 > g.jb && j + 1 < g.je;
+  const bool fast = live1 && i + 1 > g.ib && i + 2 < blk_ie(g, b) && j + 1 > g.jb && j + 1 < blk_je(g, b);
   double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [cell][field]
   if (fast) {
     double zr[3][4];
@@ -1018,7 +1018,7 @@ k_fcg_a2(DevGrid g, FusedArgs a) {
       if (!(e == 0 ? live0 : live1)) continue;
       const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
-      if (!interior(g, ii, jj)) continue;
+      if (!interior(g, b, ii, jj)) continue;
       const double r = a.R[qq];
       const double z0 = r * a.A0R[qq];
       const double wv[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};
@@ -1057,7 +1057,7 @@ k_fcg_b(DevGrid g, FusedArgs a, int par) {
   const int pp = live ? p2 : 0;
   const int i = pp % g.nxb, j = pp / g.nxb;
   const long long q = (long long)b * g.n2 + pp;
-  const bool inner = live && interior(g, i, j);
+  const bool inner = live && interior(g, b, i, j);
   double z = 0.0, az = 0.0, s = 0.0, qq = 0.0, x = 0.0, r = 0.0;
   if (inner) { z = a.Z[q]; az = a.AZ[q]; s = a.S0[q]; qq = a.Q[q]; x = a.X[q]; r = a.R[q]; }
   double rho, delta;
@@ -1075,7 +1075,7 @@ k_fcg_b(DevGrid g, FusedArgs a, int par) {
     a.X[q] = x + al * s;
     const double rn = r - al * qq;
     a.R[q] = rn;
-    if (a.sendmap && send_band(g, i, j)) pack_cell(a, q, rn * a.A0R[q]);   // next iteration's z for the neighbours' ghosts
+    if (a.sendmap && send_band(g, b, i, j)) pack_cell(a, q, rn * a.A0R[q]);   // next iteration's z for the neighbours' ghosts
   } else if (live && a.rmap) {
     // ghost owned by another rank: its z of this iteration is in the receive buffer; the search direction and the
     // solution there are advanced with the owner's arithmetic (needed by r = b - A x at the checks and as the ghost
@@ -1106,7 +1106,7 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
   const int i = pp % nxb, j = pp / nxb;
   const long long q = (long long)b * g.n2 + pp;
   // fast path: both cells strictly inside the physical domain of the same row (no ghost neighbour, no srcmap)
-  const bool fast = live1 && i + 1 > g.ib && i + 2 < g.ie && j + 1 > g.jb && j + 1 < g.je;
+  const bool fast = live1 && i + 1 > g.ib && i + 2 < blk_ie(g, b) && j + 1 > g.jb && j + 1 < blk_je(g, b);
   double v0 = 0.0, v1 = 0.0;
   double zr[3][4], sr[3][4];
   double2 cc, xx, x0, xm, y0, ym;
@@ -1164,7 +1164,7 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
       if (!(e == 0 ? live0 : live1)) continue;
       const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
-      const bool in_e = interior(g, ii, jj);
+      const bool in_e = interior(g, b, ii, jj);
       const double sold = a.S0[qq];
       if (XUPD) a.X[qq] = a.X[qq] + alpha * sold;
       const double s = (in_e ? a.Z[qq] : z_at(a, (int)qq)) + sold * bt;
@@ -1225,7 +1225,7 @@ k_fresidual(DevGrid g, FusedArgs a) {
   if (p2 < g.n2) {
     const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
     const long long q = (long long)b * g.n2 + p2;
-    if (interior(g, i, j)) {
+    if (interior(g, b, i, j)) {
       auto xs = [&](long long qq) { const int m = a.srcmap[qq]; return (m < 0) ? 0.0 : a.X[m]; };
       const double ax = a.C[q] * a.X[q] + g.WNo[q] * xs(q + nxb) + g.WNo[q - nxb] * xs(q - nxb) + g.WEa[q] * xs(q + 1) + g.WEa[q - 1] * xs(q - 1) +
                         g.WNE[q] * xs(q + nxb + 1) + g.WNE[q - nxb] * xs(q - nxb + 1) + g.WNE[q - 1] * xs(q + nxb - 1) + g.WNE[q - 1 - nxb] * xs(q - nxb - 1);
@@ -1233,7 +1233,7 @@ k_fresidual(DevGrid g, FusedArgs a) {
       a.R[q] = r;
       if (WITH_RR) v[0] = (r * r) * (double)g.mMask8[q];
       // distributed ChronGear: the z = r*A0R the next iteration's neighbours need travels from here
-      if (a.sendmap && a.A0R && send_band(g, i, j)) pack_cell(a, q, r * a.A0R[q]);
+      if (a.sendmap && a.A0R && send_band(g, b, i, j)) pack_cell(a, q, r * a.A0R[q]);
     }
   }
   if (WITH_RR) wg_reduce_store<1>(v, a.partA, b * a.nchunk + red_chunk(g));
@@ -1253,7 +1253,7 @@ k_fresidual2(DevGrid g, FusedArgs a) {
   const int pp = live0 ? (int)p0 : 0;
   const int i = pp % nxb, j = pp / nxb;
   const long long q = (long long)b * g.n2 + pp;
-  const bool fast = live1 && i + 1 > g.ib && i + 2 < g.ie && j + 1 > g.jb && j + 1 < g.je;
+  const bool fast = live1 && i + 1 > g.ib && i + 2 < blk_ie(g, b) && j + 1 > g.jb && j + 1 < blk_je(g, b);
   double v0 = 0.0, v1 = 0.0;
   if (fast) {
     double xr[3][4];
@@ -1278,8 +1278,8 @@ k_fresidual2(DevGrid g, FusedArgs a) {
     *reinterpret_cast<double2 *>(a.R + q) = make_double2(rA, rB);
     if (WITH_RR) { v0 = (rA * rA) * (double)g.mMask8[q]; v1 = (rB * rB) * (double)g.mMask8[q + 1]; }
     if (a.sendmap && a.A0R) {   // the second ring of the send band lies inside the fast region
-      if (send_band(g, i, j)) pack_cell(a, q, rA * a.A0R[q]);
-      if (send_band(g, i + 1, j)) pack_cell(a, q + 1, rB * a.A0R[q + 1]);
+      if (send_band(g, b, i, j)) pack_cell(a, q, rA * a.A0R[q]);
+      if (send_band(g, b, i + 1, j)) pack_cell(a, q + 1, rB * a.A0R[q + 1]);
     }
   } else {
 #pragma unroll
@@ -1287,14 +1287,14 @@ k_fresidual2(DevGrid g, FusedArgs a) {
       if (!(e == 0 ? live0 : live1)) continue;
       const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
-      if (!interior(g, ii, jj)) continue;
+      if (!interior(g, b, ii, jj)) continue;
       auto xs = [&](long long m0) { const int m = a.srcmap[m0]; return (m < 0) ? 0.0 : a.X[m]; };
       const double ax = a.C[qq] * a.X[qq] + g.WNo[qq] * xs(qq + nxb) + g.WNo[qq - nxb] * xs(qq - nxb) + g.WEa[qq] * xs(qq + 1) + g.WEa[qq - 1] * xs(qq - 1) +
                         g.WNE[qq] * xs(qq + nxb + 1) + g.WNE[qq - nxb] * xs(qq - nxb + 1) + g.WNE[qq - 1] * xs(qq + nxb - 1) + g.WNE[qq - 1 - nxb] * xs(qq - nxb - 1);
       const double r = a.Bv[qq] - ax;
       a.R[qq] = r;
       if (WITH_RR) { const double vv = (r * r) * (double)g.mMask8[qq]; if (e == 0) v0 = vv; else v1 = vv; }
-      if (a.sendmap && a.A0R && send_band(g, ii, jj)) pack_cell(a, qq, r * a.A0R[qq]);
+      if (a.sendmap && a.A0R && send_band(g, b, ii, jj)) pack_cell(a, qq, r * a.A0R[qq]);
     }
   }
   if (WITH_RR) {

@@ -20,6 +20,10 @@ __device__ __forceinline__ double pbc_dz(const DevGrid &g, int k, int kbot, doub
   return (k < 1 || k > g.km) ? 0.0 : ((k == kbot) ? dzbot : g.dz[k]);
 }
 
+// last physical column / row of local block b (1-based): block-uniform unless the decomposition is padded
+__device__ __forceinline__ int blk_ie(const DevGrid &g, int b) { return g.ieb ? g.ieb[b] : g.ie; }
+__device__ __forceinline__ int blk_je(const DevGrid &g, int b) { return g.jeb ? g.jeb[b] : g.je; }
+
 // Column-kernel prologue: one thread per (i,j) of local block b; returns false for threads
 // outside the physical domain ib..ie, jb..je (or outside the block).
 struct Col {
@@ -163,7 +167,7 @@ __device__ __forceinline__ bool col_setup(const DevGrid &g, Col &c, bool interio
     c.i = c.p2 % g.nxb;
     c.j = c.p2 / g.nxb;
   }
-  if (interior_only && (c.i + 1 < g.ib || c.i + 1 > g.ie || c.j + 1 < g.jb || c.j + 1 > g.je)) return false;
+  if (interior_only && (c.i + 1 < g.ib || c.i + 1 > blk_ie(g, c.b) || c.j + 1 < g.jb || c.j + 1 > blk_je(g, c.b))) return false;
   c.q2 = (long long)c.b * g.n2 + c.p2;
   c.base3 = (long long)c.b * g.n3 + c.p2;
   return true;
@@ -239,7 +243,7 @@ __device__ __forceinline__ bool red_land(const DevGrid &g, bool deep = false) {
     j0 = (int)(p0 / g.nxb); j1 = (int)(p1 / g.nxb);
     i0 = (j0 == j1) ? (int)(p0 % g.nxb) : 0; i1 = (j0 == j1) ? (int)(p1 % g.nxb) : g.nxb - 1;
   }
-  if (deep && !(i0 >= g.ib - 1 + NGHOST && i1 <= g.ie - 1 - NGHOST && j0 >= g.jb - 1 + NGHOST && j1 <= g.je - 1 - NGHOST)) return false;
+  if (deep && !(i0 >= g.ib - 1 + NGHOST && i1 <= blk_ie(g, blockIdx.y) - 1 - NGHOST && j0 >= g.jb - 1 + NGHOST && j1 <= blk_je(g, blockIdx.y) - 1 - NGHOST)) return false;
   return true;
 }
 template <int NF>

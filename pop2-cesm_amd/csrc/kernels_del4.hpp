@@ -22,7 +22,7 @@ __global__ void k_del4_d2t(DevGrid g, const double *__restrict__ AHF, const doub
   const int k0 = blockIdx.y * POP_DEL4_KC + 1, b = blockIdx.z;
   if (!patch_cell(g, tile, b, p2)) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
-  if (i + 1 < g.ib - 1 || i + 1 > g.ie + 1 || j + 1 < g.jb - 1 || j + 1 > g.je + 1) return;
+  if (i + 1 < g.ib - 1 || i + 1 > blk_ie(g, b) + 1 || j + 1 < g.jb - 1 || j + 1 > blk_je(g, b) + 1) return;
   const long long q = (long long)b * g.n2 + p2;
   const int kmt = g.KMT[q], kmtn = g.KMTN[q], kmts = g.KMTS[q], kmte = g.KMTE[q], kmtw = g.KMTW[q];
   const double dtn = g.DTN[q], dts = g.DTS[q], dte = g.DTE[q], dtw = g.DTW[q];
@@ -55,7 +55,7 @@ __global__ void k_del4_d2u(DevGrid g, const double *__restrict__ AMF, const doub
   const int k0 = blockIdx.y * POP_DEL4_KC + 1, b = blockIdx.z;
   if (!patch_cell(g, tile, b, p2)) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
-  if (i + 1 < g.ib - 1 || i + 1 > g.ie + 1 || j + 1 < g.jb - 1 || j + 1 > g.je + 1) return;
+  if (i + 1 < g.ib - 1 || i + 1 > blk_ie(g, b) + 1 || j + 1 < g.jb - 1 || j + 1 > blk_je(g, b) + 1) return;
   const long long q = (long long)b * g.n2 + p2;
   const int kmu = g.KMU[q];
   const double cc = g.DUC[q] + g.DUM[q];

@@ -174,7 +174,7 @@ k_lw_x(DevGrid g, LwDev w, const double *__restrict__ X0, const double *__restri
   const int k = blockIdx.y + 1, b = blockIdx.z >> 1, n = blockIdx.z & 1;
   if (p2 >= g.n2) return;
   const int i = p2 % g.nxb;
-  if (i + 1 < g.ib || i + 1 > g.ie) return;
+  if (i + 1 < g.ib || i + 1 > blk_ie(g, b)) return;
   const long long n2 = g.n2, q = (long long)b * n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * n2 + p2;
   const double *__restrict__ X = n ? X1 : X0;
   const double *__restrict__ XS = w.XSTAR[n];
@@ -229,7 +229,7 @@ k_lw_y(DevGrid g, LwDev w, const double *__restrict__ X0, const double *__restri
   const int k = blockIdx.y + 1, b = blockIdx.z >> 1, n = blockIdx.z & 1;
   if (p2 >= g.n2) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb, nxb = g.nxb;
-  if (i + 1 < g.ib || i + 1 > g.ie || j + 1 < g.jb || j + 1 > g.je) return;
+  if (i + 1 < g.ib || i + 1 > blk_ie(g, b) || j + 1 < g.jb || j + 1 > blk_je(g, b)) return;
   const long long n2 = g.n2, q = (long long)b * n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * n2 + p2;
   const double *__restrict__ X = n ? X1 : X0;
   const double *__restrict__ XS = w.XSTAR2[n];

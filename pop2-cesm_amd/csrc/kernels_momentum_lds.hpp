@@ -51,7 +51,7 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a, int tj_first, in
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * POP_COL_THREADS + tx;
   const int i = i0 + tx, j = j0 + ty;
   const bool inb = i < nxb && j < nyb;                       // cell exists (tiles may overhang the array)
-  const bool act = inb && i + 1 <= g.ie && j + 1 <= g.je;    // physical column (i0, j0 are already >= ib, jb)
+  const bool act = inb && i + 1 <= blk_ie(g, b) && j + 1 <= blk_je(g, b);    // physical column (i0, j0 are already >= ib, jb)
   // every lane addresses a cell that exists: lanes beyond the array read cell 0 of the block (their values are never used: the
   // stencil of a physical column stays inside the block) and store to the dump area
   const int p2 = inb ? j * nxb + i : 0;

@@ -62,7 +62,7 @@ __global__ void k_pcsi_scale(DevGrid g, double *__restrict__ R, const double *__
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (p2 >= g.n2) return;
   const int i = p2 % g.nxb, j = p2 / g.nxb;
-  if (!interior(g, i, j)) return;
+  if (!interior(g, b, i, j)) return;
   const long long q = (long long)b * g.n2 + p2;
   R[q] = R[q] * A0R[q];
 }
@@ -81,10 +81,10 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
   if (p2 < g.n2) {
     const int i = p2 % nxb, j = p2 / nxb;
     const long long q = (long long)b * g.n2 + p2;
-    if (interior(g, i, j)) {
+    if (interior(g, b, i, j)) {
       const double om = FIRST ? a.omega[0] : a.omega[*a.base + a.j];
       const double cq = FIRST ? 0.0 : a.csy * om - 1.0;
-      const bool rim = (i + 1 == g.ib || i + 1 == g.ie || j + 1 == g.jb || j + 1 == g.je);
+      const bool rim = (i + 1 == g.ib || i + 1 == blk_ie(g, b) || j + 1 == g.jb || j + 1 == blk_je(g, b));
       const int off[8] = {nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
       // gather first: every load is independent
       double rp[9], qo[9], xo[9];
@@ -141,7 +141,7 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
   const int pp = live0 ? (int)p0 : 0;
   const int i = pp % nxb, j = pp / nxb;
   const long long q = (long long)b * g.n2 + pp;
-  const bool fast = live1 && i + 1 > g.ib && i + 2 < g.ie && j + 1 > g.jb && j + 1 < g.je;
+  const bool fast = live1 && i + 1 > g.ib && i + 2 < blk_ie(g, b) && j + 1 > g.jb && j + 1 < blk_je(g, b);
   const double om = a.omega[*a.base + a.j];
   const double cq = a.csy * om - 1.0;
   double v0 = 0.0, v1 = 0.0;
@@ -180,7 +180,7 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
       if (!(e == 0 ? live0 : live1)) continue;
       const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
-      if (interior(g, ii, jj)) {
+      if (interior(g, b, ii, jj)) {
         double xn[9], dx0 = 0.0;
 #pragma unroll
         for (int n = 0; n < 9; ++n) {

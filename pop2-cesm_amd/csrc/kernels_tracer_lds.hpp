@@ -46,7 +46,7 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * POP_COL_THREADS + tx;
   const int i = i0 + tx, j = j0 + ty;
   const bool inb = i < nxb && j < nyb;
-  const bool act = inb && i + 1 <= g.ie && j + 1 <= g.je;
+  const bool act = inb && i + 1 <= blk_ie(g, b) && j + 1 <= blk_je(g, b);
   // every lane addresses a cell that exists (lanes beyond the array: cell 0, whose values are never used) and stores either to
   // the field or to the dump area
   const int p2 = inb ? j * nxb + i : 0;

@@ -1378,6 +1378,21 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
   g.lds_order = tun_or(h.tun.lds_order, 1);
   g.red_band = tun_or(h.tun.red_band, 1);
   g.ib = NGHOST + 1; g.ie = h.nxb - NGHOST; g.jb = NGHOST + 1; g.je = h.nyb - NGHOST;
+  {   // padded blocks (blocks.F90:174-265): per-block last physical column / row, only when some local block ends early
+    std::vector<int> ieb(h.nblocks), jeb(h.nblocks);
+    bool short_block = false;
+    for (int lb = 0; lb < h.nblocks; ++lb) {
+      const BlockInfo &B = h.all_blocks[h.local_ids[lb] - 1];
+      ieb[lb] = B.ie; jeb[lb] = B.je;
+      if (B.ie != g.ie || B.je != g.je) short_block = true;
+    }
+    g.ieb = nullptr; g.jeb = nullptr;
+    if (short_block) {
+      int *d0, *d1;
+      if (dev_upload(c, &d0, ieb.data(), ieb.size()) || dev_upload(c, &d1, jeb.data(), jeb.size())) return 1;
+      g.ieb = d0; g.jeb = d1;
+    }
+  }
   // vertical arrays
   {
     struct { CArr *dst; std::vector<double> *src; } V[] = {
@@ -1579,7 +1594,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
         if (is_land && multi) {   // as red_land(g, deep): chunks within NGHOST of the edge of the physical domain work for other ranks
           const int j0 = (int)(p0 / h.nxb), j1 = (int)((p1 - 1) / h.nxb);
           const int i0 = (j0 == j1) ? (int)(p0 % h.nxb) : 0, i1 = (j0 == j1) ? (int)((p1 - 1) % h.nxb) : h.nxb - 1;
-          is_land = i0 >= g.ib - 1 + NGHOST && i1 <= g.ie - 1 - NGHOST && j0 >= g.jb - 1 + NGHOST && j1 <= g.je - 1 - NGHOST;
+          const BlockInfo &Bk = h.all_blocks[h.local_ids[b] - 1];
+          is_land = i0 >= g.ib - 1 + NGHOST && i1 <= Bk.ie - 1 - NGHOST && j0 >= g.jb - 1 + NGHOST && j1 <= Bk.je - 1 - NGHOST;
         }
         (is_land && !(b == 0 && k == 0) ? land[b] : act[b]).push_back(k);
       }
@@ -2946,7 +2962,8 @@ int pop_global_sum_i4(pop_ctx *c, const char *name, long long *result) {
   long long s = 0;
   for (int lb = 0; lb < h.nblocks; ++lb) {
     const int *a = it->second.data() + (size_t)(h.local_ids[lb] - 1) * h.n2;
-    for (int j = NGHOST; j < h.nyb - NGHOST; ++j) for (int i = NGHOST; i < h.nxb - NGHOST; ++i) s += a[(size_t)j * h.nxb + i];
+    const BlockInfo &B = h.all_blocks[h.local_ids[lb] - 1];
+    for (int j = B.jb - 1; j < B.je; ++j) for (int i = B.ib - 1; i < B.ie; ++i) s += a[(size_t)j * h.nxb + i];
   }
   double tot = 0.0;
   if (pop_global_sum_scalar(c, (double)s, &tot)) return 1;

@@ -1,0 +1,88 @@
+"""Padded blocks (blocks.F90:174-265): a block size that does not divide the domain leaves the last column / row of blocks short --
+the global index maps hold 0 in the padding, every block has its own last physical column / row (ie, je).  The whole step through
+the C ABI against the CPU oracle on such decompositions, phase by phase, on the cells that exist; and against the same domain cut
+into blocks that divide it."""
+import numpy as np
+import pytest
+
+from popcfg import named_config
+from orclib import Oracle
+from test_gpu_parity import run_phases, force_kpp_case, relerr, TOL_LOCAL, TOL_SOLVE
+
+pytestmark = pytest.mark.gpu
+
+DEL4 = {"hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1, "am": -1.0e22, "ah": -1.0e21}
+
+
+def block_masks(m):
+    """phys: the physical cells of every local block; near: cells with non-zero global indices whose eight neighbours have them too"""
+    nb, ny, nx = m.nblocks, m.nyb, m.nxb
+    phys = np.zeros((nb, ny, nx), dtype=bool)
+    cell = np.zeros((nb, ny, nx), dtype=bool)
+    short = 0
+    for lb, bid in enumerate(m.local_block_ids()):
+        blk = m.get_block(bid)
+        phys[lb, blk["jb"] - 1:blk["je"], blk["ib"] - 1:blk["ie"]] = True
+        cell[lb] = (blk["j_glob"] != 0)[:, None] & (blk["i_glob"] != 0)[None, :]
+        short += (blk["ie"] < nx - 2) or (blk["je"] < ny - 2)
+    near = cell.copy()
+    for dj in (-1, 0, 1):
+        for di in (-1, 0, 1):
+            sh = np.ones_like(cell)
+            js = slice(max(dj, 0), ny + min(dj, 0)); jd = slice(max(-dj, 0), ny + min(-dj, 0))
+            is_ = slice(max(di, 0), nx + min(di, 0)); id_ = slice(max(-di, 0), nx + min(-di, 0))
+            sh[:, jd, id_] = cell[:, js, is_]
+            near &= sh
+    return {"phys": phys, "near": near, "short": short}
+
+
+@pytest.mark.parametrize("name,kw,nsteps", [
+    ("tiny", {"block_size_x": 20, "block_size_y": 16}, 5),                                   # 3 x 3 blocks, last ones 8 wide / 8 high
+    ("tiny", {"block_size_x": 36, "block_size_y": 40, "solver_choice": 2}, 4),                # 2 x 1 blocks, ChronGear
+    ("tiny", {"block_size_x": 20, "block_size_y": 16, "ew_boundary": 0, "tadvect": 2}, 4),    # closed east-west, upwind3
+    ("tiny", {"block_size_x": 20, "block_size_y": 16, "vmix_choice": 3, "km": 24, **DEL4}, 5),
+    ("tiny", {"block_size_x": 28, "block_size_y": 24, "vmix_choice": 3, "km": 60, "stepped_bathymetry": 1}, 4),   # register kernels
+    ("tiny", {"block_size_x": 20, "block_size_y": 16, "stepped_bathymetry": 1, "partial_bottom_cells": 1, "tmix_opt": 3}, 4),
+    ("tiny", {"block_size_x": 20, "block_size_y": 16, "tadvect": 3, "vmix_choice": 2}, 4),
+    ("gx3v7", {"block_size_x": 64, "block_size_y": 50}, 3),                                   # 100 x 116 in 2 x 3 blocks
+])
+def test_padded_blocks_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
+    cfg = named_config(name, **kw)
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    gpu.masks = block_masks(gpu)
+    assert gpu.masks["short"] > 0
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
+    tol = TOL_LOCAL
+    for step in range(1, nsteps + 1):
+        run_phases(gpu, orc, step, tol)
+        tol = TOL_SOLVE        # later steps inherit the solver's summation-order difference (as in test_step_phases_match_oracle)
+    assert np.abs(gpu.get("UVEL", 1)).max() > 1.0
+    gpu.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", [{}, {"vmix_choice": 3, "km": 24, **DEL4}])
+def test_padded_and_dividing_decompositions_agree(pkg, kw):
+    """the same 48 x 40 domain in 12 x 10 blocks (dividing) and in 20 x 16 blocks (padded): same iteration counts, fields equal to
+    the tolerance of the elliptic solve (the block sums of the dot products are formed in a different order)"""
+    out = {}
+    for bs in ((12, 10), (20, 16)):
+        m = pkg.PopModel(named_config("tiny", block_size_x=bs[0], block_size_y=bs[1], **kw))
+        its = []
+        for _ in range(5):
+            m.step(); its.append(m.solver_diagnostics()[0])
+        glob = {}
+        for f, three in (("PSURF", False), ("TRACER", True), ("UVEL", True)):
+            a = m.get(f, 1, 0)
+            G = np.zeros((a.shape[1] if three else 1, 40, 48))
+            for lb, bid in enumerate(m.local_block_ids()):
+                blk = m.get_block(bid)
+                js, je, is_, ie = blk["jb"] - 1, blk["je"], blk["ib"] - 1, blk["ie"]
+                gj, gi = blk["j_glob"][js:je] - 1, blk["i_glob"][is_:ie] - 1
+                G[:, gj[:, None], gi[None, :]] = a[lb][..., js:je, is_:ie] if three else a[lb][None, js:je, is_:ie]
+            glob[f] = G
+        out[bs] = (its, glob)
+        m.close()
+    assert out[(12, 10)][0] == out[(20, 16)][0]
+    for f in ("PSURF", "TRACER", "UVEL"):
+        assert relerr(out[(20, 16)][1][f], out[(12, 10)][1][f]) < TOL_SOLVE, f

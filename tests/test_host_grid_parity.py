@@ -184,8 +184,10 @@ def test_abi_exports_every_declared_symbol(pkg):
 
 
 def test_bad_configs_are_rejected(pkg):
+    with pytest.raises(pkg.PopError, match="divide"):      # padded blocks: dipole grids with pcg / ChronGear and the diagonal preconditioner only
+        pkg.PopModel(named_config("tiny", block_size_x=13, solver_choice=3), host_only=True)
     with pytest.raises(pkg.PopError, match="divide"):
-        pkg.PopModel(named_config("tiny", block_size_x=13), host_only=True)
+        pkg.PopModel(named_config("tiny", block_size_x=20, block_size_y=16, precond_choice=1), host_only=True)
     with pytest.raises(pkg.PopError, match="nt"):
         pkg.PopModel(named_config("tiny", nt=1), host_only=True)
     m = pkg.PopModel(named_config("tiny"), host_only=True)
@@ -204,3 +206,53 @@ def test_unsupported_options_are_refused_at_create(pkg, field, value):
     with pytest.raises(pkg.PopError) as e:
         pkg.PopModel(cfg, host_only=True)
     assert "pop_create" in str(e.value)
+
+
+@pytest.mark.parametrize("kw", [{"block_size_x": 20, "block_size_y": 16}, {"block_size_x": 36, "block_size_y": 40}, {"block_size_x": 20, "block_size_y": 16, "ew_boundary": 0},
+                                {"block_size_x": 20, "block_size_y": 16, "hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1, "tadvect": 2},
+                                {"block_size_x": 20, "block_size_y": 16, "stepped_bathymetry": 1, "partial_bottom_cells": 1}],
+                         ids=["20x16", "36x40", "20x16-closed", "20x16-del4-upwind3", "20x16-pbc"])
+def test_padded_blocks_host_fields_bit_exact(pkg, orclib_built, kw):
+    """Block sizes that do not divide the 48 x 40 domain (blocks.F90:174-265): the last column / row of blocks is padded.  Block
+    table (ie, je, global index maps with 0 in the padding) equal to the oracle's, and every init-time field equal bit for bit on
+    the cells that exist (global index non-zero in both directions; what sits in the padding is never read)."""
+    cfg = named_config("tiny", **kw)
+    m = pkg.PopModel(cfg, host_only=True)
+    o = Oracle(cfg)
+    assert (m.nxb, m.nyb, m.km, m.nblocks) == (o.nxb, o.nyb, o.km, o.nblocks)
+    ig, jg = o.ivec("i_glob", o.nxb * o.nblocks).reshape(o.nblocks, o.nxb), o.ivec("j_glob", o.nyb * o.nblocks).reshape(o.nblocks, o.nyb)
+    short = 0
+    for bid in range(1, m.nblocks_tot + 1):
+        blk = m.get_block(bid)
+        assert np.array_equal(blk["i_glob"], ig[bid - 1]) and np.array_equal(blk["j_glob"], jg[bid - 1])
+        assert blk["ie"] == o.ivec("blk_ie", o.nblocks)[bid - 1] and blk["je"] == o.ivec("blk_je", o.nblocks)[bid - 1]
+        short += (blk["ie"] < m.nxb - 2) or (blk["je"] < m.nyb - 2)
+    assert short > 0, "no padded block in this decomposition"
+    cell = (jg != 0)[:, :, None] & (ig != 0)[:, None, :]
+    assert (~cell).any()
+    # stencil-built coefficients (AUE = TAREA(i+1,j) / 4 UAREA ...) of a ghost cell next to the padding read the padding: compared are
+    # the cells whose eight neighbours exist too -- every physical cell and the first ring of ghost cells
+    exists = cell.copy()
+    for dj in (-1, 0, 1):
+        for di in (-1, 0, 1):
+            sh = np.ones_like(cell)
+            js = slice(max(dj, 0), cell.shape[1] + min(dj, 0)); jd = slice(max(-dj, 0), cell.shape[1] + min(-dj, 0))
+            is_ = slice(max(di, 0), cell.shape[2] + min(di, 0)); id_ = slice(max(-di, 0), cell.shape[2] + min(-di, 0))
+            sh[:, jd, id_] = cell[:, js, is_]
+            exists &= sh
+    for f in IFIELDS:
+        assert np.array_equal(m.geti(f)[exists], o.i2(f)[exists]), f
+    names = list(FIELDS)
+    if cfg.hmix_momentum == 4:
+        names += ["d4" + f for f in ("DUC", "DUN", "DUS", "DUE", "DUW", "DMC", "DMN", "DMS", "DME", "DMW", "DUM", "DTN", "DTS", "DTE", "DTW")]
+    if cfg.tadvect == 2:
+        names += ["TALFXP", "TBETXP", "TGAMXP", "TALFXM", "TBETXM", "TDELXM", "TALFYP", "TBETYP", "TGAMYP", "TALFYM", "TBETYM", "TDELYM"]
+    if cfg.partial_bottom_cells:
+        names += ["DZBC"]
+    for f in names:
+        a, b = m.get(f), o.f2(f)
+        assert np.array_equal(a[exists], b[exists]), "%s: %d of %d existing cells differ" % (f, int((a[exists] != b[exists]).sum()), int(exists.sum()))
+    assert np.isfinite(np.concatenate([m.get(f).ravel() for f in ("DXUR", "DYUR", "TAREA_R", "UAREA_R", "HUR")])).all()
+    for s in ("residualNorm", "convergenceCriterion", "rcheck", "rconst"):
+        assert m.scalar(s) == o.scalar(s), s
+    m.close(); o.close()
