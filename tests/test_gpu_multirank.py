@@ -69,6 +69,8 @@ def test_large_grid_two_ranks_equal_single_rank():
     (3, "precond_choice=1,solver_choice=3,block_size_x=24,block_size_y=20", {}),   # P-CSI + EVP, uneven ownership
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3 across ranks
     (2, "tadvect=3", {}),                                             # lw_lim: halo update of the flux-velocity fields across ranks
+    (2, "block_size_x=20,block_size_y=16", {}),                       # padded blocks (3 x 3, last column / row short): fused distributed pcg
+    (3, "block_size_x=20,block_size_y=16,solver_choice=2,vmix_choice=3,km=24", {}),   # padded blocks, ChronGear, KPP, one row of blocks per rank
     (2, "hmix_momentum=4,hmix_tracer=4,am=-1.0e22,ah=-1.0e21,lvariable_hmix=1", {"POP_D2T_FUSE": "1"}),   # del4 first Laplacians formed by the previous step's kernels: their ghost ring crosses ranks
 ])
 def test_multirank_equals_single_rank(nranks, kw, env):
