@@ -471,6 +471,8 @@ void launch_fpcg_a(pop_ctx *c, const SolveView &v, const FusedArgs &a, bool upda
 void launch_fpcg_b(pop_ctx *c, const SolveView &v, const FusedArgs &a, bool xupd) {
   const dim3 G = view_grid(v);
   const bool two = a.presummed && (v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell;
+  // (occupancy probe, profiles/r03_ab_b2_occupancy.txt: with dynamic LDS holding the kernel to 3 / 2 waves per SIMD instead of its 4
+  // the step costs +2.2 / +7.1 ms; the two-cell form needs 108 VGPRs, a 96- or 80-register budget spills 84 / 140 B)
   if (two && xupd) hipLaunchKernelGGL(k_fpcg_b2<true>, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
   else if (two) hipLaunchKernelGGL(k_fpcg_b2<false>, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
   else if (xupd) hipLaunchKernelGGL(k_fpcg_b<true>, G, dim3(POP_RED_THREADS), 0, c->stream, v.g, a);
