@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from popcfg import named_config  # noqa: E402
 
 FIELDS = [("TRACER", True), ("UVEL", True), ("VVEL", True), ("RHO", True), ("PSURF", False), ("UBTROP", False)]
-NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6, "pcsi_evp": 4, "lw_lim": 5, "pbc_kpp_del4": 5}
+NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6, "pcsi_evp": 4, "lw_lim": 5, "pbc_kpp_del4": 5, "padded": 5}
 
 
 def config(case):
@@ -30,6 +30,9 @@ def config(case):
     if case == "pbc_kpp_del4":   # partial bottom cells on stepped bathymetry with the tx0.1v3 physics (del4 + variable mixing + KPP + double diffusion)
         return named_config("tiny", vmix_choice=3, ldbl_diff=1, hmix_momentum=4, hmix_tracer=4, lvariable_hmix=1,
                             am=-1.0e23, ah=-1.0e22, stepped_bathymetry=1, partial_bottom_cells=1, **small)
+    if case == "padded":      # block size 10 x 8 on the 24 x 20 domain: 3 x 3 blocks, the last column / row 4 wide / 4 high (blocks.F90:174-265)
+        return named_config("tiny", vmix_choice=3, hmix_momentum=4, hmix_tracer=4, lvariable_hmix=1, am=-1.0e23, ah=-1.0e22,
+                            stepped_bathymetry=1, nx_global=24, ny_global=20, km=16, block_size_x=10, block_size_y=8)
     if case == "upwind3":     # third-order upwind tracer advection + Richardson vmix
         return named_config("tiny", tadvect=2, vmix_choice=2, **small)
     if case == "lw_lim":      # Lax-Wendroff advection with one-dimensional flux limiters + KPP
@@ -48,7 +51,7 @@ def surface_fluxes(tlat):
 def prepare(model, case):
     """Set the surface tracer fluxes (the KPP case needs buoyancy forcing).  `model` is an Oracle or a
     PopModel-like object with f2()/set()."""
-    if case not in ("kpp_del4", "pbc_kpp_del4"):
+    if case not in ("kpp_del4", "pbc_kpp_del4", "padded"):
         return
     tlat = model.f2("TLAT") if hasattr(model, "f2") else model.get("TLAT")
     st, ss = surface_fluxes(tlat)
@@ -70,8 +73,13 @@ def main():
         prepare(o, case)
         iters = [o.step() for _ in range(NSTEPS[case])]
         out = {"nsteps": NSTEPS[case], "iters": np.array(iters)}
+        # the cells a comparison may look at: global index non-zero in both directions (padded blocks hold nothing beyond)
+        ig = o.ivec("i_glob", o.nxb * o.nblocks).reshape(o.nblocks, o.nxb)
+        jg = o.ivec("j_glob", o.nyb * o.nblocks).reshape(o.nblocks, o.nyb)
+        out["exists"] = (jg != 0)[:, :, None] & (ig != 0)[:, None, :]
         for name, three_d in FIELDS:
-            out[name] = (o.f3 if three_d else o.f2)(name, 1, 0).copy()
+            a = (o.f3 if three_d else o.f2)(name, 1, 0).copy()
+            out[name] = np.where(out["exists"][:, None] if three_d else out["exists"], a, 0.0) if case == "padded" else a
         np.savez_compressed(os.path.join(HERE, "golden_%s.npz" % case), **out)
         print(case, "iters", iters, "Tmax", out["TRACER"].max())
         o.close()
