@@ -1308,19 +1308,26 @@ k_kpp_hmxl(DevGrid g, KppDev kp, const double *__restrict__ T, const double *__r
   if (!col_setup(g, c, false)) return;
   const int km = g.km, kmt = g.KMT[c.q2];
   const long long n2 = g.n2;
+  // partial bottom cells (:1326-1356): depths and spacings from the cell thicknesses DZT(k) (DZT(0) = 0)
+  const bool pbc = g.pbc != 0;
+  const double dzb = pbc ? g.DZBC[c.q2] : 0.0;
+  auto dzt = [&](int k) { return pbc_dz(g, k, kmt, dzb); };
   double ustar = 0.0, hmxl = (kmt == 1) ? g.zt[1] : 0.0;
   for (int k = 2; k <= km && k <= kmt; ++k) {
-    const double q = DBSFC[c.base3 + (long long)(k - 1) * n2] / g.zt[k];
+    const double zk = pbc ? g.zt[k - 1] + 0.5 * (dzt(k - 1) + dzt(k)) : g.zt[k];
+    const double q = DBSFC[c.base3 + (long long)(k - 1) * n2] / zk;
     ustar = (q > ustar) ? q : ustar;
-    hmxl = g.zt[k];
+    hmxl = zk;
   }
   double gm1 = 0.0, dbm1 = DBSFC[c.base3];
   for (int k = 2; k <= km; ++k) {
     const double db = DBSFC[c.base3 + (long long)(k - 1) * n2];
-    const double v = (ustar > 0.0) ? (db - dbm1) / (g.zt[k] - g.zt[k - 1]) : 0.0;
+    const double dzk = pbc ? 0.5 * (dzt(k) + dzt(k - 1)) : (g.zt[k] - g.zt[k - 1]);
+    const double v = (ustar > 0.0) ? (db - dbm1) / dzk : 0.0;
     if (v >= ustar && (v - gm1) != 0.0 && ustar > 0.0) {
       const double bf = (v - ustar) / (v - gm1);
-      hmxl = -0.5 * (kp.zgrid[k] + kp.zgrid[k - 1]) * (1.0 - bf) - 0.5 * (kp.zgrid[k - 1] + kp.zgrid[k - 2]) * bf;
+      hmxl = pbc ? (g.zt[k - 1] + 0.25 * (dzt(k - 1) + dzt(k))) * (1.0 - bf) + (g.zt[k - 1] - 0.25 * (dzt(k - 2) + dzt(k - 1))) * bf
+                 : -0.5 * (kp.zgrid[k] + kp.zgrid[k - 1]) * (1.0 - bf) - 0.5 * (kp.zgrid[k - 1] + kp.zgrid[k - 2]) * bf;
       ustar = 0.0;
     }
     gm1 = v; dbm1 = db;
@@ -1605,6 +1612,8 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                                             s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
     else hipLaunchKernelGGL((k_kpp_blmix<true, false>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                             s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
+    if (h.c.kpp_ml_diagnostics == 1 && s.HMXL && s.HMXL_DR)   // DBSFC holds every level here (the diagnostics switch the on-demand march off)
+      hipLaunchKernelGGL(k_kpp_hmxl, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], (const double *)DBSFC, s.HMXL, s.HMXL_DR);
     const int vp = patch_rows(g, h.tun.del4_tile);
     hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vp), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vp ? 64 * vp : 256), 0, st, g, (const double *)VISC, s.VVC, vp);
     if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }

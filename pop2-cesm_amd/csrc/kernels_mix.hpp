@@ -21,8 +21,10 @@ struct MixState {        // per-step field pointers handed to the mixing kernels
   double *S3a, *S3b, *S3c, *S3d, *E3, *F3;   // 3-D scratch
 };
 
-// ---- vmix_coeffs_rich (vmix_rich.F90:224-400), no partial bottom cells, convection by diffusion
-// pass 1: Richardson number at T points (whole array) and tracer diffusivity; 3-D parallel
+// ---- vmix_coeffs_rich (vmix_rich.F90:224-400), convection by diffusion
+// pass 1: Richardson number at T points (whole array) and tracer diffusivity; 3-D parallel.  PBC (:266-275, :308-312): the
+// vertical shear is formed at the U points from the U-cell thicknesses and averaged to the T point
+template <bool PBC>
 __global__ void k_rich_t(DevGrid g, StepParams sp, MixState s, double *__restrict__ RICH) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = blockIdx.y + 1, b = blockIdx.z;
@@ -36,11 +38,28 @@ __global__ void k_rich_t(DevGrid g, StepParams sp, MixState s, double *__restric
   };
   double rich = 0.0, vdc = 0.0;
   const double critnu = sp.convect_diff;
-  if (k < g.KMT[q2]) {
+  const int kmt = g.KMT[q2];
+  if (k < kmt) {
     const MwjfP P = mwjf_level(g.pressz[kp1]);
     const double rhok = mwjf_rho<false>(P, s.TMIX[0][ok], s.TMIX[1][ok], nullptr, nullptr);
-    const double du = u2t(s.UMIX, ok) - u2t(s.UMIX, okp), dv = u2t(s.VMIX, ok) - u2t(s.VMIX, okp);
-    rich = -sp.grav * g.dzw[k] * (rhok - s.RHOMIX[okp]) / (du * du + dv * dv + 1.0e-10);
+    if constexpr (PBC) {
+      auto shear = [&](const double *A, long long d) {   // (A(k) - A(kp1)) / (p5*(DZU(k) + DZU(kp1))) at the U point q2 + d
+        const int kmu = g.KMU[q2 + d];
+        const double dzub = g.DZUB[q2 + d];
+        return (A[ok + d] - A[okp + d]) / (0.5 * (pbc_dz(g, k, kmu, dzub) + pbc_dz(g, kp1, kmu, dzub)));
+      };
+      double ut = 0.0, vt = 0.0;
+      if (i >= 1 && j >= 1) {
+        ut = 0.25 * shear(s.UMIX, 0) + 0.25 * shear(s.UMIX, -nxb) + 0.25 * shear(s.UMIX, -1) + 0.25 * shear(s.UMIX, -1 - nxb);
+        vt = 0.25 * shear(s.VMIX, 0) + 0.25 * shear(s.VMIX, -nxb) + 0.25 * shear(s.VMIX, -1) + 0.25 * shear(s.VMIX, -1 - nxb);
+      }
+      const double dzb = g.DZBC[q2];
+      const double h = 0.5 * (pbc_dz(g, k, kmt, dzb) + pbc_dz(g, kp1, kmt, dzb));
+      rich = -sp.grav * (rhok - s.RHOMIX[okp]) / h / (ut * ut + vt * vt + 1.0e-10 / (h * h));
+    } else {
+      const double du = u2t(s.UMIX, ok) - u2t(s.UMIX, okp), dv = u2t(s.VMIX, ok) - u2t(s.VMIX, okp);
+      rich = -sp.grav * g.dzw[k] * (rhok - s.RHOMIX[okp]) / (du * du + dv * dv + 1.0e-10);
+    }
     const double f = 1.0 + 5.0 * rich;
     vdc = fmin(critnu, sp.rich_bckgrnd_vdc + (sp.rich_bckgrnd_vvc + sp.rich_mix / (f * f)) / f);
   }
@@ -110,7 +129,8 @@ inline int mix_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                            hipStream_t st, std::string &err) {
   const dim3 G3((g.n2 + 255) / 256, g.km, g.nblocks);
   if (h.c.vmix_choice == 2) {
-    hipLaunchKernelGGL(k_rich_t, G3, dim3(256), 0, st, g, sp, s, s.S3c);
+    if (g.pbc) hipLaunchKernelGGL(k_rich_t<true>, G3, dim3(256), 0, st, g, sp, s, s.S3c);
+    else hipLaunchKernelGGL(k_rich_t<false>, G3, dim3(256), 0, st, g, sp, s, s.S3c);
     hipLaunchKernelGGL(k_rich_u, G3, dim3(256), 0, st, g, sp, s, (const double *)s.S3c);
     return 0;
   }

@@ -1316,9 +1316,6 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     for (int r = 0; r < 3; ++r) if (cfg->reserved_i[r] != 0) return bad("pop_config.reserved_i must be 0");
     for (int r = 0; r < 4; ++r) if (cfg->reserved_d[r] != 0.0) return bad("pop_config.reserved_d must be 0");
     if (cfg->partial_bottom_cells != 0 && cfg->partial_bottom_cells != 1) return bad("partial_bottom_cells: 0 or 1");
-    if (cfg->partial_bottom_cells && cfg->vmix_choice == 2) return bad("partial_bottom_cells with Richardson vertical mixing (vmix_rich.F90:266-330) is not built: vmix_choice 1 (const) or 3 (kpp)");
-    if (cfg->partial_bottom_cells && cfg->tadvect == 3) return bad("partial_bottom_cells with lw_lim advection (advection.F90:582-690, 2757-3140) is not built: tadvect 1 (centered) or 2 (upwind3)");
-    if (cfg->partial_bottom_cells && cfg->kpp_ml_diagnostics) return bad("partial_bottom_cells with the HMXL diagnostic (vmix_kpp.F90:1326-1350) is not built");
     if (cfg->partial_bottom_cells && grid && grid->DZBC == nullptr && grid->KMT != nullptr) return bad("partial_bottom_cells with a topography record needs pop_grid_input.DZBC (the record of bottom_cell_file)");
     if (cfg->lsw_absorb != 0 && cfg->lsw_absorb != 1) return bad("lsw_absorb: 0 or 1");
     if (cfg->nx_global < 1 || cfg->ny_global < 1 || cfg->km < 2 || cfg->block_size_x < 1 || cfg->block_size_y < 1) return bad("domain / block sizes must be positive (km >= 2)");
@@ -2252,16 +2249,23 @@ static int phase_hmix_tracer(pop_ctx *c, hipStream_t st = nullptr) {   // del4 o
 static int phase_advt_lw_lim(pop_ctx *c) {
   const int km = c->g.km;
   const double *X0 = c->TR[0][c->mixt], *X1 = c->TR[1][c->mixt];
-  hipLaunchKernelGGL(k_lw_flux, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, c->lw, (const double *)c->U[c->curt], (const double *)c->V[c->curt], (const double *)c->DH);
+  if (c->g.pbc) hipLaunchKernelGGL(k_lw_flux<true>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, c->lw, (const double *)c->U[c->curt], (const double *)c->V[c->curt], (const double *)c->DH);
+  else hipLaunchKernelGGL(k_lw_flux<false>, grid_cols(c), dim3(POP_COL_THREADS), 0, c->stream, c->g, c->lw, (const double *)c->U[c->curt], (const double *)c->V[c->curt], (const double *)c->DH);
   // UTE: E face, vector; WTKB: centre (comp_flux_vel_ghost :1080-1100).  VTN is not exchanged by the reference: it forms it in
   // the ghost rows from the ghost velocities.  Beyond a tripole fold those are the mirrored velocities with the sign of a
   // vector, so the N-face mirror of VTN with that sign is the same number (the two products are added in the other order);
   // the degenerate top row stays as computed (location 4: N face, ghost rows only).
   if (halo_update_many(c, {{c->lw.UTE, km, 3, 1}, {c->lw.VTN, km, 4, 1}, {c->lw.WTKB, km}})) return 1;
   const dim3 G3((c->g.n2 + 255) / 256, km, c->g.nblocks * 2);
-  hipLaunchKernelGGL(k_lw_z, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
-  hipLaunchKernelGGL(k_lw_x, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
-  hipLaunchKernelGGL(k_lw_y, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+  if (c->g.pbc) {
+    hipLaunchKernelGGL(k_lw_z<true>, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+    hipLaunchKernelGGL(k_lw_x<true>, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+    hipLaunchKernelGGL(k_lw_y<true>, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+  } else {
+    hipLaunchKernelGGL(k_lw_z<false>, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+    hipLaunchKernelGGL(k_lw_x<false>, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+    hipLaunchKernelGGL(k_lw_y<false>, G3, dim3(256), 0, c->stream, c->g, c->lw, X0, X1, c->c2dtt);
+  }
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -14,10 +14,15 @@ pytestmark = pytest.mark.gpu
 DEL4 = {"hmix_momentum": 4, "hmix_tracer": 4, "lvariable_hmix": 1, "am": -1.0e22, "ah": -1.0e21}
 
 
-def _run(pkg, cfg, grid, nsteps):
+def _run(pkg, cfg, grid, nsteps, calm=False):
     gpu, orc = pkg.PopModel(cfg, grid=grid), Oracle(cfg, grid=grid)
     for n in (0, 1):
         assert np.array_equal(gpu.get("TRACER", 1, n), orc.f3("TRACER", 1, n))
+    if calm:   # lw_lim across a fold: see test_gpu_parity.py::test_grid_input_step_phases_match_oracle
+        z = np.zeros_like(gpu.get("SMF", n=0))
+        for n in (0, 1):
+            gpu.set("SMF", z, n=n); gpu.set("SMFT", z, n=n)
+            orc.f2("SMF", 1, n)[...] = 0.0; orc.f2("SMFT", 1, n)[...] = 0.0
     if cfg.vmix_choice == 3:
         force_kpp_case(gpu, orc)
     tol = TOL_LOCAL
@@ -41,6 +46,11 @@ def _run(pkg, cfg, grid, nsteps):
     ("tiny", {"stepped_bathymetry": 1, "tmix_opt": 3, "solver_choice": 3}, 4),       # Robert filter, P-CSI
     ("tiny", {"stepped_bathymetry": 1, "km": 60, "vmix_choice": 3}, 3),              # production level count
     ("tiny", {}, 3),                                                                 # flat bottom with a partial bottom level
+    ("tiny", {"stepped_bathymetry": 1, "vmix_choice": 2}, 5),                        # Richardson mixing (vmix_rich.F90:266-312)
+    ("tiny", dict(DEL4, stepped_bathymetry=1, vmix_choice=2, tadvect=2, km=24), 4),
+    ("tiny", {"stepped_bathymetry": 1, "tadvect": 3}, 5),                            # lw_lim (advection.F90:2757-3140)
+    ("tiny", dict(DEL4, stepped_bathymetry=1, tadvect=3, vmix_choice=3, km=24), 4),
+    ("tiny", {"stepped_bathymetry": 1, "tadvect": 3, "block_size_x": 48, "block_size_y": 40}, 4),   # one block
     ("test", {"stepped_bathymetry": 1, "vmix_choice": 1}, 4),                        # 96 blocks
     ("gx3v7", {"stepped_bathymetry": 1}, 3),
 ])
@@ -64,6 +74,8 @@ def test_partial_bottom_cells_step_phases_match_oracle(pkg, orclib_built, name, 
     ({"ns_boundary": 2, "block_size_x": 48, "block_size_y": 40, "tadvect": 2}, 4),
     ({"ns_boundary": 0, "ew_boundary": 0, "vmix_choice": 3, "km": 24}, 3),           # closed boundaries
     ({"ns_boundary": 1}, 3),
+    ({"ns_boundary": 2, "tadvect": 3}, 4),                                           # lw_lim through a tripole fold
+    ({"ns_boundary": 0, "ew_boundary": 0, "tadvect": 3, "vmix_choice": 2}, 4),
 ])
 def test_partial_bottom_cells_on_a_caller_grid(pkg, orclib_built, kw, nsteps):
     """the production route: horiz_grid_file / topography_file / bottom_cell_file records (pop_create_with_grid), stepped KMT and a
@@ -71,15 +83,17 @@ def test_partial_bottom_cells_on_a_caller_grid(pkg, orclib_built, kw, nsteps):
     cfg = named_config("tiny", partial_bottom_cells=1, **kw)
     grid = synthetic_grid(cfg)
     grid["DZBC"] = synthetic_dzbc(cfg, grid["KMT"])
-    _run(pkg, cfg, grid, nsteps)
+    _run(pkg, cfg, grid, nsteps, calm=(kw.get("tadvect") == 3 and kw.get("ns_boundary") == 2))
 
 
-def test_bottom_cells_of_full_thickness_change_nothing_physical(pkg, orclib_built):
+@pytest.mark.parametrize("vmix,tadvect", [(1, 1), (2, 1), (1, 3)])
+def test_bottom_cells_of_full_thickness_change_nothing_physical(pkg, orclib_built, vmix, tadvect):
     """DZBC = dz(KMT) everywhere is the full-cell geometry written through the partial-bottom-cell formulas: the two runs agree
     to rounding (the formulas divide by thicknesses where the full-cell ones multiply by reciprocals), not bitwise.  Constant
     vertical mixing: the partial-bottom-cell branches of KPP are not a generalisation of the full-cell ones (e.g. the bulk
-    Richardson number measures depth from zt(1) instead of from half the surface-layer thickness, vmix_kpp.F90:2561-2575)."""
-    kw = {"stepped_bathymetry": 1, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21}
+    Richardson number measures depth from zt(1) instead of from half the surface-layer thickness, vmix_kpp.F90:2561-2575);
+    Richardson mixing is (vmix_rich.F90:266-312: the shear over the U-cell spacing, averaged, against the difference of averages)."""
+    kw = {"stepped_bathymetry": 1, "hmix_momentum": 4, "hmix_tracer": 4, "am": -1.0e22, "ah": -1.0e21, "vmix_choice": vmix, "tadvect": tadvect}
     cfg = named_config("tiny", partial_bottom_cells=1, ns_boundary=1, **kw)
     ref = named_config("tiny", ns_boundary=1, **kw)
     grid = synthetic_grid(cfg)
@@ -97,12 +111,43 @@ def test_bottom_cells_of_full_thickness_change_nothing_physical(pkg, orclib_buil
 
 
 def test_partial_bottom_cells_refusals(pkg):
-    for kw, word in (({"vmix_choice": 2}, "Richardson"), ({"tadvect": 3}, "lw_lim"), ({"vmix_choice": 3, "kpp_diagnostics": 1}, "HMXL")):
-        with pytest.raises(pkg.PopError, match=word):
-            pkg.PopModel(named_config("tiny", partial_bottom_cells=1, **kw), host_only=True)
+    """a topography record without the record of bottom_cell_file is refused (every scheme of the path is built with partial bottom
+    cells: Richardson mixing, lw_lim advection and the mixed-layer diagnostics since round 3)"""
+    cfg = named_config("tiny", partial_bottom_cells=1)
+    grid = synthetic_grid(cfg)
+    with pytest.raises(pkg.PopError, match="DZBC"):
+        pkg.PopModel(cfg, grid=grid, host_only=True)
 
 
-@pytest.mark.parametrize("kw", [{"tadvect": 1}, {"tadvect": 2, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21}, {"vmix_choice": 3, "km": 20}])
+@pytest.mark.parametrize("kw", [{"km": 24}, {"km": 24, "ldbl_diff": 1, "ns_boundary": 2}])
+def test_mixed_layer_depth_diagnostic_with_partial_bottom_cells(pkg, orclib_built, kw):
+    """HMXL with partial bottom cells (vmix_kpp.F90:1326-1356: depths and spacings from the cell thicknesses) on a caller's grid
+    with a random bottom thickness: every cell against the oracle, and different from the full-cell diagnostic in the columns
+    whose maximum gradient sits at the bottom cell"""
+    cfg = named_config("tiny", partial_bottom_cells=1, vmix_choice=3, kpp_diagnostics=1, **kw)
+    grid = synthetic_grid(cfg)
+    grid["DZBC"] = synthetic_dzbc(cfg, grid["KMT"])
+    gpu, orc = pkg.PopModel(cfg, grid=grid), Oracle(cfg, grid=grid)
+    force_kpp_case(gpu, orc)
+    tol = TOL_LOCAL
+    for s in range(1, 4):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+        for f in ("HMXL", "HMXL_DR"):
+            a, b = gpu.get(f), orc.f2(f)
+            assert np.abs(b).max() > 1.0e3 and len(np.unique(np.round(b, 3))) > 20, f + ": trivial field"
+            assert relerr(a, b) <= tol * 100, "%s step %d: %g" % (f, s, relerr(a, b))
+    full = pkg.PopModel(named_config("tiny", vmix_choice=3, kpp_diagnostics=1, **kw), grid={k: v for k, v in grid.items() if k != "DZBC"})
+    o2 = Oracle(named_config("tiny", vmix_choice=3, kpp_diagnostics=1, **kw), grid={k: v for k, v in grid.items() if k != "DZBC"})
+    force_kpp_case(full, o2); o2.close()
+    for _ in range(3):
+        full.step()
+    assert np.abs(full.get("HMXL") - gpu.get("HMXL")).max() > 1.0     # cm
+    gpu.close(); orc.close(); full.close()
+
+
+@pytest.mark.parametrize("kw", [{"tadvect": 1}, {"tadvect": 2, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21}, {"vmix_choice": 3, "km": 20},
+                                {"tadvect": 3}, {"tadvect": 3, "vmix_choice": 2}])
 def test_tracer_content_is_conserved_with_partial_bottom_cells(pkg, kw):
     """What the flux form must do on the device, whatever the thicknesses: with no surface flux the volume integral of a tracer --
     the bottom cell of every column counted with ITS thickness DZBC, the surface layer with dz(1) + eta -- is unchanged to
