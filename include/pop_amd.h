@@ -142,6 +142,8 @@ typedef struct pop_tuning {
   int pbc_generic_thomas;  /* 1: partial bottom cells with the scratch-staged Thomas kernels even at km = 60 / 62 */
   int pbc_generic_kpp;     /* 1: partial bottom cells with the 3-D-parallel / scratch-staged KPP kernels on large grids too */
   int stream_priority;     /* 1: the launch stream above the gap-filling side streams (default 0: measured slower) */
+  int state3d_levels;      /* density of a whole 3-D array: levels per thread, 4 (default) | 2 | 8 with the per-level EOS coefficients read from
+                            * a table, 1 = one cell per thread with the coefficients formed in place */
 } pop_tuning;
 void pop_tuning_init(pop_tuning *t);   /* struct_bytes = sizeof, every field POP_TUNING_UNSET */
 int pop_get_tuning(const pop_ctx *ctx, pop_tuning *resolved);   /* fields still POP_TUNING_UNSET: the size rule applied */

@@ -45,6 +45,8 @@ struct DevGrid {
   int n2;                                          // nxb*nyb
   long long n3;                                    // n2*km
   CArr dz, dzw, zt, zw, c2dz, dzr, dz2r, dzwr, pressz, bouss, afac_t, afac_u;   // vertical arrays: scalar loads (ConstArr)
+  CArr eosP;                                       // 6 (km + 2): the pressure-dependent MWJF coefficients of every level, formed on the device by mwjf_level itself (k_eos_level_table)
+  int state_lv;                                    // k_state3d: levels per thread (0 / 1: one cell per thread with the coefficients formed in place)
   const double *DXU, *DYU, *DXUR, *DYUR, *UAREA_R, *TAREA_R, *TAREA, *FCOR, *FCORT, *HU, *HUR;
   const double *AU0, *AUN, *AUE, *AUNE, *RCALCT;
   const int *KMT, *KMU, *KMTN, *KMTS, *KMTE, *KMTW, *KMTEE, *KMTNN;

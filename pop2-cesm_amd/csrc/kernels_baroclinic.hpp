@@ -54,6 +54,50 @@ __global__ void k_state3d(DevGrid g, const double *__restrict__ T, const double 
   RHO[o] = mwjf_rho<false>(P, T[o], S[o], nullptr, nullptr);
 }
 
+// The pressure-dependent coefficients of every level as a table (6 doubles per level, slot 0 unused), formed by mwjf_level on
+// the device so that a kernel reading them (scalar loads) holds the bits a kernel forming them in place holds.
+__global__ void k_eos_level_table(DevGrid g, double *__restrict__ tab) {
+  const int k = threadIdx.x;
+  if (k < 1 || k > g.km) return;
+  const MwjfP P = mwjf_level(g.pressz[k]);
+  double *t = tab + 6 * k;
+  t[0] = P.n0; t[1] = P.n2; t[2] = P.ns1t0; t[3] = P.d0; t[4] = P.d1; t[5] = P.d3;
+}
+// LK levels of one (i,j) per thread (round 3): k_state3d above spends a quarter of its vector instructions on the level's
+// coefficients (one cell per lane to amortise them over) and as many scalar instructions as vector ones on its addressing; here
+// the coefficients come from the table through scalar loads, the land test and the addressing are shared by LK cells and the
+// 2 LK operand loads are in flight together.  Same operations per cell: bitwise k_state3d (tests/test_gpu_parity.py).
+template <int LK>
+__global__ void __launch_bounds__(256)
+k_state3d_lv(DevGrid g, const double *__restrict__ T, const double *__restrict__ S, double *__restrict__ RHO) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k0 = blockIdx.y * LK + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  if (land_run(g, b, (long long)blockIdx.x * blockDim.x, blockDim.x)) return;
+  const long long n2 = g.n2, o = (long long)b * g.n3 + (long long)(k0 - 1) * n2 + p2;
+  double t[LK], s[LK];
+#pragma unroll
+  for (int u = 0; u < LK; ++u) {
+    const bool in = k0 + u <= g.km;                                   // block-uniform
+    t[u] = in ? T[o + u * n2] : 0.0; s[u] = in ? S[o + u * n2] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < LK; ++u) {
+    if (k0 + u > g.km) break;
+    const int e = 6 * (k0 + u);
+    MwjfP P;
+    P.n0 = g.eosP[e]; P.n2 = g.eosP[e + 1]; P.ns1t0 = g.eosP[e + 2]; P.d0 = g.eosP[e + 3]; P.d1 = g.eosP[e + 4]; P.d3 = g.eosP[e + 5];
+    RHO[o + u * n2] = mwjf_rho<false>(P, t[u], s[u], nullptr, nullptr);
+  }
+}
+inline void launch_state3d(const DevGrid &g, const double *T, const double *S, double *RHO, hipStream_t st) {
+  const unsigned gx = (g.n2 + 255) / 256;
+  if (g.state_lv == 4 && g.eosP) hipLaunchKernelGGL(k_state3d_lv<4>, dim3(gx, (g.km + 3) / 4, g.nblocks), dim3(256), 0, st, g, T, S, RHO);
+  else if (g.state_lv == 2 && g.eosP) hipLaunchKernelGGL(k_state3d_lv<2>, dim3(gx, (g.km + 1) / 2, g.nblocks), dim3(256), 0, st, g, T, S, RHO);
+  else if (g.state_lv == 8 && g.eosP) hipLaunchKernelGGL(k_state3d_lv<8>, dim3(gx, (g.km + 7) / 8, g.nblocks), dim3(256), 0, st, g, T, S, RHO);
+  else hipLaunchKernelGGL(k_state3d, dim3(gx, g.km, g.nblocks), dim3(256), 0, st, g, T, S, RHO);
+}
+
 // ------------------------------------------------------------------------------------------
 // vmix_coeffs_const with convection_type='diffusion' (vmix_const.F90:205-228).  3-D parallel.
 // VDC is stored (nxb,nyb,0:km+1,block); VVC (nxb,nyb,km,block).

@@ -305,7 +305,7 @@ inline void launch_impvmixt(const DevGrid &g, const StepParams &sp, const Impvmi
       }
     } else if (g.km == 60) hipLaunchKernelGGL((k_impvmixt_reg<60, MODE, PRE, POST, true>), G2, B, 0, st, g, sp, a);
     else hipLaunchKernelGGL((k_impvmixt_reg<62, MODE, PRE, POST, true>), G2, B, 0, st, g, sp, a);
-    if (POST) hipLaunchKernelGGL(k_state3d, dim3((g.n2 + 255) / 256, g.km, g.nblocks), dim3(256), 0, st, g, (const double *)a.TNEW[0], (const double *)a.TNEW[1], a.RHO);
+    if (POST) launch_state3d(g, a.TNEW[0], a.TNEW[1], a.RHO, st);
     return;
   }
   const bool pair = MODE == 1 && allow_reg && (g.km == 60 || g.km == 62) && a.nfirst == 1 && a.nlast == 2 && a.VDC[0] == a.VDC[1] &&
@@ -315,12 +315,12 @@ inline void launch_impvmixt(const DevGrid &g, const StepParams &sp, const Impvmi
       if (g.km == 60) hipLaunchKernelGGL((k_impvmixt2_reg<60, MODE, PRE, POST>), G, B, 0, st, g, sp, a);
       else hipLaunchKernelGGL((k_impvmixt2_reg<62, MODE, PRE, POST>), G, B, 0, st, g, sp, a);
     }
-    if (POST) hipLaunchKernelGGL(k_state3d, dim3((g.n2 + 255) / 256, g.km, g.nblocks), dim3(256), 0, st, g, (const double *)a.TNEW[0], (const double *)a.TNEW[1], a.RHO);
+    if (POST) launch_state3d(g, a.TNEW[0], a.TNEW[1], a.RHO, st);
   } else if (allow_reg && (g.km == 60 || g.km == 62)) {
     if (g.km == 60) hipLaunchKernelGGL((k_impvmixt_reg<60, MODE, PRE, POST>), G2, B, 0, st, g, sp, a);
     else hipLaunchKernelGGL((k_impvmixt_reg<62, MODE, PRE, POST>), G2, B, 0, st, g, sp, a);
     // the density of the finished tracers (baroclinic.F90:1468-1475) as its own 3-D-parallel pass
-    if (POST) hipLaunchKernelGGL(k_state3d, dim3((g.n2 + 255) / 256, g.km, g.nblocks), dim3(256), 0, st, g, (const double *)a.TNEW[0], (const double *)a.TNEW[1], a.RHO);
+    if (POST) launch_state3d(g, a.TNEW[0], a.TNEW[1], a.RHO, st);
   } else hipLaunchKernelGGL((k_impvmixt<MODE, PRE, POST>), G, B, 0, st, g, sp, a);
 }
 inline void launch_impvmixu(const DevGrid &g, const StepParams &sp, const ImpvmixuArgs &a, dim3 G, hipStream_t st, bool allow_reg) {

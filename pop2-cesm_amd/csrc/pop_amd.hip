@@ -1255,7 +1255,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -1398,6 +1398,16 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       {&g.dz, &h.dz}, {&g.dzw, &h.dzw}, {&g.zt, &h.zt}, {&g.zw, &h.zw}, {&g.c2dz, &h.c2dz}, {&g.dzr, &h.dzr}, {&g.dz2r, &h.dz2r},
       {&g.dzwr, &h.dzwr}, {&g.pressz, &h.pressz}, {&g.bouss, &h.bouss}, {&g.afac_t, &h.afac_t}, {&g.afac_u, &h.afac_u}};
     for (auto &v : V) { double *p; if (dev_upload(c, &p, v.src->data(), v.src->size())) return 1; *v.dst = p; }
+    // per-level MWJF coefficients (k_state3d_lv): formed on the device
+    if (g.km + 1 <= 1024) {
+      double *p = nullptr;
+      std::vector<double> z((size_t)6 * (g.km + 2), 0.0);
+      if (dev_upload(c, &p, z.data(), z.size())) return 1;
+      hipLaunchKernelGGL(k_eos_level_table, dim3(1), dim3(g.km + 1), 0, 0, g, p);
+      HIPCHK(c, hipDeviceSynchronize());
+      g.eosP = p;
+    }
+    g.state_lv = tun_or(h.tun.state3d_levels, 4);
   }
   // 2-D fields: upload the local blocks of every host field
   for (auto &kv : h.f2) {
@@ -1818,8 +1828,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     HIPCHK(c, hipMemcpy(c->TR[0][t], h.f3["TEMP0"].data(), a3 * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->TR[1][t], h.f3["SALT0"].data(), a3 * sizeof(double), hipMemcpyHostToDevice));
   }
-  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->curt], c->TR[1][c->curt], c->RHO[c->curt]);
-  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->oldt], c->TR[1][c->oldt], c->RHO[c->oldt]);
+  launch_state3d(c->g, c->TR[0][c->curt], c->TR[1][c->curt], c->RHO[c->curt], c->stream);
+  launch_state3d(c->g, c->TR[0][c->oldt], c->TR[1][c->oldt], c->RHO[c->oldt], c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   h.f3.clear();
   return 0;
@@ -2120,8 +2130,8 @@ int pop_read_restart(pop_ctx *c, const char *path, int flags) {
   for (bool &b : c->tr_ghosts_ok) b = false;
   for (bool &b : c->uv_ghosts_ok) b = false;
   // init_ts :1665-1681: density of both time levels from the tracers just read
-  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->curt], c->TR[1][c->curt], c->RHO[c->curt]);
-  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->oldt], c->TR[1][c->oldt], c->RHO[c->oldt]);
+  launch_state3d(c->g, c->TR[0][c->curt], c->TR[1][c->curt], c->RHO[c->curt], c->stream);
+  launch_state3d(c->g, c->TR[0][c->oldt], c->TR[1][c->oldt], c->RHO[c->oldt], c->stream);
   HIPCHK(c, hipGetLastError());
   // scalars: initial.F90:1088 first_step = .false.; time_management.F90:1426 nsteps_this_interval = 0 unless the file says otherwise
   std::map<std::string, std::string> &g = sec["GLOBAL"];
@@ -2340,7 +2350,7 @@ static int phase_impvmixt_pred(pop_ctx *c) {
   return 0;
 }
 static int phase_state_new(pop_ctx *c) {
-  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, c->TR[0][c->newt], c->TR[1][c->newt], c->RHO[c->newt]);
+  launch_state3d(c->g, c->TR[0][c->newt], c->TR[1][c->newt], c->RHO[c->newt], c->stream);
   return 0;
 }
 // density of the new tracers on the rows j_first <= j < j_end (0-based) of every block
@@ -2679,8 +2689,8 @@ static int step_rf(pop_ctx *c) {
                        c->TR[n][cu], c->TR[n][nw]);
   }
   HIPCHK(c, hipMemcpyAsync(c->FW_OLD, c->FW, a2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, (const double *)c->TR[0][cu], (const double *)c->TR[1][cu], c->RHO[cu]);
-  hipLaunchKernelGGL(k_state3d, grid_3d(c), dim3(256), 0, c->stream, c->g, (const double *)c->TR[0][nw], (const double *)c->TR[1][nw], c->RHO[nw]);
+  launch_state3d(c->g, (const double *)c->TR[0][cu], (const double *)c->TR[1][cu], c->RHO[cu], c->stream);
+  launch_state3d(c->g, (const double *)c->TR[0][nw], (const double *)c->TR[1][nw], c->RHO[nw], c->stream);
   hipLaunchKernelGGL(k_pguess, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, a2, c->PGUESS, c->PS[nw], c->PS[cu], c->PS[o]);
   c->oldt = cu; c->curt = nw; c->newt = o;                              // step_mod.F90:1318-1322
   if (!h.rf_nonzero_newtime) for (int n = 0; n < nt; ++n) { c->rf_S_prev[n] = c->rf_S[n]; c->rf_S_prev_valid[n] = true; }

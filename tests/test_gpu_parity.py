@@ -684,6 +684,27 @@ def test_two_tracer_corrector_solve_is_bitwise_invisible(pkg, monkeypatch, kw):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kw", [{"km": 62, "vmix_choice": 3, "stepped_bathymetry": 1}, {"km": 21, "tmix_opt": 3}, {"km": 20, "ns_boundary": 1}])
+def test_density_kernels_agree_bitwise(pkg, monkeypatch, kw):
+    """k_state3d_lv: the density of a whole 3-D array with 2 / 4 / 8 levels per thread and the level's pressure-dependent coefficients
+    read from a table the device formed with mwjf_level itself, against one cell per thread with the coefficients formed in place
+    (level counts that are and are not multiples of the levels per thread; the Robert filter's two evaluations included)."""
+    cfg = named_config("tiny", **kw)
+    out = {}
+    for lv in ("1", "2", "4", "8"):
+        monkeypatch.setenv("POP_STATE3D_LEVELS", lv)
+        m = pkg.PopModel(cfg)
+        assert m.tuning()["state3d_levels"] == int(lv)
+        for _ in range(4):
+            m.step()
+        out[lv] = [m.get("RHO", tl, 0).copy() for tl in (0, 1, 2)] + [m.get(n, 1, 0).copy() for n in ("TRACER", "UVEL", "PSURF")]
+        m.close()
+    assert np.abs(out["1"][1]).max() > 1.0
+    for lv in ("2", "4", "8"):
+        for a, b in zip(out["1"], out[lv]):
+            assert np.array_equal(a, b), lv
+
+
 def test_del4_first_laplacian_patch_shapes_agree_bitwise(pkg, monkeypatch):
     """The first Laplacians of del4 (k_del4_d2t / k_del4_d2u) and KPP's viscosity average to U points (k_kpp_vvc) run over 256
     consecutive cells or over 64 x R patches (large grids: R = 4); the cell -> thread map is all that changes."""
