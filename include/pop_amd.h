@@ -38,7 +38,9 @@ typedef struct pop_config {
   int ew_boundary;            /* 0 closed, 1 cyclic   (domain.F90 ew_boundary_type) */
   int ns_boundary;            /* 0 closed, 1 cyclic, 2 tripole (time stepping: with pop_create_with_grid) */
   int hmix_momentum;          /* 2 del2, 4 del4       (horizontal_mix.F90:427-472) */
-  int hmix_tracer;            /* 2 del2, 4 del4 */
+  int hmix_tracer;            /* 2 del2, 4 del4, 3 gm: Gent-McWilliams eddy transport + isopycnal (Redi) diffusion with ah as the isopycnal
+                               * diffusivity (hmix_gm.F90:1102-2226 in the code-default hmix_gm_nml: constant kappa, kappa_freq 'never',
+                               * no transition layer; see gm_slope_control, ah_bolus ... below) */
   int lvariable_hmix;         /* hmix_del2.F90:223, hmix_del4.F90:200 */
   int vmix_choice;            /* 1 const, 2 rich, 3 kpp (vertical_mix.F90:280-296) */
   int tadvect;                /* 1 centered, 2 upwind3, 3 lw_lim (advection.F90:1667-1729, 2313-2676, 2684-3280) */
@@ -70,7 +72,8 @@ typedef struct pop_config {
   int partial_bottom_cells;   /* grid_nml partial_bottom_cells (grid.F90:916-1020): 1 = the bottom T cell of every column has the
                                * thickness DZBC (pop_grid_input.DZBC = the record of bottom_cell_file; NULL with the internal
                                * topography: a synthetic DZBC in (0.25, 1] dz(KMT), TEST EXTENSION), DZT / DZU as the reference forms them */
-  int reserved_i[3];          /* must be 0 */
+  int gm_slope_control;       /* hmix_gm_nml slope_control_choice: 0 'notanh' (the default, hmix_gm.F90:1508-1539), 1 'tanh' (:1490-1506) */
+  int reserved_i[2];          /* must be 0 */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;
@@ -81,7 +84,10 @@ typedef struct pop_config {
   double init_ts_perturbation;           /* amplitude of the synthetic initial T perturbation (1e-2) */
   double robert_alpha, robert_nu;        /* tmix_opt = 3 (0 = defaults 0.53, 0.20, time_management.F90:461-462) */
   double lanczos_convergence_criterion;  /* PCSI LanczosconvergenceCriterion (0 = 0.1) */
-  double reserved_d[4];                  /* must be 0 */
+  /* hmix_gm_nml (hmix_gm.F90:364-428); each 0 = the value that makes the default set-up: */
+  double ah_bolus;                       /* thickness (bolus) diffusivity, 0 = ah (then the skew-flux terms cancel, 'cancellation_occurs' :970-983) */
+  double ah_bkg_srfbl;                   /* horizontal diffusivity inside the surface boundary layer, 0 = ah */
+  double slm_r, slm_b;                   /* maximum slope for isopycnal / thickness diffusion, 0 = 0.3 */
 } pop_config;
 
 typedef struct pop_ctx pop_ctx;
@@ -275,7 +281,7 @@ int pop_solver_run(pop_ctx *ctx);
  * centre weight of local block blockIndx (1-based) = time-independent part - correction (host array) */
 int pop_solver_diagonal(pop_ctx *ctx, int block_local, const double *diagonal_correction);
 /* preconditioner(PX, X, bid) :2268-2369 on every local block: PX = M^-1 X on the physical cells.  M is the EVP
- * block preconditioner (8x8 sub-block solves, :2434-2696; preconditionerChoice = 'evp') when reserved_i[2] = 1,
+ * block preconditioner (8x8 sub-block solves, :2434-2696; preconditionerChoice = 'evp') when preconditioner_choice = 1,
  * else the diagonal (current centre weight).  Private in the reference; exported so that parity tests can pin the
  * preconditioner on its own.  x_name / px_name: 2-D device fields (time level tl where it applies). */
 int pop_solver_preconditioner(pop_ctx *ctx, const char *x_name, int x_tl, const char *px_name, int px_tl);

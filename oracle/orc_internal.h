@@ -54,6 +54,7 @@ struct orc_model {
   void *del4;
   void *upw3;
   void *lwlim;                /* orc_lwlim.inc (tadvect = 3) */
+  void *gm;                   /* orc_gm.inc (hmix_tracer = 3) */
   void *sw;                   /* short-wave absorption tables (orc_kpp.inc: orc_sw) */
   void *rf;
   void *pcsi;

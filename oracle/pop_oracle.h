@@ -51,7 +51,8 @@ typedef struct {
   int kpp_ml_diagnostics;
   int sw_absorption_type, jerlov_water_type, lsw_absorb;
   int partial_bottom_cells;   /* grid.F90:916-1020 */
-  int reserved_i[3];
+  int gm_slope_control;       /* hmix_tracer = 3 (gm): 0 notanh, 1 tanh */
+  int reserved_i[2];
   double am, ah;              /* del2 or del4 coefficients */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;
@@ -60,7 +61,7 @@ typedef struct {
   double Prandtl, kpp_rich_mix;
   double convergence_criterion;
   double init_ts_perturbation, robert_alpha, robert_nu, lanczos_convergence_criterion;
-  double reserved_d[4];
+  double ah_bolus, ah_bkg_srfbl, slm_r, slm_b;   /* hmix_gm_nml; 0 = ah, ah, 0.3, 0.3 */
 } orc_config;
 
 typedef struct orc_model orc_model;

@@ -32,7 +32,8 @@
       integer (c_int) :: kpp_ml_diagnostics = 0                            ! HMXL, HMXL_DR every step
       integer (c_int) :: sw_absorption_type = 0, jerlov_water_type = 0, lsw_absorb = 0   ! sw_absorption_nml
       integer (c_int) :: partial_bottom_cells = 0                          ! grid_nml
-      integer (c_int) :: reserved_i(3) = 0
+      integer (c_int) :: gm_slope_control = 0                              ! hmix_gm_nml slope_control_choice: 0 'notanh', 1 'tanh' (hmix_tracer = 3)
+      integer (c_int) :: reserved_i(2) = 0
       real (c_double) :: am, ah
       real (c_double) :: const_vvc, const_vdc
       real (c_double) :: convect_diff, convect_visc, bottom_drag, aidif
@@ -43,7 +44,8 @@
       real (c_double) :: init_ts_perturbation = 0.0_c_double
       real (c_double) :: robert_alpha = 0.0_c_double, robert_nu = 0.0_c_double
       real (c_double) :: lanczos_convergence_criterion = 0.0_c_double
-      real (c_double) :: reserved_d(4) = 0.0_c_double
+      real (c_double) :: ah_bolus = 0.0_c_double, ah_bkg_srfbl = 0.0_c_double   ! hmix_gm_nml; 0 = ah
+      real (c_double) :: slm_r = 0.0_c_double, slm_b = 0.0_c_double             ! hmix_gm_nml; 0 = 0.3
    end type pop_config
 
    ! mirrors `struct pop_grid_input`: the records of horiz_grid_file / topography_file (grid.F90:1314-1542, 2025-2107)

@@ -24,7 +24,7 @@ class PopConfig(C.Structure):
         ("stepped_bathymetry", C.c_int), ("distribution_type", C.c_int), ("kpp_ml_diagnostics", C.c_int),
         ("sw_absorption_type", C.c_int), ("jerlov_water_type", C.c_int), ("lsw_absorb", C.c_int),
         ("partial_bottom_cells", C.c_int),
-        ("reserved_i", C.c_int * 3),
+        ("gm_slope_control", C.c_int), ("reserved_i", C.c_int * 2),
         ("am", C.c_double), ("ah", C.c_double),
         ("const_vvc", C.c_double), ("const_vdc", C.c_double),
         ("convect_diff", C.c_double), ("convect_visc", C.c_double), ("bottom_drag", C.c_double),
@@ -35,7 +35,7 @@ class PopConfig(C.Structure):
         ("convergence_criterion", C.c_double),
         ("init_ts_perturbation", C.c_double), ("robert_alpha", C.c_double), ("robert_nu", C.c_double),
         ("lanczos_convergence_criterion", C.c_double),
-        ("reserved_d", C.c_double * 4),
+        ("ah_bolus", C.c_double), ("ah_bkg_srfbl", C.c_double), ("slm_r", C.c_double), ("slm_b", C.c_double),
     ]
 
 
