@@ -507,6 +507,17 @@ int host_build(HostModel &h) {
     h.uarea_equator = amin;
   }
 
+  if (c.hmix_tracer == 3) {   // Gent-McWilliams (init_meso_mixing, hmix_gm_submeso_share.F90:131-137; init_gm, hmix_gm.F90:889-894)
+    auto &GHYX = newf("gmHYX"), &GHXY = newf("gmHXY"), &GRBR = newf("gmRBR");
+    for (size_t p = 0; p < A2; ++p) {
+      GHYX[p] = HTE[p] / HUS[p];
+      GHXY[p] = HTN[p] / HUW[p];
+      double r = std::fabs(FCORT[p]) / 200.0;          // |f| / Cg, Cg = 200 cm/s
+      r = std::min(r, 1.0 / 1.5e+6);                   // Rossby radius >= 15 km
+      r = std::max(r, 1.e-7);                          //               <= 100 km
+      GRBR[p] = r;
+    }
+  }
   // ---------------- del2 operator weights, metric advection coefficients ----------------
   auto &AMF = newf("AMF"), &AHF = newf("AHF");
   for (size_t p = 0; p < A2; ++p) { AMF[p] = 1.0; AHF[p] = 1.0; }

@@ -1,0 +1,204 @@
+// kernels_gm.hpp -- Gent-McWilliams eddy transport + isopycnal (Redi) diffusion of tracers, hmix_tracer = 3
+// (source/hmix_gm.F90:1102-2226 hdifft_gm, hmix_gm_submeso_share.F90:149-432 tracer_diffs_and_isopyc_slopes, init_gm :283-1095) in the
+// set-up the code's own hmix_gm_nml defaults give: constant kappa (KAPPA_VERTICAL = 1), kappa_freq 'never', no transition layer,
+// use_const_ah_bkg_srfbl, ah_bkg_bottom = 0, slope control 'notanh' | 'tanh'; ah_bolus /= ah or slm_b /= slm_r take the branch
+// without cancellation of the skew-flux terms.  Bolus-velocity diagnostics are not formed.
+//
+// The reference works level by level and carries whole-block work arrays (TX, TY, TZ, RX, RY, SF_SLX, SF_SLY, FZTOP) from level to
+// level; here every value is a function of the mix-time tracers at the cell and its neighbours one level up / down, so three
+// 3-D-parallel launches form the same numbers:
+//   k_gm_coeffs   per (i,j,k): the slopes SLX, SLY of the four quarter cells of each half (top / bottom) of the T cell, the tapering
+//                 factors, and the tapered KAPPA_ISOP, KAPPA_THIC, HOR_DIFF of both halves (14 stored 3-D fields);
+//   k_gm_vdc      the isopycnal part of the vertical diffusivity added to VDC(k) (:1725-1748), every cell of the block;
+//   k_gm_flux     per physical cell and tracer: the fluxes through its six faces (east / north of the cell and of its west / south
+//                 neighbour recomputed, the flux through the top face = the bottom-face flux of the level above) -> GTK, which the
+//                 tracer right-hand side reads in place of forming del2 mixing (k_tracer_rhs<DEL4 = true>).
+// Correctness first (the production grids of this scheme are the 1-degree ones); same operations in the reference's order per value.
+#pragma once
+#include "kernels_common.hpp"
+
+namespace pop {
+
+struct GmDev {
+  double *SLX[4], *SLY[4];          // [face * 2 + half]: face 0 east / north, 1 west / south; half 0 top (ktp), 1 bottom (kbt)
+  double *KI[2], *KT[2], *HD[2];    // KAPPA_ISOP, KAPPA_THIC, HOR_DIFF of the two halves
+  double *GTK[2];
+  const double *HYX, *HXY, *RBR, *DXT, *DYT, *HBLT;   // HBLT: nullptr without KPP (BL_DEPTH = zw(1))
+  double ah, ah_bolus, ah_bkg_srfbl, slm_r, slm_b;
+  int diff_tapering, cancellation, slope_tanh;
+};
+
+// tapering factor of DM95 / its polynomial stand-in (:1490-1539)
+__device__ __forceinline__ double gm_taper23(double sla, double slm, int slope_tanh) {
+  if (slope_tanh) return (sla < slm) ? 0.5 * (1.0 - tanh(10.0 * sla / slm - 4.0)) : 0.0;
+  double t = 1.0;
+  if (sla > 0.2 * slm && sla < 0.6 * slm) t = 0.5 * (1.0 - (2.5 * sla / slm - 1.0) * (4.0 - fabs(10.0 * sla / slm - 4.0)));
+  else if (sla >= 0.6 * slm) t = 0.0;
+  return t;
+}
+
+__global__ void __launch_bounds__(256)
+k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__restrict__ S) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int kk = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  const int nxb = g.nxb, nyb = g.nyb, km = g.km, i = p2 % nxb, j = p2 / nxb;
+  const long long n2 = g.n2, q = (long long)b * n2 + p2, o = (long long)b * g.n3 + (long long)(kk - 1) * n2 + p2;
+  const int kmt = g.KMT[q];
+  auto temp = [&](long long oo) { return fmax(-2.0, T[oo]); };
+  // horizontal differences of level kk on the east / north face of cell d (0: this cell, -1 / -nxb: west / south neighbour)
+  auto kmaske = [&](long long d) { return (kk <= g.KMT[q + d] && kk <= g.KMT[q + d + 1]) ? 1.0 : 0.0; };
+  auto kmaskn = [&](long long d) { return (kk <= g.KMT[q + d] && kk <= g.KMT[q + d + nxb]) ? 1.0 : 0.0; };
+  double txp_e = 0.0, txs_e = 0.0, txp_w = 0.0, txs_w = 0.0, typ_n = 0.0, tys_n = 0.0, typ_s = 0.0, tys_s = 0.0;
+  if (i <= nxb - 2) { const double mk = kmaske(0); txp_e = mk * (temp(o + 1) - temp(o)); txs_e = mk * (S[o + 1] - S[o]); }
+  if (i >= 1) { const double mk = kmaske(-1); txp_w = mk * (temp(o) - temp(o - 1)); txs_w = mk * (S[o] - S[o - 1]); }
+  if (j <= nyb - 2) { const double mk = kmaskn(0); typ_n = mk * (temp(o + nxb) - temp(o)); tys_n = mk * (S[o + nxb] - S[o]); }
+  if (j >= 1) { const double mk = kmaskn(-nxb); typ_s = mk * (temp(o) - temp(o - nxb)); tys_s = mk * (S[o] - S[o - nxb]); }
+  double drdt, drds;
+  const MwjfP P = mwjf_level(g.pressz[kk]);
+  mwjf_rho<true>(P, T[o], S[o], &drdt, &drds);
+  const double rxe = drdt * txp_e + drds * txs_e, rxw = (i >= 1) ? drdt * txp_w + drds * txs_w : 0.0;
+  const double ryn = drdt * typ_n + drds * tys_n, rys = (j >= 1) ? drdt * typ_s + drds * tys_s : 0.0;
+  double sl[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};   // [half][xe, xw, yn, ys]
+  if (kk >= 2 && kk <= kmt) {       // top half: the vertical difference to the level above, with this level's expansion coefficients (share :383-400)
+    double rz = drdt * (temp(o - n2) - temp(o)) + drds * (S[o - n2] - S[o]);
+    rz = fmin(rz, -1.0e-20);
+    sl[0][0] = rxe / rz; sl[0][1] = rxw / rz; sl[0][2] = ryn / rz; sl[0][3] = rys / rz;
+  }
+  if (kk < km) {                    // bottom half: the difference to the level below (share :278-291)
+    double rz = drdt * (temp(o) - temp(o + n2)) + drds * (S[o] - S[o + n2]);
+    rz = fmin(rz, -1.0e-20);
+    const double mk = (kk < kmt) ? 1.0 : 0.0;
+    sl[1][0] = mk * rxe / rz; sl[1][1] = mk * rxw / rz; sl[1][2] = mk * ryn / rz; sl[1][3] = mk * rys / rz;
+  }
+  const double dxt = w.DXT[q], dyt = w.DYT[q], rbr = w.RBR[q];
+  const double bl = w.HBLT ? w.HBLT[q] : g.zw[1];
+  const double dz_bottom = (kk == 1) ? 0.0 : g.zt[kk - 1];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int kid = kk + s - 1;
+    const double sla = g.dzw[kid] * sqrt(0.5 * ((sl[s][0] * sl[s][0] + sl[s][1] * sl[s][1]) / (dxt * dxt) + (sl[s][2] * sl[s][2] + sl[s][3] * sl[s][3]) / (dyt * dyt))) + 1.0e-10;
+    const double w1 = fmin(1.0, g.zt[kk] * rbr / sla);
+    const double t1f = w.slope_tanh ? 0.5 * (1.0 + sin(3.14159265358979323846 * (w1 - 0.5))) : (0.5 + 2.0 * (w1 - 0.5) * (1.0 - fabs(w1 - 0.5)));
+    const double taper1 = (dz_bottom <= bl) ? t1f : 1.0;
+    const double taper2 = gm_taper23(sla, w.slm_r, w.slope_tanh);
+    const double taper3 = w.diff_tapering ? gm_taper23(sla, w.slm_b, w.slope_tanh) : taper2;
+    double hd = (dz_bottom <= bl) ? w.ah_bkg_srfbl * (1.0 - taper1 * taper2) * 1.0 : 0.0;
+    double ki = taper1 * taper2 * w.ah, kt = taper1 * taper3 * w.ah_bolus;
+    if (kk == 1 && s == 0) { hd = w.ah_bkg_srfbl; ki = 0.0; kt = 0.0; }   // :1208, :1663-1664
+    if (s == 1 && kk == kmt) { ki = 0.0; kt = 0.0; }                       // :1654-1657
+    w.KI[s][o] = ki; w.KT[s][o] = kt; w.HD[s][o] = hd;
+    w.SLX[0 + s][o] = sl[s][0]; w.SLX[2 + s][o] = sl[s][1]; w.SLY[0 + s][o] = sl[s][2]; w.SLY[2 + s][o] = sl[s][3];
+  }
+}
+
+// VDC(k) += the isopycnal part (:1725-1748); VDCn: the one or two diffusivity arrays (nxb,nyb,0:km+1,block)
+__global__ void __launch_bounds__(256)
+k_gm_vdc(DevGrid g, GmDev w, double *__restrict__ VDC0, double *__restrict__ VDC1) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2 || k >= g.km) return;
+  const int nxb = g.nxb, i = p2 % nxb, j = p2 / nxb;
+  const long long n2 = g.n2, q = (long long)b * n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * n2 + p2, ok = o + n2;
+  const double kmask = (k < g.KMT[q]) ? 1.0 : 0.0;
+  const double hyx = w.HYX[q], hxy = w.HXY[q], hyxw = (i >= 1) ? w.HYX[q - 1] : 0.0, hxys = (j >= 1) ? w.HXY[q - nxb] : 0.0;
+  auto sq = [](double x) { return x * x; };
+  const double add = g.dzw[k] * kmask * g.TAREA_R[q] *
+    (g.dz[k] * 0.25 * w.KI[1][o] * (hyx * sq(w.SLX[1][o]) + hyxw * sq(w.SLX[3][o]) + hxy * sq(w.SLY[1][o]) + hxys * sq(w.SLY[3][o])) +
+     g.dz[k + 1] * 0.25 * w.KI[0][ok] * (hyx * sq(w.SLX[0][ok]) + hyxw * sq(w.SLX[2][ok]) + hxy * sq(w.SLY[0][ok]) + hxys * sq(w.SLY[2][ok])));
+  const long long v = ((long long)b * (g.km + 2) + k) * n2 + p2;
+  VDC0[v] = VDC0[v] + add;
+  if (VDC1) VDC1[v] = VDC1[v] + add;
+}
+
+// horizontal differences of tracer X at level kk (TX, TY of the reference) on the east / north face of 2-D cell q (3-D index o)
+__device__ __forceinline__ double gm_tx(const DevGrid &g, const double *__restrict__ X, int kk, long long q, long long o) {
+  return ((kk <= g.KMT[q] && kk <= g.KMT[q + 1]) ? 1.0 : 0.0) * (X[o + 1] - X[o]);
+}
+__device__ __forceinline__ double gm_ty(const DevGrid &g, const double *__restrict__ X, int kk, long long q, long long o) {
+  return ((kk <= g.KMT[q] && kk <= g.KMT[q + g.nxb]) ? 1.0 : 0.0) * (X[o + g.nxb] - X[o]);
+}
+// TZ(kk) = X(kk-1) - X(kk), 0 at kk = 1 (never assigned in the reference)
+__device__ __forceinline__ double gm_tz(const DevGrid &g, const double *__restrict__ X, int kk, long long o) { return (kk >= 2) ? X[o - g.n2] - X[o] : 0.0; }
+// SF_SLX / SF_SLY (:1680-1700) of cell q at level kk: KAPPA_THIC * slope * dz where kk <= KMT, else 0
+__device__ __forceinline__ double gm_sf(const DevGrid &g, const double *__restrict__ KT, const double *__restrict__ SL, int kk, long long q, long long o) {
+  return (kk <= g.KMT[q]) ? KT[o] * SL[o] * g.dz[kk] : 0.0;
+}
+// flux through the east face of cell q at level k (:1827, :1832-1868); the caller guarantees i <= nxb - 2
+__device__ __forceinline__ double gm_fx(const DevGrid &g, const GmDev &w, const double *__restrict__ X, int k, long long q, long long o) {
+  const int km = g.km;
+  const double cx = (k <= g.KMT[q] && k <= g.KMT[q + 1]) ? w.HYX[q] * 0.25 : 0.0;
+  const double work3 = w.KI[0][o] + w.HD[0][o] + w.KI[1][o] + w.HD[1][o] + w.KI[0][o + 1] + w.HD[0][o + 1] + w.KI[1][o + 1] + w.HD[1][o + 1];
+  double fx = g.dz[k] * cx * gm_tx(g, X, k, q, o) * work3;
+  if (!w.cancellation) {
+    const int kp1 = (k == km) ? k : k + 1;
+    const long long okp = o + (long long)(kp1 - k) * g.n2;
+    const double w1 = w.KI[0][o] * w.SLX[0][o] * g.dz[k] - gm_sf(g, w.KT[0], w.SLX[0], k, q, o);
+    const double w2 = w.KI[1][o] * w.SLX[1][o] * g.dz[k] - gm_sf(g, w.KT[1], w.SLX[1], k, q, o);
+    const double w3 = w.KI[0][o + 1] * w.SLX[2][o + 1] * g.dz[k] - gm_sf(g, w.KT[0], w.SLX[2], k, q + 1, o + 1);
+    const double w4 = w.KI[1][o + 1] * w.SLX[3][o + 1] * g.dz[k] - gm_sf(g, w.KT[1], w.SLX[3], k, q + 1, o + 1);
+    fx = fx - cx * (w1 * gm_tz(g, X, k, o) + w2 * gm_tz(g, X, kp1, okp) + w3 * gm_tz(g, X, k, o + 1) + w4 * gm_tz(g, X, kp1, okp + 1));
+  }
+  return fx;
+}
+__device__ __forceinline__ double gm_fy(const DevGrid &g, const GmDev &w, const double *__restrict__ X, int k, long long q, long long o) {
+  const int km = g.km, nxb = g.nxb;
+  const double cy = (k <= g.KMT[q] && k <= g.KMT[q + nxb]) ? w.HXY[q] * 0.25 : 0.0;
+  const double work4 = w.KI[0][o] + w.HD[0][o] + w.KI[1][o] + w.HD[1][o] + w.KI[0][o + nxb] + w.HD[0][o + nxb] + w.KI[1][o + nxb] + w.HD[1][o + nxb];
+  double fy = g.dz[k] * cy * gm_ty(g, X, k, q, o) * work4;
+  if (!w.cancellation) {
+    const int kp1 = (k == km) ? k : k + 1;
+    const long long okp = o + (long long)(kp1 - k) * g.n2;
+    const double w1 = w.KI[0][o] * w.SLY[0][o] * g.dz[k] - gm_sf(g, w.KT[0], w.SLY[0], k, q, o);
+    const double w2 = w.KI[1][o] * w.SLY[1][o] * g.dz[k] - gm_sf(g, w.KT[1], w.SLY[1], k, q, o);
+    const double w3 = w.KI[0][o + nxb] * w.SLY[2][o + nxb] * g.dz[k] - gm_sf(g, w.KT[0], w.SLY[2], k, q + nxb, o + nxb);
+    const double w4 = w.KI[1][o + nxb] * w.SLY[3][o + nxb] * g.dz[k] - gm_sf(g, w.KT[1], w.SLY[3], k, q + nxb, o + nxb);
+    fy = fy - cy * (w1 * gm_tz(g, X, k, o) + w2 * gm_tz(g, X, kp1, okp) + w3 * gm_tz(g, X, k, o + nxb) + w4 * gm_tz(g, X, kp1, okp + nxb));
+  }
+  return fy;
+}
+// flux through the bottom face of level k < km of physical cell q (:1910-2050)
+__device__ __forceinline__ double gm_fz(const DevGrid &g, const GmDev &w, const double *__restrict__ X, int k, long long q, long long o) {
+  const int nxb = g.nxb, kp1 = k + 1;
+  const long long okp = o + g.n2;
+  const double kmask = (k < g.KMT[q]) ? 1.0 : 0.0;
+  const double hyx = w.HYX[q], hxy = w.HXY[q], hyxw = w.HYX[q - 1], hxys = w.HXY[q - nxb];
+  // east, north, west, south terms of one half cell at level kk (3-D index oo): coefficient * metric * horizontal difference
+  auto faces = [&](double ce, double cn, double cw, double cs, int kk, long long oo) {
+    return ce * hyx * gm_tx(g, X, kk, q, oo) + cn * hxy * gm_ty(g, X, kk, q, oo) + cw * hyxw * gm_tx(g, X, kk, q - 1, oo - 1) + cs * hxys * gm_ty(g, X, kk, q - nxb, oo - nxb);
+  };
+  if (!w.cancellation) {
+    double w3 = 0.0;
+    w3 = w3 + (g.dz[k] * w.KI[1][o] * faces(w.SLX[1][o], w.SLY[1][o], w.SLX[3][o], w.SLY[3][o], k, o));
+    w3 = w3 + faces(gm_sf(g, w.KT[1], w.SLX[1], k, q, o), gm_sf(g, w.KT[1], w.SLY[1], k, q, o), gm_sf(g, w.KT[1], w.SLX[3], k, q, o), gm_sf(g, w.KT[1], w.SLY[3], k, q, o), k, o);
+    w3 = w3 + (g.dz[kp1] * w.KI[0][okp] * faces(w.SLX[0][okp], w.SLY[0][okp], w.SLX[2][okp], w.SLY[2][okp], kp1, okp));
+    w3 = w3 + (1.0 * faces(gm_sf(g, w.KT[0], w.SLX[0], kp1, q, okp), gm_sf(g, w.KT[0], w.SLY[0], kp1, q, okp), gm_sf(g, w.KT[0], w.SLX[2], kp1, q, okp), gm_sf(g, w.KT[0], w.SLY[2], kp1, q, okp), kp1, okp));
+    return -kmask * 0.25 * w3;
+  }
+  double w3 = (g.dz[k] * w.KI[1][o] * faces(w.SLX[1][o], w.SLY[1][o], w.SLX[3][o], w.SLY[3][o], k, o));
+  w3 = w3 + (g.dz[kp1] * w.KI[0][okp] * faces(w.SLX[0][okp], w.SLY[0][okp], w.SLX[2][okp], w.SLY[2][okp], kp1, okp));
+  return -kmask * 0.5 * w3;
+}
+
+__global__ void __launch_bounds__(256)
+k_gm_flux(DevGrid g, GmDev w, const double *__restrict__ X0, const double *__restrict__ X1) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.y + 1, b = blockIdx.z >> 1, n = blockIdx.z & 1;
+  if (p2 >= g.n2) return;
+  const int nxb = g.nxb, i = p2 % nxb, j = p2 / nxb, km = g.km;
+  const long long n2 = g.n2, q = (long long)b * n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * n2 + p2;
+  const double *__restrict__ X = n ? X1 : X0;
+  double gt = 0.0;
+  if (i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b)) {
+    const double fxe = gm_fx(g, w, X, k, q, o), fxw = gm_fx(g, w, X, k, q - 1, o - 1);
+    const double fyn = gm_fy(g, w, X, k, q, o), fys = gm_fy(g, w, X, k, q - nxb, o - nxb);
+    const double fztop = (k >= 2) ? gm_fz(g, w, X, k - 1, q, o - n2) : 0.0;
+    if (k < km) {
+      const double fz = gm_fz(g, w, X, k, q, o);
+      gt = (fxe - fxw + fyn - fys + fztop - fz) * g.dzr[k] * g.TAREA_R[q];
+    } else gt = (fxe - fxw + fyn - fys + fztop) * g.dzr[k] * g.TAREA_R[q];
+  }
+  w.GTK[n][o] = gt;
+}
+
+}  // namespace pop

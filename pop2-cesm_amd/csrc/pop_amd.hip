@@ -15,6 +15,7 @@
 #include "kernels_pcsi.hpp"
 #include "kernels_evp.hpp"
 #include "kernels_lwlim.hpp"
+#include "kernels_gm.hpp"
 #include <fcntl.h>
 #include <unistd.h>
 #include "rccl_transport.hpp"
@@ -137,6 +138,7 @@ struct pop_ctx {
   double rf_S[MAXNT] = {}, rf_S_prev[MAXNT] = {}; bool rf_S_prev_valid[MAXNT] = {};   // Robert filter
   Upw3Dev upw3{};                                          // tadvect = 2
   LwDev lw{};                                              // tadvect = 3 (lw_lim): flux-velocity and work fields
+  GmDev gm{};                                              // hmix_tracer = 3 (gm): slopes, tapered diffusivities, GTK
   RcclTransport *rccl_tr = nullptr;                       // in-library RCCL transport (pop_comm_init_rccl)
   // time stepping
   int oldt = 0, curt = 1, newt = 2, mixt = 1;
@@ -1545,6 +1547,23 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->lw.HTE = c->d2["HTE"]; c->lw.HTN = c->d2["HTN"]; c->lw.DXT = c->d2["DXT"]; c->lw.DYT = c->d2["DYT"];
     if (!c->lw.HTE || !c->lw.HTN || !c->lw.DXT || !c->lw.DYT) { c->err = "lw_lim: grid fields HTE / HTN / DXT / DYT missing"; return 1; }
   }
+  if (cfg->hmix_tracer == 3) {   // Gent-McWilliams: 14 coefficient fields + the tendency of each tracer
+    const size_t a3g = h.n3 * h.nblocks;
+    GmDev &G = c->gm;
+    for (int t = 0; t < 4; ++t) if (dev_alloc(c, &G.SLX[t], a3g) || dev_alloc(c, &G.SLY[t], a3g)) return 1;
+    for (int t = 0; t < 2; ++t) if (dev_alloc(c, &G.KI[t], a3g) || dev_alloc(c, &G.KT[t], a3g) || dev_alloc(c, &G.HD[t], a3g) || dev_alloc(c, &G.GTK[t], a3g)) return 1;
+    G.HYX = c->d2["gmHYX"]; G.HXY = c->d2["gmHXY"]; G.RBR = c->d2["gmRBR"]; G.DXT = c->d2["DXT"]; G.DYT = c->d2["DYT"];
+    if (!G.HYX || !G.HXY || !G.RBR || !G.DXT || !G.DYT) { c->err = "gm: grid fields missing"; return 1; }
+    // hmix_gm_nml (hmix_gm.F90:364-428); 0 = the value of the default set-up
+    G.ah = cfg->ah;
+    G.ah_bolus = (cfg->ah_bolus != 0.0) ? cfg->ah_bolus : cfg->ah;
+    G.ah_bkg_srfbl = (cfg->ah_bkg_srfbl != 0.0) ? cfg->ah_bkg_srfbl : cfg->ah;
+    G.slm_r = (cfg->slm_r != 0.0) ? cfg->slm_r : 0.3;
+    G.slm_b = (cfg->slm_b != 0.0) ? cfg->slm_b : 0.3;
+    G.slope_tanh = cfg->gm_slope_control == 1;
+    G.diff_tapering = G.slm_r != G.slm_b;                              // :964-968
+    G.cancellation = !(G.diff_tapering || G.ah != G.ah_bolus);         // :970-983 (both kappa types 'constant')
+  }
 #define GI(f) g.f = c->di2[#f]
   GI(KMT); GI(KMU); GI(KMTN); GI(KMTS); GI(KMTE); GI(KMTW); GI(KMTEE); GI(KMTNN);
 #undef GI
@@ -1812,6 +1831,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
   // KPP look-ahead (bandwidth-bound grids; POP_KPP_AHEAD=0|1 overrides): second set of KPP outputs, own stream
   c->ahead_enabled = cfg->vmix_choice == 3 && c->side && (h.n2 * h.nblocks > (1u << 19));
   if (tun_set(h.tun.kpp_ahead)) c->ahead_enabled = cfg->vmix_choice == 3 && c->side && h.tun.kpp_ahead != 0;
+  if (cfg->hmix_tracer == 3) c->ahead_enabled = false;   // Gent-McWilliams adds to VDC after vmix_coeffs: the coefficients are formed in line
   if (c->ahead_enabled) {
     for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->KPPa[n], a3)) return 1;
     if (dev_alloc(c, &c->VDCa[0], (size_t)(h.km + 2) * a2)) return 1;
@@ -2246,7 +2266,23 @@ static int kpp_look_ahead(pop_ctx *c) {
   c->ahead_valid = true; c->ahead_slot = c->curt;
   return 0;
 }
-static int phase_hmix_tracer(pop_ctx *c, hipStream_t st = nullptr) {   // del4 only: first Laplacian of the tracers into d2t
+// hmix_tracer = 3 (horizontal_mix.F90:549-554, hmix_gm.F90:1102-2226): slopes and tapered diffusivities of the mix-time tracers, the
+// isopycnal part added to VDC (after vmix_coeffs, before the tracer right-hand side reads it), and the tendency GTK of both tracers
+static int phase_hmix_gm(pop_ctx *c) {
+  const double *T = c->TR[0][c->mixt], *S = c->TR[1][c->mixt];
+  GmDev G = c->gm;
+  G.HBLT = (c->h.c.vmix_choice == 3) ? c->HBLT : nullptr;            // BL_DEPTH = KPP_HBLT | zw(1) (:1210-1212)
+  const dim3 G3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks), G3n(G3.x, G3.y, c->g.nblocks * 2);
+  hipLaunchKernelGGL(k_gm_coeffs, G3, dim3(256), 0, c->stream, c->g, G, T, S);
+  const StepParams sp = step_params(c);
+  double *v1 = (sp.nvdc == 2 && c->VDC[1] != c->VDC[0]) ? c->VDC[1] : nullptr;   // one shared array is added to once
+  hipLaunchKernelGGL(k_gm_vdc, G3, dim3(256), 0, c->stream, c->g, G, c->VDC[0], v1);
+  hipLaunchKernelGGL(k_gm_flux, G3n, dim3(256), 0, c->stream, c->g, G, T, S);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+static int phase_hmix_tracer(pop_ctx *c, hipStream_t st = nullptr) {   // del4: first Laplacian of the tracers into d2t; gm: the whole tendency
+  if (c->h.c.hmix_tracer == 3) return phase_hmix_gm(c);
   if (c->h.c.hmix_tracer != 4) return 0;
   if (c->d2t_next_valid && c->d2t_next_slot == c->mixt) {   // formed by the previous step's tracer kernel (ghost ring already updated)
     c->d2t_next_valid = false;
@@ -2302,7 +2338,7 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   }
   // the next step's first Laplacian: valid when that step is a leapfrog step whose mix time is this step's current time and nothing
   // rewrites the current tracers before then (no averaging step, no Robert filter) -- the rule of the KPP look-ahead
-  const bool lds_kernel = c->h.c.tadvect == 1 && (c->trc_lds_rows == 8 || c->trc_lds_rows == 4);
+  const bool lds_kernel = c->h.c.tadvect == 1 && c->h.c.hmix_tracer != 3 && (c->trc_lds_rows == 8 || c->trc_lds_rows == 4);
   const bool form_next = lds_kernel && c->d2t_next[0] && !c->avg_ts && c->h.c.tmix_opt != 3 && c->tr_ghosts_ok[c->curt];
   if (form_next) { a.D2N[0] = c->d2t_next[0]; a.D2N[1] = c->d2t_next[1]; a.AHF = c->mix.D4AHF; }
   c->d2t_last_formed = form_next;
@@ -2315,6 +2351,16 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
     return 0;
   }
   if (fwd) { c->err = "fused forward elimination needs the LDS tracer kernel"; return 1; }
+  if (c->h.c.hmix_tracer == 3) {   // Gent-McWilliams: the tendency formed by phase_hmix_gm in place of del2 mixing
+    a.HDT[0] = c->gm.GTK[0]; a.HDT[1] = c->gm.GTK[1];
+    if (c->h.c.tadvect == 2) {
+      a.up = c->upw3;
+      if (c->g.pbc) hipLaunchKernelGGL((k_tracer_rhs<true, true, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+      else hipLaunchKernelGGL((k_tracer_rhs<true, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+    } else if (c->g.pbc) hipLaunchKernelGGL((k_tracer_rhs<true, false, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+    else hipLaunchKernelGGL((k_tracer_rhs<true, false>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
+    return 0;
+  }
   if (c->h.c.tadvect == 2) {
     a.up = c->upw3;
     if (c->g.pbc) hipLaunchKernelGGL((k_tracer_rhs<false, true, true>), grid_stencil(c), block_stencil(), 0, c->stream, c->g, sp, a);
@@ -2334,7 +2380,7 @@ static ImpvmixtArgs impvmixt_args(pop_ctx *c, const double *psfc) {
 // predictor with the forward elimination inside the right-hand-side kernel: bandwidth-bound grids, centred advection
 // through the LDS kernel, generic (scratch-staged) solve -- POP_TRACER_FWD=0|1 overrides
 static bool tracer_fwd_fused(const pop_ctx *c) {
-  const bool can = c->h.c.tadvect == 1 && (c->trc_lds_rows == 4 || c->trc_lds_rows == 8) && c->h.c.lpressure_avg && c->leapfrogts;
+  const bool can = c->h.c.tadvect == 1 && c->h.c.hmix_tracer != 3 && (c->trc_lds_rows == 4 || c->trc_lds_rows == 8) && c->h.c.lpressure_avg && c->leapfrogts;
   if (tun_set(c->h.tun.tracer_fwd)) return can && c->h.tun.tracer_fwd != 0;
   return can && !c->reg_thomas_t;
 }
@@ -2427,14 +2473,16 @@ int pop_baroclinic_driver(pop_ctx *c) {
   if (fork) {   // del4 first Laplacians beside the vertical-mixing coefficients
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    if (phase_hmix_tracer(c, c->side)) return 1;
+    if (c->h.c.hmix_tracer != 3 && phase_hmix_tracer(c, c->side)) return 1;
     HIPCHK(c, hipEventRecord(c->ev_d2t, c->side));
     if (phase_hmix_momentum(c, c->side)) return 1;
     HIPCHK(c, hipEventRecord(c->ev_d2u, c->side));
   }
   if (phase_vmix(c)) return 1;
-  if (fork) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2t, 0));
-  else if (phase_hmix_tracer(c)) return 1;
+  if (fork) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2t, 0));
+    if (c->h.c.hmix_tracer == 3 && phase_hmix_tracer(c)) return 1;   // Gent-McWilliams reads and adds to the coefficients vmix just formed
+  } else if (phase_hmix_tracer(c)) return 1;
   const bool fwd = sp.pavg && tracer_fwd_fused(c);
   if (phase_tracer_rhs(c, fwd)) return 1;
   // several ranks: the exchange of the new tracers' ghost rows runs on the communication stream while the launch stream

@@ -1,0 +1,117 @@
+"""Gent-McWilliams eddy transport + isopycnal diffusion of tracers (hmix_tracer = 3: hmix_gm.F90:1102-2226,
+hmix_gm_submeso_share.F90:149-432) through the C ABI against the CPU oracle, phase by phase, and by properties that do not
+involve the oracle."""
+import numpy as np
+import pytest
+
+from popcfg import named_config, synthetic_grid
+from orclib import Oracle
+from test_gpu_parity import run_phases, force_kpp_case, relerr, pick, TOL_LOCAL, TOL_SOLVE
+
+pytestmark = pytest.mark.gpu
+
+GM = {"hmix_tracer": 3, "ah": 0.8e7}
+
+
+def _steep(gpu, orc):
+    """a front: isopycnal slopes from gentle to beyond the tapering limits, so every branch of the slope control is taken"""
+    tlat = orc.f2("TLAT")
+    for tl in (0, 1, 2):
+        T = orc.f3("TRACER", tl, 0)
+        z = np.arange(T.shape[1])[None, :, None, None]
+        T[...] = T + 6.0 * np.tanh(8.0 * (tlat[:, None] - 0.3)) * np.exp(-z / 6.0) + 2.0 * np.sin(5.0 * tlat[:, None]) * np.exp(-z / 3.0)
+        gpu.set("TRACER", T, tl=tl, n=0)
+
+
+@pytest.mark.parametrize("name,kw,nsteps", [
+    ("tiny", {}, 5),                                                                  # const vmix, 16 blocks; skew-flux terms cancel
+    ("tiny", {"ah_bolus": 0.4e7}, 5),                                                 # ... do not cancel
+    ("tiny", {"slm_b": 0.2, "gm_slope_control": 1, "stepped_bathymetry": 1}, 4),      # tanh tapering, different limits for the two diffusivities
+    ("tiny", {"vmix_choice": 3, "km": 24, "stepped_bathymetry": 1}, 5),               # KPP: boundary-layer depth from HBLT, shared diffusivity array
+    ("tiny", {"vmix_choice": 3, "km": 24, "ldbl_diff": 1, "ah_bolus": 1.2e7}, 4),     # two diffusivity arrays
+    ("tiny", {"vmix_choice": 2, "tadvect": 2, "ah_bkg_srfbl": 0.3e7}, 4),             # Richardson, upwind3
+    ("tiny", {"tadvect": 3, "block_size_x": 48, "block_size_y": 40}, 4),              # lw_lim, one block
+    ("tiny", {"hmix_momentum": 4, "am": -1.0e22, "stepped_bathymetry": 1}, 4),        # del4 momentum beside it (side stream)
+    ("tiny", {"tmix_opt": 3, "solver_choice": 2}, 4),                                 # Robert filter
+    ("tiny", {"km": 60, "vmix_choice": 3}, 3),                                        # production level count (register Thomas kernels)
+    ("tiny", {"partial_bottom_cells": 1, "stepped_bathymetry": 1}, 3),                # the scheme has no partial-cell branches: dz(k) throughout
+    ("test", {"stepped_bathymetry": 1}, 3),                                           # 96 blocks
+    ("gx3v7", {"vmix_choice": 3}, 3),
+])
+def test_gm_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
+    cfg = named_config(name, **dict(GM, **kw))
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
+    _steep(gpu, orc)
+    tol = TOL_LOCAL
+    for s in range(1, nsteps + 1):
+        run_phases(gpu, orc, s, tol)
+        a, b = gpu.get("VDC", n=0), orc.vdc(0)          # with the isopycnal part added (hmix_gm.F90:1725-1748)
+        assert relerr(pick(gpu, a, True), pick(gpu, b, True)) <= max(tol, TOL_LOCAL) * 10, "step %d VDC" % s
+        tol = TOL_SOLVE
+    # the front is steep enough for the tapering to act and gentle enough elsewhere for the isopycnal part to be there
+    vd = orc.vdc(0).copy()
+    gpu.close(); orc.close()
+    if cfg.vmix_choice == 1:
+        assert (vd > 10.0 * cfg.const_vdc).sum() > 50 and (vd == cfg.const_vdc).sum() > 50
+
+
+@pytest.mark.parametrize("kw", [{"ns_boundary": 2}, {"ns_boundary": 2, "vmix_choice": 3, "km": 24, "ah_bolus": 0.5e7}, {"ns_boundary": 0, "ew_boundary": 0}])
+def test_gm_on_a_caller_grid(pkg, orclib_built, kw):
+    """tripole fold and closed boundaries on a grid supplied by the caller (the scheme exchanges nothing: everything is formed from the
+    mix-time tracers' own ghost cells)"""
+    cfg = named_config("tiny", **dict(GM, **kw))
+    grid = synthetic_grid(cfg)
+    gpu, orc = pkg.PopModel(cfg, grid=grid), Oracle(cfg, grid=grid)
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
+    tol = TOL_LOCAL
+    for s in range(1, 5):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+    gpu.close(); orc.close()
+
+
+@pytest.mark.parametrize("kw", [{}, {"ah_bolus": 0.3e7, "slm_b": 0.2}, {"vmix_choice": 3, "km": 20, "tadvect": 2}])
+def test_gm_conserves_tracer_content(pkg, kw):
+    """every term is a flux form -- east / north fluxes shared by neighbours, the flux through the bottom face of a level is the one
+    through the top face of the next, the isopycnal addition to VDC goes through the (conservative) implicit solve: with no surface
+    flux the volume integral of a tracer does not change (surface layer weighted with its actual thickness)"""
+    cfg = named_config("tiny", stepped_bathymetry=1, **dict(GM, **kw))
+    m = pkg.PopModel(cfg)
+    o = Oracle(cfg)
+    dz = o.v1("dz")[1:cfg.km + 1].copy()
+    o.close()
+    tarea, kmt = m.get("TAREA"), m.geti("KMT")
+    k = np.arange(1, cfg.km + 1)[None, :, None, None]
+    wet = (k <= kmt[:, None])[..., 2:-2, 2:-2]
+
+    def content(n):
+        T = m.get("TRACER", 1, n)[..., 2:-2, 2:-2]
+        eta = m.get("PSURF", 1)[..., 2:-2, 2:-2] / 980.6
+        thick = np.broadcast_to(dz[None, :, None, None], T.shape).copy()
+        thick[:, 0] = thick[:, 0] + eta
+        return float((np.where(wet, T * thick, 0.0) * tarea[:, None, 2:-2, 2:-2]).sum())
+
+    for _ in range(3):
+        m.step()
+    c0 = [content(n) for n in (0, 1)]
+    for _ in range(4):
+        m.step()
+    for n in (0, 1):
+        assert abs(content(n) - c0[n]) <= 2e-9 * abs(c0[n]), (kw, n)
+    m.close()
+
+
+def test_gm_leaves_level_isopycnals_alone(pkg):
+    """T(z), S(z) at rest: no slope, no flux, nothing added to VDC -- the first step gives bit for bit the tracers and the
+    diffusivity of del2 mixing, which has nothing to mix either"""
+    out = {}
+    for hm in (2, 3):
+        m = pkg.PopModel(named_config("tiny", hmix_tracer=hm, ah=0.8e7, stepped_bathymetry=1, init_ts_perturbation=0.0))
+        m.step()
+        out[hm] = [m.get("TRACER", 1, n).copy() for n in (0, 1)] + [m.get("VDC", n=0).copy()]
+        m.close()
+    for a, b in zip(out[2], out[3]):
+        assert np.array_equal(a, b)
