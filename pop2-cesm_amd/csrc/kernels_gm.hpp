@@ -5,12 +5,12 @@
 // without cancellation of the skew-flux terms.  Bolus-velocity diagnostics are not formed.
 //
 // The reference works level by level and carries whole-block work arrays (TX, TY, TZ, RX, RY, SF_SLX, SF_SLY, FZTOP) from level to
-// level; here every value is a function of the mix-time tracers at the cell and its neighbours one level up / down, so three
+// level; here every value is a function of the mix-time tracers at the cell and its neighbours one level up / down, so two
 // 3-D-parallel launches form the same numbers:
 //   k_gm_coeffs   per (i,j,k): the slopes SLX, SLY of the four quarter cells of each half (top / bottom) of the T cell, the tapering
 //                 factors, and the tapered KAPPA_ISOP, KAPPA_THIC, HOR_DIFF of both halves (14 stored 3-D fields);
-//   k_gm_vdc      the isopycnal part of the vertical diffusivity added to VDC(k) (:1725-1748), every cell of the block;
-//   k_gm_flux     per physical cell and tracer: the fluxes through its six faces (east / north of the cell and of its west / south
+//   k_gm_flux     the isopycnal part of the vertical diffusivity added to VDC(k) (:1725-1748) at every cell of the block, and per
+//                 physical cell, both tracers together: the fluxes through its six faces (east / north of the cell and of its west / south
 //                 neighbour recomputed, the flux through the top face = the bottom-face flux of the level above) -> GTK, which the
 //                 tracer right-hand side reads in place of forming del2 mixing (k_tracer_rhs<DEL4 = true>).
 // Correctness first (the production grids of this scheme are the 1-degree ones); same operations in the reference's order per value.
@@ -92,25 +92,6 @@ k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__re
   }
 }
 
-// VDC(k) += the isopycnal part (:1725-1748); VDCn: the one or two diffusivity arrays (nxb,nyb,0:km+1,block)
-__global__ void __launch_bounds__(256)
-k_gm_vdc(DevGrid g, GmDev w, double *__restrict__ VDC0, double *__restrict__ VDC1) {
-  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y + 1, b = blockIdx.z;
-  if (p2 >= g.n2 || k >= g.km) return;
-  const int nxb = g.nxb, i = p2 % nxb, j = p2 / nxb;
-  const long long n2 = g.n2, q = (long long)b * n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * n2 + p2, ok = o + n2;
-  const double kmask = (k < g.KMT[q]) ? 1.0 : 0.0;
-  const double hyx = w.HYX[q], hxy = w.HXY[q], hyxw = (i >= 1) ? w.HYX[q - 1] : 0.0, hxys = (j >= 1) ? w.HXY[q - nxb] : 0.0;
-  auto sq = [](double x) { return x * x; };
-  const double add = g.dzw[k] * kmask * g.TAREA_R[q] *
-    (g.dz[k] * 0.25 * w.KI[1][o] * (hyx * sq(w.SLX[1][o]) + hyxw * sq(w.SLX[3][o]) + hxy * sq(w.SLY[1][o]) + hxys * sq(w.SLY[3][o])) +
-     g.dz[k + 1] * 0.25 * w.KI[0][ok] * (hyx * sq(w.SLX[0][ok]) + hyxw * sq(w.SLX[2][ok]) + hxy * sq(w.SLY[0][ok]) + hxys * sq(w.SLY[2][ok])));
-  const long long v = ((long long)b * (g.km + 2) + k) * n2 + p2;
-  VDC0[v] = VDC0[v] + add;
-  if (VDC1) VDC1[v] = VDC1[v] + add;
-}
-
 // horizontal differences of tracer X at level kk (TX, TY of the reference) on the east / north face of 2-D cell q (3-D index o)
 __device__ __forceinline__ double gm_tx(const DevGrid &g, const double *__restrict__ X, int kk, long long q, long long o) {
   return ((kk <= g.KMT[q] && kk <= g.KMT[q + 1]) ? 1.0 : 0.0) * (X[o + 1] - X[o]);
@@ -124,12 +105,15 @@ __device__ __forceinline__ double gm_tz(const DevGrid &g, const double *__restri
 __device__ __forceinline__ double gm_sf(const DevGrid &g, const double *__restrict__ KT, const double *__restrict__ SL, int kk, long long q, long long o) {
   return (kk <= g.KMT[q]) ? KT[o] * SL[o] * g.dz[kk] : 0.0;
 }
+// Both tracers of the path go through every flux function together: the coefficients (diffusivities, slopes, masks, metrics) are
+// loaded and combined once, the tracer differences enter linearly -- per tracer the operations and their order are the reference's.
+struct Gm2 { double a, b; };
 // flux through the east face of cell q at level k (:1827, :1832-1868); the caller guarantees i <= nxb - 2
-__device__ __forceinline__ double gm_fx(const DevGrid &g, const GmDev &w, const double *__restrict__ X, int k, long long q, long long o) {
+__device__ __forceinline__ Gm2 gm_fx(const DevGrid &g, const GmDev &w, const double *__restrict__ X0, const double *__restrict__ X1, int k, long long q, long long o) {
   const int km = g.km;
   const double cx = (k <= g.KMT[q] && k <= g.KMT[q + 1]) ? w.HYX[q] * 0.25 : 0.0;
   const double work3 = w.KI[0][o] + w.HD[0][o] + w.KI[1][o] + w.HD[1][o] + w.KI[0][o + 1] + w.HD[0][o + 1] + w.KI[1][o + 1] + w.HD[1][o + 1];
-  double fx = g.dz[k] * cx * gm_tx(g, X, k, q, o) * work3;
+  Gm2 f = {g.dz[k] * cx * gm_tx(g, X0, k, q, o) * work3, g.dz[k] * cx * gm_tx(g, X1, k, q, o) * work3};
   if (!w.cancellation) {
     const int kp1 = (k == km) ? k : k + 1;
     const long long okp = o + (long long)(kp1 - k) * g.n2;
@@ -137,15 +121,16 @@ __device__ __forceinline__ double gm_fx(const DevGrid &g, const GmDev &w, const 
     const double w2 = w.KI[1][o] * w.SLX[1][o] * g.dz[k] - gm_sf(g, w.KT[1], w.SLX[1], k, q, o);
     const double w3 = w.KI[0][o + 1] * w.SLX[2][o + 1] * g.dz[k] - gm_sf(g, w.KT[0], w.SLX[2], k, q + 1, o + 1);
     const double w4 = w.KI[1][o + 1] * w.SLX[3][o + 1] * g.dz[k] - gm_sf(g, w.KT[1], w.SLX[3], k, q + 1, o + 1);
-    fx = fx - cx * (w1 * gm_tz(g, X, k, o) + w2 * gm_tz(g, X, kp1, okp) + w3 * gm_tz(g, X, k, o + 1) + w4 * gm_tz(g, X, kp1, okp + 1));
+    f.a = f.a - cx * (w1 * gm_tz(g, X0, k, o) + w2 * gm_tz(g, X0, kp1, okp) + w3 * gm_tz(g, X0, k, o + 1) + w4 * gm_tz(g, X0, kp1, okp + 1));
+    f.b = f.b - cx * (w1 * gm_tz(g, X1, k, o) + w2 * gm_tz(g, X1, kp1, okp) + w3 * gm_tz(g, X1, k, o + 1) + w4 * gm_tz(g, X1, kp1, okp + 1));
   }
-  return fx;
+  return f;
 }
-__device__ __forceinline__ double gm_fy(const DevGrid &g, const GmDev &w, const double *__restrict__ X, int k, long long q, long long o) {
+__device__ __forceinline__ Gm2 gm_fy(const DevGrid &g, const GmDev &w, const double *__restrict__ X0, const double *__restrict__ X1, int k, long long q, long long o) {
   const int km = g.km, nxb = g.nxb;
   const double cy = (k <= g.KMT[q] && k <= g.KMT[q + nxb]) ? w.HXY[q] * 0.25 : 0.0;
   const double work4 = w.KI[0][o] + w.HD[0][o] + w.KI[1][o] + w.HD[1][o] + w.KI[0][o + nxb] + w.HD[0][o + nxb] + w.KI[1][o + nxb] + w.HD[1][o + nxb];
-  double fy = g.dz[k] * cy * gm_ty(g, X, k, q, o) * work4;
+  Gm2 f = {g.dz[k] * cy * gm_ty(g, X0, k, q, o) * work4, g.dz[k] * cy * gm_ty(g, X1, k, q, o) * work4};
   if (!w.cancellation) {
     const int kp1 = (k == km) ? k : k + 1;
     const long long okp = o + (long long)(kp1 - k) * g.n2;
@@ -153,52 +138,90 @@ __device__ __forceinline__ double gm_fy(const DevGrid &g, const GmDev &w, const 
     const double w2 = w.KI[1][o] * w.SLY[1][o] * g.dz[k] - gm_sf(g, w.KT[1], w.SLY[1], k, q, o);
     const double w3 = w.KI[0][o + nxb] * w.SLY[2][o + nxb] * g.dz[k] - gm_sf(g, w.KT[0], w.SLY[2], k, q + nxb, o + nxb);
     const double w4 = w.KI[1][o + nxb] * w.SLY[3][o + nxb] * g.dz[k] - gm_sf(g, w.KT[1], w.SLY[3], k, q + nxb, o + nxb);
-    fy = fy - cy * (w1 * gm_tz(g, X, k, o) + w2 * gm_tz(g, X, kp1, okp) + w3 * gm_tz(g, X, k, o + nxb) + w4 * gm_tz(g, X, kp1, okp + nxb));
+    f.a = f.a - cy * (w1 * gm_tz(g, X0, k, o) + w2 * gm_tz(g, X0, kp1, okp) + w3 * gm_tz(g, X0, k, o + nxb) + w4 * gm_tz(g, X0, kp1, okp + nxb));
+    f.b = f.b - cy * (w1 * gm_tz(g, X1, k, o) + w2 * gm_tz(g, X1, kp1, okp) + w3 * gm_tz(g, X1, k, o + nxb) + w4 * gm_tz(g, X1, kp1, okp + nxb));
   }
-  return fy;
+  return f;
 }
 // flux through the bottom face of level k < km of physical cell q (:1910-2050)
-__device__ __forceinline__ double gm_fz(const DevGrid &g, const GmDev &w, const double *__restrict__ X, int k, long long q, long long o) {
+__device__ __forceinline__ Gm2 gm_fz(const DevGrid &g, const GmDev &w, const double *__restrict__ X0, const double *__restrict__ X1, int k, long long q, long long o) {
   const int nxb = g.nxb, kp1 = k + 1;
   const long long okp = o + g.n2;
   const double kmask = (k < g.KMT[q]) ? 1.0 : 0.0;
   const double hyx = w.HYX[q], hxy = w.HXY[q], hyxw = w.HYX[q - 1], hxys = w.HXY[q - nxb];
   // east, north, west, south terms of one half cell at level kk (3-D index oo): coefficient * metric * horizontal difference
-  auto faces = [&](double ce, double cn, double cw, double cs, int kk, long long oo) {
+  auto faces = [&](const double *__restrict__ X, double ce, double cn, double cw, double cs, int kk, long long oo) {
     return ce * hyx * gm_tx(g, X, kk, q, oo) + cn * hxy * gm_ty(g, X, kk, q, oo) + cw * hyxw * gm_tx(g, X, kk, q - 1, oo - 1) + cs * hxys * gm_ty(g, X, kk, q - nxb, oo - nxb);
   };
+  const double sb[4] = {w.SLX[1][o], w.SLY[1][o], w.SLX[3][o], w.SLY[3][o]};           // bottom half of level k: east, north, west, south
+  const double st[4] = {w.SLX[0][okp], w.SLY[0][okp], w.SLX[2][okp], w.SLY[2][okp]};   // top half of level k + 1
+  const double cb = g.dz[k] * w.KI[1][o], ct = g.dz[kp1] * w.KI[0][okp];
+  Gm2 r;
   if (!w.cancellation) {
-    double w3 = 0.0;
-    w3 = w3 + (g.dz[k] * w.KI[1][o] * faces(w.SLX[1][o], w.SLY[1][o], w.SLX[3][o], w.SLY[3][o], k, o));
-    w3 = w3 + faces(gm_sf(g, w.KT[1], w.SLX[1], k, q, o), gm_sf(g, w.KT[1], w.SLY[1], k, q, o), gm_sf(g, w.KT[1], w.SLX[3], k, q, o), gm_sf(g, w.KT[1], w.SLY[3], k, q, o), k, o);
-    w3 = w3 + (g.dz[kp1] * w.KI[0][okp] * faces(w.SLX[0][okp], w.SLY[0][okp], w.SLX[2][okp], w.SLY[2][okp], kp1, okp));
-    w3 = w3 + (1.0 * faces(gm_sf(g, w.KT[0], w.SLX[0], kp1, q, okp), gm_sf(g, w.KT[0], w.SLY[0], kp1, q, okp), gm_sf(g, w.KT[0], w.SLX[2], kp1, q, okp), gm_sf(g, w.KT[0], w.SLY[2], kp1, q, okp), kp1, okp));
-    return -kmask * 0.25 * w3;
+    const double ktb = (k <= g.KMT[q]) ? w.KT[1][o] : 0.0, ktt = (kp1 <= g.KMT[q]) ? w.KT[0][okp] : 0.0;
+    // SF_SLX / SF_SLY = KAPPA_THIC * slope * dz where the level is in the water, else 0
+    double fb[4], ft[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { fb[t] = (k <= g.KMT[q]) ? ktb * sb[t] * g.dz[k] : 0.0; ft[t] = (kp1 <= g.KMT[q]) ? ktt * st[t] * g.dz[kp1] : 0.0; }
+    auto one = [&](const double *__restrict__ X) {
+      double w3 = 0.0;
+      w3 = w3 + (cb * faces(X, sb[0], sb[1], sb[2], sb[3], k, o));
+      w3 = w3 + faces(X, fb[0], fb[1], fb[2], fb[3], k, o);
+      w3 = w3 + (ct * faces(X, st[0], st[1], st[2], st[3], kp1, okp));
+      w3 = w3 + (1.0 * faces(X, ft[0], ft[1], ft[2], ft[3], kp1, okp));
+      return -kmask * 0.25 * w3;
+    };
+    r.a = one(X0); r.b = one(X1);
+    return r;
   }
-  double w3 = (g.dz[k] * w.KI[1][o] * faces(w.SLX[1][o], w.SLY[1][o], w.SLX[3][o], w.SLY[3][o], k, o));
-  w3 = w3 + (g.dz[kp1] * w.KI[0][okp] * faces(w.SLX[0][okp], w.SLY[0][okp], w.SLX[2][okp], w.SLY[2][okp], kp1, okp));
-  return -kmask * 0.5 * w3;
+  auto one = [&](const double *__restrict__ X) {
+    double w3 = (cb * faces(X, sb[0], sb[1], sb[2], sb[3], k, o));
+    w3 = w3 + (ct * faces(X, st[0], st[1], st[2], st[3], kp1, okp));
+    return -kmask * 0.5 * w3;
+  };
+  r.a = one(X0); r.b = one(X1);
+  return r;
 }
 
+// tendency of both tracers at every physical cell (0 elsewhere), and -- the coefficients being in registers -- the isopycnal part
+// of the vertical diffusivity added to VDC(k) at EVERY cell of the block (:1725-1748; VDC1: the second array, nullptr when the two
+// tracer classes share one)
 __global__ void __launch_bounds__(256)
-k_gm_flux(DevGrid g, GmDev w, const double *__restrict__ X0, const double *__restrict__ X1) {
+k_gm_flux(DevGrid g, GmDev w, const double *__restrict__ X0, const double *__restrict__ X1, double *__restrict__ VDC0, double *__restrict__ VDC1) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y + 1, b = blockIdx.z >> 1, n = blockIdx.z & 1;
+  const int k = blockIdx.y + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
   const int nxb = g.nxb, i = p2 % nxb, j = p2 / nxb, km = g.km;
   const long long n2 = g.n2, q = (long long)b * n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * n2 + p2;
-  const double *__restrict__ X = n ? X1 : X0;
-  double gt = 0.0;
-  if (i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b)) {
-    const double fxe = gm_fx(g, w, X, k, q, o), fxw = gm_fx(g, w, X, k, q - 1, o - 1);
-    const double fyn = gm_fy(g, w, X, k, q, o), fys = gm_fy(g, w, X, k, q - nxb, o - nxb);
-    const double fztop = (k >= 2) ? gm_fz(g, w, X, k - 1, q, o - n2) : 0.0;
-    if (k < km) {
-      const double fz = gm_fz(g, w, X, k, q, o);
-      gt = (fxe - fxw + fyn - fys + fztop - fz) * g.dzr[k] * g.TAREA_R[q];
-    } else gt = (fxe - fxw + fyn - fys + fztop) * g.dzr[k] * g.TAREA_R[q];
+  if (k < km) {
+    const long long ok = o + n2;
+    const double kmask = (k < g.KMT[q]) ? 1.0 : 0.0;
+    const double hyx = w.HYX[q], hxy = w.HXY[q], hyxw = (i >= 1) ? w.HYX[q - 1] : 0.0, hxys = (j >= 1) ? w.HXY[q - nxb] : 0.0;
+    auto sq = [](double x) { return x * x; };
+    const double add = g.dzw[k] * kmask * g.TAREA_R[q] *
+      (g.dz[k] * 0.25 * w.KI[1][o] * (hyx * sq(w.SLX[1][o]) + hyxw * sq(w.SLX[3][o]) + hxy * sq(w.SLY[1][o]) + hxys * sq(w.SLY[3][o])) +
+       g.dz[k + 1] * 0.25 * w.KI[0][ok] * (hyx * sq(w.SLX[0][ok]) + hyxw * sq(w.SLX[2][ok]) + hxy * sq(w.SLY[0][ok]) + hxys * sq(w.SLY[2][ok])));
+    const long long v = ((long long)b * (km + 2) + k) * n2 + p2;
+    VDC0[v] = VDC0[v] + add;
+    if (VDC1) VDC1[v] = VDC1[v] + add;
   }
-  w.GTK[n][o] = gt;
+  Gm2 gt = {0.0, 0.0};
+  if (i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b)) {
+    const Gm2 fxe = gm_fx(g, w, X0, X1, k, q, o), fxw = gm_fx(g, w, X0, X1, k, q - 1, o - 1);
+    const Gm2 fyn = gm_fy(g, w, X0, X1, k, q, o), fys = gm_fy(g, w, X0, X1, k, q - nxb, o - nxb);
+    Gm2 fztop = {0.0, 0.0};
+    if (k >= 2) fztop = gm_fz(g, w, X0, X1, k - 1, q, o - n2);
+    const double sc = g.dzr[k], tar = g.TAREA_R[q];
+    if (k < km) {
+      const Gm2 fz = gm_fz(g, w, X0, X1, k, q, o);
+      gt.a = (fxe.a - fxw.a + fyn.a - fys.a + fztop.a - fz.a) * sc * tar;
+      gt.b = (fxe.b - fxw.b + fyn.b - fys.b + fztop.b - fz.b) * sc * tar;
+    } else {
+      gt.a = (fxe.a - fxw.a + fyn.a - fys.a + fztop.a) * sc * tar;
+      gt.b = (fxe.b - fxw.b + fyn.b - fys.b + fztop.b) * sc * tar;
+    }
+  }
+  w.GTK[0][o] = gt.a; w.GTK[1][o] = gt.b;
 }
 
 }  // namespace pop

@@ -1324,7 +1324,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     if (cfg->nx_global < 1 || cfg->ny_global < 1 || cfg->km < 2 || cfg->block_size_x < 1 || cfg->block_size_y < 1) return bad("domain / block sizes must be positive (km >= 2)");
     if (cfg->ew_boundary != 0 && cfg->ew_boundary != 1) return bad("ew_boundary: 0 closed, 1 cyclic");
     if (cfg->ns_boundary < 0 || cfg->ns_boundary > 2) return bad("ns_boundary: 0 closed, 1 cyclic, 2 tripole");
-    if (cfg->hmix_momentum != 2 && cfg->hmix_momentum != 4) return bad("hmix_momentum: 2 (del2) or 4 (del4); anisotropic / GM are not built");
+    if (cfg->hmix_momentum != 2 && cfg->hmix_momentum != 4) return bad("hmix_momentum: 2 (del2) or 4 (del4); the anisotropic viscosity is not built");
     if (cfg->hmix_tracer != 2 && cfg->hmix_tracer != 4 && cfg->hmix_tracer != 3) return bad("hmix_tracer: 2 (del2), 4 (del4) or 3 (gm)");
     if (cfg->vmix_choice < 1 || cfg->vmix_choice > 3) return bad("vmix_choice: 1 const, 2 rich, 3 kpp");
     if (cfg->tadvect < 1 || cfg->tadvect > 3) return bad("tadvect: 1 centered, 2 upwind3, 3 lw_lim");
@@ -2272,12 +2272,11 @@ static int phase_hmix_gm(pop_ctx *c) {
   const double *T = c->TR[0][c->mixt], *S = c->TR[1][c->mixt];
   GmDev G = c->gm;
   G.HBLT = (c->h.c.vmix_choice == 3) ? c->HBLT : nullptr;            // BL_DEPTH = KPP_HBLT | zw(1) (:1210-1212)
-  const dim3 G3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks), G3n(G3.x, G3.y, c->g.nblocks * 2);
+  const dim3 G3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks);
   hipLaunchKernelGGL(k_gm_coeffs, G3, dim3(256), 0, c->stream, c->g, G, T, S);
   const StepParams sp = step_params(c);
   double *v1 = (sp.nvdc == 2 && c->VDC[1] != c->VDC[0]) ? c->VDC[1] : nullptr;   // one shared array is added to once
-  hipLaunchKernelGGL(k_gm_vdc, G3, dim3(256), 0, c->stream, c->g, G, c->VDC[0], v1);
-  hipLaunchKernelGGL(k_gm_flux, G3n, dim3(256), 0, c->stream, c->g, G, T, S);
+  hipLaunchKernelGGL(k_gm_flux, G3, dim3(256), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
