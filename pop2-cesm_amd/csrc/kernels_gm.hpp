@@ -186,42 +186,50 @@ __device__ __forceinline__ Gm2 gm_fz(const DevGrid &g, const GmDev &w, const dou
 // tendency of both tracers at every physical cell (0 elsewhere), and -- the coefficients being in registers -- the isopycnal part
 // of the vertical diffusivity added to VDC(k) at EVERY cell of the block (:1725-1748; VDC1: the second array, nullptr when the two
 // tracer classes share one)
+#define POP_GM_KC 4   // levels per thread: the level above / below a level is then mostly the same thread's own earlier / later read
 __global__ void __launch_bounds__(256)
 k_gm_flux(DevGrid g, GmDev w, const double *__restrict__ X0, const double *__restrict__ X1, double *__restrict__ VDC0, double *__restrict__ VDC1) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y + 1, b = blockIdx.z;
+  const int k0 = blockIdx.y * POP_GM_KC + 1, b = blockIdx.z;
   if (p2 >= g.n2) return;
   const int nxb = g.nxb, i = p2 % nxb, j = p2 / nxb, km = g.km;
-  const long long n2 = g.n2, q = (long long)b * n2 + p2, o = (long long)b * g.n3 + (long long)(k - 1) * n2 + p2;
-  if (k < km) {
-    const long long ok = o + n2;
-    const double kmask = (k < g.KMT[q]) ? 1.0 : 0.0;
-    const double hyx = w.HYX[q], hxy = w.HXY[q], hyxw = (i >= 1) ? w.HYX[q - 1] : 0.0, hxys = (j >= 1) ? w.HXY[q - nxb] : 0.0;
-    auto sq = [](double x) { return x * x; };
-    const double add = g.dzw[k] * kmask * g.TAREA_R[q] *
-      (g.dz[k] * 0.25 * w.KI[1][o] * (hyx * sq(w.SLX[1][o]) + hyxw * sq(w.SLX[3][o]) + hxy * sq(w.SLY[1][o]) + hxys * sq(w.SLY[3][o])) +
-       g.dz[k + 1] * 0.25 * w.KI[0][ok] * (hyx * sq(w.SLX[0][ok]) + hyxw * sq(w.SLX[2][ok]) + hxy * sq(w.SLY[0][ok]) + hxys * sq(w.SLY[2][ok])));
-    const long long v = ((long long)b * (km + 2) + k) * n2 + p2;
-    VDC0[v] = VDC0[v] + add;
-    if (VDC1) VDC1[v] = VDC1[v] + add;
-  }
-  Gm2 gt = {0.0, 0.0};
-  if (i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b)) {
-    const Gm2 fxe = gm_fx(g, w, X0, X1, k, q, o), fxw = gm_fx(g, w, X0, X1, k, q - 1, o - 1);
-    const Gm2 fyn = gm_fy(g, w, X0, X1, k, q, o), fys = gm_fy(g, w, X0, X1, k, q - nxb, o - nxb);
-    Gm2 fztop = {0.0, 0.0};
-    if (k >= 2) fztop = gm_fz(g, w, X0, X1, k - 1, q, o - n2);
-    const double sc = g.dzr[k], tar = g.TAREA_R[q];
+  const long long n2 = g.n2, q = (long long)b * n2 + p2;
+  const bool phys = i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b);
+  const double hyx = w.HYX[q], hxy = w.HXY[q], hyxw = (i >= 1) ? w.HYX[q - 1] : 0.0, hxys = (j >= 1) ? w.HXY[q - nxb] : 0.0;
+  const double tar = g.TAREA_R[q];
+  const int kmt = g.KMT[q];
+  Gm2 fztop = {0.0, 0.0};
+  if (phys && k0 >= 2) fztop = gm_fz(g, w, X0, X1, k0 - 1, q, (long long)b * g.n3 + (long long)(k0 - 2) * n2 + p2);
+  for (int k = k0; k < k0 + POP_GM_KC && k <= km; ++k) {
+    const long long o = (long long)b * g.n3 + (long long)(k - 1) * n2 + p2;
     if (k < km) {
-      const Gm2 fz = gm_fz(g, w, X0, X1, k, q, o);
-      gt.a = (fxe.a - fxw.a + fyn.a - fys.a + fztop.a - fz.a) * sc * tar;
-      gt.b = (fxe.b - fxw.b + fyn.b - fys.b + fztop.b - fz.b) * sc * tar;
-    } else {
-      gt.a = (fxe.a - fxw.a + fyn.a - fys.a + fztop.a) * sc * tar;
-      gt.b = (fxe.b - fxw.b + fyn.b - fys.b + fztop.b) * sc * tar;
+      const long long ok = o + n2;
+      const double kmask = (k < kmt) ? 1.0 : 0.0;
+      auto sq = [](double x) { return x * x; };
+      const double add = g.dzw[k] * kmask * tar *
+        (g.dz[k] * 0.25 * w.KI[1][o] * (hyx * sq(w.SLX[1][o]) + hyxw * sq(w.SLX[3][o]) + hxy * sq(w.SLY[1][o]) + hxys * sq(w.SLY[3][o])) +
+         g.dz[k + 1] * 0.25 * w.KI[0][ok] * (hyx * sq(w.SLX[0][ok]) + hyxw * sq(w.SLX[2][ok]) + hxy * sq(w.SLY[0][ok]) + hxys * sq(w.SLY[2][ok])));
+      const long long v = ((long long)b * (km + 2) + k) * n2 + p2;
+      VDC0[v] = VDC0[v] + add;
+      if (VDC1) VDC1[v] = VDC1[v] + add;
     }
+    Gm2 gt = {0.0, 0.0};
+    if (phys) {
+      const Gm2 fxe = gm_fx(g, w, X0, X1, k, q, o), fxw = gm_fx(g, w, X0, X1, k, q - 1, o - 1);
+      const Gm2 fyn = gm_fy(g, w, X0, X1, k, q, o), fys = gm_fy(g, w, X0, X1, k, q - nxb, o - nxb);
+      const double sc = g.dzr[k];
+      if (k < km) {
+        const Gm2 fz = gm_fz(g, w, X0, X1, k, q, o);
+        gt.a = (fxe.a - fxw.a + fyn.a - fys.a + fztop.a - fz.a) * sc * tar;
+        gt.b = (fxe.b - fxw.b + fyn.b - fys.b + fztop.b - fz.b) * sc * tar;
+        fztop = fz;                                  // FZTOP of the next level (:2003)
+      } else {
+        gt.a = (fxe.a - fxw.a + fyn.a - fys.a + fztop.a) * sc * tar;
+        gt.b = (fxe.b - fxw.b + fyn.b - fys.b + fztop.b) * sc * tar;
+      }
+    }
+    w.GTK[0][o] = gt.a; w.GTK[1][o] = gt.b;
   }
-  w.GTK[0][o] = gt.a; w.GTK[1][o] = gt.b;
 }
 
 }  // namespace pop

@@ -2276,7 +2276,7 @@ static int phase_hmix_gm(pop_ctx *c) {
   hipLaunchKernelGGL(k_gm_coeffs, G3, dim3(256), 0, c->stream, c->g, G, T, S);
   const StepParams sp = step_params(c);
   double *v1 = (sp.nvdc == 2 && c->VDC[1] != c->VDC[0]) ? c->VDC[1] : nullptr;   // one shared array is added to once
-  hipLaunchKernelGGL(k_gm_flux, G3, dim3(256), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
+  hipLaunchKernelGGL(k_gm_flux, dim3(G3.x, (c->g.km + POP_GM_KC - 1) / POP_GM_KC, G3.z), dim3(256), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
   HIPCHK(c, hipGetLastError());
   return 0;
 }
