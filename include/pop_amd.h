@@ -73,7 +73,10 @@ typedef struct pop_config {
                                * thickness DZBC (pop_grid_input.DZBC = the record of bottom_cell_file; NULL with the internal
                                * topography: a synthetic DZBC in (0.25, 1] dz(KMT), TEST EXTENSION), DZT / DZU as the reference forms them */
   int gm_slope_control;       /* hmix_gm_nml slope_control_choice: 0 'notanh' (the default, hmix_gm.F90:1508-1539), 1 'tanh' (:1490-1506) */
-  int reserved_i[2];          /* must be 0 */
+  int gm_kappa_type;          /* hmix_gm_nml kappa_isop_choice = kappa_thic_choice: 0 'constant', 1 'bfre' (buoyancy_frequency_dependent_profile,
+                               * hmix_gm.F90:3011-3180: KAPPA_VERTICAL = N^2 / N_ref^2 in [0.1, 1] below the surface diabatic layer; kappa_*_deep = 0.1) */
+  int gm_kappa_freq;          /* kappa_freq_choice with gm_kappa_type = 1: 0 'never' (the profile of the first step of the run is kept, :1276-1278),
+                               * 1 'every_time_step'; 'once_a_day' is not built */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;

@@ -52,7 +52,7 @@ typedef struct {
   int sw_absorption_type, jerlov_water_type, lsw_absorb;
   int partial_bottom_cells;   /* grid.F90:916-1020 */
   int gm_slope_control;       /* hmix_tracer = 3 (gm): 0 notanh, 1 tanh */
-  int reserved_i[2];
+  int gm_kappa_type, gm_kappa_freq;   /* 0 constant | 1 bfre; 0 never | 1 every_time_step */
   double am, ah;              /* del2 or del4 coefficients */
   double const_vvc, const_vdc;
   double convect_diff, convect_visc, bottom_drag, aidif;

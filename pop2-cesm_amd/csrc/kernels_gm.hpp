@@ -2,7 +2,8 @@
 // (source/hmix_gm.F90:1102-2226 hdifft_gm, hmix_gm_submeso_share.F90:149-432 tracer_diffs_and_isopyc_slopes, init_gm :283-1095) in the
 // set-up the code's own hmix_gm_nml defaults give: constant kappa (KAPPA_VERTICAL = 1), kappa_freq 'never', no transition layer,
 // use_const_ah_bkg_srfbl, ah_bkg_bottom = 0, slope control 'notanh' | 'tanh'; ah_bolus /= ah or slm_b /= slm_r take the branch
-// without cancellation of the skew-flux terms.  Bolus-velocity diagnostics are not formed.
+// without cancellation of the skew-flux terms.  kappa type 'bfre' (buoyancy_frequency_dependent_profile :3011-3180; kappa_*_deep = 0.1,
+// kappa_freq 'never' | 'every_time_step'): k_gm_kappa_vertical, a column march.  Bolus-velocity diagnostics are not formed.
 //
 // The reference works level by level and carries whole-block work arrays (TX, TY, TZ, RX, RY, SF_SLX, SF_SLY, FZTOP) from level to
 // level; here every value is a function of the mix-time tracers at the cell and its neighbours one level up / down, so two
@@ -23,6 +24,7 @@ struct GmDev {
   double *SLX[4], *SLY[4];          // [face * 2 + half]: face 0 east / north, 1 west / south; half 0 top (ktp), 1 bottom (kbt)
   double *KI[2], *KT[2], *HD[2];    // KAPPA_ISOP, KAPPA_THIC, HOR_DIFF of the two halves
   double *GTK[2];
+  double *KV;                       // KAPPA_VERTICAL (kappa type 'bfre'; module state: 1 until computed), nullptr with constant kappa
   const double *HYX, *HXY, *RBR, *DXT, *DYT, *HBLT;   // HBLT: nullptr without KPP (BL_DEPTH = zw(1))
   double ah, ah_bolus, ah_bkg_srfbl, slm_r, slm_b;
   int diff_tapering, cancellation, slope_tanh;
@@ -35,6 +37,44 @@ __device__ __forceinline__ double gm_taper23(double sla, double slm, int slope_t
   if (sla > 0.2 * slm && sla < 0.6 * slm) t = 0.5 * (1.0 - (2.5 * sla / slm - 1.0) * (4.0 - fabs(10.0 * sla / slm - 4.0)));
   else if (sla >= 0.6 * slm) t = 0.0;
   return t;
+}
+
+// KAPPA_VERTICAL = N^2 / N_ref^2 in [0.1, 1] below the surface diabatic layer SDL (= KPP_HBLT or zw(1)), 1 above (:3011-3180).
+// One thread per column of the block (ghost columns included: the coefficients are formed there too); N^2 of the interfaces is
+// kept in registers only as far as the march needs it: the reference level K_MIN is the first interface below SDL with N^2 > 0,
+// so the march first looks for it, then normalises from there down.
+__global__ void __launch_bounds__(256)
+k_gm_kappa_vertical(DevGrid g, GmDev w, const double *__restrict__ T, const double *__restrict__ S, double grav) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const int km = g.km;
+  const long long n2 = g.n2, q = (long long)b * n2 + p2, base = (long long)b * g.n3 + p2;
+  const int kmt = g.KMT[q];
+  const double sdl = w.HBLT ? w.HBLT[q] : g.zw[1];
+  // N^2 at the bottom of level k (k < KMT; 0 elsewhere, as the module array's initial value)
+  auto bfsq = [&](int k) {
+    if (!(k < kmt)) return 0.0;
+    const long long o = base + (long long)(k - 1) * n2;
+    double rt, rs;
+    const MwjfP P = mwjf_level(g.pressz[k + 1]);
+    mwjf_rho<true>(P, T[o], S[o], &rt, &rs);
+    const double v = -(grav * g.dzwr[k] * (rt * (fmax(-2.0, T[o]) - fmax(-2.0, T[o + n2])) + rs * (S[o] - S[o + n2])));
+    return fmax(0.0, v);
+  };
+  int kmin = (kmt != 0) ? km + 1 : 0;
+  double ref = 0.0;
+  for (int k = 1; k <= km - 1; ++k) {
+    if (kmin == km + 1 && g.zw[k] > sdl && k <= kmt) { const double v = bfsq(k); if (v > 0.0) { ref = v; kmin = k; } }
+  }
+  // NORM(k) of the interfaces, KAPPA_VERTICAL(k) = NORM(k-1) where k > K_MIN and k <= KMT, else 1
+  w.KV[base] = 1.0;
+  for (int k = 2; k <= km; ++k) {
+    const int ki = k - 1;                              // the interface above level k
+    double nr;
+    if (ki >= kmin && ki < kmt && ref != 0.0) nr = fmin(fmax(bfsq(ki) / ref, 0.1), 1.0); else nr = 1.0;
+    // (:3152-3156 copies NORM(KMT-1) to the interface KMT, which only KAPPA_VERTICAL(KMT+1) would read -- below the bottom, where it is 1)
+    w.KV[base + (long long)(k - 1) * n2] = (k > kmin && k <= kmt) ? nr : 1.0;
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -83,8 +123,11 @@ k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__re
     const double taper1 = (dz_bottom <= bl) ? t1f : 1.0;
     const double taper2 = gm_taper23(sla, w.slm_r, w.slope_tanh);
     const double taper3 = w.diff_tapering ? gm_taper23(sla, w.slm_b, w.slope_tanh) : taper2;
-    double hd = (dz_bottom <= bl) ? w.ah_bkg_srfbl * (1.0 - taper1 * taper2) * 1.0 : 0.0;
-    double ki = taper1 * taper2 * w.ah, kt = taper1 * taper3 * w.ah_bolus;
+    const double kv = w.KV ? w.KV[o] : 1.0;
+    double hd = (dz_bottom <= bl) ? w.ah_bkg_srfbl * (1.0 - taper1 * taper2) * kv : 0.0;
+    // KAPPA_LATERAL * max(KAPPA_VERTICAL, kappa_*_deep) with 'bfre' (:1353-1358, 1382-1387), the constants otherwise
+    const double kis = w.KV ? w.ah * fmax(kv, 0.1) : w.ah, kts = w.KV ? w.ah_bolus * fmax(kv, 0.1) : w.ah_bolus;
+    double ki = taper1 * taper2 * kis, kt = taper1 * taper3 * kts;
     if (kk == 1 && s == 0) { hd = w.ah_bkg_srfbl; ki = 0.0; kt = 0.0; }   // :1208, :1663-1664
     if (s == 1 && kk == kmt) { ki = 0.0; kt = 0.0; }                       // :1654-1657
     w.KI[s][o] = ki; w.KT[s][o] = kt; w.HD[s][o] = hd;

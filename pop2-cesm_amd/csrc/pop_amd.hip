@@ -1315,7 +1315,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       // in the init routine of the option's own module, e.g. vertical_mix.F90:280-296, POP_SolversMod.F90:442-472)
     auto bad = [&](const std::string &m) { c->err = "pop_create: " + m; return 1; };
     if (cfg->struct_version != POP_CONFIG_VERSION) return bad("pop_config.struct_version is " + std::to_string(cfg->struct_version) + ", this library was built for " + std::to_string(POP_CONFIG_VERSION) + " (include/pop_amd.h)");
-    for (int r = 0; r < 2; ++r) if (cfg->reserved_i[r] != 0) return bad("pop_config.reserved_i must be 0");
+    if (cfg->gm_kappa_type != 0 && cfg->gm_kappa_type != 1) return bad("gm_kappa_type: 0 constant, 1 bfre (the other kappa choices of hmix_gm_nml are not built)");
+    if (cfg->gm_kappa_freq != 0 && cfg->gm_kappa_freq != 1) return bad("gm_kappa_freq: 0 never, 1 every_time_step (once_a_day is not built)");
     if (cfg->gm_slope_control != 0 && cfg->gm_slope_control != 1) return bad("gm_slope_control: 0 notanh, 1 tanh (slope clipping and the Gerdes et al. form are not built)");
     if (cfg->ah_bolus < 0.0 || cfg->ah_bkg_srfbl < 0.0 || cfg->slm_r < 0.0 || cfg->slm_b < 0.0) return bad("ah_bolus, ah_bkg_srfbl, slm_r, slm_b: >= 0 (0 = ah, ah, 0.3, 0.3)");
     if (cfg->partial_bottom_cells != 0 && cfg->partial_bottom_cells != 1) return bad("partial_bottom_cells: 0 or 1");
@@ -1552,6 +1553,11 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     GmDev &G = c->gm;
     for (int t = 0; t < 4; ++t) if (dev_alloc(c, &G.SLX[t], a3g) || dev_alloc(c, &G.SLY[t], a3g)) return 1;
     for (int t = 0; t < 2; ++t) if (dev_alloc(c, &G.KI[t], a3g) || dev_alloc(c, &G.KT[t], a3g) || dev_alloc(c, &G.HD[t], a3g) || dev_alloc(c, &G.GTK[t], a3g)) return 1;
+    if (cfg->gm_kappa_type == 1) {   // KAPPA_VERTICAL: module state, 1 until the profile is computed (hmix_gm.F90:860)
+      if (dev_alloc(c, &G.KV, a3g, false)) return 1;
+      std::vector<double> ones(a3g, 1.0);
+      HIPCHK(c, hipMemcpy(G.KV, ones.data(), a3g * sizeof(double), hipMemcpyHostToDevice));
+    }
     G.HYX = c->d2["gmHYX"]; G.HXY = c->d2["gmHXY"]; G.RBR = c->d2["gmRBR"]; G.DXT = c->d2["DXT"]; G.DYT = c->d2["DYT"];
     if (!G.HYX || !G.HXY || !G.RBR || !G.DXT || !G.DYT) { c->err = "gm: grid fields missing"; return 1; }
     // hmix_gm_nml (hmix_gm.F90:364-428); 0 = the value of the default set-up
@@ -2273,6 +2279,9 @@ static int phase_hmix_gm(pop_ctx *c) {
   GmDev G = c->gm;
   G.HBLT = (c->h.c.vmix_choice == 3) ? c->HBLT : nullptr;            // BL_DEPTH = KPP_HBLT | zw(1) (:1210-1212)
   const dim3 G3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks);
+  // compute_kappa (:1258-1332): the first step of the run, or every step
+  if (G.KV && (c->h.c.gm_kappa_freq == 1 || c->nsteps_total == 1))
+    hipLaunchKernelGGL(k_gm_kappa_vertical, dim3(G3.x, c->g.nblocks), dim3(256), 0, c->stream, c->g, G, T, S, step_params(c).grav);
   hipLaunchKernelGGL(k_gm_coeffs, G3, dim3(256), 0, c->stream, c->g, G, T, S);
   const StepParams sp = step_params(c);
   double *v1 = (sp.nvdc == 2 && c->VDC[1] != c->VDC[0]) ? c->VDC[1] : nullptr;   // one shared array is added to once

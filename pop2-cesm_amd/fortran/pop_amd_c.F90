@@ -33,7 +33,7 @@
       integer (c_int) :: sw_absorption_type = 0, jerlov_water_type = 0, lsw_absorb = 0   ! sw_absorption_nml
       integer (c_int) :: partial_bottom_cells = 0                          ! grid_nml
       integer (c_int) :: gm_slope_control = 0                              ! hmix_gm_nml slope_control_choice: 0 'notanh', 1 'tanh' (hmix_tracer = 3)
-      integer (c_int) :: reserved_i(2) = 0
+      integer (c_int) :: gm_kappa_type = 0, gm_kappa_freq = 0              ! hmix_gm_nml kappa_*_choice: 0 constant, 1 bfre; kappa_freq_choice: 0 never, 1 every_time_step
       real (c_double) :: am, ah
       real (c_double) :: const_vvc, const_vdc
       real (c_double) :: convect_diff, convect_visc, bottom_drag, aidif

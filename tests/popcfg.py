@@ -24,7 +24,7 @@ class PopConfig(C.Structure):
         ("stepped_bathymetry", C.c_int), ("distribution_type", C.c_int), ("kpp_ml_diagnostics", C.c_int),
         ("sw_absorption_type", C.c_int), ("jerlov_water_type", C.c_int), ("lsw_absorb", C.c_int),
         ("partial_bottom_cells", C.c_int),
-        ("gm_slope_control", C.c_int), ("reserved_i", C.c_int * 2),
+        ("gm_slope_control", C.c_int), ("gm_kappa_type", C.c_int), ("gm_kappa_freq", C.c_int),
         ("am", C.c_double), ("ah", C.c_double),
         ("const_vvc", C.c_double), ("const_vdc", C.c_double),
         ("convect_diff", C.c_double), ("convect_visc", C.c_double), ("bottom_drag", C.c_double),

@@ -35,6 +35,11 @@ def _steep(gpu, orc):
     ("tiny", {"tmix_opt": 3, "solver_choice": 2}, 4),                                 # Robert filter
     ("tiny", {"km": 60, "vmix_choice": 3}, 3),                                        # production level count (register Thomas kernels)
     ("tiny", {"partial_bottom_cells": 1, "stepped_bathymetry": 1}, 3),                # the scheme has no partial-cell branches: dz(k) throughout
+    # kappa type 'bfre' (buoyancy_frequency_dependent_profile): KAPPA_VERTICAL = N^2 / N_ref^2 below the surface diabatic layer
+    ("tiny", {"gm_kappa_type": 1, "stepped_bathymetry": 1}, 5),                       # 'never': the profile of the first step is kept
+    ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1, "ah_bolus": 0.5e7}, 5),   # every step, SDL = HBLT
+    ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "km": 60, "tadvect": 2, "gm_slope_control": 1}, 3),
+    ("gx3v7", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3}, 3),
     ("test", {"stepped_bathymetry": 1}, 3),                                           # 96 blocks
     ("gx3v7", {"vmix_choice": 3}, 3),
 ])
@@ -73,7 +78,7 @@ def test_gm_on_a_caller_grid(pkg, orclib_built, kw):
     gpu.close(); orc.close()
 
 
-@pytest.mark.parametrize("kw", [{}, {"ah_bolus": 0.3e7, "slm_b": 0.2}, {"vmix_choice": 3, "km": 20, "tadvect": 2}])
+@pytest.mark.parametrize("kw", [{}, {"ah_bolus": 0.3e7, "slm_b": 0.2}, {"vmix_choice": 3, "km": 20, "tadvect": 2}, {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 20}])
 def test_gm_conserves_tracer_content(pkg, kw):
     """every term is a flux form -- east / north fluxes shared by neighbours, the flux through the bottom face of a level is the one
     through the top face of the next, the isopycnal addition to VDC goes through the (conservative) implicit solve: with no surface
@@ -115,3 +120,22 @@ def test_gm_leaves_level_isopycnals_alone(pkg):
         m.close()
     for a, b in zip(out[2], out[3]):
         assert np.array_equal(a, b)
+
+
+def test_gm_buoyancy_frequency_profile_is_what_it_says(pkg, orclib_built):
+    """kappa type 'bfre': below the surface diabatic layer the isopycnal diffusivity follows N^2 / N_ref^2, clamped to [0.1, 1]
+    (hmix_gm.F90:3011-3180) -- so in the weakly stratified deep ocean of the Levitus profile the isopycnal addition to VDC must be
+    several times smaller than with constant kappa, and identical in the levels above the reference level (KAPPA_VERTICAL = 1 there)"""
+    out = {}
+    for kt in (0, 1):
+        m = pkg.PopModel(named_config("tiny", gm_kappa_type=kt, gm_kappa_freq=1, km=24, **GM))
+        o = Oracle(named_config("tiny", gm_kappa_type=kt, gm_kappa_freq=1, km=24, **GM))
+        _steep(m, o); o.close()
+        m.step()
+        out[kt] = m.get("VDC", n=0) - m.cfg.const_vdc
+        m.close()
+    a, b = out[0][:, 1:3], out[1][:, 1:3]                  # bottoms of levels 1, 2: they read KAPPA_VERTICAL(1..3) = 1 (reference level K_MIN = 2 below SDL = zw(1))
+    assert np.abs(a).max() > 1.0 and np.array_equal(a, b)
+    deep_c, deep_b = out[0][:, 15:22], out[1][:, 15:22]
+    big = deep_c > 1.0
+    assert big.sum() > 50 and np.median(deep_b[big] / deep_c[big]) < 0.5 and (deep_b[big] >= 0.1 * deep_c[big] * (1 - 1e-12)).all()
