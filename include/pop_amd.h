@@ -30,7 +30,7 @@ extern "C" {
 /* Run-time configuration: the namelist subset this path reads
  * (domain_nml, grid_nml, time_manager_nml, hmix_*_nml, vertical_mix_nml,
  *  vmix_*_nml, advect_nml, pressure_grad_nml, baroclinic_nml, &solvers). */
-#define POP_CONFIG_VERSION 3   /* layout of pop_config below; pop_create refuses any other struct_version */
+#define POP_CONFIG_VERSION 4   /* layout of pop_config below; pop_create refuses any other struct_version (4: gm_transition_layer appended) */
 typedef struct pop_config {
   int struct_version;         /* = POP_CONFIG_VERSION (round 3: every option has its own named field) */
   int nx_global, ny_global, km, nt;   /* domain_size.F90 */
@@ -91,6 +91,9 @@ typedef struct pop_config {
   double ah_bolus;                       /* thickness (bolus) diffusivity, 0 = ah (then the skew-flux terms cancel, 'cancellation_occurs' :970-983) */
   double ah_bkg_srfbl;                   /* horizontal diffusivity inside the surface boundary layer, 0 = ah */
   double slm_r, slm_b;                   /* maximum slope for isopycnal / thickness diffusion, 0 = 0.3 */
+  int gm_transition_layer;               /* hmix_gm_nml transition_layer_on (hmix_gm.F90:3183-3848: transition_layer, merged_streamfunction,
+                                          * apply_vertical_profile_to_isop_hor_diff); with KPP the diabatic depth is the smoothed HMXL */
+  int reserved_i[3];                     /* must be 0 */
 } pop_config;
 
 typedef struct pop_ctx pop_ctx;

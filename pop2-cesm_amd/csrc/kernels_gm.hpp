@@ -25,6 +25,13 @@ struct GmDev {
   double *KI[2], *KT[2], *HD[2];    // KAPPA_ISOP, KAPPA_THIC, HOR_DIFF of the two halves
   double *GTK[2];
   double *KV;                       // KAPPA_VERTICAL (kappa type 'bfre'; module state: 1 until computed), nullptr with constant kappa
+  // transition layer (transition_layer_on; hmix_gm.F90:3183-3848): nullptr / 0 when off
+  int tlt;
+  double *SLA[2];                   // SLA_SAVE of the two halves (3-D)
+  double *DD, *TH, *ID;             // TLT%DIABATIC_DEPTH, THICKNESS, INTERIOR_DEPTH (2-D)
+  int *KL, *ZTW;                    // TLT%K_LEVEL, ZTW
+  double *MW[8];                    // merged_streamfunction: WORK1, WORK2 (x) and WORK3, WORK4 (y) of the east|north and west|south side: [2 * w + face], w = 0..3
+  const double *HMXL;
   const double *HYX, *HXY, *RBR, *DXT, *DYT, *HBLT;   // HBLT: nullptr without KPP (BL_DEPTH = zw(1))
   double ah, ah_bolus, ah_bkg_srfbl, slm_r, slm_b;
   int diff_tapering, cancellation, slope_tanh;
@@ -50,7 +57,7 @@ k_gm_kappa_vertical(DevGrid g, GmDev w, const double *__restrict__ T, const doub
   const int km = g.km;
   const long long n2 = g.n2, q = (long long)b * n2 + p2, base = (long long)b * g.n3 + p2;
   const int kmt = g.KMT[q];
-  const double sdl = w.HBLT ? w.HBLT[q] : g.zw[1];
+  const double sdl = w.tlt ? w.ID[q] : (w.HBLT ? w.HBLT[q] : g.zw[1]);   // :3081-3083
   // N^2 at the bottom of level k (k < KMT; 0 elsewhere, as the module array's initial value)
   auto bfsq = [&](int k) {
     if (!(k < kmt)) return 0.0;
@@ -77,6 +84,11 @@ k_gm_kappa_vertical(DevGrid g, GmDev w, const double *__restrict__ T, const doub
   }
 }
 
+// MODE 0: everything in one launch (no transition layer).  With the transition layer: MODE 1 stores the slopes and SLA_SAVE only (the
+// transition-layer march needs SLA of the whole column first), MODE 2 is the full evaluation with the layer's rules: no near-surface
+// taper, no slope taper down to the diabatic depth, HOR_DIFF = ah_bkg_srfbl everywhere (:1428-1439, 1591-1600), and at the end the
+// vertical profile of apply_vertical_profile_to_isop_hor_diff (:3745-3846), which touches each half cell on its own
+template <int MODE>
 __global__ void __launch_bounds__(256)
 k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__restrict__ S) {
   const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,25 +126,154 @@ k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__re
   const double dxt = w.DXT[q], dyt = w.DYT[q], rbr = w.RBR[q];
   const double bl = w.HBLT ? w.HBLT[q] : g.zw[1];
   const double dz_bottom = (kk == 1) ? 0.0 : g.zt[kk - 1];
+  const int kp1r = min(kk + 1, km);
+  const double refdepth[2] = {(kk == km) ? g.zw[kp1r] : g.zt[kp1r], g.zw[kp1r]};   // :1408-1411
+  const double ddq = (MODE == 2) ? w.DD[q] : 0.0;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int kid = kk + s - 1;
     const double sla = g.dzw[kid] * sqrt(0.5 * ((sl[s][0] * sl[s][0] + sl[s][1] * sl[s][1]) / (dxt * dxt) + (sl[s][2] * sl[s][2] + sl[s][3] * sl[s][3]) / (dyt * dyt))) + 1.0e-10;
+    if (MODE == 1) {
+      w.SLA[s][o] = sla;
+      w.SLX[0 + s][o] = sl[s][0]; w.SLX[2 + s][o] = sl[s][1]; w.SLY[0 + s][o] = sl[s][2]; w.SLY[2 + s][o] = sl[s][3];
+      continue;
+    }
     const double w1 = fmin(1.0, g.zt[kk] * rbr / sla);
     const double t1f = w.slope_tanh ? 0.5 * (1.0 + sin(3.14159265358979323846 * (w1 - 0.5))) : (0.5 + 2.0 * (w1 - 0.5) * (1.0 - fabs(w1 - 0.5)));
-    const double taper1 = (dz_bottom <= bl) ? t1f : 1.0;
-    const double taper2 = gm_taper23(sla, w.slm_r, w.slope_tanh);
-    const double taper3 = w.diff_tapering ? gm_taper23(sla, w.slm_b, w.slope_tanh) : taper2;
+    const double taper1 = (MODE == 2) ? 1.0 : ((dz_bottom <= bl) ? t1f : 1.0);
+    double taper2 = gm_taper23(sla, w.slm_r, w.slope_tanh);
+    double taper3 = w.diff_tapering ? gm_taper23(sla, w.slm_b, w.slope_tanh) : taper2;
+    if (MODE == 2 && refdepth[s] <= ddq) { taper2 = 1.0; taper3 = 1.0; }
     const double kv = w.KV ? w.KV[o] : 1.0;
     double hd = (dz_bottom <= bl) ? w.ah_bkg_srfbl * (1.0 - taper1 * taper2) * kv : 0.0;
     // KAPPA_LATERAL * max(KAPPA_VERTICAL, kappa_*_deep) with 'bfre' (:1353-1358, 1382-1387), the constants otherwise
     const double kis = w.KV ? w.ah * fmax(kv, 0.1) : w.ah, kts = w.KV ? w.ah_bolus * fmax(kv, 0.1) : w.ah_bolus;
     double ki = taper1 * taper2 * kis, kt = taper1 * taper3 * kts;
+    if (MODE == 2) hd = w.ah_bkg_srfbl;
     if (kk == 1 && s == 0) { hd = w.ah_bkg_srfbl; ki = 0.0; kt = 0.0; }   // :1208, :1663-1664
     if (s == 1 && kk == kmt) { ki = 0.0; kt = 0.0; }                       // :1654-1657
+    if (MODE == 2 && kk <= kmt) {                                          // apply_vertical_profile_to_isop_hor_diff
+      const double rd = (s == 0) ? g.zt[kk] - 0.25 * g.dz[kk] : g.zt[kk] + 0.25 * g.dz[kk], th = w.TH[q], idq = w.ID[q];
+      if (rd <= ddq) ki = 0.0;
+      if (rd > ddq && rd <= idq && th > 1.0e-10) { hd = (idq - rd) * hd / th; ki = (rd - ddq) * ki / th; }
+      if (rd > idq) hd = 0.0;
+    }
     w.KI[s][o] = ki; w.KT[s][o] = kt; w.HD[s][o] = hd;
     w.SLX[0 + s][o] = sl[s][0]; w.SLX[2 + s][o] = sl[s][1]; w.SLY[0 + s][o] = sl[s][2]; w.SLY[2 + s][o] = sl[s][3];
   }
+}
+
+// TLT%DIABATIC_DEPTH: smooth_hblt(.false., .true.) (vmix_kpp.F90:3699-3881) -- one pass of the 1-1-4-1-1 filter over HMXL with land
+// neighbours' weights folded into the centre, capped at the depth of the bottom T point; the outermost ring of the block keeps HMXL
+__global__ void __launch_bounds__(256)
+k_gm_diabatic_depth(DevGrid g, GmDev w) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const int nxb = g.nxb, nyb = g.nyb, i = p2 % nxb, j = p2 / nxb;
+  const long long q = (long long)b * g.n2 + p2;
+  if (!w.HMXL) { w.DD[q] = g.zw[1]; return; }
+  double out = w.HMXL[q];
+  if (i >= 1 && i <= nxb - 2 && j >= 1 && j <= nyb - 2) {
+    const int kmt = g.KMT[q];
+    if (kmt != 0) {
+      double cw = 0.125, ce = 0.125, cn = 0.125, cs = 0.125, cc = 0.5;
+      if (g.KMT[q - 1] == 0) { cc = cc + cw; cw = 0.0; }
+      if (g.KMT[q + 1] == 0) { cc = cc + ce; ce = 0.0; }
+      if (g.KMT[q - nxb] == 0) { cc = cc + cs; cs = 0.0; }
+      if (g.KMT[q + nxb] == 0) { cc = cc + cn; cn = 0.0; }
+      out = cw * w.HMXL[q - 1] + ce * w.HMXL[q + 1] + cs * w.HMXL[q - nxb] + cn * w.HMXL[q + nxb] + cc * w.HMXL[q];
+    }
+    if (kmt >= 1 && kmt <= g.km && out > g.zt[kmt]) out = g.zt[kmt];
+  }
+  w.DD[q] = out;
+}
+
+// transition_layer (:3183-3440): one thread per column, the reference's state machine over the levels
+__global__ void __launch_bounds__(256)
+k_gm_transition_layer(DevGrid g, GmDev w) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const int km = g.km;
+  const long long n2 = g.n2, q = (long long)b * n2 + p2, base = (long long)b * g.n3 + p2;
+  const int kmt = g.KMT[q];
+  const double dd = w.DD[q], rb = 1.0 / w.RBR[q];
+  auto sla = [&](int s, int kk) { return w.SLA[s][base + (long long)(kk - 1) * n2]; };
+  int kstart = 0, ksub = 0, klev = 0, ztw = 0;
+  bool compute = kmt != 0;
+  double thick = 0.0, interior = 0.0;
+  for (int k = 1; k <= km; ++k) {
+    if (compute && dd < g.zw[k]) { kstart = k + 1; ksub = 1; thick = g.zw[k] - dd; klev = k; ztw = 2; compute = false; }
+    if (k != 1 && kstart == k + 1 && dd < g.zt[k]) { kstart = k; ksub = 2; thick = g.zt[k] - dd; klev = k; ztw = 1; }
+  }
+  compute = !(kmt == 0 || kstart > kmt || (kstart == kmt && ksub == 2));
+  for (int k = 1; k <= km - 1; ++k) {
+    double work = 0.0;
+    if (compute && ksub == 2 && kstart < kmt && kstart == k) work = fmax(sla(1, k), sla(0, k + 1)) * rb;
+    if (work != 0.0 && dd < (g.zw[k] - work)) compute = false;
+    if (work != 0.0 && dd >= (g.zw[k] - work)) { kstart = kstart + 1; ksub = 1; thick = g.zw[k] - dd; klev = k; ztw = 2; }
+  }
+  for (int k = 2; k <= km; ++k) {
+    for (int kk = 1; kk <= 2; ++kk) {
+      const double refd = (kk == 1) ? g.zt[k] : g.zw[k];
+      double work = 0.0;
+      if (kk == 1) {
+        if (compute && kstart <= kmt && kstart == k) work = fmax(sla(0, k), sla(1, k)) * rb;
+      } else {
+        if (k < km && compute && kstart < kmt && kstart == k) work = fmax(sla(1, k), sla(0, k + 1)) * rb;
+        if (compute && kstart == kmt && kstart == k) work = sla(1, k) * rb;
+      }
+      if (work != 0.0 && dd < (refd - work)) compute = false;
+      if (work != 0.0 && dd >= (refd - work)) { thick = refd - dd; klev = k; ztw = kk; }
+    }
+    if (compute && kstart == k) kstart = kstart + 1;
+  }
+  if (klev >= 1 && ztw == 1) interior = g.zt[klev];
+  if (klev >= 1 && ztw == 2) interior = g.zw[klev];
+  w.TH[q] = thick; w.ID[q] = interior; w.KL[q] = klev; w.ZTW[q] = ztw;
+}
+
+// merged_streamfunction, first part (:3488-3566): the interior streamfunction and its first derivative at the interior depth of the
+// column, for the east / north (face 0) and west / south (face 1) quarter cells -> MW[2 * {0: WORK1, 1: WORK2, 2: WORK3, 3: WORK4} + face]
+__global__ void __launch_bounds__(256)
+k_gm_msf_column(DevGrid g, GmDev w) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const int km = g.km;
+  const long long n2 = g.n2, q = (long long)b * n2 + p2, base = (long long)b * g.n3 + p2;
+  const int kmt = g.KMT[q], k = w.KL[q], zt = w.ZTW[q];
+  double W1[2] = {0.0, 0.0}, W2[2] = {0.0, 0.0}, W3[2] = {0.0, 0.0}, W4[2] = {0.0, 0.0};
+  if (k >= 1 && k <= km - 1 && k < kmt) {
+    const long long o = base + (long long)(k - 1) * n2, o1 = o + n2, o2 = o1 + n2;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const double *SXt = w.SLX[2 * n], *SXb = w.SLX[2 * n + 1], *SYt = w.SLY[2 * n], *SYb = w.SLY[2 * n + 1];
+      if (zt == 1) {
+        W1[n] = w.KT[1][o] * SXb[o] * g.dz[k];
+        W2[n] = 2.0 * g.dzwr[k] * (W1[n] - w.KT[0][o1] * SXt[o1] * g.dz[k + 1]);
+        const double w2n = 2.0 * (w.KT[0][o1] * SXt[o1] - w.KT[1][o1] * SXb[o1]);
+        W3[n] = w.KT[1][o] * SYb[o] * g.dz[k];
+        W4[n] = 2.0 * g.dzwr[k] * (W3[n] - w.KT[0][o1] * SYt[o1] * g.dz[k + 1]);
+        const double w4n = 2.0 * (w.KT[0][o1] * SYt[o1] - w.KT[1][o1] * SYb[o1]);
+        if (fabs(w2n) < fabs(W2[n])) W2[n] = w2n;
+        if (fabs(w4n) < fabs(W4[n])) W4[n] = w4n;
+      } else if (zt == 2) {
+        W1[n] = w.KT[0][o1] * SXt[o1];
+        W2[n] = 2.0 * (W1[n] - (w.KT[1][o1] * SXb[o1]));
+        W1[n] = W1[n] * g.dz[k + 1];
+        W3[n] = w.KT[0][o1] * SYt[o1];
+        W4[n] = 2.0 * (W3[n] - (w.KT[1][o1] * SYb[o1]));
+        W3[n] = W3[n] * g.dz[k + 1];
+        if (k + 1 < kmt && k < km - 1) {
+          const double w2n = 2.0 * g.dzwr[k + 1] * (w.KT[1][o1] * SXb[o1] * g.dz[k + 1] - w.KT[0][o2] * SXt[o2] * g.dz[k + 2]);
+          const double w4n = 2.0 * g.dzwr[k + 1] * (w.KT[1][o1] * SYb[o1] * g.dz[k + 1] - w.KT[0][o2] * SYt[o2] * g.dz[k + 2]);
+          if (fabs(w2n) < fabs(W2[n])) W2[n] = w2n;
+          if (fabs(w4n) < fabs(W4[n])) W4[n] = w4n;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) { w.MW[0 + n][q] = W1[n]; w.MW[2 + n][q] = W2[n]; w.MW[4 + n][q] = W3[n]; w.MW[6 + n][q] = W4[n]; }
 }
 
 // horizontal differences of tracer X at level kk (TX, TY of the reference) on the east / north face of 2-D cell q (3-D index o)
@@ -144,10 +285,25 @@ __device__ __forceinline__ double gm_ty(const DevGrid &g, const double *__restri
 }
 // TZ(kk) = X(kk-1) - X(kk), 0 at kk = 1 (never assigned in the reference)
 __device__ __forceinline__ double gm_tz(const DevGrid &g, const double *__restrict__ X, int kk, long long o) { return (kk >= 2) ? X[o - g.n2] - X[o] : 0.0; }
-// SF_SLX / SF_SLY (:1680-1700) of cell q at level kk: KAPPA_THIC * slope * dz where kk <= KMT, else 0
-__device__ __forceinline__ double gm_sf(const DevGrid &g, const double *__restrict__ KT, const double *__restrict__ SL, int kk, long long q, long long o) {
-  return (kk <= g.KMT[q]) ? KT[o] * SL[o] * g.dz[kk] : 0.0;
+// SF_SLX / SF_SLY of cell q (3-D index o) at level kk: xy 0 = x (SLX), 1 = y (SLY); face 0 = east / north, 1 = west / south; half 0 =
+// top, 1 = bottom.  Without the transition layer (:1680-1700): KAPPA_THIC * slope * dz where kk <= KMT, else 0.  With it
+// (merged_streamfunction, second part :3585-3741): linear in the diabatic region, quadratic in the transition layer, the plain
+// product in the interior, by the depth of the middle of the half cell
+__device__ __forceinline__ double gm_sf(const DevGrid &g, const GmDev &w, int xy, int face, int half, int kk, long long q, long long o) {
+  if (!(kk <= g.KMT[q])) return 0.0;
+  const double *__restrict__ SL = xy ? w.SLY[2 * face + half] : w.SLX[2 * face + half];
+  if (!w.tlt) return w.KT[half][o] * SL[o] * g.dz[kk];
+  const double rd = half ? g.zt[kk] + 0.25 * g.dz[kk] : g.zt[kk] - 0.25 * g.dz[kk];
+  const double dd = w.DD[q], th = w.TH[q], id = w.ID[q];
+  if (rd > id) return w.KT[half][o] * SL[o] * g.dz[kk];
+  const double wa = w.MW[4 * xy + face][q], wb = w.MW[4 * xy + 2 + face][q];      // WORK1 | WORK3 and WORK2 | WORK4
+  const double w5 = 1.0 / (2.0 * dd + th);                                        // KMT /= 0 here
+  const double lin = rd * w5 * (2.0 * wa + th * wb);
+  if (rd <= dd) return lin;
+  const double w6 = (th > 1.0e-10) ? w5 / th : 0.0, w7 = (dd - rd) * (dd - rd);
+  return -w7 * w6 * (wa + id * wb) + lin;
 }
+
 // Both tracers of the path go through every flux function together: the coefficients (diffusivities, slopes, masks, metrics) are
 // loaded and combined once, the tracer differences enter linearly -- per tracer the operations and their order are the reference's.
 struct Gm2 { double a, b; };
@@ -160,10 +316,10 @@ __device__ __forceinline__ Gm2 gm_fx(const DevGrid &g, const GmDev &w, const dou
   if (!w.cancellation) {
     const int kp1 = (k == km) ? k : k + 1;
     const long long okp = o + (long long)(kp1 - k) * g.n2;
-    const double w1 = w.KI[0][o] * w.SLX[0][o] * g.dz[k] - gm_sf(g, w.KT[0], w.SLX[0], k, q, o);
-    const double w2 = w.KI[1][o] * w.SLX[1][o] * g.dz[k] - gm_sf(g, w.KT[1], w.SLX[1], k, q, o);
-    const double w3 = w.KI[0][o + 1] * w.SLX[2][o + 1] * g.dz[k] - gm_sf(g, w.KT[0], w.SLX[2], k, q + 1, o + 1);
-    const double w4 = w.KI[1][o + 1] * w.SLX[3][o + 1] * g.dz[k] - gm_sf(g, w.KT[1], w.SLX[3], k, q + 1, o + 1);
+    const double w1 = w.KI[0][o] * w.SLX[0][o] * g.dz[k] - gm_sf(g, w, 0, 0, 0, k, q, o);
+    const double w2 = w.KI[1][o] * w.SLX[1][o] * g.dz[k] - gm_sf(g, w, 0, 0, 1, k, q, o);
+    const double w3 = w.KI[0][o + 1] * w.SLX[2][o + 1] * g.dz[k] - gm_sf(g, w, 0, 1, 0, k, q + 1, o + 1);
+    const double w4 = w.KI[1][o + 1] * w.SLX[3][o + 1] * g.dz[k] - gm_sf(g, w, 0, 1, 1, k, q + 1, o + 1);
     f.a = f.a - cx * (w1 * gm_tz(g, X0, k, o) + w2 * gm_tz(g, X0, kp1, okp) + w3 * gm_tz(g, X0, k, o + 1) + w4 * gm_tz(g, X0, kp1, okp + 1));
     f.b = f.b - cx * (w1 * gm_tz(g, X1, k, o) + w2 * gm_tz(g, X1, kp1, okp) + w3 * gm_tz(g, X1, k, o + 1) + w4 * gm_tz(g, X1, kp1, okp + 1));
   }
@@ -177,10 +333,10 @@ __device__ __forceinline__ Gm2 gm_fy(const DevGrid &g, const GmDev &w, const dou
   if (!w.cancellation) {
     const int kp1 = (k == km) ? k : k + 1;
     const long long okp = o + (long long)(kp1 - k) * g.n2;
-    const double w1 = w.KI[0][o] * w.SLY[0][o] * g.dz[k] - gm_sf(g, w.KT[0], w.SLY[0], k, q, o);
-    const double w2 = w.KI[1][o] * w.SLY[1][o] * g.dz[k] - gm_sf(g, w.KT[1], w.SLY[1], k, q, o);
-    const double w3 = w.KI[0][o + nxb] * w.SLY[2][o + nxb] * g.dz[k] - gm_sf(g, w.KT[0], w.SLY[2], k, q + nxb, o + nxb);
-    const double w4 = w.KI[1][o + nxb] * w.SLY[3][o + nxb] * g.dz[k] - gm_sf(g, w.KT[1], w.SLY[3], k, q + nxb, o + nxb);
+    const double w1 = w.KI[0][o] * w.SLY[0][o] * g.dz[k] - gm_sf(g, w, 1, 0, 0, k, q, o);
+    const double w2 = w.KI[1][o] * w.SLY[1][o] * g.dz[k] - gm_sf(g, w, 1, 0, 1, k, q, o);
+    const double w3 = w.KI[0][o + nxb] * w.SLY[2][o + nxb] * g.dz[k] - gm_sf(g, w, 1, 1, 0, k, q + nxb, o + nxb);
+    const double w4 = w.KI[1][o + nxb] * w.SLY[3][o + nxb] * g.dz[k] - gm_sf(g, w, 1, 1, 1, k, q + nxb, o + nxb);
     f.a = f.a - cy * (w1 * gm_tz(g, X0, k, o) + w2 * gm_tz(g, X0, kp1, okp) + w3 * gm_tz(g, X0, k, o + nxb) + w4 * gm_tz(g, X0, kp1, okp + nxb));
     f.b = f.b - cy * (w1 * gm_tz(g, X1, k, o) + w2 * gm_tz(g, X1, kp1, okp) + w3 * gm_tz(g, X1, k, o + nxb) + w4 * gm_tz(g, X1, kp1, okp + nxb));
   }
@@ -201,11 +357,9 @@ __device__ __forceinline__ Gm2 gm_fz(const DevGrid &g, const GmDev &w, const dou
   const double cb = g.dz[k] * w.KI[1][o], ct = g.dz[kp1] * w.KI[0][okp];
   Gm2 r;
   if (!w.cancellation) {
-    const double ktb = (k <= g.KMT[q]) ? w.KT[1][o] : 0.0, ktt = (kp1 <= g.KMT[q]) ? w.KT[0][okp] : 0.0;
-    // SF_SLX / SF_SLY = KAPPA_THIC * slope * dz where the level is in the water, else 0
-    double fb[4], ft[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { fb[t] = (k <= g.KMT[q]) ? ktb * sb[t] * g.dz[k] : 0.0; ft[t] = (kp1 <= g.KMT[q]) ? ktt * st[t] * g.dz[kp1] : 0.0; }
+    // SF_SLX / SF_SLY of the bottom half of level k and of the top half of level k + 1: east, north, west, south
+    const double fb[4] = {gm_sf(g, w, 0, 0, 1, k, q, o), gm_sf(g, w, 1, 0, 1, k, q, o), gm_sf(g, w, 0, 1, 1, k, q, o), gm_sf(g, w, 1, 1, 1, k, q, o)};
+    const double ft[4] = {gm_sf(g, w, 0, 0, 0, kp1, q, okp), gm_sf(g, w, 1, 0, 0, kp1, q, okp), gm_sf(g, w, 0, 1, 0, kp1, q, okp), gm_sf(g, w, 1, 1, 0, kp1, q, okp)};
     auto one = [&](const double *__restrict__ X) {
       double w3 = 0.0;
       w3 = w3 + (cb * faces(X, sb[0], sb[1], sb[2], sb[3], k, o));

@@ -1306,6 +1306,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
   pop_ctx *c = new pop_ctx();
   *out = c;
   c->h.c = *cfg; c->h.rank = rank; c->h.nranks = nranks;
+  if (cfg->hmix_tracer == 3 && cfg->gm_transition_layer == 1 && cfg->vmix_choice == 3) c->h.c.kpp_ml_diagnostics = 1;   // the diabatic depth of the transition layer is the smoothed HMXL (hmix_gm.F90:1226-1228)
   if (tuning && tuning->struct_bytes != (int)sizeof(pop_tuning)) { c->err = "pop_create_tuned: pop_tuning.struct_bytes does not match this library (use pop_tuning_init)"; return 1; }
   tuning_resolve(c->h.tun, tuning);
   c->grid_from_input = grid != nullptr;
@@ -1315,6 +1316,10 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       // in the init routine of the option's own module, e.g. vertical_mix.F90:280-296, POP_SolversMod.F90:442-472)
     auto bad = [&](const std::string &m) { c->err = "pop_create: " + m; return 1; };
     if (cfg->struct_version != POP_CONFIG_VERSION) return bad("pop_config.struct_version is " + std::to_string(cfg->struct_version) + ", this library was built for " + std::to_string(POP_CONFIG_VERSION) + " (include/pop_amd.h)");
+    for (int r = 0; r < 3; ++r) if (cfg->reserved_i[r] != 0) return bad("pop_config.reserved_i must be 0");
+    if (cfg->gm_transition_layer != 0 && cfg->gm_transition_layer != 1) return bad("gm_transition_layer: 0 or 1");
+    if (cfg->gm_transition_layer && cfg->hmix_tracer != 3) return bad("gm_transition_layer needs hmix_tracer = 3");
+    if (cfg->gm_transition_layer && cfg->partial_bottom_cells) return bad("gm_transition_layer with partial_bottom_cells (the DZT branch of smooth_hblt, vmix_kpp.F90:3835-3841) is not built");
     if (cfg->gm_kappa_type != 0 && cfg->gm_kappa_type != 1) return bad("gm_kappa_type: 0 constant, 1 bfre (the other kappa choices of hmix_gm_nml are not built)");
     if (cfg->gm_kappa_freq != 0 && cfg->gm_kappa_freq != 1) return bad("gm_kappa_freq: 0 never, 1 every_time_step (once_a_day is not built)");
     if (cfg->gm_slope_control != 0 && cfg->gm_slope_control != 1) return bad("gm_slope_control: 0 notanh, 1 tanh (slope clipping and the Gerdes et al. form are not built)");
@@ -1558,6 +1563,13 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       std::vector<double> ones(a3g, 1.0);
       HIPCHK(c, hipMemcpy(G.KV, ones.data(), a3g * sizeof(double), hipMemcpyHostToDevice));
     }
+    G.tlt = cfg->gm_transition_layer == 1;
+    if (G.tlt) {   // transition layer: SLA_SAVE of both halves, the layer's 2-D fields, the column terms of the merged stream function
+      const size_t a2g = h.n2 * h.nblocks;
+      for (int t = 0; t < 2; ++t) if (dev_alloc(c, &G.SLA[t], a3g)) return 1;
+      if (dev_alloc(c, &G.DD, a2g) || dev_alloc(c, &G.TH, a2g) || dev_alloc(c, &G.ID, a2g) || dev_alloc(c, &G.KL, a2g) || dev_alloc(c, &G.ZTW, a2g)) return 1;
+      for (int t = 0; t < 8; ++t) if (dev_alloc(c, &G.MW[t], a2g)) return 1;
+    }
     G.HYX = c->d2["gmHYX"]; G.HXY = c->d2["gmHXY"]; G.RBR = c->d2["gmRBR"]; G.DXT = c->d2["DXT"]; G.DYT = c->d2["DYT"];
     if (!G.HYX || !G.HXY || !G.RBR || !G.DXT || !G.DYT) { c->err = "gm: grid fields missing"; return 1; }
     // hmix_gm_nml (hmix_gm.F90:364-428); 0 = the value of the default set-up
@@ -1568,7 +1580,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     G.slm_b = (cfg->slm_b != 0.0) ? cfg->slm_b : 0.3;
     G.slope_tanh = cfg->gm_slope_control == 1;
     G.diff_tapering = G.slm_r != G.slm_b;                              // :964-968
-    G.cancellation = !(G.diff_tapering || G.ah != G.ah_bolus);         // :970-983 (both kappa types 'constant')
+    G.cancellation = !(G.diff_tapering || G.ah != G.ah_bolus) && !G.tlt;   // :970-987 (both kappa types equal)
   }
 #define GI(f) g.f = c->di2[#f]
   GI(KMT); GI(KMU); GI(KMTN); GI(KMTS); GI(KMTE); GI(KMTW); GI(KMTEE); GI(KMTNN);
@@ -2279,10 +2291,20 @@ static int phase_hmix_gm(pop_ctx *c) {
   GmDev G = c->gm;
   G.HBLT = (c->h.c.vmix_choice == 3) ? c->HBLT : nullptr;            // BL_DEPTH = KPP_HBLT | zw(1) (:1210-1212)
   const dim3 G3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks);
-  // compute_kappa (:1258-1332): the first step of the run, or every step
-  if (G.KV && (c->h.c.gm_kappa_freq == 1 || c->nsteps_total == 1))
-    hipLaunchKernelGGL(k_gm_kappa_vertical, dim3(G3.x, c->g.nblocks), dim3(256), 0, c->stream, c->g, G, T, S, step_params(c).grav);
-  hipLaunchKernelGGL(k_gm_coeffs, G3, dim3(256), 0, c->stream, c->g, G, T, S);
+  const dim3 G2(G3.x, c->g.nblocks);
+  const bool kappa_now = G.KV && (c->h.c.gm_kappa_freq == 1 || c->nsteps_total == 1);   // compute_kappa (:1258-1332): the first step of the run, or every step
+  if (G.tlt) {   // :1222-1250, then the tapering with the layer's rules, then merged_streamfunction / apply_vertical_profile (:1668-1674)
+    G.HMXL = (c->h.c.vmix_choice == 3) ? c->HMXL : nullptr;
+    hipLaunchKernelGGL(k_gm_diabatic_depth, G2, dim3(256), 0, c->stream, c->g, G);
+    hipLaunchKernelGGL(k_gm_coeffs<1>, G3, dim3(256), 0, c->stream, c->g, G, T, S);
+    hipLaunchKernelGGL(k_gm_transition_layer, G2, dim3(256), 0, c->stream, c->g, G);
+    if (kappa_now) hipLaunchKernelGGL(k_gm_kappa_vertical, G2, dim3(256), 0, c->stream, c->g, G, T, S, step_params(c).grav);
+    hipLaunchKernelGGL(k_gm_coeffs<2>, G3, dim3(256), 0, c->stream, c->g, G, T, S);
+    hipLaunchKernelGGL(k_gm_msf_column, G2, dim3(256), 0, c->stream, c->g, G);
+  } else {
+    if (kappa_now) hipLaunchKernelGGL(k_gm_kappa_vertical, G2, dim3(256), 0, c->stream, c->g, G, T, S, step_params(c).grav);
+    hipLaunchKernelGGL(k_gm_coeffs<0>, G3, dim3(256), 0, c->stream, c->g, G, T, S);
+  }
   const StepParams sp = step_params(c);
   double *v1 = (sp.nvdc == 2 && c->VDC[1] != c->VDC[0]) ? c->VDC[1] : nullptr;   // one shared array is added to once
   hipLaunchKernelGGL(k_gm_flux, dim3(G3.x, (c->g.km + POP_GM_KC - 1) / POP_GM_KC, G3.z), dim3(256), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);

@@ -12,7 +12,7 @@
    integer (c_int), parameter :: POP_CREATE_HOST_ONLY = 1
 
    ! mirrors `struct pop_config` field for field
-   integer (c_int), parameter :: POP_CONFIG_VERSION = 3
+   integer (c_int), parameter :: POP_CONFIG_VERSION = 4
 
    type, bind(C) :: pop_config
       integer (c_int) :: struct_version = POP_CONFIG_VERSION
@@ -46,6 +46,8 @@
       real (c_double) :: lanczos_convergence_criterion = 0.0_c_double
       real (c_double) :: ah_bolus = 0.0_c_double, ah_bkg_srfbl = 0.0_c_double   ! hmix_gm_nml; 0 = ah
       real (c_double) :: slm_r = 0.0_c_double, slm_b = 0.0_c_double             ! hmix_gm_nml; 0 = 0.3
+      integer (c_int) :: gm_transition_layer = 0                                ! hmix_gm_nml transition_layer_on
+      integer (c_int) :: reserved_i(3) = 0
    end type pop_config
 
    ! mirrors `struct pop_grid_input`: the records of horiz_grid_file / topography_file (grid.F90:1314-1542, 2025-2107)

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from popcfg import named_config  # noqa: E402
 
 FIELDS = [("TRACER", True), ("UVEL", True), ("VVEL", True), ("RHO", True), ("PSURF", False), ("UBTROP", False)]
-NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6, "pcsi_evp": 4, "lw_lim": 5, "pbc_kpp_del4": 5, "padded": 5, "gm": 5}
+NSTEPS = {"const": 4, "kpp_del4": 4, "upwind3": 5, "robert": 6, "pcsi_evp": 4, "lw_lim": 5, "pbc_kpp_del4": 5, "padded": 5, "gm": 5, "gm_tlt": 5}
 
 
 def config(case):
@@ -35,6 +35,9 @@ def config(case):
                             stepped_bathymetry=1, nx_global=24, ny_global=20, km=16, block_size_x=10, block_size_y=8)
     if case == "gm":          # Gent-McWilliams + isopycnal tracer mixing (no cancellation of the skew-flux terms), KPP, stepped bathymetry
         return named_config("tiny", hmix_tracer=3, ah=0.8e7, ah_bolus=0.5e7, slm_b=0.2, vmix_choice=3, stepped_bathymetry=1, **small)
+    if case == "gm_tlt":      # ... with the transition layer and the buoyancy-frequency-dependent kappa recomputed every step (the CESM set-up but for kappa_freq)
+        return named_config("tiny", hmix_tracer=3, ah=0.8e7, ah_bolus=0.5e7, gm_transition_layer=1, gm_kappa_type=1, gm_kappa_freq=1,
+                            vmix_choice=3, stepped_bathymetry=1, **small)
     if case == "upwind3":     # third-order upwind tracer advection + Richardson vmix
         return named_config("tiny", tadvect=2, vmix_choice=2, **small)
     if case == "lw_lim":      # Lax-Wendroff advection with one-dimensional flux limiters + KPP
@@ -53,7 +56,7 @@ def surface_fluxes(tlat):
 def prepare(model, case):
     """Set the surface tracer fluxes (the KPP case needs buoyancy forcing).  `model` is an Oracle or a
     PopModel-like object with f2()/set()."""
-    if case not in ("kpp_del4", "pbc_kpp_del4", "padded", "gm"):
+    if case not in ("kpp_del4", "pbc_kpp_del4", "padded", "gm", "gm_tlt"):
         return
     tlat = model.f2("TLAT") if hasattr(model, "f2") else model.get("TLAT")
     st, ss = surface_fluxes(tlat)

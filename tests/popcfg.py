@@ -36,6 +36,7 @@ class PopConfig(C.Structure):
         ("init_ts_perturbation", C.c_double), ("robert_alpha", C.c_double), ("robert_nu", C.c_double),
         ("lanczos_convergence_criterion", C.c_double),
         ("ah_bolus", C.c_double), ("ah_bkg_srfbl", C.c_double), ("slm_r", C.c_double), ("slm_b", C.c_double),
+        ("gm_transition_layer", C.c_int), ("reserved_i", C.c_int * 3),
     ]
 
 
@@ -44,7 +45,7 @@ def base_config(**kw):
     (vertical_mix.F90:233-240, POP_SolversMod.F90:578-662, pressure_grad.F90:118-119,
     baroclinic.F90:208, vmix_rich.F90:108-110, vmix_const.F90:101-102)."""
     c = PopConfig()
-    c.struct_version = 3
+    c.struct_version = 4
     c.nt = 2
     c.ew_boundary, c.ns_boundary = 1, 0
     c.hmix_momentum = c.hmix_tracer = 2

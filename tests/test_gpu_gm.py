@@ -40,6 +40,13 @@ def _steep(gpu, orc):
     ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1, "ah_bolus": 0.5e7}, 5),   # every step, SDL = HBLT
     ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "km": 60, "tadvect": 2, "gm_slope_control": 1}, 3),
     ("gx3v7", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3}, 3),
+    # transition layer (transition_layer, merged_streamfunction, apply_vertical_profile_to_isop_hor_diff): the diabatic depth is zw(1)
+    # without KPP, the smoothed HMXL with it
+    ("tiny", {"gm_transition_layer": 1, "stepped_bathymetry": 1}, 5),
+    ("tiny", {"gm_transition_layer": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1}, 5),
+    ("tiny", {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1, "ah_bolus": 0.5e7, "slm_b": 0.2}, 5),   # the CESM set-up but for kappa_freq
+    ("tiny", {"gm_transition_layer": 1, "gm_kappa_type": 1, "vmix_choice": 3, "km": 60, "gm_slope_control": 1, "tadvect": 2}, 3),
+    ("gx3v7", {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3}, 3),
     ("test", {"stepped_bathymetry": 1}, 3),                                           # 96 blocks
     ("gx3v7", {"vmix_choice": 3}, 3),
 ])
@@ -78,7 +85,8 @@ def test_gm_on_a_caller_grid(pkg, orclib_built, kw):
     gpu.close(); orc.close()
 
 
-@pytest.mark.parametrize("kw", [{}, {"ah_bolus": 0.3e7, "slm_b": 0.2}, {"vmix_choice": 3, "km": 20, "tadvect": 2}, {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 20}])
+@pytest.mark.parametrize("kw", [{}, {"ah_bolus": 0.3e7, "slm_b": 0.2}, {"vmix_choice": 3, "km": 20, "tadvect": 2}, {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 20},
+                                {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 20}])
 def test_gm_conserves_tracer_content(pkg, kw):
     """every term is a flux form -- east / north fluxes shared by neighbours, the flux through the bottom face of a level is the one
     through the top face of the next, the isopycnal addition to VDC goes through the (conservative) implicit solve: with no surface
@@ -139,3 +147,48 @@ def test_gm_buoyancy_frequency_profile_is_what_it_says(pkg, orclib_built):
     deep_c, deep_b = out[0][:, 15:22], out[1][:, 15:22]
     big = deep_c > 1.0
     assert big.sum() > 50 and np.median(deep_b[big] / deep_c[big]) < 0.5 and (deep_b[big] >= 0.1 * deep_c[big] * (1 - 1e-12)).all()
+
+
+def test_gm_transition_layer_switches_isopycnal_diffusion_off_in_the_diabatic_layer(pkg, orclib_built):
+    """With the transition layer on, KAPPA_ISOP is zero in every half cell whose middle lies within the diabatic depth
+    (apply_vertical_profile_to_isop_hor_diff, hmix_gm.F90:3776-3780) -- so the isopycnal addition to VDC at the bottom of level k,
+    which is made of KAPPA_ISOP of the two half cells around that interface, must be exactly zero wherever the lower of the two
+    (middle at zt(k+1) - dz(k+1)/4) is within the diabatic depth, and present below the layer.  The diabatic depth is recomputed
+    here from the library's own HMXL with the 1-1-4-1-1 filter of smooth_hblt (vmix_kpp.F90:3797-3845), independently."""
+    kw = dict(GM, gm_transition_layer=1, vmix_choice=3, km=24, block_size_x=48, block_size_y=40)
+    cfg = named_config("tiny", **kw)
+    m, o = pkg.PopModel(cfg), Oracle(cfg)
+    force_kpp_case(m, o); _steep(m, o)
+    zt, dz = o.v1("zt").copy(), o.v1("dz").copy()
+    o.close()
+    # the KPP coefficients before the isopycnal part is added: the same state with del2 mixing
+    ref, o2 = pkg.PopModel(named_config("tiny", **dict(kw, hmix_tracer=2, gm_transition_layer=0, kpp_diagnostics=1))), Oracle(named_config("tiny", **dict(kw, hmix_tracer=2, gm_transition_layer=0)))
+    force_kpp_case(ref, o2); _steep(ref, o2); o2.close()
+    for x in (m, ref):
+        x.time_manager(); x.dhdt(); x.baroclinic_driver()
+    add = m.get("VDC", n=0) - ref.get("VDC", n=0)
+    hm, kmt = m.get("HMXL")[0], m.geti("KMT")[0]
+    assert np.array_equal(hm, ref.get("HMXL")[0]) and hm.max() > 3.0 * zt[2]
+    dd = hm.copy()
+    ny, nx = hm.shape
+    for j in range(1, ny - 1):
+        for i in range(1, nx - 1):
+            if kmt[j, i] == 0:
+                continue
+            cw = ce = cn = cs = 0.125; cc = 0.5
+            if kmt[j, i - 1] == 0: cc += cw; cw = 0.0
+            if kmt[j, i + 1] == 0: cc += ce; ce = 0.0
+            if kmt[j - 1, i] == 0: cc += cs; cs = 0.0
+            if kmt[j + 1, i] == 0: cc += cn; cn = 0.0
+            dd[j, i] = cw * hm[j, i - 1] + ce * hm[j, i + 1] + cs * hm[j - 1, i] + cn * hm[j + 1, i] + cc * hm[j, i]
+            dd[j, i] = min(dd[j, i], zt[kmt[j, i]])
+    inner = np.zeros_like(hm, dtype=bool); inner[2:-2, 2:-2] = True
+    nzero = npos = 0
+    for k in range(1, cfg.km - 1):                     # VDC index k = the bottom of level k
+        wet = inner & (k < kmt)
+        within = wet & (zt[k + 1] - 0.25 * dz[k + 1] <= dd)
+        below = wet & (zt[k] + 0.25 * dz[k] > dd + 3.0 * dz[k])
+        assert (add[0, k][within] == 0.0).all(), k
+        nzero += int(within.sum()); npos += int((add[0, k][below] > 0.0).sum())
+    assert nzero > 200 and npos > 200
+    m.close(); ref.close()

@@ -9,7 +9,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 1e-8     # fp64, downstream of the solver's fixed-tree dot products (see test_gpu_parity.py)
 
 
-@pytest.mark.parametrize("case", ["const", "kpp_del4", "upwind3", "robert", "pcsi_evp", "lw_lim", "pbc_kpp_del4", "padded", "gm"])
+@pytest.mark.parametrize("case", ["const", "kpp_del4", "upwind3", "robert", "pcsi_evp", "lw_lim", "pbc_kpp_del4", "padded", "gm", "gm_tlt"])
 def test_gpu_matches_golden(pkg, case):
     import golden.make_golden as mg
     g = np.load(os.path.join(GOLD, "golden_%s.npz" % case))
