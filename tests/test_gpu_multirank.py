@@ -95,6 +95,7 @@ def test_multirank_equals_single_rank(nranks, kw, env):
     (3, "block_size_x=24,block_size_y=20,vmix_choice=3,km=24", {}),   # uneven ownership, KPP
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3
     (4, "tadvect=3,block_size_x=24,block_size_y=20", {}),             # lw_lim, one block per rank
+    (2, "hmix_tracer=3,ah=0.8e7,gm_transition_layer=1,gm_kappa_type=1,gm_kappa_freq=1,vmix_choice=3,km=24", {}),   # ... with the transition layer (the filter over HMXL reads ghost columns) and 'bfre' kappa
     (3, "hmix_tracer=3,ah=0.8e7,ah_bolus=0.5e7,vmix_choice=3,km=24,block_size_x=24,block_size_y=20", {}),   # Gent-McWilliams (no exchange of its own: ghost cells of the mix-time tracers), uneven ownership
     (2, "km=62,vmix_choice=3,ny_global=80,block_size_x=48,block_size_y=40", {"POP_VMIXU_DEFER": "1", "POP_SOLVER_DISTRIBUTED": "1"}),   # U,V vertical mixing held back past the distributed solve
     (2, "hmix_momentum=4,hmix_tracer=4,am=-1.0e22,ah=-1.0e21,ny_global=80,block_size_x=48,block_size_y=40", {"POP_D2T_FUSE": "1", "POP_SOLVER_DISTRIBUTED": "1"}),   # del4 first Laplacians formed ahead; the momentum kernel runs in three pieces beside the T,S halo
