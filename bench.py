@@ -349,8 +349,8 @@ def main():
         cfg.partial_bottom_cells = 1
     if args.gm:   # the 1-degree production tracer mixing (namelist_defaults_pop.xml hmix_tracer_choice 'gm' on the gx grids)
         cfg.hmix_tracer, cfg.ah = 3, 0.8e7
-        if args.gm == "cesm":   # transition layer + buoyancy-frequency-dependent kappa, recomputed every step (the namelist default recomputes it once a day)
-            cfg.gm_transition_layer, cfg.gm_kappa_type, cfg.gm_kappa_freq = 1, 1, 1
+        if args.gm == "cesm":   # the namelist defaults of the gx grids: transition layer + buoyancy-frequency-dependent kappa recomputed once a day
+            cfg.gm_transition_layer, cfg.gm_kappa_type, cfg.gm_kappa_freq = 1, 1, 2
     model = pkg.PopModel(cfg, rank=rank, nranks=world)
     comm, transport, transport_note = None, "none", ""
     if world > 1:
@@ -517,7 +517,7 @@ def main():
                    "block_size": [cfg.block_size_x, cfg.block_size_y], "steps_per_day": cfg.steps_per_day, "step_calls_per_day": calls_per_day,
                    "land_tile_fraction": round(land_frac, 4), "distribution": "balanced-ocean-columns" if cfg.distribution_type else "equal-block-counts",
                    "blocks_local": model.nblocks,
-                   "hmix": "del%d" % cfg.hmix_momentum, "hmix_tracer": {2: "del2", 3: "gm" + ("(transition layer, bfre kappa every step)" if cfg.gm_transition_layer else "(constant kappa)"), 4: "del4"}[cfg.hmix_tracer], "vmix": ["const", "rich", "kpp"][vm],
+                   "hmix": "del%d" % cfg.hmix_momentum, "hmix_tracer": {2: "del2", 3: "gm" + ("(transition layer, bfre kappa once a day)" if cfg.gm_transition_layer else "(constant kappa)"), 4: "del4"}[cfg.hmix_tracer], "vmix": ["const", "rich", "kpp"][vm],
                    "partial_bottom_cells": bool(cfg.partial_bottom_cells), "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport,
                    # every output of the step is bitwise what the full evaluation gives (tests/test_gpu_parity.py); DESIGN.md 3, "KPP's surface-layer buoyancy difference on demand"

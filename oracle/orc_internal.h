@@ -49,6 +49,7 @@ struct orc_model {
   /* time stepping */
   double dtt, dtu, dtp, c2dtu, c2dtp, beta;
   int first_step, leapfrogts, f_euler_ts, avg_ts, nsteps_total, nsteps_this_interval, nsteps_per_interval;
+  int eod, eod_last;          /* the step ends a day / the previous one did (time_management.F90:1809, 3586-3592), for runs that start at midnight */
   /* kpp */
   void *kpp;
   void *del4;

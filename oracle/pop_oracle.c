@@ -930,6 +930,9 @@ void orc_time_manager(orc_model *m) {
     m->nsteps_this_interval = m->nsteps_this_interval + 1;
     if (m->nsteps_this_interval > m->nsteps_per_interval) m->nsteps_this_interval = 1;
   }
+  /* end of day: with avgfit the fit interval is one day; without averaging steps every steps_per_day-th step ends at midnight */
+  m->eod_last = m->eod;
+  m->eod = (c->tmix_opt == 2) ? (m->nsteps_this_interval == m->nsteps_per_interval) : (m->nsteps_total % c->steps_per_day == 0);
   if (m->first_step) { m->leapfrogts = 0; m->f_euler_ts = 1; m->first_step = 0; }
   if (c->tmix_opt == 1) {
     if (m->nsteps_total % c->time_mix_freq == 0) m->avg_ts = 1;

@@ -143,6 +143,7 @@ struct pop_ctx {
   // time stepping
   int oldt = 0, curt = 1, newt = 2, mixt = 1;
   int first_step = 1, leapfrogts = 1, f_euler_ts = 0, avg_ts = 0, nsteps_total = 0, nsteps_this_interval = 0;
+  int eod = 0, eod_last = 0;                               // the step ends a day / the previous one did (time_management.F90:1809, 3586-3592; runs that start at midnight)
   double c2dtt = 0, c2dtu = 0, c2dtp = 0, beta = 0;
   std::map<std::string, PhaseTimer> timers;
   // the barotropic solve bracketed by two events on the launch stream, read back one step later (no synchronisation inside the
@@ -1321,7 +1322,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     if (cfg->gm_transition_layer && cfg->hmix_tracer != 3) return bad("gm_transition_layer needs hmix_tracer = 3");
     if (cfg->gm_transition_layer && cfg->partial_bottom_cells) return bad("gm_transition_layer with partial_bottom_cells (the DZT branch of smooth_hblt, vmix_kpp.F90:3835-3841) is not built");
     if (cfg->gm_kappa_type != 0 && cfg->gm_kappa_type != 1) return bad("gm_kappa_type: 0 constant, 1 bfre (the other kappa choices of hmix_gm_nml are not built)");
-    if (cfg->gm_kappa_freq != 0 && cfg->gm_kappa_freq != 1) return bad("gm_kappa_freq: 0 never, 1 every_time_step (once_a_day is not built)");
+    if (cfg->gm_kappa_freq < 0 || cfg->gm_kappa_freq > 2) return bad("gm_kappa_freq: 0 never, 1 every_time_step, 2 once_a_day");
+    if (cfg->gm_kappa_freq == 2 && cfg->tmix_opt == 1) return bad("gm_kappa_freq = once_a_day with time_mix_opt 'avg' (half steps that do not fit the day: the end-of-day test of time_management.F90:3586-3592 on the calendar) is not built: avgfit, robert or none");
     if (cfg->gm_slope_control != 0 && cfg->gm_slope_control != 1) return bad("gm_slope_control: 0 notanh, 1 tanh (slope clipping and the Gerdes et al. form are not built)");
     if (cfg->ah_bolus < 0.0 || cfg->ah_bkg_srfbl < 0.0 || cfg->slm_r < 0.0 || cfg->slm_b < 0.0) return bad("ah_bolus, ah_bkg_srfbl, slm_r, slm_b: >= 0 (0 = ah, ah, 0.3, 0.3)");
     if (cfg->partial_bottom_cells != 0 && cfg->partial_bottom_cells != 1) return bad("partial_bottom_cells: 0 or 1");
@@ -2211,6 +2213,8 @@ int pop_time_manager(pop_ctx *c) {
   c->leapfrogts = 1; c->f_euler_ts = 0; c->avg_ts = 0;
   c->nsteps_total += 1;
   if (cf.tmix_opt == 2) { c->nsteps_this_interval += 1; if (c->nsteps_this_interval > c->h.nsteps_per_interval) c->nsteps_this_interval = 1; }
+  c->eod_last = c->eod;
+  c->eod = (cf.tmix_opt == 2) ? (c->nsteps_this_interval == c->h.nsteps_per_interval) : (c->nsteps_total % cf.steps_per_day == 0);
   if (c->first_step) { c->leapfrogts = 0; c->f_euler_ts = 1; c->first_step = 0; }
   if (cf.tmix_opt == 1 && c->nsteps_total % cf.time_mix_freq == 0) c->avg_ts = 1;
   if (cf.tmix_opt == 2) {
@@ -2292,7 +2296,7 @@ static int phase_hmix_gm(pop_ctx *c) {
   G.HBLT = (c->h.c.vmix_choice == 3) ? c->HBLT : nullptr;            // BL_DEPTH = KPP_HBLT | zw(1) (:1210-1212)
   const dim3 G3((c->g.n2 + 255) / 256, c->g.km, c->g.nblocks);
   const dim3 G2(G3.x, c->g.nblocks);
-  const bool kappa_now = G.KV && (c->h.c.gm_kappa_freq == 1 || c->nsteps_total == 1);   // compute_kappa (:1258-1332): the first step of the run, or every step
+  const bool kappa_now = G.KV && (c->h.c.gm_kappa_freq == 1 || c->nsteps_total == 1 || (c->h.c.gm_kappa_freq == 2 && c->eod_last));   // compute_kappa (:1258-1332): the first step of the run, or every step
   if (G.tlt) {   // :1222-1250, then the tapering with the layer's rules, then merged_streamfunction / apply_vertical_profile (:1668-1674)
     G.HMXL = (c->h.c.vmix_choice == 3) ? c->HMXL : nullptr;
     hipLaunchKernelGGL(k_gm_diabatic_depth, G2, dim3(256), 0, c->stream, c->g, G);

@@ -47,6 +47,9 @@ def _steep(gpu, orc):
     ("tiny", {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1, "ah_bolus": 0.5e7, "slm_b": 0.2}, 5),   # the CESM set-up but for kappa_freq
     ("tiny", {"gm_transition_layer": 1, "gm_kappa_type": 1, "vmix_choice": 3, "km": 60, "gm_slope_control": 1, "tadvect": 2}, 3),
     ("gx3v7", {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3}, 3),
+    # kappa_freq 'once_a_day': recomputed at the first step after a day has ended (two day boundaries inside the run)
+    ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 2, "steps_per_day": 6, "time_mix_freq": 4, "vmix_choice": 3, "km": 20}, 20),   # avgfit: the fit interval is the day
+    ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 2, "gm_transition_layer": 1, "steps_per_day": 8, "tmix_opt": 3}, 18),          # Robert filter: every eighth step ends a day
     ("test", {"stepped_bathymetry": 1}, 3),                                           # 96 blocks
     ("gx3v7", {"vmix_choice": 3}, 3),
 ])
