@@ -38,6 +38,8 @@ def parse_hdr(path):
     ({"block_size_x": 48, "block_size_y": 40}, 3, 3),     # one block
     ({"ns_boundary": 2, "grid": 1}, 4, 4),                # tripole fold on a caller-supplied grid: U-grid fields re-read as NE-corner vectors
     ({"ns_boundary": 0, "grid": 1, "vmix_choice": 3, "km": 24}, 3, 3),
+    # Gent-McWilliams with the transition layer: everything it uses is formed from the restart fields each step (kappa every step)
+    ({"hmix_tracer": 3, "ah": 0.8e7, "ah_bolus": 0.5e7, "gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24}, 4, 4),
 ])
 def test_exact_restart(pkg, tmp_path, kw, n1, n2):
     """The reference's restart contract (CESM ERS test): n1 steps + write + read into a fresh context + n2 steps is
