@@ -752,3 +752,63 @@ def check_lw_lim_monotone(A):
             expect = float(ute[b, j, istep] * jump)
             assert abs(lost - expect) <= 1e-11 * abs(expect), "transport across the step: %r vs %r" % (lost, expect)
     return True
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Gent-McWilliams / isopycnal mixing (hmix_gm.F90): a field linear in the grid indices has closed-form fluxes
+# ------------------------------------------------------------------------------------------------------------------
+def check_gm_linear(A, tol=2e-12):
+    """T = T0 + a i + b k (b < 0: stably stratified; uniform salinity; at rest), constant kappa, ah_bolus = ah, well below the
+    boundary layer and inside the slope limits, open ocean away from coasts, on the lat-lon grid (metrics uniform in i).
+    Then every isopycnal slope is S = RX / RZ = a / (-b) (the expansion coefficient cancels), every taper is 1 and:
+      * the east-face fluxes FX = dz CX TX (8 kappa) are equal at i and i - 1 -> no horizontal contribution, FY = 0;
+      * the flux through the bottom face is fz(k) = - kappa S a HYX (dz(k) + dz(k+1)) (hmix_gm.F90:2011-2050 with SLX = S, TX = a),
+        so the tendency is GTK(k) = (fz(k-1) - fz(k)) / (dz(k) TAREA) = kappa S a HYX (dz(k+1) - dz(k-1)) / (dz(k) TAREA);
+      * the isopycnal part added to the vertical diffusivity at the bottom of level k (:1725-1748) is
+        kappa S^2 HYX dzw(k)^2 / TAREA  (= kappa times the squared true slope S dzw / dx, as it should be).
+    HYX = HTE / HUS.  The second tracer, uniform, has no tendency at all."""
+    assert A.cfg.hmix_tracer == 3 and A.cfg.vmix_choice == 1 and A.cfg.ah_bolus == 0.0 and A.cfg.gm_transition_layer == 0
+    c2dt, kmt, shp = _adv_setup(A, 0.0)
+    km = A.km
+    a, b, t0 = 2.0 ** -5, -(2.0 ** -2), 20.0
+    ii = np.arange(shp[-1], dtype=np.float64)[None, None, None, :]
+    kk = np.arange(km, dtype=np.float64)[None, :, None, None]
+    field = [t0 + a * ii + b * kk + np.zeros(shp), 0.035 + np.zeros(shp)]
+    for n in range(2):
+        for tl in range(3):
+            A.set("TRACER", field[n], tl, n)
+    A.dhdt()
+    A.run_phase("vmix")
+    A.run_phase("hmix_tracer")
+    A.run_phase("tracer_rhs")
+    ok = _patch(kmt, km, r=4)
+    kappa, S = A.cfg.ah, a / (-b)
+    dz, dzw = A.vert("dz"), A.vert("dzw")
+    hyx = A.get("HTE") / A.get("HUS")
+    tarea = A.get("TAREA")
+    assert np.abs(hyx - np.roll(hyx, 1, axis=2))[ok].max() <= 1e-14 * hyx[ok].max()      # the premise: metrics uniform in i
+    vdc_all = A.get("VDC", 1, 0)
+    vdc = vdc_all - A.cfg.const_vdc
+    gt = [A.get("TRACER", 2, n) / c2dt for n in range(2)]
+    dzr, dzwr = 1.0 / dz[1:km + 1], A.vert("dzwr")
+    worst_g = worst_v = 0.0
+    levels = list(range(4, km - 1))
+    nsig = 0
+    for k in levels:
+        exp_v = kappa * S * S * hyx * dzw[k] * dzw[k] / tarea
+        worst_v = max(worst_v, float(np.abs(vdc[:, k] - exp_v)[ok].max() / np.abs(exp_v)[ok].max()))
+        # the right-hand side also holds the explicit vertical diffusion of the old tracer with the (now larger) diffusivity
+        # (vdifft, vertical_mix.F90:795-806): VDTK(k) = (VDC(k-1) (T(k-1) - T(k)) dzwr(k-1) - VDC(k) (T(k) - T(k+1)) dzwr(k)) dzr(k)
+        vdtk = (vdc_all[:, k - 1] * (-b) * dzwr[k - 1] - vdc_all[:, k] * (-b) * dzwr[k]) * dzr[k - 1]
+        exp_g = kappa * S * a * hyx * (dz[k + 1] - dz[k - 1]) / (dz[k] * tarea)
+        rem = gt[0][:, k - 1] - vdtk
+        floor = 4.0e-16 * np.abs(vdtk)[ok].max()                                           # what the subtraction leaves of rounding
+        # levels where the closed form is a difference of two nearly equal fluxes (dz no longer changing) say nothing
+        if abs(dz[k + 1] - dz[k - 1]) > 1.0e-3 * dz[k] and np.abs(exp_g)[ok].max() > 1.0e4 * floor:
+            nsig += 1
+            worst_g = max(worst_g, float((np.abs(rem - exp_g)[ok].max() - floor) / np.abs(exp_g)[ok].max()))
+        assert np.abs(gt[1][:, k - 1])[ok].max() == 0.0
+    assert nsig >= 4
+    assert worst_g <= 1.0e-9, "GM tendency of a linear field differs from the closed form by %.3e" % worst_g     # what is left after the subtraction
+    assert worst_v <= tol, "isopycnal part of VDC differs from kappa S^2 HYX dzw^2 / TAREA by %.3e" % worst_v
+    return worst_g, worst_v

@@ -82,3 +82,9 @@ def test_limited_advection_creates_no_new_extremum(orclib_built):
     A = pins.OracleAdapter(named_config("tiny", ah=0.0, tadvect=3, block_size_x=48, block_size_y=40))
     pins.check_lw_lim_monotone(A)
     A.close()
+
+
+def test_gm_fluxes_of_a_linear_field_are_the_closed_form(orclib_built):
+    A = pins.OracleAdapter(named_config("tiny", hmix_tracer=3, ah=0.8e7, km=20, block_size_x=48, block_size_y=40))
+    print(pins.check_gm_linear(A))
+    A.close()
