@@ -767,7 +767,7 @@ def check_gm_linear(A, tol=2e-12):
       * the isopycnal part added to the vertical diffusivity at the bottom of level k (:1725-1748) is
         kappa S^2 HYX dzw(k)^2 / TAREA  (= kappa times the squared true slope S dzw / dx, as it should be).
     HYX = HTE / HUS.  The second tracer, uniform, has no tendency at all."""
-    assert A.cfg.hmix_tracer == 3 and A.cfg.vmix_choice == 1 and A.cfg.ah_bolus == 0.0 and A.cfg.gm_transition_layer == 0
+    assert A.cfg.hmix_tracer == 3 and A.cfg.vmix_choice == 1 and A.cfg.gm_transition_layer == 0
     c2dt, kmt, shp = _adv_setup(A, 0.0)
     km = A.km
     a, b, t0 = 2.0 ** -5, -(2.0 ** -2), 20.0
@@ -783,6 +783,10 @@ def check_gm_linear(A, tol=2e-12):
     A.run_phase("tracer_rhs")
     ok = _patch(kmt, km, r=4)
     kappa, S = A.cfg.ah, a / (-b)
+    # ah_bolus /= ah (the branch without cancellation, :1832-1992): the skew terms of FX are uniform in i too, and the vertical flux is
+    # -1/4 [dz kappa S a + kappa_b S dz a + ...] summed over the four quarter cells = the formula above with (kappa + kappa_b) / 2
+    kappa_b = A.cfg.ah_bolus if A.cfg.ah_bolus != 0.0 else kappa
+    kappa_f = 0.5 * (kappa + kappa_b)
     dz, dzw = A.vert("dz"), A.vert("dzw")
     hyx = A.get("HTE") / A.get("HUS")
     tarea = A.get("TAREA")
@@ -800,7 +804,7 @@ def check_gm_linear(A, tol=2e-12):
         # the right-hand side also holds the explicit vertical diffusion of the old tracer with the (now larger) diffusivity
         # (vdifft, vertical_mix.F90:795-806): VDTK(k) = (VDC(k-1) (T(k-1) - T(k)) dzwr(k-1) - VDC(k) (T(k) - T(k+1)) dzwr(k)) dzr(k)
         vdtk = (vdc_all[:, k - 1] * (-b) * dzwr[k - 1] - vdc_all[:, k] * (-b) * dzwr[k]) * dzr[k - 1]
-        exp_g = kappa * S * a * hyx * (dz[k + 1] - dz[k - 1]) / (dz[k] * tarea)
+        exp_g = kappa_f * S * a * hyx * (dz[k + 1] - dz[k - 1]) / (dz[k] * tarea)
         rem = gt[0][:, k - 1] - vdtk
         floor = 4.0e-16 * np.abs(vdtk)[ok].max()                                           # what the subtraction leaves of rounding
         # levels where the closed form is a difference of two nearly equal fluxes (dz no longer changing) say nothing

@@ -108,7 +108,8 @@ def test_limited_advection_creates_no_new_extremum(pkg):
     A.close()
 
 
-def test_gm_fluxes_of_a_linear_field_are_the_closed_form(pkg, orclib_built):
-    A = pins.GpuAdapter(pkg, named_config("tiny", hmix_tracer=3, ah=0.8e7, km=20, block_size_x=48, block_size_y=40))
+@pytest.mark.parametrize("ah_bolus", [0.0, 0.3e7])
+def test_gm_fluxes_of_a_linear_field_are_the_closed_form(pkg, orclib_built, ah_bolus):
+    A = pins.GpuAdapter(pkg, named_config("tiny", hmix_tracer=3, ah=0.8e7, ah_bolus=ah_bolus, km=20, block_size_x=48, block_size_y=40))
     pins.check_gm_linear(A)
     A.close()
