@@ -155,6 +155,7 @@ typedef struct pop_tuning {
   int pbc_generic_thomas;  /* 1: partial bottom cells with the scratch-staged Thomas kernels even at km = 60 / 62 */
   int pbc_generic_kpp;     /* 1: partial bottom cells with the 3-D-parallel / scratch-staged KPP kernels on large grids too */
   int stream_priority;     /* 1: the launch stream above the gap-filling side streams (default 0: measured slower) */
+  int gm_sf_stored;        /* 0: Gent-McWilliams without cancellation: the stream-function terms SF_SLX / SF_SLY re-derived in the flux kernel instead of stored */
   int state3d_levels;      /* density of a whole 3-D array: levels per thread, 4 (default) | 2 | 8 with the per-level EOS coefficients read from
                             * a table, 1 = one cell per thread with the coefficients formed in place */
 } pop_tuning;

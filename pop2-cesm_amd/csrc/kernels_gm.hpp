@@ -32,6 +32,9 @@ struct GmDev {
   int *KL, *ZTW;                    // TLT%K_LEVEL, ZTW
   double *MW[8];                    // merged_streamfunction: WORK1, WORK2 (x) and WORK3, WORK4 (y) of the east|north and west|south side: [2 * w + face], w = 0..3
   const double *HMXL;
+  // branch without cancellation: SF_SLX / SF_SLY of every half cell stored by k_gm_sf (as the reference stores them) instead of being
+  // re-derived at each of the ~24 places of the flux kernel that read one; [4 * xy + 2 * face + half]; nullptr: formed in place
+  double *SF[8];
   const double *HYX, *HXY, *RBR, *DXT, *DYT, *HBLT;   // HBLT: nullptr without KPP (BL_DEPTH = zw(1))
   double ah, ah_bolus, ah_bkg_srfbl, slm_r, slm_b;
   int diff_tapering, cancellation, slope_tanh;
@@ -289,7 +292,7 @@ __device__ __forceinline__ double gm_tz(const DevGrid &g, const double *__restri
 // top, 1 = bottom.  Without the transition layer (:1680-1700): KAPPA_THIC * slope * dz where kk <= KMT, else 0.  With it
 // (merged_streamfunction, second part :3585-3741): linear in the diabatic region, quadratic in the transition layer, the plain
 // product in the interior, by the depth of the middle of the half cell
-__device__ __forceinline__ double gm_sf(const DevGrid &g, const GmDev &w, int xy, int face, int half, int kk, long long q, long long o) {
+__device__ __forceinline__ double gm_sf_form(const DevGrid &g, const GmDev &w, int xy, int face, int half, int kk, long long q, long long o) {
   if (!(kk <= g.KMT[q])) return 0.0;
   const double *__restrict__ SL = xy ? w.SLY[2 * face + half] : w.SLX[2 * face + half];
   if (!w.tlt) return w.KT[half][o] * SL[o] * g.dz[kk];
@@ -302,6 +305,24 @@ __device__ __forceinline__ double gm_sf(const DevGrid &g, const GmDev &w, int xy
   if (rd <= dd) return lin;
   const double w6 = (th > 1.0e-10) ? w5 / th : 0.0, w7 = (dd - rd) * (dd - rd);
   return -w7 * w6 * (wa + id * wb) + lin;
+}
+
+__device__ __forceinline__ double gm_sf(const DevGrid &g, const GmDev &w, int xy, int face, int half, int kk, long long q, long long o) {
+  if (w.SF[0]) return w.SF[4 * xy + 2 * face + half][o];
+  return gm_sf_form(g, w, xy, face, half, kk, q, o);
+}
+__global__ void __launch_bounds__(256)
+k_gm_sf(DevGrid g, GmDev w) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x;
+  const int kk = blockIdx.y + 1, b = blockIdx.z;
+  if (p2 >= g.n2) return;
+  const long long q = (long long)b * g.n2 + p2, o = (long long)b * g.n3 + (long long)(kk - 1) * g.n2 + p2;
+#pragma unroll
+  for (int xy = 0; xy < 2; ++xy)
+#pragma unroll
+    for (int face = 0; face < 2; ++face)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) w.SF[4 * xy + 2 * face + half][o] = gm_sf_form(g, w, xy, face, half, kk, q, o);
 }
 
 // Both tracers of the path go through every flux function together: the coefficients (diffusivities, slopes, masks, metrics) are

@@ -1258,7 +1258,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -1583,6 +1583,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     G.slope_tanh = cfg->gm_slope_control == 1;
     G.diff_tapering = G.slm_r != G.slm_b;                              // :964-968
     G.cancellation = !(G.diff_tapering || G.ah != G.ah_bolus) && !G.tlt;   // :970-987 (both kappa types equal)
+    if (!G.cancellation && !tun_off(h.tun.gm_sf_stored)) for (int t = 0; t < 8; ++t) if (dev_alloc(c, &G.SF[t], a3g)) return 1;
   }
 #define GI(f) g.f = c->di2[#f]
   GI(KMT); GI(KMU); GI(KMTN); GI(KMTS); GI(KMTE); GI(KMTW); GI(KMTEE); GI(KMTNN);
@@ -2311,6 +2312,7 @@ static int phase_hmix_gm(pop_ctx *c) {
   }
   const StepParams sp = step_params(c);
   double *v1 = (sp.nvdc == 2 && c->VDC[1] != c->VDC[0]) ? c->VDC[1] : nullptr;   // one shared array is added to once
+  if (G.SF[0]) hipLaunchKernelGGL(k_gm_sf, G3, dim3(256), 0, c->stream, c->g, G);   // without cancellation: SF_SLX, SF_SLY once per half cell
   hipLaunchKernelGGL(k_gm_flux, dim3(G3.x, (c->g.km + POP_GM_KC - 1) / POP_GM_KC, G3.z), dim3(256), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
   HIPCHK(c, hipGetLastError());
   return 0;

@@ -66,7 +66,7 @@
       integer (c_int) :: kpp_lazy, kpp_ushear_hint, kpp_ushear_margin, kpp_side_stream, kpp_buoy_waves, kpp_interior_generic
       integer (c_int) :: kpp_src_full, solver_unfused, solver_nograph, solver_presum, solver_distributed, solver_overlap_off
       integer (c_int) :: fpcg_b2, pcsi_step2, halo_separate, halo_overlap_off, rccl_overlap, evp_wave
-      integer (c_int) :: fpcg_a_pair, kpp_sparse, pbc_generic_thomas, pbc_generic_kpp, stream_priority, state3d_levels
+      integer (c_int) :: fpcg_a_pair, kpp_sparse, pbc_generic_thomas, pbc_generic_kpp, stream_priority, gm_sf_stored, state3d_levels
    end type pop_tuning
 
    type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task

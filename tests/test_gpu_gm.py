@@ -195,3 +195,19 @@ def test_gm_transition_layer_switches_isopycnal_diffusion_off_in_the_diabatic_la
         nzero += int(within.sum()); npos += int((add[0, k][below] > 0.0).sum())
     assert nzero > 200 and npos > 200
     m.close(); ref.close()
+
+
+@pytest.mark.parametrize("kw", [{"ah_bolus": 0.4e7, "stepped_bathymetry": 1}, {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24}])
+def test_gm_stored_stream_function_terms_are_bitwise_the_re_derived_ones(pkg, monkeypatch, kw):
+    """k_gm_sf stores SF_SLX / SF_SLY of every half cell once (the reference's arrays); POP_GM_SF_STORED=0 re-derives them at every use
+    in the flux kernel: the same function, so the same bits"""
+    out = {}
+    for st in ("1", "0"):
+        monkeypatch.setenv("POP_GM_SF_STORED", st)
+        m = pkg.PopModel(named_config("tiny", **dict(GM, **kw)))
+        for _ in range(4):
+            m.step()
+        out[st] = [m.get("TRACER", 1, n).copy() for n in (0, 1)] + [m.get("VDC", n=0).copy(), m.get("UVEL", 1).copy()]
+        m.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
