@@ -72,7 +72,8 @@ def test_gm_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
         assert (vd > 10.0 * cfg.const_vdc).sum() > 50 and (vd == cfg.const_vdc).sum() > 50
 
 
-@pytest.mark.parametrize("kw", [{"ns_boundary": 2}, {"ns_boundary": 2, "vmix_choice": 3, "km": 24, "ah_bolus": 0.5e7}, {"ns_boundary": 0, "ew_boundary": 0}])
+@pytest.mark.parametrize("kw", [{"ns_boundary": 2}, {"ns_boundary": 2, "vmix_choice": 3, "km": 24, "ah_bolus": 0.5e7}, {"ns_boundary": 0, "ew_boundary": 0},
+                                {"ns_boundary": 2, "vmix_choice": 3, "km": 24, "gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1}])   # the filter over HMXL next to the fold
 def test_gm_on_a_caller_grid(pkg, orclib_built, kw):
     """tripole fold and closed boundaries on a grid supplied by the caller (the scheme exchanges nothing: everything is formed from the
     mix-time tracers' own ghost cells)"""

@@ -45,6 +45,9 @@ def block_masks(m):
     ("tiny", {"block_size_x": 20, "block_size_y": 16, "stepped_bathymetry": 1, "partial_bottom_cells": 1, "tmix_opt": 3}, 4),
     ("tiny", {"block_size_x": 20, "block_size_y": 16, "tadvect": 3, "vmix_choice": 2}, 4),
     ("gx3v7", {"block_size_x": 64, "block_size_y": 50}, 3),                                   # 100 x 116 in 2 x 3 blocks
+    # Gent-McWilliams: whole-block kernels that also run over the padding (nothing there is read by a cell that exists)
+    ("tiny", {"block_size_x": 20, "block_size_y": 16, "hmix_tracer": 3, "ah": 0.8e7, "ah_bolus": 0.5e7, "stepped_bathymetry": 1}, 4),
+    ("tiny", {"block_size_x": 20, "block_size_y": 16, "hmix_tracer": 3, "ah": 0.8e7, "gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24}, 4),
 ])
 def test_padded_blocks_step_phases_match_oracle(pkg, orclib_built, name, kw, nsteps):
     cfg = named_config(name, **kw)
