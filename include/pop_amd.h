@@ -94,7 +94,9 @@ typedef struct pop_config {
   double slm_r, slm_b;                   /* maximum slope for isopycnal / thickness diffusion, 0 = 0.3 */
   int gm_transition_layer;               /* hmix_gm_nml transition_layer_on (hmix_gm.F90:3183-3848: transition_layer, merged_streamfunction,
                                           * apply_vertical_profile_to_isop_hor_diff); with KPP the diabatic depth is the smoothed HMXL */
-  int reserved_i[3];                     /* must be 0 */
+  int gm_diag_bolus;                     /* hmix_gm_nml diag_gm_bolus: 1 = the eddy-induced (bolus) velocity of hdifft_gm (hmix_gm.F90:2079-2151) every step:
+                                          * fields "UISOP", "VISOP" (east / north face of the T cell) and "WISOP" (top of the T cell); nothing on the path reads them */
+  int reserved_i[2];                     /* must be 0 */
 } pop_config;
 
 typedef struct pop_ctx pop_ctx;

@@ -63,7 +63,8 @@ typedef struct {
   double init_ts_perturbation, robert_alpha, robert_nu, lanczos_convergence_criterion;
   double ah_bolus, ah_bkg_srfbl, slm_r, slm_b;   /* hmix_gm_nml; 0 = ah, ah, 0.3, 0.3 */
   int gm_transition_layer;
-  int reserved_i[3];
+  int gm_diag_bolus;
+  int reserved_i[2];
 } orc_config;
 
 typedef struct orc_model orc_model;

@@ -3,7 +3,7 @@
 // set-up the code's own hmix_gm_nml defaults give: constant kappa (KAPPA_VERTICAL = 1), kappa_freq 'never', no transition layer,
 // use_const_ah_bkg_srfbl, ah_bkg_bottom = 0, slope control 'notanh' | 'tanh'; ah_bolus /= ah or slm_b /= slm_r take the branch
 // without cancellation of the skew-flux terms.  kappa type 'bfre' (buoyancy_frequency_dependent_profile :3011-3180; kappa_*_deep = 0.1,
-// kappa_freq 'never' | 'every_time_step'): k_gm_kappa_vertical, a column march.  Bolus-velocity diagnostics are not formed.
+// kappa_freq 'never' | 'every_time_step'): k_gm_kappa_vertical, a column march.  Transition layer: see k_gm_coeffs.  Bolus velocity (diag_gm_bolus): k_gm_bolus.
 //
 // The reference works level by level and carries whole-block work arrays (TX, TY, TZ, RX, RY, SF_SLX, SF_SLY, FZTOP) from level to
 // level; here every value is a function of the mix-time tracers at the cell and its neighbours one level up / down, so two
@@ -35,6 +35,8 @@ struct GmDev {
   // branch without cancellation: SF_SLX / SF_SLY of every half cell stored by k_gm_sf (as the reference stores them) instead of being
   // re-derived at each of the ~24 places of the flux kernel that read one; [4 * xy + 2 * face + half]; nullptr: formed in place
   double *SF[8];
+  double *UISOP, *VISOP, *WISOP;   // diag_gm_bolus: U_ISOP, V_ISOP (east / north face), WTOP_ISOP (top of the cell) of every level; nullptr: off
+  const double *HTE, *HTN;
   const double *HYX, *HXY, *RBR, *DXT, *DYT, *HBLT;   // HBLT: nullptr without KPP (BL_DEPTH = zw(1))
   double ah, ah_bolus, ah_bkg_srfbl, slm_r, slm_b;
   int diff_tapering, cancellation, slope_tanh;
@@ -447,6 +449,56 @@ k_gm_flux(DevGrid g, GmDev w, const double *__restrict__ X0, const double *__res
       }
     }
     w.GTK[0][o] = gt.a; w.GTK[1][o] = gt.b;
+  }
+}
+
+// diag_gm_bolus (:2079-2151): the eddy-induced velocity.  One thread per column of the block marches the levels, carrying the stream
+// function at the top of the level (UIT, VIT of the reference) on the four faces it needs: its own east and north face (U_ISOP,
+// V_ISOP of the cell) and the east face of its west / north face of its south neighbour (the divergence that integrates to WISOP).
+__global__ void __launch_bounds__(256)
+k_gm_bolus(DevGrid g, GmDev w) {
+  const int p2 = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (p2 >= g.n2) return;
+  const int nxb = g.nxb, nyb = g.nyb, km = g.km, i = p2 % nxb, j = p2 / nxb;
+  const long long n2 = g.n2, q = (long long)b * n2 + p2, base = (long long)b * g.n3 + p2;
+  const bool phys = i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b);
+  const bool has_e = i <= nxb - 2, has_n = j <= nyb - 2;
+  const int kmt = g.KMT[q];
+  // stream function on the east face of cell c (2-D index qq, 3-D index oo) at the bottom of level k, and the same on its north face
+  auto psi_e = [&](long long qq, long long oo, int k) {
+    const double factor = (k < km) ? 1.0 : 0.0;
+    const int kp1 = (k < km) ? k + 1 : k;
+    const long long okp = oo + (long long)(kp1 - k) * n2;
+    const double v = (gm_sf(g, w, 0, 0, 1, k, qq, oo) + factor * gm_sf(g, w, 0, 0, 0, kp1, qq, okp) +
+                      gm_sf(g, w, 0, 1, 1, k, qq + 1, oo + 1) + factor * gm_sf(g, w, 0, 1, 0, kp1, qq + 1, okp + 1)) * 0.25 * w.HYX[qq];
+    return (k < g.KMT[qq] && k < g.KMT[qq + 1]) ? v : 0.0;
+  };
+  auto psi_n = [&](long long qq, long long oo, int k) {
+    const double factor = (k < km) ? 1.0 : 0.0;
+    const int kp1 = (k < km) ? k + 1 : k;
+    const long long okp = oo + (long long)(kp1 - k) * n2;
+    const double v = (gm_sf(g, w, 1, 0, 1, k, qq, oo) + factor * gm_sf(g, w, 1, 0, 0, kp1, qq, okp) +
+                      gm_sf(g, w, 1, 1, 1, k, qq + nxb, oo + nxb) + factor * gm_sf(g, w, 1, 1, 0, kp1, qq + nxb, okp + nxb)) * 0.25 * w.HXY[qq];
+    return (k < g.KMT[qq] && k < g.KMT[qq + nxb]) ? v : 0.0;
+  };
+  double uit_e = 0.0, uit_w = 0.0, vit_n = 0.0, vit_s = 0.0, wtop = 0.0;
+  const double hte = w.HTE[q], htn = w.HTN[q], tar = g.TAREA_R[q];
+  for (int k = 1; k <= km; ++k) {
+    const long long o = base + (long long)(k - 1) * n2;
+    const double uib_e = has_e ? psi_e(q, o, k) : 0.0, vib_n = has_n ? psi_n(q, o, k) : 0.0;
+    const double w1 = (has_e && k <= kmt && k <= g.KMT[q + 1]) ? uit_e - uib_e : 0.0;
+    const double w2 = (has_n && k <= kmt && k <= g.KMT[q + nxb]) ? vit_n - vib_n : 0.0;
+    w.UISOP[o] = w1 * g.dzr[k] / hte;
+    w.VISOP[o] = w2 * g.dzr[k] / htn;
+    w.WISOP[o] = wtop;
+    if (phys) {
+      const double uib_w = psi_e(q - 1, o - 1, k), vib_s = psi_n(q - nxb, o - nxb, k);
+      const double w1w = (k <= g.KMT[q - 1] && k <= kmt) ? uit_w - uib_w : 0.0;
+      const double w2s = (k <= g.KMT[q - nxb] && k <= kmt) ? vit_s - vib_s : 0.0;
+      wtop = (k < kmt) ? wtop + tar * (w1 - w1w + w2 - w2s) : 0.0;      // WBOT_ISOP of this level = WTOP_ISOP of the next
+      uit_w = uib_w; vit_s = vib_s;
+    }
+    uit_e = uib_e; vit_n = vib_n;
   }
 }
 

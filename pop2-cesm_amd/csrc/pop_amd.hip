@@ -1226,6 +1226,9 @@ int resolve(pop_ctx *c, const std::string &name, int tl, int n, double **ptr, lo
   if (name == "HBLT") return ok(c->HBLT, a2);
   if (name == "HMXL") return ok(c->HMXL, a2);
   if (name == "HMXL_DR") return ok(c->HMXL_DR, a2);
+  if (name == "UISOP") return ok(c->gm.UISOP, a3);           // diag_gm_bolus (hmix_tracer = 3): eddy-induced velocity, east / north face and top of the T cell
+  if (name == "VISOP") return ok(c->gm.VISOP, a3);
+  if (name == "WISOP") return ok(c->gm.WISOP, a3);
   if (name == "SMF") return ok(c->d2[n == 0 ? "SMF1" : "SMF2"], a2);
   if (name == "SMFT") return ok(c->d2[n == 0 ? "SMFT1" : "SMFT2"], a2);
   auto it = c->d2.find(name);
@@ -1317,7 +1320,9 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       // in the init routine of the option's own module, e.g. vertical_mix.F90:280-296, POP_SolversMod.F90:442-472)
     auto bad = [&](const std::string &m) { c->err = "pop_create: " + m; return 1; };
     if (cfg->struct_version != POP_CONFIG_VERSION) return bad("pop_config.struct_version is " + std::to_string(cfg->struct_version) + ", this library was built for " + std::to_string(POP_CONFIG_VERSION) + " (include/pop_amd.h)");
-    for (int r = 0; r < 3; ++r) if (cfg->reserved_i[r] != 0) return bad("pop_config.reserved_i must be 0");
+    for (int r = 0; r < 2; ++r) if (cfg->reserved_i[r] != 0) return bad("pop_config.reserved_i must be 0");
+    if (cfg->gm_diag_bolus != 0 && cfg->gm_diag_bolus != 1) return bad("gm_diag_bolus: 0 or 1");
+    if (cfg->gm_diag_bolus && cfg->hmix_tracer != 3) return bad("gm_diag_bolus needs hmix_tracer = 3");
     if (cfg->gm_transition_layer != 0 && cfg->gm_transition_layer != 1) return bad("gm_transition_layer: 0 or 1");
     if (cfg->gm_transition_layer && cfg->hmix_tracer != 3) return bad("gm_transition_layer needs hmix_tracer = 3");
     if (cfg->gm_transition_layer && cfg->partial_bottom_cells) return bad("gm_transition_layer with partial_bottom_cells (the DZT branch of smooth_hblt, vmix_kpp.F90:3835-3841) is not built");
@@ -1571,6 +1576,11 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       for (int t = 0; t < 2; ++t) if (dev_alloc(c, &G.SLA[t], a3g)) return 1;
       if (dev_alloc(c, &G.DD, a2g) || dev_alloc(c, &G.TH, a2g) || dev_alloc(c, &G.ID, a2g) || dev_alloc(c, &G.KL, a2g) || dev_alloc(c, &G.ZTW, a2g)) return 1;
       for (int t = 0; t < 8; ++t) if (dev_alloc(c, &G.MW[t], a2g)) return 1;
+    }
+    if (cfg->gm_diag_bolus) {
+      if (dev_alloc(c, &G.UISOP, a3g) || dev_alloc(c, &G.VISOP, a3g) || dev_alloc(c, &G.WISOP, a3g)) return 1;
+      G.HTE = c->d2["HTE"]; G.HTN = c->d2["HTN"];
+      if (!G.HTE || !G.HTN) { c->err = "gm: HTE / HTN missing"; return 1; }
     }
     G.HYX = c->d2["gmHYX"]; G.HXY = c->d2["gmHXY"]; G.RBR = c->d2["gmRBR"]; G.DXT = c->d2["DXT"]; G.DYT = c->d2["DYT"];
     if (!G.HYX || !G.HXY || !G.RBR || !G.DXT || !G.DYT) { c->err = "gm: grid fields missing"; return 1; }
@@ -1982,7 +1992,7 @@ int pop_local_block_ids(const pop_ctx *c, int *ids) { std::copy(c->h.local_ids.b
 long long pop_field_count(const pop_ctx *c, const char *name) {
   const std::string n(name);
   const long long a2 = (long long)c->h.n2 * c->h.nblocks, a3 = (long long)c->h.n3 * c->h.nblocks;
-  for (const char *s : {"TRACER", "UVEL", "VVEL", "RHO", "KPP_SRC", "VVC"}) if (n == s) return a3;
+  for (const char *s : {"TRACER", "UVEL", "VVEL", "RHO", "KPP_SRC", "VVC", "UISOP", "VISOP", "WISOP"}) if (n == s) return a3;
   if (n == "VDC") return (long long)c->h.n2 * (c->h.km + 2) * c->h.nblocks;
   return a2;
 }
@@ -2313,6 +2323,7 @@ static int phase_hmix_gm(pop_ctx *c) {
   const StepParams sp = step_params(c);
   double *v1 = (sp.nvdc == 2 && c->VDC[1] != c->VDC[0]) ? c->VDC[1] : nullptr;   // one shared array is added to once
   if (G.SF[0]) hipLaunchKernelGGL(k_gm_sf, G3, dim3(256), 0, c->stream, c->g, G);   // without cancellation: SF_SLX, SF_SLY once per half cell
+  if (G.UISOP) hipLaunchKernelGGL(k_gm_bolus, G2, dim3(256), 0, c->stream, c->g, G);   // diag_gm_bolus
   hipLaunchKernelGGL(k_gm_flux, dim3(G3.x, (c->g.km + POP_GM_KC - 1) / POP_GM_KC, G3.z), dim3(256), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
   HIPCHK(c, hipGetLastError());
   return 0;

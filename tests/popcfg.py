@@ -36,7 +36,7 @@ class PopConfig(C.Structure):
         ("init_ts_perturbation", C.c_double), ("robert_alpha", C.c_double), ("robert_nu", C.c_double),
         ("lanczos_convergence_criterion", C.c_double),
         ("ah_bolus", C.c_double), ("ah_bkg_srfbl", C.c_double), ("slm_r", C.c_double), ("slm_b", C.c_double),
-        ("gm_transition_layer", C.c_int), ("reserved_i", C.c_int * 3),
+        ("gm_transition_layer", C.c_int), ("gm_diag_bolus", C.c_int), ("reserved_i", C.c_int * 2),
     ]
 
 

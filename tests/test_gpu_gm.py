@@ -212,3 +212,36 @@ def test_gm_stored_stream_function_terms_are_bitwise_the_re_derived_ones(pkg, mo
         m.close()
     for a, b in zip(out["1"], out["0"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kw", [{"ah_bolus": 0.5e7, "stepped_bathymetry": 1},
+                                {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1},
+                                {"block_size_x": 48, "block_size_y": 40}])
+def test_gm_bolus_velocity_diagnostics(pkg, orclib_built, kw):
+    """diag_gm_bolus (hmix_gm.F90:2079-2151): U_ISOP, V_ISOP, WTOP_ISOP of every level against the oracle, and what an eddy-induced
+    velocity derived from a stream function that vanishes at the surface and at the bottom must do whatever the stream function is:
+    its transport through every face column integrates to zero, and it is non-divergent (the vertical velocity at the top of
+    a level is minus the horizontal divergence summed over the levels above ... and comes out zero below the bottom level)."""
+    cfg = named_config("tiny", gm_diag_bolus=1, **dict(GM, **kw))
+    gpu, orc = pkg.PopModel(cfg), Oracle(cfg)
+    if cfg.vmix_choice == 3:
+        force_kpp_case(gpu, orc)
+    _steep(gpu, orc)
+    tol = TOL_LOCAL
+    for s in range(1, 4):
+        run_phases(gpu, orc, s, tol)
+        tol = TOL_SOLVE
+        for f in ("UISOP", "VISOP", "WISOP"):
+            a, b = pick(gpu, gpu.get(f), True), pick(gpu, orc.f3(f), True)
+            assert np.abs(b).max() > 0.0, f
+            assert relerr(a, b) <= tol * 100, "%s step %d: %g" % (f, s, relerr(a, b))
+    dz = orc.v1("dz")[1:cfg.km + 1]
+    u, v, wv = gpu.get("UISOP"), gpu.get("VISOP"), gpu.get("WISOP")
+    kmt = gpu.geti("KMT")
+    for x in (u, v):
+        col = (x * dz[None, :, None, None]).sum(axis=1)
+        assert np.abs(col).max() <= 1e-12 * (np.abs(x) * dz[None, :, None, None]).sum(axis=1).max()
+    assert np.abs(u).max() > 1e-4 and np.abs(wv).max() > 1e-8
+    k = np.arange(1, cfg.km + 1)[None, :, None, None]
+    assert not wv[(k > kmt[:, None]) & np.ones_like(wv, dtype=bool)].any()      # nothing at the top of levels below the bottom
+    gpu.close(); orc.close()
