@@ -96,7 +96,11 @@ typedef struct pop_config {
                                           * apply_vertical_profile_to_isop_hor_diff); with KPP the diabatic depth is the smoothed HMXL */
   int gm_diag_bolus;                     /* hmix_gm_nml diag_gm_bolus: 1 = the eddy-induced (bolus) velocity of hdifft_gm (hmix_gm.F90:2079-2151) every step:
                                           * fields "UISOP", "VISOP" (east / north face of the T cell) and "WISOP" (top of the T cell); nothing on the path reads them */
-  int reserved_i[2];                     /* must be 0 */
+  int gm_kappa_bkg_srfbl;                /* 1: hmix_gm_nml use_const_ah_bkg_srfbl = .false. -- the horizontal diffusivity of the surface boundary layer follows
+                                          * KAPPA_ISOP instead of ah_bkg_srfbl (hmix_gm.F90:1369-1370, 1602-1631) */
+  int reserved_i[1];                     /* must be 0 */
+  double ah_bkg_bottom;                  /* hmix_gm_nml ah_bkg_bottom: horizontal diffusivity in the bottom half of the bottom cell (:1757-1761), 0 = none */
+  double reserved_d[3];                  /* must be 0 */
 } pop_config;
 
 typedef struct pop_ctx pop_ctx;

@@ -64,7 +64,10 @@ typedef struct {
   double ah_bolus, ah_bkg_srfbl, slm_r, slm_b;   /* hmix_gm_nml; 0 = ah, ah, 0.3, 0.3 */
   int gm_transition_layer;
   int gm_diag_bolus;
-  int reserved_i[2];
+  int gm_kappa_bkg_srfbl;
+  int reserved_i[1];
+  double ah_bkg_bottom;
+  double reserved_d[3];
 } orc_config;
 
 typedef struct orc_model orc_model;

@@ -40,6 +40,8 @@ struct GmDev {
   const double *HYX, *HXY, *RBR, *DXT, *DYT, *HBLT;   // HBLT: nullptr without KPP (BL_DEPTH = zw(1))
   double ah, ah_bolus, ah_bkg_srfbl, slm_r, slm_b;
   int diff_tapering, cancellation, slope_tanh;
+  int kappa_bkg;                    // use_const_ah_bkg_srfbl = .false.: HOR_DIFF from the (untapered) KAPPA_ISOP
+  double ah_bkg_bottom;             // HOR_DIFF of the bottom half of the bottom cell, 0 = none
 };
 
 // tapering factor of DM95 / its polynomial stand-in (:1490-1539)
@@ -150,12 +152,13 @@ k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__re
     double taper3 = w.diff_tapering ? gm_taper23(sla, w.slm_b, w.slope_tanh) : taper2;
     if (MODE == 2 && refdepth[s] <= ddq) { taper2 = 1.0; taper3 = 1.0; }
     const double kv = w.KV ? w.KV[o] : 1.0;
-    double hd = (dz_bottom <= bl) ? w.ah_bkg_srfbl * (1.0 - taper1 * taper2) * kv : 0.0;
     // KAPPA_LATERAL * max(KAPPA_VERTICAL, kappa_*_deep) with 'bfre' (:1353-1358, 1382-1387), the constants otherwise
     const double kis = w.KV ? w.ah * fmax(kv, 0.1) : w.ah, kts = w.KV ? w.ah_bolus * fmax(kv, 0.1) : w.ah_bolus;
+    double hd = w.kappa_bkg ? ((dz_bottom <= bl) ? kis * (1.0 - taper1 * taper2) : 0.0)                                // :1624-1631
+                            : ((dz_bottom <= bl) ? w.ah_bkg_srfbl * (1.0 - taper1 * taper2) * kv : 0.0);
     double ki = taper1 * taper2 * kis, kt = taper1 * taper3 * kts;
-    if (MODE == 2) hd = w.ah_bkg_srfbl;
-    if (kk == 1 && s == 0) { hd = w.ah_bkg_srfbl; ki = 0.0; kt = 0.0; }   // :1208, :1663-1664
+    if (MODE == 2) hd = w.kappa_bkg ? kis : w.ah_bkg_srfbl;               // :1598-1608
+    if (kk == 1 && s == 0) { hd = w.kappa_bkg ? kis : w.ah_bkg_srfbl; ki = 0.0; kt = 0.0; }   // :1208, :1369-1370, :1663-1664
     if (s == 1 && kk == kmt) { ki = 0.0; kt = 0.0; }                       // :1654-1657
     if (MODE == 2 && kk <= kmt) {                                          // apply_vertical_profile_to_isop_hor_diff
       const double rd = (s == 0) ? g.zt[kk] - 0.25 * g.dz[kk] : g.zt[kk] + 0.25 * g.dz[kk], th = w.TH[q], idq = w.ID[q];
@@ -163,6 +166,7 @@ k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__re
       if (rd > ddq && rd <= idq && th > 1.0e-10) { hd = (idq - rd) * hd / th; ki = (rd - ddq) * ki / th; }
       if (rd > idq) hd = 0.0;
     }
+    if (w.ah_bkg_bottom != 0.0 && s == 1 && kk == kmt) hd = w.ah_bkg_bottom;   // :1757-1761 (at the level's turn, after everything above)
     w.KI[s][o] = ki; w.KT[s][o] = kt; w.HD[s][o] = hd;
     w.SLX[0 + s][o] = sl[s][0]; w.SLX[2 + s][o] = sl[s][1]; w.SLY[0 + s][o] = sl[s][2]; w.SLY[2 + s][o] = sl[s][3];
   }

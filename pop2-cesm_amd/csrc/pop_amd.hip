@@ -1320,7 +1320,10 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       // in the init routine of the option's own module, e.g. vertical_mix.F90:280-296, POP_SolversMod.F90:442-472)
     auto bad = [&](const std::string &m) { c->err = "pop_create: " + m; return 1; };
     if (cfg->struct_version != POP_CONFIG_VERSION) return bad("pop_config.struct_version is " + std::to_string(cfg->struct_version) + ", this library was built for " + std::to_string(POP_CONFIG_VERSION) + " (include/pop_amd.h)");
-    for (int r = 0; r < 2; ++r) if (cfg->reserved_i[r] != 0) return bad("pop_config.reserved_i must be 0");
+    if (cfg->reserved_i[0] != 0) return bad("pop_config.reserved_i must be 0");
+    for (int r = 0; r < 3; ++r) if (cfg->reserved_d[r] != 0.0) return bad("pop_config.reserved_d must be 0");
+    if (cfg->gm_kappa_bkg_srfbl != 0 && cfg->gm_kappa_bkg_srfbl != 1) return bad("gm_kappa_bkg_srfbl: 0 or 1");
+    if (cfg->ah_bkg_bottom < 0.0) return bad("ah_bkg_bottom: >= 0");
     if (cfg->gm_diag_bolus != 0 && cfg->gm_diag_bolus != 1) return bad("gm_diag_bolus: 0 or 1");
     if (cfg->gm_diag_bolus && cfg->hmix_tracer != 3) return bad("gm_diag_bolus needs hmix_tracer = 3");
     if (cfg->gm_transition_layer != 0 && cfg->gm_transition_layer != 1) return bad("gm_transition_layer: 0 or 1");
@@ -1591,6 +1594,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     G.slm_r = (cfg->slm_r != 0.0) ? cfg->slm_r : 0.3;
     G.slm_b = (cfg->slm_b != 0.0) ? cfg->slm_b : 0.3;
     G.slope_tanh = cfg->gm_slope_control == 1;
+    G.kappa_bkg = cfg->gm_kappa_bkg_srfbl == 1; G.ah_bkg_bottom = cfg->ah_bkg_bottom;
     G.diff_tapering = G.slm_r != G.slm_b;                              // :964-968
     G.cancellation = !(G.diff_tapering || G.ah != G.ah_bolus) && !G.tlt;   // :970-987 (both kappa types equal)
     if (!G.cancellation && !tun_off(h.tun.gm_sf_stored)) for (int t = 0; t < 8; ++t) if (dev_alloc(c, &G.SF[t], a3g)) return 1;

@@ -48,7 +48,10 @@
       real (c_double) :: slm_r = 0.0_c_double, slm_b = 0.0_c_double             ! hmix_gm_nml; 0 = 0.3
       integer (c_int) :: gm_transition_layer = 0                                ! hmix_gm_nml transition_layer_on
       integer (c_int) :: gm_diag_bolus = 0                                      ! hmix_gm_nml diag_gm_bolus: UISOP, VISOP, WISOP every step
-      integer (c_int) :: reserved_i(2) = 0
+      integer (c_int) :: gm_kappa_bkg_srfbl = 0                                 ! hmix_gm_nml: 1 = use_const_ah_bkg_srfbl .false.
+      integer (c_int) :: reserved_i(1) = 0
+      real (c_double) :: ah_bkg_bottom = 0.0_c_double                           ! hmix_gm_nml ah_bkg_bottom
+      real (c_double) :: reserved_d(3) = 0.0_c_double
    end type pop_config
 
    ! mirrors `struct pop_grid_input`: the records of horiz_grid_file / topography_file (grid.F90:1314-1542, 2025-2107)

@@ -50,6 +50,9 @@ def _steep(gpu, orc):
     # kappa_freq 'once_a_day': recomputed at the first step after a day has ended (two day boundaries inside the run)
     ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 2, "steps_per_day": 6, "time_mix_freq": 4, "vmix_choice": 3, "km": 20}, 20),   # avgfit: the fit interval is the day
     ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 2, "gm_transition_layer": 1, "steps_per_day": 8, "tmix_opt": 3}, 18),          # Robert filter: every eighth step ends a day
+    # the remaining switches of hmix_gm_nml: horizontal diffusivity of the boundary layer from KAPPA_ISOP, and in the bottom half of the bottom cell
+    ("tiny", {"gm_kappa_bkg_srfbl": 1, "ah_bkg_bottom": 0.2e7, "stepped_bathymetry": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1}, 4),
+    ("tiny", {"gm_kappa_bkg_srfbl": 1, "ah_bkg_bottom": 0.2e7, "gm_transition_layer": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1}, 4),
     ("test", {"stepped_bathymetry": 1}, 3),                                           # 96 blocks
     ("gx3v7", {"vmix_choice": 3}, 3),
 ])
