@@ -72,8 +72,10 @@ typedef struct pop_config {
   int partial_bottom_cells;   /* grid_nml partial_bottom_cells (grid.F90:916-1020): 1 = the bottom T cell of every column has the
                                * thickness DZBC (pop_grid_input.DZBC = the record of bottom_cell_file; NULL with the internal
                                * topography: a synthetic DZBC in (0.25, 1] dz(KMT), TEST EXTENSION), DZT / DZU as the reference forms them */
-  int gm_slope_control;       /* hmix_gm_nml slope_control_choice: 0 'notanh' (the default, hmix_gm.F90:1508-1539), 1 'tanh' (:1490-1506) */
-  int gm_kappa_type;          /* hmix_gm_nml kappa_isop_choice = kappa_thic_choice: 0 'constant', 1 'bfre' (buoyancy_frequency_dependent_profile,
+  int gm_slope_control;       /* hmix_gm_nml slope_control_choice: 0 'notanh' (the default, hmix_gm.F90:1508-1539), 1 'tanh' (:1490-1506),
+                               * 2 'clip' (:1541-1573: the slopes themselves are limited), 3 'Gerd' (:1575-1594) */
+  int gm_kappa_type;          /* hmix_gm_nml kappa_isop_choice = kappa_thic_choice: 0 'constant', 2 'depth' (kappa_depth_1 + kappa_depth_2 exp(-zt / kappa_depth_scale),
+                               * hmix_gm.F90:850-874), 1 'bfre' (buoyancy_frequency_dependent_profile,
                                * hmix_gm.F90:3011-3180: KAPPA_VERTICAL = N^2 / N_ref^2 in [0.1, 1] below the surface diabatic layer; kappa_*_deep = 0.1) */
   int gm_kappa_freq;          /* kappa_freq_choice with gm_kappa_type = 1: 0 'never' (the profile of the first step of the run is kept, :1276-1278),
                                * 1 'every_time_step', 2 'once_a_day' (the first step after a day has ended, eod_last; for runs that start at midnight:
@@ -100,7 +102,7 @@ typedef struct pop_config {
                                           * KAPPA_ISOP instead of ah_bkg_srfbl (hmix_gm.F90:1369-1370, 1602-1631) */
   int reserved_i[1];                     /* must be 0 */
   double ah_bkg_bottom;                  /* hmix_gm_nml ah_bkg_bottom: horizontal diffusivity in the bottom half of the bottom cell (:1757-1761), 0 = none */
-  double reserved_d[3];                  /* must be 0 */
+  double kappa_depth_1, kappa_depth_2, kappa_depth_scale;   /* gm_kappa_type = 2; scale 0 = 150000 cm */
 } pop_config;
 
 typedef struct pop_ctx pop_ctx;

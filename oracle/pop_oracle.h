@@ -67,7 +67,7 @@ typedef struct {
   int gm_kappa_bkg_srfbl;
   int reserved_i[1];
   double ah_bkg_bottom;
-  double reserved_d[3];
+  double kappa_depth_1, kappa_depth_2, kappa_depth_scale;
 } orc_config;
 
 typedef struct orc_model orc_model;

@@ -40,13 +40,18 @@ struct GmDev {
   const double *HYX, *HXY, *RBR, *DXT, *DYT, *HBLT;   // HBLT: nullptr without KPP (BL_DEPTH = zw(1))
   double ah, ah_bolus, ah_bkg_srfbl, slm_r, slm_b;
   int diff_tapering, cancellation, slope_tanh;
+  int slope_ctl;                    // 0 notanh, 1 tanh, 2 clip, 3 Gerd
+  const double *HUS, *HUW;          // clip
+  const double *kdepth;             // kappa type 'depth': KAPPA_VERTICAL(k), nullptr otherwise
   int kappa_bkg;                    // use_const_ah_bkg_srfbl = .false.: HOR_DIFF from the (untapered) KAPPA_ISOP
   double ah_bkg_bottom;             // HOR_DIFF of the bottom half of the bottom cell, 0 = none
 };
 
 // tapering factor of DM95 / its polynomial stand-in (:1490-1539)
-__device__ __forceinline__ double gm_taper23(double sla, double slm, int slope_tanh) {
-  if (slope_tanh) return (sla < slm) ? 0.5 * (1.0 - tanh(10.0 * sla / slm - 4.0)) : 0.0;
+__device__ __forceinline__ double gm_taper23(double sla, double slm, int ctl) {
+  if (ctl == 1) return (sla < slm) ? 0.5 * (1.0 - tanh(10.0 * sla / slm - 4.0)) : 0.0;
+  if (ctl == 2) return 1.0;                                                       // clip: the slopes are limited instead
+  if (ctl == 3) return (sla > slm) ? (slm / sla) * (slm / sla) : 1.0;             // Gerdes et al. (1991)
   double t = 1.0;
   if (sla > 0.2 * slm && sla < 0.6 * slm) t = 0.5 * (1.0 - (2.5 * sla / slm - 1.0) * (4.0 - fabs(10.0 * sla / slm - 4.0)));
   else if (sla >= 0.6 * slm) t = 0.0;
@@ -148,12 +153,20 @@ k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__re
     const double w1 = fmin(1.0, g.zt[kk] * rbr / sla);
     const double t1f = w.slope_tanh ? 0.5 * (1.0 + sin(3.14159265358979323846 * (w1 - 0.5))) : (0.5 + 2.0 * (w1 - 0.5) * (1.0 - fabs(w1 - 0.5)));
     const double taper1 = (MODE == 2) ? 1.0 : ((dz_bottom <= bl) ? t1f : 1.0);
-    double taper2 = gm_taper23(sla, w.slm_r, w.slope_tanh);
-    double taper3 = w.diff_tapering ? gm_taper23(sla, w.slm_b, w.slope_tanh) : taper2;
+    double taper2 = gm_taper23(sla, w.slm_r, w.slope_ctl);
+    double taper3 = w.diff_tapering ? gm_taper23(sla, w.slm_b, w.slope_ctl) : taper2;
+    if (w.slope_ctl == 2) {   // :1541-1573: slope clipping (after SLA, which keeps the unclipped slopes)
+      const double dzwk = g.dzw[kid], dzwrk = g.dzwr[kid], hus = w.HUS[q], huw = w.HUW[q];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        if (fabs(sl[s][n] * dzwk / hus) > w.slm_r) sl[s][n] = copysign(w.slm_r * hus * dzwrk, sl[s][n]);
+        if (fabs(sl[s][2 + n] * dzwk / huw) > w.slm_r) sl[s][2 + n] = copysign(w.slm_r * huw * dzwrk, sl[s][2 + n]);
+      }
+    }
     if (MODE == 2 && refdepth[s] <= ddq) { taper2 = 1.0; taper3 = 1.0; }
-    const double kv = w.KV ? w.KV[o] : 1.0;
+    const double kv = w.kdepth ? w.kdepth[kk] : (w.KV ? w.KV[o] : 1.0);
     // KAPPA_LATERAL * max(KAPPA_VERTICAL, kappa_*_deep) with 'bfre' (:1353-1358, 1382-1387), the constants otherwise
-    const double kis = w.KV ? w.ah * fmax(kv, 0.1) : w.ah, kts = w.KV ? w.ah_bolus * fmax(kv, 0.1) : w.ah_bolus;
+    const double kis = w.kdepth ? w.ah * kv : (w.KV ? w.ah * fmax(kv, 0.1) : w.ah), kts = w.kdepth ? w.ah_bolus * kv : (w.KV ? w.ah_bolus * fmax(kv, 0.1) : w.ah_bolus);   // 'depth': :1360-1366, 1375-1381
     double hd = w.kappa_bkg ? ((dz_bottom <= bl) ? kis * (1.0 - taper1 * taper2) : 0.0)                                // :1624-1631
                             : ((dz_bottom <= bl) ? w.ah_bkg_srfbl * (1.0 - taper1 * taper2) * kv : 0.0);
     double ki = taper1 * taper2 * kis, kt = taper1 * taper3 * kts;

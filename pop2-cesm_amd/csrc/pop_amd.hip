@@ -1321,7 +1321,6 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     auto bad = [&](const std::string &m) { c->err = "pop_create: " + m; return 1; };
     if (cfg->struct_version != POP_CONFIG_VERSION) return bad("pop_config.struct_version is " + std::to_string(cfg->struct_version) + ", this library was built for " + std::to_string(POP_CONFIG_VERSION) + " (include/pop_amd.h)");
     if (cfg->reserved_i[0] != 0) return bad("pop_config.reserved_i must be 0");
-    for (int r = 0; r < 3; ++r) if (cfg->reserved_d[r] != 0.0) return bad("pop_config.reserved_d must be 0");
     if (cfg->gm_kappa_bkg_srfbl != 0 && cfg->gm_kappa_bkg_srfbl != 1) return bad("gm_kappa_bkg_srfbl: 0 or 1");
     if (cfg->ah_bkg_bottom < 0.0) return bad("ah_bkg_bottom: >= 0");
     if (cfg->gm_diag_bolus != 0 && cfg->gm_diag_bolus != 1) return bad("gm_diag_bolus: 0 or 1");
@@ -1329,10 +1328,11 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     if (cfg->gm_transition_layer != 0 && cfg->gm_transition_layer != 1) return bad("gm_transition_layer: 0 or 1");
     if (cfg->gm_transition_layer && cfg->hmix_tracer != 3) return bad("gm_transition_layer needs hmix_tracer = 3");
     if (cfg->gm_transition_layer && cfg->partial_bottom_cells) return bad("gm_transition_layer with partial_bottom_cells (the DZT branch of smooth_hblt, vmix_kpp.F90:3835-3841) is not built");
-    if (cfg->gm_kappa_type != 0 && cfg->gm_kappa_type != 1) return bad("gm_kappa_type: 0 constant, 1 bfre (the other kappa choices of hmix_gm_nml are not built)");
+    if (cfg->gm_kappa_type < 0 || cfg->gm_kappa_type > 2) return bad("gm_kappa_type: 0 constant, 1 bfre, 2 depth (the other kappa choices of hmix_gm_nml are not built)");
     if (cfg->gm_kappa_freq < 0 || cfg->gm_kappa_freq > 2) return bad("gm_kappa_freq: 0 never, 1 every_time_step, 2 once_a_day");
     if (cfg->gm_kappa_freq == 2 && cfg->tmix_opt == 1) return bad("gm_kappa_freq = once_a_day with time_mix_opt 'avg' (half steps that do not fit the day: the end-of-day test of time_management.F90:3586-3592 on the calendar) is not built: avgfit, robert or none");
-    if (cfg->gm_slope_control != 0 && cfg->gm_slope_control != 1) return bad("gm_slope_control: 0 notanh, 1 tanh (slope clipping and the Gerdes et al. form are not built)");
+    if (cfg->gm_slope_control < 0 || cfg->gm_slope_control > 3) return bad("gm_slope_control: 0 notanh, 1 tanh, 2 clip, 3 Gerd");
+    if (cfg->gm_slope_control == 2 && cfg->gm_transition_layer) return bad("gm_slope_control = clip with the transition layer (SLA_SAVE is formed before the slopes are clipped, hmix_gm.F90:1234-1245) is not built");
     if (cfg->ah_bolus < 0.0 || cfg->ah_bkg_srfbl < 0.0 || cfg->slm_r < 0.0 || cfg->slm_b < 0.0) return bad("ah_bolus, ah_bkg_srfbl, slm_r, slm_b: >= 0 (0 = ah, ah, 0.3, 0.3)");
     if (cfg->partial_bottom_cells != 0 && cfg->partial_bottom_cells != 1) return bad("partial_bottom_cells: 0 or 1");
     if (cfg->partial_bottom_cells && grid && grid->DZBC == nullptr && grid->KMT != nullptr) return bad("partial_bottom_cells with a topography record needs pop_grid_input.DZBC (the record of bottom_cell_file)");
@@ -1593,7 +1593,16 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     G.ah_bkg_srfbl = (cfg->ah_bkg_srfbl != 0.0) ? cfg->ah_bkg_srfbl : cfg->ah;
     G.slm_r = (cfg->slm_r != 0.0) ? cfg->slm_r : 0.3;
     G.slm_b = (cfg->slm_b != 0.0) ? cfg->slm_b : 0.3;
-    G.slope_tanh = cfg->gm_slope_control == 1;
+    G.slope_tanh = cfg->gm_slope_control == 1; G.slope_ctl = cfg->gm_slope_control;
+    G.HUS = c->d2["HUS"]; G.HUW = c->d2["HUW"];
+    if (cfg->gm_kappa_type == 2) {   // KAPPA_VERTICAL(k) = kappa_depth(k) (:850-874): a 1-D profile, uploaded as the level table the coefficient kernel reads
+      std::vector<double> kd(h.km + 2, 1.0);
+      const double sc = (cfg->kappa_depth_scale != 0.0) ? cfg->kappa_depth_scale : 150000.0;
+      for (int k = 1; k <= h.km; ++k) kd[k] = cfg->kappa_depth_1 + cfg->kappa_depth_2 * std::exp(-h.zt[k] / sc);
+      double *p = nullptr;
+      if (dev_upload(c, &p, kd.data(), kd.size())) return 1;
+      G.kdepth = p;
+    }
     G.kappa_bkg = cfg->gm_kappa_bkg_srfbl == 1; G.ah_bkg_bottom = cfg->ah_bkg_bottom;
     G.diff_tapering = G.slm_r != G.slm_b;                              // :964-968
     G.cancellation = !(G.diff_tapering || G.ah != G.ah_bolus) && !G.tlt;   // :970-987 (both kappa types equal)

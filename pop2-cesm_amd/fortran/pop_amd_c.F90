@@ -51,7 +51,7 @@
       integer (c_int) :: gm_kappa_bkg_srfbl = 0                                 ! hmix_gm_nml: 1 = use_const_ah_bkg_srfbl .false.
       integer (c_int) :: reserved_i(1) = 0
       real (c_double) :: ah_bkg_bottom = 0.0_c_double                           ! hmix_gm_nml ah_bkg_bottom
-      real (c_double) :: reserved_d(3) = 0.0_c_double
+      real (c_double) :: kappa_depth_1 = 0.0_c_double, kappa_depth_2 = 0.0_c_double, kappa_depth_scale = 0.0_c_double   ! gm_kappa_type = 2
    end type pop_config
 
    ! mirrors `struct pop_grid_input`: the records of horiz_grid_file / topography_file (grid.F90:1314-1542, 2025-2107)

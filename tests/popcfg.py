@@ -37,7 +37,7 @@ class PopConfig(C.Structure):
         ("lanczos_convergence_criterion", C.c_double),
         ("ah_bolus", C.c_double), ("ah_bkg_srfbl", C.c_double), ("slm_r", C.c_double), ("slm_b", C.c_double),
         ("gm_transition_layer", C.c_int), ("gm_diag_bolus", C.c_int), ("gm_kappa_bkg_srfbl", C.c_int), ("reserved_i", C.c_int * 1),
-        ("ah_bkg_bottom", C.c_double), ("reserved_d", C.c_double * 3),
+        ("ah_bkg_bottom", C.c_double), ("kappa_depth_1", C.c_double), ("kappa_depth_2", C.c_double), ("kappa_depth_scale", C.c_double),
     ]
 
 

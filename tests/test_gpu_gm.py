@@ -53,6 +53,10 @@ def _steep(gpu, orc):
     # the remaining switches of hmix_gm_nml: horizontal diffusivity of the boundary layer from KAPPA_ISOP, and in the bottom half of the bottom cell
     ("tiny", {"gm_kappa_bkg_srfbl": 1, "ah_bkg_bottom": 0.2e7, "stepped_bathymetry": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1}, 4),
     ("tiny", {"gm_kappa_bkg_srfbl": 1, "ah_bkg_bottom": 0.2e7, "gm_transition_layer": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1}, 4),
+    # slope control 'clip' and 'Gerd' (limits low enough that the front is beyond them), kappa type 'depth'
+    ("tiny", {"gm_slope_control": 2, "slm_r": 1.0e-3, "slm_b": 1.0e-3, "stepped_bathymetry": 1, "ah_bolus": 0.5e7}, 4),
+    ("tiny", {"gm_slope_control": 3, "slm_r": 1.0e-3, "slm_b": 2.0e-3, "vmix_choice": 3, "km": 24}, 4),
+    ("tiny", {"gm_kappa_type": 2, "kappa_depth_1": 0.2, "kappa_depth_2": 0.8, "kappa_depth_scale": 1.0e5, "ah_bolus": 0.5e7, "stepped_bathymetry": 1}, 4),
     ("test", {"stepped_bathymetry": 1}, 3),                                           # 96 blocks
     ("gx3v7", {"vmix_choice": 3}, 3),
 ])
