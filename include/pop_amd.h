@@ -109,6 +109,10 @@ typedef struct pop_ctx pop_ctx;
 
 /* flags for pop_create */
 #define POP_CREATE_HOST_ONLY 1   /* build blocks/grid/plans on the host, touch no GPU */
+#define POP_CREATE_PLAN_ONLY 2   /* implies HOST_ONLY: the block table (create_blocks, blocks.F90:100-270), the distribution (domain.F90:379-543)
+                                  * and the halo plan (POP_HaloCreate, mpi/POP_HaloMod.F90:142-1640) of this rank only -- no grid fields.  For
+                                  * checking a decomposition of any size in milliseconds: pop_get_block, pop_local_block_ids, pop_halo_plan_*,
+                                  * pop_halo_update_host_*, pop_get_dim("ocean_columns_local" | "ocean_columns_total") work; field access does not */
 
 /* ---- tuning: kernel-form and schedule choices.  NONE changes a result: every alternative is tested bitwise equal to the
  *      default (tests/test_gpu_parity.py, test_gpu_land.py, test_gpu_multirank.py); they exist for measurement and for those

@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("POP_AMD_LIB") or os.path.join(_HERE, "libpop_amd.so")   # POP_AMD_LIB: build-variant experiments
 POP_CREATE_HOST_ONLY = 1
+POP_CREATE_PLAN_ONLY = 2
 
 XCHG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong),
                       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
@@ -174,13 +175,14 @@ class PopModel:
     """One rank's model instance.  Array views are numpy arrays shaped
     (nblocks_local, [km,] ny_block, nx_block) = the reference layout read in C order."""
 
-    def __init__(self, cfg, rank=0, nranks=1, host_only=False, grid=None, tuning=None):
+    def __init__(self, cfg, rank=0, nranks=1, host_only=False, grid=None, tuning=None, plan_only=False):
         """grid: None (the internal lat-lon grid) or a dict of global (ny_global, nx_global) arrays ULAT, ULON, HTN,
-        HTE, HUS, HUW [, ANGLE] [, KMT] -- the records of horiz_grid_file / topography_file (pop_create_with_grid)."""
+        HTE, HUS, HUW [, ANGLE] [, KMT] -- the records of horiz_grid_file / topography_file (pop_create_with_grid).
+        plan_only: block table, distribution and halo plan of this rank only (POP_CREATE_PLAN_ONLY; no fields, no GPU)."""
         self.L = lib()
         self.cfg = cfg
         self.h = C.c_void_p()
-        flags = POP_CREATE_HOST_ONLY if host_only else 0
+        flags = (POP_CREATE_HOST_ONLY if host_only else 0) | (POP_CREATE_PLAN_ONLY if plan_only else 0)
         tun = C.cast(make_tuning(**tuning), C.c_void_p) if tuning else None    # dict of pop_tuning fields (pop_create_tuned)
         if grid is None:
             e = self.L.pop_create_tuned(C.byref(cfg), None, tun, rank, nranks, flags, C.byref(self.h))

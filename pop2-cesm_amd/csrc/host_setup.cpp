@@ -130,6 +130,19 @@ void make_blocks(HostModel &h) {
     if (h.block_owner[n] == h.rank) { h.local_ids.push_back(n + 1); h.all_blocks[n].local_id = h.block_local[n] + 1; }
   }
   h.nblocks = (int)h.local_ids.size();
+  if (h.plan_only) {   // ocean columns per rank without any field: what a decomposition check wants to know about the balance
+    h.ocean_cols_local = 0; h.ocean_cols_total = 0;
+    for (int n = 0; n < h.nblocks_tot; ++n) {
+      const BlockInfo &B = h.all_blocks[n];
+      long long w = 0;
+      for (int j = B.jb; j <= B.je; ++j) for (int i = B.ib; i <= B.ie; ++i) {
+        const int ig = B.i_glob[i - 1], jg = B.j_glob[j - 1];
+        if (ig > 0 && jg > 0 && kmt_global(h, ig, jg) > 0) ++w;
+      }
+      h.ocean_cols_total += w;
+      if (h.block_owner[n] == h.rank) h.ocean_cols_local += w;
+    }
+  }
 }
 
 int make_vertical(HostModel &h) {
@@ -289,6 +302,7 @@ int host_build(HostModel &h) {
   if (h.nblocks == 0) { h.err = "rank owns no blocks (more ranks than blocks)"; return 1; }
   build_halo_plan(h);   // needs the blocks only; the tripole pass of the grid-time halo updates below reads it
   if (h.halo.tripole_split) { h.err = "tripole: the top row of blocks must belong to one rank (use full-width blocks, block_size_x = nx_global, or fewer ranks)"; return 1; }
+  if (h.plan_only) return 0;   // POP_CREATE_PLAN_ONLY: the block table, the distribution and the halo plan are all a decomposition check reads
   if (make_vertical(h)) return 1;
 
   const int nxb = h.nxb, nyb = h.nyb, NB = h.nblocks_tot;

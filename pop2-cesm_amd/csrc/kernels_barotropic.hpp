@@ -709,26 +709,39 @@ __device__ __forceinline__ double z_at(const FusedArgs &a, int m) {
   return a.Z[m];
 }
 
+// A value another launch left in memory and nothing in THIS launch changes (the solver scalars eta0 / eta1 / alpha / stop, the block
+// sums): read through the constant address space it becomes a scalar (SMEM) load -- no VGPR, no vmcnt, so it neither queues
+// behind the operand loads in flight nor forces a full wait on them.  (r4, from the ISA of k_fpcg_b2: `alpha`, the block sum and
+// `eta0` were three VECTOR loads with uniform addresses behind the 24 operand loads, each followed by s_waitcnt vmcnt(0): two more
+// dependent round trips per wave.)  The scalar cache is invalidated at every kernel start, so the previous launch's stores are seen.
+template <class T>
+__device__ __forceinline__ T sld(const T *p) { return *(const __attribute__((address_space(4))) T *)p; }
+// presummed form of the total: the block sums (already ordered sums, k_block_sums) added in block order; scalar loads
+__device__ __forceinline__ double presummed_total(const double *__restrict__ bs, int nblocks) {
+  double total = 0.0;
+  for (int b = 0; b < nblocks; ++b) total = total + sld(bs + b);
+  return total;
+}
 // ordered total of workgroup partials: per POP block a thread-strided sequential sum + fixed tree,
-// block sums added in block order.  Every thread returns the same value.
+// block sums added in block order.  Every thread returns the same value.  (r4: the levels 32 .. 1 of the tree inside the first
+// wavefront, as in wg_reduce_store -- the operands and the order of shf[t] + shf[t + s] -- three barriers per block instead of nine.)
 __device__ __forceinline__ double fused_total(const double *__restrict__ partial, int nchunk, int nblocks,
                                               const double *__restrict__ bs, int presummed) {
   __shared__ double shf[POP_RED_THREADS];
   const int t = threadIdx.x;
   double total = 0.0;
-  if (presummed) {                       // block sums already formed (same ordered rule): add in block order
-    for (int b = 0; b < nblocks; ++b) total = total + bs[b];
-    return total;
-  }
+  if (presummed) return presummed_total(bs, nblocks);   // block sums already formed (same ordered rule): add in block order
   for (int b = 0; b < nblocks; ++b) {
     double v = 0.0;
     for (int c = t; c < nchunk; c += POP_RED_THREADS) v = v + partial[(long long)b * nchunk + c];
     shf[t] = v;
     __syncthreads();
-    for (int s = POP_RED_THREADS / 2; s > 0; s >>= 1) {
+    for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
       if (t < s) shf[t] = shf[t] + shf[t + s];
       __syncthreads();
     }
+    if (t < 64) { const double x = tree_tail64(shf[t]); if (t == 0) shf[0] = x; }
+    __syncthreads();
     total = total + shf[0];
     __syncthreads();
   }
@@ -743,7 +756,7 @@ __device__ __forceinline__ double fused_total(const double *__restrict__ partial
 template <bool UPDATE>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_a(DevGrid g, FusedArgs a) {
-  const int stop = a.sc->stop;   // an earlier check has converged: this launch belongs to the look-ahead interval (branch below, after the loads are issued)
+  const int stop = sld(&a.sc->stop);   // an earlier check has converged: this launch belongs to the look-ahead interval (branch below, after the loads are issued)
   if (red_land_out<1>(g, a.partA, a.nchunk, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
@@ -755,7 +768,7 @@ k_fpcg_a(DevGrid g, FusedArgs a) {
   double alpha = 0.0;
   if (UPDATE) {
     const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, a.presummed);
-    const double rz = a.sc->eta1;
+    const double rz = sld(&a.sc->eta1);
     alpha = rz / sq;                                   // eta1 = eta0/(s,q), POP_SolversMod.F90:1419
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta0 = rz; a.sc->alpha = alpha; }
   }
@@ -847,7 +860,7 @@ k_fpcg_a_pair(DevGrid g, FusedArgs a) {
 template <bool XUPD>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_b(DevGrid g, FusedArgs a) {
-  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  if (sld(&a.sc->stop)) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   if (red_land_out<1>(g, a.partB, a.nchunk, a.sendmap != nullptr)) return;
   const int p2 = red_cell(g), b = blockIdx.y;
   const bool live = p2 < g.n2;
@@ -879,11 +892,11 @@ k_fpcg_b(DevGrid g, FusedArgs a) {
   }
   const double mk = (double)g.mMask8[q];
   const double rz = fused_total(a.partA, a.nchunk, a.nblocks, a.bsA, a.presummed);
-  const double bt = rz / a.sc->eta0;
+  const double bt = rz / sld(&a.sc->eta0);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.sc->eta1 = rz; a.sc->beta_cg = bt; }
   double v[1] = {0.0};
   if (live) {
-    if (XUPD) a.X[q] = xold + a.sc->alpha * sv[0];
+    if (XUPD) a.X[q] = xold + sld(&a.sc->alpha) * sv[0];
     const double s = zv[0] + sv[0] * bt;
     a.S1[q] = s;
     double aq = 0.0;
@@ -1096,7 +1109,11 @@ k_fcg_b(DevGrid g, FusedArgs a, int par) {
 template <bool XUPD>
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_fpcg_b2(DevGrid g, FusedArgs a) {
-  const int stop = a.sc->stop;   // an earlier check has converged: this launch belongs to the look-ahead interval (branch below, after the loads are issued)
+  const int stop = sld(&a.sc->stop);   // an earlier check has converged: this launch belongs to the look-ahead interval (branch below, after the loads are issued)
+  // the scalars of the iteration first (scalar loads, see sld): presummed block sums only (host selects this kernel for large grids)
+  const double alpha = XUPD ? sld(&a.sc->alpha) : 0.0;
+  const double eta0 = sld(&a.sc->eta0);
+  const double rz = presummed_total(a.bsA, a.nblocks);
   if (red_land_out<1>(g, a.partB, a.nchunk, a.sendmap != nullptr)) return;
   __shared__ double sh[POP_RED_THREADS];
   const int b = blockIdx.y, t = threadIdx.x, nxb = g.nxb;
@@ -1128,10 +1145,7 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
     if (XUPD) xx = *reinterpret_cast<const double2 *>(a.X + q);
   }
   if (stop) return;
-  const double alpha = XUPD ? a.sc->alpha : 0.0;
-  // presummed block sums only (host selects this kernel for large grids): no barrier inside
-  const double rz = fused_total(a.partA, a.nchunk, a.nblocks, a.bsA, 1);
-  const double bt = rz / a.sc->eta0;
+  const double bt = rz / eta0;
   if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { a.sc->eta1 = rz; a.sc->beta_cg = bt; }
   if (fast) {
     // rows: 0 = j-1, 1 = j, 2 = j+1; columns: 0 = q-1, 1 = q, 2 = q+1, 3 = q+2

@@ -1360,10 +1360,11 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     if (cfg->vmix_choice == 3 && cfg->num_v_smooth_Ri < 1) return bad("KPP: num_v_smooth_Ri must be >= 1 (the reference leaves FRI unset otherwise)");
     if (!(cfg->convergence_criterion >= 0.0)) return bad("convergence_criterion must be >= 0");
   }
+  c->h.plan_only = (flags & POP_CREATE_PLAN_ONLY) != 0;
   const int hb = host_build(c->h);
   c->h.gin = nullptr;
   if (hb) { c->err = c->h.err; return 1; }
-  c->host_only = (flags & POP_CREATE_HOST_ONLY) != 0;
+  c->host_only = (flags & (POP_CREATE_HOST_ONLY | POP_CREATE_PLAN_ONLY)) != 0;
   if (c->host_only) return 0;
   if (cfg->nt != 2) { c->err = "device kernels are built for nt = 2 (T,S) in this round"; return 1; }
   int ndev = 0;
@@ -1934,6 +1935,7 @@ int pop_destroy(pop_ctx *c) {
 }
 const char *pop_last_error(const pop_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
+static int solver_path_code(const pop_ctx *c);
 int pop_get_dim(const pop_ctx *c, const char *name) {
   const std::string n(name);
   if (n == "nx_block") return c->h.nxb;
@@ -1961,6 +1963,12 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "solver_iterations_enqueued") return (int)c->solver_enq;
   if (n == "rank") return c->h.rank;
   if (n == "nranks") return c->h.nranks;
+  if (n == "solver_path") return c->host_only ? 0 : solver_path_code(c);   // 1 per operation, 2 fused, 3 fused distributed, 4 replicated fused
+  if (n == "thomas_register_tracers") return c->reg_thomas_t && (c->g.km == 60 || c->g.km == 62);    // column-in-registers Thomas kernels in use
+  if (n == "thomas_register_velocity") return c->reg_thomas && (c->g.km == 60 || c->g.km == 62);
+  if (n == "max_blocks_per_rank") return c->max_blocks_per_rank;
+  if (n == "ocean_columns_local") return (int)c->h.ocean_cols_local;     // POP_CREATE_PLAN_ONLY contexts (-1 otherwise)
+  if (n == "ocean_columns_total") return (int)c->h.ocean_cols_total;
   return -1;
 }
 double pop_get_scalar(const pop_ctx *c, const char *name) {
@@ -2596,6 +2604,27 @@ int pop_baroclinic_driver(pop_ctx *c) {
   return 0;
 }
 
+// which form of the solver pop_solver_run dispatches to (same tests, same order): 1 operation by operation, 2 fused on one rank,
+// 3 fused with the blocks spread over ranks, 4 replicated fused solve on every rank -- reported per rank by bench.py
+static int solver_path_code(const pop_ctx *c) {
+  const bool unf = tun_on(c->h.tun.solver_unfused);
+  if (c->h.c.solver_choice == 2) {
+    if (c->fused_ok && !c->use_evp) return 2;
+    if (c->h.nranks > 1 && c->max_blocks_per_rank <= 16 && !c->use_evp && !unf) return 3;
+    return 1;
+  }
+  if (c->h.c.solver_choice == 3) {
+    if (c->use_evp) return c->evp_fused_ok ? 2 : 1;
+    if (c->fused_ok) return 2;
+    if (c->h.nranks > 1 && !unf) return 3;
+    return 1;
+  }
+  if (c->use_evp) return 1;
+  if (c->replicated) return 4;
+  if (c->fused_ok) return 2;
+  if (c->h.nranks > 1 && c->max_blocks_per_rank <= 16 && !unf) return 3;
+  return 1;
+}
 int pop_solver_run(pop_ctx *c) {
   if (need_device(c)) return 1;
   if (c->h.c.solver_choice == 2) {

@@ -84,6 +84,8 @@ struct HostModel {
   pop_tuning tun{};
   const pop_grid_input *gin = nullptr;     // caller's grid (pop_create_with_grid); read during host_build only
   int rank = 0, nranks = 1;
+  bool plan_only = false;                  // POP_CREATE_PLAN_ONLY: blocks, distribution and halo plan, no fields
+  long long ocean_cols_local = -1, ocean_cols_total = -1;   // ocean columns of the physical domain (global KMT rule / record), make_blocks
   int nxb = 0, nyb = 0, km = 0, nt = 2;
   int nbx = 0, nby = 0, nblocks_tot = 0, nblocks = 0;   // nblocks = local
   size_t n2 = 0, n3 = 0;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--config", default="tiny")
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--kw", default="")
+    ap.add_argument("--no-restart", action="store_true", help="skip the restart round trip (two more models per rank: memory of the large cases)")
     ap.add_argument("--grid", type=int, default=0, help="1: the caller-supplied synthetic grid (pop_create_with_grid), e.g. for ns_boundary=2")
     ap.add_argument("--transport", default="staged", choices=["staged", "native"],
                     help="staged: callback transport over gloo; native: the library's own RCCL binding "
@@ -85,6 +86,13 @@ def main():
             print("rank %d: global_extreme(max=%s) differs" % (rank, want_max)); ok = False
     if m.global_count("UBTROP", 1, 0) != ref.global_count("UBTROP", 1, 0) or m.global_sum("PSURF", 1, 0) != ref.global_sum("PSURF", 1, 0):
         print("rank %d: global count / sum differs" % rank); ok = False
+    if args.no_restart:
+        t = torch.tensor([1 if ok else 0]); dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            print("MR_GPU_CHECK", "OK" if int(t.item()) == 1 else "FAILED", "world", world, "config", args.config, args.kw, "transport", args.transport)
+        m.close(); ref.close()
+        dist.destroy_process_group()
+        sys.exit(0 if int(t.item()) == 1 else 1)
     # restart file written by all ranks together (each its own rows), read back by all ranks and by the single-rank twin
     import tempfile
     path = os.path.join(tempfile.gettempdir(), "mr_restart_%s.bin" % os.environ.get("MASTER_PORT", "0"))
