@@ -30,7 +30,8 @@ extern "C" {
 /* Run-time configuration: the namelist subset this path reads
  * (domain_nml, grid_nml, time_manager_nml, hmix_*_nml, vertical_mix_nml,
  *  vmix_*_nml, advect_nml, pressure_grad_nml, baroclinic_nml, &solvers). */
-#define POP_CONFIG_VERSION 4   /* layout of pop_config below; pop_create refuses any other struct_version (4: gm_transition_layer appended) */
+#define POP_CONFIG_VERSION 5   /* layout of pop_config below; pop_create refuses any other struct_version (4: gm_transition_layer appended; 5: gm_diag_bolus and
+                                 * gm_kappa_bkg_srfbl out of reserved_i, ah_bkg_bottom and kappa_depth_* appended -- added late in round 3 without a new number) */
 typedef struct pop_config {
   int struct_version;         /* = POP_CONFIG_VERSION (round 3: every option has its own named field) */
   int nx_global, ny_global, km, nt;   /* domain_size.F90 */
@@ -170,6 +171,9 @@ typedef struct pop_tuning {
   int gm_sf_stored;        /* 0: Gent-McWilliams without cancellation: the stream-function terms SF_SLX / SF_SLY re-derived in the flux kernel instead of stored */
   int state3d_levels;      /* density of a whole 3-D array: levels per thread, 4 (default) | 2 | 8 with the per-level EOS coefficients read from
                             * a table, 1 = one cell per thread with the coefficients formed in place */
+  int pcg_persist;         /* pcg with the diagonal preconditioner on small 2-D systems (<= 1024 chunks of 256 cells, single rank or the replicated solve):
+                            * 1 = the whole solve as ONE resident launch, vectors in LDS / registers, workgroups exchanging partials and halo z through
+                            * memory words that are their own flags (kernels_pcg_persist.hpp); 0 = the two-launch fused iteration */
 } pop_tuning;
 void pop_tuning_init(pop_tuning *t);   /* struct_bytes = sizeof, every field POP_TUNING_UNSET */
 int pop_get_tuning(const pop_ctx *ctx, pop_tuning *resolved);   /* fields still POP_TUNING_UNSET: the size rule applied */

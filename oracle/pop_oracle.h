@@ -26,8 +26,9 @@ extern "C" {
 
 /* Same field order as include/pop_amd.h's pop_config so one ctypes
  * Structure serves both libraries (declared separately on purpose). */
+#define ORC_CONFIG_VERSION 5   /* = POP_CONFIG_VERSION of include/pop_amd.h */
 typedef struct {
-  int struct_version;         /* = 3, as include/pop_amd.h POP_CONFIG_VERSION */
+  int struct_version;         /* = ORC_CONFIG_VERSION = include/pop_amd.h POP_CONFIG_VERSION; orc_create returns NULL for any other */
   int nx_global, ny_global, km, nt;
   int block_size_x, block_size_y;
   int ew_boundary;            /* 0 closed, 1 cyclic */

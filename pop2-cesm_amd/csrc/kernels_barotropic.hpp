@@ -748,6 +748,9 @@ __device__ __forceinline__ double fused_total(const double *__restrict__ partial
   return total;
 }
 
+// "not written yet" in a memory word that is its own flag (kernels_pcg_persist.hpp): a NaN bit pattern no arithmetic produces
+constexpr unsigned long long POP_SPIN_EMPTY = 0x7FF8DEADBEEF0001ULL;
+
 // step A: [r -= alpha q]; z = r/diag; partial (r,z).  The cell's operands are loaded before the ordered total of the
 // previous partials is formed, so memory latency overlaps it.  The other half of the pending update, x += alpha s, is
 // done by step B of the same iteration (round 3): B holds s of the previous iteration in registers anyway, so x costs it one
@@ -799,7 +802,7 @@ template <bool UPDATE>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_fpcg_a_pair(DevGrid g, FusedArgs a) {
   __shared__ double sh[2][POP_RED_THREADS];
-  const int stop = a.sc->stop;
+  const int stop = sld(&a.sc->stop);
   const int b = blockIdx.y, t = threadIdx.x;
   const int e0 = ((int)blockIdx.x >> 3) * 16 + ((int)blockIdx.x & 7);
   int ch[2]; bool land[2]; long long q[2]; bool live[2];
@@ -824,7 +827,7 @@ k_fpcg_a_pair(DevGrid g, FusedArgs a) {
   double alpha = 0.0;
   if (UPDATE) {
     const double sq = fused_total(a.partB, a.nchunk, a.nblocks, a.bsB, 1);
-    const double rz = a.sc->eta1;
+    const double rz = sld(&a.sc->eta1);
     alpha = rz / sq;
     if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { a.sc->eta0 = rz; a.sc->alpha = alpha; }
   }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <unordered_map>
 #include "kernels_baroclinic.hpp"
 #include "kernels_barotropic.hpp"
 #include "kernels_mix.hpp"
@@ -16,6 +17,7 @@
 #include "kernels_evp.hpp"
 #include "kernels_lwlim.hpp"
 #include "kernels_gm.hpp"
+#include "kernels_pcg_persist.hpp"
 #include <fcntl.h>
 #include <unistd.h>
 #include "rccl_transport.hpp"
@@ -100,6 +102,17 @@ struct pop_ctx {
   bool land_skip = true; int land_full_steps = 4, full_left = 4, full_seen = 0; double land_fraction = 0.0;
   bool fpcg_one_cell = false;   // POP_FPCG_B2=0: one cell per thread in step B of the fused pcg even on large grids
   bool force_presum = false;
+  // the resident pcg of small grids (kernels_pcg_persist.hpp; pop_tuning.pcg_persist): one plan per solver view
+  struct PersistPlan {
+    const void *key = nullptr; bool ok = false; std::string why;
+    int CP = 0, nwg = 0, nwin_max = 0, nslots = 0;
+    int *own_q = nullptr, *halo_off = nullptr, *halo_q = nullptr; unsigned short *nbr = nullptr;
+    unsigned long long *P = nullptr, *Zb = nullptr;
+  };
+  std::vector<PersistPlan> persist;
+  std::vector<int> h_srcmap;                               // host copy of srcmap (local view)
+  double *persist_out = nullptr;                           // pinned: iterations, (r,r), status, checks
+  int persist_used = 0;                                    // the last pcg solve ran as the resident launch
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
   bool reg_thomas_t = true;
   int trc_lds_rows = 4;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
@@ -436,6 +449,13 @@ int solver_pcg(pop_ctx *c) {
 // convergenceCheckFreq iterations (same arithmetic and summation order as solver_pcg).  It runs on a
 // SolveView: the rank's own blocks (single rank), or -- replicated barotropic mode -- every block
 // of the decomposition on every rank.
+// which forms of step A / step B the fused pcg launches (launch_fpcg_a / launch_fpcg_b)
+static bool fpcg_pair_ok(const pop_ctx *c, const SolveView &v, const FusedArgs &a) {
+  return v.g.red_act && a.presummed && !a.sendmap && (v.g.red_nact % 16) == 0 && !c->fpcg_one_cell && !tun_off(c->h.tun.fpcg_a_pair);
+}
+static bool fpcg_two_ok(const pop_ctx *c, const SolveView &v, const FusedArgs &a) {
+  return a.presummed && (v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell;
+}
 FusedArgs fused_args(pop_ctx *c, const SolveView &v) {
   FusedArgs a{};
   a.X = v.X; a.R = v.R; a.Z = v.Z; a.S0 = v.S0; a.S1 = v.S1; a.Q = v.Q;
@@ -461,7 +481,7 @@ void launch_fresidual(pop_ctx *c, const SolveView &v, const FusedArgs &a) {
 // step A of the fused pcg: two chunks per workgroup on compacted launches (single rank), else one
 void launch_fpcg_a(pop_ctx *c, const SolveView &v, const FusedArgs &a, bool update) {
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
-  const bool pair = v.g.red_act && a.presummed && !a.sendmap && (v.g.red_nact % 16) == 0 && !c->fpcg_one_cell && !tun_off(c->h.tun.fpcg_a_pair);
+  const bool pair = fpcg_pair_ok(c, v, a);
   if (pair) {
     const dim3 GP(G.x / 2, G.y);
     if (update) hipLaunchKernelGGL(k_fpcg_a_pair<true>, GP, B, 0, c->stream, v.g, a);
@@ -473,7 +493,7 @@ void launch_fpcg_a(pop_ctx *c, const SolveView &v, const FusedArgs &a, bool upda
 // xupd: the pending x += alpha s of the previous iteration is applied here (k_fpcg_a<true> ran before and published alpha)
 void launch_fpcg_b(pop_ctx *c, const SolveView &v, const FusedArgs &a, bool xupd) {
   const dim3 G = view_grid(v);
-  const bool two = a.presummed && (v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell;
+  const bool two = fpcg_two_ok(c, v, a);
   // (occupancy probe, profiles/r03_ab_b2_occupancy.txt: with dynamic LDS holding the kernel to 3 / 2 waves per SIMD instead of its 4
   // the step costs +2.2 / +7.1 ms; the two-cell form needs 108 VGPRs, a 96- or 80-register budget spills 84 / 140 B)
   if (two && xupd) hipLaunchKernelGGL(k_fpcg_b2<true>, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
@@ -534,8 +554,125 @@ int run_intervals(pop_ctx *c, int nint, Enqueue enqueue, double &rr, int &err) {
   return -1;
 }
 
+// ---- the resident pcg of small grids (kernels_pcg_persist.hpp) ------------------------------------------------------------------
+// Plan of one view: which chunks a workgroup owns, the window index of every stencil neighbour, the halo cells.  Built on the host
+// from the view's source map (ghost -> source cell, -1 = fill), so block boundaries inside the view, the cyclic wrap, closed
+// boundaries and a tripole fold need no case of their own.  Returns nullptr (with the reason kept) when the view does not qualify.
+static pop_ctx::PersistPlan *persist_plan(pop_ctx *c, const SolveView &v) {
+  for (auto &p : c->persist) if (p.key == (const void *)v.srcmap) return p.ok ? &p : nullptr;
+  c->persist.emplace_back();
+  pop_ctx::PersistPlan &pl = c->persist.back();
+  pl.key = (const void *)v.srcmap;
+  const HostModel &h = c->h;
+  const int n2 = (int)h.n2, nxb = h.nxb, nchunk = v.nchunk, nb = v.g.nblocks, nslots = nchunk * nb;
+  const bool global = v.srcmap != c->srcmap;                // the replicated view holds every block of the decomposition
+  auto refuse = [&](const char *why) -> pop_ctx::PersistPlan * { pl.why = why; return nullptr; };
+  if (nb * ((nchunk + POP_RED_THREADS - 1) / POP_RED_THREADS) > POP_PERSIST_MAXP) return refuse("too many partial slots per thread");
+  int CP = 0;
+  for (int cp : {1, 2, 4, 8}) if ((nslots + cp - 1) / cp <= 128) { CP = cp; break; }
+  if (!CP) return refuse("more than 1024 chunks");
+  const std::vector<int> sm = global ? global_srcmap(h) : c->h_srcmap;
+  if ((long long)sm.size() != (long long)n2 * nb) return refuse("source map size");
+  const int nwg = (nslots + CP - 1) / CP, NOWN = CP * POP_RED_THREADS;
+  std::vector<int> own((size_t)nwg * NOWN, -1), hoff(nwg + 1, 0), hq;
+  std::vector<unsigned short> nbr((size_t)nwg * NOWN * 8, 0);
+  const int off[8] = {nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+  int nwin_max = 0;
+  for (int w = 0; w < nwg; ++w) {
+    std::unordered_map<int, int> where;                    // cell -> window index
+    for (int u = 0; u < CP; ++u) {
+      const int slot = w * CP + u;
+      if (slot >= nslots) break;
+      const int b = slot / nchunk, ch = slot % nchunk;
+      const BlockInfo &B = h.all_blocks[global ? b : h.local_ids[b] - 1];
+      for (int t = 0; t < POP_RED_THREADS; ++t) {
+        const int p2 = ch * POP_RED_THREADS + t;
+        if (p2 >= n2) break;
+        const int i = p2 % nxb + 1, j = p2 / nxb + 1;
+        if (i < B.ib || i > B.ie || j < B.jb || j > B.je) continue;
+        own[(size_t)w * NOWN + u * POP_RED_THREADS + t] = b * n2 + p2;
+        where[b * n2 + p2] = u * POP_RED_THREADS + t;
+      }
+    }
+    const size_t h0 = hq.size();
+    std::vector<std::pair<size_t, int>> zero_refs;
+    for (int L = 0; L < NOWN; ++L) {
+      const int q = own[(size_t)w * NOWN + L];
+      if (q < 0) continue;
+      for (int n = 0; n < 8; ++n) {
+        const int m = sm[q + off[n]];
+        int idx;
+        if (m < 0) idx = -1;
+        else {
+          auto it = where.find(m);
+          if (it != where.end()) idx = it->second;
+          else { idx = NOWN + (int)(hq.size() - h0); where[m] = idx; hq.push_back(m); }
+        }
+        nbr[((size_t)w * NOWN + L) * 8 + n] = (unsigned short)(idx < 0 ? 0xFFFF : idx);
+      }
+    }
+    const int nhalo = (int)(hq.size() - h0), nwin = NOWN + nhalo + 1;
+    if ((nhalo + POP_RED_THREADS - 1) / POP_RED_THREADS > POP_PERSIST_MAXH) return refuse("halo of a workgroup too large");
+    if (nwin >= 0xFFFF) return refuse("window too large");
+    for (int L = 0; L < NOWN; ++L) for (int n = 0; n < 8; ++n) {
+      unsigned short &x = nbr[((size_t)w * NOWN + L) * 8 + n];
+      if (x == 0xFFFF) x = (unsigned short)(nwin - 1);     // the cell of zeros (fill value of closed boundaries)
+    }
+    hoff[w + 1] = (int)hq.size();
+    nwin_max = std::max(nwin_max, nwin);
+  }
+  if ((size_t)3 * nwin_max * sizeof(double) > 60000) return refuse("window does not fit the LDS budget");
+  if (hq.empty()) hq.push_back(0);
+  if (dev_upload(c, &pl.own_q, own.data(), own.size()) || dev_upload(c, &pl.nbr, nbr.data(), nbr.size()) ||
+      dev_upload(c, &pl.halo_off, hoff.data(), hoff.size()) || dev_upload(c, &pl.halo_q, hq.data(), hq.size())) return nullptr;
+  double *p = nullptr;
+  if (dev_alloc(c, &p, (size_t)3 * nslots)) return nullptr;
+  pl.P = reinterpret_cast<unsigned long long *>(p);
+  if (dev_alloc(c, &p, (size_t)3 * n2 * nb)) return nullptr;
+  pl.Zb = reinterpret_cast<unsigned long long *>(p);
+  pl.CP = CP; pl.nwg = nwg; pl.nwin_max = nwin_max; pl.nslots = nslots; pl.ok = true;
+  return &pl;
+}
+int solver_pcg_persist(pop_ctx *c, SolveView &v, const pop_ctx::PersistPlan &pl) {
+  const pop_config &cf = c->h.c;
+  const long long ncell = (long long)v.g.n2 * v.g.nblocks;
+  PersistArgs a{};
+  a.X = v.X; a.Bv = v.RHS; a.C = v.C; a.WNo = v.g.WNo; a.WEa = v.g.WEa; a.WNE = v.g.WNE; a.mMask8 = v.g.mMask8;
+  a.nxb = v.g.nxb; a.nchunk = v.nchunk; a.nblocks = v.g.nblocks; a.nslots = pl.nslots; a.ncell = ncell;
+  a.own_q = pl.own_q; a.nbr = pl.nbr; a.halo_off = pl.halo_off; a.halo_q = pl.halo_q; a.P = pl.P; a.Zb = pl.Zb;
+  a.max_iter = cf.max_iterations; a.freq = cf.convergence_check_freq; a.criterion = c->h.convergenceCriterion; a.out = c->persist_out;
+  // the words the first phase / first iteration polls must be empty (the rest is reset in rotation by its owners)
+  hipLaunchKernelGGL(k_fill_words, dim3((unsigned)((pl.nslots + 255) / 256)), dim3(256), 0, c->stream, pl.P, (long long)pl.nslots, POP_SPIN_EMPTY);
+  hipLaunchKernelGGL(k_fill_words, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, pl.Zb + ncell, ncell, POP_SPIN_EMPTY);
+  c->persist_out[0] = -1.0; c->persist_out[1] = 0.0; c->persist_out[2] = 0.0; c->persist_out[3] = 0.0;
+  const size_t lds = (size_t)3 * pl.nwin_max * sizeof(double);
+  const dim3 G(pl.nwg), B(POP_RED_THREADS);
+  switch (pl.CP) {
+    case 1: hipLaunchKernelGGL(k_pcg_persist<1>, G, B, lds, c->stream, a); break;
+    case 2: hipLaunchKernelGGL(k_pcg_persist<2>, G, B, lds, c->stream, a); break;
+    case 4: hipLaunchKernelGGL(k_pcg_persist<4>, G, B, lds, c->stream, a); break;
+    default: hipLaunchKernelGGL(k_pcg_persist<8>, G, B, lds, c->stream, a); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->chk_ev[0], c->stream));
+  HIPCHK(c, hipEventSynchronize(c->chk_ev[0]));
+  if (c->persist_out[2] != 0.0 || c->persist_out[0] < 0.0) { c->err = "resident pcg: a wait for another workgroup's data gave up (kernels_pcg_persist.hpp)"; return 1; }
+  c->numIterations = (int)c->persist_out[0];
+  c->rmsResidual = std::sqrt(c->persist_out[1] * c->h.residualNorm);
+  c->persist_used = 1;
+  hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, v.X, v.srcmap, ncell);
+  HIPCHK(c, hipGetLastError());
+  const bool conv = c->persist_out[3] > 0.0 && c->persist_out[1] < c->h.convergenceCriterion;
+  if (!conv && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCG: solver not converged"; return 2; }
+  return 0;
+}
+
 int solver_pcg_fused(pop_ctx *c, SolveView &v) {
   const pop_config &cf = c->h.c;
+  c->persist_used = 0;
+  if (tun_on(c->h.tun.pcg_persist) && !fused_args(c, v).presummed) {
+    if (const pop_ctx::PersistPlan *pl = persist_plan(c, v)) return solver_pcg_persist(c, v, *pl);
+  }
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
   const int freq = cf.convergence_check_freq;
   SolverScalars init{}; init.eta0 = 1.0;
@@ -1261,7 +1398,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED") X(pcg_persist, "POP_PCG_PERSIST")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -1327,7 +1464,11 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     if (cfg->gm_diag_bolus && cfg->hmix_tracer != 3) return bad("gm_diag_bolus needs hmix_tracer = 3");
     if (cfg->gm_transition_layer != 0 && cfg->gm_transition_layer != 1) return bad("gm_transition_layer: 0 or 1");
     if (cfg->gm_transition_layer && cfg->hmix_tracer != 3) return bad("gm_transition_layer needs hmix_tracer = 3");
-    if (cfg->gm_transition_layer && cfg->partial_bottom_cells) return bad("gm_transition_layer with partial_bottom_cells (the DZT branch of smooth_hblt, vmix_kpp.F90:3835-3841) is not built");
+    // the reference aborts in init_gm: 'hmix_gm currently incompatible with partial bottom cells' (hmix_gm.F90:782-785) -- its slopes, stream-function
+    // terms and flux divergence use dz(k), the tracer budget DZT (accepted until round 3 with dz(k) throughout, tracer content not conserved)
+    if (cfg->hmix_tracer == 3 && cfg->partial_bottom_cells) return bad("hmix_tracer = 3 (Gent-McWilliams) with partial_bottom_cells: the reference refuses the combination (hmix_gm.F90:782-785), so does this library");
+    // hmix_gm.F90:724-730: kappa_depth_2 = 0 with the 'depth' profile aborts in init_gm
+    if (cfg->hmix_tracer == 3 && cfg->gm_kappa_type == 2 && cfg->kappa_depth_2 == 0.0) return bad("gm_kappa_type = 2 ('depth') needs kappa_depth_2 /= 0 (hmix_gm.F90:724-730)");
     if (cfg->gm_kappa_type < 0 || cfg->gm_kappa_type > 2) return bad("gm_kappa_type: 0 constant, 1 bfre, 2 depth (the other kappa choices of hmix_gm_nml are not built)");
     if (cfg->gm_kappa_freq < 0 || cfg->gm_kappa_freq > 2) return bad("gm_kappa_freq: 0 never, 1 every_time_step, 2 once_a_day");
     if (cfg->gm_kappa_freq == 2 && cfg->tmix_opt == 1) return bad("gm_kappa_freq = once_a_day with time_mix_opt 'avg' (half steps that do not fit the day: the end-of-day test of time_management.F90:3586-3592 on the calendar) is not built: avgfit, robert or none");
@@ -1763,6 +1904,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       for (size_t e = 0; e < T.dst.size(); ++e) sm[T.dst[e]] = T.a[e];
     }
     if (dev_upload(c, &c->srcmap, sm.data(), sm.size())) return 1;
+    c->h_srcmap = sm;
+    HIPCHK(c, hipHostMalloc((void **)&c->persist_out, 4 * sizeof(double)));
     HIPCHK(c, hipHostMalloc((void **)&c->host_sc, sizeof(SolverScalars)));
     HIPCHK(c, hipHostMalloc((void **)&c->host_rr, 8 * sizeof(double)));
     for (auto &e : c->chk_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1908,6 +2051,7 @@ int pop_destroy(pop_ctx *c) {
   for (auto &g : c->pcsi_graphs) hipGraphExecDestroy(g.second);
   if (c->host_sc) hipHostFree(c->host_sc);
   if (c->host_rr) hipHostFree(c->host_rr);
+  if (c->persist_out) hipHostFree(c->persist_out);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_d2t) hipEventDestroy(c->ev_d2t);
   if (c->ev_d2u) hipEventDestroy(c->ev_d2u);
@@ -1963,6 +2107,7 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "solver_iterations_enqueued") return (int)c->solver_enq;
   if (n == "rank") return c->h.rank;
   if (n == "nranks") return c->h.nranks;
+  if (n == "pcg_persist_used") return c->persist_used;
   if (n == "solver_path") return c->host_only ? 0 : solver_path_code(c);   // 1 per operation, 2 fused, 3 fused distributed, 4 replicated fused
   if (n == "thomas_register_tracers") return c->reg_thomas_t && (c->g.km == 60 || c->g.km == 62);    // column-in-registers Thomas kernels in use
   if (n == "thomas_register_velocity") return c->reg_thomas && (c->g.km == 60 || c->g.km == 62);
@@ -2130,6 +2275,7 @@ int pop_write_restart(pop_ctx *c, const char *path) {
       {"elapsed_days", "int", std::to_string(day)}, {"seconds_this_day", "r8", fmt_r8((double)sod)},
       {"nsteps_total", "int", std::to_string(c->nsteps_total)},
       {"nsteps_this_interval", "int", std::to_string(c->nsteps_this_interval)},   // extension: exact restart inside an averaging interval
+      {"eod_last", "log", c->eod ? "T" : "F"},   // restart.F90:346: the step that has just finished ended a day (what the next step's eod_last will be, time_management.F90:1809)
     };
     if (h.c.tmix_opt == 3) {
       static const char *tn[2] = {"TEMP", "SALT"};
@@ -2212,6 +2358,16 @@ int pop_read_restart(pop_ctx *c, const char *path, int flags) {
   c->nsteps_total = atoi(g["nsteps_total"].c_str());
   c->nsteps_this_interval = g.count("nsteps_this_interval") ? atoi(g["nsteps_this_interval"].c_str()) : 0;
   c->first_step = 0;
+  // restart.F90:468: eod_last comes from the file (list-directed logical); time_manager of the next step copies eod into eod_last
+  // (time_management.F90:1809), so the value read is parked in eod.  A file without it (another writer): not the end of a day.
+  c->eod = 0; c->eod_last = 0;
+  if (g.count("eod_last")) { std::string v = g["eod_last"]; size_t k = v.find_first_not_of(" ."); c->eod = (k != std::string::npos && (v[k] == 'T' || v[k] == 't')) ? 1 : 0; }
+  // module state of hmix_gm that no restart file carries: KAPPA_VERTICAL is 1 until compute_kappa runs again (init_gm, hmix_gm.F90:860) -- with
+  // 'once_a_day' that is the first step of a restart written at the end of a day (eod_last), with 'never' it stays 1 (the reference's behaviour too)
+  if (c->gm.KV) {
+    std::vector<double> ones((size_t)c->g.n3 * c->g.nblocks, 1.0);
+    HIPCHK(c, hipMemcpy(c->gm.KV, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   if (h.c.tmix_opt == 3) {
     static const char *tn[2] = {"TEMP", "SALT"};
     for (int n = 0; n < 2; ++n) {

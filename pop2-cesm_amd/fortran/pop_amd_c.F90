@@ -12,7 +12,7 @@
    integer (c_int), parameter :: POP_CREATE_HOST_ONLY = 1
 
    ! mirrors `struct pop_config` field for field
-   integer (c_int), parameter :: POP_CONFIG_VERSION = 4
+   integer (c_int), parameter :: POP_CONFIG_VERSION = 5
 
    type, bind(C) :: pop_config
       integer (c_int) :: struct_version = POP_CONFIG_VERSION
@@ -32,8 +32,8 @@
       integer (c_int) :: kpp_ml_diagnostics = 0                            ! HMXL, HMXL_DR every step
       integer (c_int) :: sw_absorption_type = 0, jerlov_water_type = 0, lsw_absorb = 0   ! sw_absorption_nml
       integer (c_int) :: partial_bottom_cells = 0                          ! grid_nml
-      integer (c_int) :: gm_slope_control = 0                              ! hmix_gm_nml slope_control_choice: 0 'notanh', 1 'tanh' (hmix_tracer = 3)
-      integer (c_int) :: gm_kappa_type = 0, gm_kappa_freq = 0              ! hmix_gm_nml kappa_*_choice: 0 constant, 1 bfre; kappa_freq_choice: 0 never, 1 every_time_step
+      integer (c_int) :: gm_slope_control = 0                              ! hmix_gm_nml slope_control_choice: 0 'notanh', 1 'tanh', 2 'clip', 3 'Gerd' (hmix_tracer = 3)
+      integer (c_int) :: gm_kappa_type = 0, gm_kappa_freq = 0              ! hmix_gm_nml kappa_*_choice: 0 constant, 1 bfre, 2 depth; kappa_freq_choice: 0 never, 1 every_time_step, 2 once_a_day
       real (c_double) :: am, ah
       real (c_double) :: const_vvc, const_vdc
       real (c_double) :: convect_diff, convect_visc, bottom_drag, aidif
@@ -71,6 +71,7 @@
       integer (c_int) :: kpp_src_full, solver_unfused, solver_nograph, solver_presum, solver_distributed, solver_overlap_off
       integer (c_int) :: fpcg_b2, pcsi_step2, halo_separate, halo_overlap_off, rccl_overlap, evp_wave
       integer (c_int) :: fpcg_a_pair, kpp_sparse, pbc_generic_thomas, pbc_generic_kpp, stream_priority, gm_sf_stored, state3d_levels
+      integer (c_int) :: pcg_persist
    end type pop_tuning
 
    type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task

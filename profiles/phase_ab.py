@@ -20,6 +20,7 @@ m = pkg.PopModel(named_config(sys.argv[2], **kw))
 for _ in range(6):
     m.step()
 m.sync()
+m.scalar("solver_ms_reset")
 t0 = time.perf_counter()
 n = 8
 for _ in range(n):
@@ -27,6 +28,11 @@ for _ in range(n):
 m.sync()
 ms = 1e3 * (time.perf_counter() - t0) / n
 out = {"ms_per_step": round(ms, 3), "iters": m.solver_diagnostics()[0]}
+try:
+    out["solver_us_per_iter"] = round(1e3 * m.scalar("solver_ms_total") / max(m.scalar("solver_iterations_total"), 1.0), 2)
+    out["solver_ms"] = round(m.scalar("solver_ms_total") / max(m.scalar("solver_calls_total"), 1.0), 3)
+except Exception:
+    pass
 m.time_manager()
 for ph in ("vmix", "tracer_rhs", "impvmixt", "state", "momentum_rhs", "impvmixu", "correct"):
     try:

@@ -46,7 +46,7 @@ def base_config(**kw):
     (vertical_mix.F90:233-240, POP_SolversMod.F90:578-662, pressure_grad.F90:118-119,
     baroclinic.F90:208, vmix_rich.F90:108-110, vmix_const.F90:101-102)."""
     c = PopConfig()
-    c.struct_version = 4
+    c.struct_version = 5
     c.nt = 2
     c.ew_boundary, c.ns_boundary = 1, 0
     c.hmix_momentum = c.hmix_tracer = 2

@@ -1140,6 +1140,38 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
     a.close(); b.close(); c.close(); d.close(); e.close()
 
 
+@pytest.mark.parametrize("name,kw,grid", [
+    ("tiny", {"block_size_x": 24, "block_size_y": 20}, False),                      # 4 blocks: ghosts between blocks through the source map
+    ("tiny", {"block_size_x": 48, "block_size_y": 40}, False),                      # one block, cyclic east-west
+    ("tiny", {"block_size_x": 24, "block_size_y": 20, "ew_boundary": 0, "stepped_bathymetry": 1}, False),   # closed east-west: fill-value neighbours
+    ("tiny", {"block_size_x": 28, "block_size_y": 24}, False),                      # padded blocks (2 x 2, last column / row short)
+    ("tiny", {"block_size_x": 24, "block_size_y": 20, "convergence_check_freq": 4, "max_iterations": 203, "convergence_criterion": 1.0e-13}, False),
+    ("tiny", {"ns_boundary": 2, "block_size_x": 24, "block_size_y": 20}, True),     # tripole fold inside the source map
+    ("test", {}, False),                                                            # 96 blocks (more than a thread can collect: must fall back)
+    ("gx3v7", {}, False),
+    ("gx1v7", {}, False),                                                           # BASELINE configs[2]: 492 chunks, 123 workgroups of 4 chunks
+    ("gx1v7", {"block_size_y": 96}, False),                                         # four j-band blocks in one view (the shape of the replicated solve)
+])
+def test_persistent_pcg_is_bitwise_the_fused_pcg(pkg, name, kw, grid):
+    """pop_tuning.pcg_persist: the whole pcg solve of a small 2-D system as one resident launch (kernels_pcg_persist.hpp) -- the
+    vectors in LDS / registers, partials and halo z exchanged through memory words that are their own flags.  Same chunk
+    partials, same ordered totals, same cell arithmetic: iteration counts and every field bit for bit the two-launch fused form."""
+    cfg = named_config(name, **kw)
+    g = synthetic_grid(cfg) if grid else None
+    a = pkg.PopModel(cfg, grid=g)
+    b = pkg.PopModel(cfg, grid=g, tuning={"pcg_persist": 1})
+    used = 0
+    for step in range(5):
+        a.step(); b.step()
+        assert a.solver_diagnostics() == b.solver_diagnostics(), "step %d" % step
+        used += b.dim("pcg_persist_used")
+        assert a.dim("pcg_persist_used") == 0
+    assert used == (0 if name == "test" else 5)
+    for f in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER", "GRADPX"):
+        assert np.array_equal(a.get(f), b.get(f)), f
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("kw,env", [({"vmix_choice": 3, "km": 24}, {}),
                                     ({"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1, "hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21}, {}),
                                     ({"vmix_choice": 3, "km": 24, "tmix_opt": 1, "time_mix_freq": 3}, {}), ({"vmix_choice": 3, "km": 24, "tmix_opt": 3}, {}),
