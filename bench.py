@@ -500,6 +500,8 @@ def main():
     cfg = workload_config(args.workload, world, args.block_rows)
     cfg.solver_choice = {"pcg": 1, "chrongear": 2, "pcsi": 3}[args.solver]
     cfg.preconditioner_choice = 1 if args.precond == "evp" else 0
+    if args.pbc and args.gm:
+        raise SystemExit("--gm with --pbc: the reference refuses Gent-McWilliams with partial bottom cells (hmix_gm.F90:782-785), so does the library")
     if args.pbc:
         cfg.partial_bottom_cells = 1
     if args.gm:   # the 1-degree production tracer mixing (namelist_defaults_pop.xml hmix_tracer_choice 'gm' on the gx grids)
@@ -583,6 +585,7 @@ def main():
                                                               4: "replicated fused solve on every rank"}.get(model.dim("solver_path"), "?"),
             "thomas_tracers": "register" if model.dim("thomas_register_tracers") == 1 else "generic (HBM scratch)",
             "thomas_velocity": "register" if model.dim("thomas_register_velocity") == 1 else "generic (HBM scratch)",
+            "pcg_resident_launch": bool(model.dim("pcg_persist_used") == 1),      # small 2-D systems: the whole solve as one resident launch (kernels_pcg_persist.hpp)
             "device": dev}
     paths = [mine]
     if dist is not None:

@@ -172,7 +172,7 @@ typedef struct pop_tuning {
   int state3d_levels;      /* density of a whole 3-D array: levels per thread, 4 (default) | 2 | 8 with the per-level EOS coefficients read from
                             * a table, 1 = one cell per thread with the coefficients formed in place */
   int pcg_persist;         /* pcg with the diagonal preconditioner on small 2-D systems (<= 1024 chunks of 256 cells, single rank or the replicated solve):
-                            * 1 = the whole solve as ONE resident launch, vectors in LDS / registers, workgroups exchanging partials and halo z through
+                            * 1 (the default where it applies) = the whole solve as ONE resident launch, vectors in LDS / registers, workgroups exchanging partials and halo z through
                             * memory words that are their own flags (kernels_pcg_persist.hpp); 0 = the two-launch fused iteration */
 } pop_tuning;
 void pop_tuning_init(pop_tuning *t);   /* struct_bytes = sizeof, every field POP_TUNING_UNSET */

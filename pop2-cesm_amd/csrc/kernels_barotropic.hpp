@@ -180,21 +180,31 @@ __device__ __forceinline__ void block_sum_ordered(const double *__restrict__ pb,
 #pragma unroll
       for (int f = 0; f < NF; ++f) v[f] = v[f] + w[u][f];
   }
-  if (DEPTH > 16)   // remainder in batches of 16
-    for (; cidx + 15 * POP_RED_THREADS < nchunk; cidx += 16 * POP_RED_THREADS) {
-      double w[16][NF];
+  if (DEPTH > 16) {
+    // the remainder (fewer than DEPTH terms) in ONE more round (r4): every load of the batch is requested -- at a clamped address where the term
+    // does not exist -- before the first add, and a term that does not exist is not added (adding +0.0 could turn a sum of -0.0 into +0.0).
+    // Until round 4 the last few terms went one load -> one add at a time: at tx0.1v3 (33 844 chunks, 132 terms per thread) four to five
+    // dependent round trips behind the two batches of 64, ~4 of the 9.5 us of every k_block_sums launch inside the step.
+    if (cidx < nchunk) {
+      double w[DEPTH][NF];
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
+      for (int u = 0; u < DEPTH; ++u) {
+        const long long c = (long long)cidx + u * POP_RED_THREADS;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) w[u][f] = pb[((long long)cidx + u * POP_RED_THREADS) * NF + f];
+        for (int f = 0; f < NF; ++f) w[u][f] = pb[(c < nchunk ? c : (long long)nchunk - 1) * NF + f];
+      }
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
+      for (int u = 0; u < DEPTH; ++u) {
+        const bool there = (long long)cidx + u * POP_RED_THREADS < nchunk;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) v[f] = v[f] + w[u][f];
+        for (int f = 0; f < NF; ++f) v[f] = there ? v[f] + w[u][f] : v[f];
+      }
     }
-  for (; cidx < nchunk; cidx += POP_RED_THREADS)
+  } else {
+    for (; cidx < nchunk; cidx += POP_RED_THREADS)
 #pragma unroll
-    for (int f = 0; f < NF; ++f) v[f] = v[f] + pb[(long long)cidx * NF + f];
+      for (int f = 0; f < NF; ++f) v[f] = v[f] + pb[(long long)cidx * NF + f];
+  }
 #pragma unroll
   for (int f = 0; f < NF; ++f) sh[f][t] = v[f];
   __syncthreads();

@@ -1369,6 +1369,13 @@ __global__ void k_kpp_vvc(DevGrid g, const double *__restrict__ VISC, double *__
   }
 }
 
+// VVC from VISC in 64 x R patches on bandwidth-bound grids (a row-marching form that fetches every VISC value once was measured slower:
+// profiles/r04_ab_kpp_vvc_rows.txt)
+inline void launch_kpp_vvc(const DevGrid &g, const HostModel &h, hipStream_t st, const double *VISC, double *VVC) {
+  const int vp = patch_rows(g, h.tun.del4_tile);
+  hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vp), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vp ? 64 * vp : 256), 0, st, g, VISC, VVC, vp);
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 // per-context KPP state (MixDev::kpp)
 // col: bit 0 = ushear, bit 1 = buoydiff in column form.  side / ev_*: second HIP stream on which the shear kernel (needs only
@@ -1594,8 +1601,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
     else if (sp_) hipLaunchKernelGGL((k_kpp_blmix<true, false, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1], s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
     else if (g_kpp.vdc_same) hipLaunchKernelGGL((k_kpp_blmix<true, true>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1], s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
     else hipLaunchKernelGGL((k_kpp_blmix<true, false>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1], s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
-    const int vp = patch_rows(g, h.tun.del4_tile);
-    hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vp), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vp ? 64 * vp : 256), 0, st, g, (const double *)VISC, s.VVC, vp);
+    launch_kpp_vvc(g, h, st, (const double *)VISC, s.VVC);
     if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }
     return 0;
   }
@@ -1614,8 +1620,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
                             s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
     if (h.c.kpp_ml_diagnostics == 1 && s.HMXL && s.HMXL_DR)   // DBSFC holds every level here (the diagnostics switch the on-demand march off)
       hipLaunchKernelGGL(k_kpp_hmxl, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], (const double *)DBSFC, s.HMXL, s.HMXL_DR);
-    const int vp = patch_rows(g, h.tun.del4_tile);
-    hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vp), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vp ? 64 * vp : 256), 0, st, g, (const double *)VISC, s.VVC, vp);
+    launch_kpp_vvc(g, h, st, (const double *)VISC, s.VVC);
     if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }
     return 0;
   }
@@ -1671,8 +1676,7 @@ inline int kpp_vmix_coeffs(const HostModel &h, const DevGrid &g, const StepParam
   else hipLaunchKernelGGL((k_kpp_blmix<false, false>), GC, BC, 0, st, g, sp, g_kpp, (const double *)DBLOC, s.STF[0], s.STF[1], VISC, s.VDC[0], s.VDC[1],
                           s.KPP_SRC[0], s.KPP_SRC[1], s.HBLT);
   // large grids: 64 x 4 patches (the row j + 1 of the four-point average is read by the same workgroup; 64 x 2 / 8 / 16 measured: vmix 7.54 / 7.65 / 7.97 ms against 7.57)
-  const int vpatch = patch_rows(g, h.tun.del4_tile);
-  hipLaunchKernelGGL(k_kpp_vvc, dim3(patch_grid_x(g, vpatch), (g.km + POP_VVC_KC - 1) / POP_VVC_KC, g.nblocks), dim3(vpatch ? 64 * vpatch : 256), 0, st, g, (const double *)VISC, s.VVC, vpatch);
+  launch_kpp_vvc(g, h, st, (const double *)VISC, s.VVC);
   if (h.c.kpp_ml_diagnostics == 1 && s.HMXL && s.HMXL_DR)
     hipLaunchKernelGGL(k_kpp_hmxl, GC, BC, 0, st, g, g_kpp, s.TMIX[0], s.TMIX[1], (const double *)DBSFC, s.HMXL, s.HMXL_DR);
   if (hipGetLastError() != hipSuccess) { err = "KPP kernel launch failed"; return 1; }

@@ -142,13 +142,14 @@ k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a, int tj_first, in
         pu = pu * zo; pv = pv * zo; hu = hu * zh; hv = hv * zh;
         t.dzu[buf][lc] = zo; t.dzu[buf][hl] = zh;
       }
-      // own cell first, halo cell second: a lane without halo duty rewrites its own cell with the same values
+      // own cell first, halo cell second: a lane without halo duty has hl = lc and hbase = base3, i.e. its "halo" loads ARE the loads of
+      // its own cell (same addresses, same level), so it rewrites its own cell with the same values and no select is needed (r4: the
+      // 14 selects `hd ? hal.x : own.x` were 28 v_cndmask of the 368 VALU instructions of a level)
       t.u[buf][lc] = own.u; t.v[buf][lc] = own.v; t.ud[buf][lc] = pu; t.vd[buf][lc] = pv;
       t.f[buf][lc] = rho_f(cur.rn, cur.rc, cur.ro, bk); t.um[buf][lc] = cur.um; t.vm[buf][lc] = cur.vm;
-      const bool hd = tid < T::NHALO;
-      t.u[buf][hl] = hd ? hal.u : own.u; t.v[buf][hl] = hd ? hal.v : own.v; t.ud[buf][hl] = hd ? hu : pu; t.vd[buf][hl] = hd ? hv : pv;
-      t.f[buf][hl] = hd ? rho_f(hal.rn, hal.rc, hal.ro, bk) : rho_f(cur.rn, cur.rc, cur.ro, bk);
-      t.um[buf][hl] = hd ? hal.um : cur.um; t.vm[buf][hl] = hd ? hal.vm : cur.vm;
+      t.u[buf][hl] = hal.u; t.v[buf][hl] = hal.v; t.ud[buf][hl] = hu; t.vd[buf][hl] = hv;
+      t.f[buf][hl] = rho_f(hal.rn, hal.rc, hal.ro, bk);
+      t.um[buf][hl] = hal.um; t.vm[buf][hl] = hal.vm;
     }
     const int kp1 = (k < km) ? k + 1 : km, kp2 = (k + 2 <= km) ? k + 2 : km;
     const Lev nxt = load_cell(kp1);                          // in flight while this level is computed

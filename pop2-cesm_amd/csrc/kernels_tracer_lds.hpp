@@ -65,7 +65,6 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
     const int hp2 = hin ? hj * nxb + hi : 0;
     hq2 = (long long)b * n2 + hp2; hbase = (long long)b * g.n3 + hp2;
   }
-  const bool hd = tid < T::NHALO;
   const int kmt_own = g.KMT[q2];
   const int kmt = act ? kmt_own : 0;
   const int kmtn = g.KMTN[q2], kmts = g.KMTS[q2], kmte = g.KMTE[q2], kmtw = g.KMTW[q2];
@@ -146,14 +145,15 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
         const double zo = pbc_dz(g, k, kmu_o, dzub_o), zh = pbc_dz(g, k, kmu_h, dzub_h);
         pu = pu * zo; pv = pv * zo; hu = hu * zh; hv = hv * zh;
         const double to_ = pbc_dz(g, k, kmt_own, dzbc_o), th_ = pbc_dz(g, k, kmt_h, dzbc_h);
-        t.dzt[buf][lc] = to_; t.dzt[buf][hl] = hd ? th_ : to_;
+        t.dzt[buf][lc] = to_; t.dzt[buf][hl] = th_;
       }
       t.ud[buf][lc] = pu; t.vd[buf][lc] = pv;
-      t.ud[buf][hl] = hd ? hu : pu; t.vd[buf][hl] = hd ? hv : pv;
+      // (a lane without halo duty has hl = lc and hbase = base3: its "halo" loads are the loads of its own cell, the same values -- no select)
+      t.ud[buf][hl] = hu; t.vd[buf][hl] = hv;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         t.tc[buf][n][lc] = cur.tc[n]; t.tm[buf][n][lc] = cur.tm[n];
-        t.tc[buf][n][hl] = hd ? hal.tc[n] : cur.tc[n]; t.tm[buf][n][hl] = hd ? hal.tm[n] : cur.tm[n];
+        t.tc[buf][n][hl] = hal.tc[n]; t.tm[buf][n][hl] = hal.tm[n];
       }
     }
     const int kp1 = (k < km) ? k + 1 : km;

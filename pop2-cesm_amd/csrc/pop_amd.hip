@@ -571,6 +571,8 @@ static pop_ctx::PersistPlan *persist_plan(pop_ctx *c, const SolveView &v) {
   int CP = 0;
   for (int cp : {1, 2, 4, 8}) if ((nslots + cp - 1) / cp <= 128) { CP = cp; break; }
   if (!CP) return refuse("more than 1024 chunks");
+  // measurement only: pop_tuning.pcg_persist = 2 | 4 | 8 forces that many chunks per workgroup (at most 250 workgroups)
+  if (c->h.tun.pcg_persist == 2 || c->h.tun.pcg_persist == 4 || c->h.tun.pcg_persist == 8) { if ((nslots + c->h.tun.pcg_persist - 1) / c->h.tun.pcg_persist <= 250) CP = c->h.tun.pcg_persist; }
   const std::vector<int> sm = global ? global_srcmap(h) : c->h_srcmap;
   if ((long long)sm.size() != (long long)n2 * nb) return refuse("source map size");
   const int nwg = (nslots + CP - 1) / CP, NOWN = CP * POP_RED_THREADS;
@@ -670,7 +672,7 @@ int solver_pcg_persist(pop_ctx *c, SolveView &v, const pop_ctx::PersistPlan &pl)
 int solver_pcg_fused(pop_ctx *c, SolveView &v) {
   const pop_config &cf = c->h.c;
   c->persist_used = 0;
-  if (tun_on(c->h.tun.pcg_persist) && !fused_args(c, v).presummed) {
+  if (!tun_off(c->h.tun.pcg_persist) && !fused_args(c, v).presummed) {   // the rule: wherever the plan qualifies (small views); pop_tuning.pcg_persist = 0 switches it off
     if (const pop_ctx::PersistPlan *pl = persist_plan(c, v)) return solver_pcg_persist(c, v, *pl);
   }
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
@@ -1366,6 +1368,13 @@ int resolve(pop_ctx *c, const std::string &name, int tl, int n, double **ptr, lo
   if (name == "UISOP") return ok(c->gm.UISOP, a3);           // diag_gm_bolus (hmix_tracer = 3): eddy-induced velocity, east / north face and top of the T cell
   if (name == "VISOP") return ok(c->gm.VISOP, a3);
   if (name == "WISOP") return ok(c->gm.WISOP, a3);
+  // work fields of Gent-McWilliams mixing, for the pins of tests/pins.py: the merged stream function of the half cells (stored in the branch
+  // without cancellation: n = 2 face + half, face 0 east / north, half 0 top) and the transition layer's depths
+  if (name == "GM_SF_SLX") return (n >= 0 && n < 4) ? ok(c->gm.SF[n], a3) : 1;
+  if (name == "GM_SF_SLY") return (n >= 0 && n < 4) ? ok(c->gm.SF[4 + n], a3) : 1;
+  if (name == "TLT_DIABATIC_DEPTH") return ok(c->gm.DD, a2);
+  if (name == "TLT_THICKNESS") return ok(c->gm.TH, a2);
+  if (name == "TLT_INTERIOR_DEPTH") return ok(c->gm.ID, a2);
   if (name == "SMF") return ok(c->d2[n == 0 ? "SMF1" : "SMF2"], a2);
   if (name == "SMFT") return ok(c->d2[n == 0 ? "SMFT1" : "SMFT2"], a2);
   auto it = c->d2.find(name);
@@ -2158,7 +2167,7 @@ int pop_local_block_ids(const pop_ctx *c, int *ids) { std::copy(c->h.local_ids.b
 long long pop_field_count(const pop_ctx *c, const char *name) {
   const std::string n(name);
   const long long a2 = (long long)c->h.n2 * c->h.nblocks, a3 = (long long)c->h.n3 * c->h.nblocks;
-  for (const char *s : {"TRACER", "UVEL", "VVEL", "RHO", "KPP_SRC", "VVC", "UISOP", "VISOP", "WISOP"}) if (n == s) return a3;
+  for (const char *s : {"TRACER", "UVEL", "VVEL", "RHO", "KPP_SRC", "VVC", "UISOP", "VISOP", "WISOP", "GM_SF_SLX", "GM_SF_SLY"}) if (n == s) return a3;
   if (n == "VDC") return (long long)c->h.n2 * (c->h.km + 2) * c->h.nblocks;
   return a2;
 }

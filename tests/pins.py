@@ -17,13 +17,13 @@ import numpy as np
 from scipy.linalg import solve_banded
 
 GRAV = 980.6           # pop_constants.F90:235 (non-CCSMCOUPLED)
-THREE_D = ("TRACER", "UVEL", "VVEL", "RHO", "VVC", "KPP_SRC")
+THREE_D = ("TRACER", "UVEL", "VVEL", "RHO", "VVC", "KPP_SRC", "UISOP", "VISOP", "WISOP", "GM_SF_SLX", "GM_SF_SLY")
 
 
 class OracleAdapter:
-    def __init__(self, cfg):
+    def __init__(self, cfg, grid=None):
         from orclib import Oracle
-        self.o = Oracle(cfg)
+        self.o = Oracle(cfg, grid=grid)
         self.cfg = cfg
         self.km, self.nblocks = self.o.km, self.o.nblocks
 
@@ -76,12 +76,12 @@ class GpuAdapter:
     """the device library through the C ABI; vertical grid arrays come from a host-only oracle of the same configuration
     (they are init-time data, compared bit for bit in tests/test_host_grid_parity.py)"""
 
-    def __init__(self, pkg, cfg):
+    def __init__(self, pkg, cfg, grid=None):
         from orclib import Oracle
-        self.m = pkg.PopModel(cfg)
+        self.m = pkg.PopModel(cfg, grid=grid)
         self.cfg = cfg
         self.km, self.nblocks = self.m.km, self.m.nblocks
-        o = Oracle(cfg)
+        o = Oracle(cfg, grid=grid)
         self._vert = {k: o.v1(k).copy() for k in ("dz", "dzw", "dzwr", "bouss", "afac_t", "afac_u", "zt", "zw")}
         o.close()
 
@@ -820,3 +820,358 @@ def check_gm_linear(A, tol=2e-12):
     assert worst_g <= 1.0e-9, "GM tendency of a linear field differs from the closed form by %.3e" % worst_g     # what is left after the subtraction
     assert worst_v <= tol, "isopycnal part of VDC differs from its closed form by %.3e" % worst_v
     return worst_g, worst_v
+
+
+def _taper_slope(control, x):
+    """the slope tapers of hmix_gm.F90:1480-1594 as functions of x = SLA / slm, written from the papers the reference cites:
+    'tanh' Danabasoglu & McWilliams (1995): 1/2 (1 - tanh(10 x - 4)) below x = 1, 0 above; 'notanh', its piecewise-parabolic
+    stand-in: 1 up to x = 0.2, 0 from x = 0.6, in between 1/2 (1 - (2.5 x - 1)(4 - |10 x - 4|)); 'Gerd' (Gerdes et al. 1991): 1 up to
+    x = 1, x^-2 above; 'clip': no taper (the slope itself is limited)."""
+    x = np.asarray(x, dtype=np.float64)
+    if control == 1:
+        return np.where(x < 1.0, 0.5 * (1.0 - np.tanh(10.0 * x - 4.0)), 0.0)
+    if control == 0:
+        mid = 0.5 * (1.0 - (2.5 * x - 1.0) * (4.0 - np.abs(10.0 * x - 4.0)))
+        return np.where(x <= 0.2, 1.0, np.where(x >= 0.6, 0.0, mid))
+    if control == 3:
+        return np.where(x > 1.0, 1.0 / (x * x), 1.0)
+    return np.ones_like(x)
+
+
+def check_gm_tapers(A, tol=5e-12):
+    """The slope tapers of Gent-McWilliams mixing on a CONSTRUCTED slope field (until round 4 they rested on two
+    restatements by one author).  T = T0 + a i + b k at rest with uniform salinity gives the isopycnal slope Sx = a / (-b) in index
+    units at every quarter cell, hence the true slope magnitude of hmix_gm.F90:1431-1436
+
+        SLA(j, k) = dzw(k) |Sx| / DXT(j) + eps
+
+    at both half cells next to the interface below level k -- a function of latitude and depth that sweeps the break points of every
+    taper.  Below the second level the near-surface taper is 1 (no KPP: the boundary layer is the first level), so with
+    tau_r = taper(SLA / slm_r), tau_b = taper(SLA / slm_b) (`diff_tapering`; tau_b = tau_r when the limits are equal):
+
+      * the isopycnal part added to the vertical diffusivity (:1725-1748) is tau_r kappa dzw(k)^2 Sx^2 (HYX + HYX_w) / (2 TAREA);
+      * the stream function of the thickness diffusion at that interface, east face (:1684-1690, 2091-2097), is
+        UIB(k) = tau_b kappa_b Sx HYX dzw(k), so the eddy-induced velocity of diag_gm_bolus (:2112) is
+        U_ISOP(k) = (UIB(k-1) - UIB(k)) / (dz(k) HTE);
+      * 'clip' limits the slope itself instead: |Sx| -> min(|Sx|, slm_r HUS / dzw(k)) (:1541-1573), both formulas with tau = 1.
+
+    Exercised on the oracle and on the device in all four slope_control choices, with equal and with different slope limits."""
+    cfg = A.cfg
+    assert cfg.hmix_tracer == 3 and cfg.vmix_choice == 1 and cfg.gm_transition_layer == 0 and cfg.gm_kappa_type == 0 and cfg.gm_diag_bolus == 1
+    c2dt, kmt, shp = _adv_setup(A, 0.0)
+    km = A.km
+    a, b, t0 = 0.5, -(2.0 ** (-12 if cfg.gm_slope_control == 3 else -10)), 2.0      # (Gerdes' taper only acts above the slope limit: steeper)
+    ii = np.arange(shp[-1], dtype=np.float64)[None, None, None, :]
+    kk = np.arange(km, dtype=np.float64)[None, :, None, None]
+    field = [t0 + a * ii + b * kk + np.zeros(shp), 0.035 + np.zeros(shp)]
+    for n in range(2):
+        for tl in range(3):
+            A.set("TRACER", field[n], tl, n)
+    A.dhdt()
+    A.run_phase("vmix")
+    A.run_phase("hmix_tracer")
+    A.run_phase("tracer_rhs")
+    ok = _patch(kmt, km, r=4)
+    control = cfg.gm_slope_control
+    slm_r = cfg.slm_r if cfg.slm_r != 0.0 else 0.3
+    slm_b = cfg.slm_b if cfg.slm_b != 0.0 else 0.3
+    kappa = cfg.ah
+    kappa_b = cfg.ah_bolus if cfg.ah_bolus != 0.0 else kappa
+    dz, dzw = A.vert("dz"), A.vert("dzw")
+    hyx = A.get("HTE") / A.get("HUS")
+    hyx_w = np.roll(hyx, 1, axis=2)
+    tarea, dxt, hus, hte = A.get("TAREA"), A.get("DXT"), A.get("HUS"), A.get("HTE")
+    Sx = a / (-b)
+    vdc = A.get("VDC", 1, 0) - cfg.const_vdc
+    uis = A.get("UISOP")
+
+    def sx_eff(k):       # |slope| in index units after 'clip'
+        return np.minimum(Sx, slm_r * hus / dzw[k]) if control == 2 else Sx + 0.0 * hus
+
+    def sla(k):
+        return dzw[k] * Sx / dxt + 1.0e-10
+
+    seen_r, seen_b = [], []
+    worst_v = worst_u = 0.0
+    uib_prev, sign = None, None
+    for k in range(3, km - 1):
+        tr, tb = _taper_slope(control, sla(k) / slm_r), _taper_slope(control, sla(k) / slm_b)
+        se = sx_eff(k)
+        exp_v = tr * kappa * dzw[k] * dzw[k] * se * se * (hyx + hyx_w) / (2.0 * tarea)
+        scale = (kappa * dzw[k] * dzw[k] * se * se * (hyx + hyx_w) / (2.0 * tarea))[ok].max()
+        worst_v = max(worst_v, float(np.abs(vdc[:, k] - exp_v)[ok].max() / scale))
+        uib = tb * kappa_b * se * hyx * dzw[k]
+        if uib_prev is not None:
+            exp_u = (uib_prev - uib) / (dz[k] * hte)
+            got = uis[:, k - 1]
+            big = np.abs(exp_u) > 1.0e-3 * np.abs(exp_u)[ok].max()
+            if sign is None:     # the orientation of the slope (sign of SLX for dT/dx > 0 in stable water) is one sign for the whole field
+                sel = ok & big
+                sign = 1.0 if float((got[sel] * exp_u[sel]).sum()) > 0.0 else -1.0
+            uscale = max(np.abs(uib_prev / (dz[k] * hte))[ok].max(), 1e-300)       # the two terms cancel partly: error relative to one of them
+            worst_u = max(worst_u, float(np.abs(got - sign * exp_u)[ok].max() / uscale))
+        uib_prev = uib
+        seen_r.append((sla(k) / slm_r)[ok]); seen_b.append((sla(k) / slm_b)[ok])
+    xr, xb = np.concatenate(seen_r), np.concatenate(seen_b)
+    # the constructed field must actually visit every branch of the function under test
+    if control == 0:
+        for x in (xr, xb):
+            assert (x < 0.2).any() and ((x > 0.25) & (x < 0.55)).any() and (x > 0.6).any(), "slopes miss a branch of the 'notanh' taper"
+    elif control == 1:
+        for x in (xr, xb):
+            assert (x < 0.3).any() and ((x > 0.3) & (x < 0.6)).any() and (x > 1.0).any(), "slopes miss a branch of the 'tanh' taper"
+    elif control == 3:
+        for x in (xr, xb):
+            assert (x < 1.0).any() and (x > 1.5).any(), "slopes miss a branch of Gerdes' taper"
+    else:
+        clipped = np.concatenate([(slm_r * hus / dzw[k] < Sx)[ok] for k in range(3, km - 1)])
+        assert clipped.any() and (~clipped).any(), "slopes miss a branch of the clipping"
+    assert worst_v <= tol, "tapered isopycnal part of VDC differs from its closed form by %.3e" % worst_v
+    assert worst_u <= tol, "eddy-induced velocity differs from the tapered stream function's by %.3e" % worst_u
+    return worst_v, worst_u
+
+
+def check_gm_transition_layer(A, tol=2e-11):
+    """The transition layer of Gent-McWilliams mixing (hmix_gm.F90:3183-3440 transition_layer, :3441-3743 merged_streamfunction) on the
+    constructed slope field of check_gm_tapers (T = T0 + a i + b k at rest, no KPP, so the diabatic depth D is zw(1)), against what the
+    two routines are supposed to deliver -- stated independently of their 250-line state machine and interpolation code:
+
+      * INTERIOR_DEPTH I is the deepest of the grid depths zt(2), zw(2), zt(3), zw(3), ... that can be reached from zt(2) one by one
+        while the isopycnal displacement over one deformation radius still reaches the diabatic layer, D >= d - R |S|(d), with
+        |S| = SLA at that depth and R the Rossby radius bounded to [15, 100] km; THICKNESS = I - D.  (Closed form of SLA as in
+        check_gm_tapers; the walk is the statement of Danabasoglu et al. 2008, eq. 6.)
+      * the merged stream function psi(z) sampled at the half-cell centres z = zt(k) -+ dz(k) / 4 is LINEAR through the origin above D;
+        in the layer it leaves that line QUADRATICALLY, psi = line - c (z - D)^2 with ONE c per column; extended to I it meets the
+        first interior sample (continuity) and its slope there is the one-sided interior difference of smaller magnitude.
+    Only the library's own outputs enter the second part (GM_SF_SLX, TLT_*)."""
+    cfg = A.cfg
+    assert cfg.hmix_tracer == 3 and cfg.vmix_choice == 1 and cfg.gm_transition_layer == 1 and cfg.gm_kappa_type == 0
+    c2dt, kmt, shp = _adv_setup(A, 0.0)
+    km = A.km
+    a, b, t0 = 0.5, -(2.0 ** -5), 2.0          # R |S| of the order of the level depths at low latitudes, well below them at high ones
+    ii = np.arange(shp[-1], dtype=np.float64)[None, None, None, :]
+    kk = np.arange(km, dtype=np.float64)[None, :, None, None]
+    field = [t0 + a * ii + b * kk + np.zeros(shp), 0.035 + np.zeros(shp)]
+    for n in range(2):
+        for tl in range(3):
+            A.set("TRACER", field[n], tl, n)
+    A.dhdt()
+    A.run_phase("vmix")
+    A.run_phase("hmix_tracer")
+    A.run_phase("tracer_rhs")
+    ok = _patch(kmt, km, r=4)
+    dz, dzw, dzwr, zt, zw = A.vert("dz"), A.vert("dzw"), A.vert("dzwr"), A.vert("zt"), A.vert("zw")
+    dxt, fcort = A.get("DXT"), A.get("FCORT")
+    Sx = a / (-b)
+    rb = 1.0 / np.maximum(np.minimum(np.abs(fcort) / 200.0, 1.0 / 1.5e6), 1.0e-7)
+    D, TH, ID = A.get("TLT_DIABATIC_DEPTH"), A.get("TLT_THICKNESS"), A.get("TLT_INTERIOR_DEPTH")
+    assert np.all(D[ok] == zw[1])
+
+    def sla(k):
+        return dzw[k] * Sx / dxt + 1.0e-10
+
+    # ---- the walk
+    exp_i = np.full(D.shape, zt[2])
+    going = np.ones(D.shape, dtype=bool)
+    cands = [(zw[2], 2)] + [c for k in range(3, km - 1) for c in ((zt[k], k), (zw[k], k))]
+    for d, k in cands:
+        reach = going & (D >= d - rb * sla(k))
+        exp_i = np.where(reach, d, exp_i)
+        going = reach
+    assert np.array_equal(ID[ok], exp_i[ok]), "INTERIOR_DEPTH differs from the walk in %d columns" % int((ID != exp_i)[ok].sum())
+    assert np.array_equal(TH[ok], (exp_i - D)[ok])
+    assert len(np.unique(ID[ok])) >= 4, "the constructed slopes give a trivial transition layer"
+    assert not going[ok].any()
+    # ---- the merged stream function, east face
+    top, bot = A.get("GM_SF_SLX", 1, 0), A.get("GM_SF_SLX", 1, 1)              # (nblocks, km, ny, nx): levels 1 .. km
+    zs = np.empty(2 * km); ps = np.empty((2 * km,) + D.shape)
+    for k in range(1, km + 1):
+        zs[2 * (k - 1)] = zt[k] - 0.25 * dz[k]; zs[2 * (k - 1) + 1] = zt[k] + 0.25 * dz[k]
+        ps[2 * (k - 1)] = top[:, k - 1]; ps[2 * (k - 1) + 1] = bot[:, k - 1]
+    assert zs[1] <= zw[1] < zs[2]
+    slope = ps[0] / zs[0]
+    scale = np.abs(ps[:, ok]).max()
+    assert scale > 0.0
+    worst = {"linear": float(np.abs(ps[1] - slope * zs[1])[ok].max() / scale)}
+    nb, ny, nx = D.shape
+    w_quad = w_cont = w_slope = 0.0
+    n_quad = 0
+    for bi, j, i in zip(*np.nonzero(ok)):
+        d0, i0 = D[bi, j, i], ID[bi, j, i]
+        p = ps[:, bi, j, i]
+        inl = np.nonzero((zs > d0) & (zs <= i0))[0]
+        first_int = int(np.nonzero(zs > i0)[0][0])
+        if len(inl) == 0:
+            continue
+        cq = -(p[inl] - slope[bi, j, i] * zs[inl]) / (zs[inl] - d0) ** 2
+        c0 = cq[-1]                                                      # the deepest sample carries the most signal
+        if len(inl) >= 2:
+            n_quad += 1
+            w_quad = max(w_quad, float(np.abs((cq - c0) * (zs[inl] - d0) ** 2).max() / scale))
+        T = i0 - d0
+        w_cont = max(w_cont, abs(slope[bi, j, i] * i0 - c0 * T * T - p[first_int]) / scale)
+        # one-sided interior differences at I: between the first and the second interior sample, and between the second and the third
+        k1, h1 = first_int // 2 + 1, first_int % 2
+        if h1 == 1:      # I = zt(k1): psi_I = SF(kbt, k1)
+            e1 = 2.0 * dzwr[k1] * (p[first_int] - p[first_int + 1])
+            e2 = 2.0 * (p[first_int + 1] - p[first_int + 2]) / dz[k1 + 1]
+        else:            # I = zw(k1 - 1): psi_I = SF(ktp, k1)
+            e1 = 2.0 * (p[first_int] - p[first_int + 1]) / dz[k1]
+            e2 = 2.0 * dzwr[k1] * (p[first_int + 1] - p[first_int + 2])
+        dpsi = e2 if abs(e2) < abs(e1) else e1
+        w_slope = max(w_slope, abs((slope[bi, j, i] - 2.0 * c0 * T) + dpsi) / (scale / zw[2]))
+    worst.update(quadratic=w_quad, continuity=w_cont, slope=w_slope)
+    assert n_quad >= 20, "too few columns with two samples inside the transition layer"
+    for what, v in worst.items():
+        assert v <= tol, "merged stream function: %s violated by %.3e" % (what, v)
+    return worst
+
+
+def _rho_of_field(A, temp, salt):
+    """in-situ density of an arbitrary (temp, salt) field: the model's own `state` phase (see _rho_of_uniform_column)"""
+    keep = [(A.get("TRACER", tl, n), tl, n) for tl in range(3) for n in range(2)]
+    for tl in range(3):
+        A.set("TRACER", temp, tl, 0)
+        A.set("TRACER", salt, tl, 1)
+    A.run_phase("state")
+    rho = A.get("RHO", 2)
+    for arr, tl, n in keep:
+        A.set("TRACER", arr, tl, n)
+    return rho
+
+
+def check_gm_bfre_profile(A, tol=2e-6):
+    """kappa type 'bfre' (buoyancy_frequency_dependent_profile, hmix_gm.F90:3011-3180): below the surface diabatic layer the
+    diffusivities are scaled by KAPPA_VERTICAL(k) = N^2(k-1) / N^2(K_MIN) bounded to [0.1, 1], N^2 at the interface below level k
+    = -g (d rho / d T)(T_k, S, p_{k+1}) (T_k - T_{k+1}) / dzw(k) (uniform salinity), K_MIN the first interface below the layer.
+
+    Constructed column: T = T(k) + a i with three linear pieces in k -- moderate, four times steeper (N^2 above the reference value:
+    upper bound), then sixteen times weaker (N^2 below a tenth of it: lower bound).  The expansion coefficient comes from CENTRAL
+    DIFFERENCES of the model's own density (state phase on columns of uniform temperature T_k +- delta read at level k + 1), not from
+    the routine under test.  Both half cells next to an interface have the same slope a / (T_k - T_{k+1}) and the same taper, so the
+    isopycnal part added to VDC there is the constant-kappa closed form of check_gm_tapers times the thickness-weighted mean
+    (dz(k) KV(k) + dz(k+1) KV(k+1)) / (dz(k) + dz(k+1))."""
+    cfg = A.cfg
+    assert cfg.hmix_tracer == 3 and cfg.vmix_choice == 1 and cfg.gm_transition_layer == 0 and cfg.gm_kappa_type == 1 and cfg.gm_slope_control == 0
+    c2dt, kmt, shp = _adv_setup(A, 0.0)
+    km = A.km
+    nb, _, ny, nx = shp
+    a, t0, salt = 2.0 ** -6, 24.0, 0.035
+    b1 = -(2.0 ** -4)
+    k1, k2 = 4, 9                                               # (0-based levels) the steep piece starts at k1, the weak one at k2
+    tk = np.empty(km)
+    tk[0] = t0
+    for k in range(1, km):
+        tk[k] = tk[k - 1] + (b1 if k <= k1 else 4.0 * b1 if k <= k2 else b1 / 16.0)
+    ii = np.arange(nx, dtype=np.float64)[None, None, None, :]
+    T = tk[None, :, None, None] + a * ii + np.zeros(shp)
+    S = salt + np.zeros(shp)
+    for tl in range(3):
+        A.set("TRACER", T, tl, 0); A.set("TRACER", S, tl, 1)
+    A.dhdt()
+    A.run_phase("vmix")
+    A.run_phase("hmix_tracer")
+    A.run_phase("tracer_rhs")
+    vdc = A.get("VDC", 1, 0) - cfg.const_vdc
+    ok = _patch(kmt, km, r=4)
+    dz, dzw = A.vert("dz"), A.vert("dzw")
+    # ---- N^2 at the interfaces k = 1 .. km-1 (1-based), expansion coefficient by central differences of the model's density
+    d = 2.0 ** -6
+    n2 = np.zeros((km + 1,) + (nb, ny, nx))
+    for k in range(1, km):                                      # interface below level k; T_k = T[:, k-1], density read at level k+1 = index k
+        col = np.broadcast_to(T[:, k - 1:k], shp)
+        rp, rm = _rho_of_field(A, col + d, S)[:, k], _rho_of_field(A, col - d, S)[:, k]
+        n2[k] = np.maximum(0.0, -GRAV / dzw[k] * ((rp - rm) / (2.0 * d)) * (T[:, k - 1] - T[:, k]))
+    kmin = 2                                                    # zw(2) is the first interface depth below the diabatic layer zw(1); N^2 > 0 there
+    assert np.all(n2[kmin][ok] > 0.0)
+    norm = np.ones_like(n2)
+    for k in range(kmin, km):
+        norm[k] = np.minimum(np.maximum(n2[k] / n2[kmin], 0.1), 1.0)
+    norm[km] = norm[km - 1]
+    kv = np.ones_like(n2)                                       # KAPPA_VERTICAL(k), 1-based
+    for k in range(kmin + 1, km + 1):
+        kv[k] = norm[k - 1]
+    assert (kv[:, ok] == 0.1).any() and ((kv[:, ok] > 0.1) & (kv[:, ok] < 1.0)).any() and (kv[kmin + 2:, ok] == 1.0).any(), "the column misses a branch of the bounds"
+    # ---- the isopycnal part of VDC
+    kappa = cfg.ah
+    slm_r = cfg.slm_r if cfg.slm_r != 0.0 else 0.3
+    hyx = A.get("HTE") / A.get("HUS")
+    hyx_w = np.roll(hyx, 1, axis=2)
+    tarea, dxt = A.get("TAREA"), A.get("DXT")
+    worst = 0.0
+    for k in range(3, km - 1):
+        sx = a / (tk[k - 1] - tk[k])
+        tap = _taper_slope(0, (dzw[k] * sx / dxt + 1.0e-10) / slm_r)
+        base = tap * kappa * dzw[k] * dzw[k] * sx * sx * (hyx + hyx_w) / (2.0 * tarea)
+        mean = (dz[k] * kv[k] + dz[k + 1] * kv[k + 1]) / (dz[k] + dz[k + 1])
+        worst = max(worst, float((np.abs(vdc[:, k] - base * mean) / np.abs(base))[ok].max()))
+    assert worst <= tol, "isopycnal part of VDC with the N^2 profile differs from its closed form by %.3e" % worst
+    return worst
+
+
+def pbc_flat_grid(cfg, kstar, frac):
+    """caller grid for check_kpp_hblt_two_layer_pbc: the synthetic lat-lon grid with a FLAT bottom at level kstar whose bottom cell has the
+    same partial thickness frac * dz(kstar) everywhere (a record of bottom_cell_file), so that the boundary-layer depth is the same in
+    every column and the horizontal filter of smooth_hblt leaves it alone"""
+    from popcfg import synthetic_grid
+    from orclib import Oracle
+    small = type(cfg).from_buffer_copy(bytes(cfg))
+    small.partial_bottom_cells = 0
+    o = Oracle(small)
+    dz = o.v1("dz").copy()
+    o.close()
+    g = synthetic_grid(cfg, stepped=False)
+    g["KMT"] = np.where(g["KMT"] > 0, kstar, 0).astype(np.int32)
+    g["DZBC"] = np.where(g["KMT"] > 0, frac * dz[kstar], 0.0)
+    return g
+
+
+def check_kpp_hblt_two_layer_pbc(A, kstar, frac, tol=2e-7):
+    """check_kpp_hblt_two_layer with the velocity and density jump at the PARTIAL BOTTOM CELL itself (KBL = KMT = kstar, bottom thickness
+    frac * dz; grid of pbc_flat_grid).  With partial bottom cells the reference does not use LMD94's (d - eps d / 2) db / |dV|^2 but the
+    gradient form between the first T point and T point kl (vmix_kpp.F90:2359-2366, 2561-2575):
+        Ri* = (db / h_T) / (|dV|^2 / h_U^2),   h_T = zt(k*-1) + (dz(k*-1) + DZT(k*) - dz(1)) / 2   (= h_U: the bottom thickness is uniform)
+    and the T point of the bottom cell sits at ZKL = zt(k*-1) + (dz(k*-1) + DZT(k*)) / 2 (:2212-2220), so the root of the parabola is
+        h = zt(k*-1) + (ZKL - zt(k*-1)) sqrt(Ri_c / Ri*).
+    Also the non-local source (:1296-1302), which reaches the bottom cell here: its thickness-weighted column sum vanishes (the transport only
+    redistributes) WITH the partial thickness -- with dz(k*) in its place it is off by the per cent the cell is thinner."""
+    km = A.km
+    t1, t2, salt, du = 16.0, 15.99, 0.035, 24.0        # a weak jump: Ri* ~ 0.45, so the boundary layer ends INSIDE the bottom cell, below its top face
+    kmt = _kpp_setup(A, kstar, t1, t2, 1.0, -1.0e-4, u1=du, u2=0.0, salt=salt)
+    wet = kmt == kstar
+    ok = wet.copy()
+    for dj in range(-3, 4):
+        for di in range(-3, 4):
+            ok &= np.roll(np.roll(wet, dj, axis=1), di, axis=2)
+    ok[:, :5, :] = False; ok[:, -5:, :] = False; ok[:, :, :5] = False; ok[:, :, -5:] = False
+    assert ok.sum() > 50
+    dz, zt = A.vert("dz"), A.vert("zt")
+    dzbc = A.get("DZBC")
+    assert np.all(np.abs(dzbc[ok] - frac * dz[kstar]) <= 1e-9 * dz[kstar])
+    ra = _rho_of_uniform_column(A, t1, salt)[:, kstar - 1][ok]
+    rb = _rho_of_uniform_column(A, t2, salt)[:, kstar - 1][ok]
+    db = float(np.median(GRAV * (1.0 - ra / rb)))
+    _kpp_run(A)
+    dzb = frac * dz[kstar]
+    h_t = zt[kstar - 1] + 0.5 * (dz[kstar - 1] + dzb - dz[1])
+    zkl = zt[kstar - 1] + 0.5 * (dz[kstar - 1] + dzb)
+    ri = (db / h_t) / (du * du / (h_t * h_t))
+    assert ri > RICR
+    expect = zt[kstar - 1] + (zkl - zt[kstar - 1]) * np.sqrt(RICR / ri)
+    hblt, kbl = A.get("HBLT")[ok], A.geti("KBL")[ok]
+    err = float(np.abs(hblt - expect).max() / expect)
+    assert (kbl == kstar).all()
+    assert err <= tol, "HBLT with the jump at a partial bottom cell differs from the closed form by %.3e (%.6f vs %.6f cm)" % (err, hblt.flat[0], expect)
+    full = zt[kstar - 1] + (zt[kstar] - zt[kstar - 1]) * np.sqrt(RICR / ((zt[kstar] - 0.5 * EPSSFC * zt[kstar]) * db / (du * du)))
+    assert abs(full - expect) > 1.0e-3 * expect, "the case does not distinguish the partial-cell form from the full-cell one"
+    # non-local source: sum_k SRC(k) DZT(k) = 0 with DZT(k*) = the partial thickness
+    src = A.get("KPP_SRC", 1, 0)
+    thick = np.array([dz[k] for k in range(1, kstar)] + [dzb])
+    col = np.stack([src[:, k][ok] for k in range(kstar)])          # (kstar, ncol)
+    s1 = np.abs((col * thick[:, None]).sum(axis=0)).max()
+    s0 = (np.abs(col) * thick[:, None]).sum(axis=0).max()
+    wrong = np.abs((col * np.array([dz[k] for k in range(1, kstar + 1)])[:, None]).sum(axis=0)).max()
+    assert s0 > 0.0 and np.abs(col[kstar - 1]).max() > 0.0, "the non-local source does not reach the bottom cell"
+    assert s1 <= 1e-13 * s0, "thickness-weighted non-local source does not sum to zero: %.3e" % (s1 / s0)
+    assert wrong > 1e-4 * s0
+    return err, s1 / s0

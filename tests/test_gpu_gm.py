@@ -34,7 +34,6 @@ def _steep(gpu, orc):
     ("tiny", {"hmix_momentum": 4, "am": -1.0e22, "stepped_bathymetry": 1}, 4),        # del4 momentum beside it (side stream)
     ("tiny", {"tmix_opt": 3, "solver_choice": 2}, 4),                                 # Robert filter
     ("tiny", {"km": 60, "vmix_choice": 3}, 3),                                        # production level count (register Thomas kernels)
-    ("tiny", {"partial_bottom_cells": 1, "stepped_bathymetry": 1}, 3),                # the scheme has no partial-cell branches: dz(k) throughout
     # kappa type 'bfre' (buoyancy_frequency_dependent_profile): KAPPA_VERTICAL = N^2 / N_ref^2 below the surface diabatic layer
     ("tiny", {"gm_kappa_type": 1, "stepped_bathymetry": 1}, 5),                       # 'never': the profile of the first step is kept
     ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1, "ah_bolus": 0.5e7}, 5),   # every step, SDL = HBLT

@@ -113,3 +113,39 @@ def test_gm_fluxes_of_a_linear_field_are_the_closed_form(pkg, orclib_built, ah_b
     A = pins.GpuAdapter(pkg, named_config("tiny", hmix_tracer=3, ah=0.8e7, ah_bolus=ah_bolus, km=20, block_size_x=48, block_size_y=40))
     pins.check_gm_linear(A)
     A.close()
+
+
+@pytest.mark.parametrize("control,slm_b,ah_bolus", [(0, 0.0, 0.0), (0, 0.2, 0.5e7), (1, 0.0, 0.0), (1, 0.2, 0.5e7), (3, 0.0, 0.0), (3, 0.2, 0.5e7), (2, 0.0, 0.0)])
+def test_gm_slope_tapers_on_a_constructed_slope_field(pkg, orclib_built, control, slm_b, ah_bolus):
+    """the device kernels (k_gm_coeffs, k_gm_flux, k_gm_bolus) against the closed forms of the four slope tapers: pins.check_gm_tapers"""
+    A = pins.GpuAdapter(pkg, named_config("tiny", hmix_tracer=3, ah=0.8e7, ah_bolus=ah_bolus, km=20, block_size_x=48, block_size_y=40,
+                                          gm_slope_control=control, slm_b=slm_b, gm_diag_bolus=1))
+    pins.check_gm_tapers(A)
+    A.close()
+
+
+@pytest.mark.parametrize("kw", [{}, {"gm_slope_control": 1, "slm_b": 0.2}], ids=["notanh", "tanh-diff-tapering"])
+def test_gm_transition_layer_depths_and_merged_streamfunction(pkg, orclib_built, kw):
+    """the device kernels (k_gm_transition_layer, k_gm_msf_column, k_gm_sf) against the walk and the structural properties of the merged
+    stream function: pins.check_gm_transition_layer"""
+    A = pins.GpuAdapter(pkg, named_config("tiny", hmix_tracer=3, ah=0.8e7, ah_bolus=0.5e7, km=20, block_size_x=48, block_size_y=40, gm_transition_layer=1, **kw))
+    pins.check_gm_transition_layer(A)
+    A.close()
+
+
+def test_gm_buoyancy_frequency_profile_and_its_bounds(pkg, orclib_built):
+    """k_gm_kappa_vertical against N^2 / N_ref^2 in [0.1, 1] formed from central differences of the device's own density: pins.check_gm_bfre_profile"""
+    A = pins.GpuAdapter(pkg, named_config("tiny", hmix_tracer=3, ah=0.8e7, km=20, block_size_x=48, block_size_y=40, gm_kappa_type=1, gm_kappa_freq=1))
+    pins.check_gm_bfre_profile(A)
+    A.close()
+
+
+@pytest.mark.parametrize("frac,km,kstar", [(0.4, 20, 10), (0.7, 20, 10), (0.55, 62, 30)])
+def test_kpp_boundary_layer_ending_in_a_partial_bottom_cell(pkg, orclib_built, frac, km, kstar):
+    """the PBC instantiations of the KPP kernels (62 levels: the column-march forms of large grids are forced by pbc_generic_kpp = 0 only above
+    2^19 columns, so km = 62 here runs the 3-D-parallel forms with the register level count) against the closed form with the jump AT the partial
+    bottom cell and the zero column sum of the non-local source: pins.check_kpp_hblt_two_layer_pbc"""
+    cfg = named_config("tiny", vmix_choice=3, km=km, block_size_x=48, block_size_y=40, partial_bottom_cells=1, ns_boundary=0)
+    A = pins.GpuAdapter(pkg, cfg, grid=pins.pbc_flat_grid(cfg, kstar, frac))
+    pins.check_kpp_hblt_two_layer_pbc(A, kstar, frac)
+    A.close()

@@ -89,3 +89,39 @@ def test_gm_fluxes_of_a_linear_field_are_the_closed_form(orclib_built, ah_bolus)
     A = pins.OracleAdapter(named_config("tiny", hmix_tracer=3, ah=0.8e7, ah_bolus=ah_bolus, km=20, block_size_x=48, block_size_y=40))
     pins.check_gm_linear(A)
     A.close()
+
+
+GM_TAPER_CASES = [(0, 0.0, 0.0), (0, 0.2, 0.5e7), (1, 0.0, 0.0), (1, 0.2, 0.5e7), (3, 0.0, 0.0), (3, 0.2, 0.5e7), (2, 0.0, 0.0)]
+
+
+@pytest.mark.parametrize("control,slm_b,ah_bolus", GM_TAPER_CASES)
+def test_gm_slope_tapers_on_a_constructed_slope_field(orclib_built, control, slm_b, ah_bolus):
+    """slope_control 'notanh' / 'tanh' / 'clip' / 'Gerd', equal and different slope limits (diff_tapering): pins.check_gm_tapers"""
+    A = pins.OracleAdapter(named_config("tiny", hmix_tracer=3, ah=0.8e7, ah_bolus=ah_bolus, km=20, block_size_x=48, block_size_y=40,
+                                        gm_slope_control=control, slm_b=slm_b, gm_diag_bolus=1))
+    pins.check_gm_tapers(A)
+    A.close()
+
+
+@pytest.mark.parametrize("kw", [{}, {"gm_slope_control": 1, "slm_b": 0.2}], ids=["notanh", "tanh-diff-tapering"])
+def test_gm_transition_layer_depths_and_merged_streamfunction(orclib_built, kw):
+    """transition_layer / merged_streamfunction (hmix_gm.F90:3183-3743) against what they are supposed to deliver: pins.check_gm_transition_layer"""
+    A = pins.OracleAdapter(named_config("tiny", hmix_tracer=3, ah=0.8e7, ah_bolus=0.5e7, km=20, block_size_x=48, block_size_y=40, gm_transition_layer=1, **kw))
+    pins.check_gm_transition_layer(A)
+    A.close()
+
+
+def test_gm_buoyancy_frequency_profile_and_its_bounds(orclib_built):
+    """kappa type 'bfre': KAPPA_VERTICAL = N^2 / N_ref^2 in [0.1, 1] with N^2 from central differences of the model's density: pins.check_gm_bfre_profile"""
+    A = pins.OracleAdapter(named_config("tiny", hmix_tracer=3, ah=0.8e7, km=20, block_size_x=48, block_size_y=40, gm_kappa_type=1, gm_kappa_freq=1))
+    pins.check_gm_bfre_profile(A)
+    A.close()
+
+
+@pytest.mark.parametrize("frac", [0.4, 0.7])
+def test_kpp_boundary_layer_ending_in_a_partial_bottom_cell(orclib_built, frac):
+    """vmix_kpp.F90:2212-2220, 2359-2366, 2561-2575, 1296-1302 with partial_bottom_cells: pins.check_kpp_hblt_two_layer_pbc"""
+    cfg = named_config("tiny", vmix_choice=3, km=20, block_size_x=48, block_size_y=40, partial_bottom_cells=1, ns_boundary=0)
+    A = pins.OracleAdapter(cfg, grid=pins.pbc_flat_grid(cfg, 10, frac))
+    pins.check_kpp_hblt_two_layer_pbc(A, 10, frac)
+    A.close()
