@@ -213,7 +213,7 @@ def pmc_traffic(workload, kernel):
     """HBM/fabric bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
     WRITE_SIZE, separate passes; profiles/r02_pmc_traffic.json).  None when no pass exists for this case."""
     try:
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 with open(path) as f:
@@ -449,6 +449,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--block-rows", type=int, default=0, help="rows per j-band block (default: one band per rank, or balanced bands on large grids)")
     ap.add_argument("--no-deep-state", action="store_true", help="skip the second (deep KPP boundary layer) measurement after the timed region")
+    ap.add_argument("--profile-run", default="", choices=["", "headline", "deep"],
+                    help="under rocprofv3 only (profiles/collect_r04.sh): nothing but step launches of ONE state in the process -- no per-phase "
+                         "HIP-event repetitions, no CPU baseline; 'deep' edits the state to the deep-boundary-layer one before the steps.  The line "
+                         "then carries no roofline object and is not a bench line")
     ap.add_argument("--gm", nargs="?", const="constant", default="", choices=["constant", "cesm"], help="NOT the headline: Gent-McWilliams + isopycnal tracer mixing (hmix_tracer = 3, SURVEY 8 f4) in place of del2 / del4; "
                                                       "config.hmix_tracer says so in the line")
     ap.add_argument("--pbc", action="store_true", help="NOT the headline: partial bottom cells on stepped bathymetry (grid_nml partial_bottom_cells, SURVEY 8 f3); "
@@ -556,6 +560,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.profile_run:
+        if args.profile_run == "deep":
+            kpp_deep_state(pkg, model, cfg, torch, warm=max(args.warmup, 6), steps=args.steps)
+        else:
+            for _ in range(args.warmup + args.steps):
+                model.step()
+        model.sync()
+        print(json.dumps({"profile_run": args.profile_run, "workload": args.workload, "steps": args.steps, "warmup": args.warmup}))
+        model.close()
+        return
     iters = []
     for _ in range(args.warmup):
         model.step()
@@ -644,7 +658,7 @@ def main():
             "frac": round(phases[dom]["GBps"] / HBM_PEAK_GBS, 4),
             "frac_definition": "SURVEY.md 8(d) words of the phase (E = 10, B = 12) x 8 B x computed cells / HIP-event launch time / 8 TB/s",
             "traffic": pmc_traffic(args.workload, kern) if world == 1 else None,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes, profiles/r03_pmc_traffic.json (r02 if absent)",
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes of `bench.py --profile-run headline` (separate runs, profiles/collect_r04.sh): committed profiles/r04_pmc_traffic.json (r03 if absent), not measured in this process",
             "alg_bytes_per_launch": phases[dom]["alg_GB"] * 1e9, "avg_launch_ms": phases[dom]["ms"], "phases": phases}
     if dom in extra_words:
         w = phases[dom]["alg_words"] + extra_words[dom]

@@ -12,25 +12,33 @@
 // The search direction and the solution at halo cells are advanced by the workgroup itself with the owner's arithmetic (the rule of
 // the distributed solvers), so they never travel.
 //
-// Every exchanged word is its own flag: a 64-bit relaxed agent-scope atomic store of the VALUE into a slot that holds
-// POP_SPIN_EMPTY (a NaN bit pattern no arithmetic produces) until then; readers re-load until they see something else.  No fence,
-// no ticket, no read-modify-write, no ordering assumption between two words.  The slots of phase n live in buffer n mod 3; a
-// workgroup resets its own slots of buffer (n+1) mod 3 before it writes phase n -- that buffer was last read in phase n-2, and
-// nobody can be in phase n before everybody has written phase n-1, i.e. finished reading phase n-2.  Collecting all partials of a
-// phase is therefore also the grid-wide barrier of the phase.
+// Every exchanged item is ONE aligned 16-byte word {value, tag} written by one 16-byte store and read by one 16-byte load, both at
+// agent scope (sc1: through to / from memory, no cache in between): the tag is the number of the exchange (the launch's epoch in the
+// high half, the phase or iteration in the low half) and never repeats, so a reader takes a value only if its tag is the one it waits
+// for -- a stale word of an earlier phase, iteration or solve cannot be mistaken for it, nothing has to be reset, and no ordering
+// between two different words is assumed.  (The first form of this kernel used 8-byte words that were their own flag, reset to an
+// "empty" pattern one phase ahead: correct only if the reset became visible before a later reader polled -- an ordering between two
+// words that relaxed accesses do not promise.  A 16-byte aligned access of one lane is one memory transaction on this hardware.)
+// The words of phase n live in buffer n mod 2: a workgroup can be in phase n + 1 only after everybody has written phase n, i.e. has
+// finished reading phase n - 1.  Collecting all partials of a phase is therefore also the grid-wide barrier of the phase.
 //
 // Same numbers as the fused launches, bit for bit (tests/test_gpu_parity.py::test_persistent_pcg_is_bitwise_the_fused_pcg): the
 // chunk partials are formed by the tree of wg_reduce_store, their total by the rule of fused_total (thread-strided left-to-right
 // sums per block, fixed tree, blocks in order), the cell arithmetic in the order of k_fpcg_a / k_fpcg_b / k_fpcg_xr / k_fresidual.
-// A wait that does not end (a workgroup that died) gives up after ~0.5 s, marks the workgroup dead -- no later wait spins -- and
-// the solve reports it (status word), so a bug here is a loud failure and never a hung GPU.
+// A wait that does not end gives up after PersistArgs::wait_ticks of wall-clock time (2 s), marks the workgroup dead -- no later wait
+// of it spins -- and the solve reports it (status word): never a hung GPU.  The host then restores the first guess, solves with the
+// two-launch form, says so on stderr and does not use the resident form again in that model (solver_pcg_fused).  Seen so far only
+// with several PROCESSES sharing one GPU (the multi-rank rehearsals of tests/), where the residency of all workgroups at once that
+// the waits assume is not this kernel's to guarantee.
 #pragma once
 #include "kernels_barotropic.hpp"
 
 namespace pop {
 
 constexpr int POP_PERSIST_MAXP = 8;      // partial slots one thread collects per phase: nblocks * ceil(nchunk / 256) must not exceed it
-constexpr int POP_PERSIST_MAXH = 8;      // halo cells one thread fetches per iteration: ceil(nhalo / 256)
+constexpr int POP_PERSIST_MAXH = 6;      // halo cells one thread fetches per iteration: ceil(nhalo / 256)  (8 + 6 loads and their operands fit one asm block)
+
+struct alignas(16) PWord { double v; unsigned long long tag; };
 
 struct PersistArgs {
   double *X; const double *Bv, *C, *WNo, *WEa, *WNE; const unsigned char *mMask8;
@@ -39,14 +47,40 @@ struct PersistArgs {
   const int *own_q;                      // [nwg * CP * 256] cell of own position L = u * 256 + t; -1: not a physical (interior) cell
   const unsigned short *nbr;             // [nwg * CP * 256 * 8] window index of the eight stencil neighbours (order of k_fpcg_b)
   const int *halo_off, *halo_q;          // halo cells of workgroup w: halo_q[halo_off[w] .. halo_off[w+1]), window index CP * 256 + h
-  unsigned long long *P, *Zb;            // [3][nslots] partials, [3][ncell] z
+  PWord *W;                              // one buffer: [2][nslots] partials, then [2][ncell] z (byte offsets fit 32 bits)
+  unsigned long long epoch;              // high half of every tag of this launch
   int max_iter, freq;
   double criterion;
+  unsigned long long wait_ticks;         // a wait for another workgroup gives up after this many ticks of the 100 MHz wall clock
   double *out;                           // pinned: [0] iterations, [1] last (r,r), [2] 0 ok / 1 a wait gave up, [3] checks done
 };
 
-__device__ __forceinline__ unsigned long long ld_word(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_word(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+typedef unsigned pword4 __attribute__((ext_vector_type(4)));
+// one 16-byte agent-scope store of {value, tag}
+__device__ __forceinline__ void st_pword(PWord *p, double v, unsigned long long tag) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  pword4 x;
+  x[0] = (unsigned)b; x[1] = (unsigned)(b >> 32); x[2] = (unsigned)tag; x[3] = (unsigned)(tag >> 32);
+  // (s_nop: a store of more than 8 bytes must not have its data registers overwritten in the next cycles -- the compiler's hazard
+  // recogniser inserts that wait state for its own stores but does not look inside an asm block)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" : : "v"(p), "v"(x) : "memory");
+}
+// fourteen 16-byte agent-scope loads at base + 32-bit byte offsets, requested together, one wait
+__device__ __forceinline__ void ld_pwords14(const PWord *base, const unsigned (&off)[14], pword4 (&o)[14]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %14, %28 sc1\n\tglobal_load_dwordx4 %1, %15, %28 sc1\n\tglobal_load_dwordx4 %2, %16, %28 sc1\n\t"
+      "global_load_dwordx4 %3, %17, %28 sc1\n\tglobal_load_dwordx4 %4, %18, %28 sc1\n\tglobal_load_dwordx4 %5, %19, %28 sc1\n\t"
+      "global_load_dwordx4 %6, %20, %28 sc1\n\tglobal_load_dwordx4 %7, %21, %28 sc1\n\tglobal_load_dwordx4 %8, %22, %28 sc1\n\t"
+      "global_load_dwordx4 %9, %23, %28 sc1\n\tglobal_load_dwordx4 %10, %24, %28 sc1\n\tglobal_load_dwordx4 %11, %25, %28 sc1\n\t"
+      "global_load_dwordx4 %12, %26, %28 sc1\n\tglobal_load_dwordx4 %13, %27, %28 sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
+        "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13])
+      : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]), "v"(off[9]),
+        "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "s"(base)
+      : "memory");
+}
+__device__ __forceinline__ double pword_value(const pword4 &x) { return __longlong_as_double((long long)(((unsigned long long)x[1] << 32) | x[0])); }
+__device__ __forceinline__ unsigned long long pword_tag(const pword4 &x) { return ((unsigned long long)x[3] << 32) | x[2]; }
 
 template <int CP>
 __global__ void __launch_bounds__(POP_RED_THREADS)
@@ -104,46 +138,55 @@ k_pcg_persist(PersistArgs a) {
       }
       __syncthreads();
     }
-    unsigned long long *Pn = a.P + (long long)(phase % 3) * a.nslots, *Pr = a.P + (long long)((phase + 1) % 3) * a.nslots;
+    const unsigned long long ptag = a.epoch | (unsigned long long)(unsigned)phase, ztag = a.epoch | (unsigned long long)(unsigned)m | 0x80000000ULL;
+    const long long pbase = (long long)(phase & 1) * a.nslots;                       // in PWords from a.W
+    const long long zbase = 2LL * a.nslots + (long long)(m & 1) * a.ncell;
     if (t < 64) {
 #pragma unroll
       for (int u = 0; u < CP; ++u) {
         const double x = tree_tail64(sh[u][t]);
         const int slot = w * CP + u;
-        if (t == 0 && slot < a.nslots) { st_word(Pr + slot, POP_SPIN_EMPTY); st_word(Pn + slot, (unsigned long long)__double_as_longlong(x)); }
+        if (t == 0 && slot < a.nslots) st_pword(a.W + pbase + slot, x, ptag);
       }
     }
-    // what this thread collects: slots b * nchunk + c, c = t, t + 256, ... of every block, and (with_z) its halo cells
-    unsigned long long pv[POP_PERSIST_MAXP], zv[POP_PERSIST_MAXH];
-    const unsigned long long *Zn = a.Zb + (long long)(m % 3) * a.ncell;
+    // what this thread collects: slots b * nchunk + c, c = t, t + 256, ... of every block, and (with_z) its halo cells; a load it does
+    // not need is aimed at the first word of the phase and accepted whatever its tag
     const int per_b = (a.nchunk - t + NT - 1) / NT;        // chunks of one block this thread adds (<= 0: none)
+    unsigned off[14]; bool need[14]; unsigned long long want[14];
+#pragma unroll
+    for (int k = 0; k < POP_PERSIST_MAXP; ++k) {
+      const int b = per_b > 0 ? k / per_b : a.nblocks, c = per_b > 0 ? t + (k % per_b) * NT : 0;
+      need[k] = b < a.nblocks; want[k] = ptag;
+      off[k] = (unsigned)((pbase + (need[k] ? (long long)b * a.nchunk + c : 0)) * (long long)sizeof(PWord));
+    }
+#pragma unroll
+    for (int k = 0; k < POP_PERSIST_MAXH; ++k) {
+      const int hh = t + k * NT;
+      need[POP_PERSIST_MAXP + k] = with_z && hh < nhalo; want[POP_PERSIST_MAXP + k] = ztag;
+      off[POP_PERSIST_MAXP + k] = (unsigned)((need[POP_PERSIST_MAXP + k] ? zbase + a.halo_q[h0 + hh] : pbase) * (long long)sizeof(PWord));
+    }
+    pword4 got[14];
+    unsigned long long t0 = 0;
     for (int tries = 0;; ++tries) {
+      ld_pwords14(a.W, off, got);
       bool ok = true;
 #pragma unroll
-      for (int k = 0; k < POP_PERSIST_MAXP; ++k) {
-        const int b = per_b > 0 ? k / per_b : a.nblocks, c = per_b > 0 ? t + (k % per_b) * NT : 0;
-        pv[k] = (b < a.nblocks) ? ld_word(Pn + (long long)b * a.nchunk + c) : 0ULL;
-      }
-      if (with_z) {
-#pragma unroll
-        for (int k = 0; k < POP_PERSIST_MAXH; ++k) {
-          const int hh = t + k * NT;
-          zv[k] = (hh < nhalo) ? ld_word(Zn + a.halo_q[h0 + hh]) : 0ULL;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < POP_PERSIST_MAXP; ++k) ok = ok && pv[k] != POP_SPIN_EMPTY;
-      if (with_z) {
-#pragma unroll
-        for (int k = 0; k < POP_PERSIST_MAXH; ++k) ok = ok && zv[k] != POP_SPIN_EMPTY;
-      }
+      for (int k = 0; k < 14; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == want[k]);
       if (ok) break;
-      if (tries > (1 << 20) || *(volatile int *)&dead) { dead = 1; break; }
+      if (*(volatile int *)&dead) break;
+      if ((tries & 255) == 0) {                              // the bound is wall-clock time (100 MHz counter), not a number of polls
+        const unsigned long long now = wall_clock64();
+        if (tries == 0) t0 = now;
+        else if (now - t0 > a.wait_ticks) { dead = 1; break; }
+      }
       __builtin_amdgcn_s_sleep(1);
     }
+    unsigned long long pv[POP_PERSIST_MAXP];
+#pragma unroll
+    for (int k = 0; k < POP_PERSIST_MAXP; ++k) pv[k] = need[k] ? (unsigned long long)__double_as_longlong(pword_value(got[k])) : 0ULL;
     if (with_z) {
 #pragma unroll
-      for (int k = 0; k < POP_PERSIST_MAXH; ++k) { const int hh = t + k * NT; if (hh < nhalo) Zw[NOWN + hh] = __longlong_as_double((long long)zv[k]); }
+      for (int k = 0; k < POP_PERSIST_MAXH; ++k) { const int hh = t + k * NT; if (hh < nhalo) Zw[NOWN + hh] = pword_value(got[POP_PERSIST_MAXP + k]); }
     }
     // the rule of fused_total: per block the thread-strided left-to-right sum, the fixed tree, blocks in order
     double total = 0.0;
@@ -193,7 +236,8 @@ k_pcg_persist(PersistArgs a) {
     // ---- step A (k_fpcg_a): [r -= alpha q]; z = r / diag; partial (r, z)
     double alpha = 0.0;
     if (pending) { alpha = eta1 / sq; eta0 = eta1; }
-    unsigned long long *Zn = a.Zb + (long long)(m % 3) * a.ncell, *Zr = a.Zb + (long long)((m + 1) % 3) * a.ncell;
+    PWord *const Zn = a.W + 2LL * a.nslots + (long long)(m & 1) * a.ncell;
+    const unsigned long long ztag = a.epoch | (unsigned long long)(unsigned)m | 0x80000000ULL;
 #pragma unroll
     for (int u = 0; u < CP; ++u) {
       v[u] = 0.0;
@@ -201,8 +245,7 @@ k_pcg_persist(PersistArgs a) {
         if (pending) r[u] = r[u] - alpha * qq[u];
         const double z = (cw[u] != 0.0) ? r[u] / cw[u] : 0.0;
         Zw[u * NT + t] = z;
-        st_word(Zr + q[u], POP_SPIN_EMPTY);
-        st_word(Zn + q[u], (unsigned long long)__double_as_longlong(z));
+        st_pword(Zn + q[u], z, ztag);
         v[u] = (r[u] * z) * mk[u];
       }
     }
@@ -245,12 +288,6 @@ k_pcg_persist(PersistArgs a) {
   for (int u = 0; u < CP; ++u) if (inner[u]) a.X[q[u]] = Xw[u * NT + t];
   if (w == 0 && t == 0) { a.out[0] = converged ? (double)m : (double)a.max_iter; a.out[1] = rr; a.out[3] = (double)nchecks; }
   if (t == 0 && dead) a.out[2] = 1.0;
-}
-
-// every exchange word empty before a solve
-__global__ void k_fill_words(unsigned long long *p, long long n, unsigned long long v) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
 }
 
 }  // namespace pop

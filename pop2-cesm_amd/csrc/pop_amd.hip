@@ -107,12 +107,15 @@ struct pop_ctx {
     const void *key = nullptr; bool ok = false; std::string why;
     int CP = 0, nwg = 0, nwin_max = 0, nslots = 0;
     int *own_q = nullptr, *halo_off = nullptr, *halo_q = nullptr; unsigned short *nbr = nullptr;
-    unsigned long long *P = nullptr, *Zb = nullptr;
+    PWord *W = nullptr;                                    // [2][nslots] partial words + [2][ncell] z words
+    double *X0 = nullptr;                                  // copy of the first guess (a solve that gave up is repeated by the two-launch form)
   };
+  unsigned long long persist_epoch = 0;                    // high half of the tags of the next resident solve (never repeats)
   std::vector<PersistPlan> persist;
   std::vector<int> h_srcmap;                               // host copy of srcmap (local view)
   double *persist_out = nullptr;                           // pinned: iterations, (r,r), status, checks
   int persist_used = 0;                                    // the last pcg solve ran as the resident launch
+  int persist_gave_up = 0;                                 // resident solves that gave up a wait (then never used again in this model)
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
   bool reg_thomas_t = true;
   int trc_lds_rows = 4;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
@@ -627,11 +630,12 @@ static pop_ctx::PersistPlan *persist_plan(pop_ctx *c, const SolveView &v) {
   if (hq.empty()) hq.push_back(0);
   if (dev_upload(c, &pl.own_q, own.data(), own.size()) || dev_upload(c, &pl.nbr, nbr.data(), nbr.size()) ||
       dev_upload(c, &pl.halo_off, hoff.data(), hoff.size()) || dev_upload(c, &pl.halo_q, hq.data(), hq.size())) return nullptr;
+  const size_t nwords = 2 * ((size_t)nslots + (size_t)n2 * nb);
+  if (nwords * sizeof(PWord) >= (1ULL << 32)) return refuse("exchange buffer beyond 32-bit offsets");
   double *p = nullptr;
-  if (dev_alloc(c, &p, (size_t)3 * nslots)) return nullptr;
-  pl.P = reinterpret_cast<unsigned long long *>(p);
-  if (dev_alloc(c, &p, (size_t)3 * n2 * nb)) return nullptr;
-  pl.Zb = reinterpret_cast<unsigned long long *>(p);
+  if (dev_alloc(c, &p, 2 * nwords)) return nullptr;          // zero-filled: tag 0 is never waited for (epochs start at 1)
+  pl.W = reinterpret_cast<PWord *>(p);
+  if (dev_alloc(c, &pl.X0, (size_t)n2 * nb)) return nullptr;
   pl.CP = CP; pl.nwg = nwg; pl.nwin_max = nwin_max; pl.nslots = nslots; pl.ok = true;
   return &pl;
 }
@@ -641,11 +645,11 @@ int solver_pcg_persist(pop_ctx *c, SolveView &v, const pop_ctx::PersistPlan &pl)
   PersistArgs a{};
   a.X = v.X; a.Bv = v.RHS; a.C = v.C; a.WNo = v.g.WNo; a.WEa = v.g.WEa; a.WNE = v.g.WNE; a.mMask8 = v.g.mMask8;
   a.nxb = v.g.nxb; a.nchunk = v.nchunk; a.nblocks = v.g.nblocks; a.nslots = pl.nslots; a.ncell = ncell;
-  a.own_q = pl.own_q; a.nbr = pl.nbr; a.halo_off = pl.halo_off; a.halo_q = pl.halo_q; a.P = pl.P; a.Zb = pl.Zb;
+  a.own_q = pl.own_q; a.nbr = pl.nbr; a.halo_off = pl.halo_off; a.halo_q = pl.halo_q; a.W = pl.W;
+  a.epoch = (++c->persist_epoch) << 32;                    // tags of this solve: no word of an earlier solve can carry one of them
   a.max_iter = cf.max_iterations; a.freq = cf.convergence_check_freq; a.criterion = c->h.convergenceCriterion; a.out = c->persist_out;
-  // the words the first phase / first iteration polls must be empty (the rest is reset in rotation by its owners)
-  hipLaunchKernelGGL(k_fill_words, dim3((unsigned)((pl.nslots + 255) / 256)), dim3(256), 0, c->stream, pl.P, (long long)pl.nslots, POP_SPIN_EMPTY);
-  hipLaunchKernelGGL(k_fill_words, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, pl.Zb + ncell, ncell, POP_SPIN_EMPTY);
+  a.wait_ticks = 200000000ULL;                             // 2 s
+  HIPCHK(c, hipMemcpyAsync(pl.X0, v.X, sizeof(double) * ncell, hipMemcpyDeviceToDevice, c->stream));   // the first guess, should the solve have to be repeated
   c->persist_out[0] = -1.0; c->persist_out[1] = 0.0; c->persist_out[2] = 0.0; c->persist_out[3] = 0.0;
   const size_t lds = (size_t)3 * pl.nwin_max * sizeof(double);
   const dim3 G(pl.nwg), B(POP_RED_THREADS);
@@ -658,7 +662,12 @@ int solver_pcg_persist(pop_ctx *c, SolveView &v, const pop_ctx::PersistPlan &pl)
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->chk_ev[0], c->stream));
   HIPCHK(c, hipEventSynchronize(c->chk_ev[0]));
-  if (c->persist_out[2] != 0.0 || c->persist_out[0] < 0.0) { c->err = "resident pcg: a wait for another workgroup's data gave up (kernels_pcg_persist.hpp)"; return 1; }
+  if (c->persist_out[2] != 0.0 || c->persist_out[0] < 0.0) {
+    char b[200];
+    snprintf(b, sizeof b, " [iterations %g, status %g, checks %g, %d workgroups x %d chunks, %d blocks]", c->persist_out[0], c->persist_out[2], c->persist_out[3], pl.nwg, pl.CP, v.g.nblocks);
+    c->err = std::string(c->persist_out[0] < 0.0 ? "resident pcg: the launch left no result" : "resident pcg: a wait for another workgroup's data gave up (kernels_pcg_persist.hpp)") + b;
+    return 3;
+  }
   c->numIterations = (int)c->persist_out[0];
   c->rmsResidual = std::sqrt(c->persist_out[1] * c->h.residualNorm);
   c->persist_used = 1;
@@ -673,7 +682,17 @@ int solver_pcg_fused(pop_ctx *c, SolveView &v) {
   const pop_config &cf = c->h.c;
   c->persist_used = 0;
   if (!tun_off(c->h.tun.pcg_persist) && !fused_args(c, v).presummed) {   // the rule: wherever the plan qualifies (small views); pop_tuning.pcg_persist = 0 switches it off
-    if (const pop_ctx::PersistPlan *pl = persist_plan(c, v)) return solver_pcg_persist(c, v, *pl);
+    const pop_ctx::PersistPlan *pl = c->persist_gave_up ? nullptr : persist_plan(c, v);
+    if (pl) {
+      const int e = solver_pcg_persist(c, v, *pl);
+      if (e != 3) return e;
+      // the resident launch did not complete its exchanges (its header: several processes on one GPU): not again in this model; this
+      // solve is repeated from the same first guess with the two launches per iteration -- the same numbers
+      c->persist_gave_up += 1;
+      fprintf(stderr, "libpop_amd: %s -- continuing with the two-launch pcg\n", c->err.c_str());
+      c->err.clear();
+      HIPCHK(c, hipMemcpyAsync(v.X, pl->X0, sizeof(double) * v.g.n2 * v.g.nblocks, hipMemcpyDeviceToDevice, c->stream));
+    }
   }
   const dim3 G = view_grid(v), B(POP_RED_THREADS);
   const int freq = cf.convergence_check_freq;
@@ -2117,6 +2136,7 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "rank") return c->h.rank;
   if (n == "nranks") return c->h.nranks;
   if (n == "pcg_persist_used") return c->persist_used;
+  if (n == "pcg_persist_gave_up") return c->persist_gave_up;
   if (n == "solver_path") return c->host_only ? 0 : solver_path_code(c);   // 1 per operation, 2 fused, 3 fused distributed, 4 replicated fused
   if (n == "thomas_register_tracers") return c->reg_thomas_t && (c->g.km == 60 || c->g.km == 62);    // column-in-registers Thomas kernels in use
   if (n == "thomas_register_velocity") return c->reg_thomas && (c->g.km == 60 || c->g.km == 62);
@@ -2145,6 +2165,10 @@ double pop_get_scalar(const pop_ctx *c, const char *name) {
   if (n == "rf_volume_2_km") return c->h.rf_volume_2_km;
   if (n == "open_ocean_volume_2_km") return c->h.open_ocean_volume_2_km;
   if (n == "bgtarea_t_1") return c->h.bgtarea_t_1;
+  if (n == "persist_iterations") return c->persist_out ? c->persist_out[0] : NAN;   // what the last resident pcg launch reported (kernels_pcg_persist.hpp)
+  if (n == "persist_rr") return c->persist_out ? c->persist_out[1] : NAN;
+  if (n == "persist_status") return c->persist_out ? c->persist_out[2] : NAN;
+  if (n == "persist_checks") return c->persist_out ? c->persist_out[3] : NAN;
   if (n == "rf_S1") return c->rf_S[0];
   if (n == "rf_S2") return c->rf_S[1];
   // HIP-event time of the barotropic solves (POP_SolversRun) since "solver_ms_reset", the iterations they took and their number

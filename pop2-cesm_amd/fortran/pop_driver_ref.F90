@@ -25,7 +25,7 @@
    use POP_ReductionsMod, only: POP_GlobalSum
    use global_reductions, only: global_sum, field_loc_center
    use operators, only: grad, div, zcurl
-   use POP_SolversMod, only: POP_SolversRun, POP_SolversGetDiagnostics
+   use POP_SolversMod, only: POP_SolversRun, POP_SolversGetDiagnostics, POP_SolversInit, POP_SolversPrep
    use surface_hgt, only: dhdt
    use baroclinic, only: baroclinic_driver, baroclinic_correct_adjust
    use barotropic, only: barotropic_driver
@@ -37,6 +37,9 @@
    real (POP_r8) :: rms, tsum, psum, dmax
    real (POP_r8), allocatable, dimension(:,:) :: GX, GY, DV, CU
    integer (c_int), allocatable :: ids(:)
+   real (POP_r4), allocatable :: P4(:,:,:), P43(:,:,:,:), P44(:,:,:,:,:)
+   integer (POP_i4), allocatable :: I3(:,:,:,:), I4(:,:,:,:,:), K2(:,:,:)
+   real (POP_r8), allocatable :: NF(:,:,:,:), nfsum(:)
    type (block) :: this_block
    integer (POP_i4) :: iblock
    character (char_len) :: arg, msg, horiz_grid_file, topography_file
@@ -69,6 +72,10 @@
    if (errorCode /= POP_Success) call die('pop_create')
    call init_blocks_from_ctx
    POP_haloClinic = POP_HaloCreate(errorCode)
+   call POP_SolversInit(errorCode)                                           ! initial.F90 calls both; set-up happened in pop_create
+   if (errorCode /= POP_Success) call die('POP_SolversInit')
+   call POP_SolversPrep(errorCode)
+   if (errorCode /= POP_Success) call die('POP_SolversPrep')
 
    allocate(DH(nx_block,ny_block,nblocks_clinic), DHU(nx_block,ny_block,nblocks_clinic), ZX(nx_block,ny_block,nblocks_clinic), &
             ZY(nx_block,ny_block,nblocks_clinic), PSURF(nx_block,ny_block,nblocks_clinic), RHS(nx_block,ny_block,nblocks_clinic), &
@@ -115,6 +122,45 @@
    ! the legacy reduction and the logical mask, reference lists (global_reductions.F90:383, POP_ReductionsMod.F90:144)
    write(*,'(a,es23.15)') 'legacy sumP ', global_sum(PSURF, POP_distrbClinic, field_loc_center, MASK)
    write(*,'(a,es23.15)') 'lmask sumP ', POP_GlobalSum(PSURF, POP_distrbClinic, POP_gridHorzLocCenter, errorCode, lMask = (MASK > 0.5_POP_r8))
+   ! the remaining specifics of the two generic names (mpi/POP_HaloMod.F90:79-89, mpi/POP_ReductionsMod.F90:50-58), reference lists:
+   ! single-precision and integer halo updates of 2-, 3- and 4-D arrays built from the surface pressure -- the ghost cells are cleared
+   ! first, so what comes back was put there by the update -- and the scalar / integer / several-field sums
+   allocate(P4(nx_block,ny_block,nblocks_clinic), P43(nx_block,ny_block,2,nblocks_clinic), P44(nx_block,ny_block,2,2,nblocks_clinic), &
+            I3(nx_block,ny_block,2,nblocks_clinic), I4(nx_block,ny_block,2,2,nblocks_clinic), K2(nx_block,ny_block,nblocks_clinic), &
+            NF(nx_block,ny_block,2,nblocks_clinic), nfsum(2))
+   P4 = real(PSURF, POP_r4); call clear_ghosts_r4(P4)
+   call POP_HaloUpdate(P4, POP_haloClinic, POP_gridHorzLocCenter, POP_fieldKindScalar, errorCode, fillValue = 0.0_POP_r4)
+   if (errorCode /= POP_Success) call die('POP_HaloUpdate2DR4')
+   write(*,'(a,es23.15)') 'halo r4 2d ', sum(abs(real(P4, POP_r8)))
+   P43(:,:,1,:) = P4; P43(:,:,2,:) = 2.0_POP_r4 * P4
+   do n = 1, 2
+      call clear_ghosts_r4(P43(:,:,n,:))
+   end do
+   call POP_HaloUpdate(P43, POP_haloClinic, POP_gridHorzLocCenter, POP_fieldKindScalar, errorCode)
+   if (errorCode /= POP_Success) call die('POP_HaloUpdate3DR4')
+   write(*,'(a,es23.15)') 'halo r4 3d ', sum(abs(real(P43, POP_r8)))
+   P44(:,:,:,1,:) = P43; P44(:,:,:,2,:) = -P43
+   call POP_HaloUpdate(P44, POP_haloClinic, POP_gridHorzLocCenter, POP_fieldKindScalar, errorCode)
+   if (errorCode /= POP_Success) call die('POP_HaloUpdate4DR4')
+   write(*,'(a,es23.15)') 'halo r4 4d ', sum(abs(real(P44, POP_r8)))
+   K2 = nint(1.0e3_POP_r8 * PSURF / max(maxval(abs(PSURF)), 1.0e-30_POP_r8))
+   I3(:,:,1,:) = K2; I3(:,:,2,:) = K2 + 7
+   I3(1:2,:,:,:) = -5000; I3(nx_block-1:nx_block,:,:,:) = -5000; I3(:,1:2,:,:) = -5000; I3(:,ny_block-1:ny_block,:,:) = -5000
+   call POP_HaloUpdate(I3, POP_haloClinic, POP_gridHorzLocCenter, POP_fieldKindScalar, errorCode, fillValue = 0)
+   if (errorCode /= POP_Success) call die('POP_HaloUpdate3DI4')
+   write(*,'(a,i12)') 'halo i4 3d ', sum(abs(I3))
+   I4(:,:,:,1,:) = I3; I4(:,:,:,2,:) = 2 * I3
+   call POP_HaloUpdate(I4, POP_haloClinic, POP_gridHorzLocCenter, POP_fieldKindScalar, errorCode)
+   if (errorCode /= POP_Success) call die('POP_HaloUpdate4DI4')
+   write(*,'(a,i12)') 'halo i4 4d ', sum(abs(I4))
+   write(*,'(a,es23.15)') 'scalar r8 ', POP_GlobalSum(2.5_POP_r8, POP_distrbClinic, errorCode)
+   write(*,'(a,es23.15)') 'scalar r4 ', real(POP_GlobalSum(1.25_POP_r4, POP_distrbClinic, errorCode), POP_r8)
+   write(*,'(a,i12)') 'scalar i4 ', POP_GlobalSum(3, POP_distrbClinic, errorCode)
+   write(*,'(a,i12)') 'sum i4 2d ', POP_GlobalSum(K2, POP_distrbClinic, POP_gridHorzLocCenter, errorCode, lMask = (MASK > 0.5_POP_r8))
+   write(*,'(a,es23.15)') 'sum r4 2d ', real(POP_GlobalSum(real(PSURF, POP_r4), POP_distrbClinic, POP_gridHorzLocCenter, errorCode, mMask = real(MASK, POP_r4)), POP_r8)
+   NF(:,:,1,:) = PSURF; NF(:,:,2,:) = 3.0_POP_r8 * PSURF
+   nfsum = POP_GlobalSum(NF, POP_distrbClinic, POP_gridHorzLocCenter, errorCode, mMask = MASK)
+   write(*,'(a,2es23.15)') 'sum nfields ', nfsum
    ! operators.F90 with its own lists, block by block: grad of the surface pressure, then div and zcurl of that gradient
    allocate(ids(nblocks_clinic), GX(nx_block,ny_block), GY(nx_block,ny_block), DV(nx_block,ny_block), CU(nx_block,ny_block))
    errorCode = pop_local_block_ids(pop_ctx, ids)
@@ -134,6 +180,11 @@
       call pop_amd_error_message(msg)
       write(*,*) trim(what), ' failed: ', trim(msg)
       stop 2
+   end subroutine
+
+   subroutine clear_ghosts_r4(A)
+      real (POP_r4), intent(inout) :: A(:,:,:)
+      A(1:2,:,:) = -99.0_POP_r4; A(size(A,1)-1:,:,:) = -99.0_POP_r4; A(:,1:2,:) = -99.0_POP_r4; A(:,size(A,2)-1:,:) = -99.0_POP_r4
    end subroutine
 
    subroutine geti(i, v)

@@ -71,7 +71,11 @@ def main():
     ids = m.local_block_ids()
     ok = True
     for s in range(args.steps):
-        m.step(); ref.step()
+        for who, model in (("multi-rank model", m), ("single-rank twin", ref)):
+            try:
+                model.step()
+            except Exception as e:
+                raise RuntimeError("%s, step %d: %s" % (who, s, e))
         if m.solver_diagnostics()[0] != ref.solver_diagnostics()[0]:
             print("rank %d step %d: iterations %s vs %s" % (rank, s, m.solver_diagnostics(), ref.solver_diagnostics())); ok = False
         for name in ("TRACER", "UVEL", "VVEL", "PSURF", "UBTROP", "RHO"):
@@ -106,8 +110,10 @@ def main():
         m.step(); m2.step(); ref2.step()
     for name in ("TRACER", "UVEL", "PSURF", "UBTROP"):
         a = m.get(name, 1, 0)
-        if not (np.array_equal(a, m2.get(name, 1, 0)) and np.array_equal(a, ref2.get(name, 1, 0)[[i - 1 for i in ids]])):
-            print("rank %d: %s differs after the restart round trip" % (rank, name)); ok = False
+        b2, r2 = m2.get(name, 1, 0), ref2.get(name, 1, 0)[[i - 1 for i in ids]]
+        if not (np.array_equal(a, b2) and np.array_equal(a, r2)):
+            print("rank %d: %s differs after the restart round trip (continued vs re-read on the same ranks: max %g; vs re-read single rank: max %g)"
+                  % (rank, name, np.abs(a - b2).max(), np.abs(a - r2).max())); ok = False
     dist.barrier()
     if rank == 0:
         for f in (path, path + ".hdr"):
@@ -123,4 +129,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # the launcher keeps only the tail of stderr of the rank it reports: say on stdout which rank failed first and why
+        import traceback
+        print("MR_GPU_CHECK EXCEPTION rank %s\n%s" % (os.environ.get("RANK"), traceback.format_exc()), flush=True)
+        raise

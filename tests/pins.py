@@ -1138,6 +1138,15 @@ def check_kpp_hblt_two_layer_pbc(A, kstar, frac, tol=2e-7):
     km = A.km
     t1, t2, salt, du = 16.0, 15.99, 0.035, 24.0        # a weak jump: Ri* ~ 0.45, so the boundary layer ends INSIDE the bottom cell, below its top face
     kmt = _kpp_setup(A, kstar, t1, t2, 1.0, -1.0e-4, u1=du, u2=0.0, salt=salt)
+    # A shear of 1e-3 du across the upper layer (level 1 keeps du, so |dV|^2 at the jump is unchanged).  With NO shear above the jump the
+    # bulk Richardson number there is (roundoff of the density difference of equal water) / (the eps regularisation of the denominator)
+    # -- noise of either sign and of any size up to O(0.1), which the parabola takes its slope at z(k*-1) from (the reference's formula
+    # has the same property; seen at km = 62, k* = 30: -0.053 at level 28 moved HBLT by 2e-4).  With it that number is O(1e-8).
+    shp = A.get("UVEL", 1).shape
+    lev = np.arange(1, km + 1)[None, :, None, None]
+    U = np.where(lev < kstar, du * (1.0 + 1.0e-3 * (lev - 1.0) / kstar), 0.0) + np.zeros(shp)
+    for tl in range(3):
+        A.set("UVEL", U, tl)
     wet = kmt == kstar
     ok = wet.copy()
     for dj in range(-3, 4):
@@ -1155,7 +1164,13 @@ def check_kpp_hblt_two_layer_pbc(A, kstar, frac, tol=2e-7):
     dzb = frac * dz[kstar]
     h_t = zt[kstar - 1] + 0.5 * (dz[kstar - 1] + dzb - dz[1])
     zkl = zt[kstar - 1] + 0.5 * (dz[kstar - 1] + dzb)
-    ri = (db / h_t) / (du * du / (h_t * h_t))
+    # the reference velocity is the mean over the surface layer eps zt(k*) (vmix_kpp.F90:2324-2349; full-cell depths also with partial cells)
+    zw = np.concatenate([[0.0], np.cumsum(dz[1:])])
+    surf = EPSSFC * zt[kstar]
+    kref = next(k for k in range(1, kstar + 1) if zw[k] >= surf)
+    ulev = U[0, :, 0, 0]
+    uref = (ulev[kref - 1] * (surf - zw[kref - 1]) + sum(dz[k] * ulev[k - 1] for k in range(1, kref))) / surf
+    ri = (db / h_t) / (uref * uref / (h_t * h_t))
     assert ri > RICR
     expect = zt[kstar - 1] + (zkl - zt[kstar - 1]) * np.sqrt(RICR / ri)
     hblt, kbl = A.get("HBLT")[ok], A.geti("KBL")[ok]

@@ -82,6 +82,31 @@ def test_reference_argument_lists_match_python(pkg):
     for tag in ("legacy", "lmask"):
         got = re.search(tag + r" sumP\s+(\S+)", out)
         assert got and float(got.group(1)) == pytest.approx(want, rel=1e-13, abs=1e-9), tag
+    # r4: the remaining specifics of POP_HaloUpdate (2-/3-/4-D r4, 3-/4-D i4) and POP_GlobalSum (scalars, 2-D r4 / i4, several fields),
+    # POP_SolversInit / POP_SolversPrep: called with the reference's lists from Fortran, expected values formed here from the same pressure
+    def val(tag, cast=float):
+        got = re.search(tag + r"[ \t]+(\S+)(?:[ \t]+(\S+))?", out)
+        assert got, tag
+        return cast(got.group(1)) if got.group(2) is None else (cast(got.group(1)), cast(got.group(2)))
+    ps = m.get("PSURF", 1, 0)
+    p4 = np.abs(ps.astype(np.float32).astype(np.float64)).sum()          # the ghost cells were cleared and must have come back
+    assert val("halo r4 2d") == pytest.approx(p4, rel=1e-12) and val("halo r4 3d") == pytest.approx(3.0 * p4, rel=1e-12)
+    assert val("halo r4 4d") == pytest.approx(6.0 * p4, rel=1e-12)
+    k2 = np.rint(1.0e3 * ps / max(np.abs(ps).max(), 1e-30)).astype(np.int32)
+    i3 = np.stack([k2, k2 + 7], axis=1)                                   # (nblocks, 2, ny, nx)
+    i3[:, :, :2, :] = -5000; i3[:, :, -2:, :] = -5000; i3[:, :, :, :2] = -5000; i3[:, :, :, -2:] = -5000   # (|k2| <= 1000: not a value of the field)
+    i3 = np.ascontiguousarray(i3)
+    m.halo_update_host(i3, fill=0)
+    assert val("halo i4 3d", int) == int(np.abs(i3).sum()) and val("halo i4 4d", int) == 3 * int(np.abs(i3).sum())
+    assert (i3 != -5000).all()
+    assert val("scalar r8") == 2.5 and val("scalar r4") == 1.25 and val("scalar i4", int) == 3
+    mask = m.get("mMask")
+    inner = (slice(None), slice(2, -2), slice(2, -2))
+    assert val("sum i4 2d", int) == int(k2[inner][mask[inner] > 0.5].sum())
+    want4 = np.float32(m.global_sum_host(ps.astype(np.float32).astype(np.float64) * mask.astype(np.float32).astype(np.float64)))
+    assert val("sum r4 2d") == pytest.approx(float(want4), rel=1e-6, abs=1e-9)
+    nf = val("sum nfields")
+    assert nf[0] == pytest.approx(want, rel=1e-13, abs=1e-9) and nf[1] == pytest.approx(3.0 * want, rel=1e-12, abs=1e-9)
     # grad / div / zcurl(k, ..., this_block) on host arrays of one block against the same entry points from Python
     ops = re.findall(r"ops block\s+(\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", out)
     assert len(ops) == m.nblocks
@@ -90,8 +115,8 @@ def test_reference_argument_lists_match_python(pkg):
         ib = int(row[0])
         gx, gy = m.operator_host("grad", 1, ib, ps[ib - 1])
         dv, cu = m.operator_host("div", 1, ib, gx, gy), m.operator_host("zcurl", 1, ib, gx, gy)
-        for val, arr in zip(row[1:], (gx, gy, dv, cu)):
-            assert float(val) == pytest.approx(np.abs(arr).sum(), rel=1e-12), row
+        for printed, arr in zip(row[1:], (gx, gy, dv, cu)):
+            assert float(printed) == pytest.approx(np.abs(arr).sum(), rel=1e-12), row
         assert np.abs(gx).sum() > 0.0 and np.abs(dv).sum() > 0.0
     m.close()
 

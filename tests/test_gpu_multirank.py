@@ -33,7 +33,7 @@ def _run_check(args, timeout, env=None, transport="staged"):
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
         if "MR_GPU_CHECK" in out.stdout or not any(e in out.stderr for e in _RDZV_ERRORS):
             break
-    assert "MR_GPU_CHECK OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "MR_GPU_CHECK OK" in out.stdout, out.stdout[-6000:] + out.stderr[-3000:]
     return out.stdout
 
 

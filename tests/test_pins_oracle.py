@@ -118,10 +118,10 @@ def test_gm_buoyancy_frequency_profile_and_its_bounds(orclib_built):
     A.close()
 
 
-@pytest.mark.parametrize("frac", [0.4, 0.7])
-def test_kpp_boundary_layer_ending_in_a_partial_bottom_cell(orclib_built, frac):
+@pytest.mark.parametrize("frac,km,kstar", [(0.4, 20, 10), (0.7, 20, 10), (0.55, 62, 30)])
+def test_kpp_boundary_layer_ending_in_a_partial_bottom_cell(orclib_built, frac, km, kstar):
     """vmix_kpp.F90:2212-2220, 2359-2366, 2561-2575, 1296-1302 with partial_bottom_cells: pins.check_kpp_hblt_two_layer_pbc"""
-    cfg = named_config("tiny", vmix_choice=3, km=20, block_size_x=48, block_size_y=40, partial_bottom_cells=1, ns_boundary=0)
-    A = pins.OracleAdapter(cfg, grid=pins.pbc_flat_grid(cfg, 10, frac))
-    pins.check_kpp_hblt_two_layer_pbc(A, 10, frac)
+    cfg = named_config("tiny", vmix_choice=3, km=km, block_size_x=48, block_size_y=40, partial_bottom_cells=1, ns_boundary=0)
+    A = pins.OracleAdapter(cfg, grid=pins.pbc_flat_grid(cfg, kstar, frac))
+    pins.check_kpp_hblt_two_layer_pbc(A, kstar, frac)
     A.close()
