@@ -289,11 +289,8 @@ int host_build(HostModel &h) {
   if (c.nt < 2 || c.nt > MAXNT) { h.err = "nt must be in [2,8]"; return 1; }
   if (c.km < 2) { h.err = "km must be >= 2"; return 1; }
   // block sizes that do not divide the domain: the last column / row of blocks is padded (blocks.F90:174-265; make_blocks)
-  const bool padded = c.nx_global % c.block_size_x != 0 || c.ny_global % c.block_size_y != 0;
-  if (padded && (c.ns_boundary == 2 || c.solver_choice == 3 || use_evp(c))) {
-    h.err = "padded blocks (block size not dividing the domain) are built for dipole grids with pcg / ChronGear and the diagonal preconditioner; "
-            "tripole grids, P-CSI and EVP need block sizes that divide the domain"; return 1;
-  }
+  // (round 4: also with the tripole fold, P-CSI and the EVP preconditioner -- the fold and the halo plan work on global indices, the
+  // Lanczos bounds and the sub-block tables on every block's own ib .. ie / jb .. je, POP_SolversMod.F90:2483-2488)
   if (c.ns_boundary < 0 || c.ns_boundary > 2) { h.err = "ns_boundary: 0 closed, 1 cyclic, 2 tripole"; return 1; }
   if (c.ns_boundary == 2 && (c.ew_boundary != 1 || c.nx_global % 2 || c.block_size_y < NGHOST + 1)) {
     h.err = "tripole needs a cyclic east-west boundary, even nx_global and blocks of at least nghost+1 rows"; return 1;

@@ -181,20 +181,32 @@ __device__ __forceinline__ void block_sum_ordered(const double *__restrict__ pb,
       for (int f = 0; f < NF; ++f) v[f] = v[f] + w[u][f];
   }
   if (DEPTH > 16) {
-    // the remainder (fewer than DEPTH terms) in ONE more round (r4): every load of the batch is requested -- at a clamped address where the term
-    // does not exist -- before the first add, and a term that does not exist is not added (adding +0.0 could turn a sum of -0.0 into +0.0).
-    // Until round 4 the last few terms went one load -> one add at a time: at tx0.1v3 (33 844 chunks, 132 terms per thread) four to five
-    // dependent round trips behind the two batches of 64, ~4 of the 9.5 us of every k_block_sums launch inside the step.
-    if (cidx < nchunk) {
-      double w[DEPTH][NF];
+    // the remainder (fewer than DEPTH terms; r4): full batches of 16 while there are that many, then ONE batch of 8 in which every load is
+    // requested -- at a clamped address where the term does not exist -- before the first add, and a term that does not exist is not added
+    // (adding +0.0 could turn a sum of -0.0 into +0.0); repeated only if more than 8 terms are left.  Until round 4 the last terms went one
+    // load -> one add at a time (tx0.1v3: 33 844 chunks, 132 terms per thread = four dependent round trips behind the two batches of 64); a
+    // predicated batch of all 64 was tried first and cost more than it saved (11.2 against 9.6 us per launch inside the step).
+    for (; cidx + 15 * POP_RED_THREADS < nchunk; cidx += 16 * POP_RED_THREADS) {
+      double w[16][NF];
 #pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) w[u][f] = pb[((long long)cidx + u * POP_RED_THREADS) * NF + f];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f] = v[f] + w[u][f];
+    }
+    for (; cidx < nchunk; cidx += 8 * POP_RED_THREADS) {
+      double w[8][NF];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
         const long long c = (long long)cidx + u * POP_RED_THREADS;
 #pragma unroll
         for (int f = 0; f < NF; ++f) w[u][f] = pb[(c < nchunk ? c : (long long)nchunk - 1) * NF + f];
       }
 #pragma unroll
-      for (int u = 0; u < DEPTH; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const bool there = (long long)cidx + u * POP_RED_THREADS < nchunk;
 #pragma unroll
         for (int f = 0; f < NF; ++f) v[f] = there ? v[f] + w[u][f] : v[f];

@@ -34,6 +34,11 @@ struct MomTile {
 template <int R, bool PBC = false>
 __global__ void __launch_bounds__(POP_COL_THREADS * R)
 k_momentum_rhs_lds(DevGrid g, StepParams sp, MomentumRhsArgs a, int tj_first, int tj_count) {
+#ifdef POP_PROBE_MOM_CONTRACT
+  // MEASUREMENT PROBE, never part of libpop_amd.so (profiles/r04_probe_mom_contract.txt): the same kernel with multiply-adds fused, to
+  // see what the instruction count of a level is worth.  Results are no longer those of the reference's operation order.
+#pragma clang fp contract(fast)
+#endif
   using T = MomTile<R, PBC>;
   __shared__ T t;
   const int nxb = g.nxb, nyb = g.nyb, km = g.km;

@@ -86,8 +86,9 @@ template <int CP>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_pcg_persist(PersistArgs a) {
   extern __shared__ double lds[];                          // Xw | Sw | Zw, nwin doubles each
-  __shared__ double sh[CP][POP_RED_THREADS];               // the chunk trees; row 0 also serves the total's tree
-  __shared__ double sh_x;
+  constexpr int NSH = CP > POP_PERSIST_MAXP ? CP : POP_PERSIST_MAXP;
+  __shared__ double sh[NSH][POP_RED_THREADS];              // the chunk trees, then the trees of the blocks' totals
+  __shared__ double sh_tot[POP_PERSIST_MAXP];
   __shared__ int dead;
   constexpr int NT = POP_RED_THREADS, NOWN = CP * NT;
   const int t = threadIdx.x, w = blockIdx.x;
@@ -124,7 +125,7 @@ k_pcg_persist(PersistArgs a) {
   }
   __syncthreads();
 
-  int phase = 0;                                           // number of the next exchange: its slots are in buffer phase % 3
+  int phase = 0;                                           // number of the next exchange: its slots are in buffer phase % 2
   // ---- one exchange: the chunk partials of v[] out, everybody's partials in, their ordered total back (every thread the same
   //      value); with_z: also z of the halo cells of iteration m
   auto exchange = [&](double (&v)[CP], bool with_z, int m) -> double {
@@ -150,19 +151,23 @@ k_pcg_persist(PersistArgs a) {
       }
     }
     // what this thread collects: slots b * nchunk + c, c = t, t + 256, ... of every block, and (with_z) its halo cells; a load it does
-    // not need is aimed at the first word of the phase and accepted whatever its tag
+    // not need is aimed at the first word of the phase and accepted whatever its tag.  (Forming these once before the iteration loop
+    // instead of in every exchange -- 22 more live registers -- was measured 1 us per iteration SLOWER: profiles/r04_ab_persist_shape.txt.)
     const int per_b = (a.nchunk - t + NT - 1) / NT;        // chunks of one block this thread adds (<= 0: none)
     unsigned off[14]; bool need[14]; unsigned long long want[14];
+    int kb[POP_PERSIST_MAXP];
 #pragma unroll
     for (int k = 0; k < POP_PERSIST_MAXP; ++k) {
       const int b = per_b > 0 ? k / per_b : a.nblocks, c = per_b > 0 ? t + (k % per_b) * NT : 0;
-      need[k] = b < a.nblocks; want[k] = ptag;
+      need[k] = b < a.nblocks; want[k] = ptag; kb[k] = need[k] ? b : -1;
       off[k] = (unsigned)((pbase + (need[k] ? (long long)b * a.nchunk + c : 0)) * (long long)sizeof(PWord));
     }
+    int halo_cell[POP_PERSIST_MAXH];
 #pragma unroll
     for (int k = 0; k < POP_PERSIST_MAXH; ++k) {
       const int hh = t + k * NT;
       need[POP_PERSIST_MAXP + k] = with_z && hh < nhalo; want[POP_PERSIST_MAXP + k] = ztag;
+      halo_cell[k] = hh < nhalo ? 0 : -1;
       off[POP_PERSIST_MAXP + k] = (unsigned)((need[POP_PERSIST_MAXP + k] ? zbase + a.halo_q[h0 + hh] : pbase) * (long long)sizeof(PWord));
     }
     pword4 got[14];
@@ -186,26 +191,31 @@ k_pcg_persist(PersistArgs a) {
     for (int k = 0; k < POP_PERSIST_MAXP; ++k) pv[k] = need[k] ? (unsigned long long)__double_as_longlong(pword_value(got[k])) : 0ULL;
     if (with_z) {
 #pragma unroll
-      for (int k = 0; k < POP_PERSIST_MAXH; ++k) { const int hh = t + k * NT; if (hh < nhalo) Zw[NOWN + hh] = pword_value(got[POP_PERSIST_MAXP + k]); }
+      for (int k = 0; k < POP_PERSIST_MAXH; ++k) if (halo_cell[k] >= 0) Zw[NOWN + t + k * NT] = pword_value(got[POP_PERSIST_MAXP + k]);
     }
-    // the rule of fused_total: per block the thread-strided left-to-right sum, the fixed tree, blocks in order
-    double total = 0.0;
-    for (int b = 0; b < a.nblocks; ++b) {
+    // the rule of fused_total: per block the thread-strided left-to-right sum, the fixed tree, blocks in order -- the trees of all blocks
+    // side by side (one set of barriers; with the eight bands of an 8-rank decomposition in one view, eight trees one after the other
+    // were 5 us of every exchange)
+    const int nb = a.nblocks;
+    __syncthreads();                                         // the chunk trees above have been read
+    for (int b = 0; b < nb; ++b) {
       double x = 0.0;
 #pragma unroll
       for (int k = 0; k < POP_PERSIST_MAXP; ++k)
-        if (per_b > 0 && k / per_b == b) x = x + __longlong_as_double((long long)pv[k]);
-      __syncthreads();
-      sh[0][t] = x;
-      __syncthreads();
-      for (int s = NT / 2; s >= 64; s >>= 1) {
-        if (t < s) sh[0][t] = sh[0][t] + sh[0][t + s];
-        __syncthreads();
-      }
-      if (t < 64) { const double y = tree_tail64(sh[0][t]); if (t == 0) sh_x = y; }
-      __syncthreads();
-      total = total + sh_x;
+        if (kb[k] == b) x = x + __longlong_as_double((long long)pv[k]);
+      sh[b][t] = x;
     }
+    __syncthreads();
+    for (int s = NT / 2; s >= 64; s >>= 1) {
+      if (t < s)
+        for (int b = 0; b < nb; ++b) sh[b][t] = sh[b][t] + sh[b][t + s];
+      __syncthreads();
+    }
+    if (t < 64)
+      for (int b = 0; b < nb; ++b) { const double y = tree_tail64(sh[b][t]); if (t == 0) sh_tot[b] = y; }
+    __syncthreads();
+    double total = 0.0;
+    for (int b = 0; b < nb; ++b) total = total + sh_tot[b];
     __syncthreads();
     ++phase;
     return total;

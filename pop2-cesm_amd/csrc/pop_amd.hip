@@ -116,6 +116,7 @@ struct pop_ctx {
   double *persist_out = nullptr;                           // pinned: iterations, (r,r), status, checks
   int persist_used = 0;                                    // the last pcg solve ran as the resident launch
   int persist_gave_up = 0;                                 // resident solves that gave up a wait (then never used again in this model)
+  int persist_nwg = 0, persist_cp = 0;                     // shape of the last resident launch
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
   bool reg_thomas_t = true;
   int trc_lds_rows = 4;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
@@ -571,62 +572,74 @@ static pop_ctx::PersistPlan *persist_plan(pop_ctx *c, const SolveView &v) {
   const bool global = v.srcmap != c->srcmap;                // the replicated view holds every block of the decomposition
   auto refuse = [&](const char *why) -> pop_ctx::PersistPlan * { pl.why = why; return nullptr; };
   if (nb * ((nchunk + POP_RED_THREADS - 1) / POP_RED_THREADS) > POP_PERSIST_MAXP) return refuse("too many partial slots per thread");
-  int CP = 0;
-  for (int cp : {1, 2, 4, 8}) if ((nslots + cp - 1) / cp <= 128) { CP = cp; break; }
-  if (!CP) return refuse("more than 1024 chunks");
-  // measurement only: pop_tuning.pcg_persist = 2 | 4 | 8 forces that many chunks per workgroup (at most 250 workgroups)
-  if (c->h.tun.pcg_persist == 2 || c->h.tun.pcg_persist == 4 || c->h.tun.pcg_persist == 8) { if ((nslots + c->h.tun.pcg_persist - 1) / c->h.tun.pcg_persist <= 250) CP = c->h.tun.pcg_persist; }
+  // chunks per workgroup: the smallest of 1 / 2 / 4 / 8 that needs at most 250 workgroups (one per CU: the waits need every workgroup
+  // resident).  gx1v7 in one block: 246 x 2 (10.7 us per iteration; 123 x 4: 12.0, 62 x 8: 14.1 on the same box, profiles/r04_ab_persist_shape.txt);
+  // gx1v7 in the eight 48-row bands of the 8-rank decomposition (replicated solve): 144 x 4.
+  // measurement only: pop_tuning.pcg_persist = 2 | 4 | 8 forces that many chunks per workgroup
+  std::vector<int> cand;
+  if (c->h.tun.pcg_persist == 2 || c->h.tun.pcg_persist == 4 || c->h.tun.pcg_persist == 8) { if ((nslots + c->h.tun.pcg_persist - 1) / c->h.tun.pcg_persist <= 250) cand.push_back(c->h.tun.pcg_persist); }
+  if (cand.empty())
+    for (int cp : {1, 2, 4, 8}) if ((nslots + cp - 1) / cp <= 250) { cand.push_back(cp); break; }
+  if (cand.empty()) return refuse("more than 2000 chunks");
   const std::vector<int> sm = global ? global_srcmap(h) : c->h_srcmap;
   if ((long long)sm.size() != (long long)n2 * nb) return refuse("source map size");
-  const int nwg = (nslots + CP - 1) / CP, NOWN = CP * POP_RED_THREADS;
-  std::vector<int> own((size_t)nwg * NOWN, -1), hoff(nwg + 1, 0), hq;
-  std::vector<unsigned short> nbr((size_t)nwg * NOWN * 8, 0);
   const int off[8] = {nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
-  int nwin_max = 0;
-  for (int w = 0; w < nwg; ++w) {
-    std::unordered_map<int, int> where;                    // cell -> window index
-    for (int u = 0; u < CP; ++u) {
-      const int slot = w * CP + u;
-      if (slot >= nslots) break;
-      const int b = slot / nchunk, ch = slot % nchunk;
-      const BlockInfo &B = h.all_blocks[global ? b : h.local_ids[b] - 1];
-      for (int t = 0; t < POP_RED_THREADS; ++t) {
-        const int p2 = ch * POP_RED_THREADS + t;
-        if (p2 >= n2) break;
-        const int i = p2 % nxb + 1, j = p2 / nxb + 1;
-        if (i < B.ib || i > B.ie || j < B.jb || j > B.je) continue;
-        own[(size_t)w * NOWN + u * POP_RED_THREADS + t] = b * n2 + p2;
-        where[b * n2 + p2] = u * POP_RED_THREADS + t;
-      }
-    }
-    const size_t h0 = hq.size();
-    std::vector<std::pair<size_t, int>> zero_refs;
-    for (int L = 0; L < NOWN; ++L) {
-      const int q = own[(size_t)w * NOWN + L];
-      if (q < 0) continue;
-      for (int n = 0; n < 8; ++n) {
-        const int m = sm[q + off[n]];
-        int idx;
-        if (m < 0) idx = -1;
-        else {
-          auto it = where.find(m);
-          if (it != where.end()) idx = it->second;
-          else { idx = NOWN + (int)(hq.size() - h0); where[m] = idx; hq.push_back(m); }
+  int CP = 0, nwg = 0, nwin_max = 0;
+  std::vector<int> own, hoff, hq;
+  std::vector<unsigned short> nbr;
+  const char *why = "";
+  for (int cp : cand) {
+    why = "";
+    nwg = (nslots + cp - 1) / cp; nwin_max = 0;
+    const int NOWN = cp * POP_RED_THREADS;
+    own.assign((size_t)nwg * NOWN, -1); hoff.assign(nwg + 1, 0); hq.clear();
+    nbr.assign((size_t)nwg * NOWN * 8, 0);
+    for (int w = 0; w < nwg && !*why; ++w) {
+      std::unordered_map<int, int> where;                    // cell -> window index
+      for (int u = 0; u < cp; ++u) {
+        const int slot = w * cp + u;
+        if (slot >= nslots) break;
+        const int b = slot / nchunk, ch = slot % nchunk;
+        const BlockInfo &B = h.all_blocks[global ? b : h.local_ids[b] - 1];
+        for (int t = 0; t < POP_RED_THREADS; ++t) {
+          const int p2 = ch * POP_RED_THREADS + t;
+          if (p2 >= n2) break;
+          const int i = p2 % nxb + 1, j = p2 / nxb + 1;
+          if (i < B.ib || i > B.ie || j < B.jb || j > B.je) continue;
+          own[(size_t)w * NOWN + u * POP_RED_THREADS + t] = b * n2 + p2;
+          where[b * n2 + p2] = u * POP_RED_THREADS + t;
         }
-        nbr[((size_t)w * NOWN + L) * 8 + n] = (unsigned short)(idx < 0 ? 0xFFFF : idx);
       }
+      const size_t h0 = hq.size();
+      for (int L = 0; L < NOWN; ++L) {
+        const int q = own[(size_t)w * NOWN + L];
+        if (q < 0) continue;
+        for (int n = 0; n < 8; ++n) {
+          const int m = sm[q + off[n]];
+          int idx;
+          if (m < 0) idx = -1;
+          else {
+            auto it = where.find(m);
+            if (it != where.end()) idx = it->second;
+            else { idx = NOWN + (int)(hq.size() - h0); where[m] = idx; hq.push_back(m); }
+          }
+          nbr[((size_t)w * NOWN + L) * 8 + n] = (unsigned short)(idx < 0 ? 0xFFFF : idx);
+        }
+      }
+      const int nhalo = (int)(hq.size() - h0), nwin = NOWN + nhalo + 1;
+      if ((nhalo + POP_RED_THREADS - 1) / POP_RED_THREADS > POP_PERSIST_MAXH) { why = "halo of a workgroup too large"; break; }
+      if (nwin >= 0xFFFF) { why = "window too large"; break; }
+      for (int L = 0; L < NOWN; ++L) for (int n = 0; n < 8; ++n) {
+        unsigned short &x = nbr[((size_t)w * NOWN + L) * 8 + n];
+        if (x == 0xFFFF) x = (unsigned short)(nwin - 1);     // the cell of zeros (fill value of closed boundaries)
+      }
+      hoff[w + 1] = (int)hq.size();
+      nwin_max = std::max(nwin_max, nwin);
     }
-    const int nhalo = (int)(hq.size() - h0), nwin = NOWN + nhalo + 1;
-    if ((nhalo + POP_RED_THREADS - 1) / POP_RED_THREADS > POP_PERSIST_MAXH) return refuse("halo of a workgroup too large");
-    if (nwin >= 0xFFFF) return refuse("window too large");
-    for (int L = 0; L < NOWN; ++L) for (int n = 0; n < 8; ++n) {
-      unsigned short &x = nbr[((size_t)w * NOWN + L) * 8 + n];
-      if (x == 0xFFFF) x = (unsigned short)(nwin - 1);     // the cell of zeros (fill value of closed boundaries)
-    }
-    hoff[w + 1] = (int)hq.size();
-    nwin_max = std::max(nwin_max, nwin);
+    if (!*why && (size_t)3 * nwin_max * sizeof(double) > 60000) why = "window does not fit the LDS budget";
+    if (!*why) { CP = cp; break; }
   }
-  if ((size_t)3 * nwin_max * sizeof(double) > 60000) return refuse("window does not fit the LDS budget");
+  if (!CP) return refuse(why);
   if (hq.empty()) hq.push_back(0);
   if (dev_upload(c, &pl.own_q, own.data(), own.size()) || dev_upload(c, &pl.nbr, nbr.data(), nbr.size()) ||
       dev_upload(c, &pl.halo_off, hoff.data(), hoff.size()) || dev_upload(c, &pl.halo_q, hq.data(), hq.size())) return nullptr;
@@ -670,7 +683,7 @@ int solver_pcg_persist(pop_ctx *c, SolveView &v, const pop_ctx::PersistPlan &pl)
   }
   c->numIterations = (int)c->persist_out[0];
   c->rmsResidual = std::sqrt(c->persist_out[1] * c->h.residualNorm);
-  c->persist_used = 1;
+  c->persist_used = 1; c->persist_nwg = pl.nwg; c->persist_cp = pl.CP;
   hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, v.X, v.srcmap, ncell);
   HIPCHK(c, hipGetLastError());
   const bool conv = c->persist_out[3] > 0.0 && c->persist_out[1] < c->h.convergenceCriterion;
@@ -2137,6 +2150,8 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "nranks") return c->h.nranks;
   if (n == "pcg_persist_used") return c->persist_used;
   if (n == "pcg_persist_gave_up") return c->persist_gave_up;
+  if (n == "pcg_persist_workgroups") return c->persist_nwg;
+  if (n == "pcg_persist_chunks_per_workgroup") return c->persist_cp;
   if (n == "solver_path") return c->host_only ? 0 : solver_path_code(c);   // 1 per operation, 2 fused, 3 fused distributed, 4 replicated fused
   if (n == "thomas_register_tracers") return c->reg_thomas_t && (c->g.km == 60 || c->g.km == 62);    // column-in-registers Thomas kernels in use
   if (n == "thomas_register_velocity") return c->reg_thomas && (c->g.km == 60 || c->g.km == 62);

@@ -57,6 +57,7 @@ def sq_summary():
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     nd = collections.defaultdict(lambda: collections.defaultdict(set))
     meta = {}
+    dsum = collections.defaultdict(dict)           # kernel -> dispatch id -> duration [ns] (under the counter pass)
     newest = []                                    # one file per SQ pass: the newest collection
     for d in sorted(glob.glob(os.path.join(PROF, "tx0.1v3_SQ*"))):
         fs = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
@@ -67,19 +68,31 @@ def sq_summary():
             if not k.startswith("k_"):
                 continue
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                dsum[k][r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
             nd[k][r["Counter_Name"]].add(r["Dispatch_Id"])
             meta[k] = {"vgprs": int(r.get("VGPR_Count") or 0), "lds_bytes": int(r.get("LDS_Block_Size") or 0),
                        "workgroup": int(r.get("Workgroup_Size") or 0), "scratch_bytes": int(r.get("Scratch_Size") or 0)}
     out = {}
+    durations = {k: sum(v.values()) / len(v) for k, v in dsum.items() if v}
     for k, cs in acc.items():
         per = {c: v / max(len(nd[k][c]), 1) for c, v in cs.items()}
         e = dict(meta[k])
         e["per_dispatch"] = {c: round(v) for c, v in sorted(per.items())}
         wc = per.get("SQ_WAVE_CYCLES")
         if wc:
-            # SQ_WAVE_CYCLES, SQ_WAIT_ANY: wave-cycles; SQ_ACTIVE_INST_VALU: cycles a wave occupies the VALU (x4 for the quad-cycle unit)
+            # Units (MI355X_MICROARCH.md, PMC table): SQ_WAVE_CYCLES, SQ_WAIT_* and SQ_ACTIVE_INST_* all count QUAD-cycles of a wave, and
+            # WAIT_ANY (parked: s_waitcnt / barrier) + WAIT_INST_ANY (ready but not issued: pipe busy or operand not ready) + ACTIVE_INST_*
+            # ~ WAVE_CYCLES.  (The r3 summary multiplied ACTIVE_INST_VALU by four and so reported the momentum kernel as 0.83 "VALU-busy";
+            # in the same units it is 0.21 of a wave's cycles.)  simd_valu_utilisation: the VALU quad-cycles of all waves over the SIMD
+            # quad-cycles of the launch (1024 SIMDs x its duration at 2.4 GHz) -- what "instruction-issue-bound" would have to be near 1 for.
             e["wait_share_of_wave_cycles"] = round(per.get("SQ_WAIT_ANY", 0.0) / wc, 3) if "SQ_WAIT_ANY" in per else None
-            e["valu_busy_share_of_wave_cycles"] = round(4.0 * per.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 3) if "SQ_ACTIVE_INST_VALU" in per else None
+            e["issue_stall_share_of_wave_cycles"] = round(per.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3) if "SQ_WAIT_INST_ANY" in per else None
+            e["valu_active_share_of_wave_cycles"] = round(per.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 3) if "SQ_ACTIVE_INST_VALU" in per else None
+            dur = durations.get(k)
+            if dur and "SQ_ACTIVE_INST_VALU" in per:
+                e["avg_us_under_pmc"] = round(dur / 1e3, 2)
+                e["simd_valu_utilisation"] = round(per["SQ_ACTIVE_INST_VALU"] / (1024.0 * dur * 1e-9 * 2.4e9 / 4.0), 3)
         out[k] = e
     if out:
         p = os.path.join(ROOT, "profiles", "r04_sq_summary.json")

@@ -1149,8 +1149,9 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
     ("tiny", {"ns_boundary": 2, "block_size_x": 24, "block_size_y": 20}, True),     # tripole fold inside the source map
     ("test", {}, False),                                                            # 96 blocks (more than a thread can collect: must fall back)
     ("gx3v7", {}, False),
-    ("gx1v7", {}, False),                                                           # BASELINE configs[2]: 492 chunks, 123 workgroups of 4 chunks
+    ("gx1v7", {}, False),                                                           # BASELINE configs[2]: 492 chunks, 246 workgroups of 2 chunks
     ("gx1v7", {"block_size_y": 96}, False),                                         # four j-band blocks in one view (the shape of the replicated solve)
+    ("gx1v7", {"block_size_y": 48}, False),                                         # the eight bands of the 8-rank decomposition in one view: eight block totals per exchange
 ])
 def test_persistent_pcg_is_bitwise_the_fused_pcg(pkg, name, kw, grid):
     """pop_tuning.pcg_persist: the whole pcg solve of a small 2-D system as one resident launch (kernels_pcg_persist.hpp) -- the
@@ -1167,6 +1168,8 @@ def test_persistent_pcg_is_bitwise_the_fused_pcg(pkg, name, kw, grid):
         used += b.dim("pcg_persist_used")
         assert a.dim("pcg_persist_used") == 0
     assert used == (0 if name == "test" else 5)
+    if kw.get("block_size_y") == 48:
+        assert (b.dim("pcg_persist_workgroups"), b.dim("pcg_persist_chunks_per_workgroup")) == (144, 4)
     for f in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER", "GRADPX"):
         assert np.array_equal(a.get(f), b.get(f)), f
     a.close(); b.close()

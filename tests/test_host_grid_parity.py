@@ -184,10 +184,6 @@ def test_abi_exports_every_declared_symbol(pkg):
 
 
 def test_bad_configs_are_rejected(pkg):
-    with pytest.raises(pkg.PopError, match="divide"):      # padded blocks: dipole grids with pcg / ChronGear and the diagonal preconditioner only
-        pkg.PopModel(named_config("tiny", block_size_x=13, solver_choice=3), host_only=True)
-    with pytest.raises(pkg.PopError, match="divide"):
-        pkg.PopModel(named_config("tiny", block_size_x=20, block_size_y=16, precond_choice=1), host_only=True)
     with pytest.raises(pkg.PopError, match="nt"):
         pkg.PopModel(named_config("tiny", nt=1), host_only=True)
     m = pkg.PopModel(named_config("tiny"), host_only=True)
@@ -221,6 +217,20 @@ def test_unsupported_options_are_refused_at_create(pkg, field, value):
     with pytest.raises(pkg.PopError) as e:
         pkg.PopModel(cfg, host_only=True)
     assert "pop_create" in str(e.value)
+
+
+@pytest.mark.parametrize("kw", [{"block_size_x": 20, "block_size_y": 16, "solver_choice": 3}, {"block_size_x": 28, "block_size_y": 24, "solver_choice": 3, "precond_choice": 1},
+                                {"block_size_x": 20, "block_size_y": 16, "ns_boundary": 2, "solver_choice": 3, "precond_choice": 1}])
+def test_padded_blocks_solver_set_up_bit_exact(pkg, orclib_built, kw):
+    """r4: padded blocks with P-CSI (Lanczos bounds, POP_SolversMod.F90:2699-2990), the EVP preconditioner (sub-block tables on every
+    block's own extents, :2434-2696) and the tripole fold: the eigenvalue bounds and step count equal the oracle's bit for bit."""
+    cfg = named_config("tiny", **kw)
+    g = synthetic_grid(cfg) if cfg.ns_boundary == 2 else None
+    m, o = pkg.PopModel(cfg, host_only=True, grid=g), Oracle(cfg, grid=g)
+    for s in ("PcsiMaxEigs", "PcsiMinEigs", "lanczos_steps", "residualNorm", "convergenceCriterion"):
+        assert m.scalar(s) == o.scalar(s), s
+    assert 0.0 < m.scalar("PcsiMinEigs") < m.scalar("PcsiMaxEigs")
+    m.close(); o.close()
 
 
 @pytest.mark.parametrize("kw", [{"block_size_x": 20, "block_size_y": 16}, {"block_size_x": 36, "block_size_y": 40}, {"block_size_x": 20, "block_size_y": 16, "ew_boundary": 0},
