@@ -110,30 +110,45 @@ k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__re
   const long long n2 = g.n2, q = (long long)b * n2 + p2, o = (long long)b * g.n3 + (long long)(kk - 1) * n2 + p2;
   const int kmt = g.KMT[q];
   auto temp = [&](long long oo) { return fmax(-2.0, T[oo]); };
-  // horizontal differences of level kk on the east / north face of cell d (0: this cell, -1 / -nxb: west / south neighbour)
-  auto kmaske = [&](long long d) { return (kk <= g.KMT[q + d] && kk <= g.KMT[q + d + 1]) ? 1.0 : 0.0; };
-  auto kmaskn = [&](long long d) { return (kk <= g.KMT[q + d] && kk <= g.KMT[q + d + nxb]) ? 1.0 : 0.0; };
-  double txp_e = 0.0, txs_e = 0.0, txp_w = 0.0, txs_w = 0.0, typ_n = 0.0, tys_n = 0.0, typ_s = 0.0, tys_s = 0.0;
-  if (i <= nxb - 2) { const double mk = kmaske(0); txp_e = mk * (temp(o + 1) - temp(o)); txs_e = mk * (S[o + 1] - S[o]); }
-  if (i >= 1) { const double mk = kmaske(-1); txp_w = mk * (temp(o) - temp(o - 1)); txs_w = mk * (S[o] - S[o - 1]); }
-  if (j <= nyb - 2) { const double mk = kmaskn(0); typ_n = mk * (temp(o + nxb) - temp(o)); tys_n = mk * (S[o + nxb] - S[o]); }
-  if (j >= 1) { const double mk = kmaskn(-nxb); typ_s = mk * (temp(o) - temp(o - nxb)); tys_s = mk * (S[o] - S[o - nxb]); }
-  double drdt, drds;
-  const MwjfP P = mwjf_level(g.pressz[kk]);
-  mwjf_rho<true>(P, T[o], S[o], &drdt, &drds);
-  const double rxe = drdt * txp_e + drds * txs_e, rxw = (i >= 1) ? drdt * txp_w + drds * txs_w : 0.0;
-  const double ryn = drdt * typ_n + drds * tys_n, rys = (j >= 1) ? drdt * typ_s + drds * tys_s : 0.0;
   double sl[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};   // [half][xe, xw, yn, ys]
-  if (kk >= 2 && kk <= kmt) {       // top half: the vertical difference to the level above, with this level's expansion coefficients (share :383-400)
-    double rz = drdt * (temp(o - n2) - temp(o)) + drds * (S[o - n2] - S[o]);
-    rz = fmin(rz, -1.0e-20);
-    sl[0][0] = rxe / rz; sl[0][1] = rxw / rz; sl[0][2] = ryn / rz; sl[0][3] = rys / rz;
-  }
-  if (kk < km) {                    // bottom half: the difference to the level below (share :278-291)
-    double rz = drdt * (temp(o) - temp(o + n2)) + drds * (S[o] - S[o + n2]);
-    rz = fmin(rz, -1.0e-20);
-    const double mk = (kk < kmt) ? 1.0 : 0.0;
-    sl[1][0] = mk * rxe / rz; sl[1][1] = mk * rxw / rz; sl[1][2] = mk * ryn / rz; sl[1][3] = mk * rys / rz;
+  if (MODE != 2) {
+    // Straight-line (round 4): every neighbour is read at a clamped, always valid index and the conditions select values, so the loads of a
+    // cell are requested together (with the loads inside `if (i >= 1)` ... each was a round trip of its own).  Same values, same operations.
+    const bool he = i <= nxb - 2, hw = i >= 1, hn = j <= nyb - 2, hs = j >= 1;
+    const long long de = he ? 1 : 0, dw = hw ? 1 : 0, dn = hn ? nxb : 0, ds = hs ? nxb : 0;
+    const int ke = g.KMT[q + de], kw = g.KMT[q - dw], kn = g.KMT[q + dn], ks = g.KMT[q - ds];
+    const double tc = temp(o), sc = S[o];
+    const double te = temp(o + de), tw = temp(o - dw), tn = temp(o + dn), ts = temp(o - ds);
+    const double se = S[o + de], sw = S[o - dw], sn = S[o + dn], ss = S[o - ds];
+    const long long dup = (kk >= 2) ? n2 : 0, ddn = (kk < km) ? n2 : 0;
+    const double tu = temp(o - dup), su = S[o - dup], tb = temp(o + ddn), sb = S[o + ddn];
+    // horizontal differences of level kk on the east / north face of this cell and of its west / south neighbour
+    const double mke = ((kk <= kmt) & (kk <= ke)) ? 1.0 : 0.0, mkw = ((kk <= kw) & (kk <= kmt)) ? 1.0 : 0.0;
+    const double mkn = ((kk <= kmt) & (kk <= kn)) ? 1.0 : 0.0, mks = ((kk <= ks) & (kk <= kmt)) ? 1.0 : 0.0;
+    const double txp_e = he ? mke * (te - tc) : 0.0, txs_e = he ? mke * (se - sc) : 0.0;
+    const double txp_w = hw ? mkw * (tc - tw) : 0.0, txs_w = hw ? mkw * (sc - sw) : 0.0;
+    const double typ_n = hn ? mkn * (tn - tc) : 0.0, tys_n = hn ? mkn * (sn - sc) : 0.0;
+    const double typ_s = hs ? mks * (tc - ts) : 0.0, tys_s = hs ? mks * (sc - ss) : 0.0;
+    double drdt, drds;
+    const MwjfP P = mwjf_level(g.pressz[kk]);
+    mwjf_rho<true>(P, T[o], S[o], &drdt, &drds);
+    const double rxe = drdt * txp_e + drds * txs_e, rxw = hw ? drdt * txp_w + drds * txs_w : 0.0;
+    const double ryn = drdt * typ_n + drds * tys_n, rys = hs ? drdt * typ_s + drds * tys_s : 0.0;
+    {                                 // top half: the vertical difference to the level above, with this level's expansion coefficients (share :383-400)
+      double rz = drdt * (tu - tc) + drds * (su - sc);
+      rz = fmin(rz, -1.0e-20);
+      if (kk >= 2 && kk <= kmt) { sl[0][0] = rxe / rz; sl[0][1] = rxw / rz; sl[0][2] = ryn / rz; sl[0][3] = rys / rz; }
+    }
+    {                                 // bottom half: the difference to the level below (share :278-291)
+      double rz = drdt * (tc - tb) + drds * (sc - sb);
+      rz = fmin(rz, -1.0e-20);
+      const double mk = (kk < kmt) ? 1.0 : 0.0;
+      if (kk < km) { sl[1][0] = mk * rxe / rz; sl[1][1] = mk * rxw / rz; sl[1][2] = mk * ryn / rz; sl[1][3] = mk * rys / rz; }
+    }
+  } else {
+    // MODE 2 follows MODE 1 on the same tracers: the slopes MODE 1 stored (unclipped) are the ones this launch would form again
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) { sl[s2][0] = w.SLX[0 + s2][o]; sl[s2][1] = w.SLX[2 + s2][o]; sl[s2][2] = w.SLY[0 + s2][o]; sl[s2][3] = w.SLY[2 + s2][o]; }
   }
   const double dxt = w.DXT[q], dyt = w.DYT[q], rbr = w.RBR[q];
   const double bl = w.HBLT ? w.HBLT[q] : g.zw[1];
@@ -144,7 +159,8 @@ k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__re
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int kid = kk + s - 1;
-    const double sla = g.dzw[kid] * sqrt(0.5 * ((sl[s][0] * sl[s][0] + sl[s][1] * sl[s][1]) / (dxt * dxt) + (sl[s][2] * sl[s][2] + sl[s][3] * sl[s][3]) / (dyt * dyt))) + 1.0e-10;
+    const double sla = (MODE == 2) ? w.SLA[s][o]      // (stored by MODE 1: the same expression of the same slopes)
+                                   : g.dzw[kid] * sqrt(0.5 * ((sl[s][0] * sl[s][0] + sl[s][1] * sl[s][1]) / (dxt * dxt) + (sl[s][2] * sl[s][2] + sl[s][3] * sl[s][3]) / (dyt * dyt))) + 1.0e-10;
     if (MODE == 1) {
       w.SLA[s][o] = sla;
       w.SLX[0 + s][o] = sl[s][0]; w.SLX[2 + s][o] = sl[s][1]; w.SLY[0 + s][o] = sl[s][2]; w.SLY[2 + s][o] = sl[s][3];
@@ -181,7 +197,9 @@ k_gm_coeffs(DevGrid g, GmDev w, const double *__restrict__ T, const double *__re
     }
     if (w.ah_bkg_bottom != 0.0 && s == 1 && kk == kmt) hd = w.ah_bkg_bottom;   // :1757-1761 (at the level's turn, after everything above)
     w.KI[s][o] = ki; w.KT[s][o] = kt; w.HD[s][o] = hd;
-    w.SLX[0 + s][o] = sl[s][0]; w.SLX[2 + s][o] = sl[s][1]; w.SLY[0 + s][o] = sl[s][2]; w.SLY[2 + s][o] = sl[s][3];
+    if (MODE != 2 || w.slope_ctl == 2) {   // (MODE 2 without clipping: the stored slopes are already these)
+      w.SLX[0 + s][o] = sl[s][0]; w.SLX[2 + s][o] = sl[s][1]; w.SLY[0 + s][o] = sl[s][2]; w.SLY[2 + s][o] = sl[s][3];
+    }
   }
 }
 
@@ -466,6 +484,189 @@ k_gm_flux(DevGrid g, GmDev w, const double *__restrict__ X0, const double *__res
       }
     }
     w.GTK[0][o] = gt.a; w.GTK[1][o] = gt.b;
+  }
+}
+
+// ---- the flux functions once more, straight-line (round 4) ---------------------------------------------------------------------------
+// gm_fx / gm_fy / gm_fz above guard loads with conditions (`kk >= 2 ? X[o - n2] ...`, `a && b` on two loaded values, the stored / re-derived
+// choice of SF inside gm_sf): 522 loads behind 494 waits and 420 branches in k_gm_flux, every load a round trip of its own -- the kernel
+// took 1.6 ms for 2 GB at gx1v7.  Here every load is unconditional at a clamped (always valid) address and conditions select VALUES, the
+// two uniform choices (cancellation of the skew terms, SF stored by k_gm_sf) are template parameters.  Per value the same operations in the
+// same order as above (tests/test_gpu_gm.py::test_gm_flux_tile_is_bitwise_the_cell_kernel compares the two sets bit for bit).
+__device__ __forceinline__ double gmb_mask(int kk, int ka, int kb) { return ((kk <= ka) & (kk <= kb)) ? 1.0 : 0.0; }
+__device__ __forceinline__ double gmb_tz(const double *__restrict__ X, int kk, long long o, long long n2) {
+  const double d = X[o - (kk >= 2 ? n2 : 0)] - X[o];
+  return (kk >= 2) ? d : 0.0;
+}
+// east-face flux of cell q (needs i <= nxb - 2)
+template <bool CANCEL>
+__device__ __forceinline__ Gm2 gmb_fx(const DevGrid &g, const GmDev &w, const double *__restrict__ X0, const double *__restrict__ X1, int k, long long q, long long o) {
+  const long long n2 = g.n2;
+  const int ka = g.KMT[q], kb = g.KMT[q + 1];
+  const double hyx = w.HYX[q];
+  const double cx = ((k <= ka) & (k <= kb)) ? hyx * 0.25 : 0.0;
+  const double ki0 = w.KI[0][o], ki1 = w.KI[1][o], ki0e = w.KI[0][o + 1], ki1e = w.KI[1][o + 1];
+  const double work3 = ki0 + w.HD[0][o] + ki1 + w.HD[1][o] + ki0e + w.HD[0][o + 1] + ki1e + w.HD[1][o + 1];
+  const double m = gmb_mask(k, ka, kb), dz = g.dz[k];
+  const double tx0 = m * (X0[o + 1] - X0[o]), tx1 = m * (X1[o + 1] - X1[o]);
+  Gm2 f = {dz * cx * tx0 * work3, dz * cx * tx1 * work3};
+  if (!CANCEL) {
+    const int kp1 = (k == g.km) ? k : k + 1;
+    const long long okp = o + (long long)(kp1 - k) * n2;
+    const double w1 = ki0 * w.SLX[0][o] * dz - w.SF[0][o];              // SF[4 xy + 2 face + half]
+    const double w2 = ki1 * w.SLX[1][o] * dz - w.SF[1][o];
+    const double w3 = ki0e * w.SLX[2][o + 1] * dz - w.SF[2][o + 1];
+    const double w4 = ki1e * w.SLX[3][o + 1] * dz - w.SF[3][o + 1];
+    f.a = f.a - cx * (w1 * gmb_tz(X0, k, o, n2) + w2 * gmb_tz(X0, kp1, okp, n2) + w3 * gmb_tz(X0, k, o + 1, n2) + w4 * gmb_tz(X0, kp1, okp + 1, n2));
+    f.b = f.b - cx * (w1 * gmb_tz(X1, k, o, n2) + w2 * gmb_tz(X1, kp1, okp, n2) + w3 * gmb_tz(X1, k, o + 1, n2) + w4 * gmb_tz(X1, kp1, okp + 1, n2));
+  }
+  return f;
+}
+// north-face flux of cell q (needs j <= nyb - 2)
+template <bool CANCEL>
+__device__ __forceinline__ Gm2 gmb_fy(const DevGrid &g, const GmDev &w, const double *__restrict__ X0, const double *__restrict__ X1, int k, long long q, long long o) {
+  const long long n2 = g.n2;
+  const int nxb = g.nxb;
+  const int ka = g.KMT[q], kb = g.KMT[q + nxb];
+  const double hxy = w.HXY[q];
+  const double cy = ((k <= ka) & (k <= kb)) ? hxy * 0.25 : 0.0;
+  const double ki0 = w.KI[0][o], ki1 = w.KI[1][o], ki0n = w.KI[0][o + nxb], ki1n = w.KI[1][o + nxb];
+  const double work4 = ki0 + w.HD[0][o] + ki1 + w.HD[1][o] + ki0n + w.HD[0][o + nxb] + ki1n + w.HD[1][o + nxb];
+  const double m = gmb_mask(k, ka, kb), dz = g.dz[k];
+  const double ty0 = m * (X0[o + nxb] - X0[o]), ty1 = m * (X1[o + nxb] - X1[o]);
+  Gm2 f = {dz * cy * ty0 * work4, dz * cy * ty1 * work4};
+  if (!CANCEL) {
+    const int kp1 = (k == g.km) ? k : k + 1;
+    const long long okp = o + (long long)(kp1 - k) * n2;
+    const double w1 = ki0 * w.SLY[0][o] * dz - w.SF[4][o];
+    const double w2 = ki1 * w.SLY[1][o] * dz - w.SF[5][o];
+    const double w3 = ki0n * w.SLY[2][o + nxb] * dz - w.SF[6][o + nxb];
+    const double w4 = ki1n * w.SLY[3][o + nxb] * dz - w.SF[7][o + nxb];
+    f.a = f.a - cy * (w1 * gmb_tz(X0, k, o, n2) + w2 * gmb_tz(X0, kp1, okp, n2) + w3 * gmb_tz(X0, k, o + nxb, n2) + w4 * gmb_tz(X0, kp1, okp + nxb, n2));
+    f.b = f.b - cy * (w1 * gmb_tz(X1, k, o, n2) + w2 * gmb_tz(X1, kp1, okp, n2) + w3 * gmb_tz(X1, k, o + nxb, n2) + w4 * gmb_tz(X1, kp1, okp + nxb, n2));
+  }
+  return f;
+}
+// flux through the bottom face of level k < km of a PHYSICAL cell q (its west and south neighbours exist)
+template <bool CANCEL>
+__device__ __forceinline__ Gm2 gmb_fz(const DevGrid &g, const GmDev &w, const double *__restrict__ X0, const double *__restrict__ X1, int k, long long q, long long o) {
+  const int nxb = g.nxb, kp1 = k + 1;
+  const long long okp = o + g.n2;
+  const int kc = g.KMT[q], ke = g.KMT[q + 1], kn = g.KMT[q + nxb], kw = g.KMT[q - 1], ks = g.KMT[q - nxb];
+  const double kmask = (k < kc) ? 1.0 : 0.0;
+  const double hyx = w.HYX[q], hxy = w.HXY[q], hyxw = w.HYX[q - 1], hxys = w.HXY[q - nxb];
+  // masked horizontal differences of both tracers at level k and k + 1: east, north, west, south (gm_tx / gm_ty)
+  const double me = gmb_mask(k, kc, ke), mn = gmb_mask(k, kc, kn), mw = gmb_mask(k, kw, kc), ms = gmb_mask(k, ks, kc);
+  const double pe = gmb_mask(kp1, kc, ke), pn = gmb_mask(kp1, kc, kn), pw = gmb_mask(kp1, kw, kc), ps = gmb_mask(kp1, ks, kc);
+  const double sb[4] = {w.SLX[1][o], w.SLY[1][o], w.SLX[3][o], w.SLY[3][o]};           // bottom half of level k: east, north, west, south
+  const double st[4] = {w.SLX[0][okp], w.SLY[0][okp], w.SLX[2][okp], w.SLY[2][okp]};   // top half of level k + 1
+  const double cb = g.dz[k] * w.KI[1][o], ct = g.dz[kp1] * w.KI[0][okp];
+  double fb[4] = {0.0, 0.0, 0.0, 0.0}, ft[4] = {0.0, 0.0, 0.0, 0.0};
+  if (!CANCEL) {
+    fb[0] = w.SF[1][o]; fb[1] = w.SF[5][o]; fb[2] = w.SF[3][o]; fb[3] = w.SF[7][o];
+    ft[0] = w.SF[0][okp]; ft[1] = w.SF[4][okp]; ft[2] = w.SF[2][okp]; ft[3] = w.SF[6][okp];
+  }
+  auto one = [&](const double *__restrict__ X) {
+    const double xc = X[o], xp = X[okp];
+    const double de = me * (X[o + 1] - xc), dn = mn * (X[o + nxb] - xc), dw = mw * (xc - X[o - 1]), ds = ms * (xc - X[o - nxb]);
+    const double qe = pe * (X[okp + 1] - xp), qn = pn * (X[okp + nxb] - xp), qw = pw * (xp - X[okp - 1]), qs = ps * (xp - X[okp - nxb]);
+    auto faces = [&](double ce, double cn, double cw, double cs, double e, double n, double w_, double s_) {
+      return ce * hyx * e + cn * hxy * n + cw * hyxw * w_ + cs * hxys * s_;
+    };
+    if (!CANCEL) {
+      double w3 = 0.0;
+      w3 = w3 + (cb * faces(sb[0], sb[1], sb[2], sb[3], de, dn, dw, ds));
+      w3 = w3 + faces(fb[0], fb[1], fb[2], fb[3], de, dn, dw, ds);
+      w3 = w3 + (ct * faces(st[0], st[1], st[2], st[3], qe, qn, qw, qs));
+      w3 = w3 + (1.0 * faces(ft[0], ft[1], ft[2], ft[3], qe, qn, qw, qs));
+      return -kmask * 0.25 * w3;
+    }
+    double w3 = (cb * faces(sb[0], sb[1], sb[2], sb[3], de, dn, dw, ds));
+    w3 = w3 + (ct * faces(st[0], st[1], st[2], st[3], qe, qn, qw, qs));
+    return -kmask * 0.5 * w3;
+  };
+  Gm2 r;
+  r.a = one(X0); r.b = one(X1);
+  return r;
+}
+
+// k_gm_flux with the straight-line flux functions and every horizontal face flux formed ONCE (round 4).  A workgroup owns a 64 x R
+// patch of the block of which it COMPUTES the tendency on the 63 x (R - 1) cells right of its first column and above its first row: a
+// thread forms the east and the north flux of its own cell, takes the west flux from the lane to its left (a wave is one patch row: DPP
+// shuffle) and the south flux from the row below through LDS; the first column and the first row only supply those fluxes, so no lane
+// evaluates a second flux and no wave diverges (a first form let lane 0 / row 0 evaluate their neighbour's flux themselves: the whole
+// wave waited for it, slower than k_gm_flux).  The isopycnal part of VDC is added by the thread that computes the cell.
+template <int R, bool CANCEL>
+__global__ void __launch_bounds__(64 * R)
+k_gm_flux_tile(DevGrid g, GmDev w, const double *__restrict__ X0, const double *__restrict__ X1, double *__restrict__ VDC0, double *__restrict__ VDC1) {
+  __shared__ double fy_a[2][R][64], fy_b[2][R][64];
+  const int nxb = g.nxb, nyb = g.nyb, km = g.km;
+  const int tiles_i = (nxb + 62) / 63;
+  const int ti = blockIdx.x % tiles_i, tj = blockIdx.x / tiles_i;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int i = ti * 63 - 1 + tx, j = tj * (R - 1) - 1 + ty;              // the first column / row of the patch belongs to the neighbour
+  const int k0 = blockIdx.y * POP_GM_KC + 1, b = blockIdx.z;
+  const bool inb = i >= 0 && i < nxb && j >= 0 && j < nyb;
+  const bool own = inb && tx >= 1 && ty >= 1;                             // this thread computes the cell
+  const int p2 = inb ? j * nxb + i : 0;
+  const long long n2 = g.n2, q = (long long)b * n2 + p2;
+  const bool phys = own && i + 1 >= g.ib && i + 1 <= blk_ie(g, b) && j + 1 >= g.jb && j + 1 <= blk_je(g, b);
+  const bool has_e = inb && i <= nxb - 2, has_n = inb && j <= nyb - 2;
+  // lanes whose face does not exist evaluate the flux of a cell where it does (clamped index) and discard it: no divergent block around the loads
+  const int pe2 = has_e ? p2 : 0, pn2 = has_n ? p2 : 0;
+  const long long qe_ = (long long)b * n2 + pe2, qn_ = (long long)b * n2 + pn2;
+  const long long qz = phys ? q : (long long)b * n2 + (long long)(g.jb - 1) * nxb + (g.ib - 1);   // a physical cell for the lanes that compute no tendency
+  const int pz2 = (int)(qz - (long long)b * n2);
+  const double hyx = w.HYX[q], hxy = w.HXY[q], hyxw = w.HYX[q - ((inb && i >= 1) ? 1 : 0)], hxys = w.HXY[q - ((inb && j >= 1) ? nxb : 0)];
+  const double hyxw_ = (inb && i >= 1) ? hyxw : 0.0, hxys_ = (inb && j >= 1) ? hxys : 0.0;
+  const double tar = g.TAREA_R[q];
+  const int kmt = g.KMT[q];
+  Gm2 fztop = {0.0, 0.0};
+  if (k0 >= 2) {
+    const Gm2 t = gmb_fz<CANCEL>(g, w, X0, X1, k0 - 1, qz, (long long)b * g.n3 + (long long)(k0 - 2) * n2 + pz2);
+    if (phys) fztop = t;
+  }
+  for (int k = k0; k < k0 + POP_GM_KC && k <= km; ++k) {
+    const long long lev = (long long)b * g.n3 + (long long)(k - 1) * n2;
+    const long long o = lev + p2;
+    const int buf = k & 1;
+    {
+      const int kq = (k < km) ? k : km - 1;                               // (k = km: computed at the level above and discarded)
+      const long long oq = (long long)b * g.n3 + (long long)(kq - 1) * n2 + p2, ok = oq + n2;
+      const double kmask = (kq < kmt) ? 1.0 : 0.0;
+      auto sq = [](double x) { return x * x; };
+      const double add = g.dzw[kq] * kmask * tar *
+        (g.dz[kq] * 0.25 * w.KI[1][oq] * (hyx * sq(w.SLX[1][oq]) + hyxw_ * sq(w.SLX[3][oq]) + hxy * sq(w.SLY[1][oq]) + hxys_ * sq(w.SLY[3][oq])) +
+         g.dz[kq + 1] * 0.25 * w.KI[0][ok] * (hyx * sq(w.SLX[0][ok]) + hyxw_ * sq(w.SLX[2][ok]) + hxy * sq(w.SLY[0][ok]) + hxys_ * sq(w.SLY[2][ok])));
+      if (own && k < km) {
+        const long long v = ((long long)b * (km + 2) + k) * n2 + p2;
+        VDC0[v] = VDC0[v] + add;
+        if (VDC1) VDC1[v] = VDC1[v] + add;
+      }
+    }
+    Gm2 fxe = gmb_fx<CANCEL>(g, w, X0, X1, k, qe_, lev + pe2);
+    Gm2 fyn = gmb_fy<CANCEL>(g, w, X0, X1, k, qn_, lev + pn2);
+    if (!has_e) { fxe.a = 0.0; fxe.b = 0.0; }
+    if (!has_n) { fyn.a = 0.0; fyn.b = 0.0; }
+    fy_a[buf][ty][tx] = fyn.a; fy_b[buf][ty][tx] = fyn.b;
+    const Gm2 fxw = {__shfl_up(fxe.a, 1), __shfl_up(fxe.b, 1)};
+    const int kz = (k < km) ? k : km - 1;
+    const Gm2 fzr = gmb_fz<CANCEL>(g, w, X0, X1, kz, qz, (long long)b * g.n3 + (long long)(kz - 1) * n2 + pz2);
+    __syncthreads();                                         // (the buffer of level k - 1 is free again: everybody has passed this barrier since)
+    Gm2 gt = {0.0, 0.0};
+    if (phys) {
+      const Gm2 fys = {fy_a[buf][ty - 1][tx], fy_b[buf][ty - 1][tx]};
+      const double sc = g.dzr[k];
+      if (k < km) {
+        gt.a = (fxe.a - fxw.a + fyn.a - fys.a + fztop.a - fzr.a) * sc * tar;
+        gt.b = (fxe.b - fxw.b + fyn.b - fys.b + fztop.b - fzr.b) * sc * tar;
+        fztop = fzr;
+      } else {
+        gt.a = (fxe.a - fxw.a + fyn.a - fys.a + fztop.a) * sc * tar;
+        gt.b = (fxe.b - fxw.b + fyn.b - fys.b + fztop.b) * sc * tar;
+      }
+    }
+    if (own) { w.GTK[0][o] = gt.a; w.GTK[1][o] = gt.b; }
   }
 }
 

@@ -29,7 +29,9 @@ struct TrcTile {
 // passes per tracer less than right-hand side + k_impvmixt; the same operations in the same order (bitwise equal, tested).
 // PBC: partial bottom cells (advection.F90:2040-2062, 2110, 2223-2294; hmix_del2.F90:1034-1051 / hmix_del4.F90:964-984;
 // vertical_mix.F90:790-807, 1279-1287; sw_absorption.F90:880-921).
-template <int R, bool FWD = false, bool PBC = false>
+// HDIN (round 4): the horizontal mixing tendency of both tracers is given (TracerRhsArgs::HDT: Gent-McWilliams, formed by phase_hmix_gm) and read in
+// place of the del2 operator on the staged mix-time tracers, which are then neither loaded nor staged -- k_tracer_rhs<DEL4 = true>'s `FT = HDT`
+template <int R, bool FWD = false, bool PBC = false, bool HDIN = false>
 __global__ void __launch_bounds__(POP_COL_THREADS * R, POP_TRC_WAVES)
 k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
   using T = TrcTile<R, PBC>;
@@ -101,7 +103,7 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
     L.u = a.UCUR[o]; L.v = a.VCUR[o];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-      L.tc[n] = a.TCUR[n][o]; L.tm[n] = a.TMIX[n][o]; L.to[n] = a.TOLD[n][o];
+      L.tc[n] = a.TCUR[n][o]; L.tm[n] = (HDIN ? a.HDT[n] : a.TMIX[n])[o]; L.to[n] = a.TOLD[n][o];
       L.vdc[n] = a.VDC[n][vdcbase + (long long)k * n2];
     }
     const bool rd = k <= ksrc;
@@ -113,7 +115,7 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
     const long long o = hbase + (long long)(k - 1) * n2;
     Hh.u = a.UCUR[o]; Hh.v = a.VCUR[o];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) { Hh.tc[n] = a.TCUR[n][o]; Hh.tm[n] = a.TMIX[n][o]; }
+    for (int n = 0; n < 2; ++n) { Hh.tc[n] = a.TCUR[n][o]; Hh.tm[n] = HDIN ? 0.0 : a.TMIX[n][o]; }
     return Hh;
   };
   // outputs: the field for physical columns, the dump area for the other lanes
@@ -152,8 +154,8 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
       t.ud[buf][hl] = hu; t.vd[buf][hl] = hv;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        t.tc[buf][n][lc] = cur.tc[n]; t.tm[buf][n][lc] = cur.tm[n];
-        t.tc[buf][n][hl] = hal.tc[n]; t.tm[buf][n][hl] = hal.tm[n];
+        t.tc[buf][n][lc] = cur.tc[n]; t.tc[buf][n][hl] = hal.tc[n];
+        if (!HDIN) { t.tm[buf][n][lc] = cur.tm[n]; t.tm[buf][n][hl] = hal.tm[n]; }
       }
     }
     const int kp1 = (k < km) ? k + 1 : km;
@@ -187,7 +189,7 @@ k_tracer_rhs_lds(DevGrid g, StepParams sp, TracerRhsArgs a) {
       for (int n = 0; n < 2; ++n) {
         const double *TM = t.tm[buf][n], *TC = t.tc[buf][n];
         const double tc_k = cur.tc[n], tc_kp1 = nxt.tc[n], to_k = cur.to[n], to_kp1 = nxt.to[n];
-        double FT = sp.ah * (CC * TM[lc] + CN * TM[lc + T::W] + CS * TM[lc - T::W] + CE * TM[lc + 1] + CW * TM[lc - 1]);
+        double FT = HDIN ? cur.tm[n] : sp.ah * (CC * TM[lc] + CN * TM[lc + T::W] + CS * TM[lc - T::W] + CE * TM[lc + 1] + CW * TM[lc - 1]);
         // hdifft_del4's first Laplacian of the current tracers, for the next step (same expression as k_del4_d2t); to the dump area
         // when it is not formed
         (n == 0 ? D0p : D1p)[d2n ? oo : 0] = ahf_next * (CC * TC[lc] + CN * TC[lc + T::W] + CS * TC[lc - T::W] + CE * TC[lc + 1] + CW * TC[lc - 1]);
@@ -265,6 +267,9 @@ inline void launch_tracer_lds(const DevGrid &g, const StepParams &sp, const Trac
   if (g.pbc) {
     if (fwd) hipLaunchKernelGGL((k_tracer_rhs_lds<R, true, true>), G, B, 0, st, g, sp, a);
     else hipLaunchKernelGGL((k_tracer_rhs_lds<R, false, true>), G, B, 0, st, g, sp, a);
+  } else if (a.HDT[0]) {   // the mixing tendency given (Gent-McWilliams; not with partial bottom cells: refused at create)
+    if (fwd) hipLaunchKernelGGL((k_tracer_rhs_lds<R, true, false, true>), G, B, 0, st, g, sp, a);
+    else hipLaunchKernelGGL((k_tracer_rhs_lds<R, false, false, true>), G, B, 0, st, g, sp, a);
   } else if (fwd) hipLaunchKernelGGL((k_tracer_rhs_lds<R, true, false>), G, B, 0, st, g, sp, a);
   else hipLaunchKernelGGL((k_tracer_rhs_lds<R, false, false>), G, B, 0, st, g, sp, a);
 }

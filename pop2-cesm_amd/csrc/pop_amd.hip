@@ -81,7 +81,7 @@ struct pop_ctx {
   bool vdc_shared = false;
   bool kpp_src_user = false;   // the caller wrote KPP_SRC (pop_set_field): read it at every level until KPP has run again
   bool src_dirty = true, src_dirty_alt = true;   // KPP_SRC / KPPa may hold non-zeros below the KBL stored with them: the next evaluation into that set clears every level
-  double *VDCa[2] = {nullptr, nullptr}, *VVCa = nullptr, *KPPa[MAXNT] = {}, *HBLTa = nullptr;
+  double *VDCa[2] = {nullptr, nullptr}, *VVCa = nullptr, *KPPa[MAXNT] = {}, *HBLTa = nullptr, *HMXLa = nullptr, *HMXL_DRa = nullptr;
   int *KBL = nullptr, *KBLa = nullptr;   // KBL that belongs to KPP_SRC / KPPa (the tracer kernel reads KPP_SRC down to it)
   hipStream_t ahead = nullptr; hipEvent_t ev_ahead_fork = nullptr, ev_ahead = nullptr;
   bool ahead_enabled = false, ahead_valid = false; int ahead_slot = -1;
@@ -1439,7 +1439,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED") X(pcg_persist, "POP_PCG_PERSIST")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED") X(pcg_persist, "POP_PCG_PERSIST") X(gm_flux_tile, "POP_GM_FLUX_TILE")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -2058,15 +2058,21 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     HIPCHK(c, hipMemcpy(c->CHL, chl.data(), chl.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   // KPP look-ahead (bandwidth-bound grids; POP_KPP_AHEAD=0|1 overrides): second set of KPP outputs, own stream
-  c->ahead_enabled = cfg->vmix_choice == 3 && c->side && (h.n2 * h.nblocks > (1u << 19));
+  // ... and (round 4) small grids whose pcg solve is the one resident launch: that launch keeps at most one workgroup per CU busy waiting
+  // on memory for 2 ms, the KPP kernels of the next step fill the rest (gx1v7: 3.26 -> 3.09, 3.36 -> 3.18 ms per step, A/B on one box)
+  const bool resident_solve = cfg->solver_choice == 1 && !use_evp(*cfg) && !tun_off(h.tun.pcg_persist) && h.nranks == 1 && h.nblocks <= 8 &&
+                              h.n2 * h.nblocks <= 250u * 8u * 256u;
+  c->ahead_enabled = cfg->vmix_choice == 3 && c->side && (h.n2 * h.nblocks > (1u << 19) || resident_solve);
   if (tun_set(h.tun.kpp_ahead)) c->ahead_enabled = cfg->vmix_choice == 3 && c->side && h.tun.kpp_ahead != 0;
-  if (cfg->hmix_tracer == 3) c->ahead_enabled = false;   // Gent-McWilliams adds to VDC after vmix_coeffs: the coefficients are formed in line
+  // (Gent-McWilliams adds its isopycnal part to VDC after vmix_coeffs -- to the arrays swapped in, at the step they belong to; with the
+  // mixed-layer-depth diagnostics the look-ahead writes a second pair HMXL / HMXL_DR that is swapped in with the rest)
   if (c->ahead_enabled) {
     for (int n = 0; n < 2; ++n) if (dev_alloc(c, &c->KPPa[n], a3)) return 1;
     if (dev_alloc(c, &c->VDCa[0], (size_t)(h.km + 2) * a2)) return 1;
     if (c->vdc_shared) c->VDCa[1] = c->VDCa[0];
     else if (dev_alloc(c, &c->VDCa[1], (size_t)(h.km + 2) * a2)) return 1;
     if (dev_alloc(c, &c->VVCa, a3) || dev_alloc(c, &c->HBLTa, a2) || dev_alloc(c, &c->KBLa, a2)) return 1;
+    if (c->h.c.kpp_ml_diagnostics == 1 && (dev_alloc(c, &c->HMXLa, a2) || dev_alloc(c, &c->HMXL_DRa, a2))) return 1;
     if (c->prio_on) HIPCHK(c, hipStreamCreateWithPriority(&c->ahead, hipStreamNonBlocking, c->prio_least));
     else HIPCHK(c, hipStreamCreateWithFlags(&c->ahead, hipStreamNonBlocking));
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_ahead_fork, hipEventDisableTiming));
@@ -2481,7 +2487,8 @@ static MixState kpp_mix_state(pop_ctx *c, int slot, bool into_alt) {
     ms.KPP_SRC[n] = into_alt ? c->KPPa[n] : c->KPP_SRC[n]; ms.VDC[n] = into_alt ? c->VDCa[n] : c->VDC[n];
   }
   ms.UMIX = c->U[slot]; ms.VMIX = c->V[slot]; ms.UCUR = c->U[c->curt]; ms.VCUR = c->V[c->curt]; ms.RHOMIX = c->RHO[slot];
-  ms.VVC = into_alt ? c->VVCa : c->VVC; ms.SHF_QSW = c->SHF_QSW; ms.HBLT = into_alt ? c->HBLTa : c->HBLT; ms.HMXL = c->HMXL; ms.HMXL_DR = c->HMXL_DR;
+  ms.VVC = into_alt ? c->VVCa : c->VVC; ms.SHF_QSW = c->SHF_QSW; ms.HBLT = into_alt ? c->HBLTa : c->HBLT;
+  ms.HMXL = (into_alt && c->HMXLa) ? c->HMXLa : c->HMXL; ms.HMXL_DR = (into_alt && c->HMXL_DRa) ? c->HMXL_DRa : c->HMXL_DR;
   ms.KBL = into_alt ? c->KBLa : c->KBL;
   ms.src_clear_all = (into_alt ? c->src_dirty_alt : c->src_dirty) ? 1 : 0;
   (into_alt ? c->src_dirty_alt : c->src_dirty) = false;   // the evaluation that follows clears the set
@@ -2499,6 +2506,7 @@ static int phase_vmix(pop_ctx *c) {
       c->ahead_valid = false; c->kpp_src_user = false;
       for (int n = 0; n < 2; ++n) { std::swap(c->VDC[n], c->VDCa[n]); std::swap(c->KPP_SRC[n], c->KPPa[n]); }
       std::swap(c->VVC, c->VVCa); std::swap(c->HBLT, c->HBLTa); std::swap(c->KBL, c->KBLa); std::swap(c->src_dirty, c->src_dirty_alt);
+      if (c->HMXLa) { std::swap(c->HMXL, c->HMXLa); std::swap(c->HMXL_DR, c->HMXL_DRa); }
       return 0;
     }
     if (ahead_cancel(c)) return 1;
@@ -2514,8 +2522,8 @@ static int phase_vmix(pop_ctx *c) {
 // next step; outputs: the second set of VDC / VVC / KPP_SRC / HBLT.
 static int kpp_look_ahead(pop_ctx *c) {
   // an averaging step rewrites oldtime and curtime in its tail and does not rotate; the Robert filter rewrites curtime
-  // (with the mixed-layer-depth diagnostics on, HMXL / HMXL_DR must belong to the step that just ran: no look-ahead)
-  if (!c->ahead_enabled || c->h.c.vmix_choice != 3 || c->avg_ts || c->h.c.tmix_opt == 3 || c->h.c.kpp_ml_diagnostics == 1) return 0;
+  // (with the mixed-layer-depth diagnostics on, HMXL / HMXL_DR of the step that just ran stay where they are: the look-ahead writes the second pair)
+  if (!c->ahead_enabled || c->h.c.vmix_choice != 3 || c->avg_ts || c->h.c.tmix_opt == 3 || (c->h.c.kpp_ml_diagnostics == 1 && !c->HMXLa)) return 0;
   HIPCHK(c, hipEventRecord(c->ev_ahead_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->ahead, c->ev_ahead_fork, 0));
   const MixState ms = kpp_mix_state(c, c->curt, true);
@@ -2549,6 +2557,19 @@ static int phase_hmix_gm(pop_ctx *c) {
   double *v1 = (sp.nvdc == 2 && c->VDC[1] != c->VDC[0]) ? c->VDC[1] : nullptr;   // one shared array is added to once
   if (G.SF[0]) hipLaunchKernelGGL(k_gm_sf, G3, dim3(256), 0, c->stream, c->g, G);   // without cancellation: SF_SLX, SF_SLY once per half cell
   if (G.UISOP) hipLaunchKernelGGL(k_gm_bolus, G2, dim3(256), 0, c->stream, c->g, G);   // diag_gm_bolus
+  if (!tun_off(c->h.tun.gm_flux_tile) && (G.cancellation || G.SF[0])) {
+    // straight-line flux functions, every horizontal face flux formed once (64 x 4 patches computing 63 x 3 cells); pop_tuning.gm_flux_tile = 0,
+    // or the stream-function terms not stored (gm_sf_stored = 0): the cell-by-cell kernel
+    const int R = (c->h.tun.gm_flux_tile == 4) ? 4 : 8;     // rows of the patch: 64 x 8 computing 63 x 7 cells (gm_flux_tile = 4: 64 x 4, measured 2 % of the step slower)
+    const dim3 GT(((c->g.nxb + 62) / 63) * ((c->g.nyb + R - 2) / (R - 1)), (c->g.km + POP_GM_KC - 1) / POP_GM_KC, G3.z);
+    if (R == 8) {
+      if (G.cancellation) hipLaunchKernelGGL((k_gm_flux_tile<8, true>), GT, dim3(64, 8), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
+      else hipLaunchKernelGGL((k_gm_flux_tile<8, false>), GT, dim3(64, 8), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
+    } else {
+      if (G.cancellation) hipLaunchKernelGGL((k_gm_flux_tile<4, true>), GT, dim3(64, 4), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
+      else hipLaunchKernelGGL((k_gm_flux_tile<4, false>), GT, dim3(64, 4), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
+    }
+  } else
   hipLaunchKernelGGL(k_gm_flux, dim3(G3.x, (c->g.km + POP_GM_KC - 1) / POP_GM_KC, G3.z), dim3(256), 0, c->stream, c->g, G, T, S, c->VDC[0], v1);
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -2610,8 +2631,11 @@ static int phase_tracer_rhs(pop_ctx *c, bool fwd = false) {
   }
   // the next step's first Laplacian: valid when that step is a leapfrog step whose mix time is this step's current time and nothing
   // rewrites the current tracers before then (no averaging step, no Robert filter) -- the rule of the KPP look-ahead
-  const bool lds_kernel = c->h.c.tadvect == 1 && c->h.c.hmix_tracer != 3 && (c->trc_lds_rows == 8 || c->trc_lds_rows == 4);
-  const bool form_next = lds_kernel && c->d2t_next[0] && !c->avg_ts && c->h.c.tmix_opt != 3 && c->tr_ghosts_ok[c->curt];
+  // Gent-McWilliams (r4): the LDS kernel with the mixing tendency given (k_tracer_rhs_lds<., ., false, true>); pop_tuning.gm_flux_tile = 0: the generic kernel
+  const bool gm_lds = c->h.c.hmix_tracer == 3 && !c->g.pbc && !tun_off(c->h.tun.gm_flux_tile);
+  const bool lds_kernel = c->h.c.tadvect == 1 && (c->h.c.hmix_tracer != 3 || gm_lds) && (c->trc_lds_rows == 8 || c->trc_lds_rows == 4);
+  if (lds_kernel && gm_lds) { a.HDT[0] = c->gm.GTK[0]; a.HDT[1] = c->gm.GTK[1]; }
+  const bool form_next = lds_kernel && !gm_lds && c->d2t_next[0] && !c->avg_ts && c->h.c.tmix_opt != 3 && c->tr_ghosts_ok[c->curt];
   if (form_next) { a.D2N[0] = c->d2t_next[0]; a.D2N[1] = c->d2t_next[1]; a.AHF = c->mix.D4AHF; }
   c->d2t_last_formed = form_next;
   if (lds_kernel) {

@@ -72,6 +72,7 @@
       integer (c_int) :: fpcg_b2, pcsi_step2, halo_separate, halo_overlap_off, rccl_overlap, evp_wave
       integer (c_int) :: fpcg_a_pair, kpp_sparse, pbc_generic_thomas, pbc_generic_kpp, stream_priority, gm_sf_stored, state3d_levels
       integer (c_int) :: pcg_persist
+      integer (c_int) :: gm_flux_tile
    end type pop_tuning
 
    type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task

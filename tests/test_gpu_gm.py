@@ -220,6 +220,26 @@ def test_gm_stored_stream_function_terms_are_bitwise_the_re_derived_ones(pkg, mo
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("kw", [{"ah_bolus": 0.4e7, "stepped_bathymetry": 1},                                                   # with cancellation of the skew terms
+                                {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24},       # CESM's set-up: without
+                                {"ah_bolus": 0.4e7, "block_size_x": 20, "block_size_y": 16, "ldbl_diff": 1, "vmix_choice": 3, "km": 20},   # padded blocks, tiles overhang; two VDC arrays
+                                {"gm_transition_layer": 1, "block_size_x": 48, "block_size_y": 40, "ew_boundary": 0, "km": 62}])
+def test_gm_flux_tile_is_bitwise_the_cell_kernel(pkg, kw):
+    """k_gm_flux_tile (r4: every horizontal face flux formed once per 64 x 4 tile -- own east / north face, west by lane shuffle, south
+    through LDS) against k_gm_flux (pop_tuning.gm_flux_tile = 0: each face flux evaluated in both cells): the same six flux values
+    combined in the same order, so tendencies and the isopycnal VDC agree to the last bit"""
+    out = {}
+    for tile in (1, 0):
+        m = pkg.PopModel(named_config("tiny", **dict(GM, **kw)), tuning={"gm_flux_tile": tile})
+        for _ in range(4):
+            m.step()
+        out[tile] = [m.get("TRACER", 1, n).copy() for n in (0, 1)] + [m.get("VDC", n=0).copy(), m.get("VDC", n=1).copy(), m.get("UVEL", 1).copy()]
+        m.close()
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a, b)
+    assert np.abs(out[1][0]).max() > 0.0
+
+
 @pytest.mark.parametrize("kw", [{"ah_bolus": 0.5e7, "stepped_bathymetry": 1},
                                 {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1},
                                 {"block_size_x": 48, "block_size_y": 40}])

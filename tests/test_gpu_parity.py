@@ -1180,7 +1180,12 @@ def test_persistent_pcg_is_bitwise_the_fused_pcg(pkg, name, kw, grid):
                                     ({"vmix_choice": 3, "km": 24, "tmix_opt": 1, "time_mix_freq": 3}, {}), ({"vmix_choice": 3, "km": 24, "tmix_opt": 3}, {}),
                                     # the scratch-staged corrector and interior kernels share E3 with the look-ahead: the corrector must follow it
                                     ({"vmix_choice": 3, "km": 62, "stepped_bathymetry": 1}, {"POP_REG_THOMAS_T": "0", "POP_KPP_INTERIOR_GENERIC": "1", "POP_KPP_COL": "1"}),
-                                    ({"vmix_choice": 3, "km": 20, "ldbl_diff": 1, "block_size_x": 48, "block_size_y": 40}, {"POP_KPP_COL": "0"})])
+                                    ({"vmix_choice": 3, "km": 20, "ldbl_diff": 1, "block_size_x": 48, "block_size_y": 40}, {"POP_KPP_COL": "0"}),
+                                    # r4: with the mixed-layer-depth diagnostics (a second HMXL / HMXL_DR pair) and with Gent-McWilliams mixing, which adds to the
+                                    # VDC swapped in and whose transition layer reads the HMXL swapped in
+                                    ({"vmix_choice": 3, "km": 24, "kpp_diagnostics": 1}, {}),
+                                    ({"vmix_choice": 3, "km": 24, "hmix_tracer": 3, "ah": 0.8e7, "gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1}, {}),
+                                    ({"vmix_choice": 3, "km": 20, "hmix_tracer": 3, "ah": 0.8e7, "ah_bolus": 0.5e7, "block_size_x": 48, "block_size_y": 40, "tmix_opt": 1, "time_mix_freq": 4}, {})])
 def test_kpp_look_ahead_is_bitwise_neutral(pkg, orclib_built, monkeypatch, kw, env):
     """POP_KPP_AHEAD=1: pop_step computes the next step's KPP coefficients on a third stream beside the barotropic solver
     (inputs: this step's curtime fields) and the next step swaps them in.  Twelve steps -- first (Euler) step, leapfrog
@@ -1202,6 +1207,8 @@ def test_kpp_look_ahead_is_bitwise_neutral(pkg, orclib_built, monkeypatch, kw, e
             if s == 8:
                 m.get("UVEL", 1, 0)
         out[mode] = [m.get(n, 1, 0).copy() for n in ("UVEL", "VVEL", "TRACER", "PSURF", "VVC", "HBLT", "KPP_SRC")] + [m.get("VDC", 0, 1).copy()]
+        if cfg.kpp_ml_diagnostics or (cfg.hmix_tracer == 3 and cfg.gm_transition_layer):
+            out[mode] += [m.get("HMXL").copy(), m.get("HMXL_DR").copy()]
         m.close()
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a, b)
