@@ -1196,30 +1196,44 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
     *reinterpret_cast<double2 *>(a.Q + q) = make_double2(aqA, aqB);
     v0 = (aqA * sA) * mk0; v1 = (aqB * sB) * mk1;
   } else {
-    // generic path, cell by cell (rim of the physical domain, ghost cells, ragged end of the block)
+    // generic path, cell by cell (rim of the physical domain, ghost cells, ragged end of the block).  Straight-line since round 4: a wave
+    // that holds ONE such lane runs this path for all of them, and with the loads inside `if (in_e)` / `if (m >= 0)` it was ~17 dependent
+    // round trips (srcmap -> z, s per neighbour); now every load is unconditional at a clamped address -- three rounds (cell, source map,
+    // neighbours) -- and the conditions select values.  Same operations on the same operands.
     const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+    const long long qsafe = (long long)b * g.n2 + nxb + 1;            // a cell whose eight neighbours exist in the array
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      if (!(e == 0 ? live0 : live1)) continue;
-      const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
+      const bool live = (e == 0 ? live0 : live1);
+      const int p2 = live ? (int)(p0 + e) : 0, ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
-      const bool in_e = interior(g, b, ii, jj);
-      const double sold = a.S0[qq];
-      if (XUPD) a.X[qq] = a.X[qq] + alpha * sold;
-      const double s = (in_e ? a.Z[qq] : z_at(a, (int)qq)) + sold * bt;
+      const bool in_e = live && interior(g, b, ii, jj);
+      const long long qn = in_e ? qq : qsafe;                         // where the stencil operands are read
+      const double sold = a.S0[qq], xold = XUPD ? a.X[qq] : 0.0;
+      const double zown = in_e ? a.Z[qq] : z_at(a, (int)qq);
+      int m[9];
+#pragma unroll
+      for (int n = 1; n < 9; ++n) m[n] = a.srcmap[qn + off[n]];
+      const double wv[9] = {a.C[qn], g.WNo[qn], g.WNo[qn - nxb], g.WEa[qn], g.WEa[qn - 1], g.WNE[qn], g.WNE[qn - nxb], g.WNE[qn - 1], g.WNE[qn - 1 - nxb]};
+      const double mk = (double)g.mMask8[qn];
+      double zn[9], sn0[9];
+#pragma unroll
+      for (int n = 1; n < 9; ++n) { const int mm = (m[n] >= 0) ? m[n] : (int)qn; zn[n] = z_at(a, mm); sn0[n] = a.S0[mm]; }
+      const double s = zown + sold * bt;
       double aq = 0.0, vv = 0.0;
       if (in_e) {
-        const double wv[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};
         aq = wv[0] * s;
 #pragma unroll
         for (int n = 1; n < 9; ++n) {
-          const int m = a.srcmap[qq + off[n]];
-          const double sn = (m >= 0) ? z_at(a, m) + a.S0[m] * bt : 0.0 + 0.0 * bt;
+          const double sn = (m[n] >= 0) ? zn[n] + sn0[n] * bt : 0.0 + 0.0 * bt;
           aq = aq + wv[n] * sn;
         }
-        vv = (aq * s) * (double)g.mMask8[qq];
+        vv = (aq * s) * mk;
       }
-      a.S1[qq] = s; a.Q[qq] = aq;
+      if (live) {
+        if (XUPD) a.X[qq] = xold + alpha * sold;
+        a.S1[qq] = s; a.Q[qq] = aq;
+      }
       if (e == 0) v0 = vv; else v1 = vv;
     }
   }
@@ -1321,19 +1335,31 @@ k_fresidual2(DevGrid g, FusedArgs a) {
       if (send_band(g, b, i + 1, j)) pack_cell(a, q + 1, rB * a.A0R[q + 1]);
     }
   } else {
+    // rim cells, straight-line (round 4; see k_fpcg_b2): source map, then the neighbours, every load unconditional at a clamped address
+    const int off[8] = {nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+    const long long qsafe = (long long)b * g.n2 + nxb + 1;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      if (!(e == 0 ? live0 : live1)) continue;
-      const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
+      const bool live = (e == 0 ? live0 : live1);
+      const int p2 = live ? (int)(p0 + e) : 0, ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
-      if (!interior(g, b, ii, jj)) continue;
-      auto xs = [&](long long m0) { const int m = a.srcmap[m0]; return (m < 0) ? 0.0 : a.X[m]; };
-      const double ax = a.C[qq] * a.X[qq] + g.WNo[qq] * xs(qq + nxb) + g.WNo[qq - nxb] * xs(qq - nxb) + g.WEa[qq] * xs(qq + 1) + g.WEa[qq - 1] * xs(qq - 1) +
-                        g.WNE[qq] * xs(qq + nxb + 1) + g.WNE[qq - nxb] * xs(qq - nxb + 1) + g.WNE[qq - 1] * xs(qq + nxb - 1) + g.WNE[qq - 1 - nxb] * xs(qq - nxb - 1);
-      const double r = a.Bv[qq] - ax;
-      a.R[qq] = r;
-      if (WITH_RR) { const double vv = (r * r) * (double)g.mMask8[qq]; if (e == 0) v0 = vv; else v1 = vv; }
-      if (a.sendmap && a.A0R && send_band(g, b, ii, jj)) pack_cell(a, qq, r * a.A0R[qq]);
+      const bool in_e = live && interior(g, b, ii, jj);
+      const long long qn = in_e ? qq : qsafe;
+      int m[8];
+#pragma unroll
+      for (int n = 0; n < 8; ++n) m[n] = a.srcmap[qn + off[n]];
+      const double wc = a.C[qn], xc = a.X[qn], bvv = a.Bv[qn], mk = (double)g.mMask8[qn];
+      const double wv[8] = {g.WNo[qn], g.WNo[qn - nxb], g.WEa[qn], g.WEa[qn - 1], g.WNE[qn], g.WNE[qn - nxb], g.WNE[qn - 1], g.WNE[qn - 1 - nxb]};
+      double xn[8];
+#pragma unroll
+      for (int n = 0; n < 8; ++n) { const double x = a.X[(m[n] >= 0) ? m[n] : (int)qn]; xn[n] = (m[n] < 0) ? 0.0 : x; }
+      const double ax = wc * xc + wv[0] * xn[0] + wv[1] * xn[1] + wv[2] * xn[2] + wv[3] * xn[3] + wv[4] * xn[4] + wv[5] * xn[5] + wv[6] * xn[6] + wv[7] * xn[7];
+      const double r = bvv - ax;
+      if (in_e) {
+        a.R[qq] = r;
+        if (WITH_RR) { const double vv = (r * r) * mk; if (e == 0) v0 = vv; else v1 = vv; }
+        if (a.sendmap && a.A0R && send_band(g, b, ii, jj)) pack_cell(a, qq, r * a.A0R[qq]);
+      }
     }
   }
   if (WITH_RR) {

@@ -174,29 +174,41 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
     *reinterpret_cast<double2 *>(a.Ro + q) = a.raw_r ? make_double2(rA, rB) : make_double2(rA * a0r.x, rB * a0r.y);
     if (WITH_RR) { v0 = (rA * rA) * (double)g.mMask8[q]; v1 = (rB * rB) * (double)g.mMask8[q + 1]; }
   } else {
+    // rim cells, straight-line (round 4; see k_fpcg_b2): source map, then the neighbours, every load unconditional at a clamped address
     const int off[8] = {nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+    const long long qsafe = (long long)b * g.n2 + nxb + 1;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      if (!(e == 0 ? live0 : live1)) continue;
-      const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
+      const bool live = (e == 0 ? live0 : live1);
+      const int p2 = live ? (int)(p0 + e) : 0, ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
-      if (interior(g, b, ii, jj)) {
-        double xn[9], dx0 = 0.0;
+      const bool in_e = live && interior(g, b, ii, jj);
+      const long long qn = in_e ? qq : qsafe;
+      long long m[9];
+      m[0] = qn;
 #pragma unroll
-        for (int n = 0; n < 9; ++n) {
-          const long long m = (n == 0) ? qq : (long long)a.srcmap[qq + off[n - 1]];
-          double x = 0.0;
-          if (m >= 0) { const double dx = om * a.Ri[m] + cq * a.Qi[m]; if (n == 0) dx0 = dx; x = a.Xi[m] + dx; }
-          xn[n] = x;
-        }
-        const double w[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};
+      for (int n = 1; n < 9; ++n) m[n] = (long long)a.srcmap[qn + off[n - 1]];
+      const int self = a.srcmap[qq];
+      const double w[9] = {a.C[qn], g.WNo[qn], g.WNo[qn - nxb], g.WEa[qn], g.WEa[qn - 1], g.WNE[qn], g.WNE[qn - nxb], g.WNE[qn - 1], g.WNE[qn - 1 - nxb]};
+      const double bvv = a.Bv[qn], a0r = a.A0R[qn], mk = (double)g.mMask8[qn];
+      const double ri_own = a.Ri[qq], qi_own = a.Qi[qq], xi_own = a.Xi[qq];       // a ghost cell that advances itself (remote_ghosts)
+      double xn[9], dx0 = 0.0;
+#pragma unroll
+      for (int n = 0; n < 9; ++n) {
+        const long long mm = (m[n] >= 0) ? m[n] : qn;
+        const double dx = om * a.Ri[mm] + cq * a.Qi[mm];
+        const double x = a.Xi[mm] + dx;
+        if (n == 0) dx0 = dx;
+        xn[n] = (m[n] >= 0) ? x : 0.0;
+      }
+      if (in_e) {
         const double ax = w[0] * xn[0] + w[1] * xn[1] + w[2] * xn[2] + w[3] * xn[3] + w[4] * xn[4] + w[5] * xn[5] + w[6] * xn[6] + w[7] * xn[7] + w[8] * xn[8];
-        const double r = a.Bv[qq] - ax;
-        a.Qo[qq] = dx0; a.Xo[qq] = xn[0]; a.Ro[qq] = a.raw_r ? r : r * a.A0R[qq];
-        if (WITH_RR) { const double vv = (r * r) * (double)g.mMask8[qq]; if (e == 0) v0 = vv; else v1 = vv; }
-      } else if (a.remote_ghosts && a.srcmap[qq] == qq) {
-        const double dx = om * a.Ri[qq] + cq * a.Qi[qq];
-        a.Qo[qq] = dx; a.Xo[qq] = a.Xi[qq] + dx;
+        const double r = bvv - ax;
+        a.Qo[qq] = dx0; a.Xo[qq] = xn[0]; a.Ro[qq] = a.raw_r ? r : r * a0r;
+        if (WITH_RR) { const double vv = (r * r) * mk; if (e == 0) v0 = vv; else v1 = vv; }
+      } else if (live && a.remote_ghosts && self == (int)qq) {
+        const double dx = om * ri_own + cq * qi_own;
+        a.Qo[qq] = dx; a.Xo[qq] = xi_own + dx;
       }
     }
   }
