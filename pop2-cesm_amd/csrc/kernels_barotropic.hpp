@@ -1050,25 +1050,33 @@ k_fcg_a2(DevGrid g, FusedArgs a) {
     v[0][0] = (rr.x * zr[1][1]) * mk0; v[0][1] = (azA * zr[1][1]) * mk0;
     v[1][0] = (rr.y * zr[1][2]) * mk1; v[1][1] = (azB * zr[1][2]) * mk1;
   } else {
+    // rim cells, straight-line (round 4; see k_fpcg_b2): source map, then the neighbours, every load unconditional at a clamped address
     const int off[9] = {0, nxb, -nxb, 1, -1, nxb + 1, -nxb + 1, nxb - 1, -nxb - 1};
+    const long long qsafe = (long long)b * g.n2 + nxb + 1;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      if (!(e == 0 ? live0 : live1)) continue;
-      const int p2 = (int)(p0 + e), ii = p2 % nxb, jj = p2 / nxb;
+      const bool live = (e == 0 ? live0 : live1);
+      const int p2 = live ? (int)(p0 + e) : 0, ii = p2 % nxb, jj = p2 / nxb;
       const long long qq = (long long)b * g.n2 + p2;
-      if (!interior(g, b, ii, jj)) continue;
-      const double r = a.R[qq];
-      const double z0 = r * a.A0R[qq];
-      const double wv[9] = {a.C[qq], g.WNo[qq], g.WNo[qq - nxb], g.WEa[qq], g.WEa[qq - 1], g.WNE[qq], g.WNE[qq - nxb], g.WNE[qq - 1], g.WNE[qq - 1 - nxb]};
+      const bool in_e = live && interior(g, b, ii, jj);
+      const long long qn = in_e ? qq : qsafe;
+      int m[9];
+#pragma unroll
+      for (int n = 1; n < 9; ++n) m[n] = a.srcmap[qn + off[n]];
+      const double r = a.R[qn];
+      const double z0 = r * a.A0R[qn];
+      const double wv[9] = {a.C[qn], g.WNo[qn], g.WNo[qn - nxb], g.WEa[qn], g.WEa[qn - 1], g.WNE[qn], g.WNE[qn - nxb], g.WNE[qn - 1], g.WNE[qn - 1 - nxb]};
+      const double mk = (double)g.mMask8[qn];
+      double zn[9];
+#pragma unroll
+      for (int n = 1; n < 9; ++n) zn[n] = cg_z_at(a, (m[n] >= 0) ? m[n] : (int)qn);
       double az = wv[0] * z0;
 #pragma unroll
-      for (int n = 1; n < 9; ++n) {
-        const int m = a.srcmap[qq + off[n]];
-        az = az + wv[n] * ((m >= 0) ? cg_z_at(a, m) : 0.0);
+      for (int n = 1; n < 9; ++n) az = az + wv[n] * ((m[n] >= 0) ? zn[n] : 0.0);
+      if (in_e) {
+        a.Z[qq] = z0; a.AZ[qq] = az;
+        v[e][0] = (r * z0) * mk; v[e][1] = (az * z0) * mk;
       }
-      a.Z[qq] = z0; a.AZ[qq] = az;
-      const double mk = (double)g.mMask8[qq];
-      v[e][0] = (r * z0) * mk; v[e][1] = (az * z0) * mk;
     }
   }
   // the tree of wg_reduce_store<2> over the 256 cells of the chunk
