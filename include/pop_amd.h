@@ -78,7 +78,7 @@ typedef struct pop_config {
   int gm_kappa_type;          /* hmix_gm_nml kappa_isop_choice = kappa_thic_choice: 0 'constant', 2 'depth' (kappa_depth_1 + kappa_depth_2 exp(-zt / kappa_depth_scale),
                                * hmix_gm.F90:850-874), 1 'bfre' (buoyancy_frequency_dependent_profile,
                                * hmix_gm.F90:3011-3180: KAPPA_VERTICAL = N^2 / N_ref^2 in [0.1, 1] below the surface diabatic layer; kappa_*_deep = 0.1) */
-  int gm_kappa_freq;          /* kappa_freq_choice with gm_kappa_type = 1: 0 'never' (the profile of the first step of the run is kept, :1276-1278),
+  int gm_kappa_freq;          /* kappa_freq_choice with gm_kappa_type = 1: 0 'never' (refused with 'bfre' as in the reference, hmix_gm.F90:756-780),
                                * 1 'every_time_step', 2 'once_a_day' (the first step after a day has ended, eod_last; for runs that start at midnight:
                                * with avgfit the fit interval is the day, without averaging steps every steps_per_day-th step ends one) */
   double am, ah;              /* del2 [cm^2/s] or del4 [cm^4/s] */

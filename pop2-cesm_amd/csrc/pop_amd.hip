@@ -1510,6 +1510,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     if (cfg->hmix_tracer == 3 && cfg->partial_bottom_cells) return bad("hmix_tracer = 3 (Gent-McWilliams) with partial_bottom_cells: the reference refuses the combination (hmix_gm.F90:782-785), so does this library");
     // hmix_gm.F90:724-730: kappa_depth_2 = 0 with the 'depth' profile aborts in init_gm
     if (cfg->hmix_tracer == 3 && cfg->gm_kappa_type == 2 && cfg->kappa_depth_2 == 0.0) return bad("gm_kappa_type = 2 ('depth') needs kappa_depth_2 /= 0 (hmix_gm.F90:724-730)");
+    if (cfg->hmix_tracer == 3 && cfg->gm_kappa_type == 1 && cfg->gm_kappa_freq == 0) return bad("gm_kappa_type = 1 ('bfre') needs gm_kappa_freq = 1 | 2: 'kappa_freq should not be set to never when model fields dependent kappa types are chosen' (hmix_gm.F90:756-780; no N^2 file here)");
     if (cfg->gm_kappa_type < 0 || cfg->gm_kappa_type > 2) return bad("gm_kappa_type: 0 constant, 1 bfre, 2 depth (the other kappa choices of hmix_gm_nml are not built)");
     if (cfg->gm_kappa_freq < 0 || cfg->gm_kappa_freq > 2) return bad("gm_kappa_freq: 0 never, 1 every_time_step, 2 once_a_day");
     if (cfg->gm_kappa_freq == 2 && cfg->tmix_opt == 1) return bad("gm_kappa_freq = once_a_day with time_mix_opt 'avg' (half steps that do not fit the day: the end-of-day test of time_management.F90:3586-3592 on the calendar) is not built: avgfit, robert or none");

@@ -35,7 +35,7 @@ def _steep(gpu, orc):
     ("tiny", {"tmix_opt": 3, "solver_choice": 2}, 4),                                 # Robert filter
     ("tiny", {"km": 60, "vmix_choice": 3}, 3),                                        # production level count (register Thomas kernels)
     # kappa type 'bfre' (buoyancy_frequency_dependent_profile): KAPPA_VERTICAL = N^2 / N_ref^2 below the surface diabatic layer
-    ("tiny", {"gm_kappa_type": 1, "stepped_bathymetry": 1}, 5),                       # 'never': the profile of the first step is kept
+    ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 2, "stepped_bathymetry": 1}, 5),    # 'once_a_day': the profile of the first step is kept until a day has ended
     ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1, "ah_bolus": 0.5e7}, 5),   # every step, SDL = HBLT
     ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "km": 60, "tadvect": 2, "gm_slope_control": 1}, 3),
     ("gx3v7", {"gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3}, 3),
@@ -44,7 +44,7 @@ def _steep(gpu, orc):
     ("tiny", {"gm_transition_layer": 1, "stepped_bathymetry": 1}, 5),
     ("tiny", {"gm_transition_layer": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1}, 5),
     ("tiny", {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3, "km": 24, "stepped_bathymetry": 1, "ah_bolus": 0.5e7, "slm_b": 0.2}, 5),   # the CESM set-up but for kappa_freq
-    ("tiny", {"gm_transition_layer": 1, "gm_kappa_type": 1, "vmix_choice": 3, "km": 60, "gm_slope_control": 1, "tadvect": 2}, 3),
+    ("tiny", {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 2, "vmix_choice": 3, "km": 60, "gm_slope_control": 1, "tadvect": 2}, 3),
     ("gx3v7", {"gm_transition_layer": 1, "gm_kappa_type": 1, "gm_kappa_freq": 1, "vmix_choice": 3}, 3),
     # kappa_freq 'once_a_day': recomputed at the first step after a day has ended (two day boundaries inside the run)
     ("tiny", {"gm_kappa_type": 1, "gm_kappa_freq": 2, "steps_per_day": 6, "time_mix_freq": 4, "vmix_choice": 3, "km": 20}, 20),   # avgfit: the fit interval is the day

@@ -195,10 +195,11 @@ def test_bad_configs_are_rejected(pkg):
 def test_combinations_the_reference_aborts_on_are_refused(pkg, orclib_built):
     """init_gm aborts for Gent-McWilliams with partial bottom cells ('hmix_gm currently incompatible with partial bottom cells',
     hmix_gm.F90:782-785: slopes and fluxes use dz(k), the tracer budget DZT) and for the 'depth' kappa profile with kappa_depth_2 = 0
-    (:724-730).  Library and oracle refuse both; a pop_config of another layout version is refused by both as well."""
+    (:724-730) and for the 'bfre' kappa with kappa_freq 'never' (:756-780).  Library and oracle refuse all three; a pop_config of another layout version is refused by both as well."""
     from orclib import Oracle
     for kw, word in (({"hmix_tracer": 3, "ah": 0.8e7, "partial_bottom_cells": 1, "stepped_bathymetry": 1}, "partial_bottom_cells"),
                      ({"hmix_tracer": 3, "ah": 0.8e7, "gm_kappa_type": 2, "kappa_depth_1": 1.0}, "kappa_depth_2"),
+                     ({"hmix_tracer": 3, "ah": 0.8e7, "gm_kappa_type": 1}, "gm_kappa_freq"),
                      ({"struct_version": 4}, "struct_version")):
         cfg = named_config("tiny", **kw)
         with pytest.raises(pkg.PopError, match=word):
