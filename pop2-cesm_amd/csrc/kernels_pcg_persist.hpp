@@ -300,4 +300,247 @@ k_pcg_persist(PersistArgs a) {
   if (t == 0 && dead) a.out[2] = 1.0;
 }
 
+
+// ---- ChronGear (POP_SolversMod.F90:1960-2266, diagonal preconditioner) of a small 2-D system as one resident launch (round 4) ------------
+// The iterations of solver_chrongear_fused (k_fcg_a | block sums | k_fcg_b per iteration, k_fresidual + k_rr_total per check) after its
+// start-up pass, which stays as it is: this kernel takes over x, r, s, q, A0R and (rho, sigma) of the start-up.  Same windows, tags and
+// buffers as k_pcg_persist.  Per iteration: z = r A0R of the own cells is published for the neighbours' halos and the neighbours' z
+// collected (a wait for the NEIGHBOURS only), az = A z, the chunk partials of (r, z) and (az, z) are exchanged (the one grid-wide wait of
+// the iteration; pcg has two), then s = z + beta s, q = az + beta q, x += alpha s, r -= alpha q with s and x advanced at the halo cells
+// too (the owner's arithmetic).  Totals by the rule of fused_total2, chunk partials by the tree of wg_reduce_store<2>: bitwise the fused form.
+struct CgPersistArgs {
+  PersistArgs p;                         // X, Bv, C, weights, mask, plan, W (partials: [2][2 * nslots], then z), epoch, limits, out
+  double *R, *S, *Q;                     // r, s, q of the start-up pass (not written back: nothing reads them after the solve)
+  const double *A0R;
+  const SolverScalars *sc;               // rho2[0], sigma2[0] of the start-up pass
+};
+constexpr int POP_CGP_MAXP = 7;          // partial slots per field one thread collects: 7 + 7 words in one request
+
+template <int CP>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_cg_persist(CgPersistArgs ca) {
+  const PersistArgs &a = ca.p;
+  extern __shared__ double lds[];                          // Xw | Sw | Zw, nwin doubles each
+  constexpr int NSH = CP > POP_CGP_MAXP ? CP : POP_CGP_MAXP;
+  __shared__ double sh[2][NSH][POP_RED_THREADS];
+  __shared__ double sh_tot[2][POP_CGP_MAXP];
+  __shared__ int dead;
+  constexpr int NT = POP_RED_THREADS, NOWN = CP * NT;
+  const int t = threadIdx.x, w = blockIdx.x;
+  const int h0 = a.halo_off[w], nhalo = a.halo_off[w + 1] - h0, nwin = NOWN + nhalo + 1;
+  double *Xw = lds, *Sw = lds + nwin, *Zw = lds + 2 * nwin;
+  if (t == 0) dead = 0;
+  int q[CP]; bool inner[CP];
+  double cw[CP], mk[CP], wv[CP][8], r[CP], sq_[CP], qv[CP], a0r[CP];
+  unsigned short nb[CP][8];
+#pragma unroll
+  for (int u = 0; u < CP; ++u) {
+    const long long L = (long long)w * NOWN + u * NT + t;
+    q[u] = a.own_q[L];
+    inner[u] = q[u] >= 0;
+    const long long qc = inner[u] ? q[u] : 0;
+    const int nxb = a.nxb;
+    cw[u] = a.C[qc]; mk[u] = (double)a.mMask8[qc];
+    const long long qs = (qc - nxb - 1 >= 0) ? qc : (long long)nxb + 1;
+    wv[u][0] = a.WNo[qs]; wv[u][1] = a.WNo[qs - nxb]; wv[u][2] = a.WEa[qs]; wv[u][3] = a.WEa[qs - 1];
+    wv[u][4] = a.WNE[qs]; wv[u][5] = a.WNE[qs - nxb]; wv[u][6] = a.WNE[qs - 1]; wv[u][7] = a.WNE[qs - 1 - nxb];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) nb[u][n] = a.nbr[L * 8 + n];
+    r[u] = inner[u] ? ca.R[qc] : 0.0; qv[u] = inner[u] ? ca.Q[qc] : 0.0; a0r[u] = ca.A0R[qc];
+    sq_[u] = 0.0;
+  }
+  // window: x and s of the own and the halo cells as the start-up pass left them (ghost values there are copies of their sources)
+  for (int L = t; L < nwin; L += NT) {
+    int qL = -1;
+    if (L < NOWN) qL = a.own_q[(long long)w * NOWN + L];
+    else if (L < NOWN + nhalo) qL = a.halo_q[h0 + L - NOWN];
+    Xw[L] = qL >= 0 ? a.X[qL] : 0.0; Sw[L] = qL >= 0 ? ca.S[qL] : 0.0; Zw[L] = 0.0;
+  }
+  double rho_o = ca.sc->rho2[0], sig_o = ca.sc->sigma2[0];
+  __syncthreads();
+
+  int phase = 0;
+  // ---- z of the halo cells of iteration m (the neighbours published it with tag m)
+  auto halo_z = [&](int m) {
+    const unsigned long long ztag = a.epoch | (unsigned long long)(unsigned)m | 0x80000000ULL;
+    const long long zbase = 4LL * a.nslots + (long long)(m & 1) * a.ncell;
+    unsigned off[14]; bool need[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+      const int hh = t + (k % POP_PERSIST_MAXH) * NT;
+      need[k] = k < POP_PERSIST_MAXH && hh < nhalo;
+      off[k] = (unsigned)((need[k] ? zbase + a.halo_q[h0 + hh] : zbase) * (long long)sizeof(PWord));
+    }
+    pword4 got[14];
+    unsigned long long t0 = 0;
+    for (int tries = 0;; ++tries) {
+      ld_pwords14(a.W, off, got);
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < POP_PERSIST_MAXH; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == ztag);
+      if (ok) break;
+      if (*(volatile int *)&dead) break;
+      if ((tries & 255) == 0) { const unsigned long long now = wall_clock64(); if (tries == 0) t0 = now; else if (now - t0 > a.wait_ticks) { dead = 1; break; } }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < POP_PERSIST_MAXH; ++k) { const int hh = t + k * NT; if (hh < nhalo) Zw[NOWN + hh] = pword_value(got[k]); }
+    __syncthreads();
+  };
+  // ---- the chunk partials of NF fields out, everybody's in, their ordered totals back (rule of fused_total2 / fused_total)
+  auto exchange = [&](double (&v)[2][CP], int nf, double (&tot)[2]) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int u = 0; u < CP; ++u) sh[f][u][t] = v[f][u];
+    __syncthreads();
+    for (int s = NT / 2; s >= 64; s >>= 1) {
+      if (t < s) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int u = 0; u < CP; ++u) sh[f][u][t] = sh[f][u][t] + sh[f][u][t + s];
+      }
+      __syncthreads();
+    }
+    const unsigned long long ptag = a.epoch | (unsigned long long)(unsigned)phase;
+    const long long pbase = (long long)(phase & 1) * 2 * a.nslots;               // [field][slot] inside the buffer of the phase
+    if (t < 64) {
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int u = 0; u < CP; ++u) {
+          const double x = tree_tail64(sh[f][u][t]);
+          const int slot = w * CP + u;
+          if (t == 0 && slot < a.nslots && f < nf) st_pword(a.W + pbase + (long long)f * a.nslots + slot, x, ptag);
+        }
+    }
+    const int per_b = (a.nchunk - t + NT - 1) / NT;
+    unsigned off[14]; bool need[14]; int kb[POP_CGP_MAXP];
+#pragma unroll
+    for (int k = 0; k < POP_CGP_MAXP; ++k) {
+      const int b = per_b > 0 ? k / per_b : a.nblocks, c = per_b > 0 ? t + (k % per_b) * NT : 0;
+      const bool nd = b < a.nblocks;
+      kb[k] = nd ? b : -1;
+      const long long sl = nd ? (long long)b * a.nchunk + c : 0;
+      need[k] = nd; need[POP_CGP_MAXP + k] = nd && nf > 1;
+      off[k] = (unsigned)((pbase + sl) * (long long)sizeof(PWord));
+      off[POP_CGP_MAXP + k] = (unsigned)((pbase + (nf > 1 ? a.nslots : 0) + sl) * (long long)sizeof(PWord));
+    }
+    pword4 got[14];
+    unsigned long long t0 = 0;
+    for (int tries = 0;; ++tries) {
+      ld_pwords14(a.W, off, got);
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < 14; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == ptag);
+      if (ok) break;
+      if (*(volatile int *)&dead) break;
+      if ((tries & 255) == 0) { const unsigned long long now = wall_clock64(); if (tries == 0) t0 = now; else if (now - t0 > a.wait_ticks) { dead = 1; break; } }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const int nbk = a.nblocks;
+    __syncthreads();
+    for (int b = 0; b < nbk; ++b) {
+      double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < POP_CGP_MAXP; ++k)
+        if (kb[k] == b) { x0 = x0 + pword_value(got[k]); x1 = x1 + pword_value(got[POP_CGP_MAXP + k]); }
+      sh[0][b][t] = x0; sh[1][b][t] = x1;
+    }
+    __syncthreads();
+    for (int s = NT / 2; s >= 64; s >>= 1) {
+      if (t < s)
+        for (int b = 0; b < nbk; ++b) { sh[0][b][t] = sh[0][b][t] + sh[0][b][t + s]; sh[1][b][t] = sh[1][b][t] + sh[1][b][t + s]; }
+      __syncthreads();
+    }
+    if (t < 64)
+      for (int b = 0; b < nbk; ++b) {
+        const double y0 = tree_tail64(sh[0][b][t]), y1 = tree_tail64(sh[1][b][t]);
+        if (t == 0) { sh_tot[0][b] = y0; sh_tot[1][b] = y1; }
+      }
+    __syncthreads();
+    tot[0] = 0.0; tot[1] = 0.0;
+    for (int b = 0; b < nbk; ++b) { tot[0] = tot[0] + sh_tot[0][b]; tot[1] = tot[1] + sh_tot[1][b]; }
+    __syncthreads();
+    ++phase;
+  };
+  auto apply = [&](const double *W, int u) -> double {
+    double ax = cw[u] * W[u * NT + t];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) ax = ax + wv[u][n] * W[nb[u][n]];
+    return ax;
+  };
+
+  double rr = 0.0;
+  int m = 0, nchecks = 0, converged = 0;
+  double v[2][CP], tot[2];
+  while (m < a.max_iter) {
+    ++m;
+    // ---- k_fcg_a: z = r A0R (own cells; the halo cells' from their owners), az = A z, partials (r, z), (az, z)
+    PWord *const Zn = a.W + 4LL * a.nslots + (long long)(m & 1) * a.ncell;
+    const unsigned long long ztag = a.epoch | (unsigned long long)(unsigned)m | 0x80000000ULL;
+    double z[CP];
+#pragma unroll
+    for (int u = 0; u < CP; ++u) {
+      z[u] = 0.0;
+      if (inner[u]) {
+        z[u] = r[u] * a0r[u];
+        Zw[u * NT + t] = z[u];
+        st_pword(Zn + q[u], z[u], ztag);
+      }
+    }
+    halo_z(m);                                             // (ends with a barrier: the own z of every thread is in the window too)
+    double az[CP];
+#pragma unroll
+    for (int u = 0; u < CP; ++u) {
+      az[u] = 0.0; v[0][u] = 0.0; v[1][u] = 0.0;
+      if (inner[u]) {
+        az[u] = apply(Zw, u);
+        v[0][u] = (r[u] * z[u]) * mk[u]; v[1][u] = (az[u] * z[u]) * mk[u];
+      }
+    }
+    exchange(v, 2, tot);
+    // ---- k_fcg_b: the scalar recurrences, then s, q, x, r; s and x at the halo cells with the owner's arithmetic
+    const double rho = tot[0], delta = tot[1];
+    const double bt = rho / rho_o;
+    const double sigma = delta - (bt * bt) * sig_o;
+    const double al = rho / sigma;
+    rho_o = rho; sig_o = sigma;
+#pragma unroll
+    for (int u = 0; u < CP; ++u)
+      if (inner[u]) {
+        const double s = z[u] + bt * Sw[u * NT + t];
+        qv[u] = az[u] + bt * qv[u];
+        Sw[u * NT + t] = s;
+        Xw[u * NT + t] = Xw[u * NT + t] + al * s;
+        r[u] = r[u] - al * qv[u];
+      }
+    for (int L = NOWN + t; L < nwin - 1; L += NT) {        // halo cells: sg = z + beta sg; x += alpha sg
+      const double sg = Zw[L] + bt * Sw[L];
+      Sw[L] = sg;
+      Xw[L] = Xw[L] + al * sg;
+    }
+    __syncthreads();
+    if (m % a.freq == 0) {
+      // ---- convergence check: r = b - A x, (r, r)
+#pragma unroll
+      for (int u = 0; u < CP; ++u) {
+        r[u] = inner[u] ? a.Bv[q[u]] - apply(Xw, u) : 0.0;
+        v[0][u] = inner[u] ? (r[u] * r[u]) * mk[u] : 0.0; v[1][u] = 0.0;
+      }
+      exchange(v, 1, tot);
+      rr = tot[0];
+      ++nchecks;
+      if (rr < a.criterion) { converged = 1; break; }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < CP; ++u) if (inner[u]) a.X[q[u]] = Xw[u * NT + t];
+  if (w == 0 && t == 0) { a.out[0] = converged ? (double)m : (double)a.max_iter; a.out[1] = rr; a.out[3] = (double)nchecks; }
+  if (t == 0 && dead) a.out[2] = 1.0;
+  (void)sq_;
+}
+
 }  // namespace pop

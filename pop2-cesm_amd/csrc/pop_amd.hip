@@ -643,7 +643,7 @@ static pop_ctx::PersistPlan *persist_plan(pop_ctx *c, const SolveView &v) {
   if (hq.empty()) hq.push_back(0);
   if (dev_upload(c, &pl.own_q, own.data(), own.size()) || dev_upload(c, &pl.nbr, nbr.data(), nbr.size()) ||
       dev_upload(c, &pl.halo_off, hoff.data(), hoff.size()) || dev_upload(c, &pl.halo_q, hq.data(), hq.size())) return nullptr;
-  const size_t nwords = 2 * ((size_t)nslots + (size_t)n2 * nb);
+  const size_t nwords = 4 * (size_t)nslots + 2 * (size_t)n2 * nb;      // partials [2 buffers][2 fields (ChronGear)][nslots], then z [2][ncell]
   if (nwords * sizeof(PWord) >= (1ULL << 32)) return refuse("exchange buffer beyond 32-bit offsets");
   double *p = nullptr;
   if (dev_alloc(c, &p, 2 * nwords)) return nullptr;          // zero-filled: tag 0 is never waited for (epochs start at 1)
@@ -688,6 +688,48 @@ int solver_pcg_persist(pop_ctx *c, SolveView &v, const pop_ctx::PersistPlan &pl)
   HIPCHK(c, hipGetLastError());
   const bool conv = c->persist_out[3] > 0.0 && c->persist_out[1] < c->h.convergenceCriterion;
   if (!conv && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCG: solver not converged"; return 2; }
+  return 0;
+}
+
+// the iterations of the fused ChronGear as one resident launch (k_cg_persist), after the start-up pass of solver_chrongear_fused
+int solver_cg_persist(pop_ctx *c, SolveView &v, const pop_ctx::PersistPlan &pl, const FusedArgs &fa) {
+  const pop_config &cf = c->h.c;
+  const long long ncell = (long long)v.g.n2 * v.g.nblocks;
+  CgPersistArgs ca{};
+  PersistArgs &a = ca.p;
+  a.X = v.X; a.Bv = v.RHS; a.C = v.C; a.WNo = v.g.WNo; a.WEa = v.g.WEa; a.WNE = v.g.WNE; a.mMask8 = v.g.mMask8;
+  a.nxb = v.g.nxb; a.nchunk = v.nchunk; a.nblocks = v.g.nblocks; a.nslots = pl.nslots; a.ncell = ncell;
+  a.own_q = pl.own_q; a.nbr = pl.nbr; a.halo_off = pl.halo_off; a.halo_q = pl.halo_q; a.W = pl.W;
+  a.epoch = (++c->persist_epoch) << 32;
+  a.max_iter = cf.max_iterations; a.freq = cf.convergence_check_freq; a.criterion = c->h.convergenceCriterion; a.out = c->persist_out;
+  a.wait_ticks = 200000000ULL;
+  ca.R = fa.R; ca.S = fa.S0; ca.Q = fa.Q; ca.A0R = fa.A0R; ca.sc = c->sc;
+  c->persist_out[0] = -1.0; c->persist_out[1] = 0.0; c->persist_out[2] = 0.0; c->persist_out[3] = 0.0;
+  HIPCHK(c, hipMemcpyAsync(pl.X0, v.X, sizeof(double) * ncell, hipMemcpyDeviceToDevice, c->stream));   // x after the start-up pass, should the iterations have to be repeated
+  const size_t lds = (size_t)3 * pl.nwin_max * sizeof(double);
+  const dim3 G(pl.nwg), B(POP_RED_THREADS);
+  switch (pl.CP) {
+    case 1: hipLaunchKernelGGL(k_cg_persist<1>, G, B, lds, c->stream, ca); break;
+    case 2: hipLaunchKernelGGL(k_cg_persist<2>, G, B, lds, c->stream, ca); break;
+    case 4: hipLaunchKernelGGL(k_cg_persist<4>, G, B, lds, c->stream, ca); break;
+    default: hipLaunchKernelGGL(k_cg_persist<8>, G, B, lds, c->stream, ca); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->chk_ev[0], c->stream));
+  HIPCHK(c, hipEventSynchronize(c->chk_ev[0]));
+  if (c->persist_out[2] != 0.0 || c->persist_out[0] < 0.0) {
+    char b[200];
+    snprintf(b, sizeof b, " [iterations %g, status %g, checks %g, %d workgroups x %d chunks, %d blocks]", c->persist_out[0], c->persist_out[2], c->persist_out[3], pl.nwg, pl.CP, v.g.nblocks);
+    c->err = std::string("resident ChronGear: a wait for another workgroup's data gave up (kernels_pcg_persist.hpp)") + b;
+    return 3;
+  }
+  c->numIterations = (int)c->persist_out[0];
+  c->rmsResidual = std::sqrt(c->persist_out[1] * c->h.residualNorm);
+  c->persist_used = 1; c->persist_nwg = pl.nwg; c->persist_cp = pl.CP;
+  hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, v.X, v.srcmap, ncell);
+  HIPCHK(c, hipGetLastError());
+  const bool conv = c->persist_out[3] > 0.0 && c->persist_out[1] < c->h.convergenceCriterion;
+  if (!conv && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversChronGear: solver not converged"; return 2; }
   return 0;
 }
 
@@ -1014,6 +1056,24 @@ int solver_chrongear_fused(pop_ctx *c) {
   if (reduce_finish<2>(c, FIN_CG_INIT)) return 1;
   hipLaunchKernelGGL(k_cg_update<true>, grid_2d(c), B, 0, c->stream, c->g, a);
   hipLaunchKernelGGL(k_pcsi_a0r, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->centerWgt, v.S1, a2);
+  c->persist_used = 0;
+  {   // small views: the iterations as one resident launch (k_cg_persist); pop_tuning.pcg_persist = 0 switches it off
+    FusedArgs fa = fused_args(c, v);
+    fa.AZ = c->AZ; fa.A0R = v.S1;
+    if (!tun_off(c->h.tun.pcg_persist) && !fa.presummed && !c->persist_gave_up &&
+        v.g.nblocks * ((v.nchunk + POP_RED_THREADS - 1) / POP_RED_THREADS) <= POP_CGP_MAXP) {
+      if (const pop_ctx::PersistPlan *pl = persist_plan(c, v)) {
+        const int e = solver_cg_persist(c, v, *pl, fa);
+        if (e != 3) return e;
+        // the resident launch did not complete its exchanges: not again in this model.  It changed x only at its very end, if at all: x of the
+        // start-up pass is restored; r, s, q and the scalars were only read
+        c->persist_gave_up += 1;
+        fprintf(stderr, "libpop_amd: %s -- continuing with the two-launch ChronGear\n", c->err.c_str());
+        c->err.clear();
+        HIPCHK(c, hipMemcpyAsync(v.X, pl->X0, sizeof(double) * a2, hipMemcpyDeviceToDevice, c->stream));
+      }
+    }
+  }
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
   const bool use_graph = (freq % 2 == 0) && !c->no_graph;   // even: the (rho, sigma) ping-pong ends where it started
@@ -2061,6 +2121,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
   // KPP look-ahead (bandwidth-bound grids; POP_KPP_AHEAD=0|1 overrides): second set of KPP outputs, own stream
   // ... and (round 4) small grids whose pcg solve is the one resident launch: that launch keeps at most one workgroup per CU busy waiting
   // on memory for 2 ms, the KPP kernels of the next step fill the rest (gx1v7: 3.26 -> 3.09, 3.36 -> 3.18 ms per step, A/B on one box)
+  // (pcg only: beside the resident ChronGear the look-ahead costs more than it hides -- 3.08 -> 3.34 ms per step, its neighbour waits are hit harder)
   const bool resident_solve = cfg->solver_choice == 1 && !use_evp(*cfg) && !tun_off(h.tun.pcg_persist) && h.nranks == 1 && h.nblocks <= 8 &&
                               h.n2 * h.nblocks <= 250u * 8u * 256u;
   c->ahead_enabled = cfg->vmix_choice == 3 && c->side && (h.n2 * h.nblocks > (1u << 19) || resident_solve);

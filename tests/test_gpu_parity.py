@@ -1152,6 +1152,14 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
     ("gx1v7", {}, False),                                                           # BASELINE configs[2]: 492 chunks, 246 workgroups of 2 chunks
     ("gx1v7", {"block_size_y": 96}, False),                                         # four j-band blocks in one view (the shape of the replicated solve)
     ("gx1v7", {"block_size_y": 48}, False),                                         # the eight bands of the 8-rank decomposition in one view: eight block totals per exchange
+    # ChronGear (k_cg_persist): the iterations after the start-up pass as one resident launch
+    ("tiny", {"solver_choice": 2, "block_size_x": 24, "block_size_y": 20}, False),
+    ("tiny", {"solver_choice": 2, "block_size_x": 24, "block_size_y": 20, "ew_boundary": 0, "stepped_bathymetry": 1}, False),
+    ("tiny", {"solver_choice": 2, "block_size_x": 28, "block_size_y": 24, "convergence_check_freq": 4, "max_iterations": 203, "convergence_criterion": 1.0e-13}, False),
+    ("tiny", {"solver_choice": 2, "ns_boundary": 2, "block_size_x": 24, "block_size_y": 20}, True),
+    ("gx3v7", {"solver_choice": 2}, False),
+    ("gx1v7", {"solver_choice": 2}, False),
+    ("gx1v7", {"solver_choice": 2, "block_size_y": 96}, False),
 ])
 def test_persistent_pcg_is_bitwise_the_fused_pcg(pkg, name, kw, grid):
     """pop_tuning.pcg_persist: the whole pcg solve of a small 2-D system as one resident launch (kernels_pcg_persist.hpp) -- the
@@ -1168,7 +1176,7 @@ def test_persistent_pcg_is_bitwise_the_fused_pcg(pkg, name, kw, grid):
         used += b.dim("pcg_persist_used")
         assert a.dim("pcg_persist_used") == 0
     assert used == (0 if name == "test" else 5)
-    if kw.get("block_size_y") == 48:
+    if kw.get("block_size_y") == 48 and kw.get("solver_choice", 1) == 1:
         assert (b.dim("pcg_persist_workgroups"), b.dim("pcg_persist_chunks_per_workgroup")) == (144, 4)
     for f in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER", "GRADPX"):
         assert np.array_equal(a.get(f), b.get(f)), f
