@@ -1,10 +1,10 @@
 // kernels_pcg_persist.hpp -- the whole preconditioned conjugate-gradient solve (POP_SolversMod.F90:1200-1503, diagonal
-// preconditioner) of a SMALL 2-D system as ONE resident launch (round 4; pop_tuning.pcg_persist).
+// preconditioner) of a SMALL 2-D system as ONE resident launch (round 4; pop_tuning.pcg_persist); the ChronGear iterations likewise (k_cg_persist, below).
 //
 // On grids whose ten solver vectors are a few megabytes (gx1v7: 122 880 points) the fused two-launch iteration of
 // kernels_barotropic.hpp sits at the floor of a dependent launch: 2 x ~5 us of launch boundary + the in-kernel total of the
 // previous launch's partials = 14 us per iteration for ~1 us of arithmetic, and at N > 1 that solve is replicated on every rank, so
-// it is the part of the step that does not shard.  Here at most 128 workgroups stay resident for the whole solve.  A workgroup owns
+// it is the part of the step that does not shard.  Here at most 250 workgroups (one per CU) stay resident for the whole solve.  A workgroup owns
 // CP consecutive 256-cell chunks (the chunks and partial slots of the fused kernels); x, s and z of its cells AND of every cell its
 // stencils read (its "window": own cells, then the halo cells, then one cell that holds zeros for the fill value of closed
 // boundaries) live in LDS, r, q, the nine weights and the window indices of the eight neighbours in registers, for all iterations.
