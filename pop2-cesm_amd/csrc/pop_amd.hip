@@ -116,6 +116,7 @@ struct pop_ctx {
   double *persist_out = nullptr;                           // pinned: iterations, (r,r), status, checks
   int persist_used = 0;                                    // the last pcg solve ran as the resident launch
   int persist_gave_up = 0;                                 // resident solves that gave up a wait (then never used again in this model)
+  int red_active_total = 0;                                // fused solver kernels: chunks that have work, summed over the local blocks
   int persist_nwg = 0, persist_cp = 0;                     // shape of the last resident launch
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
   bool reg_thomas_t = true;
@@ -1917,6 +1918,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
         (is_land && !(b == 0 && k == 0) ? land[b] : act[b]).push_back(k);
       }
       longest = std::max(longest, act[b].size());
+      c->red_active_total += (int)act[b].size();
     }
     // launch order: workgroup w runs on XCD w % 8; XCD x takes one contiguous band of the chunks with ocean (as red_band does
     // for the full launch), so the rows j +- 1 of the 9-point matvec are in the L2 that fetched row j.  The publishing workgroup
@@ -2216,6 +2218,9 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "solver_iterations_enqueued") return (int)c->solver_enq;
   if (n == "rank") return c->h.rank;
   if (n == "nranks") return c->h.nranks;
+  if (n == "solver_chunks_per_block") return c->nchunk;                 // 256-cell chunks of a block (the full launch of the fused solver kernels)
+  if (n == "solver_chunks_listed") return c->red_act ? c->red_nact : -1;  // compacted launch: workgroups per block (-1: no list, every chunk is launched)
+  if (n == "solver_chunks_active") return c->red_active_total;          // chunks with an ocean cell (or work for another rank), all local blocks
   if (n == "pcg_persist_used") return c->persist_used;
   if (n == "pcg_persist_gave_up") return c->persist_gave_up;
   if (n == "pcg_persist_workgroups") return c->persist_nwg;
