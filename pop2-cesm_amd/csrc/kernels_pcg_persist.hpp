@@ -86,9 +86,11 @@ template <int CP>
 __global__ void __launch_bounds__(POP_RED_THREADS)
 k_pcg_persist(PersistArgs a) {
   extern __shared__ double lds[];                          // Xw | Sw | Zw, nwin doubles each
-  constexpr int NSH = CP > POP_PERSIST_MAXP ? CP : POP_PERSIST_MAXP;
-  __shared__ double sh[NSH][POP_RED_THREADS];              // the chunk trees, then the trees of the blocks' totals
-  __shared__ double sh_tot[POP_PERSIST_MAXP];
+  // the chunk trees and the trees of the blocks' totals in arrays of their own, the totals double-buffered by the parity of the exchange:
+  // three barriers per exchange (values in, block sums in, totals out) -- a value is overwritten only two or more barriers after its last read
+  __shared__ double sh[CP][POP_RED_THREADS];
+  __shared__ double shb[POP_PERSIST_MAXP][POP_RED_THREADS];
+  __shared__ double sh_tot[2][POP_PERSIST_MAXP];
   __shared__ int dead;
   constexpr int NT = POP_RED_THREADS, NOWN = CP * NT;
   const int t = threadIdx.x, w = blockIdx.x;
@@ -132,23 +134,17 @@ k_pcg_persist(PersistArgs a) {
 #pragma unroll
     for (int u = 0; u < CP; ++u) sh[u][t] = v[u];
     __syncthreads();
-    for (int s = NT / 2; s >= 64; s >>= 1) {
-      if (t < s) {
-#pragma unroll
-        for (int u = 0; u < CP; ++u) sh[u][t] = sh[u][t] + sh[u][t + s];
-      }
-      __syncthreads();
-    }
     const unsigned long long ptag = a.epoch | (unsigned long long)(unsigned)phase, ztag = a.epoch | (unsigned long long)(unsigned)m | 0x80000000ULL;
     const long long pbase = (long long)(phase & 1) * a.nslots;                       // in PWords from a.W
     const long long zbase = 2LL * a.nslots + (long long)(m & 1) * a.ncell;
-    if (t < 64) {
-#pragma unroll
-      for (int u = 0; u < CP; ++u) {
-        const double x = tree_tail64(sh[u][t]);
-        const int slot = w * CP + u;
-        if (t == 0 && slot < a.nslots) st_pword(a.W + pbase + slot, x, ptag);
-      }
+    // the tree of wg_reduce_store over the 256 values of a chunk, one WAVE per chunk: lane l forms what the two LDS steps leave in
+    // element l -- (v[l] + v[l+128]) + (v[l+64] + v[l+192]) -- and the wave finishes with tree_tail64: no barrier between the steps,
+    // and the chunks of a workgroup (the blocks of a view, below) go through their trees side by side instead of one after the other
+    const int wave = t >> 6, lane = t & 63;
+    for (int u = wave; u < CP; u += 4) {
+      const double x = tree_tail64((sh[u][lane] + sh[u][lane + 128]) + (sh[u][lane + 64] + sh[u][lane + 192]));
+      const int slot = w * CP + u;
+      if (lane == 0 && slot < a.nslots) st_pword(a.W + pbase + slot, x, ptag);
     }
     // what this thread collects: slots b * nchunk + c, c = t, t + 256, ... of every block, and (with_z) its halo cells; a load it does
     // not need is aimed at the first word of the phase and accepted whatever its tag.  (Forming these once before the iteration loop
@@ -196,27 +192,22 @@ k_pcg_persist(PersistArgs a) {
     // the rule of fused_total: per block the thread-strided left-to-right sum, the fixed tree, blocks in order -- the trees of all blocks
     // side by side (one set of barriers; with the eight bands of an 8-rank decomposition in one view, eight trees one after the other
     // were 5 us of every exchange)
-    const int nb = a.nblocks;
-    __syncthreads();                                         // the chunk trees above have been read
+    const int nb = a.nblocks, par = phase & 1;
     for (int b = 0; b < nb; ++b) {
       double x = 0.0;
 #pragma unroll
       for (int k = 0; k < POP_PERSIST_MAXP; ++k)
         if (kb[k] == b) x = x + __longlong_as_double((long long)pv[k]);
-      sh[b][t] = x;
+      shb[b][t] = x;
     }
     __syncthreads();
-    for (int s = NT / 2; s >= 64; s >>= 1) {
-      if (t < s)
-        for (int b = 0; b < nb; ++b) sh[b][t] = sh[b][t] + sh[b][t + s];
-      __syncthreads();
+    for (int b = wave; b < nb; b += 4) {
+      const double y = tree_tail64((shb[b][lane] + shb[b][lane + 128]) + (shb[b][lane + 64] + shb[b][lane + 192]));
+      if (lane == 0) sh_tot[par][b] = y;
     }
-    if (t < 64)
-      for (int b = 0; b < nb; ++b) { const double y = tree_tail64(sh[b][t]); if (t == 0) sh_tot[b] = y; }
     __syncthreads();
     double total = 0.0;
-    for (int b = 0; b < nb; ++b) total = total + sh_tot[b];
-    __syncthreads();
+    for (int b = 0; b < nb; ++b) total = total + sh_tot[par][b];
     ++phase;
     return total;
   };
@@ -321,9 +312,9 @@ __global__ void __launch_bounds__(POP_RED_THREADS)
 k_cg_persist(CgPersistArgs ca) {
   const PersistArgs &a = ca.p;
   extern __shared__ double lds[];                          // Xw | Sw | Zw, nwin doubles each
-  constexpr int NSH = CP > POP_CGP_MAXP ? CP : POP_CGP_MAXP;
-  __shared__ double sh[2][NSH][POP_RED_THREADS];
-  __shared__ double sh_tot[2][POP_CGP_MAXP];
+  __shared__ double sh[2][CP][POP_RED_THREADS];            // (arrays and barriers as in k_pcg_persist)
+  __shared__ double shb[2][POP_CGP_MAXP][POP_RED_THREADS];
+  __shared__ double sh_tot[2][2][POP_CGP_MAXP];
   __shared__ int dead;
   constexpr int NT = POP_RED_THREADS, NOWN = CP * NT;
   const int t = threadIdx.x, w = blockIdx.x;
@@ -394,26 +385,14 @@ k_cg_persist(CgPersistArgs ca) {
 #pragma unroll
       for (int u = 0; u < CP; ++u) sh[f][u][t] = v[f][u];
     __syncthreads();
-    for (int s = NT / 2; s >= 64; s >>= 1) {
-      if (t < s) {
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-          for (int u = 0; u < CP; ++u) sh[f][u][t] = sh[f][u][t] + sh[f][u][t + s];
-      }
-      __syncthreads();
-    }
     const unsigned long long ptag = a.epoch | (unsigned long long)(unsigned)phase;
     const long long pbase = (long long)(phase & 1) * 2 * a.nslots;               // [field][slot] inside the buffer of the phase
-    if (t < 64) {
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int u = 0; u < CP; ++u) {
-          const double x = tree_tail64(sh[f][u][t]);
-          const int slot = w * CP + u;
-          if (t == 0 && slot < a.nslots && f < nf) st_pword(a.W + pbase + (long long)f * a.nslots + slot, x, ptag);
-        }
+    const int wave = t >> 6, lane = t & 63;                                      // one wave per (field, chunk) tree: see k_pcg_persist
+    for (int e = wave; e < 2 * CP; e += 4) {
+      const int f = e / CP, u = e % CP;
+      const double x = tree_tail64((sh[f][u][lane] + sh[f][u][lane + 128]) + (sh[f][u][lane + 64] + sh[f][u][lane + 192]));
+      const int slot = w * CP + u;
+      if (lane == 0 && slot < a.nslots && f < nf) st_pword(a.W + pbase + (long long)f * a.nslots + slot, x, ptag);
     }
     const int per_b = (a.nchunk - t + NT - 1) / NT;
     unsigned off[14]; bool need[14]; int kb[POP_CGP_MAXP];
@@ -439,30 +418,23 @@ k_cg_persist(CgPersistArgs ca) {
       if ((tries & 255) == 0) { const unsigned long long now = wall_clock64(); if (tries == 0) t0 = now; else if (now - t0 > a.wait_ticks) { dead = 1; break; } }
       __builtin_amdgcn_s_sleep(1);
     }
-    const int nbk = a.nblocks;
-    __syncthreads();
+    const int nbk = a.nblocks, par = phase & 1;
     for (int b = 0; b < nbk; ++b) {
       double x0 = 0.0, x1 = 0.0;
 #pragma unroll
       for (int k = 0; k < POP_CGP_MAXP; ++k)
         if (kb[k] == b) { x0 = x0 + pword_value(got[k]); x1 = x1 + pword_value(got[POP_CGP_MAXP + k]); }
-      sh[0][b][t] = x0; sh[1][b][t] = x1;
+      shb[0][b][t] = x0; shb[1][b][t] = x1;
     }
     __syncthreads();
-    for (int s = NT / 2; s >= 64; s >>= 1) {
-      if (t < s)
-        for (int b = 0; b < nbk; ++b) { sh[0][b][t] = sh[0][b][t] + sh[0][b][t + s]; sh[1][b][t] = sh[1][b][t] + sh[1][b][t + s]; }
-      __syncthreads();
+    for (int e = wave; e < 2 * nbk; e += 4) {
+      const int f = e & 1, b = e >> 1;
+      const double y = tree_tail64((shb[f][b][lane] + shb[f][b][lane + 128]) + (shb[f][b][lane + 64] + shb[f][b][lane + 192]));
+      if (lane == 0) sh_tot[par][f][b] = y;
     }
-    if (t < 64)
-      for (int b = 0; b < nbk; ++b) {
-        const double y0 = tree_tail64(sh[0][b][t]), y1 = tree_tail64(sh[1][b][t]);
-        if (t == 0) { sh_tot[0][b] = y0; sh_tot[1][b] = y1; }
-      }
     __syncthreads();
     tot[0] = 0.0; tot[1] = 0.0;
-    for (int b = 0; b < nbk; ++b) { tot[0] = tot[0] + sh_tot[0][b]; tot[1] = tot[1] + sh_tot[1][b]; }
-    __syncthreads();
+    for (int b = 0; b < nbk; ++b) { tot[0] = tot[0] + sh_tot[par][0][b]; tot[1] = tot[1] + sh_tot[par][1][b]; }
     ++phase;
   };
   auto apply = [&](const double *W, int u) -> double {
