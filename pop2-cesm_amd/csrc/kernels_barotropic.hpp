@@ -138,17 +138,12 @@ __device__ __forceinline__ void wg_reduce_store(double (&v)[NF], double *partial
 #pragma unroll
   for (int f = 0; f < NF; ++f) sh[f][t] = v[f];
   __syncthreads();
-  for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
-    if (t < s) {
-#pragma unroll
-      for (int f = 0; f < NF; ++f) sh[f][t] = sh[f][t] + sh[f][t + s];
-    }
-    __syncthreads();
-  }
+  // the fixed tree (LDS steps 128, 64, then the shuffles of tree_tail64) without a barrier inside it (round 4): lane l of ONE wave forms what the two
+  // LDS steps leave in element l, (v[l] + v[l+128]) + (v[l+64] + v[l+192]) -- the same additions in the same order
   if (t < 64) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const double x = tree_tail64(sh[f][t]);
+      const double x = tree_tail64((sh[f][t] + sh[f][t + 128]) + (sh[f][t + 64] + sh[f][t + 192]));
       if (t == 0) partial[(long long)slot * NF + f] = x;
     }
   }
@@ -746,10 +741,12 @@ __device__ __forceinline__ double presummed_total(const double *__restrict__ bs,
 }
 // ordered total of workgroup partials: per POP block a thread-strided sequential sum + fixed tree,
 // block sums added in block order.  Every thread returns the same value.  (r4: the levels 32 .. 1 of the tree inside the first
-// wavefront, as in wg_reduce_store -- the operands and the order of shf[t] + shf[t + s] -- three barriers per block instead of nine.)
+// wavefront, as in wg_reduce_store -- the operands and the order of shf[t] + shf[t + s] -- and, later in r4, the two LDS levels formed by the
+// lanes of that wavefront themselves: two barriers per block.)
 __device__ __forceinline__ double fused_total(const double *__restrict__ partial, int nchunk, int nblocks,
                                               const double *__restrict__ bs, int presummed) {
   __shared__ double shf[POP_RED_THREADS];
+  __shared__ double shf_tot;
   const int t = threadIdx.x;
   double total = 0.0;
   if (presummed) return presummed_total(bs, nblocks);   // block sums already formed (same ordered rule): add in block order
@@ -758,14 +755,9 @@ __device__ __forceinline__ double fused_total(const double *__restrict__ partial
     for (int c = t; c < nchunk; c += POP_RED_THREADS) v = v + partial[(long long)b * nchunk + c];
     shf[t] = v;
     __syncthreads();
-    for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
-      if (t < s) shf[t] = shf[t] + shf[t + s];
-      __syncthreads();
-    }
-    if (t < 64) { const double x = tree_tail64(shf[t]); if (t == 0) shf[0] = x; }
+    if (t < 64) { const double x = tree_tail64((shf[t] + shf[t + 128]) + (shf[t + 64] + shf[t + 192])); if (t == 0) shf_tot = x; }
     __syncthreads();
-    total = total + shf[0];
-    __syncthreads();
+    total = total + shf_tot;
   }
   return total;
 }
@@ -868,13 +860,10 @@ k_fpcg_a_pair(DevGrid g, FusedArgs a) {
     sh[u][t] = v;
   }
   __syncthreads();
-  for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
-    if (t < s) { sh[0][t] = sh[0][t] + sh[0][t + s]; sh[1][t] = sh[1][t] + sh[1][t + s]; }
-    __syncthreads();
-  }
-  if (t < 64) {
-    const double x0 = tree_tail64(sh[0][t]), x1 = tree_tail64(sh[1][t]);
-    if (t == 0) { a.partA[(long long)b * a.nchunk + ch[0]] = x0; a.partA[(long long)b * a.nchunk + ch[1]] = x1; }
+  if (t < 128) {   // the two chunks' trees in two waves, no barrier inside a tree (see wg_reduce_store)
+    const int u = t >> 6, l = t & 63;
+    const double x = tree_tail64((sh[u][l] + sh[u][l + 128]) + (sh[u][l + 64] + sh[u][l + 192]));
+    if (l == 0) a.partA[(long long)b * a.nchunk + ch[u]] = x;
   }
 }
 
@@ -1248,12 +1237,8 @@ k_fpcg_b2(DevGrid g, FusedArgs a) {
   // the tree of wg_reduce_store<1> over the 256 cells of the chunk
   sh[2 * t] = v0; sh[2 * t + 1] = v1;
   __syncthreads();
-  for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
-    if (t < s) sh[t] = sh[t] + sh[t + s];
-    __syncthreads();
-  }
-  if (t < 64) {
-    const double x = tree_tail64(sh[t]);
+  if (t < 64) {   // (one wave, no barrier inside the tree: see wg_reduce_store)
+    const double x = tree_tail64((sh[t] + sh[t + 128]) + (sh[t + 64] + sh[t + 192]));
     if (t == 0) a.partB[(long long)b * a.nchunk + red_chunk(g)] = x;
   }
 }
