@@ -215,16 +215,9 @@ __device__ __forceinline__ void block_sum_ordered(const double *__restrict__ pb,
 #pragma unroll
   for (int f = 0; f < NF; ++f) sh[f][t] = v[f];
   __syncthreads();
-  for (int s = POP_RED_THREADS / 2; s >= 64; s >>= 1) {
-    if (t < s) {
+  // out is used by thread 0 only (every caller stores from threadIdx.x == 0); the tree without a barrier inside it (see wg_reduce_store)
 #pragma unroll
-      for (int f = 0; f < NF; ++f) sh[f][t] = sh[f][t] + sh[f][t + s];
-    }
-    __syncthreads();
-  }
-  // out is used by thread 0 only (every caller stores from threadIdx.x == 0)
-#pragma unroll
-  for (int f = 0; f < NF; ++f) out[f] = (t < 64) ? tree_tail64(sh[f][t]) : 0.0;
+  for (int f = 0; f < NF; ++f) out[f] = (t < 64) ? tree_tail64((sh[f][t] + sh[f][t + 128]) + (sh[f][t + 64] + sh[f][t + 192])) : 0.0;
 }
 template <int NF>
 __global__ void __launch_bounds__(POP_RED_THREADS) k_block_sums(const double *__restrict__ partial, int nchunk, const int *__restrict__ gid,
