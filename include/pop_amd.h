@@ -171,7 +171,7 @@ typedef struct pop_tuning {
   int gm_sf_stored;        /* 0: Gent-McWilliams without cancellation: the stream-function terms SF_SLX / SF_SLY re-derived in the flux kernel instead of stored */
   int state3d_levels;      /* density of a whole 3-D array: levels per thread, 4 (default) | 2 | 8 with the per-level EOS coefficients read from
                             * a table, 1 = one cell per thread with the coefficients formed in place */
-  int pcg_persist;         /* pcg and ChronGear with the diagonal preconditioner on small 2-D systems (<= 2000 chunks of 256 cells in <= 8 blocks, single rank or the replicated solve):
+  int pcg_persist;         /* pcg, ChronGear and P-CSI with the diagonal preconditioner on small 2-D systems (<= 2000 chunks of 256 cells in <= 8 blocks, single rank or the replicated solve):
                             * 1 (the default where it applies) = the whole solve as ONE resident launch, vectors in LDS / registers, workgroups exchanging partials and halo z through
                             * tagged 16-byte memory words (kernels_pcg_persist.hpp); 0 = the two-launch fused iteration; 2 | 4 | 8: measurement only, that many chunks per workgroup */
   int gm_flux_tile;        /* 0: Gent-McWilliams fluxes cell by cell (every horizontal face flux evaluated in both cells that share it) instead of once per face in 64 x 4 tiles */

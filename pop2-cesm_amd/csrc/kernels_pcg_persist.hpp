@@ -515,4 +515,191 @@ k_cg_persist(CgPersistArgs ca) {
   (void)sq_;
 }
 
+
+// ---- P-CSI (POP_SolversMod.F90:1510-1835, diagonal preconditioner) of a small 2-D system as one resident launch (round 4) ----------------
+// The iterations of solver_pcsi_fused after its start-up step.  P-CSI has no inner product: per iteration dx = omega_k r' + (gamma omega_k
+// - 1) dx, x += dx, r = b - A x, r' = r / diag -- so what crosses workgroups per iteration is r' of the cells in somebody's halo, and a
+// workgroup waits for its NEIGHBOURS only (tagged words, two buffers by the parity of the iteration: a workgroup can be one iteration
+// ahead of a neighbour, never two, because it needs that neighbour's r' of the iteration before).  dx and x at the halo cells are advanced
+// by the reader with the owner's arithmetic, as k_pcsi_step does for its eight neighbours.  Only the convergence checks (every `freq`
+// iterations from `start` on) are grid-wide: the chunk partials of (r, r) by the tree of wg_reduce_store, their total by the rule of
+// k_rr_total.  Bitwise the fused form (tests/test_gpu_parity.py::test_persistent_pcg_is_bitwise_the_fused_pcg).
+struct PcsiPersistArgs {
+  PersistArgs p;                         // X (out: the solution array), Bv, C, weights, mask, plan, W, epoch, limits, out
+  const double *Xin, *Rin, *Qin;         // x, r' and dx after the start-up step
+  const double *A0R, *omega;             // 1 / diag; omega_k (1-based)
+  double csy;
+  int start;                             // first iteration count at which a check is made (convergenceCheckStart)
+};
+
+template <int CP>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_pcsi_persist(PcsiPersistArgs pa) {
+  const PersistArgs &a = pa.p;
+  extern __shared__ double lds[];                          // Xw | Qw | Rw, nwin doubles each
+  __shared__ double sh[CP][POP_RED_THREADS];
+  __shared__ double shb[POP_PERSIST_MAXP][POP_RED_THREADS];
+  __shared__ double sh_tot[2][POP_PERSIST_MAXP];
+  __shared__ int dead;
+  constexpr int NT = POP_RED_THREADS, NOWN = CP * NT;
+  const int t = threadIdx.x, w = blockIdx.x;
+  const int h0 = a.halo_off[w], nhalo = a.halo_off[w + 1] - h0, nwin = NOWN + nhalo + 1;
+  double *Xw = lds, *Qw = lds + nwin, *Rw = lds + 2 * nwin;
+  if (t == 0) dead = 0;
+  int q[CP]; bool inner[CP];
+  double cw[CP], mk[CP], wv[CP][8], bv[CP], a0r[CP];
+  unsigned short nb[CP][8];
+#pragma unroll
+  for (int u = 0; u < CP; ++u) {
+    const long long L = (long long)w * NOWN + u * NT + t;
+    q[u] = a.own_q[L];
+    inner[u] = q[u] >= 0;
+    const long long qc = inner[u] ? q[u] : 0;
+    const int nxb = a.nxb;
+    cw[u] = a.C[qc]; mk[u] = (double)a.mMask8[qc]; bv[u] = a.Bv[qc]; a0r[u] = pa.A0R[qc];
+    const long long qs = (qc - nxb - 1 >= 0) ? qc : (long long)nxb + 1;
+    wv[u][0] = a.WNo[qs]; wv[u][1] = a.WNo[qs - nxb]; wv[u][2] = a.WEa[qs]; wv[u][3] = a.WEa[qs - 1];
+    wv[u][4] = a.WNE[qs]; wv[u][5] = a.WNE[qs - nxb]; wv[u][6] = a.WNE[qs - 1]; wv[u][7] = a.WNE[qs - 1 - nxb];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) nb[u][n] = a.nbr[L * 8 + n];
+  }
+  for (int L = t; L < nwin; L += NT) {
+    int qL = -1;
+    if (L < NOWN) qL = a.own_q[(long long)w * NOWN + L];
+    else if (L < NOWN + nhalo) qL = a.halo_q[h0 + L - NOWN];
+    Xw[L] = qL >= 0 ? pa.Xin[qL] : 0.0; Qw[L] = qL >= 0 ? pa.Qin[qL] : 0.0; Rw[L] = qL >= 0 ? pa.Rin[qL] : 0.0;
+  }
+  __syncthreads();
+
+  int phase = 0;
+  // r' of the halo cells as published in iteration m (tag m)
+  auto halo_r = [&](int m) {
+    const unsigned long long ztag = a.epoch | (unsigned long long)(unsigned)m | 0x80000000ULL;
+    const long long zbase = 4LL * a.nslots + (long long)(m & 1) * a.ncell;
+    unsigned off[14]; bool need[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+      const int hh = t + (k % POP_PERSIST_MAXH) * NT;
+      need[k] = k < POP_PERSIST_MAXH && hh < nhalo;
+      off[k] = (unsigned)((need[k] ? zbase + a.halo_q[h0 + hh] : zbase) * (long long)sizeof(PWord));
+    }
+    pword4 got[14];
+    unsigned long long t0 = 0;
+    for (int tries = 0;; ++tries) {
+      ld_pwords14(a.W, off, got);
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < POP_PERSIST_MAXH; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == ztag);
+      if (ok) break;
+      if (*(volatile int *)&dead) break;
+      if ((tries & 255) == 0) { const unsigned long long now = wall_clock64(); if (tries == 0) t0 = now; else if (now - t0 > a.wait_ticks) { dead = 1; break; } }
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < POP_PERSIST_MAXH; ++k) { const int hh = t + k * NT; if (hh < nhalo) Rw[NOWN + hh] = pword_value(got[k]); }
+  };
+  // the grid-wide total of the chunk partials of v (the checks): as k_pcg_persist's exchange without halo words
+  auto exchange = [&](double (&v)[CP]) -> double {
+#pragma unroll
+    for (int u = 0; u < CP; ++u) sh[u][t] = v[u];
+    __syncthreads();
+    const unsigned long long ptag = a.epoch | (unsigned long long)(unsigned)phase;
+    const long long pbase = (long long)(phase & 1) * 2 * a.nslots;
+    const int wave = t >> 6, lane = t & 63;
+    for (int u = wave; u < CP; u += 4) {
+      const double x = tree_tail64((sh[u][lane] + sh[u][lane + 128]) + (sh[u][lane + 64] + sh[u][lane + 192]));
+      const int slot = w * CP + u;
+      if (lane == 0 && slot < a.nslots) st_pword(a.W + pbase + slot, x, ptag);
+    }
+    const int per_b = (a.nchunk - t + NT - 1) / NT;
+    unsigned off[14]; bool need[14]; int kb[POP_PERSIST_MAXP];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) {
+      const int kk = k < POP_PERSIST_MAXP ? k : 0;
+      const int b = per_b > 0 ? kk / per_b : a.nblocks, c = per_b > 0 ? t + (kk % per_b) * NT : 0;
+      need[k] = k < POP_PERSIST_MAXP && b < a.nblocks;
+      if (k < POP_PERSIST_MAXP) kb[k] = need[k] ? b : -1;
+      off[k] = (unsigned)((pbase + (need[k] ? (long long)b * a.nchunk + c : 0)) * (long long)sizeof(PWord));
+    }
+    pword4 got[14];
+    unsigned long long t0 = 0;
+    for (int tries = 0;; ++tries) {
+      ld_pwords14(a.W, off, got);
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < POP_PERSIST_MAXP; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == ptag);
+      if (ok) break;
+      if (*(volatile int *)&dead) break;
+      if ((tries & 255) == 0) { const unsigned long long now = wall_clock64(); if (tries == 0) t0 = now; else if (now - t0 > a.wait_ticks) { dead = 1; break; } }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const int nbk = a.nblocks, par = phase & 1;
+    for (int b = 0; b < nbk; ++b) {
+      double x = 0.0;
+#pragma unroll
+      for (int k = 0; k < POP_PERSIST_MAXP; ++k)
+        if (kb[k] == b) x = x + pword_value(got[k]);
+      shb[b][t] = x;
+    }
+    __syncthreads();
+    for (int b = wave; b < nbk; b += 4) {
+      const double y = tree_tail64((shb[b][lane] + shb[b][lane + 128]) + (shb[b][lane + 64] + shb[b][lane + 192]));
+      if (lane == 0) sh_tot[par][b] = y;
+    }
+    __syncthreads();
+    double total = 0.0;
+    for (int b = 0; b < nbk; ++b) total = total + sh_tot[par][b];
+    ++phase;
+    return total;
+  };
+  auto apply = [&](const double *W, int u) -> double {
+    double ax = cw[u] * W[u * NT + t];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) ax = ax + wv[u][n] * W[nb[u][n]];
+    return ax;
+  };
+
+  double rr = 0.0;
+  int m = 0, nchecks = 0, converged = 0;
+  double v[CP];
+  while (m < a.max_iter) {
+    ++m;
+    // dx = omega r' + (gamma omega - 1) dx; x += dx -- at every window cell (own and halo: the owner's arithmetic)
+    const double om = pa.omega[m], cq = pa.csy * om - 1.0;
+    for (int L = t; L < nwin - 1; L += NT) {
+      const double dx = om * Rw[L] + cq * Qw[L];
+      Qw[L] = dx;
+      Xw[L] = Xw[L] + dx;
+    }
+    __syncthreads();
+    // r = b - A x, r' = r / diag at the own cells; r' published for the neighbours' halos
+    PWord *const Rn = a.W + 4LL * a.nslots + (long long)(m & 1) * a.ncell;
+    const unsigned long long ztag = a.epoch | (unsigned long long)(unsigned)m | 0x80000000ULL;
+    const bool check = (m % a.freq == 0) && m >= pa.start;
+#pragma unroll
+    for (int u = 0; u < CP; ++u) {
+      v[u] = 0.0;
+      if (inner[u]) {
+        const double r = bv[u] - apply(Xw, u);
+        const double rp = r * a0r[u];
+        Rw[u * NT + t] = rp;
+        st_pword(Rn + q[u], rp, ztag);
+        v[u] = (r * r) * mk[u];
+      }
+    }
+    if (check) {
+      rr = exchange(v);
+      ++nchecks;
+      if (rr < a.criterion) { converged = 1; break; }
+    }
+    halo_r(m);
+    __syncthreads();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < CP; ++u) if (inner[u]) a.X[q[u]] = Xw[u * NT + t];
+  if (w == 0 && t == 0) { a.out[0] = converged ? (double)m : (double)a.max_iter; a.out[1] = rr; a.out[3] = (double)nchecks; }
+  if (t == 0 && dead) a.out[2] = 1.0;
+}
+
 }  // namespace pop

@@ -1309,6 +1309,50 @@ int solver_pcsi_fused(pop_ctx *c) {
   }
   hipLaunchKernelGGL((k_pcsi_step<true, false>), G, B, 0, c->stream, c->g, pcsi_args(c, bf, 0, 0));
   if (c->use_evp && evp_apply(c, c->AZ, c->R)) return 1;
+  c->persist_used = 0;
+  if (!c->use_evp && !tun_off(c->h.tun.pcg_persist) && !c->persist_gave_up) {
+    // small views: the iterations as one resident launch (k_pcsi_persist: neighbour waits only, grid-wide exchanges at the checks)
+    SolveView v = local_view(c);
+    const FusedArgs fa = fused_args(c, v);
+    const pop_ctx::PersistPlan *pl = fa.presummed ? nullptr : persist_plan(c, v);
+    if (pl) {
+      const long long ncell = (long long)v.g.n2 * v.g.nblocks;
+      PcsiPersistArgs pa{};
+      PersistArgs &a = pa.p;
+      a.X = bf.X[0]; a.Bv = c->RHS; a.C = c->centerWgt; a.WNo = v.g.WNo; a.WEa = v.g.WEa; a.WNE = v.g.WNE; a.mMask8 = v.g.mMask8;
+      a.nxb = v.g.nxb; a.nchunk = v.nchunk; a.nblocks = v.g.nblocks; a.nslots = pl->nslots; a.ncell = ncell;
+      a.own_q = pl->own_q; a.nbr = pl->nbr; a.halo_off = pl->halo_off; a.halo_q = pl->halo_q; a.W = pl->W;
+      a.epoch = (++c->persist_epoch) << 32;
+      a.max_iter = cf.max_iterations; a.freq = freq; a.criterion = c->h.convergenceCriterion; a.out = c->persist_out; a.wait_ticks = 200000000ULL;
+      pa.Xin = bf.X[1]; pa.Rin = bf.R[1]; pa.Qin = bf.Q[1]; pa.A0R = c->S0; pa.omega = c->pcsi_omega; pa.csy = c->pcsi_csy; pa.start = start;
+      c->persist_out[0] = -1.0; c->persist_out[1] = 0.0; c->persist_out[2] = 0.0; c->persist_out[3] = 0.0;
+      const size_t lds = (size_t)3 * pl->nwin_max * sizeof(double);
+      const dim3 GP(pl->nwg);
+      switch (pl->CP) {
+        case 1: hipLaunchKernelGGL(k_pcsi_persist<1>, GP, B, lds, c->stream, pa); break;
+        case 2: hipLaunchKernelGGL(k_pcsi_persist<2>, GP, B, lds, c->stream, pa); break;
+        case 4: hipLaunchKernelGGL(k_pcsi_persist<4>, GP, B, lds, c->stream, pa); break;
+        default: hipLaunchKernelGGL(k_pcsi_persist<8>, GP, B, lds, c->stream, pa); break;
+      }
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipEventRecord(c->chk_ev[0], c->stream));
+      HIPCHK(c, hipEventSynchronize(c->chk_ev[0]));
+      if (c->persist_out[2] == 0.0 && c->persist_out[0] >= 0.0) {
+        c->numIterations = (int)c->persist_out[0];
+        c->rmsResidual = std::sqrt(c->persist_out[1] * c->h.residualNorm);
+        c->persist_used = 1; c->persist_nwg = pl->nwg; c->persist_cp = pl->CP;
+        hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, c->stream, bf.X[0], c->srcmap, ncell);
+        HIPCHK(c, hipGetLastError());
+        const bool conv = c->persist_out[3] > 0.0 && c->persist_out[1] < c->h.convergenceCriterion;
+        if (!conv && c->h.convergenceCriterion != 0.0) { c->err = "POP_SolversPCSI: solver not converged"; return 2; }
+        return 0;
+      }
+      // a wait gave up: the launch wrote its solution array only at its end (x of the start-up step is still in the other half of the pair,
+      // r', dx were only read): the iterations are repeated by the launches below, and the resident form is not used again in this model
+      c->persist_gave_up += 1;
+      fprintf(stderr, "libpop_amd: resident P-CSI: a wait for another workgroup's data gave up -- continuing with one launch per iteration\n");
+    }
+  }
   if (pcsi_grid(c).red_act)   // compacted launches from here on: the partials of the chunks that are left out must read as zero
     HIPCHK(c, hipMemsetAsync(c->partial, 0, (size_t)c->nchunk * c->g.nblocks * 2 * sizeof(double), c->stream));
   int in = 1;
@@ -2123,8 +2167,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
   // KPP look-ahead (bandwidth-bound grids; POP_KPP_AHEAD=0|1 overrides): second set of KPP outputs, own stream
   // ... and (round 4) small grids whose pcg solve is the one resident launch: that launch keeps at most one workgroup per CU busy waiting
   // on memory for 2 ms, the KPP kernels of the next step fill the rest (gx1v7: 3.26 -> 3.09, 3.36 -> 3.18 ms per step, A/B on one box)
-  // (pcg only: beside the resident ChronGear the look-ahead costs more than it hides -- 3.08 -> 3.34 ms per step, its neighbour waits are hit harder)
-  const bool resident_solve = cfg->solver_choice == 1 && !use_evp(*cfg) && !tun_off(h.tun.pcg_persist) && h.nranks == 1 && h.nblocks <= 8 &&
+  // (pcg and P-CSI -- 1.85 -> 1.81 ms there; beside the resident ChronGear the look-ahead costs more than it hides: 3.08 -> 3.34 ms per step)
+  const bool resident_solve = (cfg->solver_choice == 1 || cfg->solver_choice == 3) && !use_evp(*cfg) && !tun_off(h.tun.pcg_persist) && h.nranks == 1 && h.nblocks <= 8 &&
                               h.n2 * h.nblocks <= 250u * 8u * 256u;
   c->ahead_enabled = cfg->vmix_choice == 3 && c->side && (h.n2 * h.nblocks > (1u << 19) || resident_solve);
   if (tun_set(h.tun.kpp_ahead)) c->ahead_enabled = cfg->vmix_choice == 3 && c->side && h.tun.kpp_ahead != 0;

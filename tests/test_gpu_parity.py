@@ -1160,6 +1160,14 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
     ("gx3v7", {"solver_choice": 2}, False),
     ("gx1v7", {"solver_choice": 2}, False),
     ("gx1v7", {"solver_choice": 2, "block_size_y": 96}, False),
+    # P-CSI (k_pcsi_persist): neighbour waits per iteration, grid-wide exchanges only at the checks
+    ("tiny", {"solver_choice": 3, "block_size_x": 24, "block_size_y": 20}, False),
+    ("tiny", {"solver_choice": 3, "block_size_x": 24, "block_size_y": 20, "ew_boundary": 0, "stepped_bathymetry": 1}, False),
+    ("tiny", {"solver_choice": 3, "block_size_x": 28, "block_size_y": 24, "convergence_check_freq": 4, "max_iterations": 203, "convergence_check_start": 8}, False),
+    ("tiny", {"solver_choice": 3, "ns_boundary": 2, "block_size_x": 24, "block_size_y": 20}, True),
+    ("gx3v7", {"solver_choice": 3}, False),
+    ("gx1v7", {"solver_choice": 3}, False),
+    ("gx1v7", {"solver_choice": 3, "block_size_y": 96}, False),
 ])
 def test_persistent_pcg_is_bitwise_the_fused_pcg(pkg, name, kw, grid):
     """pop_tuning.pcg_persist: the whole pcg solve of a small 2-D system as one resident launch (kernels_pcg_persist.hpp) -- the
