@@ -1,5 +1,5 @@
 // kernels_pcg_persist.hpp -- the whole preconditioned conjugate-gradient solve (POP_SolversMod.F90:1200-1503, diagonal
-// preconditioner) of a SMALL 2-D system as ONE resident launch (round 4; pop_tuning.pcg_persist); the ChronGear iterations likewise (k_cg_persist, below).
+// preconditioner) of a SMALL 2-D system as ONE resident launch (round 4; pop_tuning.pcg_persist); the ChronGear and the P-CSI iterations likewise (k_cg_persist, k_pcsi_persist, below).
 //
 // On grids whose ten solver vectors are a few megabytes (gx1v7: 122 880 points) the fused two-launch iteration of
 // kernels_barotropic.hpp sits at the floor of a dependent launch: 2 x ~5 us of launch boundary + the in-kernel total of the
