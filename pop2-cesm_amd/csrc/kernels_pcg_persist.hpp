@@ -81,6 +81,26 @@ __device__ __forceinline__ void ld_pwords14(const PWord *base, const unsigned (&
 }
 __device__ __forceinline__ double pword_value(const pword4 &x) { return __longlong_as_double((long long)(((unsigned long long)x[1] << 32) | x[0])); }
 __device__ __forceinline__ unsigned long long pword_tag(const pword4 &x) { return ((unsigned long long)x[3] << 32) | x[2]; }
+// Polls fourteen words (ld_pwords14) until every one a thread needs carries the tag it waits for.  The bound is wall-clock time (100 MHz
+// counter), not a number of polls: after `ticks` the workgroup is marked dead (sticky, in LDS) and neither this nor any later wait of it spins.
+__device__ __forceinline__ void wait_pwords14(const PWord *W, const unsigned (&off)[14], const bool (&need)[14], const unsigned long long (&want)[14],
+                                              pword4 (&got)[14], int *dead, unsigned long long ticks) {
+  unsigned long long t0 = 0;
+  for (int tries = 0;; ++tries) {
+    ld_pwords14(W, off, got);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 14; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == want[k]);
+    if (ok) break;
+    if (*(volatile int *)dead) break;
+    if ((tries & 255) == 0) {
+      const unsigned long long now = wall_clock64();
+      if (tries == 0) t0 = now;
+      else if (now - t0 > ticks) { *dead = 1; break; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
 
 template <int CP>
 __global__ void __launch_bounds__(POP_RED_THREADS)
@@ -167,21 +187,7 @@ k_pcg_persist(PersistArgs a) {
       off[POP_PERSIST_MAXP + k] = (unsigned)((need[POP_PERSIST_MAXP + k] ? zbase + a.halo_q[h0 + hh] : pbase) * (long long)sizeof(PWord));
     }
     pword4 got[14];
-    unsigned long long t0 = 0;
-    for (int tries = 0;; ++tries) {
-      ld_pwords14(a.W, off, got);
-      bool ok = true;
-#pragma unroll
-      for (int k = 0; k < 14; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == want[k]);
-      if (ok) break;
-      if (*(volatile int *)&dead) break;
-      if ((tries & 255) == 0) {                              // the bound is wall-clock time (100 MHz counter), not a number of polls
-        const unsigned long long now = wall_clock64();
-        if (tries == 0) t0 = now;
-        else if (now - t0 > a.wait_ticks) { dead = 1; break; }
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
+    wait_pwords14(a.W, off, need, want, got, &dead, a.wait_ticks);
     unsigned long long pv[POP_PERSIST_MAXP];
 #pragma unroll
     for (int k = 0; k < POP_PERSIST_MAXP; ++k) pv[k] = need[k] ? (unsigned long long)__double_as_longlong(pword_value(got[k])) : 0ULL;
@@ -363,17 +369,10 @@ k_cg_persist(CgPersistArgs ca) {
       off[k] = (unsigned)((need[k] ? zbase + a.halo_q[h0 + hh] : zbase) * (long long)sizeof(PWord));
     }
     pword4 got[14];
-    unsigned long long t0 = 0;
-    for (int tries = 0;; ++tries) {
-      ld_pwords14(a.W, off, got);
-      bool ok = true;
+    unsigned long long want[14];
 #pragma unroll
-      for (int k = 0; k < POP_PERSIST_MAXH; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == ztag);
-      if (ok) break;
-      if (*(volatile int *)&dead) break;
-      if ((tries & 255) == 0) { const unsigned long long now = wall_clock64(); if (tries == 0) t0 = now; else if (now - t0 > a.wait_ticks) { dead = 1; break; } }
-      __builtin_amdgcn_s_sleep(1);
-    }
+    for (int k = 0; k < 14; ++k) want[k] = ztag;
+    wait_pwords14(a.W, off, need, want, got, &dead, a.wait_ticks);
 #pragma unroll
     for (int k = 0; k < POP_PERSIST_MAXH; ++k) { const int hh = t + k * NT; if (hh < nhalo) Zw[NOWN + hh] = pword_value(got[k]); }
     __syncthreads();
@@ -407,17 +406,10 @@ k_cg_persist(CgPersistArgs ca) {
       off[POP_CGP_MAXP + k] = (unsigned)((pbase + (nf > 1 ? a.nslots : 0) + sl) * (long long)sizeof(PWord));
     }
     pword4 got[14];
-    unsigned long long t0 = 0;
-    for (int tries = 0;; ++tries) {
-      ld_pwords14(a.W, off, got);
-      bool ok = true;
+    unsigned long long want[14];
 #pragma unroll
-      for (int k = 0; k < 14; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == ptag);
-      if (ok) break;
-      if (*(volatile int *)&dead) break;
-      if ((tries & 255) == 0) { const unsigned long long now = wall_clock64(); if (tries == 0) t0 = now; else if (now - t0 > a.wait_ticks) { dead = 1; break; } }
-      __builtin_amdgcn_s_sleep(1);
-    }
+    for (int k = 0; k < 14; ++k) want[k] = ptag;
+    wait_pwords14(a.W, off, need, want, got, &dead, a.wait_ticks);
     const int nbk = a.nblocks, par = phase & 1;
     for (int b = 0; b < nbk; ++b) {
       double x0 = 0.0, x1 = 0.0;
@@ -584,17 +576,10 @@ k_pcsi_persist(PcsiPersistArgs pa) {
       off[k] = (unsigned)((need[k] ? zbase + a.halo_q[h0 + hh] : zbase) * (long long)sizeof(PWord));
     }
     pword4 got[14];
-    unsigned long long t0 = 0;
-    for (int tries = 0;; ++tries) {
-      ld_pwords14(a.W, off, got);
-      bool ok = true;
+    unsigned long long want[14];
 #pragma unroll
-      for (int k = 0; k < POP_PERSIST_MAXH; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == ztag);
-      if (ok) break;
-      if (*(volatile int *)&dead) break;
-      if ((tries & 255) == 0) { const unsigned long long now = wall_clock64(); if (tries == 0) t0 = now; else if (now - t0 > a.wait_ticks) { dead = 1; break; } }
-      __builtin_amdgcn_s_sleep(1);
-    }
+    for (int k = 0; k < 14; ++k) want[k] = ztag;
+    wait_pwords14(a.W, off, need, want, got, &dead, a.wait_ticks);
 #pragma unroll
     for (int k = 0; k < POP_PERSIST_MAXH; ++k) { const int hh = t + k * NT; if (hh < nhalo) Rw[NOWN + hh] = pword_value(got[k]); }
   };
@@ -622,17 +607,10 @@ k_pcsi_persist(PcsiPersistArgs pa) {
       off[k] = (unsigned)((pbase + (need[k] ? (long long)b * a.nchunk + c : 0)) * (long long)sizeof(PWord));
     }
     pword4 got[14];
-    unsigned long long t0 = 0;
-    for (int tries = 0;; ++tries) {
-      ld_pwords14(a.W, off, got);
-      bool ok = true;
+    unsigned long long want[14];
 #pragma unroll
-      for (int k = 0; k < POP_PERSIST_MAXP; ++k) ok = ok && (!need[k] || pword_tag(got[k]) == ptag);
-      if (ok) break;
-      if (*(volatile int *)&dead) break;
-      if ((tries & 255) == 0) { const unsigned long long now = wall_clock64(); if (tries == 0) t0 = now; else if (now - t0 > a.wait_ticks) { dead = 1; break; } }
-      __builtin_amdgcn_s_sleep(1);
-    }
+    for (int k = 0; k < 14; ++k) want[k] = ptag;
+    wait_pwords14(a.W, off, need, want, got, &dead, a.wait_ticks);
     const int nbk = a.nblocks, par = phase & 1;
     for (int b = 0; b < nbk; ++b) {
       double x = 0.0;
