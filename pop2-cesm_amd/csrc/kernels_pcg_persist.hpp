@@ -260,8 +260,11 @@ k_pcg_persist(PersistArgs a) {
     // ---- step B (k_fpcg_b): [x += alpha s]; s = z + s beta at every window cell; q = A s; partial (q, s)
     const double bt = rz / eta0;
     eta1 = rz;
-    if (pending) advance_x(alpha);
-    for (int L = t; L < nwin - 1; L += NT) Sw[L] = Zw[L] + Sw[L] * bt;
+    for (int L = t; L < nwin - 1; L += NT) {               // one pass over the window: the pending x += alpha s, then the new s
+      const double so = Sw[L];
+      if (pending) Xw[L] = Xw[L] + alpha * so;
+      Sw[L] = Zw[L] + so * bt;
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < CP; ++u) {
