@@ -175,6 +175,8 @@ typedef struct pop_tuning {
                             * 1 (the default where it applies) = the whole solve as ONE resident launch, vectors in LDS / registers, workgroups exchanging partials and halo z through
                             * tagged 16-byte memory words (kernels_pcg_persist.hpp); 0 = the two-launch fused iteration; 2 | 4 | 8: measurement only, that many chunks per workgroup */
   int gm_flux_tile;        /* 0: Gent-McWilliams fluxes cell by cell (every horizontal face flux evaluated in both cells that share it) instead of once per face in 64 x 4 tiles */
+  int pcsi_two_step;       /* fused P-CSI (diagonal preconditioner, one rank, no tripole fold): 1 = two iterations per pass over the state where no check follows
+                            * (k_pcsi_step_x2; the default on large grids), 0 = one launch per iteration */
 } pop_tuning;
 void pop_tuning_init(pop_tuning *t);   /* struct_bytes = sizeof, every field POP_TUNING_UNSET */
 int pop_get_tuning(const pop_ctx *ctx, pop_tuning *resolved);   /* fields still POP_TUNING_UNSET: the size rule applied */

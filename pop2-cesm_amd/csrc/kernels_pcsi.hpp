@@ -223,4 +223,124 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
   }
 }
 
+
+// ---- two P-CSI iterations in ONE pass over the state (round 4; large grids) ---------------------------------------------------------------
+// P-CSI has no inner product, so nothing but the stencil couples iteration k + 1 to iteration k: a workgroup that holds x, dx, r' on a
+// tile and TWO rings of cells around it can form both iterations of the tile itself -- x1 = x0 + dx1 on tile + 2 rings (pointwise),
+// r'1 = (b - A x1) / diag and then dx2, x2 on tile + 1 ring, r'2 on the tile -- reading the state once and writing it once per two
+// iterations instead of twice (13 -> ~8 words per point and iteration with 64 x 8 tiles).  Every cell value is formed by the operations
+// k_pcsi_step2 uses for it, whoever forms it: bitwise two k_pcsi_step2 launches (tests/test_gpu_parity.py::
+// test_two_step_pcsi_is_bitwise_the_one_step_pcsi).  The cells of the rings are addressed by their ARRAY position (the block has two
+// ghost rings: NGHOST = 2) and read at their source cell (srcmap: own index, the cyclic image, or -1 = fill: x, dx, r' are 0 there in
+// every iteration); not for a tripole fold, whose ghost cells do not have their array neighbours as stencil neighbours.
+// Launch: 64 x 8 threads per tile of the physical domain (the tile lists of the 3-D LDS kernels, DevGrid::lds_act8); no (r, r): the
+// iterations before a check go through k_pcsi_step2.
+struct Pcsi2Tile {
+  static constexpr int R = 8, W = 64 + 4, H = R + 4, N = W * H;      // tile + two rings
+  double x1[N], dx1[N], rp1[N], x2[N];
+};
+__global__ void __launch_bounds__(512)
+k_pcsi_step_x2(DevGrid g, PcsiArgs a) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  using T = Pcsi2Tile;
+  __shared__ T t;
+  const int nxb = g.nxb, nyb = g.nyb, b = blockIdx.y;
+  const int tiles_i = (nxb - 2 * NGHOST + 63) / 64, tiles_j = (nyb - 2 * NGHOST + T::R - 1) / T::R;
+  int ti, tj;
+  bool listed = false;
+  if (!lds_tile_active<8>(g, b, tiles_i, tiles_j, ti, tj, listed)) return;
+  const int i0 = NGHOST + ti * 64, j0 = NGHOST + tj * T::R;
+  if (!listed && land_tile(g, b, i0, 64, j0, T::R)) return;       // x, dx, r' stay exactly 0 where no ocean cell is near
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const double om1 = a.omega[*a.base + a.j], cq1 = a.csy * om1 - 1.0;
+  const double om2 = a.omega[*a.base + a.j + 1], cq2 = a.csy * om2 - 1.0;
+  const long long boff = (long long)b * g.n2;
+  // array position -> (source cell or -1, does the cell exist and belong to the physical domain)
+  auto src_of = [&](int i, int j) -> long long {
+    if (i < 0 || i >= nxb || j < 0 || j >= nyb) return -1;
+    const int m = a.srcmap[boff + (long long)j * nxb + i];
+    return m;
+  };
+  // own position: a physical cell, or (tiles overhang the physical domain) a ghost position / a position outside the array, which is
+  // treated like a cell of the rings: formed at its source cell for the benefit of its physical neighbours, never stored
+  const int i = i0 + tx, j = j0 + ty;
+  const int lc = (ty + 2) * T::W + tx + 2;
+  const bool own = i + 1 <= blk_ie(g, b) && j + 1 <= blk_je(g, b);            // physical (i0, j0 >= ib - 1, jb - 1 already)
+  const long long om_ = src_of(i, j);
+  const long long qsafe = boff + (long long)NGHOST * nxb + NGHOST;            // a cell that exists and has all its neighbours in the array
+  const long long q = (om_ >= 0) ? om_ : qsafe;
+  // ring duty: thread tid < NR1 forms a cell of the first ring (both iterations' stencil values there), tid < NR1 + NR2 one of the second
+  constexpr int NR1 = (64 + 2) * (T::R + 2) - 64 * T::R, NR2 = T::N - (64 + 2) * (T::R + 2);
+  int hl = -1, hi = 0, hj = 0; bool ring1 = false;
+  if (tid < NR1) {
+    ring1 = true;
+    int li, lj;
+    const int W1 = 66;
+    if (tid < W1) { lj = 0; li = tid; }
+    else if (tid < 2 * W1) { lj = T::R + 1; li = tid - W1; }
+    else if (tid < 2 * W1 + T::R) { lj = 1 + (tid - 2 * W1); li = 0; }
+    else { lj = 1 + (tid - 2 * W1 - T::R); li = W1 - 1; }
+    hi = i0 - 1 + li; hj = j0 - 1 + lj; hl = (lj + 1) * T::W + li + 1;
+  } else if (tid < NR1 + NR2) {
+    const int e = tid - NR1;
+    int li, lj;
+    if (e < T::W) { lj = 0; li = e; }
+    else if (e < 2 * T::W) { lj = T::H - 1; li = e - T::W; }
+    else if (e < 2 * T::W + T::R + 2) { lj = 1 + (e - 2 * T::W); li = 0; }
+    else { lj = 1 + (e - 2 * T::W - (T::R + 2)); li = T::W - 1; }
+    hi = i0 - 2 + li; hj = j0 - 2 + lj; hl = lj * T::W + li;
+  }
+  const long long hm = (hl >= 0) ? src_of(hi, hj) : -1;
+  const long long hq = (hm >= 0) ? hm : qsafe;
+  // ---- iteration k: dx1, x1 at the own position and at the ring cell (0 where there is no source cell: fill)
+  double x1o, dx1o;
+  {
+    const double r0 = a.Ri[q], q0 = a.Qi[q], x0 = a.Xi[q];
+    const double hr0 = a.Ri[hq], hq0 = a.Qi[hq], hx0 = a.Xi[hq];
+    dx1o = om1 * r0 + cq1 * q0; x1o = x0 + dx1o;
+    if (om_ < 0) { dx1o = 0.0; x1o = 0.0; }
+    double hdx = om1 * hr0 + cq1 * hq0, hx1 = hx0 + hdx;
+    if (hm < 0) { hdx = 0.0; hx1 = 0.0; }
+    t.x1[lc] = x1o; t.dx1[lc] = dx1o;
+    if (hl >= 0) { t.x1[hl] = hx1; t.dx1[hl] = hdx; }
+  }
+  // weights of the own position and of the first-ring cell (at their source cells)
+  const double cc = a.C[q], wn = g.WNo[q], ws = g.WNo[q - nxb], we = g.WEa[q], ww = g.WEa[q - 1];
+  const double wne = g.WNE[q], wse = g.WNE[q - nxb], wnw = g.WNE[q - 1], wsw = g.WNE[q - 1 - nxb];
+  const double bq = a.Bv[q], a0r = a.A0R[q];
+  const long long hq1 = (ring1 && hm >= 0) ? hm : qsafe;
+  const double hcc = a.C[hq1], hwn = g.WNo[hq1], hws = g.WNo[hq1 - nxb], hwe = g.WEa[hq1], hww = g.WEa[hq1 - 1];
+  const double hwne = g.WNE[hq1], hwse = g.WNE[hq1 - nxb], hwnw = g.WNE[hq1 - 1], hwsw = g.WNE[hq1 - 1 - nxb];
+  const double hbq = a.Bv[hq1], ha0r = a.A0R[hq1];
+  __syncthreads();
+  auto stencil = [&](const double *X, int l, double c0, double n, double s_, double e, double w_, double ne, double se, double nw, double sw) {
+    return c0 * X[l] + n * X[l + T::W] + s_ * X[l - T::W] + e * X[l + 1] + w_ * X[l - 1] +
+           ne * X[l + T::W + 1] + se * X[l - T::W + 1] + nw * X[l + T::W - 1] + sw * X[l - T::W - 1];
+  };
+  // ---- r'1, then dx2, x2 at the own cell and at the first-ring cell
+  double x2o, dx2o;
+  {
+    const double r1 = bq - stencil(t.x1, lc, cc, wn, ws, we, ww, wne, wse, wnw, wsw);
+    const double rp = r1 * a0r;
+    dx2o = om2 * rp + cq2 * dx1o; x2o = x1o + dx2o;
+    t.x2[lc] = (om_ >= 0) ? x2o : 0.0;
+    if (ring1) {
+      double hx2 = 0.0;
+      if (hm >= 0) {
+        const double hr1 = hbq - stencil(t.x1, hl, hcc, hwn, hws, hwe, hww, hwne, hwse, hwnw, hwsw);
+        const double hrp = hr1 * ha0r;
+        const double hdx2 = om2 * hrp + cq2 * t.dx1[hl];
+        hx2 = t.x1[hl] + hdx2;
+      }
+      t.x2[hl] = hx2;
+    }
+  }
+  __syncthreads();
+  // ---- r'2 at the own cell; the state after two iterations
+  if (own) {
+    const double r2 = bq - stencil(t.x2, lc, cc, wn, ws, we, ww, wne, wse, wnw, wsw);
+    a.Qo[q] = dx2o; a.Xo[q] = x2o; a.Ro[q] = r2 * a0r;
+  }
+}
+
 }  // namespace pop

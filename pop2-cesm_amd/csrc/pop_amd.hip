@@ -119,6 +119,7 @@ struct pop_ctx {
   int red_active_total = 0;                                // fused solver kernels: chunks that have work, summed over the local blocks
   int persist_nwg = 0, persist_cp = 0;                     // shape of the last resident launch
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
+  bool pcsi_two_step = false;   // ... and two iterations per launch where no check follows (k_pcsi_step_x2; pop_tuning.pcsi_two_step)
   bool reg_thomas_t = true;
   int trc_lds_rows = 4;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
   int mom_lds_rows = 4;                                    // momentum RHS: LDS tile rows (0 = direct-load kernel)
@@ -1267,10 +1268,21 @@ static DevGrid pcsi_grid(const pop_ctx *c) {
   return g;
 }
 // `freq` steps starting from buffer `in`; the last one also forms (r,r) -> host when with_rr
+// two iterations per launch (k_pcsi_step_x2): how many of the n iterations of an interval go in pairs -- the last two stay single (the check
+// needs the chunk partials of (r, r) of k_pcsi_step2, and a single step before it keeps the pairs aligned for every n)
+static int pcsi_pairs(const pop_ctx *c, int n) { return (c->pcsi_two_step && n > 2) ? (n - 2) / 2 : 0; }
+static int pcsi_launches(const pop_ctx *c, int n) { return n - pcsi_pairs(c, n); }
 static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool with_rr) {
   const DevGrid gg = pcsi_grid(c);
   const dim3 G(red_grid_x(gg), gg.nblocks), B(POP_RED_THREADS);
-  for (int j = 1; j <= freq; ++j) {
+  int j0 = 1;
+  for (int p = 0; p < pcsi_pairs(c, freq); ++p, j0 += 2) {
+    const PcsiArgs a = pcsi_args(c, bf, in, j0);
+    const int tiles_i = (gg.nxb - 2 * NGHOST + 63) / 64, tiles_j = (gg.nyb - 2 * NGHOST + 7) / 8;
+    hipLaunchKernelGGL(k_pcsi_step_x2, dim3(lds_launch_x<8>(gg, tiles_i, tiles_j), gg.nblocks), dim3(64, 8), 0, c->stream, gg, a);
+    in = 1 - in;
+  }
+  for (int j = j0; j <= freq; ++j) {
     const PcsiArgs a = pcsi_args(c, bf, in, j);
     if (c->pcsi_two_cell) {
       if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step2<true>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, gg, a);
@@ -1382,7 +1394,7 @@ int solver_pcsi_fused(pop_ctx *c) {
       }
       if (hipGraphLaunch(exec, c->stream) != hipSuccess) return -1;
     } else pcsi_interval(c, bf, in, n, with_rr);
-    if (n % 2) in = 1 - in;
+    if (pcsi_launches(c, n) % 2) in = 1 - in;
     in_after[i] = in;
     return with_rr ? 1 : 0;
   }, rr, lerr);
@@ -1544,7 +1556,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED") X(pcg_persist, "POP_PCG_PERSIST") X(gm_flux_tile, "POP_GM_FLUX_TILE")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED") X(pcg_persist, "POP_PCG_PERSIST") X(gm_flux_tile, "POP_GM_FLUX_TILE") X(pcsi_two_step, "POP_PCSI_TWO_STEP")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -2123,6 +2135,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->force_presum = tun_on(h.tun.solver_presum);
     c->fpcg_one_cell = tun_off(h.tun.fpcg_b2);
     c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && (long long)c->nchunk * h.nblocks > 2048;
+    c->pcsi_two_step = c->pcsi_two_cell && h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg);
+    if (tun_set(h.tun.pcsi_two_step)) c->pcsi_two_step = h.tun.pcsi_two_step != 0 && h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg) && !g.red_tiles;
     if (tun_set(h.tun.pcsi_step2)) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && h.tun.pcsi_step2 != 0;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && !use_evp(*cfg) && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !tun_on(h.tun.solver_distributed);

@@ -73,6 +73,7 @@
       integer (c_int) :: fpcg_a_pair, kpp_sparse, pbc_generic_thomas, pbc_generic_kpp, stream_priority, gm_sf_stored, state3d_levels
       integer (c_int) :: pcg_persist
       integer (c_int) :: gm_flux_tile
+      integer (c_int) :: pcsi_two_step
    end type pop_tuning
 
    type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task

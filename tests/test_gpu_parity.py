@@ -1140,6 +1140,31 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
     a.close(); b.close(); c.close(); d.close(); e.close()
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("tiny", {"block_size_x": 48, "block_size_y": 40}),                                     # one block, cyclic east-west, closed north-south
+    ("tiny", {"block_size_x": 24, "block_size_y": 20}),                                     # 4 blocks: the rings of a tile cross block boundaries through the source map
+    ("tiny", {"block_size_x": 24, "block_size_y": 20, "ew_boundary": 0, "stepped_bathymetry": 1}),   # closed everywhere: fill cells in the rings
+    ("tiny", {"block_size_x": 28, "block_size_y": 24}),                                     # padded blocks: tiles overhang the physical domain
+    ("tiny", {"block_size_x": 48, "block_size_y": 40, "convergence_check_freq": 7, "max_iterations": 200, "convergence_check_start": 14}),   # odd interval: an odd number of launches
+    ("tiny", {"block_size_x": 48, "block_size_y": 40, "convergence_check_freq": 4, "max_iterations": 203}),                                    # a last interval of 3 without a check
+    ("gx3v7", {}),                                                                          # 100 x 116: two tile columns, the second 36 wide
+    ("wide", {}),                                                                           # 2112 columns: 33 tile columns
+])
+def test_two_step_pcsi_is_bitwise_the_one_step_pcsi(pkg, name, kw):
+    """pop_tuning.pcsi_two_step: two P-CSI iterations per pass over the state (k_pcsi_step_x2: x, dx, r' of a 64 x 8 tile and two rings
+    of cells around it in LDS, the cells of the rings formed at their source cells) wherever no check follows.  Every value goes through
+    the operations of k_pcsi_step / k_pcsi_step2: iteration counts and fields bit for bit."""
+    cfg = named_config(name, solver_choice=3, **kw)
+    a = pkg.PopModel(cfg, tuning={"pcg_persist": 0, "pcsi_two_step": 0})
+    b = pkg.PopModel(cfg, tuning={"pcg_persist": 0, "pcsi_two_step": 1})
+    for step in range(5):
+        a.step(); b.step()
+        assert a.solver_diagnostics() == b.solver_diagnostics(), "step %d" % step
+    for f in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER", "GRADPX"):
+        assert np.array_equal(a.get(f), b.get(f)), f
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("name,kw,grid", [
     ("tiny", {"block_size_x": 24, "block_size_y": 20}, False),                      # 4 blocks: ghosts between blocks through the source map
     ("tiny", {"block_size_x": 48, "block_size_y": 40}, False),                      # one block, cyclic east-west
