@@ -11,6 +11,8 @@
 // Lanczos eigenvalue bounds: it is tabulated once on the device and indexed by base + j, where j is
 // baked into the launch and `base` is a device word the host bumps per interval -- so one hipGraph
 // serves every interval of every solve.
+// Round 4: on large grids TWO iterations per launch where no check follows (k_pcsi_step_x2, below); on small grids the whole
+// iteration loop as one resident launch (k_pcsi_persist, kernels_pcg_persist.hpp).
 #pragma once
 #include "kernels_barotropic.hpp"
 
