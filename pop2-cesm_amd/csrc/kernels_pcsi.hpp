@@ -241,8 +241,11 @@ struct Pcsi2Tile {
   static constexpr int R = 8, W = 64 + 4, H = R + 4, N = W * H;      // tile + two rings
   double x1[N], dx1[N], rp1[N], x2[N];
 };
+// RAW: the pair before a convergence check also leaves the residual r2 itself in `raw` (a scratch field); k_pcsi_rr_chunks then forms the
+// chunk partials of (r, r) exactly as k_pcsi_step2<true> does, so the check sees the same number
+template <bool RAW>
 __global__ void __launch_bounds__(512)
-k_pcsi_step_x2(DevGrid g, PcsiArgs a) {
+k_pcsi_step_x2(DevGrid g, PcsiArgs a, double *__restrict__ raw) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
   using T = Pcsi2Tile;
   __shared__ T t;
@@ -342,7 +345,22 @@ k_pcsi_step_x2(DevGrid g, PcsiArgs a) {
   if (own) {
     const double r2 = bq - stencil(t.x2, lc, cc, wn, ws, we, ww, wne, wse, wnw, wsw);
     a.Qo[q] = dx2o; a.Xo[q] = x2o; a.Ro[q] = r2 * a0r;
+    if (RAW) raw[q] = r2;
   }
+}
+// chunk partials of (r, r) from the residual k_pcsi_step_x2<true> left: the cells, the factors and the tree of k_pcsi_step2<true>
+__global__ void __launch_bounds__(POP_RED_THREADS)
+k_pcsi_rr_chunks(DevGrid g, PcsiArgs a, const double *__restrict__ raw) {
+  if (a.sc->stop) return;
+  if (red_land_out<1>(g, a.partial, a.nchunk, false)) return;
+  const int p2 = red_cell(g), b = blockIdx.y;
+  double v[1] = {0.0};
+  if (p2 < g.n2) {
+    const int i = p2 % g.nxb, j = p2 / g.nxb;
+    const long long q = (long long)b * g.n2 + p2;
+    if (interior(g, b, i, j)) { const double r = raw[q]; v[0] = (r * r) * (double)g.mMask8[q]; }
+  }
+  wg_reduce_store<1>(v, a.partial, b * a.nchunk + red_chunk(g));
 }
 
 }  // namespace pop

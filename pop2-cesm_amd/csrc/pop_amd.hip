@@ -119,7 +119,8 @@ struct pop_ctx {
   int red_active_total = 0;                                // fused solver kernels: chunks that have work, summed over the local blocks
   int persist_nwg = 0, persist_cp = 0;                     // shape of the last resident launch
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
-  bool pcsi_two_step = false;   // ... and two iterations per launch where no check follows (k_pcsi_step_x2; pop_tuning.pcsi_two_step)
+  bool pcsi_two_step = false;   // ... and two iterations per launch (k_pcsi_step_x2; pop_tuning.pcsi_two_step)
+  double *pcsi_raw = nullptr;   // the residual of the pair before a check (k_pcsi_step_x2<true> -> k_pcsi_rr_chunks)
   bool reg_thomas_t = true;
   int trc_lds_rows = 4;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
   int mom_lds_rows = 4;                                    // momentum RHS: LDS tile rows (0 = direct-load kernel)
@@ -1270,16 +1271,23 @@ static DevGrid pcsi_grid(const pop_ctx *c) {
 // `freq` steps starting from buffer `in`; the last one also forms (r,r) -> host when with_rr
 // two iterations per launch (k_pcsi_step_x2): how many of the n iterations of an interval go in pairs -- the last two stay single (the check
 // needs the chunk partials of (r, r) of k_pcsi_step2, and a single step before it keeps the pairs aligned for every n)
-static int pcsi_pairs(const pop_ctx *c, int n) { return (c->pcsi_two_step && n > 2) ? (n - 2) / 2 : 0; }
+// An interval of an even number of iterations goes in pairs throughout: the pair before a check leaves the residual itself in a scratch field
+// and k_pcsi_rr_chunks forms the chunk partials of (r, r) from it.  An odd interval: pairs, then one single step (which carries the check).
+static int pcsi_pairs(const pop_ctx *c, int n) { return c->pcsi_two_step ? n / 2 : 0; }
 static int pcsi_launches(const pop_ctx *c, int n) { return n - pcsi_pairs(c, n); }
 static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool with_rr) {
   const DevGrid gg = pcsi_grid(c);
   const dim3 G(red_grid_x(gg), gg.nblocks), B(POP_RED_THREADS);
   int j0 = 1;
-  for (int p = 0; p < pcsi_pairs(c, freq); ++p, j0 += 2) {
+  const int npairs = pcsi_pairs(c, freq);
+  for (int p = 0; p < npairs; ++p, j0 += 2) {
     const PcsiArgs a = pcsi_args(c, bf, in, j0);
     const int tiles_i = (gg.nxb - 2 * NGHOST + 63) / 64, tiles_j = (gg.nyb - 2 * NGHOST + 7) / 8;
-    hipLaunchKernelGGL(k_pcsi_step_x2, dim3(lds_launch_x<8>(gg, tiles_i, tiles_j), gg.nblocks), dim3(64, 8), 0, c->stream, gg, a);
+    const dim3 GT(lds_launch_x<8>(gg, tiles_i, tiles_j), gg.nblocks);
+    if (with_rr && j0 + 1 == freq) {                       // the last pair of an even interval that ends in a check
+      hipLaunchKernelGGL(k_pcsi_step_x2<true>, GT, dim3(64, 8), 0, c->stream, gg, a, c->pcsi_raw);
+      hipLaunchKernelGGL(k_pcsi_rr_chunks, G, B, 0, c->stream, gg, a, (const double *)c->pcsi_raw);
+    } else hipLaunchKernelGGL(k_pcsi_step_x2<false>, GT, dim3(64, 8), 0, c->stream, gg, a, (double *)nullptr);
     in = 1 - in;
   }
   for (int j = j0; j <= freq; ++j) {
@@ -2137,6 +2145,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && (long long)c->nchunk * h.nblocks > 2048;
     c->pcsi_two_step = c->pcsi_two_cell && h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg);
     if (tun_set(h.tun.pcsi_two_step)) c->pcsi_two_step = h.tun.pcsi_two_step != 0 && h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg) && !g.red_tiles;
+    if (c->pcsi_two_step && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
     if (tun_set(h.tun.pcsi_step2)) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && h.tun.pcsi_step2 != 0;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && !use_evp(*cfg) && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !tun_on(h.tun.solver_distributed);
