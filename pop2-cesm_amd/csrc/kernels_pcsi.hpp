@@ -239,7 +239,7 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
 // iterations before a check go through k_pcsi_step2.
 struct Pcsi2Tile {
   static constexpr int R = 8, W = 64 + 4, H = R + 4, N = W * H;      // tile + two rings
-  double x1[N], dx1[N], rp1[N], x2[N];
+  double x1[N], dx1[N], x2[N];
 };
 // RAW: the pair before a convergence check also leaves the residual r2 itself in `raw` (a scratch field); k_pcsi_rr_chunks then forms the
 // chunk partials of (r, r) exactly as k_pcsi_step2<true> does, so the check sees the same number
