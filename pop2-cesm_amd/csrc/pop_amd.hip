@@ -120,6 +120,7 @@ struct pop_ctx {
   int persist_nwg = 0, persist_cp = 0;                     // shape of the last resident launch
   bool pcsi_two_cell = false;   // fused P-CSI step with two cells per thread (large grids, even row pitch; POP_PCSI_STEP2=0|1)
   bool pcsi_two_step = false;   // ... and two iterations per launch (k_pcsi_step_x2; pop_tuning.pcsi_two_step)
+  bool pcsi_two_step_dist = false;   // ... with blocks spread over ranks
   double *pcsi_raw = nullptr;   // the residual of the pair before a check (k_pcsi_step_x2<true> -> k_pcsi_rr_chunks)
   bool reg_thomas_t = true;
   int trc_lds_rows = 4;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
@@ -1449,10 +1450,29 @@ int solver_pcsi_fused_dist(pop_ctx *c) {
   int in = 1;
   c->numIterations = cf.max_iterations;
   double rr = 0.0;
+  if (c->pcsi_two_step_dist && halo_update_many(c, {{c->RHS, 1}})) return 1;   // the pairs form r at the first ring of ghost cells
+  // two iterations per launch across ranks (k_pcsi_step_x2): x, dx and r' travel two rings wide once per PAIR instead of r' once per
+  // iteration -- half the messages per iteration
+  const bool pairs = c->pcsi_two_step_dist;
+  const DevGrid gg = c->g;
   for (int m = 1; m <= cf.max_iterations; ++m) {
-    const bool check = (m % freq == 0) && m >= start;
+    bool check = (m % freq == 0) && m >= start;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, c->pcsi_base, m - 1);
-    if (step(in, 1, false, check)) return 1;
+    if (pairs && !check && m + 1 <= cf.max_iterations) {
+      if (halo_update_many(c, {{bf.X[in], 1}, {bf.Q[in], 1}, {bf.R[in], 1}})) return 1;
+      const bool check2 = ((m + 1) % freq == 0) && m + 1 >= start;
+      const PcsiArgs a = pcsi_args(c, bf, in, 1);
+      const int tiles_i = (gg.nxb - 2 * NGHOST + 63) / 64, tiles_j = (gg.nyb - 2 * NGHOST + 7) / 8;
+      const dim3 GT(lds_launch_x<8>(gg, tiles_i, tiles_j), gg.nblocks);
+      if (check2) {
+        hipLaunchKernelGGL(k_pcsi_step_x2<true>, GT, dim3(64, 8), 0, c->stream, gg, a, c->pcsi_raw);
+        hipLaunchKernelGGL(k_pcsi_rr_chunks, G, B, 0, c->stream, gg, a, (const double *)c->pcsi_raw);
+      } else hipLaunchKernelGGL(k_pcsi_step_x2<false>, GT, dim3(64, 8), 0, c->stream, gg, a, (double *)nullptr);
+      ++m; check = check2;
+    } else {
+      if (pairs && halo_update_many(c, {{bf.X[in], 1}, {bf.Q[in], 1}})) return 1;   // (the pairs do not advance x, dx at the ghosts of other ranks)
+      if (step(in, 1, false, check)) return 1;
+    }
     in = 1 - in;
     if (check) {
       hipLaunchKernelGGL(k_block_sums_global<1>, dim3(nbt), dim3(POP_RED_THREADS), 0, c->stream, (const double *)c->partial, c->nchunk, c->loc_of_gid, c->redbuf);
@@ -1465,6 +1485,7 @@ int solver_pcsi_fused_dist(pop_ctx *c) {
     }
   }
   if (in == 1) HIPCHK(c, hipMemcpyAsync(bf.X[0], bf.X[1], sizeof(double) * a2, hipMemcpyDeviceToDevice, c->stream));
+  if (pairs && halo_remote(c, bf.X[0], 1)) return 1;   // (the single steps keep x current at the ghosts of other ranks; the pairs do not)
   hipLaunchKernelGGL(k_halo_srcmap, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, bf.X[0], c->srcmap, a2);
   c->rmsResidual = std::sqrt(rr * c->h.residualNorm);
   HIPCHK(c, hipGetLastError());
@@ -1749,6 +1770,26 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       // (the area and the mask in the other part are mirrored copies already).  The host copy keeps the reference's values.
       all = kv.second;
       host_halo_r8_loc(h, all.data(), 1, 0.0, 0, 0);
+      src = &all;
+    }
+    const int wgt = kv.first == "btropWgtNE" ? 1 : kv.first == "btropWgtEast" ? 2 : kv.first == "btropWgtNorth" ? 3 : 0;
+    if (wgt) {
+      // The reference forms the off-centre weights from i = 2, j = 2 of the block array on (POP_SolversMod.F90:795-815); the
+      // first row and column stay 0 and nothing reads them.  The two-iterations-per-launch P-CSI across ranks forms the operator at the
+      // first ring of ghost cells, whose west / south weights live in that row and column: the device copy holds them, made of the
+      // same two U-point terms in the same order.  The host copy keeps the reference's values.
+      all = kv.second;
+      const std::vector<double> &XW = h.f2.at("btropXW"), &YW = h.f2.at("btropYW");
+      const int nxb = h.nxb, nyb = h.nyb;
+      const size_t n2 = (size_t)nxb * nyb;
+      for (size_t b = 0; b < all.size() / n2; ++b)
+        for (int j = 0; j < nyb; ++j) for (int i = 0; i < nxb; ++i) {
+          if (i > 0 && j > 0) continue;
+          const size_t q = b * n2 + (size_t)j * nxb + i;
+          if (wgt == 1) all[q] = XW[q] + YW[q];
+          else if (wgt == 2 && j > 0) all[q] = XW[q] + XW[q - nxb] - YW[q] - YW[q - nxb];
+          else if (wgt == 3 && i > 0) all[q] = YW[q] + YW[q - 1] - XW[q] - XW[q - 1];
+        }
       src = &all;
     }
     auto loc = local_part(h, *src); double *p; if (dev_upload(c, &p, loc.data(), loc.size())) return 1; c->d2[kv.first] = p;
@@ -2145,7 +2186,9 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && (long long)c->nchunk * h.nblocks > 2048;
     c->pcsi_two_step = c->pcsi_two_cell && h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg);
     if (tun_set(h.tun.pcsi_two_step)) c->pcsi_two_step = h.tun.pcsi_two_step != 0 && h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg) && !g.red_tiles;
-    if (c->pcsi_two_step && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
+    c->pcsi_two_step_dist = !h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg) && !g.red_tiles &&
+                            (tun_set(h.tun.pcsi_two_step) ? h.tun.pcsi_two_step != 0 : c->pcsi_two_cell);
+    if ((c->pcsi_two_step || c->pcsi_two_step_dist) && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
     if (tun_set(h.tun.pcsi_step2)) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && h.tun.pcsi_step2 != 0;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && !use_evp(*cfg) && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !tun_on(h.tun.solver_distributed);

@@ -61,6 +61,9 @@ def test_large_grid_two_ranks_equal_single_rank():
     (2, "solver_choice=3", {}),                                       # P-CSI fused: one r' halo + one launch per iteration, no collective
     (2, "solver_choice=3", {"POP_SOLVER_UNFUSED": "1"}),              # P-CSI operation by operation
     (4, "solver_choice=3,block_size_x=24,block_size_y=20", {}),       # P-CSI, one block per rank
+    (2, "solver_choice=3", {"POP_PCSI_TWO_STEP": "1"}),               # P-CSI two iterations per launch across ranks: x, dx, r' two rings wide once per pair
+    (4, "solver_choice=3,block_size_x=24,block_size_y=20,convergence_check_freq=5", {"POP_PCSI_TWO_STEP": "1"}),   # ... one block per rank, pairs and single steps mixed
+    (3, "solver_choice=3,block_size_x=20,block_size_y=16", {"POP_PCSI_TWO_STEP": "1"}),   # ... padded blocks, uneven ownership
     (2, "solver_choice=2", {}),                                       # ChronGear, fused distributed form (one all-reduce per iteration)
     (2, "solver_choice=2", {"POP_SOLVER_UNFUSED": "1"}),              # ChronGear operation by operation
     (4, "solver_choice=2,block_size_x=24,block_size_y=20", {}),       # ChronGear fused, one block per rank: corner cells go to three peers
@@ -92,6 +95,7 @@ def test_multirank_equals_single_rank(nranks, kw, env):
     (2, "ny_global=80,block_size_x=48,block_size_y=40,vmix_choice=3,km=24", {"POP_HALO_OVERLAP_OFF": "1", "POP_SOLVER_DISTRIBUTED": "1"}),
     (3, "ny_global=120,block_size_x=24,block_size_y=40,vmix_choice=3,km=24", {"POP_SOLVER_DISTRIBUTED": "1"}),   # two blocks per rank side by side, three bands
     (4, "solver_choice=3,block_size_x=24,block_size_y=20", {}),       # P-CSI
+    (4, "solver_choice=3,block_size_x=24,block_size_y=20,convergence_check_freq=5", {"POP_PCSI_TWO_STEP": "1"}),   # P-CSI, two iterations per launch
     (3, "block_size_x=24,block_size_y=20,vmix_choice=3,km=24", {}),   # uneven ownership, KPP
     (2, "tmix_opt=3,tadvect=2", {}),                                  # Robert filter sums + upwind3
     (4, "tadvect=3,block_size_x=24,block_size_y=20", {}),             # lw_lim, one block per rank
