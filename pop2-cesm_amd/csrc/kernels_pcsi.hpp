@@ -32,6 +32,7 @@ struct PcsiArgs {
   int remote_ghosts;               // multi-rank: also advance dx, x at ghosts owned by other ranks
   int nchunk;                      // stride of the partial slots per block (the launch may be compacted: DevGrid::red_act)
   int raw_r;                       // EVP preconditioner (r3): Ro receives the residual itself; k_evp_apply_wave2 turns it into r' for the next step
+  const int *jfold;                // k_pcsi_step_x2<., true>: per block, the first array row (0-based) beyond a tripole fold; nyb where the block does not touch it
 };
 
 // unfused building blocks (multi-rank path and cross-check): whole-array operations as the reference has them
@@ -234,7 +235,7 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
 // k_pcsi_step2 uses for it, whoever forms it: bitwise two k_pcsi_step2 launches (tests/test_gpu_parity.py::
 // test_two_step_pcsi_is_bitwise_the_one_step_pcsi).  The cells of the rings are addressed by their ARRAY position (the block has two
 // ghost rings: NGHOST = 2) and read at their source cell (srcmap: own index, the cyclic image, or -1 = fill: x, dx, r' are 0 there in
-// every iteration); not for a tripole fold, whose ghost cells do not have their array neighbours as stencil neighbours.
+// every iteration).  Beyond a tripole fold (FOLD) a ghost cell's stencil neighbours are its array neighbours in mirrored order.
 // Launch: 64 x 8 threads per tile of the physical domain (the tile lists of the 3-D LDS kernels, DevGrid::lds_act8); no (r, r): the
 // iterations before a check go through k_pcsi_step2.
 struct Pcsi2Tile {
@@ -243,7 +244,7 @@ struct Pcsi2Tile {
 };
 // RAW: the pair before a convergence check also leaves the residual r2 itself in `raw` (a scratch field); k_pcsi_rr_chunks then forms the
 // chunk partials of (r, r) exactly as k_pcsi_step2<true> does, so the check sees the same number
-template <bool RAW>
+template <bool RAW, bool FOLD>
 __global__ void __launch_bounds__(512)
 k_pcsi_step_x2(DevGrid g, PcsiArgs a, double *__restrict__ raw) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
@@ -318,21 +319,26 @@ k_pcsi_step_x2(DevGrid g, PcsiArgs a, double *__restrict__ raw) {
   const double hwne = g.WNE[hq1], hwse = g.WNE[hq1 - nxb], hwnw = g.WNE[hq1 - 1], hwsw = g.WNE[hq1 - 1 - nxb];
   const double hbq = a.Bv[hq1], ha0r = a.A0R[hq1];
   __syncthreads();
-  auto stencil = [&](const double *X, int l, double c0, double n, double s_, double e, double w_, double ne, double se, double nw, double sw) {
-    return c0 * X[l] + n * X[l + T::W] + s_ * X[l - T::W] + e * X[l + 1] + w_ * X[l - 1] +
-           ne * X[l + T::W + 1] + se * X[l - T::W + 1] + nw * X[l + T::W - 1] + sw * X[l - T::W - 1];
+  // A ghost cell G beyond a tripole fold is the mirror image of its source cell S: the array neighbour G + (di, dj) holds the value of
+  // S - (di, dj).  The operator at S -- its weights, its order of additions -- is formed at G by walking the tile the other way round.
+  const int jf = FOLD ? a.jfold[b] : 0;
+  const int odW = (FOLD && j >= jf) ? -T::W : T::W, od1 = (FOLD && j >= jf) ? -1 : 1;
+  const int hdW = (FOLD && hj >= jf) ? -T::W : T::W, hd1 = (FOLD && hj >= jf) ? -1 : 1;
+  auto stencil = [&](const double *X, int l, int dW, int d1, double c0, double n, double s_, double e, double w_, double ne, double se, double nw, double sw) {
+    return c0 * X[l] + n * X[l + dW] + s_ * X[l - dW] + e * X[l + d1] + w_ * X[l - d1] +
+           ne * X[l + dW + d1] + se * X[l - dW + d1] + nw * X[l + dW - d1] + sw * X[l - dW - d1];
   };
   // ---- r'1, then dx2, x2 at the own cell and at the first-ring cell
   double x2o, dx2o;
   {
-    const double r1 = bq - stencil(t.x1, lc, cc, wn, ws, we, ww, wne, wse, wnw, wsw);
+    const double r1 = bq - stencil(t.x1, lc, odW, od1, cc, wn, ws, we, ww, wne, wse, wnw, wsw);
     const double rp = r1 * a0r;
     dx2o = om2 * rp + cq2 * dx1o; x2o = x1o + dx2o;
     t.x2[lc] = (om_ >= 0) ? x2o : 0.0;
     if (ring1) {
       double hx2 = 0.0;
       if (hm >= 0) {
-        const double hr1 = hbq - stencil(t.x1, hl, hcc, hwn, hws, hwe, hww, hwne, hwse, hwnw, hwsw);
+        const double hr1 = hbq - stencil(t.x1, hl, hdW, hd1, hcc, hwn, hws, hwe, hww, hwne, hwse, hwnw, hwsw);
         const double hrp = hr1 * ha0r;
         const double hdx2 = om2 * hrp + cq2 * t.dx1[hl];
         hx2 = t.x1[hl] + hdx2;
@@ -343,7 +349,7 @@ k_pcsi_step_x2(DevGrid g, PcsiArgs a, double *__restrict__ raw) {
   __syncthreads();
   // ---- r'2 at the own cell; the state after two iterations
   if (own) {
-    const double r2 = bq - stencil(t.x2, lc, cc, wn, ws, we, ww, wne, wse, wnw, wsw);
+    const double r2 = bq - stencil(t.x2, lc, T::W, 1, cc, wn, ws, we, ww, wne, wse, wnw, wsw);
     a.Qo[q] = dx2o; a.Xo[q] = x2o; a.Ro[q] = r2 * a0r;
     if (RAW) raw[q] = r2;
   }

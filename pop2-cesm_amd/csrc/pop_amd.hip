@@ -122,6 +122,7 @@ struct pop_ctx {
   bool pcsi_two_step = false;   // ... and two iterations per launch (k_pcsi_step_x2; pop_tuning.pcsi_two_step)
   bool pcsi_two_step_dist = false;   // ... with blocks spread over ranks
   double *pcsi_raw = nullptr;   // the residual of the pair before a check (k_pcsi_step_x2<true> -> k_pcsi_rr_chunks)
+  int *pcsi_jfold = nullptr;    // tripole: per local block, the first array row beyond the fold (PcsiArgs::jfold)
   bool reg_thomas_t = true;
   int trc_lds_rows = 4;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
   int mom_lds_rows = 4;                                    // momentum RHS: LDS tile rows (0 = direct-load kernel)
@@ -1275,6 +1276,19 @@ static DevGrid pcsi_grid(const pop_ctx *c) {
 // An interval of an even number of iterations goes in pairs throughout: the pair before a check leaves the residual itself in a scratch field
 // and k_pcsi_rr_chunks forms the chunk partials of (r, r) from it.  An odd interval: pairs, then one single step (which carries the check).
 static int pcsi_pairs(const pop_ctx *c, int n) { return c->pcsi_two_step ? n / 2 : 0; }
+// one pair; with_raw: the residual itself to pcsi_raw as well, and the chunk partials of (r, r) from it
+static void pcsi_launch_pair(pop_ctx *c, const DevGrid &gg, PcsiArgs a, bool with_raw) {
+  const int tiles_i = (gg.nxb - 2 * NGHOST + 63) / 64, tiles_j = (gg.nyb - 2 * NGHOST + 7) / 8;
+  const dim3 GT(lds_launch_x<8>(gg, tiles_i, tiles_j), gg.nblocks), TB(64, 8);
+  a.jfold = c->pcsi_jfold;
+  double *raw = with_raw ? c->pcsi_raw : nullptr;
+  if (a.jfold) {
+    if (with_raw) hipLaunchKernelGGL((k_pcsi_step_x2<true, true>), GT, TB, 0, c->stream, gg, a, raw);
+    else hipLaunchKernelGGL((k_pcsi_step_x2<false, true>), GT, TB, 0, c->stream, gg, a, raw);
+  } else if (with_raw) hipLaunchKernelGGL((k_pcsi_step_x2<true, false>), GT, TB, 0, c->stream, gg, a, raw);
+  else hipLaunchKernelGGL((k_pcsi_step_x2<false, false>), GT, TB, 0, c->stream, gg, a, raw);
+  if (with_raw) hipLaunchKernelGGL(k_pcsi_rr_chunks, dim3(red_grid_x(gg), gg.nblocks), dim3(POP_RED_THREADS), 0, c->stream, gg, a, (const double *)raw);
+}
 static int pcsi_launches(const pop_ctx *c, int n) { return n - pcsi_pairs(c, n); }
 static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool with_rr) {
   const DevGrid gg = pcsi_grid(c);
@@ -1282,13 +1296,7 @@ static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool
   int j0 = 1;
   const int npairs = pcsi_pairs(c, freq);
   for (int p = 0; p < npairs; ++p, j0 += 2) {
-    const PcsiArgs a = pcsi_args(c, bf, in, j0);
-    const int tiles_i = (gg.nxb - 2 * NGHOST + 63) / 64, tiles_j = (gg.nyb - 2 * NGHOST + 7) / 8;
-    const dim3 GT(lds_launch_x<8>(gg, tiles_i, tiles_j), gg.nblocks);
-    if (with_rr && j0 + 1 == freq) {                       // the last pair of an even interval that ends in a check
-      hipLaunchKernelGGL(k_pcsi_step_x2<true>, GT, dim3(64, 8), 0, c->stream, gg, a, c->pcsi_raw);
-      hipLaunchKernelGGL(k_pcsi_rr_chunks, G, B, 0, c->stream, gg, a, (const double *)c->pcsi_raw);
-    } else hipLaunchKernelGGL(k_pcsi_step_x2<false>, GT, dim3(64, 8), 0, c->stream, gg, a, (double *)nullptr);
+    pcsi_launch_pair(c, gg, pcsi_args(c, bf, in, j0), with_rr && j0 + 1 == freq);   // (the last pair of an even interval that ends in a check)
     in = 1 - in;
   }
   for (int j = j0; j <= freq; ++j) {
@@ -1461,13 +1469,7 @@ int solver_pcsi_fused_dist(pop_ctx *c) {
     if (pairs && !check && m + 1 <= cf.max_iterations) {
       if (halo_update_many(c, {{bf.X[in], 1}, {bf.Q[in], 1}, {bf.R[in], 1}})) return 1;
       const bool check2 = ((m + 1) % freq == 0) && m + 1 >= start;
-      const PcsiArgs a = pcsi_args(c, bf, in, 1);
-      const int tiles_i = (gg.nxb - 2 * NGHOST + 63) / 64, tiles_j = (gg.nyb - 2 * NGHOST + 7) / 8;
-      const dim3 GT(lds_launch_x<8>(gg, tiles_i, tiles_j), gg.nblocks);
-      if (check2) {
-        hipLaunchKernelGGL(k_pcsi_step_x2<true>, GT, dim3(64, 8), 0, c->stream, gg, a, c->pcsi_raw);
-        hipLaunchKernelGGL(k_pcsi_rr_chunks, G, B, 0, c->stream, gg, a, (const double *)c->pcsi_raw);
-      } else hipLaunchKernelGGL(k_pcsi_step_x2<false>, GT, dim3(64, 8), 0, c->stream, gg, a, (double *)nullptr);
+      pcsi_launch_pair(c, gg, pcsi_args(c, bf, in, 1), check2);
       ++m; check = check2;
     } else {
       if (pairs && halo_update_many(c, {{bf.X[in], 1}, {bf.Q[in], 1}})) return 1;   // (the pairs do not advance x, dx at the ghosts of other ranks)
@@ -2184,11 +2186,25 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->force_presum = tun_on(h.tun.solver_presum);
     c->fpcg_one_cell = tun_off(h.tun.fpcg_b2);
     c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && (long long)c->nchunk * h.nblocks > 2048;
-    c->pcsi_two_step = c->pcsi_two_cell && h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg);
-    if (tun_set(h.tun.pcsi_two_step)) c->pcsi_two_step = h.tun.pcsi_two_step != 0 && h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg) && !g.red_tiles;
-    c->pcsi_two_step_dist = !h.halo.peers.empty() && cfg->ns_boundary != 2 && !use_evp(*cfg) && !g.red_tiles &&
-                            (tun_set(h.tun.pcsi_two_step) ? h.tun.pcsi_two_step != 0 : c->pcsi_two_cell);
+    // two iterations per launch with a tripole fold: the ghost cells beyond the fold are formed as mirror images of their source cells, which
+    // must be cells of this rank (true of any decomposition into bands of whole rows, and of one rank)
+    bool fold_local = true;
+    std::vector<int> jfold(h.nblocks, h.nyb);
+    if (cfg->ns_boundary == 2)
+      for (int lb = 0; lb < h.nblocks; ++lb) {
+        const BlockInfo &B = h.all_blocks[h.local_ids[lb] - 1];
+        if (!(B.j_glob[B.je] < 0)) continue;
+        jfold[lb] = B.je;
+        for (int j = B.je; j < h.nyb; ++j) for (int i = 0; i < h.nxb; ++i) {
+          const int cell = lb * (int)h.n2 + j * h.nxb + i;
+          if (c->h_srcmap[cell] == cell) fold_local = false;
+        }
+      }
+    const bool two_ok = !use_evp(*cfg) && !g.red_tiles && fold_local, two_on = tun_set(h.tun.pcsi_two_step) ? h.tun.pcsi_two_step != 0 : c->pcsi_two_cell;
+    c->pcsi_two_step = two_ok && two_on && h.halo.peers.empty();
+    c->pcsi_two_step_dist = two_ok && two_on && !h.halo.peers.empty();
     if ((c->pcsi_two_step || c->pcsi_two_step_dist) && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
+    if ((c->pcsi_two_step || c->pcsi_two_step_dist) && cfg->ns_boundary == 2 && dev_upload(c, &c->pcsi_jfold, jfold.data(), jfold.size())) return 1;
     if (tun_set(h.tun.pcsi_step2)) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && h.tun.pcsi_step2 != 0;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && !use_evp(*cfg) && h.nblocks_tot <= 8 &&
                     (long long)h.n2 * h.nblocks_tot <= (4LL << 20) && !tun_on(h.tun.solver_distributed);
@@ -2333,6 +2349,7 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "solver_chunks_active") return c->red_active_total;          // chunks with an ocean cell (or work for another rank), all local blocks
   if (n == "pcg_persist_used") return c->persist_used;
   if (n == "pcg_persist_gave_up") return c->persist_gave_up;
+  if (n == "pcsi_two_step") return (c->pcsi_two_step || c->pcsi_two_step_dist) ? 1 : 0;   // P-CSI: two iterations per launch (k_pcsi_step_x2) in use
   if (n == "pcg_persist_workgroups") return c->persist_nwg;
   if (n == "pcg_persist_chunks_per_workgroup") return c->persist_cp;
   if (n == "solver_path") return c->host_only ? 0 : solver_path_code(c);   // 1 per operation, 2 fused, 3 fused distributed, 4 replicated fused

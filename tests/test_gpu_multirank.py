@@ -176,6 +176,8 @@ def test_balanced_distribution_equals_single_rank(nranks, kw, env, transport):
     (3, "ns_boundary=2,solver_choice=2,hmix_momentum=4,hmix_tracer=4,am=-1.0e22,ah=-1.0e21", {"POP_SOLVER_DISTRIBUTED": "1"}, "native"),
     (2, "ns_boundary=2,block_size_x=48,block_size_y=10", {"POP_SOLVER_UNFUSED": "1", "POP_SOLVER_DISTRIBUTED": "1"}, "native"),   # full-width j-bands
     (2, "ns_boundary=2,solver_choice=3", {}, "native"),
+    (2, "ns_boundary=2,solver_choice=3", {"POP_PCSI_TWO_STEP": "1"}, "staged"),          # P-CSI two iterations per launch: mirrored ring cells beyond the fold, x, dx, r' two rings wide across the ranks
+    (2, "ns_boundary=2,solver_choice=3,block_size_x=48,block_size_y=10,convergence_check_freq=5", {"POP_PCSI_TWO_STEP": "1"}, "native"),   # ... full-width j-bands, pairs and single steps mixed
     (2, "ns_boundary=2,tadvect=3,block_size_x=48,block_size_y=10", {"POP_SOLVER_DISTRIBUTED": "1"}, "native"),   # lw_lim: flux-velocity fields across the fold and the ranks
 ])
 def test_tripole_across_ranks_equals_single_rank(nranks, kw, env, transport):

@@ -13,7 +13,7 @@ Tolerances (fp64):
 import numpy as np
 import pytest
 
-from popcfg import named_config, synthetic_grid
+from popcfg import named_config, synthetic_grid, synthetic_dzbc
 from orclib import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -1149,14 +1149,26 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
     ("tiny", {"block_size_x": 48, "block_size_y": 40, "convergence_check_freq": 4, "max_iterations": 203}),                                    # a last interval of 3 without a check
     ("gx3v7", {}),                                                                          # 100 x 116: two tile columns, the second 36 wide
     ("wide", {}),                                                                           # 2112 columns: 33 tile columns
+    # tripole fold: the ghost cells beyond it are formed as mirror images of their source cells (the tile walked the other way round)
+    ("tiny", {"ns_boundary": 2, "block_size_x": 48, "block_size_y": 40}),                   # one block: the fold partner is the block itself
+    ("tiny", {"ns_boundary": 2, "block_size_x": 24, "block_size_y": 20}),                   # 2 x 2 blocks: the partner is the other block of the top row
+    ("tiny", {"ns_boundary": 2, "block_size_x": 12, "block_size_y": 10, "convergence_check_freq": 5}),   # 16 blocks, pairs and single steps mixed
+    ("tiny", {"ns_boundary": 2, "block_size_x": 28, "block_size_y": 24, "partial_bottom_cells": 1}),   # padded blocks below the fold: tiles overhang beyond it
+    ("tiny", {"ns_boundary": 2, "nx_global": 192, "block_size_x": 96, "block_size_y": 40}),   # two tile columns per block: mirrored partners in other tiles
 ])
 def test_two_step_pcsi_is_bitwise_the_one_step_pcsi(pkg, name, kw):
     """pop_tuning.pcsi_two_step: two P-CSI iterations per pass over the state (k_pcsi_step_x2: x, dx, r' of a 64 x 8 tile and two rings
     of cells around it in LDS, the cells of the rings formed at their source cells) wherever no check follows.  Every value goes through
     the operations of k_pcsi_step / k_pcsi_step2: iteration counts and fields bit for bit."""
     cfg = named_config(name, solver_choice=3, **kw)
-    a = pkg.PopModel(cfg, tuning={"pcg_persist": 0, "pcsi_two_step": 0})
-    b = pkg.PopModel(cfg, tuning={"pcg_persist": 0, "pcsi_two_step": 1})
+    grid = None
+    if cfg.ns_boundary == 2:
+        grid = synthetic_grid(cfg)
+        if cfg.partial_bottom_cells:
+            grid["DZBC"] = synthetic_dzbc(cfg, grid["KMT"])
+    a = pkg.PopModel(cfg, tuning={"pcg_persist": 0, "pcsi_two_step": 0}, grid=grid)
+    b = pkg.PopModel(cfg, tuning={"pcg_persist": 0, "pcsi_two_step": 1}, grid=grid)
+    assert (a.dim("pcsi_two_step"), b.dim("pcsi_two_step")) == (0, 1)
     for step in range(5):
         a.step(); b.step()
         assert a.solver_diagnostics() == b.solver_diagnostics(), "step %d" % step
