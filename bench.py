@@ -457,6 +457,9 @@ def main():
                                                       "config.hmix_tracer says so in the line")
     ap.add_argument("--pbc", action="store_true", help="NOT the headline: partial bottom cells on stepped bathymetry (grid_nml partial_bottom_cells, SURVEY 8 f3); "
                                                        "config.partial_bottom_cells says so in the line")
+    ap.add_argument("--grid-input", action="store_true", help="NOT the headline: horizontal grid and bathymetry supplied by the caller (pop_create_with_grid; the synthetic "
+                                                              "lat-lon arrays of tests/popcfg.synthetic_grid) instead of the internal grid; config.grid_input says so")
+    ap.add_argument("--tripole", action="store_true", help="NOT the headline: tripole northern boundary (ns_boundary_type 'tripole') on the --grid-input arrays")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -512,7 +515,14 @@ def main():
         cfg.hmix_tracer, cfg.ah = 3, 0.8e7
         if args.gm == "cesm":   # the namelist defaults of the gx grids: transition layer + buoyancy-frequency-dependent kappa recomputed once a day
             cfg.gm_transition_layer, cfg.gm_kappa_type, cfg.gm_kappa_freq = 1, 1, 2
-    model = pkg.PopModel(cfg, rank=rank, nranks=world)
+    grid = None
+    if args.tripole or args.grid_input:
+        from popcfg import synthetic_grid
+        if args.tripole:
+            cfg.ns_boundary = 2
+        grid = synthetic_grid(cfg)
+    model = pkg.PopModel(cfg, rank=rank, nranks=world, grid=grid)
+    del grid
     comm, transport, transport_note = None, "none", ""
     if world > 1:
         # default: the library's own RCCL transport (stream-ordered ncclSend/Recv/AllReduce, no host call per
@@ -698,7 +708,8 @@ def main():
                    "land_tile_fraction": round(land_frac, 4), "distribution": "balanced-ocean-columns" if cfg.distribution_type else "equal-block-counts",
                    "blocks_local": model.nblocks,
                    "hmix": "del%d" % cfg.hmix_momentum, "hmix_tracer": {2: "del2", 3: "gm" + ("(transition layer, bfre kappa once a day)" if cfg.gm_transition_layer else "(constant kappa)"), 4: "del4"}[cfg.hmix_tracer], "vmix": ["const", "rich", "kpp"][vm],
-                   "partial_bottom_cells": bool(cfg.partial_bottom_cells), "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
+                   "partial_bottom_cells": bool(cfg.partial_bottom_cells), "ns_boundary": ["closed", "cyclic", "tripole"][cfg.ns_boundary],
+                   "grid_input": bool(args.tripole or args.grid_input), "pcsi_two_iterations_per_launch": bool(model.dim("pcsi_two_step")) if cfg.solver_choice == 3 else None, "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport,
                    # every output of the step is bitwise what the full evaluation gives (tests/test_gpu_parity.py); DESIGN.md 3, "KPP's surface-layer buoyancy difference on demand"
                    "kpp_surface_buoyancy": ("on-demand down to the boundary-layer depth" if vm == 2 and tun.get("kpp_lazy", 1) != 0
