@@ -175,8 +175,11 @@ typedef struct pop_tuning {
                             * 1 (the default where it applies) = the whole solve as ONE resident launch, vectors in LDS / registers, workgroups exchanging partials and halo z through
                             * tagged 16-byte memory words (kernels_pcg_persist.hpp); 0 = the two-launch fused iteration; 2 | 4 | 8: measurement only, that many chunks per workgroup */
   int gm_flux_tile;        /* 0: Gent-McWilliams fluxes cell by cell (every horizontal face flux evaluated in both cells that share it) instead of once per face in 64 x 4 tiles */
-  int pcsi_two_step;       /* fused P-CSI (diagonal preconditioner, one rank, no tripole fold): 1 = two iterations per pass over the state where no check follows
+  int pcsi_two_step;       /* fused P-CSI (diagonal preconditioner; one rank or blocks spread over ranks; through a tripole fold whose partners are on the rank): 1 = two iterations per pass over the state where no check follows
                             * (k_pcsi_step_x2; the default on large grids), 0 = one launch per iteration */
+  int block_sums_relay;    /* ordered block sums of more than 64 x 256 chunk partials (the fused pcg / ChronGear of large grids): 0 = 256 threads, each adding
+                            * its accumulator's terms in batches (two or three memory round trips); default 1 = 1024 threads, four per accumulator, every term
+                            * requested at once and the quarters added in turn (k_block_sums_relay: the same additions in the same order); 2 = also below 64 terms (cross-check) */
 } pop_tuning;
 void pop_tuning_init(pop_tuning *t);   /* struct_bytes = sizeof, every field POP_TUNING_UNSET */
 int pop_get_tuning(const pop_ctx *ctx, pop_tuning *resolved);   /* fields still POP_TUNING_UNSET: the size rule applied */

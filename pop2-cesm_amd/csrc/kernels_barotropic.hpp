@@ -230,6 +230,48 @@ __global__ void __launch_bounds__(POP_RED_THREADS) k_block_sums(const double *__
     for (int f = 0; f < NF; ++f) blocksum[(long long)gid[b] * NF + f] = r[f];
   }
 }
+// The same sum by 1024 threads (large grids, r4).  The order of block_sum_ordered -- 256 accumulators, accumulator a adds the partials
+// a, a + 256, a + 512, ... strictly left to right, then the fixed tree over the accumulators -- bounds a 256-thread workgroup by the 63
+// loads a wave can have in flight: 132 terms per thread (tx0.1v3) are three memory round trips.  Here every accumulator is shared by
+// FOUR threads, thread (a, h) holding the h-th quarter of its terms: all 1024 threads request their <= LMAX terms at once (ONE round
+// trip), then the quarters are added in turn -- thread (a, 0) from +0.0, thread (a, h) from what thread (a, h - 1) left in LDS.  The
+// same additions in the same order; a term that does not exist is not added.
+constexpr int POP_RELAY_SLACK = 4096;
+template <int NF, int LMAX>
+__global__ void __launch_bounds__(1024) k_block_sums_relay(const double *__restrict__ partial, int nchunk, const int *__restrict__ gid,
+                                                            double *__restrict__ blocksum) {
+  __shared__ double relay[POP_RED_THREADS];
+  const int b = blockIdx.x, f = blockIdx.y, T = threadIdx.x, a = T & (POP_RED_THREADS - 1), h = T >> 8;   // one workgroup per (block, field)
+  const double *__restrict__ pb = partial + (long long)b * nchunk * NF + f;
+  const int terms = (nchunk + POP_RED_THREADS - 1) / POP_RED_THREADS, L = (terms + 3) / 4;   // L <= LMAX (host)
+  // term u of this thread: partial a + 256 (h L + u) = (a wave-uniform base that advances with u) + (one offset per thread): a scalar
+  // base and ONE address register for all the loads.  Unpredicated: the host allocates POP_RELAY_SLACK doubles behind the partials, a
+  // value read from there is not added.
+  const unsigned toff = ((unsigned)a + (unsigned)POP_RED_THREADS * (unsigned)(h * L)) * NF;
+  double w[LMAX];
+#pragma unroll
+  for (int u = 0; u < LMAX; ++u) {
+    const double *__restrict__ pu = pb + (size_t)POP_RED_THREADS * u * NF;
+    w[u] = (u < L) ? pu[toff] : 0.0;   // (uniform condition)
+  }
+#pragma unroll 1
+  for (int hh = 0; hh < 4; ++hh) {
+    if (h == hh) {
+      double v = (hh == 0) ? 0.0 : relay[a];
+#pragma unroll
+      for (int u = 0; u < LMAX; ++u) {
+        const bool there = u < L && (long long)a + (long long)POP_RED_THREADS * (h * L + u) < nchunk;
+        v = there ? v + w[u] : v;
+      }
+      relay[a] = v;
+    }
+    __syncthreads();
+  }
+  if (T < 64) {
+    const double x = tree_tail64((relay[T] + relay[T + 128]) + (relay[T + 64] + relay[T + 192]));
+    if (T == 0) blocksum[(long long)gid[b] * NF + f] = x;
+  }
+}
 // the whole block-sum vector of the decomposition in one launch (grid = nblocks_tot): own blocks get their
 // ordered sum, the others 0, ready for the all-reduce (replaces memset + k_block_sums)
 template <int NF>

@@ -475,8 +475,16 @@ FusedArgs fused_args(pop_ctx *c, const SolveView &v) {
   return a;
 }
 // large grids: ordered block sums of a partial array between solver kernels (view-local block order)
+// (more than 64 terms per accumulator: the four-threads-per-accumulator form, one memory round trip instead of two or three)
+constexpr int POP_RELAY_LMAX = 36;
+static bool presum_relay(const pop_ctx *c, const SolveView &v) {
+  const int terms = (v.nchunk + POP_RED_THREADS - 1) / POP_RED_THREADS;
+  const int t = tun_or(c->h.tun.block_sums_relay, 1);   // 2: wherever it can run (the cross-check on small grids)
+  return (terms > 64 || t == 2) && (terms + 3) / 4 <= POP_RELAY_LMAX && t != 0;
+}
 void presum(pop_ctx *c, const SolveView &v, const double *partial, double *bs) {
-  hipLaunchKernelGGL(k_block_sums<1>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->iota, bs);
+  if (presum_relay(c, v)) hipLaunchKernelGGL((k_block_sums_relay<1, POP_RELAY_LMAX>), dim3(v.g.nblocks), dim3(1024), 0, c->stream, partial, v.nchunk, (const int *)c->iota, bs);
+  else hipLaunchKernelGGL(k_block_sums<1>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, partial, v.nchunk, c->iota, bs);
 }
 dim3 view_grid(const SolveView &v) { return dim3(red_grid_x(v.g), v.g.nblocks); }
 // r = b - A x (+ partial (r,r)) of the fused solvers: two cells per thread on large grids, else one
@@ -1030,7 +1038,8 @@ static int cg_fused_iterations(pop_ctx *c, SolveView &v, int n, int &par) {
     a.AZ = c->AZ; a.A0R = v.S1;
     if (a.presummed && (v.g.nxb & 1) == 0 && !v.g.red_tiles && !c->fpcg_one_cell) hipLaunchKernelGGL(k_fcg_a2, G, dim3(POP_RED_THREADS / 2), 0, c->stream, v.g, a);
     else hipLaunchKernelGGL(k_fcg_a, G, B, 0, c->stream, v.g, a);
-    if (a.presummed) hipLaunchKernelGGL(k_block_sums<2>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, (const double *)a.partA, v.nchunk, (const int *)c->iota, (double *)a.bsA);
+    if (a.presummed && presum_relay(c, v)) hipLaunchKernelGGL((k_block_sums_relay<2, POP_RELAY_LMAX>), dim3(v.g.nblocks, 2), dim3(1024), 0, c->stream, (const double *)a.partA, v.nchunk, (const int *)c->iota, (double *)a.bsA);
+    else if (a.presummed) hipLaunchKernelGGL(k_block_sums<2>, dim3(v.g.nblocks), dim3(POP_RED_THREADS), 0, c->stream, (const double *)a.partA, v.nchunk, (const int *)c->iota, (double *)a.bsA);
     hipLaunchKernelGGL(k_fcg_b, G, B, 0, c->stream, v.g, a, par);
     par = 1 - par;
   }
@@ -1587,7 +1596,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED") X(pcg_persist, "POP_PCG_PERSIST") X(gm_flux_tile, "POP_GM_FLUX_TILE") X(pcsi_two_step, "POP_PCSI_TWO_STEP")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED") X(pcg_persist, "POP_PCG_PERSIST") X(gm_flux_tile, "POP_GM_FLUX_TILE") X(pcsi_two_step, "POP_PCSI_TWO_STEP") X(block_sums_relay, "POP_BLOCK_SUMS_RELAY")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -2048,7 +2057,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       c->red_nact = (int)longest;
     }
   }
-  if (dev_alloc(c, &c->partial, (size_t)c->nchunk * h.nblocks * 2) || dev_alloc(c, &c->blocksum, (size_t)h.nblocks_tot * 4)) return 1;
+  if (dev_alloc(c, &c->partial, (size_t)c->nchunk * h.nblocks * 2 + POP_RELAY_SLACK) || dev_alloc(c, &c->blocksum, (size_t)h.nblocks_tot * 4)) return 1;
   { std::vector<int> io(h.nblocks_tot); for (int b = 0; b < h.nblocks_tot; ++b) io[b] = b; if (dev_upload(c, &c->iota, io.data(), io.size())) return 1; }
   if (dev_alloc(c, &c->sc, 1)) return 1;
   { std::vector<int> gid(h.nblocks); for (int lb = 0; lb < h.nblocks; ++lb) gid[lb] = h.local_ids[lb] - 1; if (dev_upload(c, &c->gid, gid.data(), gid.size())) return 1; }
@@ -2226,7 +2235,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
       if (dev_upload(c, &c->gKMT, h.i2["KMT"].data(), NG)) return 1;
       double **vecs[] = {&v.X, &v.R, &v.Z, &v.S0, &v.S1, &v.Q, &v.RHS, &v.C};
       for (auto q : vecs) if (dev_alloc(c, q, NG)) return 1;
-      if (dev_alloc(c, &v.partial, (size_t)c->nchunk * h.nblocks_tot * 2) || dev_alloc(c, &v.blocksum, (size_t)h.nblocks_tot * 4)) return 1;
+      if (dev_alloc(c, &v.partial, (size_t)c->nchunk * h.nblocks_tot * 2 + POP_RELAY_SLACK) || dev_alloc(c, &v.blocksum, (size_t)h.nblocks_tot * 4)) return 1;
       std::vector<int> gsm = global_srcmap(h), gid(h.nblocks_tot);
       for (int b = 0; b < h.nblocks_tot; ++b) gid[b] = b;
       if (dev_upload(c, &v.srcmap, gsm.data(), gsm.size()) || dev_upload(c, &v.gid, gid.data(), gid.size())) return 1;

@@ -74,6 +74,7 @@
       integer (c_int) :: pcg_persist
       integer (c_int) :: gm_flux_tile
       integer (c_int) :: pcsi_two_step
+      integer (c_int) :: block_sums_relay
    end type pop_tuning
 
    type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task

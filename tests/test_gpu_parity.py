@@ -1141,6 +1141,34 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
 
 
 @pytest.mark.parametrize("name,kw", [
+    ("tiny", {"block_size_x": 48, "block_size_y": 40}),                                     # 9 chunks: accumulators with one term or none, three of the four quarters empty
+    ("tiny", {"block_size_x": 24, "block_size_y": 20}),                                     # 4 blocks: one workgroup per block
+    ("gx3v7", {}),                                                                          # 49 chunks
+    ("gx1v7", {}),                                                                          # 492 chunks: two terms per accumulator, ragged
+    ("gx1v7", {"solver_choice": 2}),                                                        # ChronGear: two fields, one workgroup per (block, field)
+    ("tiny", {"solver_choice": 2, "block_size_x": 24, "block_size_y": 20}),
+    ("tx0.1v3", {"nx_global": 1800, "ny_global": 1200, "block_size_x": 1800, "block_size_y": 1200, "km": 20, "vmix_choice": 1}),   # 8 484 chunks: 34 terms, quarters of 9, 9, 9, 7 (+1 ragged)
+    ("tx0.1v3", {"nx_global": 1800, "ny_global": 1200, "block_size_x": 1800, "block_size_y": 1200, "km": 20, "vmix_choice": 1, "solver_choice": 2}),
+])
+def test_relay_block_sums_are_bitwise_the_batched_block_sums(pkg, name, kw):
+    """pop_tuning.block_sums_relay: the ordered block sums between the kernels of a fused pcg / ChronGear iteration by 1024 threads, four per
+    accumulator (k_block_sums_relay: every term requested at once, the quarters of an accumulator's terms added in turn) against the
+    256-thread form.  The same additions in the same order: iteration counts and fields bit for bit.  (2 = also where an accumulator
+    has fewer than 64 terms; the default 1 applies from 64 terms on, i.e. tx0.1v3 in one block -- compared at full size by
+    profiles/probes/relay_fullsize.py.)"""
+    cfg = named_config(name, **kw)
+    base = {"pcg_persist": 0, "solver_presum": 1}
+    a = pkg.PopModel(cfg, tuning=dict(base, block_sums_relay=0))
+    b = pkg.PopModel(cfg, tuning=dict(base, block_sums_relay=2))
+    for step in range(3):
+        a.step(); b.step()
+        assert a.solver_diagnostics() == b.solver_diagnostics(), "step %d" % step
+    for f in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER", "GRADPX"):
+        assert np.array_equal(a.get(f), b.get(f)), f
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,kw", [
     ("tiny", {"block_size_x": 48, "block_size_y": 40}),                                     # one block, cyclic east-west, closed north-south
     ("tiny", {"block_size_x": 24, "block_size_y": 20}),                                     # 4 blocks: the rings of a tile cross block boundaries through the source map
     ("tiny", {"block_size_x": 24, "block_size_y": 20, "ew_boundary": 0, "stepped_bathymetry": 1}),   # closed everywhere: fill cells in the rings
