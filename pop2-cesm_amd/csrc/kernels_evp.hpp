@@ -261,4 +261,139 @@ k_evp_apply_wave2(EvpDev e, int nxb, const double *__restrict__ X, double *__res
     if (solve && c <= m - 1 && a0 <= n - 1) PX[cell(a0, c)] = ys[w][at(a0, c)];
 }
 
+// ---- P-CSI iteration + sub-block solves in ONE launch (round 4) ---------------------------------------------------------------------------
+// With the EVP preconditioner a P-CSI iteration was two launches: k_pcsi_step2 (dx, x, r = b - A x; the residual itself to memory) and
+// k_evp_apply_wave2 (r' = M^-1 r, sub-block by sub-block).  Here the wave that solves eight sub-blocks first forms what the step kernel forms
+// for them: x_new = x + (omega r' + (csy omega - 1) dx) on every sub-block WITH its rim (100 cells; a rim cell that is a ghost cell of the block
+// is formed at its source cell, the fill value where there is none) into the LDS array the marching sweeps use afterwards, then r = b - A x_new on
+// the 8 x 8 interior -- lane = column, so r(i, j) lands in the register slot of the anti-diagonal step that consumes it -- and then the solve of
+// k_evp_apply_wave2.  The expressions and their order are those of k_pcsi_step2 / k_evp_apply_wave2: bitwise the two launches
+// (tests/test_gpu_parity.py).  r' ping-pongs like x and dx (a neighbouring sub-block still reads the old one).  RAW: the residual itself also
+// goes to `raw`, from which k_pcsi_rr_chunks forms the chunk partials of (r, r) for the check.
+template <bool RAW>
+__global__ void __launch_bounds__(64)
+k_pcsi_evp_step(EvpDev e, DevGrid g, PcsiArgs a, double *__restrict__ raw) {
+  if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
+  __shared__ double ys[POP_EVP_SB][EVP_PAD], nes[POP_EVP_SB][EVP_PAD];
+  __shared__ double rs[POP_EVP_SB][EVP_LE + 1];
+  const int nxb = g.nxb;
+  const int t = threadIdx.x, w = t >> 3, l = t & 7;
+  const long long s = (long long)blockIdx.x * POP_EVP_SB + w;
+  const bool live = s < e.S;
+  int4 mt = make_int4(0, 3 | (3 << 8), 1, 0);
+  if (live) mt = e.meta[s];
+  const int n = mt.y & 255, m = mt.y >> 8;
+  const bool solve = live && !mt.z;
+  auto cell = [&](int a_, int c) { return (long long)mt.x + (long long)(c - 1) * nxb + (a_ - 1); };
+  auto at = [](int a_, int c) { return (a_ - 1) + EVP_LD * (c - 1); };
+  const double om = a.omega[*a.base + a.j], cq = a.csy * om - 1.0;
+  const long long qsafe = cell(2, 2);
+  // position of (1,1) in its block: the sub-blocks tile the NOMINAL block, so on padded blocks (blocks.F90:174-265) a sub-block can hold
+  // cells beyond the block's own extent (ghost cells and cells of no block at all): only physical cells are advanced in place and stored
+  const int bk = (int)(mt.x / g.n2), p11 = (int)(mt.x - (long long)bk * g.n2), i11 = p11 % nxb, j11 = p11 / nxb;
+  auto phys = [&](int a_, int c) { return interior(g, bk, i11 + a_ - 1, j11 + c - 1); };
+  // ---- x_new of the sub-block with its rim -> ys; dx_new, x_new of the interior -> memory; ne with its rim -> nes
+  auto advance = [&](int a_, int c) {
+    double xn = 0.0, nev = 0.0;
+    if (live && c <= m && a_ <= n) {
+      const long long q = cell(a_, c);
+      const bool rim = a_ == 1 || a_ == n || c == 1 || c == m, own = phys(a_, c);
+      const long long src = own ? q : (long long)a.srcmap[q];
+      const long long qq = (src >= 0) ? src : qsafe;
+      const double dx = om * a.Ri[qq] + cq * a.Qi[qq];
+      const double x = a.Xi[qq] + dx;
+      xn = (src >= 0) ? x : 0.0;
+      nev = e.WNE[q];
+      if (!rim && own) { a.Qo[q] = dx; a.Xo[q] = x; }
+    }
+    ys[w][at(a_, c)] = xn; nes[w][at(a_, c)] = nev;
+  };
+  for (int c = 1; c <= EVP_LD; ++c) {
+    advance(1 + l, c);
+    if (l < 2) advance(9 + l, c);
+  }
+  // the correction rows of this lane (as in k_evp_apply_wave2), requested before the first barrier
+  const int i = 2 + l;
+  const int nm = n + m - 5;
+  double rv0[EVP_LE], rv1[EVP_LE];
+  const int row0 = 1 + l, row1 = 9 + l;
+#pragma unroll
+  for (int k = 1; k <= EVP_LE; ++k) {
+    rv0[k - 1] = (solve && row0 <= nm && k <= nm) ? e.rinv[(long long)((k - 1) + EVP_LE * (row0 - 1)) * e.S + s] : 0.0;
+    rv1[k - 1] = (solve && row1 <= nm && k <= nm) ? e.rinv[(long long)((k - 1) + EVP_LE * (row1 - 1)) * e.S + s] : 0.0;
+  }
+  __syncthreads();
+  // ---- r = b - A x_new on the interior: lane = column i, row j = step + 4 - i; the operator of k_pcsi_step2 (weights at the cell, its
+  // southern and western neighbours; centre, N, S, E, W, NE, SE, NW, SW added in this order)
+  double xx[EVP_STEPS], cs[EVP_STEPS];
+#pragma unroll
+  for (int q = 0; q < EVP_STEPS; ++q) {
+    const int j = q + 4 - i;
+    const bool in_sb = live && j >= 2 && j <= m - 1 && i <= n - 1, ok = in_sb && phys(i, j);
+    double r = 0.0, c0 = 0.0;
+    if (in_sb) c0 = e.C0[cell(i, j)];
+    if (ok) {
+      const long long qc = cell(i, j);
+      const double wv[9] = {a.C[qc], g.WNo[qc], g.WNo[qc - nxb], g.WEa[qc], g.WEa[qc - 1], g.WNE[qc], g.WNE[qc - nxb], g.WNE[qc - 1], g.WNE[qc - 1 - nxb]};
+      const double *X = ys[w];
+      const double ax = wv[0] * X[at(i, j)] + wv[1] * X[at(i, j + 1)] + wv[2] * X[at(i, j - 1)] + wv[3] * X[at(i + 1, j)] + wv[4] * X[at(i - 1, j)] +
+                        wv[5] * X[at(i + 1, j + 1)] + wv[6] * X[at(i + 1, j - 1)] + wv[7] * X[at(i - 1, j + 1)] + wv[8] * X[at(i - 1, j - 1)];
+      r = a.Bv[qc] - ax;
+      if (RAW) raw[qc] = r;
+      if (mt.z) a.Ro[qc] = r * ((c0 != 0.0) ? 1.0 / c0 : 0.0);   // sub-blocks with land: diagonal scaling (:2344-2348)
+    }
+    xx[q] = solve ? r : 0.0; cs[q] = solve ? c0 : 0.0;
+  }
+  __syncthreads();
+  // ---- the solve of k_evp_apply_wave2 from here on (y = 0 first: the array held x_new)
+  for (int c = 1; c <= EVP_LD; ++c) {
+    ys[w][at(1 + l, c)] = 0.0;
+    if (l < 2) ys[w][at(9 + l, c)] = 0.0;
+  }
+  double in[EVP_STEPS];
+#pragma unroll
+  for (int q = 0; q < EVP_STEPS; ++q) {
+    const int j = q + 4 - i;
+    const bool ok = solve && j >= 2 && j <= m - 1 && i <= n - 1;
+    const double nv = ok ? nes[w][at(i, j)] : 0.0;
+    in[q] = (nv != 0.0) ? 1.0 / nv : 0.0;
+  }
+  __syncthreads();
+  auto sweep = [&](int imax, int jmax) {
+#pragma unroll
+    for (int q = 0; q < EVP_STEPS; ++q) {
+      const int j = q + 4 - i;
+      const bool on = solve && j >= 2 && j <= jmax && i <= imax;
+      double v = 0.0;
+      if (on)
+        v = (xx[q] - cs[q] * ys[w][at(i, j)] - nes[w][at(i, j - 1)] * ys[w][at(i + 1, j - 1)] -
+             nes[w][at(i - 1, j)] * ys[w][at(i - 1, j + 1)] - nes[w][at(i - 1, j - 1)] * ys[w][at(i - 1, j - 1)]) * in[q];
+      if (on) ys[w][at(i + 1, j + 1)] = v;
+      __syncthreads();
+    }
+  };
+  sweep(n - 1, m - 1);
+  for (int k = 1 + l; k <= EVP_LE; k += 8)
+    if (solve && k <= nm) rs[w][k] = (k <= n - 2) ? ys[w][at(k + 2, m)] : ys[w][at(n, m - (k - (n - 2)))];
+  __syncthreads();
+  auto target = [&](int jj) { return (jj <= m - 2) ? at(2, m - jj) : at(jj - (m - 2) + 2, 2); };
+  if (solve && row0 <= nm) {
+    double acc = ys[w][target(row0)];
+#pragma unroll
+    for (int k = 1; k <= EVP_LE; ++k) if (k <= nm) acc = acc + rv0[k - 1] * rs[w][k];
+    ys[w][target(row0)] = acc;
+  }
+  if (solve && row1 <= nm) {
+    double acc = ys[w][target(row1)];
+#pragma unroll
+    for (int k = 1; k <= EVP_LE; ++k) if (k <= nm) acc = acc + rv1[k - 1] * rs[w][k];
+    ys[w][target(row1)] = acc;
+  }
+  __syncthreads();
+  sweep(n - 2, m - 2);
+  const int a0 = 2 + l;
+  for (int c = 2; c <= EVP_LD - 1; ++c)
+    if (solve && c <= m - 1 && a0 <= n - 1) a.Ro[cell(a0, c)] = ys[w][at(a0, c)];
+}
+
 }  // namespace pop

@@ -123,6 +123,7 @@ struct pop_ctx {
   bool pcsi_two_step_dist = false;   // ... with blocks spread over ranks
   double *pcsi_raw = nullptr;   // the residual of the pair before a check (k_pcsi_step_x2<true> -> k_pcsi_rr_chunks)
   int *pcsi_jfold = nullptr;    // tripole: per local block, the first array row beyond the fold (PcsiArgs::jfold)
+  bool pcsi_evp_fused = false;  // P-CSI + EVP: iteration and sub-block solves in one launch (k_pcsi_evp_step; pop_tuning.pcsi_evp_fused)
   bool reg_thomas_t = true;
   int trc_lds_rows = 4;                                    // tracer RHS (centred advection): LDS tile rows, 0 = direct loads
   int mom_lds_rows = 4;                                    // momentum RHS: LDS tile rows (0 = direct-load kernel)
@@ -1303,6 +1304,20 @@ static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool
   const DevGrid gg = pcsi_grid(c);
   const dim3 G(red_grid_x(gg), gg.nblocks), B(POP_RED_THREADS);
   int j0 = 1;
+  if (c->pcsi_evp_fused) {   // EVP: one launch per iteration (the step and the sub-block solves); r' ping-pongs with x and dx
+    const dim3 GE((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB));
+    for (int j = 1; j <= freq; ++j) {
+      PcsiArgs a = pcsi_args(c, bf, in, j);
+      a.raw_r = 0; a.Ri = bf.R[in]; a.Ro = bf.R[1 - in];
+      if (j == freq && with_rr) {
+        hipLaunchKernelGGL(k_pcsi_evp_step<true>, GE, dim3(64), 0, c->stream, c->evp, gg, a, c->pcsi_raw);
+        hipLaunchKernelGGL(k_pcsi_rr_chunks, G, B, 0, c->stream, gg, a, (const double *)c->pcsi_raw);
+      } else hipLaunchKernelGGL(k_pcsi_evp_step<false>, GE, dim3(64), 0, c->stream, c->evp, gg, a, (double *)nullptr);
+      in = 1 - in;
+    }
+    if (with_rr) hipLaunchKernelGGL(k_rr_total, dim3(1), dim3(POP_RED_THREADS), 0, c->stream, (const double *)c->partial, c->nchunk, c->g.nblocks, c->sc, c->host_rr, c->h.convergenceCriterion);
+    return;
+  }
   const int npairs = pcsi_pairs(c, freq);
   for (int p = 0; p < npairs; ++p, j0 += 2) {
     pcsi_launch_pair(c, gg, pcsi_args(c, bf, in, j0), with_rr && j0 + 1 == freq);   // (the last pair of an even interval that ends in a check)
@@ -1327,6 +1342,7 @@ int solver_pcsi_fused(pop_ctx *c) {
   const dim3 G = grid_2d(c), B(POP_RED_THREADS);
   const int freq = cf.convergence_check_freq, start = pcsi_check_start(c);
   PcsiBufs bf{{c->PS[c->newt], c->Z}, {c->R, c->AZ}, {c->Q, c->S1}};   // (with EVP the residual pair is fixed: pcsi_args)
+  if (c->pcsi_evp_fused) std::swap(bf.R[0], bf.R[1]);   // ... except in the one-launch form: the start-up step leaves r' in R, which is then the half the first iteration reads
   SolverScalars init{};
   HIPCHK(c, hipMemcpyAsync(c->sc, &init, sizeof(init), hipMemcpyHostToDevice, c->stream));
   // r0 = b - A x0 (ghosts of x0 read at their sources), then the start-up step x1 = x0 + r0'/gamma, r1 = b - A x1
@@ -1596,7 +1612,7 @@ int pop_create_with_grid(const pop_config *cfg, const pop_grid_input *grid, int 
   X(kpp_src_full, "POP_KPP_SRC_FULL") X(solver_unfused, "POP_SOLVER_UNFUSED") X(solver_nograph, "POP_SOLVER_NOGRAPH")                   \
   X(solver_presum, "POP_SOLVER_PRESUM") X(solver_distributed, "POP_SOLVER_DISTRIBUTED") X(solver_overlap_off, "POP_SOLVER_OVERLAP_OFF") \
   X(fpcg_b2, "POP_FPCG_B2") X(pcsi_step2, "POP_PCSI_STEP2") X(halo_separate, "POP_HALO_SEPARATE")                                       \
-  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED") X(pcg_persist, "POP_PCG_PERSIST") X(gm_flux_tile, "POP_GM_FLUX_TILE") X(pcsi_two_step, "POP_PCSI_TWO_STEP") X(block_sums_relay, "POP_BLOCK_SUMS_RELAY")
+  X(halo_overlap_off, "POP_HALO_OVERLAP_OFF") X(rccl_overlap, "POP_RCCL_OVERLAP") X(evp_wave, "POP_EVP_WAVE") X(fpcg_a_pair, "POP_FPCG_A_PAIR") X(stream_priority, "POP_STREAM_PRIORITY") X(kpp_sparse, "POP_KPP_SPARSE") X(pbc_generic_thomas, "POP_PBC_GENERIC_THOMAS") X(pbc_generic_kpp, "POP_PBC_GENERIC_KPP") X(state3d_levels, "POP_STATE3D_LEVELS") X(gm_sf_stored, "POP_GM_SF_STORED") X(pcg_persist, "POP_PCG_PERSIST") X(gm_flux_tile, "POP_GM_FLUX_TILE") X(pcsi_two_step, "POP_PCSI_TWO_STEP") X(block_sums_relay, "POP_BLOCK_SUMS_RELAY") X(pcsi_evp_fused, "POP_PCSI_EVP_FUSED")
 void pop_tuning_init(pop_tuning *t) {
   if (!t) return;
   t->struct_bytes = (int)sizeof(pop_tuning);
@@ -2213,6 +2229,8 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->pcsi_two_step = two_ok && two_on && h.halo.peers.empty();
     c->pcsi_two_step_dist = two_ok && two_on && !h.halo.peers.empty();
     if ((c->pcsi_two_step || c->pcsi_two_step_dist) && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
+    c->pcsi_evp_fused = c->evp_fused_ok && c->evp.C0 && tun_or(h.tun.evp_wave, 2) == 2 && !tun_off(h.tun.pcsi_evp_fused);
+    if (c->pcsi_evp_fused && !c->pcsi_raw && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
     if ((c->pcsi_two_step || c->pcsi_two_step_dist) && cfg->ns_boundary == 2 && dev_upload(c, &c->pcsi_jfold, jfold.data(), jfold.size())) return 1;
     if (tun_set(h.tun.pcsi_step2)) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && h.tun.pcsi_step2 != 0;
     c->replicated = !h.halo.peers.empty() && cfg->solver_choice == 1 && !use_evp(*cfg) && h.nblocks_tot <= 8 &&
@@ -2358,6 +2376,7 @@ int pop_get_dim(const pop_ctx *c, const char *name) {
   if (n == "solver_chunks_active") return c->red_active_total;          // chunks with an ocean cell (or work for another rank), all local blocks
   if (n == "pcg_persist_used") return c->persist_used;
   if (n == "pcg_persist_gave_up") return c->persist_gave_up;
+  if (n == "pcsi_evp_fused") return c->pcsi_evp_fused ? 1 : 0;   // P-CSI + EVP: one launch per iteration (k_pcsi_evp_step) in use
   if (n == "pcsi_two_step") return (c->pcsi_two_step || c->pcsi_two_step_dist) ? 1 : 0;   // P-CSI: two iterations per launch (k_pcsi_step_x2) in use
   if (n == "pcg_persist_workgroups") return c->persist_nwg;
   if (n == "pcg_persist_chunks_per_workgroup") return c->persist_cp;

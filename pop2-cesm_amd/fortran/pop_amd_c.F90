@@ -75,6 +75,7 @@
       integer (c_int) :: gm_flux_tile
       integer (c_int) :: pcsi_two_step
       integer (c_int) :: block_sums_relay
+      integer (c_int) :: pcsi_evp_fused
    end type pop_tuning
 
    type (c_ptr), save :: pop_ctx = c_null_ptr   ! the one model instance of this task

@@ -1141,6 +1141,34 @@ def test_fused_solver_is_bitwise_the_unfused_solver(pkg, monkeypatch, kw):
 
 
 @pytest.mark.parametrize("name,kw", [
+    ("tiny", {"block_size_x": 48, "block_size_y": 40}),                                     # one block, cyclic east-west: rim cells of the sub-blocks read at their source cells
+    ("tiny", {"block_size_x": 24, "block_size_y": 20}),                                     # 4 blocks
+    ("tiny", {"block_size_x": 24, "block_size_y": 20, "ew_boundary": 0, "stepped_bathymetry": 1}),   # closed everywhere: fill values in the rims; sub-blocks with land (diagonal scaling)
+    ("tiny", {"block_size_x": 28, "block_size_y": 24}),                                     # padded blocks: ragged sub-blocks
+    ("tiny", {"block_size_x": 24, "block_size_y": 20, "convergence_check_freq": 7, "max_iterations": 200, "convergence_check_start": 14}),   # odd interval, a last interval without a check
+    ("tiny", {"ns_boundary": 2, "block_size_x": 24, "block_size_y": 20}),                   # tripole fold: rim cells beyond it are mirrored copies (formed at their source cells)
+    ("gx3v7", {}),
+    ("gx1v7", {}),
+    ("tx0.1v3", {"nx_global": 1800, "ny_global": 1200, "block_size_x": 1800, "block_size_y": 1200, "km": 20, "vmix_choice": 1}),
+])
+def test_one_launch_pcsi_evp_is_bitwise_the_two_launch_form(pkg, name, kw):
+    """pop_tuning.pcsi_evp_fused: a P-CSI iteration with the EVP preconditioner as ONE launch (k_pcsi_evp_step: the wave that solves eight
+    sub-blocks first forms dx, x and r = b - A x for them) against k_pcsi_step2 + k_evp_apply_wave2.  Same expressions in the same order:
+    iteration counts and fields bit for bit."""
+    cfg = named_config(name, solver_choice=3, preconditioner_choice=1, **kw)
+    grid = synthetic_grid(cfg) if cfg.ns_boundary == 2 else None
+    a = pkg.PopModel(cfg, tuning={"pcsi_evp_fused": 0}, grid=grid)
+    b = pkg.PopModel(cfg, tuning={"pcsi_evp_fused": 1}, grid=grid)
+    assert (a.dim("pcsi_evp_fused"), b.dim("pcsi_evp_fused")) == (0, 1)
+    for step in range(4):
+        a.step(); b.step()
+        assert a.solver_diagnostics() == b.solver_diagnostics(), "step %d" % step
+    for f in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER", "GRADPX"):
+        assert np.array_equal(a.get(f), b.get(f)), f
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,kw", [
     ("tiny", {"block_size_x": 48, "block_size_y": 40}),                                     # 9 chunks: accumulators with one term or none, three of the four quarters empty
     ("tiny", {"block_size_x": 24, "block_size_y": 20}),                                     # 4 blocks: one workgroup per block
     ("gx3v7", {}),                                                                          # 49 chunks
