@@ -180,8 +180,9 @@ typedef struct pop_tuning {
   int block_sums_relay;    /* ordered block sums of more than 64 x 256 chunk partials (the fused pcg / ChronGear of large grids): 0 = 256 threads, each adding
                             * its accumulator's terms in batches (two or three memory round trips); default 1 = 1024 threads, four per accumulator, every term
                             * requested at once and the quarters added in turn (k_block_sums_relay: the same additions in the same order); 2 = also below 64 terms (cross-check) */
-  int pcsi_evp_fused;      /* fused P-CSI with the EVP preconditioner: default 1 = the iteration (dx, x, r = b - A x) and the sub-block solves r' = M^-1 r in ONE
-                            * launch (k_pcsi_evp_step); 0 = two launches per iteration (k_pcsi_step2, k_evp_apply_wave2) */
+  int pcsi_evp_fused;      /* fused P-CSI with the EVP preconditioner: 1 = the iteration (dx, x, r = b - A x) and the sub-block solves r' = M^-1 r in ONE
+                            * launch (k_pcsi_evp_step; bitwise, but measured slower: its loads are issued by the few waves of the sub-block solve);
+                            * default 0 = two launches per iteration (k_pcsi_step2, k_evp_apply_wave2) */
 } pop_tuning;
 void pop_tuning_init(pop_tuning *t);   /* struct_bytes = sizeof, every field POP_TUNING_UNSET */
 int pop_get_tuning(const pop_ctx *ctx, pop_tuning *resolved);   /* fields still POP_TUNING_UNSET: the size rule applied */

@@ -270,6 +270,10 @@ k_evp_apply_wave2(EvpDev e, int nxb, const double *__restrict__ X, double *__res
 // k_evp_apply_wave2.  The expressions and their order are those of k_pcsi_step2 / k_evp_apply_wave2: bitwise the two launches
 // (tests/test_gpu_parity.py).  r' ping-pongs like x and dx (a neighbouring sub-block still reads the old one).  RAW: the residual itself also
 // goes to `raw`, from which k_pcsi_rr_chunks forms the chunk partials of (r, r) for the check.
+// MEASURED SLOWER than the two launches (gx1v7 28.9 against 22.7 us per iteration, tx0.1v3 515 against 283): the step's loads -- issued by
+// 4 waves per SIMD in k_pcsi_step2 -- come here from the one wave per eight sub-blocks of the solve, row by row behind their conditions, and
+// the launch loses the land elimination of the step kernel.  Kept behind pop_tuning.pcsi_evp_fused = 1 (default off) as the bitwise-checked
+// starting point of a version with every load issued up front.
 template <bool RAW>
 __global__ void __launch_bounds__(64)
 k_pcsi_evp_step(EvpDev e, DevGrid g, PcsiArgs a, double *__restrict__ raw) {

@@ -2229,7 +2229,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->pcsi_two_step = two_ok && two_on && h.halo.peers.empty();
     c->pcsi_two_step_dist = two_ok && two_on && !h.halo.peers.empty();
     if ((c->pcsi_two_step || c->pcsi_two_step_dist) && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
-    c->pcsi_evp_fused = c->evp_fused_ok && c->evp.C0 && tun_or(h.tun.evp_wave, 2) == 2 && !tun_off(h.tun.pcsi_evp_fused);
+    c->pcsi_evp_fused = c->evp_fused_ok && c->evp.C0 && tun_or(h.tun.evp_wave, 2) == 2 && tun_on(h.tun.pcsi_evp_fused);   // measured slower: off unless asked for
     if (c->pcsi_evp_fused && !c->pcsi_raw && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
     if ((c->pcsi_two_step || c->pcsi_two_step_dist) && cfg->ns_boundary == 2 && dev_upload(c, &c->pcsi_jfold, jfold.data(), jfold.size())) return 1;
     if (tun_set(h.tun.pcsi_step2)) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && h.tun.pcsi_step2 != 0;
