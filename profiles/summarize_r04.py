@@ -24,15 +24,16 @@ def kernel_stats(wl, sub="_stats", tag=""):
     fs = sorted(glob.glob(os.path.join(PROF, wl + sub, "*", "*kernel_trace.csv")), key=os.path.getmtime, reverse=True)   # newest collection first
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(fs[0])):
-        a = acc.setdefault(r["Kernel_Name"], [0, 0])
+        a = acc.setdefault(r["Kernel_Name"], [0, 0, []])
         a[0] += 1
         a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        a[2].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     tot = sum(a[1] for a in acc.values())
     out = os.path.join(ROOT, "profiles", "r04_%s%s_kernel_stats.csv" % (wl, tag))
     with open(out, "w") as f:
-        f.write("kernel,calls,total_ms,avg_us,percent\n")
+        f.write("kernel,calls,total_ms,avg_us,percent,median_us\n")      # (the mean of a short kernel carries the first launches' outliers)
         for k, a in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-            f.write('"%s",%d,%.3f,%.2f,%.2f\n' % (k, a[0], a[1] / 1e6, a[1] / a[0] / 1e3, 100.0 * a[1] / tot))
+            f.write('"%s",%d,%.3f,%.2f,%.2f,%.2f\n' % (k, a[0], a[1] / 1e6, a[1] / a[0] / 1e3, 100.0 * a[1] / tot, sorted(a[2])[len(a[2]) // 2] / 1e3))
     return out
 
 
