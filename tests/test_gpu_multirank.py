@@ -52,6 +52,13 @@ def test_large_grid_two_ranks_equal_single_rank():
                 "--kw", "nx_global=1800,ny_global=1200,block_size_x=1800,block_size_y=600"], 900)
 
 
+def test_large_grid_pcsi_two_ranks_equal_single_rank():
+    """... and with P-CSI, where the large-grid selection is two iterations per launch and per halo exchange on both sides of the
+    comparison (k_pcsi_step_x2: single rank with the rings read at their source cells, two ranks with x, dx, r' exchanged two rings wide)."""
+    _run_check(["--nproc-per-node", "2", os.path.join(ROOT, "tests", "mr_gpu_check.py"), "--config", "tx0.1v3", "--steps", "2",
+                "--kw", "nx_global=1800,ny_global=1200,block_size_x=1800,block_size_y=600,solver_choice=3"], 900)
+
+
 @pytest.mark.parametrize("nranks,kw,env", [
     (2, "block_size_x=48,block_size_y=20", {}),                       # replicated barotropic solve
     (2, "", {}),                                                      # 16 blocks: fused distributed pcg (one z halo per iteration)
