@@ -457,6 +457,9 @@ def main():
                                                       "config.hmix_tracer says so in the line")
     ap.add_argument("--pbc", action="store_true", help="NOT the headline: partial bottom cells on stepped bathymetry (grid_nml partial_bottom_cells, SURVEY 8 f3); "
                                                        "config.partial_bottom_cells says so in the line")
+    ap.add_argument("--tmix", default="", choices=["", "avg", "avgfit", "robert"], help="NOT the headline: time_mix_opt (default: the workload's, avgfit); 'robert' = the Robert-Asselin-Williams "
+                                                                                      "filter step (SURVEY 8 f2), CESM's default on gx1v7; config.time_mix says so")
+    ap.add_argument("--tadvect", default="", choices=["", "centered", "upwind3", "lw_lim"], help="NOT the headline: tracer advection (default centred); 'upwind3' is CESM's default on the gx grids")
     ap.add_argument("--grid-input", action="store_true", help="NOT the headline: horizontal grid and bathymetry supplied by the caller (pop_create_with_grid; the synthetic "
                                                               "lat-lon arrays of tests/popcfg.synthetic_grid) instead of the internal grid; config.grid_input says so")
     ap.add_argument("--tripole", action="store_true", help="NOT the headline: tripole northern boundary (ns_boundary_type 'tripole') on the --grid-input arrays")
@@ -515,6 +518,10 @@ def main():
         cfg.hmix_tracer, cfg.ah = 3, 0.8e7
         if args.gm == "cesm":   # the namelist defaults of the gx grids: transition layer + buoyancy-frequency-dependent kappa recomputed once a day
             cfg.gm_transition_layer, cfg.gm_kappa_type, cfg.gm_kappa_freq = 1, 1, 2
+    if args.tmix:
+        cfg.tmix_opt = {"avg": 1, "avgfit": 2, "robert": 3}[args.tmix]
+    if args.tadvect:
+        cfg.tadvect = {"centered": 1, "upwind3": 2, "lw_lim": 3}[args.tadvect]
     grid = None
     if args.tripole or args.grid_input:
         from popcfg import synthetic_grid
@@ -709,7 +716,7 @@ def main():
                    "blocks_local": model.nblocks,
                    "hmix": "del%d" % cfg.hmix_momentum, "hmix_tracer": {2: "del2", 3: "gm" + ("(transition layer, bfre kappa once a day)" if cfg.gm_transition_layer else "(constant kappa)"), 4: "del4"}[cfg.hmix_tracer], "vmix": ["const", "rich", "kpp"][vm],
                    "partial_bottom_cells": bool(cfg.partial_bottom_cells), "ns_boundary": ["closed", "cyclic", "tripole"][cfg.ns_boundary],
-                   "grid_input": bool(args.tripole or args.grid_input), "pcsi_two_iterations_per_launch": bool(model.dim("pcsi_two_step")) if cfg.solver_choice == 3 else None, "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
+                   "grid_input": bool(args.tripole or args.grid_input), "time_mix": ["", "avg", "avgfit", "robert"][cfg.tmix_opt], "tadvect": ["", "centered", "upwind3", "lw_lim"][cfg.tadvect], "pcsi_two_iterations_per_launch": bool(model.dim("pcsi_two_step")) if cfg.solver_choice == 3 else None, "solver": ["pcg", "ChronGear", "PCSI"][cfg.solver_choice - 1], "preconditioner": args.precond, "pcg_iters_per_step": float(np.mean(iters)),
                    "cells_local_with_ghosts": ncell_local, "transport": transport,
                    # every output of the step is bitwise what the full evaluation gives (tests/test_gpu_parity.py); DESIGN.md 3, "KPP's surface-layer buoyancy difference on demand"
                    "kpp_surface_buoyancy": ("on-demand down to the boundary-layer depth" if vm == 2 and tun.get("kpp_lazy", 1) != 0
