@@ -162,7 +162,8 @@ typedef struct pop_tuning {
   int halo_overlap_off;    /* 1: mid-step tracer halo in line instead of beside interior tiles */
   int rccl_overlap;        /* second communicator: 0 none, 1 (default) own stream, 2 ... */
   int evp_wave;            /* EVP block preconditioner: 0 one thread per sub-block, 1 anti-diagonal wavefronts (8 lanes per sub-block) with the
-                            * operands in LDS, 2 (default) with the operands in registers and the coefficients read from their 2-D fields */
+                            * operands in LDS, 2 with the operands in registers and the coefficients read from their 2-D fields, 3 (default) = 2 with
+                            * every load of the front end issued up front (unconditional at clamped addresses; the conditions select values) */
   int fpcg_a_pair;         /* 0: one chunk per workgroup in step A of the fused pcg even on compacted launches */
   int kpp_sparse;          /* 0: KPP boundary-layer kernel streams every level even when the interior kernel formed the convection mask */
   int pbc_generic_thomas;  /* 1: partial bottom cells with the scratch-staged Thomas kernels even at km = 60 / 62 */

@@ -261,6 +261,118 @@ k_evp_apply_wave2(EvpDev e, int nxb, const double *__restrict__ X, double *__res
     if (solve && c <= m - 1 && a0 <= n - 1) PX[cell(a0, c)] = ys[w][at(a0, c)];
 }
 
+// ---- wavefront form, third version (r4): the same solve with every load of the front end issued up front ------------------------------------
+// k_evp_apply_wave2 requests its operands behind their conditions: one row of ne, one step's X and cc, one entry of the correction matrix
+// at a time, each `if (...) v = load` a branch with its own s_waitcnt -- ~50 dependent round trips before the first marching step
+// (90 s_waitcnt vmcnt in the ISA; gx1v7: 11.6 us per application for ~3 us of marching).  Here every load is unconditional at a clamped
+// address and the conditions select values (the rewriting of the solver kernels' rim paths, 3d); X and cc of the interior are loaded once for
+// both uses (the solve and the diagonal scaling of sub-blocks with land).  Same expressions on the same operands: bitwise.
+__global__ void __launch_bounds__(64)
+k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__restrict__ PX) {
+  __shared__ double ys[POP_EVP_SB][EVP_PAD], nes[POP_EVP_SB][EVP_PAD];
+  __shared__ double rs[POP_EVP_SB][EVP_LE + 1];
+  const int t = threadIdx.x, w = t >> 3, l = t & 7;
+  const long long s = (long long)blockIdx.x * POP_EVP_SB + w;
+  const bool live = s < e.S;
+  const long long sl = live ? s : 0;
+  const int4 mt0 = e.meta[sl];
+  const int4 mt = live ? mt0 : make_int4(0, 3 | (3 << 8), 1, 0);
+  const int n = mt.y & 255, m = mt.y >> 8;
+  const bool solve = live && !mt.z;
+  auto cell = [&](int a, int c) { return (long long)mt.x + (long long)(c - 1) * nxb + (a - 1); };
+  auto at = [](int a, int c) { return (a - 1) + EVP_LD * (c - 1); };
+  const long long qs = mt.x;   // a cell that exists (0 for a lane without a sub-block)
+  // ---- requests: ne with its rim, X and cc of the lane's column, the lane's two rows of the correction matrix
+  const int a1 = 1 + l, a2 = 9 + l, i = 2 + l;
+  double nv1[EVP_LD], nv2[EVP_LD];
+#pragma unroll
+  for (int c = 1; c <= EVP_LD; ++c) {
+    const bool ok1 = live && c <= m && a1 <= n, ok2 = live && c <= m && l < 2 && a2 <= n;
+    nv1[c - 1] = e.WNE[ok1 ? cell(a1, c) : qs];
+    nv2[c - 1] = e.WNE[ok2 ? cell(a2, c) : qs];
+  }
+  double xx[EVP_STEPS], cs[EVP_STEPS];
+#pragma unroll
+  for (int q = 0; q < EVP_STEPS; ++q) {
+    const int j = q + 4 - i;
+    const bool ok = live && j >= 2 && j <= m - 1 && i <= n - 1;
+    const long long qa = ok ? cell(i, j) : qs;
+    xx[q] = X[qa]; cs[q] = e.C0[qa];
+  }
+  const int nm = n + m - 5;
+  double rv0[EVP_LE], rv1[EVP_LE];
+  const int row0 = 1 + l, row1 = 9 + l;
+#pragma unroll
+  for (int k = 1; k <= EVP_LE; ++k) {
+    const bool ok0 = solve && row0 <= nm && k <= nm, ok1 = solve && row1 <= nm && k <= nm;
+    rv0[k - 1] = e.rinv[(ok0 ? (long long)((k - 1) + EVP_LE * (row0 - 1)) * e.S : 0) + sl];
+    rv1[k - 1] = e.rinv[(ok1 ? (long long)((k - 1) + EVP_LE * (row1 - 1)) * e.S : 0) + sl];
+  }
+  // ---- values
+#pragma unroll
+  for (int c = 1; c <= EVP_LD; ++c) {
+    const bool ok1 = live && c <= m && a1 <= n, ok2 = live && c <= m && l < 2 && a2 <= n;
+    nes[w][at(a1, c)] = ok1 ? nv1[c - 1] : 0.0; ys[w][at(a1, c)] = 0.0;
+    if (l < 2) { nes[w][at(a2, c)] = ok2 ? nv2[c - 1] : 0.0; ys[w][at(a2, c)] = 0.0; }
+  }
+#pragma unroll
+  for (int k = 1; k <= EVP_LE; ++k) {
+    if (!(solve && row0 <= nm && k <= nm)) rv0[k - 1] = 0.0;
+    if (!(solve && row1 <= nm && k <= nm)) rv1[k - 1] = 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < EVP_STEPS; ++q) {
+    const int j = q + 4 - i;
+    const bool ok = live && j >= 2 && j <= m - 1 && i <= n - 1;
+    if (ok && mt.z) PX[cell(i, j)] = xx[q] * ((cs[q] != 0.0) ? 1.0 / cs[q] : 0.0);   // sub-blocks with land: diagonal scaling (:2344-2348)
+    if (!(ok && solve)) { xx[q] = 0.0; cs[q] = 0.0; }
+  }
+  __syncthreads();
+  double in[EVP_STEPS];         // 1 / ne(i, j) of the step (host: ine = 1 / ne where ne != 0, else 0)
+#pragma unroll
+  for (int q = 0; q < EVP_STEPS; ++q) {
+    const int j = q + 4 - i;
+    const bool ok = solve && j >= 2 && j <= m - 1 && i <= n - 1;
+    const double nv = ok ? nes[w][at(i, j)] : 0.0;
+    in[q] = (nv != 0.0) ? 1.0 / nv : 0.0;
+  }
+  auto sweep = [&](int imax, int jmax) {
+#pragma unroll
+    for (int q = 0; q < EVP_STEPS; ++q) {
+      const int j = q + 4 - i;
+      const bool on = solve && j >= 2 && j <= jmax && i <= imax;
+      double v = 0.0;
+      if (on)
+        v = (xx[q] - cs[q] * ys[w][at(i, j)] - nes[w][at(i, j - 1)] * ys[w][at(i + 1, j - 1)] -
+             nes[w][at(i - 1, j)] * ys[w][at(i - 1, j + 1)] - nes[w][at(i - 1, j - 1)] * ys[w][at(i - 1, j - 1)]) * in[q];
+      if (on) ys[w][at(i + 1, j + 1)] = v;
+      __syncthreads();
+    }
+  };
+  sweep(n - 1, m - 1);
+  for (int k = 1 + l; k <= EVP_LE; k += 8)
+    if (solve && k <= nm) rs[w][k] = (k <= n - 2) ? ys[w][at(k + 2, m)] : ys[w][at(n, m - (k - (n - 2)))];
+  __syncthreads();
+  auto target = [&](int jj) { return (jj <= m - 2) ? at(2, m - jj) : at(jj - (m - 2) + 2, 2); };
+  if (solve && row0 <= nm) {
+    double acc = ys[w][target(row0)];
+#pragma unroll
+    for (int k = 1; k <= EVP_LE; ++k) if (k <= nm) acc = acc + rv0[k - 1] * rs[w][k];
+    ys[w][target(row0)] = acc;
+  }
+  if (solve && row1 <= nm) {
+    double acc = ys[w][target(row1)];
+#pragma unroll
+    for (int k = 1; k <= EVP_LE; ++k) if (k <= nm) acc = acc + rv1[k - 1] * rs[w][k];
+    ys[w][target(row1)] = acc;
+  }
+  __syncthreads();
+  sweep(n - 2, m - 2);
+  const int a0 = 2 + l;
+  for (int c = 2; c <= EVP_LD - 1; ++c)
+    if (solve && c <= m - 1 && a0 <= n - 1) PX[cell(a0, c)] = ys[w][at(a0, c)];
+}
+
 // ---- P-CSI iteration + sub-block solves in ONE launch (round 4) ---------------------------------------------------------------------------
 // With the EVP preconditioner a P-CSI iteration was two launches: k_pcsi_step2 (dx, x, r = b - A x; the residual itself to memory) and
 // k_evp_apply_wave2 (r' = M^-1 r, sub-block by sub-block).  Here the wave that solves eight sub-blocks first forms what the step kernel forms

@@ -394,8 +394,10 @@ SolverArgs solver_args(pop_ctx *c) {
 
 // preconditioner() with preconditionerChoice = 'evp' (:2331-2366): PX <- sub-block solves of X on the physical cells
 int evp_apply(pop_ctx *c, const double *X, double *PX) {
-  const int wave = tun_or(c->h.tun.evp_wave, 2);   // 2 (default): wavefronts, operands in registers; 1: wavefronts, operands in LDS; 0: a thread per sub-block
-  if (wave == 2 && c->evp.C0)
+  const int wave = tun_or(c->h.tun.evp_wave, 3);   // 3 (default): wavefronts, operands in registers, every load up front; 2: the same with the loads behind their conditions; 1: wavefronts, operands in LDS; 0: a thread per sub-block
+  if (wave == 3 && c->evp.C0)
+    hipLaunchKernelGGL(k_evp_apply_wave3, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
+  else if (wave == 2 && c->evp.C0)
     hipLaunchKernelGGL(k_evp_apply_wave2, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
   else if (wave != 0)   // anti-diagonal wavefronts: eight lanes per sub-block, eight sub-blocks per wave
     hipLaunchKernelGGL(k_evp_apply_wave, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
@@ -2229,7 +2231,7 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
     c->pcsi_two_step = two_ok && two_on && h.halo.peers.empty();
     c->pcsi_two_step_dist = two_ok && two_on && !h.halo.peers.empty();
     if ((c->pcsi_two_step || c->pcsi_two_step_dist) && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
-    c->pcsi_evp_fused = c->evp_fused_ok && c->evp.C0 && tun_or(h.tun.evp_wave, 2) == 2 && tun_on(h.tun.pcsi_evp_fused);   // measured slower: off unless asked for
+    c->pcsi_evp_fused = c->evp_fused_ok && c->evp.C0 && tun_or(h.tun.evp_wave, 3) >= 2 && tun_on(h.tun.pcsi_evp_fused);   // measured slower: off unless asked for
     if (c->pcsi_evp_fused && !c->pcsi_raw && dev_alloc(c, &c->pcsi_raw, a2)) return 1;
     if ((c->pcsi_two_step || c->pcsi_two_step_dist) && cfg->ns_boundary == 2 && dev_upload(c, &c->pcsi_jfold, jfold.data(), jfold.size())) return 1;
     if (tun_set(h.tun.pcsi_step2)) c->pcsi_two_cell = (h.nxb & 1) == 0 && !g.red_tiles && h.tun.pcsi_step2 != 0;

@@ -927,7 +927,7 @@ def test_global_sum_family_and_solver_diagonal(pkg, orclib_built):
     gpu.close(); orc.close()
 
 
-@pytest.mark.parametrize("wave", ["2", "1", "0"], ids=["wavefront-registers", "wavefront-lds", "thread-per-sub-block"])
+@pytest.mark.parametrize("wave", ["3", "2", "1", "0"], ids=["wavefront-registers-loads-up-front", "wavefront-registers", "wavefront-lds", "thread-per-sub-block"])
 @pytest.mark.parametrize("name,kw", [("tiny", {}), ("tiny", {"block_size_x": 16, "block_size_y": 20}), ("gx3v7", {}),
                                      ("tiny", {"nx_global": 66, "ny_global": 52, "block_size_x": 33, "block_size_y": 26, "stepped_bathymetry": 1})])
 def test_evp_preconditioner_is_bitwise_the_oracle(pkg, orclib_built, monkeypatch, name, kw, wave):
