@@ -291,13 +291,15 @@ k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__res
     nv1[c - 1] = e.WNE[ok1 ? cell(a1, c) : qs];
     nv2[c - 1] = e.WNE[ok2 ? cell(a2, c) : qs];
   }
-  double xx[EVP_STEPS], cs[EVP_STEPS];
+  // X and cc of the lane's column by ROW (8 loads each, not one per step: the kernel is bound by its vector-memory instructions), moved to
+  // the slot of the step that meets the row (row j at step q = j + i - 4) by selects below
+  double xr[EVP_LD - 2], cr[EVP_LD - 2];
 #pragma unroll
-  for (int q = 0; q < EVP_STEPS; ++q) {
-    const int j = q + 4 - i;
-    const bool ok = live && j >= 2 && j <= m - 1 && i <= n - 1;
+  for (int jr = 0; jr < EVP_LD - 2; ++jr) {
+    const int j = 2 + jr;
+    const bool ok = live && j <= m - 1 && i <= n - 1;
     const long long qa = ok ? cell(i, j) : qs;
-    xx[q] = X[qa]; cs[q] = e.C0[qa];
+    xr[jr] = X[qa]; cr[jr] = e.C0[qa];
   }
   const int nm = n + m - 5;
   double rv0[EVP_LE], rv1[EVP_LE];
@@ -321,11 +323,20 @@ k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__res
     if (!(solve && row1 <= nm && k <= nm)) rv1[k - 1] = 0.0;
   }
 #pragma unroll
+  for (int jr = 0; jr < EVP_LD - 2; ++jr) {
+    const int j = 2 + jr;
+    const bool ok = live && j <= m - 1 && i <= n - 1;
+    if (ok && mt.z) PX[cell(i, j)] = xr[jr] * ((cr[jr] != 0.0) ? 1.0 / cr[jr] : 0.0);   // sub-blocks with land: diagonal scaling (:2344-2348)
+    if (!(ok && solve)) { xr[jr] = 0.0; cr[jr] = 0.0; }
+  }
+  double xx[EVP_STEPS], cs[EVP_STEPS];
+#pragma unroll
   for (int q = 0; q < EVP_STEPS; ++q) {
-    const int j = q + 4 - i;
-    const bool ok = live && j >= 2 && j <= m - 1 && i <= n - 1;
-    if (ok && mt.z) PX[cell(i, j)] = xx[q] * ((cs[q] != 0.0) ? 1.0 / cs[q] : 0.0);   // sub-blocks with land: diagonal scaling (:2344-2348)
-    if (!(ok && solve)) { xx[q] = 0.0; cs[q] = 0.0; }
+    double xv = 0.0, cv = 0.0;
+#pragma unroll
+    for (int jr = 0; jr < EVP_LD - 2; ++jr)
+      if (q - jr >= 0 && q - jr < 8) { const bool hit = (l == q - jr); xv = hit ? xr[jr] : xv; cv = hit ? cr[jr] : cv; }   // j = q + 4 - i  <=>  jr = q - l
+    xx[q] = xv; cs[q] = cv;
   }
   __syncthreads();
   double in[EVP_STEPS];         // 1 / ne(i, j) of the step (host: ine = 1 / ne where ne != 0, else 0)
