@@ -283,13 +283,15 @@ k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__res
   auto at = [](int a, int c) { return (a - 1) + EVP_LD * (c - 1); };
   const long long qs = mt.x;   // a cell that exists (0 for a lane without a sub-block)
   // ---- requests: ne with its rim, X and cc of the lane's column, the lane's two rows of the correction matrix
-  const int a1 = 1 + l, a2 = 9 + l, i = 2 + l;
-  double nv1[EVP_LD], nv2[EVP_LD];
+  const int i = 2 + l;
+  // ne with its rim: the 100 cells of the sub-block dealt to its eight lanes in linear order (cell t = l + 8 k: 13 loads, not 2 x 10 by row)
+  constexpr int NEK = (EVP_CELLS + 7) / 8;
+  double nv[NEK];
 #pragma unroll
-  for (int c = 1; c <= EVP_LD; ++c) {
-    const bool ok1 = live && c <= m && a1 <= n, ok2 = live && c <= m && l < 2 && a2 <= n;
-    nv1[c - 1] = e.WNE[ok1 ? cell(a1, c) : qs];
-    nv2[c - 1] = e.WNE[ok2 ? cell(a2, c) : qs];
+  for (int k = 0; k < NEK; ++k) {
+    const int tt = l + 8 * k, a = tt % EVP_LD + 1, c = tt / EVP_LD + 1;
+    const bool ok = live && tt < EVP_CELLS && c <= m && a <= n;
+    nv[k] = e.WNE[ok ? cell(a, c) : qs];
   }
   // X and cc of the lane's column by ROW (8 loads each, not one per step: the kernel is bound by its vector-memory instructions), moved to
   // the slot of the step that meets the row (row j at step q = j + i - 4) by selects below
@@ -312,10 +314,10 @@ k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__res
   }
   // ---- values
 #pragma unroll
-  for (int c = 1; c <= EVP_LD; ++c) {
-    const bool ok1 = live && c <= m && a1 <= n, ok2 = live && c <= m && l < 2 && a2 <= n;
-    nes[w][at(a1, c)] = ok1 ? nv1[c - 1] : 0.0; ys[w][at(a1, c)] = 0.0;
-    if (l < 2) { nes[w][at(a2, c)] = ok2 ? nv2[c - 1] : 0.0; ys[w][at(a2, c)] = 0.0; }
+  for (int k = 0; k < NEK; ++k) {
+    const int tt = l + 8 * k, a = tt % EVP_LD + 1, c = tt / EVP_LD + 1;
+    const bool ok = live && tt < EVP_CELLS && c <= m && a <= n;
+    if (tt < EVP_CELLS) { nes[w][tt] = ok ? nv[k] : 0.0; ys[w][tt] = 0.0; }   // (at(a, c) = tt)
   }
 #pragma unroll
   for (int k = 1; k <= EVP_LE; ++k) {
