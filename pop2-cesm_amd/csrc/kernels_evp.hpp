@@ -16,7 +16,7 @@ namespace pop {
 
 struct EvpDev {
   long long S;                    // local sub-blocks (stride of the coefficient arrays)
-  const int4 *meta;               // x: cell index of (1,1) of the sub-block with rim; y: n | m << 8; z: land
+  const int4 *meta;               // x: cell index of (1,1) of the sub-block with rim; y: n | m << 8; z: land (diagonal scaling); w: not a single ocean cell
   const double *cc, *ne, *icc, *ine;   // [EVP_LD*EVP_LD][S]
   const double *rinv;             // [EVP_LE*EVP_LE][S]
   const double *C0, *WNE;         // r3: the 2-D fields cc and ne are copies of (centre weight at set-up, NE weight), for k_evp_apply_wave2
@@ -267,6 +267,9 @@ k_evp_apply_wave2(EvpDev e, int nxb, const double *__restrict__ X, double *__res
 // (90 s_waitcnt vmcnt in the ISA; gx1v7: 11.6 us per application for ~3 us of marching).  Here every load is unconditional at a clamped
 // address and the conditions select values (the rewriting of the solver kernels' rim paths, 3d); X and cc of the interior are loaded once for
 // both uses (the solve and the diagonal scaling of sub-blocks with land).  Same expressions on the same operands: bitwise.
+// RESIDUAL: X is a residual of the solvers -- exactly zero on land, so a sub-block without a single ocean cell (meta.w) yields zeros (x * icc
+// of the diagonal scaling): its loads are not issued, and a wave whose eight sub-blocks are all of that kind stores its zeros and leaves.
+template <bool RESIDUAL>
 __global__ void __launch_bounds__(64)
 k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__restrict__ PX) {
   __shared__ double ys[POP_EVP_SB][EVP_PAD], nes[POP_EVP_SB][EVP_PAD];
@@ -282,6 +285,13 @@ k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__res
   auto cell = [&](int a, int c) { return (long long)mt.x + (long long)(c - 1) * nxb + (a - 1); };
   auto at = [](int a, int c) { return (a - 1) + EVP_LD * (c - 1); };
   const long long qs = mt.x;   // a cell that exists (0 for a lane without a sub-block)
+  const bool allland = RESIDUAL && live && mt.w != 0;
+  if (RESIDUAL && __all(allland || !live)) {
+    const int a0 = 2 + (t & 7);
+    for (int c = 2; c <= EVP_LD - 1; ++c)
+      if (allland && c <= m - 1 && a0 <= n - 1) PX[cell(a0, c)] = 0.0;
+    return;
+  }
   // ---- requests: ne with its rim, X and cc of the lane's column, the lane's two rows of the correction matrix
   const int i = 2 + l;
   // ne with its rim: the 100 cells of the sub-block dealt to its eight lanes in linear order (cell t = l + 8 k: 13 loads, not 2 x 10 by row)
@@ -290,7 +300,7 @@ k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__res
 #pragma unroll
   for (int k = 0; k < NEK; ++k) {
     const int tt = l + 8 * k, a = tt % EVP_LD + 1, c = tt / EVP_LD + 1;
-    const bool ok = live && tt < EVP_CELLS && c <= m && a <= n;
+    const bool ok = live && !allland && tt < EVP_CELLS && c <= m && a <= n;
     nv[k] = e.WNE[ok ? cell(a, c) : qs];
   }
   // X and cc of the lane's column by ROW (8 loads each, not one per step: the kernel is bound by its vector-memory instructions), moved to
@@ -299,7 +309,7 @@ k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__res
 #pragma unroll
   for (int jr = 0; jr < EVP_LD - 2; ++jr) {
     const int j = 2 + jr;
-    const bool ok = live && j <= m - 1 && i <= n - 1;
+    const bool ok = live && !allland && j <= m - 1 && i <= n - 1;
     const long long qa = ok ? cell(i, j) : qs;
     xr[jr] = X[qa]; cr[jr] = e.C0[qa];
   }
@@ -328,7 +338,7 @@ k_evp_apply_wave3(EvpDev e, int nxb, const double *__restrict__ X, double *__res
   for (int jr = 0; jr < EVP_LD - 2; ++jr) {
     const int j = 2 + jr;
     const bool ok = live && j <= m - 1 && i <= n - 1;
-    if (ok && mt.z) PX[cell(i, j)] = xr[jr] * ((cr[jr] != 0.0) ? 1.0 / cr[jr] : 0.0);   // sub-blocks with land: diagonal scaling (:2344-2348)
+    if (ok && mt.z) PX[cell(i, j)] = allland ? 0.0 : xr[jr] * ((cr[jr] != 0.0) ? 1.0 / cr[jr] : 0.0);   // sub-blocks with land: diagonal scaling (:2344-2348)
     if (!(ok && solve)) { xr[jr] = 0.0; cr[jr] = 0.0; }
   }
   double xx[EVP_STEPS], cs[EVP_STEPS];

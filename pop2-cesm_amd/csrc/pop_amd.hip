@@ -393,10 +393,13 @@ SolverArgs solver_args(pop_ctx *c) {
 }
 
 // preconditioner() with preconditionerChoice = 'evp' (:2331-2366): PX <- sub-block solves of X on the physical cells
-int evp_apply(pop_ctx *c, const double *X, double *PX) {
+// residual: X is a residual of a solver (zero on land): sub-blocks without an ocean cell are not read (k_evp_apply_wave3<true>)
+int evp_apply(pop_ctx *c, const double *X, double *PX, bool residual = true) {
   const int wave = tun_or(c->h.tun.evp_wave, 3);   // 3 (default): wavefronts, operands in registers, every load up front; 2: the same with the loads behind their conditions; 1: wavefronts, operands in LDS; 0: a thread per sub-block
-  if (wave == 3 && c->evp.C0)
-    hipLaunchKernelGGL(k_evp_apply_wave3, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
+  if (wave == 3 && c->evp.C0 && residual)
+    hipLaunchKernelGGL(k_evp_apply_wave3<true>, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
+  else if (wave == 3 && c->evp.C0)
+    hipLaunchKernelGGL(k_evp_apply_wave3<false>, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
   else if (wave == 2 && c->evp.C0)
     hipLaunchKernelGGL(k_evp_apply_wave2, dim3((unsigned)((c->evp.S + POP_EVP_SB - 1) / POP_EVP_SB)), dim3(64), 0, c->stream, c->evp, c->g.nxb, X, PX);
   else if (wave != 0)   // anti-diagonal wavefronts: eight lanes per sub-block, eight sub-blocks per wave
@@ -2175,7 +2178,13 @@ int pop_create_tuned(const pop_config *cfg, const pop_grid_input *grid, const po
         for (int j = 1; j <= E.ynb; ++j) for (int i = 1; i <= E.xnb; ++i) {
           const size_t sl = lb * nsb + (size_t)(j - 1) * E.xnb + (i - 1), sg = gb * nsb + (size_t)(j - 1) * E.xnb + (i - 1);
           const int is = E.xidx[i], ie = E.xidx[i + 1] + 1, js = E.yidx[j], je = E.yidx[j + 1] + 1;
-          meta[sl] = make_int4((int)(lb * h.n2 + (size_t)(js - 1) * h.nxb + (is - 1)), (ie - is + 1) | ((je - js + 1) << 8), E.land[sg], 0);
+          int ocean = 0;   // w: no ocean cell in the interior of the sub-block (cells of no block at all count as land)
+          {
+            const std::vector<int> &KMT = h.i2.at("KMT");
+            for (int cj = js + 1; cj <= je - 1; ++cj) for (int ci = is + 1; ci <= ie - 1; ++ci)
+              if (KMT[gb * h.n2 + (size_t)(cj - 1) * h.nxb + (ci - 1)] > 0) ocean = 1;
+          }
+          meta[sl] = make_int4((int)(lb * h.n2 + (size_t)(js - 1) * h.nxb + (is - 1)), (ie - is + 1) | ((je - js + 1) << 8), E.land[sg], (E.land[sg] && !ocean) ? 1 : 0);
           for (int q = 0; q < NC; ++q) {
             cc[q * S + sl] = E.cc[sg * NC + q]; ne[q * S + sl] = E.ne[sg * NC + q];
             icc[q * S + sl] = E.icc[sg * NC + q]; ine[q * S + sl] = E.ine[sg * NC + q];
@@ -3107,7 +3116,7 @@ int pop_solver_preconditioner(pop_ctx *c, const char *x_name, int x_tl, const ch
   if (resolve(c, x_name, x_tl, 0, &x, &cnt) || cnt != a2) { c->err = std::string("unknown 2-D field ") + x_name; return 1; }
   if (resolve(c, px_name, px_tl, 0, &px, &cnt) || cnt != a2 || px == x) { c->err = std::string("unknown 2-D field ") + px_name; return 1; }
   HIPCHK(c, hipMemsetAsync(px, 0, sizeof(double) * a2, c->stream));
-  if (c->use_evp) return evp_apply(c, x, px);
+  if (c->use_evp) return evp_apply(c, x, px, false);   // (any field the caller names: no assumption about its land values)
   HIPCHK(c, hipMemcpyAsync(px, x, sizeof(double) * a2, hipMemcpyDeviceToDevice, c->stream));
   hipLaunchKernelGGL(k_pcsi_precond, dim3((unsigned)((a2 + 255) / 256)), dim3(256), 0, c->stream, c->g, px, (const double *)c->centerWgt, a2);
   HIPCHK(c, hipGetLastError());

@@ -955,6 +955,31 @@ def test_evp_preconditioner_is_bitwise_the_oracle(pkg, orclib_built, monkeypatch
     gpu.close(); orc.close()
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("tiny", {"solver_choice": 3, "stepped_bathymetry": 1}),                                  # P-CSI (fused: step kernel + sub-block solves)
+    ("tiny", {"solver_choice": 3, "block_size_x": 24, "block_size_y": 20, "ew_boundary": 0}),
+    ("tiny", {"solver_choice": 1, "block_size_x": 28, "block_size_y": 24}),                   # pcg, padded blocks: sub-blocks beyond the block's own extent
+    ("tiny", {"solver_choice": 2}),                                                           # ChronGear
+    ("test", {"solver_choice": 3}),                                                           # 96 blocks of 16 x 16
+    ("gx1v7", {"solver_choice": 3}),                                                          # continents: whole waves of sub-blocks without an ocean cell
+    ("gx1v7", {"solver_choice": 1}),
+    ("tx0.1v3", {"nx_global": 1800, "ny_global": 1200, "block_size_x": 1800, "block_size_y": 1200, "km": 20, "vmix_choice": 1, "solver_choice": 3}),
+])
+def test_evp_without_reading_land_sub_blocks_is_bitwise(pkg, monkeypatch, name, kw):
+    """k_evp_apply_wave3<true> (the solvers' applications: the operand is a residual, zero on land) does not read sub-blocks without an ocean
+    cell and lets waves that hold nothing else leave at once; k_evp_apply_wave2 reads and scales every sub-block.  Iteration counts and
+    fields equal (np.array_equal: a zero is a zero)."""
+    cfg = named_config(name, preconditioner_choice=1, **kw)
+    a = pkg.PopModel(cfg, tuning={"evp_wave": 2})
+    b = pkg.PopModel(cfg, tuning={"evp_wave": 3})
+    for step in range(3):
+        a.step(); b.step()
+        assert a.solver_diagnostics() == b.solver_diagnostics(), "step %d" % step
+    for f in ("PSURF", "UBTROP", "VBTROP", "UVEL", "TRACER", "GRADPX"):
+        assert np.array_equal(a.get(f), b.get(f)), f
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("kw", [{}, {"tadvect": 2}, {"tadvect": 3}, {"hmix_tracer": 4, "hmix_momentum": 4, "am": -1.0e22, "ah": -1.0e21},
                                 {"block_size_x": 48, "block_size_y": 40}])
 def test_uniform_tracers_stay_uniform_in_the_interior(pkg, kw):
