@@ -131,7 +131,8 @@ k_pcsi_step(DevGrid g, PcsiArgs a) {
 // fused step with two horizontally adjacent cells per thread (large grids with an even row pitch; not the first
 // step): the pair shares its three stencil rows of (r', dx, x), read as (q-1), (q, q+1) in one 16-byte load, (q+2).
 // Same operations per cell in the same order and the same reduction tree as k_pcsi_step: bitwise equal.
-template <bool WITH_RR>
+// RAWR: the EVP form (PcsiArgs::raw_r, host: every launch of a model with that preconditioner) -- 1/diag is not read
+template <bool WITH_RR, bool RAWR = false>
 __global__ void __launch_bounds__(POP_RED_THREADS / 2)
 k_pcsi_step2(DevGrid g, PcsiArgs a) {
   if (a.sc->stop) return;   // an earlier check has converged: this launch belongs to the look-ahead interval
@@ -166,7 +167,9 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
     const double eaw = g.WEa[q - 1];
     const double2 ne0 = *reinterpret_cast<const double2 *>(g.WNE + q), nem = *reinterpret_cast<const double2 *>(g.WNE + q - nxb);
     const double ne0w = g.WNE[q - 1], nemw = g.WNE[q - 1 - nxb];
-    const double2 bq = *reinterpret_cast<const double2 *>(a.Bv + q), a0r = *reinterpret_cast<const double2 *>(a.A0R + q);
+    const double2 bq = *reinterpret_cast<const double2 *>(a.Bv + q);
+    double2 a0r = make_double2(0.0, 0.0);
+    if (!RAWR) a0r = *reinterpret_cast<const double2 *>(a.A0R + q);
     const double axA = cc.x * xn[1][1] + no0.x * xn[2][1] + nom.x * xn[0][1] + ea0.x * xn[1][2] + eaw * xn[1][0] +
                        ne0.x * xn[2][2] + nem.x * xn[0][2] + ne0w * xn[2][0] + nemw * xn[0][0];
     const double axB = cc.y * xn[1][2] + no0.y * xn[2][2] + nom.y * xn[0][2] + ea0.y * xn[1][3] + ea0.x * xn[1][1] +
@@ -174,7 +177,7 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
     const double rA = bq.x - axA, rB = bq.y - axB;
     *reinterpret_cast<double2 *>(a.Qo + q) = make_double2(dxc[0], dxc[1]);
     *reinterpret_cast<double2 *>(a.Xo + q) = make_double2(xn[1][1], xn[1][2]);
-    *reinterpret_cast<double2 *>(a.Ro + q) = a.raw_r ? make_double2(rA, rB) : make_double2(rA * a0r.x, rB * a0r.y);
+    *reinterpret_cast<double2 *>(a.Ro + q) = (RAWR || a.raw_r) ? make_double2(rA, rB) : make_double2(rA * a0r.x, rB * a0r.y);
     if (WITH_RR) { v0 = (rA * rA) * (double)g.mMask8[q]; v1 = (rB * rB) * (double)g.mMask8[q + 1]; }
   } else {
     // rim cells, straight-line (round 4; see k_fpcg_b2): source map, then the neighbours, every load unconditional at a clamped address

@@ -1331,7 +1331,10 @@ static void pcsi_interval(pop_ctx *c, const PcsiBufs &bf, int in, int freq, bool
   for (int j = j0; j <= freq; ++j) {
     const PcsiArgs a = pcsi_args(c, bf, in, j);
     if (c->pcsi_two_cell) {
-      if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step2<true>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, gg, a);
+      const bool rr = j == freq && with_rr;
+      if (rr && c->use_evp) hipLaunchKernelGGL((k_pcsi_step2<true, true>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, gg, a);
+      else if (c->use_evp) hipLaunchKernelGGL((k_pcsi_step2<false, true>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, gg, a);
+      else if (rr) hipLaunchKernelGGL((k_pcsi_step2<true>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, gg, a);
       else hipLaunchKernelGGL((k_pcsi_step2<false>), G, dim3(POP_RED_THREADS / 2), 0, c->stream, gg, a);
     } else if (j == freq && with_rr) hipLaunchKernelGGL((k_pcsi_step<false, true>), G, B, 0, c->stream, gg, a);
     else hipLaunchKernelGGL((k_pcsi_step<false, false>), G, B, 0, c->stream, gg, a);
