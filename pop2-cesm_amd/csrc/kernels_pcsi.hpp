@@ -162,11 +162,18 @@ k_pcsi_step2(DevGrid g, PcsiArgs a) {
       if (r == 1) { dxc[0] = d1; dxc[1] = d2; }
     }
     const double2 cc = *reinterpret_cast<const double2 *>(a.C + q);
-    const double2 no0 = *reinterpret_cast<const double2 *>(g.WNo + q), nom = *reinterpret_cast<const double2 *>(g.WNo + q - nxb);
-    const double2 ea0 = *reinterpret_cast<const double2 *>(g.WEa + q);
-    const double eaw = g.WEa[q - 1];
-    const double2 ne0 = *reinterpret_cast<const double2 *>(g.WNE + q), nem = *reinterpret_cast<const double2 *>(g.WNE + q - nxb);
-    const double ne0w = g.WNE[q - 1], nemw = g.WNE[q - 1 - nxb];
+    // the off-centre weights from their two U-point terms, as k_fpcg_b2 forms them (two fields instead of three; WNE = xne + yne,
+    // WEa = xne + xse - yne - yse, WNo = yne + ynw - xne - xnw: host_setup.cpp, the same additions in the same order)
+    const double2 x0 = *reinterpret_cast<const double2 *>(g.XW + q), xm = *reinterpret_cast<const double2 *>(g.XW + q - nxb);
+    const double2 y0 = *reinterpret_cast<const double2 *>(g.YW + q), ym = *reinterpret_cast<const double2 *>(g.YW + q - nxb);
+    const double x0w = g.XW[q - 1], xmw = g.XW[q - 1 - nxb], y0w = g.YW[q - 1], ymw = g.YW[q - 1 - nxb];
+    double2 no0, nom, ea0, ne0, nem;
+    const double ne0w = x0w + y0w, nemw = xmw + ymw;
+    ne0.x = x0.x + y0.x; ne0.y = x0.y + y0.y; nem.x = xm.x + ym.x; nem.y = xm.y + ym.y;
+    const double eaw = x0w + xmw - y0w - ymw;
+    ea0.x = x0.x + xm.x - y0.x - ym.x; ea0.y = x0.y + xm.y - y0.y - ym.y;
+    no0.x = y0.x + y0w - x0.x - x0w; no0.y = y0.y + y0.x - x0.y - x0.x;
+    nom.x = ym.x + ymw - xm.x - xmw; nom.y = ym.y + ym.x - xm.y - xm.x;
     const double2 bq = *reinterpret_cast<const double2 *>(a.Bv + q);
     double2 a0r = make_double2(0.0, 0.0);
     if (!RAWR) a0r = *reinterpret_cast<const double2 *>(a.A0R + q);
