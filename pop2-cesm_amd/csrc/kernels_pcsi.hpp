@@ -321,13 +321,21 @@ k_pcsi_step_x2(DevGrid g, PcsiArgs a, double *__restrict__ raw) {
     if (hl >= 0) { t.x1[hl] = hx1; t.dx1[hl] = hdx; }
   }
   // weights of the own position and of the first-ring cell (at their source cells)
-  const double cc = a.C[q], wn = g.WNo[q], ws = g.WNo[q - nxb], we = g.WEa[q], ww = g.WEa[q - 1];
-  const double wne = g.WNE[q], wse = g.WNE[q - nxb], wnw = g.WNE[q - 1], wsw = g.WNE[q - 1 - nxb];
-  const double bq = a.Bv[q], a0r = a.A0R[q];
+  // (the off-centre weights from their two U-point terms -- two fields instead of three; the additions of host_setup.cpp in their order, as in
+  // k_fpcg_b2 and k_pcsi_step2)
+  const double cc = a.C[q], bq = a.Bv[q], a0r = a.A0R[q];
+  const double x00 = g.XW[q], x0m = g.XW[q - nxb], xm0 = g.XW[q - 1], xmm = g.XW[q - 1 - nxb];
+  const double y00 = g.YW[q], y0m = g.YW[q - nxb], ym0 = g.YW[q - 1], ymm = g.YW[q - 1 - nxb];
   const long long hq1 = (ring1 && hm >= 0) ? hm : qsafe;
-  const double hcc = a.C[hq1], hwn = g.WNo[hq1], hws = g.WNo[hq1 - nxb], hwe = g.WEa[hq1], hww = g.WEa[hq1 - 1];
-  const double hwne = g.WNE[hq1], hwse = g.WNE[hq1 - nxb], hwnw = g.WNE[hq1 - 1], hwsw = g.WNE[hq1 - 1 - nxb];
-  const double hbq = a.Bv[hq1], ha0r = a.A0R[hq1];
+  const double hcc = a.C[hq1], hbq = a.Bv[hq1], ha0r = a.A0R[hq1];
+  const double hx00 = g.XW[hq1], hx0m = g.XW[hq1 - nxb], hxm0 = g.XW[hq1 - 1], hxmm = g.XW[hq1 - 1 - nxb];
+  const double hy00 = g.YW[hq1], hy0m = g.YW[hq1 - nxb], hym0 = g.YW[hq1 - 1], hymm = g.YW[hq1 - 1 - nxb];
+  const double wne = x00 + y00, wse = x0m + y0m, wnw = xm0 + ym0, wsw = xmm + ymm;
+  const double we = x00 + x0m - y00 - y0m, ww = xm0 + xmm - ym0 - ymm;
+  const double wn = y00 + ym0 - x00 - xm0, ws = y0m + ymm - x0m - xmm;
+  const double hwne = hx00 + hy00, hwse = hx0m + hy0m, hwnw = hxm0 + hym0, hwsw = hxmm + hymm;
+  const double hwe = hx00 + hx0m - hy00 - hy0m, hww = hxm0 + hxmm - hym0 - hymm;
+  const double hwn = hy00 + hym0 - hx00 - hxm0, hws = hy0m + hymm - hx0m - hxmm;
   __syncthreads();
   // A ghost cell G beyond a tripole fold is the mirror image of its source cell S: the array neighbour G + (di, dj) holds the value of
   // S - (di, dj).  The operator at S -- its weights, its order of additions -- is formed at G by walking the tile the other way round.
