@@ -1063,7 +1063,7 @@ static int cg_fused_interval(pop_ctx *c, SolveView &v, int freq) {
 int solver_chrongear_fused(pop_ctx *c) {
   const pop_config &cf = c->h.c;
   SolveView v = fused_view(c);
-  const dim3 G = view_grid(v), B(POP_RED_THREADS);
+  const dim3 B(POP_RED_THREADS);
   const int freq = cf.convergence_check_freq;
   const long long a2 = (long long)c->g.n2 * c->g.nblocks;
   SolverScalars init{};
@@ -1224,7 +1224,7 @@ int pcsi_check_start(const pop_ctx *c) { return c->h.c.convergence_check_start >
 
 int solver_pcsi(pop_ctx *c) {
   const pop_config &cf = c->h.c;
-  const dim3 G = grid_2d(c), B(POP_RED_THREADS);
+  const dim3 B(POP_RED_THREADS);
   const long long a2 = (long long)c->g.n2 * c->g.nblocks;
   const dim3 G1((unsigned)((a2 + 255) / 256)), B1(256);
   SolverScalars init{};
